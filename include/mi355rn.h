@@ -1,0 +1,200 @@
+/*
+ * mi355rn.h — C-ABI of libmi355rn.so: the MI355X (gfx950) native ResNet-50 training hot path.
+ *
+ * This is the drop-in boundary for the path bonlime/sota_imagenet drives through torch's dispatcher:
+ *   model(data)            reference call form  sota_imagenet/callbacks.py:316, built at train.py:64
+ *   criterion(out, target) reference call form  sota_imagenet/callbacks.py:316, built at train.py:81
+ *   loss.backward()        reference call form  sota_imagenet/callbacks.py:317
+ *   optimizer.step()       reference call form  sota_imagenet/callbacks.py:309, built at train.py:92
+ * The reference has no FFI of its own (it is pure Python on top of torch / cuDNN / NCCL), so every entry
+ * point below cites the reference call site whose native work it replaces.
+ *
+ * Conventions
+ *   - plain C types only: device pointers as void* / float*, sizes as int / size_t, streams as void*
+ *     (a hipStream_t; pass torch.cuda.current_stream().cuda_stream).  No torch types cross the boundary.
+ *   - every function returns 0 on success, a negative mi355_status otherwise; mi355_last_error() gives
+ *     the message (thread-local).  Nothing throws across the boundary.
+ *   - the caller (PyTorch-ROCm tensors) owns parameters / gradients / momentum / inputs / logits; the
+ *     library owns only its workspace arena (saved activations, split-K partials) inside a ctx.
+ *   - nothing in here synchronises the host with the device; all work is enqueued on `stream`.
+ *   - there is NO CPU fallback: without a gfx950 device every compute call fails with MI355_E_HIP.
+ *
+ * Layouts
+ *   activations  NHWC, dtype MI355_F32 or MI355_BF16           (the loader's NCHW fp32 batch,
+ *                sota_imagenet/dali_dataloader.py:113-122, is converted once by mi355_ingest_*)
+ *   conv weights KRSC = [Cout][KH][KW][Cin] fp32 master copy   (== a torch OIHW tensor in channels_last
+ *                memory format, so state_dict() keeps torchvision names/shapes)
+ *   BN / FC / loss / optimizer state: fp32.
+ */
+#ifndef MI355RN_H
+#define MI355RN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum mi355_status {
+  MI355_OK = 0,
+  MI355_E_ARG = -1,   /* bad argument (shape / dtype / null pointer / unsupported geometry) */
+  MI355_E_HIP = -2,   /* a HIP runtime call failed (message holds file:line and hipGetErrorString) */
+  MI355_E_STATE = -3, /* call order violated (e.g. backward before forward, params not bound) */
+  MI355_E_NOMEM = -4  /* workspace too small / allocation failed */
+} mi355_status;
+
+typedef enum mi355_dtype { MI355_F32 = 0, MI355_BF16 = 1 } mi355_dtype;
+
+/* ---- library ------------------------------------------------------------------------------------ */
+const char* mi355_last_error(void);
+int mi355_version(void);
+/* number of HIP devices visible (0 on a GPU-less host); never fails */
+int mi355_device_count(void);
+
+/* ---- per-op entry points (unit parity tests; the executor below calls the same kernels) ----------
+ * All pointers are device pointers.  `ws`/`ws_bytes` is caller-provided scratch; query the need with
+ * mi355_conv2d_workspace_bytes().                                                                   */
+
+/* scratch needed by dgrad (transposed weights) / wgrad (split-K partials) for one conv geometry */
+size_t mi355_conv2d_workspace_bytes(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                    int stride, int pad);
+
+/* y[N,Ho,Wo,Cout] = conv(x[N,H,W,Cin], w[Cout,KH,KW,Cin]); x,w,y in `dtype`.  Cin%64==0, Cout%64==0.
+ * replaces cuDNN conv fwd under model(data) — callbacks.py:316 (K2 of SURVEY §2.3)                  */
+int mi355_conv2d_fwd(int dtype, const void* x, const void* w, void* y, int N, int H, int W, int Cin,
+                     int Cout, int KH, int KW, int stride, int pad, void* stream);
+
+/* dx[N,H,W,Cin] = conv_transpose(dy[N,Ho,Wo,Cout], w) (+ addend[N,H,W,Cin] if non-null).
+ * replaces cuDNN dgrad under loss.backward() — callbacks.py:317 (K8)                                */
+int mi355_conv2d_dgrad(int dtype, const void* dy, const void* w, void* dx, const void* addend, int N,
+                       int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* ws,
+                       size_t ws_bytes, void* stream);
+
+/* dw[Cout,KH,KW,Cin] (fp32) = sum_{n,oh,ow} dy (x) x.  beta=0 overwrites, beta=1 accumulates.
+ * replaces cuDNN wgrad under loss.backward() — callbacks.py:317 (K8)                                */
+int mi355_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw, float beta, int N, int H,
+                       int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* ws,
+                       size_t ws_bytes, void* stream);
+
+/* the 7x7/2 stem on the loader's NCHW fp32 batch: ingest (NCHW fp32 -> zero-padded NHWC4 `dtype`),
+ * forward y[N,H/2,W/2,64], and wgrad dw[64,7,7,3] fp32.  xpad is scratch of
+ * mi355_stem_xpad_bytes() bytes that must be ZEROED once by the caller before the first ingest.
+ * replaces DALI's NCHW hand-off + cuDNN stem conv — dali_dataloader.py:113-122, callbacks.py:316 (K1) */
+size_t mi355_stem_xpad_bytes(int dtype, int N, int H, int W);
+int mi355_stem_ingest(int dtype, const float* x_nchw, void* xpad, int N, int H, int W, void* stream);
+int mi355_stem_fwd(int dtype, const void* xpad, const float* w_krsc, void* y, int N, int H, int W,
+                   void* ws, size_t ws_bytes, void* stream);
+int mi355_stem_wgrad(int dtype, const void* dy, const void* xpad, float* dw, float beta, int N, int H,
+                     int W, void* ws, size_t ws_bytes, void* stream);
+size_t mi355_stem_workspace_bytes(int dtype, int N, int H, int W);
+
+/* BatchNorm2d, training mode, over x[M,C] (M = N*H*W rows, NHWC):
+ *   mean/var over M (biased var to normalise, unbiased into running_var), eps inside the sqrt,
+ *   running = (1-momentum)*running + momentum*batch.   Outputs save_mean/save_invstd [C] for backward.
+ *   out = act(x_hat*gamma + beta (+ residual)),   act = ReLU if relu!=0.
+ *   ws: >= mi355_bn_workspace_bytes(C) bytes.
+ * replaces cuDNN BatchNormalizationForwardTraining + ATen relu/add — callbacks.py:316 (K3,K4);
+ * momentum semantics: train.py:76 / arg_parser.py:132                                              */
+size_t mi355_bn_workspace_bytes(int C);
+int mi355_bn_fwd_train(int dtype, const void* x, const void* residual, void* out, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, float* save_mean,
+                       float* save_invstd, int M, int C, float eps, float momentum, int relu, void* ws,
+                       size_t ws_bytes, void* stream);
+/* inference mode: uses running stats */
+int mi355_bn_fwd_eval(int dtype, const void* x, const void* residual, void* out, const float* gamma,
+                      const float* beta, const float* running_mean, const float* running_var, int M,
+                      int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream);
+/* backward of out = act(bn(x) (+residual)):  dz = dout * [out>0] (if relu),  dx = bn_bwd(dz),
+ * dgamma/dbeta fp32 (beta_acc=0 overwrite / 1 accumulate).  If dz_out != NULL the masked gradient is
+ * also stored (it is the residual branch's gradient).
+ * replaces cuDNN BN bwd + ATen threshold_backward — callbacks.py:317 (K8)                           */
+int mi355_bn_bwd(int dtype, const void* dout, const void* out, const void* x, const float* gamma,
+                 const float* save_mean, const float* save_invstd, void* dx, void* dz_out,
+                 float* dgamma, float* dbeta, float beta_acc, int M, int C, int relu, void* ws,
+                 size_t ws_bytes, void* stream);
+
+/* MaxPool 3x3 stride 2 pad 1 on NHWC; idx[N,Ho,Wo,C] uint8 = window position of the first maximum.
+ * replaces ATen max_pool2d_with_indices fwd/bwd — callbacks.py:316-317 (K5)                         */
+int mi355_maxpool_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, int H, int W, int C,
+                      void* stream);
+int mi355_maxpool_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int N, int H, int W,
+                      int C, void* stream);
+
+/* global average pool x[N,HW,C] -> pooled[N,C] fp32, and its backward (broadcast of dpooled/HW).
+ * replaces ATen mean / its backward — callbacks.py:316-317 (K6)                                     */
+int mi355_gap_fwd(int dtype, const void* x, float* pooled, int N, int HW, int C, void* stream);
+int mi355_gap_bwd(int dtype, const float* dpooled, void* dx, int N, int HW, int C, void* stream);
+
+/* label-smoothed softmax cross-entropy on float (one-hot or soft) targets, reduction = mean:
+ *   loss = mean_n[ (1-s) * -(sum_c y*logp) + s * -(mean_c logp) ],  logp = log_softmax(logits)
+ *   dlogits = d loss / d logits (already divided by N) times grad_scale.
+ * loss: 1 float on device.  row_loss: N floats of scratch.  dlogits may be NULL (evaluation).
+ * replaces pytorch_tools.losses.smooth.CrossEntropyLoss — arg_parser.py:140-142, callbacks.py:316 (K7)*/
+int mi355_ce_loss(const float* logits, const float* target, float smoothing, float grad_scale,
+                  float* loss, float* row_loss, float* dlogits, int N, int C, void* stream);
+
+/* fused SGD with momentum on a flat fp32 range (torch.optim.SGD semantics, dampening 0, no nesterov):
+ *   g = g*grad_scale + wd*p;  m = mu*m + g;  p -= lr*m       (m must start at 0 => first step m = g)
+ * replaces torch.optim._multi_tensor.SGD.step — arg_parser.py:136-138, callbacks.py:309 (K10)       */
+int mi355_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float momentum,
+                   float weight_decay, float grad_scale, void* stream);
+
+/* ---- whole-network executor: torchvision-layout ResNet-50 v1.5 ----------------------------------
+ * replaces hydra.utils.call(cfg.model) -> pytorch_tools.models.resnet50 (train.py:64,
+ * configs/hydra_exp/1.r50_baseline.yaml:22-23) and everything autograd runs beneath it.            */
+typedef struct mi355_ctx mi355_ctx;
+
+/* N = per-GPU batch, H = W = image size (multiple of 32), dtype = activation/compute dtype of the convs
+ * (accumulation, BN statistics, FC, loss and optimizer state are always fp32).                      */
+int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, int W, int num_classes);
+int mi355_resnet50_destroy(mi355_ctx* ctx);
+
+/* Parameter / buffer table (torchvision names).  Flat layouts are in REVERSE execution order (fc
+ * first, stem last) so that gradient buckets complete front-to-back during backward.
+ *   kind: 0 = parameter (offset into flat params/grads), 1 = buffer (offset into flat buffers:
+ *         running_mean / running_var; num_batches_tracked is kept host-side by the caller).
+ *   shape: torch logical shape (conv: [Cout,Cin,KH,KW], stored channels_last = KRSC).               */
+int mi355_resnet50_num_tensors(const mi355_ctx* ctx);
+int mi355_resnet50_tensor_info(const mi355_ctx* ctx, int idx, char* name, int name_cap, int* kind,
+                               size_t* offset, int* ndim, int shape[4]);
+size_t mi355_resnet50_flat_param_elems(const mi355_ctx* ctx);  /* incl. alignment / FC row padding */
+size_t mi355_resnet50_flat_buffer_elems(const mi355_ctx* ctx);
+size_t mi355_resnet50_workspace_bytes(const mi355_ctx* ctx);
+
+/* caller-owned flat fp32 device arrays; must outlive the ctx.  Padding elements must be zero. */
+int mi355_resnet50_bind(mi355_ctx* ctx, float* params, float* grads, float* buffers);
+
+/* logits[N,num_classes] fp32 = model(x_nchw[N,3,H,W] fp32).  training!=0: batch statistics, running
+ * stats updated with `bn_momentum`, activations saved for backward.  training==0: running stats.     */
+int mi355_resnet50_forward(mi355_ctx* ctx, const float* x_nchw, float* logits, int training,
+                           float bn_momentum, void* stream);
+
+/* Backward is split into mi355_resnet50_num_segments() segments (0 = fc, then one per bottleneck block
+ * from layer4.2 down to layer1.0, last = stem) so the caller can launch a gradient all-reduce on a side
+ * stream as soon as a segment's slice [grad_begin, grad_end) of the flat gradient array is complete.
+ * Segments must be run in order 0..n-1 after a training forward.  Gradients OVERWRITE the flat array
+ * (accumulate != 0: add into it, for accumulate_steps > 1 — arg_parser.py:85-86).                   */
+int mi355_resnet50_num_segments(const mi355_ctx* ctx);
+int mi355_resnet50_segment_range(const mi355_ctx* ctx, int seg, size_t* grad_begin, size_t* grad_end);
+int mi355_resnet50_backward(mi355_ctx* ctx, const float* dlogits, int seg_begin, int seg_end,
+                            int accumulate, void* stream);
+
+/* algorithmic work of the ctx's conv/FC kernels (2 FLOP/MAC, padding-free): forward and fwd+bwd */
+int mi355_resnet50_flops(const mi355_ctx* ctx, double* fwd_flops, double* train_flops);
+
+/* HIP-event timing of kernel classes inside a step, recorded on the stream the kernels are launched on.
+ * mi355_resnet50_profile(ctx, class_mask): bit k set => every launch of class k is bracketed by a pair of
+ * hipEvents from now on (mask 0 switches it off; calling it also clears earlier records).  Classes:
+ *   0 conv fwd (igemm)   1 conv dgrad (igemm)   2 conv wgrad   3 BN fwd (stats+apply)   4 BN bwd
+ *   5 other (ingest, pools, FC, weight prep)   6 conv 3x3 fwd only
+ * mi355_resnet50_profile_read(ctx, k, ...) waits for the recorded events of class k and returns their
+ * summed duration (ms), launch count and the algorithmic FLOPs / bytes those launches represent.    */
+int mi355_resnet50_profile(mi355_ctx* ctx, int class_mask);
+int mi355_resnet50_profile_read(mi355_ctx* ctx, int kind, double* total_ms, int* launches,
+                                double* alg_flops, double* alg_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355RN_H */

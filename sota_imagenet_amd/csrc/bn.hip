@@ -1,0 +1,493 @@
+// bn.hip — BatchNorm2d (training + inference) forward/backward with fused ReLU / residual add, NHWC, gfx950.
+//
+// Replaces cuDNN BatchNormalization{ForwardTraining,Backward} + ATen relu/add/threshold_backward under
+// `model(data)` / `loss.backward()` in the reference (sota_imagenet/callbacks.py:316-317); BN momentum
+// semantics follow train.py:76 + arg_parser.py:132 (torch: running = (1-m)*running + m*batch, unbiased
+// variance into running_var, eps inside the sqrt).
+//
+// All kernels are HBM-bound streams: each thread owns one 16-byte channel group (4 fp32 / 8 bf16 channels)
+// and walks pixels, so every wave-instruction moves 1 KiB of contiguous NHWC memory.  Per-channel sums:
+// registers -> wavefront __shfl_xor across the pixel rows that share a wave -> LDS across waves -> one
+// partial row per block -> a finalize kernel that adds the (<= 512) block partials in fp64 in block order
+// (bitwise reproducible; no float atomics).
+#include "common.h"
+#include "vec.h"
+
+namespace mi355 {
+namespace {
+
+constexpr int MAXBLK = 512;
+
+struct ReduceArgs {
+  const void* x;      // pre-BN tensor [M][C]
+  const void* g;      // upstream gradient (bwd) or null
+  const void* mask;   // post-activation tensor for the ReLU mask, or null
+  void* dz_out;       // optional masked gradient output
+  const float* mean;  // [C] (bwd)
+  const float* invstd;
+  float* partial;     // [gridDim.x][2][C]
+  int M, C;
+};
+
+// MODE 0: s1 = sum x, s2 = sum x^2.   MODE 1: s1 = sum dz, s2 = sum dz*xhat.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[2][256 * V];
+  const int tpr_full = p.C / V;
+  const int tpr = tpr_full < 256 ? tpr_full : 256;
+  const int rpp = 256 / tpr;
+  const int tid = threadIdx.x;
+  const int cv = tid % tpr, r = tid / tpr;
+  const int c0 = (blockIdx.y * tpr + cv) * V;
+  const T* x = reinterpret_cast<const T*>(p.x);
+  const T* g = reinterpret_cast<const T*>(p.g);
+  const T* mk = reinterpret_cast<const T*>(p.mask);
+  T* dz_out = reinterpret_cast<T*>(p.dz_out);
+
+  float s1[V], s2[V], mu[V], is[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    s1[e] = 0.f;
+    s2[e] = 0.f;
+    mu[e] = 0.f;
+    is[e] = 0.f;
+  }
+  if (MODE == 1) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      mu[e] = p.mean[c0 + e];
+      is[e] = p.invstd[c0 + e];
+    }
+  }
+  const int step = gridDim.x * rpp;
+#pragma unroll 2
+  for (int m = blockIdx.x * rpp + r; m < p.M; m += step) {
+    const size_t off = (size_t)m * p.C + c0;
+    float xv[V];
+    Vec16<T>::load(x + off, xv);
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        s1[e] += xv[e];
+        s2[e] += xv[e] * xv[e];
+      }
+    } else {
+      float gv[V];
+      Vec16<T>::load(g + off, gv);
+      if (mk) {
+        float mv[V];
+        Vec16<T>::load(mk + off, mv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) gv[e] = mv[e] > 0.f ? gv[e] : 0.f;
+      }
+      if (dz_out) Vec16<T>::store(dz_out + off, gv);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float xh = (xv[e] - mu[e]) * is[e];
+        s1[e] += gv[e];
+        s2[e] += gv[e] * xh;
+      }
+    }
+  }
+  // rows that share a wavefront: shuffle-reduce, then one LDS row per wave; otherwise one LDS row per r
+  int nrows, myrow;
+  bool writer;
+  if (tpr < 64) {
+    for (int off = tpr; off < 64; off <<= 1) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        s1[e] += __shfl_xor(s1[e], off);
+        s2[e] += __shfl_xor(s2[e], off);
+      }
+    }
+    nrows = 4;
+    myrow = tid >> 6;
+    writer = (tid & 63) < tpr;
+  } else {
+    nrows = rpp;
+    myrow = r;
+    writer = true;
+  }
+  if (writer) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      red[0][(myrow * tpr + cv) * V + e] = s1[e];
+      red[1][(myrow * tpr + cv) * V + e] = s2[e];
+    }
+  }
+  __syncthreads();
+  if (tid < tpr) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float a = 0.f, b = 0.f;
+      for (int rr = 0; rr < nrows; ++rr) {
+        a += red[0][(rr * tpr + tid) * V + e];
+        b += red[1][(rr * tpr + tid) * V + e];
+      }
+      const int c = (blockIdx.y * tpr + tid) * V + e;
+      p.partial[((size_t)blockIdx.x * 2 + 0) * p.C + c] = a;
+      p.partial[((size_t)blockIdx.x * 2 + 1) * p.C + c] = b;
+    }
+  }
+}
+
+// 16 channels x 16 slices of the block partials per workgroup; fp64 sums in fixed order.
+struct FinalizeArgs {
+  const float* partial;
+  int nblk, M, C;
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  float* save_mean;
+  float* save_invstd;
+  float* scale;
+  float* shift;
+  float eps, momentum;
+  // bwd
+  const float* invstd;
+  float* dgamma;
+  float* dbeta;
+  float beta_acc;
+  float* coef;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const FinalizeArgs p) {
+  __shared__ double red[2][16][17];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double a = 0.0, b = 0.0;
+  for (int k = sl; k < p.nblk; k += 16) {
+    a += (double)p.partial[((size_t)k * 2 + 0) * p.C + c];
+    b += (double)p.partial[((size_t)k * 2 + 1) * p.C + c];
+  }
+  red[0][sl][cl] = a;
+  red[1][sl][cl] = b;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < 16; ++k) {
+      s1 += red[0][k][cl];
+      s2 += red[1][k][cl];
+    }
+    const double M = (double)p.M;
+    if (MODE == 0) {
+      const double mean = s1 / M;
+      double var = s2 / M - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)p.eps));
+      const float meanf = (float)mean;
+      p.save_mean[c] = meanf;
+      p.save_invstd[c] = invstd;
+      const float sc = p.gamma[c] * invstd;
+      p.scale[c] = sc;
+      p.shift[c] = p.beta[c] - meanf * sc;
+      if (p.running_mean) {
+        const double unb = p.M > 1 ? var * M / (M - 1.0) : var;
+        p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * meanf;
+        p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unb;
+      }
+    } else {
+      const float db = (float)s1, dg = (float)s2;
+      p.dbeta[c] = (p.beta_acc != 0.f ? p.beta_acc * p.dbeta[c] : 0.f) + db;
+      p.dgamma[c] = (p.beta_acc != 0.f ? p.beta_acc * p.dgamma[c] : 0.f) + dg;
+      p.coef[c] = p.gamma[c] * p.invstd[c];
+      p.coef[p.C + c] = (float)(s1 / M);
+      p.coef[2 * p.C + c] = (float)(s2 / M);
+    }
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float* scale, float* shift, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(rv[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+struct ApplyArgs {
+  const void* x;
+  const float* scale;
+  const float* shift;
+  const void* residual;
+  const void* x2;
+  const float* scale2;
+  const float* shift2;
+  void* out;
+  size_t nvec;  // M*C/V
+  int cvecs;    // C/V
+  int relu;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
+  constexpr int V = Vec16<T>::N;
+  const T* x = reinterpret_cast<const T*>(p.x);
+  const T* res = reinterpret_cast<const T*>(p.residual);
+  const T* x2 = reinterpret_cast<const T*>(p.x2);
+  T* out = reinterpret_cast<T*>(p.out);
+  const size_t stride = (size_t)gridDim.x * 256;  // multiple of cvecs (host guarantees)
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int c0 = (int)(i % p.cvecs) * V;
+  float sc[V], sh[V], sc2[V], sh2[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    sc[e] = p.scale[c0 + e];
+    sh[e] = p.shift[c0 + e];
+    sc2[e] = x2 ? p.scale2[c0 + e] : 0.f;
+    sh2[e] = x2 ? p.shift2[c0 + e] : 0.f;
+  }
+#pragma unroll 2
+  for (; i < p.nvec; i += stride) {
+    float v[V];
+    Vec16<T>::load(x + i * V, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+    if (res) {
+      float rv[V];
+      Vec16<T>::load(res + i * V, rv);
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] += rv[e];
+    }
+    if (x2) {
+      float rv[V];
+      Vec16<T>::load(x2 + i * V, rv);
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] += fmaf(rv[e], sc2[e], sh2[e]);
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    }
+    Vec16<T>::store(out + i * V, v);
+  }
+}
+
+struct BwdApplyArgs {
+  const void* g;
+  const void* mask;
+  const void* x;
+  const float* mean;
+  const float* invstd;
+  const float* coef;  // [3][C]: gamma*invstd, mean(dz), mean(dz*xhat)
+  void* dx;
+  size_t nvec;
+  int cvecs, C;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p) {
+  constexpr int V = Vec16<T>::N;
+  const T* g = reinterpret_cast<const T*>(p.g);
+  const T* mk = reinterpret_cast<const T*>(p.mask);
+  const T* x = reinterpret_cast<const T*>(p.x);
+  T* dx = reinterpret_cast<T*>(p.dx);
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int c0 = (int)(i % p.cvecs) * V;
+  float mu[V], is[V], k0[V], k1[V], k2[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    mu[e] = p.mean[c0 + e];
+    is[e] = p.invstd[c0 + e];
+    k0[e] = p.coef[c0 + e];
+    k1[e] = p.coef[p.C + c0 + e];
+    k2[e] = p.coef[2 * p.C + c0 + e];
+  }
+#pragma unroll 2
+  for (; i < p.nvec; i += stride) {
+    float gv[V], xv[V];
+    Vec16<T>::load(g + i * V, gv);
+    Vec16<T>::load(x + i * V, xv);
+    if (mk) {
+      float mv[V];
+      Vec16<T>::load(mk + i * V, mv);
+#pragma unroll
+      for (int e = 0; e < V; ++e) gv[e] = mv[e] > 0.f ? gv[e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float xh = (xv[e] - mu[e]) * is[e];
+      gv[e] = k0[e] * (gv[e] - k1[e] - xh * k2[e]);
+    }
+    Vec16<T>::store(dx + i * V, gv);
+  }
+}
+
+int reduce_grid(int dtype, int M, int C, dim3* grid) {
+  const int V = 16 / (int)dtype_size(dtype);
+  const int tpr_full = C / V;
+  const int tpr = tpr_full < 256 ? tpr_full : 256;
+  const int rpp = 256 / tpr;
+  const int gy = tpr_full / tpr;
+  int nblk = cdiv(M, rpp * 8);
+  if (nblk > MAXBLK / gy) nblk = MAXBLK / gy;
+  if (nblk < 1) nblk = 1;
+  *grid = dim3(nblk, gy);
+  return nblk;
+}
+
+int elementwise_blocks(size_t nvec, int cvecs) {
+  size_t b = (nvec + 255) / 256;
+  if (b > 4096) b = 4096;
+  // stride = b*256 must be a multiple of cvecs (a power of two <= 1024): make b a multiple of 4
+  b = (b + 3) / 4 * 4;
+  (void)cvecs;
+  return (int)b;
+}
+
+int check_c(int dtype, int C) {
+  MI355_ARG(dtype == MI355_F32 || dtype == MI355_BF16, "bn: bad dtype %d", dtype);
+  MI355_ARG(C >= 64 && (C & (C - 1)) == 0 && C <= 4096, "bn: C=%d must be a power of two in [64, 4096]", C);
+  return 0;
+}
+
+}  // namespace
+
+int bn_max_blocks() { return MAXBLK; }
+
+int launch_bn_stats(int dtype, const void* x, float* partial, int* nblk_out, int M, int C, hipStream_t s) {
+  MI355_TRY(check_c(dtype, C));
+  ReduceArgs a{};
+  a.x = x;
+  a.partial = partial;
+  a.M = M;
+  a.C = C;
+  dim3 grid;
+  *nblk_out = reduce_grid(dtype, M, C, &grid);
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0>), grid, dim3(256), 0, s, a);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_bn_finalize(const float* partial, int nblk, int M, int C, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                       float* scale, float* shift, float eps, float momentum, hipStream_t s) {
+  FinalizeArgs a{};
+  a.partial = partial;
+  a.nblk = nblk;
+  a.M = M;
+  a.C = C;
+  a.gamma = gamma;
+  a.beta = beta;
+  a.running_mean = running_mean;
+  a.running_var = running_var;
+  a.save_mean = save_mean;
+  a.save_invstd = save_invstd;
+  a.scale = scale;
+  a.shift = shift;
+  a.eps = eps;
+  a.momentum = momentum;
+  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(C / 16), dim3(256), 0, s, a);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float* scale,
+                          float* shift, int C, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, gamma, beta, rm, rv, scale, shift, C,
+                     eps);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
+                    const void* x2, const float* scale2, const float* shift2, void* out, int M, int C, int relu,
+                    hipStream_t s) {
+  MI355_TRY(check_c(dtype, C));
+  const int V = 16 / (int)dtype_size(dtype);
+  ApplyArgs a{};
+  a.x = x;
+  a.scale = scale;
+  a.shift = shift;
+  a.residual = residual;
+  a.x2 = x2;
+  a.scale2 = scale2;
+  a.shift2 = shift2;
+  a.out = out;
+  a.nvec = (size_t)M * C / V;
+  a.cvecs = C / V;
+  a.relu = relu;
+  const int blocks = elementwise_blocks(a.nvec, a.cvecs);
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, a);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_bn_bwd_reduce(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
+                         const float* invstd, void* dz_out, float* partial, int* nblk_out, int M, int C,
+                         hipStream_t s) {
+  MI355_TRY(check_c(dtype, C));
+  ReduceArgs a{};
+  a.x = x;
+  a.g = g;
+  a.mask = mask_src;
+  a.dz_out = dz_out;
+  a.mean = mean;
+  a.invstd = invstd;
+  a.partial = partial;
+  a.M = M;
+  a.C = C;
+  dim3 grid;
+  *nblk_out = reduce_grid(dtype, M, C, &grid);
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1>), grid, dim3(256), 0, s, a);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_bn_bwd_finalize(const float* partial, int nblk, int M, int C, const float* gamma, const float* invstd,
+                           float* dgamma, float* dbeta, float beta_acc, float* coef, hipStream_t s) {
+  FinalizeArgs a{};
+  a.partial = partial;
+  a.nblk = nblk;
+  a.M = M;
+  a.C = C;
+  a.gamma = gamma;
+  a.invstd = invstd;
+  a.dgamma = dgamma;
+  a.dbeta = dbeta;
+  a.beta_acc = beta_acc;
+  a.coef = coef;
+  hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(C / 16), dim3(256), 0, s, a);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
+                        const float* invstd, const float* coef, void* dx, int M, int C, hipStream_t s) {
+  MI355_TRY(check_c(dtype, C));
+  const int V = 16 / (int)dtype_size(dtype);
+  BwdApplyArgs a{};
+  a.g = g;
+  a.mask = mask_src;
+  a.x = x;
+  a.mean = mean;
+  a.invstd = invstd;
+  a.coef = coef;
+  a.dx = dx;
+  a.nvec = (size_t)M * C / V;
+  a.cvecs = C / V;
+  a.C = C;
+  const int blocks = elementwise_blocks(a.nvec, a.cvecs);
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, a);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace mi355

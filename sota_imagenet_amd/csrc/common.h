@@ -1,0 +1,166 @@
+// common.h — shared types/helpers for the gfx950 kernels of libmi355rn.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/mi355rn.h"
+
+namespace mi355 {
+
+typedef __bf16 bf16_t;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+void set_error(const char* fmt, ...);
+
+#define MI355_HIP(expr)                                                                         \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      ::mi355::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_));  \
+      return MI355_E_HIP;                                                                       \
+    }                                                                                           \
+  } while (0)
+
+#define MI355_LAUNCH_CHECK()                                                                    \
+  do {                                                                                          \
+    hipError_t e_ = hipGetLastError();                                                          \
+    if (e_ != hipSuccess) {                                                                     \
+      ::mi355::set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return MI355_E_HIP;                                                                       \
+    }                                                                                           \
+  } while (0)
+
+#define MI355_ARG(cond, ...)                      \
+  do {                                            \
+    if (!(cond)) {                                \
+      ::mi355::set_error(__VA_ARGS__);            \
+      return MI355_E_ARG;                         \
+    }                                             \
+  } while (0)
+
+#define MI355_TRY(expr)            \
+  do {                             \
+    int rc_ = (expr);              \
+    if (rc_ != 0) return rc_;      \
+  } while (0)
+
+static inline size_t dtype_size(int dt) { return dt == MI355_BF16 ? 2 : 4; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// Gather-GEMM geometry shared by conv forward and dgrad (conv_igemm.hip).
+//   out[(n, i*OS+ph, j*OS+pw)][col] = sum_t sum_c in[(n, i*IS+dh_t, j*IS+dw_t)][c] * wt[col][wtap_t][c]
+// (n,i,j) runs over a sub-grid N x Hsub x Wsub; rows whose source pixel is out of range read zeros.
+// ---------------------------------------------------------------------------------------------
+struct Tap {
+  int8_t dh, dw;
+  int16_t wtap;
+};
+struct TapClass {
+  int ph, pw, ntaps;
+  Tap taps[9];
+};
+struct IgemmArgs {
+  const void* in;      // [N][Hin][Win] pixels of pix_stride elements
+  const void* wt;      // [Ncols][wtaps][Ck], K-contiguous
+  void* out;           // [N][Hout][Wout][Ncols]
+  const void* addend;  // optional, laid out like out
+  int N, Hin, Win, pix_stride;
+  int Hsub, Wsub, IS;
+  int Hout, Wout, OS;
+  int Ck, Ncols, wtaps;
+  TapClass cls[4];     // blockIdx.z selects the class
+};
+
+// Weight-gradient GEMM (conv_wgrad.hip):
+//   partial[split][co][wtap_t][c] = sum_{m in split} dy[m][co] * x[(n, oh*IS+dh_t, ow*IS+dw_t)][c]
+struct WgradArgs {
+  const void* dy;   // [N][Ho][Wo][Cout]
+  const void* x;    // [N][Hin][Win] pixels of pix_stride elements
+  float* partial;   // [splits][Cout][wtaps][Ck]
+  int N, Ho, Wo, Cout;
+  int Hin, Win, pix_stride, IS;
+  int Ck, wtaps, ntaps;
+  int chunks_per_split;  // BKP-pixel chunks handled by one split
+  Tap taps[9];
+};
+
+// ---- kernel launchers (all enqueue on `stream`, return mi355_status) -------------------------------
+int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream);
+// splits chosen by plan_wgrad_splits(); partial must hold splits*Cout*wtaps*Ck floats
+int plan_wgrad_splits(int M, int Cout, int ntaps, int Ck);
+int launch_wgrad(int dtype, const WgradArgs& a, int splits, hipStream_t stream);
+// dst[i] = beta*dst[i] + sum_s partial[s][i], i < n  (n multiple of 4); deterministic order
+int launch_splitk_reduce(const float* partial, int splits, size_t stride, float* dst, size_t n, float beta,
+                         hipStream_t stream);
+// stem unpack: dw[64][7][7][3] = beta*dw + sum_s partial[s][co][kh][kw*4+c]
+int launch_stem_unpack(const float* partial, int splits, float* dw, float beta, hipStream_t stream);
+
+// weight preparation (weights.hip): fp32 KRSC master -> what the kernels consume
+//   wT (dtype) [Cout][taps][Cin]   (skipped when dtype==F32: the master is used directly; pass NULL)
+//   wTt(dtype) [Cin][taps][Cout]   transposed for dgrad (NULL to skip)
+int launch_weight_prep(int dtype, const float* w, void* w_cast, void* w_tr, int Cout, int taps, int Cin,
+                       hipStream_t stream);
+// same-dtype transpose [Cout][taps][Cin] -> [Cin][taps][Cout] (per-op API, weights already in `dtype`)
+int launch_transpose_any(int dtype, const void* w, void* wt, int Cout, int taps, int Cin, hipStream_t stream);
+// stem: w[64][7][7][3] fp32 -> packed [64][7][64] dtype (kw*4+c, zero padded)
+int launch_stem_pack(int dtype, const float* w, void* packed, hipStream_t stream);
+
+// conv geometry builders (conv_api.cpp)
+void build_fwd_args(IgemmArgs& a, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int build_dgrad_args(IgemmArgs& a, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+void build_wgrad_args(WgradArgs& a, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+void build_stem_fwd_args(IgemmArgs& a, int N, int H, int W);
+void build_stem_wgrad_args(WgradArgs& a, int N, int H, int W);
+
+// stem geometry: padded NHWC4 input
+static constexpr int STEM_PAD = 3, STEM_PS = 4, STEM_CK = 64, STEM_RPAD = 16;
+static inline int stem_hp(int H) { return H + 2 * STEM_PAD; }
+static inline int stem_wp(int W) { return W + STEM_RPAD; }  // 2*(W/2-1)+16 = W+14 <= Wp, Wp even
+
+// BN (bn.hip)
+int launch_bn_stats(int dtype, const void* x, float* partial, int* nblk_out, int M, int C, hipStream_t s);
+int launch_bn_finalize(const float* partial, int nblk, int M, int C, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                       float* scale, float* shift, float eps, float momentum, hipStream_t s);
+int launch_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float* scale,
+                          float* shift, int C, float eps, hipStream_t s);
+// out = act(x*scale+shift (+ residual) (+ x2*scale2+shift2))
+int launch_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
+                    const void* x2, const float* scale2, const float* shift2, void* out, int M, int C, int relu,
+                    hipStream_t s);
+int launch_bn_bwd_reduce(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
+                         const float* invstd, void* dz_out, float* partial, int* nblk_out, int M, int C,
+                         hipStream_t s);
+int launch_bn_bwd_finalize(const float* partial, int nblk, int M, int C, const float* gamma, const float* invstd,
+                           float* dgamma, float* dbeta, float beta_acc, float* coef /*[3][C]*/, hipStream_t s);
+int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
+                        const float* invstd, const float* coef, void* dx, int M, int C, hipStream_t s);
+int bn_max_blocks();
+
+// pooling / head / loss / optimizer
+int launch_maxpool_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, hipStream_t s);
+int launch_maxpool_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C,
+                       hipStream_t s);
+int launch_gap_fwd(int dtype, const void* x, float* pooled, int N, int HW, int C, hipStream_t s);
+int launch_gap_bwd(int dtype, const float* dpooled, void* dx, int N, int HW, int C, hipStream_t s);
+int launch_ce(const float* logits, const float* target, float smoothing, float grad_scale, float* loss,
+              float* row_loss, float* dlogits, int N, int C, hipStream_t s);
+int launch_sgd(float* p, const float* g, float* m, size_t n, float lr, float mom, float wd, float gscale,
+               hipStream_t s);
+int launch_stem_ingest(int dtype, const float* x, void* xpad, int N, int H, int W, hipStream_t s);
+// logits[n][o] = tmp[n*ld + o] + bias[o]
+int launch_bias_slice(const float* tmp, int ld, const float* bias, float* out, int N, int O, hipStream_t s);
+// dst[n*ld + o] = o < O ? src[n*O + o] : 0 ; dbias[o] = beta*dbias + sum_n src[n][o]
+int launch_pad_dlogits(const float* src, float* dst, int ld, float* dbias, float beta, int N, int O, hipStream_t s);
+
+}  // namespace mi355

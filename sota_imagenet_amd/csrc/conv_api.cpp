@@ -1,0 +1,305 @@
+// conv_api.cpp — geometry builders and the per-op C-ABI entry points declared in include/mi355rn.h.
+#include <algorithm>
+#include <string>
+
+#include "common.h"
+
+namespace mi355 {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+const char* get_error() { return g_err.c_str(); }
+
+static int out_dim(int H, int K, int s, int p) { return (H + 2 * p - K) / s + 1; }
+
+void build_fwd_args(IgemmArgs& a, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+  memset(&a, 0, sizeof(a));
+  const int Ho = out_dim(H, KH, stride, pad), Wo = out_dim(W, KW, stride, pad);
+  a.N = N; a.Hin = H; a.Win = W; a.pix_stride = Cin;
+  a.Hsub = Ho; a.Wsub = Wo; a.IS = stride;
+  a.Hout = Ho; a.Wout = Wo; a.OS = 1;
+  a.Ck = Cin; a.Ncols = Cout; a.wtaps = KH * KW;
+  TapClass& c = a.cls[0];
+  c.ph = c.pw = 0;
+  c.ntaps = KH * KW;
+  for (int kh = 0; kh < KH; ++kh)
+    for (int kw = 0; kw < KW; ++kw) {
+      Tap& t = c.taps[kh * KW + kw];
+      t.dh = (int8_t)(kh - pad);
+      t.dw = (int8_t)(kw - pad);
+      t.wtap = (int16_t)(kh * KW + kw);
+    }
+}
+
+// returns the number of tap classes (1 for stride 1, 4 for stride 2), or a negative status
+int build_dgrad_args(IgemmArgs& a, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+  memset(&a, 0, sizeof(a));
+  const int Ho = out_dim(H, KH, stride, pad), Wo = out_dim(W, KW, stride, pad);
+  a.N = N; a.Hin = Ho; a.Win = Wo; a.pix_stride = Cout;
+  a.IS = 1; a.Hout = H; a.Wout = W;
+  a.Ck = Cout; a.Ncols = Cin; a.wtaps = KH * KW;
+  if (stride == 1) {
+    a.OS = 1; a.Hsub = H; a.Wsub = W;
+    TapClass& c = a.cls[0];
+    c.ph = c.pw = 0;
+    c.ntaps = KH * KW;
+    for (int kh = 0; kh < KH; ++kh)
+      for (int kw = 0; kw < KW; ++kw) {
+        Tap& t = c.taps[kh * KW + kw];
+        t.dh = (int8_t)(pad - kh);
+        t.dw = (int8_t)(pad - kw);
+        t.wtap = (int16_t)(kh * KW + kw);
+      }
+    return 1;
+  }
+  MI355_ARG(stride == 2 && H % 2 == 0 && W % 2 == 0, "dgrad: stride=%d with H=%d W=%d unsupported", stride, H, W);
+  a.OS = 2; a.Hsub = H / 2; a.Wsub = W / 2;
+  for (int ph = 0; ph < 2; ++ph)
+    for (int pw = 0; pw < 2; ++pw) {
+      TapClass& c = a.cls[ph * 2 + pw];
+      c.ph = ph; c.pw = pw; c.ntaps = 0;
+      for (int kh = 0; kh < KH; ++kh) {
+        const int vh = ph + pad - kh;
+        if (vh & 1) continue;
+        for (int kw = 0; kw < KW; ++kw) {
+          const int vw = pw + pad - kw;
+          if (vw & 1) continue;
+          Tap& t = c.taps[c.ntaps++];
+          t.dh = (int8_t)(vh / 2);
+          t.dw = (int8_t)(vw / 2);
+          t.wtap = (int16_t)(kh * KW + kw);
+        }
+      }
+    }
+  return 4;
+}
+
+void build_wgrad_args(WgradArgs& a, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+  memset(&a, 0, sizeof(a));
+  a.N = N; a.Ho = out_dim(H, KH, stride, pad); a.Wo = out_dim(W, KW, stride, pad); a.Cout = Cout;
+  a.Hin = H; a.Win = W; a.pix_stride = Cin; a.IS = stride;
+  a.Ck = Cin; a.wtaps = KH * KW; a.ntaps = KH * KW;
+  for (int kh = 0; kh < KH; ++kh)
+    for (int kw = 0; kw < KW; ++kw) {
+      Tap& t = a.taps[kh * KW + kw];
+      t.dh = (int8_t)(kh - pad);
+      t.dw = (int8_t)(kw - pad);
+      t.wtap = (int16_t)(kh * KW + kw);
+    }
+}
+
+void build_stem_fwd_args(IgemmArgs& a, int N, int H, int W) {
+  memset(&a, 0, sizeof(a));
+  a.N = N; a.Hin = stem_hp(H); a.Win = stem_wp(W); a.pix_stride = STEM_PS;
+  a.Hsub = H / 2; a.Wsub = W / 2; a.IS = 2;
+  a.Hout = H / 2; a.Wout = W / 2; a.OS = 1;
+  a.Ck = STEM_CK; a.Ncols = 64; a.wtaps = 7;
+  TapClass& c = a.cls[0];
+  c.ntaps = 7;
+  for (int kh = 0; kh < 7; ++kh) {
+    c.taps[kh].dh = (int8_t)kh;
+    c.taps[kh].dw = 0;
+    c.taps[kh].wtap = (int16_t)kh;
+  }
+}
+
+void build_stem_wgrad_args(WgradArgs& a, int N, int H, int W) {
+  memset(&a, 0, sizeof(a));
+  a.N = N; a.Ho = H / 2; a.Wo = W / 2; a.Cout = 64;
+  a.Hin = stem_hp(H); a.Win = stem_wp(W); a.pix_stride = STEM_PS; a.IS = 2;
+  a.Ck = STEM_CK; a.wtaps = 7; a.ntaps = 7;
+  for (int kh = 0; kh < 7; ++kh) {
+    a.taps[kh].dh = (int8_t)kh;
+    a.taps[kh].dw = 0;
+    a.taps[kh].wtap = (int16_t)kh;
+  }
+}
+
+static int check_conv(int dtype, int Cin, int Cout, int KH, int KW, int stride) {
+  MI355_ARG(dtype == MI355_F32 || dtype == MI355_BF16, "conv: bad dtype %d", dtype);
+  MI355_ARG(Cin % 64 == 0 && Cout % 64 == 0, "conv: Cin=%d Cout=%d must be multiples of 64", Cin, Cout);
+  MI355_ARG(KH * KW <= 9 && KH >= 1 && KW >= 1, "conv: kernel %dx%d unsupported (<= 9 taps)", KH, KW);
+  MI355_ARG(stride == 1 || stride == 2, "conv: stride %d unsupported", stride);
+  return 0;
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+extern "C" {
+
+const char* mi355_last_error(void) { return mi355::get_error(); }
+int mi355_version(void) { return 100; }
+int mi355_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+size_t mi355_conv2d_workspace_bytes(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                                    int pad) {
+  const size_t es = dtype_size(dtype);
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  const size_t wbytes = align_up((size_t)Cin * KH * KW * Cout * es, 256);
+  const int splits = plan_wgrad_splits(N * Ho * Wo, Cout, KH * KW, Cin);
+  const size_t pbytes = align_up((size_t)splits * Cout * KH * KW * Cin * 4, 256);
+  return wbytes + pbytes + wbytes;  // transposed + partials + cast copy
+}
+
+int mi355_conv2d_fwd(int dtype, const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int KH,
+                     int KW, int stride, int pad, void* stream) {
+  MI355_TRY(check_conv(dtype, Cin, Cout, KH, KW, stride));
+  IgemmArgs a;
+  build_fwd_args(a, N, H, W, Cin, Cout, KH, KW, stride, pad);
+  a.in = x; a.wt = w; a.out = y;
+  return launch_igemm(dtype, a, 1, (hipStream_t)stream);
+}
+
+int mi355_conv2d_dgrad(int dtype, const void* dy, const void* w, void* dx, const void* addend, int N, int H, int W,
+                       int Cin, int Cout, int KH, int KW, int stride, int pad, void* ws, size_t ws_bytes,
+                       void* stream) {
+  MI355_TRY(check_conv(dtype, Cin, Cout, KH, KW, stride));
+  const size_t es = dtype_size(dtype);
+  const size_t wbytes = (size_t)Cin * KH * KW * Cout * es;
+  MI355_ARG(ws && ws_bytes >= wbytes, "dgrad: workspace too small (%zu < %zu)", ws_bytes, wbytes);
+  hipStream_t s = (hipStream_t)stream;
+  // transpose [Cout][taps][Cin] -> [Cin][taps][Cout] in the same dtype
+  MI355_TRY(launch_transpose_any(dtype, w, ws, Cout, KH * KW, Cin, s));
+  IgemmArgs a;
+  const int nclass = build_dgrad_args(a, N, H, W, Cin, Cout, KH, KW, stride, pad);
+  if (nclass < 0) return nclass;
+  a.in = dy; a.wt = ws; a.out = dx; a.addend = addend;
+  return launch_igemm(dtype, a, nclass, s);
+}
+
+int mi355_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw, float beta, int N, int H, int W, int Cin,
+                       int Cout, int KH, int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+  MI355_TRY(check_conv(dtype, Cin, Cout, KH, KW, stride));
+  WgradArgs a;
+  build_wgrad_args(a, N, H, W, Cin, Cout, KH, KW, stride, pad);
+  const int splits = plan_wgrad_splits(a.N * a.Ho * a.Wo, Cout, KH * KW, Cin);
+  const size_t n = (size_t)Cout * KH * KW * Cin;
+  MI355_ARG(ws && ws_bytes >= (size_t)splits * n * 4, "wgrad: workspace too small (%zu < %zu)", ws_bytes,
+            (size_t)splits * n * 4);
+  a.dy = dy; a.x = x; a.partial = (float*)ws;
+  hipStream_t s = (hipStream_t)stream;
+  MI355_TRY(launch_wgrad(dtype, a, splits, s));
+  return launch_splitk_reduce((const float*)ws, splits, n, dw, n, beta, s);
+}
+
+size_t mi355_stem_xpad_bytes(int dtype, int N, int H, int W) {
+  return (size_t)N * stem_hp(H) * stem_wp(W) * STEM_PS * dtype_size(dtype);
+}
+
+size_t mi355_stem_workspace_bytes(int dtype, int N, int H, int W) {
+  const int splits = plan_wgrad_splits(N * (H / 2) * (W / 2), 64, 7, STEM_CK);
+  return align_up((size_t)64 * 7 * 64 * dtype_size(dtype), 256) + (size_t)splits * 64 * 7 * 64 * 4;
+}
+
+int mi355_stem_ingest(int dtype, const float* x_nchw, void* xpad, int N, int H, int W, void* stream) {
+  MI355_ARG(x_nchw && xpad && H % 2 == 0 && W % 2 == 0, "stem_ingest: bad arguments");
+  return launch_stem_ingest(dtype, x_nchw, xpad, N, H, W, (hipStream_t)stream);
+}
+
+int mi355_stem_fwd(int dtype, const void* xpad, const float* w_krsc, void* y, int N, int H, int W, void* ws,
+                   size_t ws_bytes, void* stream) {
+  const size_t pk = (size_t)64 * 7 * 64 * dtype_size(dtype);
+  MI355_ARG(ws && ws_bytes >= pk, "stem_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  MI355_TRY(launch_stem_pack(dtype, w_krsc, ws, s));
+  IgemmArgs a;
+  build_stem_fwd_args(a, N, H, W);
+  a.in = xpad; a.wt = ws; a.out = y;
+  return launch_igemm(dtype, a, 1, s);
+}
+
+int mi355_stem_wgrad(int dtype, const void* dy, const void* xpad, float* dw, float beta, int N, int H, int W, void* ws,
+                     size_t ws_bytes, void* stream) {
+  WgradArgs a;
+  build_stem_wgrad_args(a, N, H, W);
+  const int splits = plan_wgrad_splits(a.N * a.Ho * a.Wo, 64, 7, STEM_CK);
+  MI355_ARG(ws && ws_bytes >= (size_t)splits * 64 * 7 * 64 * 4, "stem_wgrad: workspace too small");
+  a.dy = dy; a.x = xpad; a.partial = (float*)ws;
+  hipStream_t s = (hipStream_t)stream;
+  MI355_TRY(launch_wgrad(dtype, a, splits, s));
+  return launch_stem_unpack((const float*)ws, splits, dw, beta, s);
+}
+
+size_t mi355_bn_workspace_bytes(int C) { return ((size_t)bn_max_blocks() * 2 * C + 8 * (size_t)C) * 4; }
+
+int mi355_bn_fwd_train(int dtype, const void* x, const void* residual, void* out, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, float* save_mean,
+                       float* save_invstd, int M, int C, float eps, float momentum, int relu, void* ws,
+                       size_t ws_bytes, void* stream) {
+  MI355_ARG(ws && ws_bytes >= mi355_bn_workspace_bytes(C), "bn: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = (float*)ws;
+  float* scale = partial + (size_t)bn_max_blocks() * 2 * C;
+  float* shift = scale + C;
+  int nblk = 0;
+  MI355_TRY(launch_bn_stats(dtype, x, partial, &nblk, M, C, s));
+  MI355_TRY(launch_bn_finalize(partial, nblk, M, C, gamma, beta, running_mean, running_var, save_mean, save_invstd,
+                               scale, shift, eps, momentum, s));
+  return launch_bn_apply(dtype, x, scale, shift, residual, nullptr, nullptr, nullptr, out, M, C, relu, s);
+}
+
+int mi355_bn_fwd_eval(int dtype, const void* x, const void* residual, void* out, const float* gamma,
+                      const float* beta, const float* running_mean, const float* running_var, int M, int C, float eps,
+                      int relu, void* ws, size_t ws_bytes, void* stream) {
+  MI355_ARG(ws && ws_bytes >= (size_t)2 * C * 4, "bn_eval: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* scale = (float*)ws;
+  float* shift = scale + C;
+  MI355_TRY(launch_bn_eval_coeffs(gamma, beta, running_mean, running_var, scale, shift, C, eps, s));
+  return launch_bn_apply(dtype, x, scale, shift, residual, nullptr, nullptr, nullptr, out, M, C, relu, s);
+}
+
+int mi355_bn_bwd(int dtype, const void* dout, const void* out, const void* x, const float* gamma,
+                 const float* save_mean, const float* save_invstd, void* dx, void* dz_out, float* dgamma,
+                 float* dbeta, float beta_acc, int M, int C, int relu, void* ws, size_t ws_bytes, void* stream) {
+  MI355_ARG(ws && ws_bytes >= mi355_bn_workspace_bytes(C), "bn: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = (float*)ws;
+  float* coef = partial + (size_t)bn_max_blocks() * 2 * C;
+  int nblk = 0;
+  const void* mask = relu ? out : nullptr;
+  MI355_TRY(launch_bn_bwd_reduce(dtype, dout, mask, x, save_mean, save_invstd, dz_out, partial, &nblk, M, C, s));
+  MI355_TRY(launch_bn_bwd_finalize(partial, nblk, M, C, gamma, save_invstd, dgamma, dbeta, beta_acc, coef, s));
+  return launch_bn_bwd_apply(dtype, dout, mask, x, save_mean, save_invstd, coef, dx, M, C, s);
+}
+
+int mi355_maxpool_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+  return launch_maxpool_fwd(dtype, x, y, idx, N, H, W, C, (hipStream_t)stream);
+}
+int mi355_maxpool_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C,
+                      void* stream) {
+  return launch_maxpool_bwd(dtype, dy, idx, dx, N, H, W, C, (hipStream_t)stream);
+}
+int mi355_gap_fwd(int dtype, const void* x, float* pooled, int N, int HW, int C, void* stream) {
+  return launch_gap_fwd(dtype, x, pooled, N, HW, C, (hipStream_t)stream);
+}
+int mi355_gap_bwd(int dtype, const float* dpooled, void* dx, int N, int HW, int C, void* stream) {
+  return launch_gap_bwd(dtype, dpooled, dx, N, HW, C, (hipStream_t)stream);
+}
+int mi355_ce_loss(const float* logits, const float* target, float smoothing, float grad_scale, float* loss,
+                  float* row_loss, float* dlogits, int N, int C, void* stream) {
+  return launch_ce(logits, target, smoothing, grad_scale, loss, row_loss, dlogits, N, C, (hipStream_t)stream);
+}
+int mi355_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float momentum, float weight_decay,
+                   float grad_scale, void* stream) {
+  return launch_sgd(p, g, m, n, lr, momentum, weight_decay, grad_scale, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,412 @@
+// misc.hip — the remaining HBM-bound pieces of the ResNet-50 step on gfx950:
+//   stem ingest (NCHW fp32 -> zero-padded NHWC4), maxpool 3x3/2 fwd/bwd, global average pool fwd/bwd,
+//   label-smoothed soft-target cross entropy fwd+bwd, fused SGD-momentum, FC bias/padding helpers.
+// Reference call sites: sota_imagenet/dali_dataloader.py:113-123 (tensor contract of the batch),
+// sota_imagenet/callbacks.py:316-317 (model / criterion / backward), arg_parser.py:136-142 (SGD, CE).
+#include "common.h"
+#include "vec.h"
+
+namespace mi355 {
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void stem_ingest_kernel(const float* __restrict__ x, T* __restrict__ xpad, int N, int H, int W, int Hp,
+                                   int Wp) {
+  const size_t total = (size_t)N * H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    const size_t t = i / W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    const size_t plane = (size_t)H * W;
+    const float* src = x + (size_t)n * 3 * plane + (size_t)h * W + w;
+    const float r = src[0], g = src[plane], b = src[2 * plane];
+    T* dst = xpad + (((size_t)n * Hp + h + STEM_PAD) * Wp + w + STEM_PAD) * 4;
+    if constexpr (sizeof(T) == 4) {
+      f32x4 v = {r, g, b, 0.f};
+      *reinterpret_cast<f32x4*>(dst) = v;
+    } else {
+      bf16x4 v = {(bf16_t)r, (bf16_t)g, (bf16_t)b, (bf16_t)0.f};
+      *reinterpret_cast<bf16x4*>(dst) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int N,
+                                   int H, int W, int C, int Ho, int Wo) {
+  constexpr int V = Vec16<T>::N;
+  const int cv = C / V;
+  const size_t total = (size_t)N * Ho * Wo * cv;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cv) * V;
+    size_t t = i / cv;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float best[V];
+    int bi[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      best[e] = -INFINITY;
+      bi[e] = -1;
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = oh * 2 - 1 + kh;
+      if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow * 2 - 1 + kw;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        float v[V];
+        Vec16<T>::load(x + (((size_t)n * H + ih) * W + iw) * C + c0, v);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          if (bi[e] < 0 || v[e] > best[e] || v[e] != v[e]) {
+            best[e] = v[e];
+            bi[e] = kh * 3 + kw;
+          }
+        }
+      }
+    }
+    const size_t o = (((size_t)n * Ho + oh) * Wo + ow) * C + c0;
+    Vec16<T>::store(y + o, best);
+#pragma unroll
+    for (int e = 0; e < V; ++e) idx[o + e] = (uint8_t)bi[e];
+  }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx,
+                                   int N, int H, int W, int C, int Ho, int Wo) {
+  constexpr int V = Vec16<T>::N;
+  const int cv = C / V;
+  const size_t total = (size_t)N * H * W * cv;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cv) * V;
+    size_t t = i / cv;
+    const int iw = (int)(t % W);
+    t /= W;
+    const int ih = (int)(t % H);
+    const int n = (int)(t / H);
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    const int oh_hi = (ih + 1) / 2 < Ho - 1 ? (ih + 1) / 2 : Ho - 1;
+    const int ow_hi = (iw + 1) / 2 < Wo - 1 ? (iw + 1) / 2 : Wo - 1;
+    for (int oh = ih / 2; oh <= oh_hi; ++oh) {
+      const int kh = ih - 2 * oh + 1;
+      for (int ow = iw / 2; ow <= ow_hi; ++ow) {
+        const int kw = iw - 2 * ow + 1;
+        const int pos = kh * 3 + kw;
+        const size_t o = (((size_t)n * Ho + oh) * Wo + ow) * C + c0;
+        float g[V];
+        Vec16<T>::load(dy + o, g);
+        uint8_t id[V];
+        if constexpr (V == 4) {
+          const uint32_t w = *reinterpret_cast<const uint32_t*>(idx + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) id[e] = (uint8_t)(w >> (8 * e));
+        } else {
+          const uint2 w = *reinterpret_cast<const uint2*>(idx + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            id[e] = (uint8_t)(w.x >> (8 * e));
+            id[4 + e] = (uint8_t)(w.y >> (8 * e));
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          if (id[e] == pos) acc[e] += g[e];
+      }
+    }
+    Vec16<T>::store(dx + (((size_t)n * H + ih) * W + iw) * C + c0, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void gap_fwd_kernel(const T* __restrict__ x, float* __restrict__ pooled, int N, int HW, int C) {
+  constexpr int V = Vec16<T>::N;
+  const int cv = C / V;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * cv) return;
+  const int c0 = (i % cv) * V, n = i / cv;
+  float s[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) s[e] = 0.f;
+  for (int p = 0; p < HW; ++p) {
+    float v[V];
+    Vec16<T>::load(x + ((size_t)n * HW + p) * C + c0, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) s[e] += v[e];
+  }
+  const float inv = 1.f / (float)HW;
+#pragma unroll
+  for (int e = 0; e < V; ++e) pooled[(size_t)n * C + c0 + e] = s[e] * inv;
+}
+
+template <typename T>
+__global__ void gap_bwd_kernel(const float* __restrict__ dpooled, T* __restrict__ dx, int N, int HW, int C) {
+  constexpr int V = Vec16<T>::N;
+  const int cv = C / V;
+  const size_t total = (size_t)N * HW * cv;
+  const float inv = 1.f / (float)HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cv) * V;
+    const int n = (int)(i / ((size_t)cv * HW));
+    float v[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = dpooled[(size_t)n * C + c0 + e] * inv;
+    Vec16<T>::store(dx + i * V, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = -INFINITY;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t = fmaxf(t, sh[w]);
+  return t;
+}
+
+// one workgroup per sample
+__global__ __launch_bounds__(256) void ce_row_kernel(const float* __restrict__ logits, const float* __restrict__ target,
+                                                     float smoothing, float gscale, float* __restrict__ row_loss,
+                                                     float* __restrict__ dlogits, int N, int C) {
+  __shared__ float sh[4];
+  const int n = blockIdx.x;
+  const float* z = logits + (size_t)n * C;
+  const float* y = target + (size_t)n * C;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, z[c]);
+  mx = block_max(mx, sh);
+  float se = 0.f, sy = 0.f, syz = 0.f, sz = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float zc = z[c], yc = y[c];
+    se += expf(zc - mx);
+    sy += yc;
+    syz += yc * zc;
+    sz += zc;
+  }
+  se = block_sum(se, sh);
+  sy = block_sum(sy, sh);
+  syz = block_sum(syz, sh);
+  sz = block_sum(sz, sh);
+  const float lse = mx + logf(se);
+  if (threadIdx.x == 0) {
+    const float nll = -(syz - lse * sy);
+    const float uni = -(sz / (float)C - lse);
+    row_loss[n] = (1.f - smoothing) * nll + smoothing * uni;
+  }
+  if (dlogits) {
+    const float k = gscale / (float)N;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float pc = expf(z[c] - lse);
+      dlogits[(size_t)n * C + c] = k * ((1.f - smoothing) * (pc * sy - y[c]) + smoothing * (pc - 1.f / (float)C));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ row_loss, float* __restrict__ loss, int N) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) s += row_loss[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) *loss = s / (float)N;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  size_t n4, size_t n, float lr, float mom, float wd, float gscale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ge = gv[e] * gscale + wd * pv[e];
+      mv[e] = mom * mv[e] + ge;
+      pv[e] = pv[e] - lr * mv[e];
+    }
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+  }
+  // tail (n not a multiple of 4)
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    const float ge = g[i] * gscale + wd * p[i];
+    const float me = mom * m[i] + ge;
+    m[i] = me;
+    p[i] = p[i] - lr * me;
+  }
+}
+
+__global__ void bias_slice_kernel(const float* __restrict__ tmp, int ld, const float* __restrict__ bias,
+                                  float* __restrict__ out, int N, int O) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * O) return;
+  const int o = i % O, n = i / O;
+  out[i] = tmp[(size_t)n * ld + o] + bias[o];
+}
+
+__global__ void pad_dlogits_kernel(const float* __restrict__ src, float* __restrict__ dst, int ld, int N, int O) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * ld) return;
+  const int o = i % ld, n = i / ld;
+  dst[i] = o < O ? src[(size_t)n * O + o] : 0.f;
+}
+
+__global__ void dbias_kernel(const float* __restrict__ src, float* __restrict__ dbias, float beta, int N, int O) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= O) return;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += src[(size_t)n * O + o];
+  dbias[o] = (beta != 0.f ? beta * dbias[o] : 0.f) + s;
+}
+
+int grid_for(size_t total, int cap = 8192) {
+  size_t b = (total + 255) / 256;
+  if (b > (size_t)cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+#define DISPATCH_T(dtype, KERNEL, grid, ...)                                                    \
+  do {                                                                                          \
+    if ((dtype) == MI355_F32)                                                                   \
+      hipLaunchKernelGGL(KERNEL<float>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);              \
+    else if ((dtype) == MI355_BF16)                                                             \
+      hipLaunchKernelGGL(KERNEL<bf16_t>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);             \
+    else {                                                                                      \
+      set_error("bad dtype %d", (dtype));                                                       \
+      return MI355_E_ARG;                                                                       \
+    }                                                                                           \
+    MI355_LAUNCH_CHECK();                                                                       \
+  } while (0)
+
+}  // namespace
+
+int launch_stem_ingest(int dtype, const float* x, void* xpad, int N, int H, int W, hipStream_t s) {
+  const int Hp = stem_hp(H), Wp = stem_wp(W);
+  const int grid = grid_for((size_t)N * H * W);
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL(stem_ingest_kernel<float>, dim3(grid), dim3(256), 0, s, x, (float*)xpad, N, H, W, Hp, Wp);
+  else
+    hipLaunchKernelGGL(stem_ingest_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, x, (bf16_t*)xpad, N, H, W, Hp, Wp);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_maxpool_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, hipStream_t s) {
+  MI355_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "maxpool: H=%d W=%d C=%d", H, W, C);
+  const int Ho = H / 2, Wo = W / 2;
+  const int V = 16 / (int)dtype_size(dtype);
+  const int grid = grid_for((size_t)N * Ho * Wo * (C / V));
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, idx, N, H, W,
+                       C, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N,
+                       H, W, C, Ho, Wo);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_maxpool_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C,
+                       hipStream_t s) {
+  MI355_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "maxpool: H=%d W=%d C=%d", H, W, C);
+  const int Ho = H / 2, Wo = W / 2;
+  const int V = 16 / (int)dtype_size(dtype);
+  const int grid = grid_for((size_t)N * H * W * (C / V));
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, idx, (float*)dx, N, H,
+                       W, C, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, idx, (bf16_t*)dx, N,
+                       H, W, C, Ho, Wo);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_gap_fwd(int dtype, const void* x, float* pooled, int N, int HW, int C, hipStream_t s) {
+  MI355_ARG(C % 8 == 0, "gap: C=%d", C);
+  const int V = 16 / (int)dtype_size(dtype);
+  const int grid = cdiv(N * (C / V), 256);
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL(gap_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, pooled, N, HW, C);
+  else
+    hipLaunchKernelGGL(gap_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, pooled, N, HW, C);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_gap_bwd(int dtype, const float* dpooled, void* dx, int N, int HW, int C, hipStream_t s) {
+  MI355_ARG(C % 8 == 0, "gap: C=%d", C);
+  const int V = 16 / (int)dtype_size(dtype);
+  const int grid = grid_for((size_t)N * HW * (C / V));
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, dpooled, (float*)dx, N, HW, C);
+  else
+    hipLaunchKernelGGL(gap_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, dpooled, (bf16_t*)dx, N, HW, C);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ce(const float* logits, const float* target, float smoothing, float grad_scale, float* loss,
+              float* row_loss, float* dlogits, int N, int C, hipStream_t s) {
+  MI355_ARG(logits && target && loss && row_loss, "ce: null pointer");
+  hipLaunchKernelGGL(ce_row_kernel, dim3(N), dim3(256), 0, s, logits, target, smoothing, grad_scale, row_loss, dlogits,
+                     N, C);
+  MI355_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, s, row_loss, loss, N);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_sgd(float* p, const float* g, float* m, size_t n, float lr, float mom, float wd, float gscale,
+               hipStream_t s) {
+  MI355_ARG(p && g && m, "sgd: null pointer");
+  MI355_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0),
+            "sgd: pointers must be 16-byte aligned");
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n4, 4096)), dim3(256), 0, s, p, g, m, n4, n, lr, mom, wd, gscale);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_bias_slice(const float* tmp, int ld, const float* bias, float* out, int N, int O, hipStream_t s) {
+  hipLaunchKernelGGL(bias_slice_kernel, dim3(cdiv(N * O, 256)), dim3(256), 0, s, tmp, ld, bias, out, N, O);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_pad_dlogits(const float* src, float* dst, int ld, float* dbias, float beta, int N, int O, hipStream_t s) {
+  hipLaunchKernelGGL(pad_dlogits_kernel, dim3(cdiv(N * ld, 256)), dim3(256), 0, s, src, dst, ld, N, O);
+  MI355_LAUNCH_CHECK();
+  if (dbias) {
+    hipLaunchKernelGGL(dbias_kernel, dim3(cdiv(O, 256)), dim3(256), 0, s, src, dbias, beta, N, O);
+    MI355_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+}  // namespace mi355

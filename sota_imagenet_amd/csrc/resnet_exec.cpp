@@ -1,0 +1,691 @@
+// resnet_exec.cpp — static ResNet-50 v1.5 training/inference executor behind the C-ABI (include/mi355rn.h).
+//
+// Replaces what the reference gets from `hydra.utils.call(cfg.model)` -> pytorch_tools.models.resnet50
+// (train.py:64, configs/hydra_exp/1.r50_baseline.yaml:22-23) plus the autograd graph torch builds under it
+// (model(data) / loss.backward(): sota_imagenet/callbacks.py:316-317).  The whole forward and backward
+// schedule is fixed at ctx creation: one workspace arena, NHWC activations, no allocation and no host
+// synchronisation inside a step.
+//
+// Schedule (torchvision layout): stem 7x7/2 -> BN -> ReLU -> maxpool 3x3/2 -> 16 bottlenecks
+// (1x1 -> 3x3(stride) -> 1x1, BN after each, ReLU after the first two, residual add + ReLU at the end,
+// 1x1(stride)+BN downsample on the first block of each stage) -> global average pool -> FC.
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace mi355 {
+
+void build_stem_fwd_args(IgemmArgs& a, int N, int H, int W);
+void build_stem_wgrad_args(WgradArgs& a, int N, int H, int W);
+
+namespace {
+
+constexpr float BN_EPS = 1e-5f;
+constexpr size_t PARAM_ALIGN = 64;  // floats (256 B)
+constexpr int NPROF = 8;            // profile classes
+constexpr int MAX_EVENTS = 8192;
+
+struct TensorInfo {
+  std::string name;
+  int kind;  // 0 param, 1 buffer
+  size_t offset;
+  int ndim;
+  int shape[4];
+};
+
+struct ConvBN {
+  std::string conv_name, bn_name;
+  int Cin, Cout, K, stride, pad;
+  int Hin, Win, Hout, Wout;
+  size_t w_off = 0, gamma_off = 0, beta_off = 0;  // flat params
+  size_t rm_off = 0, rv_off = 0;                  // flat buffers
+  void* y = nullptr;                              // raw conv output
+  void* w_cast = nullptr;                         // bf16 copy (bf16 ctx)
+  void* w_tr = nullptr;                           // transposed copy for dgrad
+  float* stat = nullptr;                          // [4][Cout]: save_mean, save_invstd, scale, shift
+  int splits = 1;
+  bool is_stem = false;
+};
+
+struct Block {
+  ConvBN c1, c2, c3, ds;
+  bool has_ds = false;
+  const void* in = nullptr;  // block input activation
+  void* a1 = nullptr;
+  void* a2 = nullptr;
+  void* out = nullptr;
+  int Hin, Win, Hout, Wout, Cin, Cout;
+  size_t grad_begin = 0, grad_end = 0;
+};
+
+struct Arena {
+  size_t size = 0;
+  std::vector<std::pair<void**, size_t>> slots;
+  void add(void** p, size_t bytes) {
+    slots.push_back({p, size});
+    size += align_up(bytes, 256);
+  }
+};
+
+}  // namespace
+}  // namespace mi355
+
+using namespace mi355;
+
+struct mi355_ctx {
+  int device = 0, dtype = 0, N = 0, H = 0, W = 0, num_classes = 0, fc_pad = 0;
+  size_t es = 4;
+  ConvBN stem;
+  std::vector<Block> blocks;
+  std::vector<TensorInfo> tensors;
+  size_t param_elems = 0, buffer_elems = 0;
+  size_t fc_w_off = 0, fc_b_off = 0;
+  size_t fc_grad_begin = 0, fc_grad_end = 0, stem_grad_begin = 0, stem_grad_end = 0;
+  float *params = nullptr, *grads = nullptr, *buffers = nullptr;
+
+  // workspace
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  void *xpad = nullptr, *stem_pack = nullptr, *a0 = nullptr, *p0 = nullptr;
+  uint8_t* pool_idx = nullptr;
+  float *pooled = nullptr, *fc_tmp = nullptr, *dlogits_pad = nullptr, *dpooled = nullptr, *fc_wtr = nullptr;
+  float *bn_partial = nullptr, *bn_coef = nullptr, *wg_partial = nullptr;
+  void* gbuf[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool fwd_training_done = false;
+  int next_seg = 0;
+  void* cur_dout = nullptr;  // gradient wrt the current block output during backward
+  double fwd_flops = 0, train_flops = 0;
+
+  // profiling
+  unsigned prof_mask = 0;
+  std::vector<hipEvent_t> ev;
+  struct Rec {
+    int cls;
+    double flops, bytes;
+  };
+  std::vector<Rec> recs;
+};
+
+namespace {
+
+size_t act_bytes(const mi355_ctx* c, int H, int W, int C) { return (size_t)c->N * H * W * C * c->es; }
+
+void add_param(mi355_ctx* c, std::vector<TensorInfo>& rev, const std::string& name, size_t* off, int ndim, int s0,
+               int s1 = 0, int s2 = 0, int s3 = 0, size_t extra_pad = 0) {
+  size_t n = (size_t)s0 * (ndim > 1 ? s1 : 1) * (ndim > 2 ? s2 : 1) * (ndim > 3 ? s3 : 1);
+  *off = c->param_elems;
+  c->param_elems += align_up(n + extra_pad, PARAM_ALIGN);
+  TensorInfo t{name, 0, *off, ndim, {s0, s1, s2, s3}};
+  rev.push_back(t);
+}
+void add_buffer(mi355_ctx* c, std::vector<TensorInfo>& rev, const std::string& name, size_t* off, int n) {
+  *off = c->buffer_elems;
+  c->buffer_elems += align_up((size_t)n, PARAM_ALIGN);
+  TensorInfo t{name, 1, *off, 1, {n, 0, 0, 0}};
+  rev.push_back(t);
+}
+
+void init_conv(ConvBN& l, const std::string& conv_name, const std::string& bn_name, int Cin, int Cout, int K,
+               int stride, int Hin, int Win) {
+  l.conv_name = conv_name;
+  l.bn_name = bn_name;
+  l.Cin = Cin; l.Cout = Cout; l.K = K; l.stride = stride; l.pad = K / 2;
+  l.Hin = Hin; l.Win = Win;
+  l.Hout = (Hin + 2 * l.pad - K) / stride + 1;
+  l.Wout = (Win + 2 * l.pad - K) / stride + 1;
+}
+
+// params of one conv+bn in reverse-execution registration order: bn.bias, bn.weight, conv.weight
+void register_convbn(mi355_ctx* c, std::vector<TensorInfo>& rev, ConvBN& l) {
+  add_param(c, rev, l.bn_name + ".bias", &l.beta_off, 1, l.Cout);
+  add_param(c, rev, l.bn_name + ".weight", &l.gamma_off, 1, l.Cout);
+  add_param(c, rev, l.conv_name + ".weight", &l.w_off, 4, l.Cout, l.Cin, l.K, l.K);
+  add_buffer(c, rev, l.bn_name + ".running_var", &l.rv_off, l.Cout);
+  add_buffer(c, rev, l.bn_name + ".running_mean", &l.rm_off, l.Cout);
+}
+
+struct Prof {
+  mi355_ctx* c;
+  hipStream_t stream;
+  int idx = -1;
+  Prof(mi355_ctx* ctx, int cls, double flops, double bytes, hipStream_t s) : c(ctx), stream(s) {
+    if (!(c->prof_mask & (1u << cls))) return;
+    if ((c->recs.size() + 1) * 2 > c->ev.size()) return;
+    idx = (int)c->recs.size();
+    c->recs.push_back({cls, flops, bytes});
+    (void)hipEventRecord(c->ev[2 * idx], stream);
+  }
+  ~Prof() {
+    if (idx >= 0) (void)hipEventRecord(c->ev[2 * idx + 1], stream);
+  }
+};
+
+// profile classes
+enum { PC_CONV_FWD = 0, PC_CONV_DGRAD = 1, PC_CONV_WGRAD = 2, PC_BN_FWD = 3, PC_BN_BWD = 4, PC_OTHER = 5, PC_CONV3_FWD = 6 };
+
+double conv_flops(const mi355_ctx* c, const ConvBN& l) {
+  return 2.0 * c->N * l.Hout * l.Wout * (double)l.Cout * l.Cin * l.K * l.K;
+}
+
+int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, hipStream_t s) {
+  IgemmArgs a;
+  build_fwd_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
+  a.in = in;
+  a.wt = c->dtype == MI355_F32 ? (const void*)(c->params + l.w_off) : (const void*)l.w_cast;
+  a.out = l.y;
+  const double fl = conv_flops(c, l);
+  const double by = ((double)c->N * l.Hin * l.Win * l.Cin + (double)c->N * l.Hout * l.Wout * l.Cout) * c->es;
+  Prof p(c, PC_CONV_FWD, fl, by, s);
+  Prof p3(c, l.K == 3 ? PC_CONV3_FWD : 31, fl, by, s);
+  return launch_igemm(c->dtype, a, 1, s);
+}
+
+// BN statistics + finalize for one layer (training) or eval coefficients
+int bn_prepare(mi355_ctx* c, ConvBN& l, int training, float momentum, hipStream_t s) {
+  const int M = c->N * l.Hout * l.Wout, C = l.Cout;
+  float* save_mean = l.stat;
+  float* save_invstd = l.stat + C;
+  float* scale = l.stat + 2 * C;
+  float* shift = l.stat + 3 * C;
+  const float* gamma = c->params + l.gamma_off;
+  const float* beta = c->params + l.beta_off;
+  if (training) {
+    int nblk = 0;
+    {
+      Prof p(c, PC_BN_FWD, 0, (double)M * C * c->es, s);
+      MI355_TRY(launch_bn_stats(c->dtype, l.y, c->bn_partial, &nblk, M, C, s));
+    }
+    return launch_bn_finalize(c->bn_partial, nblk, M, C, gamma, beta, c->buffers + l.rm_off, c->buffers + l.rv_off,
+                              save_mean, save_invstd, scale, shift, BN_EPS, momentum, s);
+  }
+  return launch_bn_eval_coeffs(gamma, beta, c->buffers + l.rm_off, c->buffers + l.rv_off, scale, shift, C, BN_EPS, s);
+}
+
+int bn_apply(mi355_ctx* c, ConvBN& l, const void* residual, ConvBN* l2, void* out, int relu, hipStream_t s) {
+  const int M = c->N * l.Hout * l.Wout, C = l.Cout;
+  const int nin = 1 + (residual ? 1 : 0) + (l2 ? 1 : 0);
+  Prof p(c, PC_BN_FWD, 0, (double)M * C * c->es * (nin + 1), s);
+  return launch_bn_apply(c->dtype, l.y, l.stat + 2 * C, l.stat + 3 * C, residual, l2 ? l2->y : nullptr,
+                         l2 ? l2->stat + 2 * C : nullptr, l2 ? l2->stat + 3 * C : nullptr, out, M, C, relu, s);
+}
+
+// BN backward of layer l: g (gradient wrt the activation), mask (post-activation tensor or null),
+// optional in-place masked write-back; dx written to `dx` (may alias g).
+int bn_backward(mi355_ctx* c, ConvBN& l, const void* g, const void* mask, void* dz_out, void* dx, float beta_acc,
+                hipStream_t s) {
+  const int M = c->N * l.Hout * l.Wout, C = l.Cout;
+  int nblk = 0;
+  const int nrd = 2 + (mask ? 1 : 0);
+  {
+    Prof p(c, PC_BN_BWD, 0, (double)M * C * c->es * (nrd + (dz_out ? 1 : 0)), s);
+    MI355_TRY(launch_bn_bwd_reduce(c->dtype, g, mask, l.y, l.stat, l.stat + C, dz_out, c->bn_partial, &nblk, M, C, s));
+  }
+  MI355_TRY(launch_bn_bwd_finalize(c->bn_partial, nblk, M, C, c->params + l.gamma_off, l.stat + C,
+                                   c->grads + l.gamma_off, c->grads + l.beta_off, beta_acc, c->bn_coef, s));
+  // after an in-place masked write-back the mask is already applied
+  const void* mask2 = dz_out ? nullptr : mask;
+  const void* g2 = dz_out ? dz_out : g;
+  Prof p(c, PC_BN_BWD, 0, (double)M * C * c->es * (3 + (mask2 ? 1 : 0)), s);
+  return launch_bn_bwd_apply(c->dtype, g2, mask2, l.y, l.stat, l.stat + C, c->bn_coef, dx, M, C, s);
+}
+
+int conv_wgrad(mi355_ctx* c, ConvBN& l, const void* dy, const void* x, float beta_acc, hipStream_t s) {
+  WgradArgs a;
+  build_wgrad_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
+  a.dy = dy; a.x = x; a.partial = c->wg_partial;
+  const size_t n = (size_t)l.Cout * l.K * l.K * l.Cin;
+  const double by = ((double)c->N * l.Hin * l.Win * l.Cin + (double)c->N * l.Hout * l.Wout * l.Cout) * c->es;
+  {
+    Prof p(c, PC_CONV_WGRAD, conv_flops(c, l), by, s);
+    MI355_TRY(launch_wgrad(c->dtype, a, l.splits, s));
+  }
+  return launch_splitk_reduce(c->wg_partial, l.splits, n, c->grads + l.w_off, n, beta_acc, s);
+}
+
+int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* addend, hipStream_t s) {
+  IgemmArgs a;
+  const int nclass = build_dgrad_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
+  if (nclass < 0) return nclass;
+  a.in = dy; a.wt = l.w_tr; a.out = dx; a.addend = addend;
+  const double by = ((double)c->N * l.Hin * l.Win * l.Cin * (addend ? 2 : 1) + (double)c->N * l.Hout * l.Wout * l.Cout) * c->es;
+  Prof p(c, PC_CONV_DGRAD, conv_flops(c, l), by, s);
+  return launch_igemm(c->dtype, a, nclass, s);
+}
+
+int plan_arena(mi355_ctx* c, Arena& ar) {
+  const int N = c->N;
+  size_t max_act = 0, max_wg = 0, max_c = 64;
+  auto conv_ws = [&](ConvBN& l) {
+    ar.add(&l.y, act_bytes(c, l.Hout, l.Wout, l.Cout));
+    ar.add((void**)&l.stat, (size_t)4 * l.Cout * 4);
+    max_act = std::max(max_act, act_bytes(c, l.Hout, l.Wout, l.Cout));
+    max_act = std::max(max_act, act_bytes(c, l.Hin, l.Win, l.Cin));
+    max_c = std::max<size_t>(max_c, l.Cout);
+    if (!l.is_stem) {
+      const size_t wn = (size_t)l.Cout * l.K * l.K * l.Cin;
+      if (c->dtype != MI355_F32) ar.add(&l.w_cast, wn * c->es);
+      ar.add(&l.w_tr, wn * c->es);
+      l.splits = plan_wgrad_splits(N * l.Hout * l.Wout, l.Cout, l.K * l.K, l.Cin);
+      max_wg = std::max(max_wg, (size_t)l.splits * wn * 4);
+    } else {
+      l.splits = plan_wgrad_splits(N * l.Hout * l.Wout, 64, 7, STEM_CK);
+      max_wg = std::max(max_wg, (size_t)l.splits * 64 * 7 * 64 * 4);
+    }
+  };
+  ar.add(&c->xpad, mi355_stem_xpad_bytes(c->dtype, N, c->H, c->W));
+  ar.add(&c->stem_pack, (size_t)64 * 7 * 64 * c->es);
+  conv_ws(c->stem);
+  ar.add(&c->a0, act_bytes(c, c->stem.Hout, c->stem.Wout, 64));
+  ar.add(&c->p0, act_bytes(c, c->stem.Hout / 2, c->stem.Wout / 2, 64));
+  ar.add((void**)&c->pool_idx, (size_t)N * (c->stem.Hout / 2) * (c->stem.Wout / 2) * 64);
+  for (auto& b : c->blocks) {
+    conv_ws(b.c1);
+    ar.add(&b.a1, act_bytes(c, b.c1.Hout, b.c1.Wout, b.c1.Cout));
+    conv_ws(b.c2);
+    ar.add(&b.a2, act_bytes(c, b.c2.Hout, b.c2.Wout, b.c2.Cout));
+    conv_ws(b.c3);
+    if (b.has_ds) conv_ws(b.ds);
+    ar.add(&b.out, act_bytes(c, b.Hout, b.Wout, b.Cout));
+  }
+  const int fcp = c->fc_pad;
+  ar.add((void**)&c->pooled, (size_t)N * 2048 * 4);
+  ar.add((void**)&c->fc_tmp, (size_t)N * fcp * 4);
+  ar.add((void**)&c->dlogits_pad, (size_t)N * fcp * 4);
+  ar.add((void**)&c->dpooled, (size_t)N * 2048 * 4);
+  ar.add((void**)&c->fc_wtr, (size_t)fcp * 2048 * 4);
+  {
+    const int fsplits = plan_wgrad_splits(N, fcp, 1, 2048);
+    max_wg = std::max(max_wg, (size_t)fsplits * fcp * 2048 * 4);
+  }
+  ar.add((void**)&c->bn_partial, (size_t)bn_max_blocks() * 2 * max_c * 4);
+  ar.add((void**)&c->bn_coef, (size_t)3 * max_c * 4);
+  ar.add((void**)&c->wg_partial, max_wg);
+  for (int i = 0; i < 4; ++i) ar.add(&c->gbuf[i], max_act);
+  return 0;
+}
+
+int weight_prep_all(mi355_ctx* c, bool need_tr, hipStream_t s) {
+  Prof p(c, PC_OTHER, 0, 0, s);
+  MI355_TRY(launch_stem_pack(c->dtype, c->params + c->stem.w_off, c->stem_pack, s));
+  auto prep = [&](ConvBN& l) -> int {
+    return launch_weight_prep(c->dtype, c->params + l.w_off, l.w_cast, need_tr ? l.w_tr : nullptr, l.Cout, l.K * l.K,
+                              l.Cin, s);
+  };
+  for (auto& b : c->blocks) {
+    MI355_TRY(prep(b.c1));
+    MI355_TRY(prep(b.c2));
+    MI355_TRY(prep(b.c3));
+    if (b.has_ds) MI355_TRY(prep(b.ds));
+  }
+  if (need_tr)
+    MI355_TRY(launch_weight_prep(MI355_F32, c->params + c->fc_w_off, nullptr, c->fc_wtr, c->fc_pad, 1, 2048, s));
+  return 0;
+}
+
+int backward_fc(mi355_ctx* c, const float* dlogits, float beta_acc, hipStream_t s) {
+  const int N = c->N, O = c->num_classes, P = c->fc_pad;
+  MI355_TRY(launch_pad_dlogits(dlogits, c->dlogits_pad, P, c->grads + c->fc_b_off, beta_acc, N, O, s));
+  // wgrad: dW[o][k] = sum_n dlogits[n][o] * pooled[n][k]
+  WgradArgs w;
+  build_wgrad_args(w, N, 1, 1, 2048, P, 1, 1, 1, 0);
+  w.dy = c->dlogits_pad; w.x = c->pooled; w.partial = c->wg_partial;
+  const int splits = plan_wgrad_splits(N, P, 1, 2048);
+  MI355_TRY(launch_wgrad(MI355_F32, w, splits, s));
+  MI355_TRY(launch_splitk_reduce(c->wg_partial, splits, (size_t)P * 2048, c->grads + c->fc_w_off, (size_t)O * 2048,
+                                 beta_acc, s));
+  // dgrad: dpooled[n][k] = sum_o dlogits[n][o] * W[o][k]
+  IgemmArgs a;
+  build_dgrad_args(a, N, 1, 1, 2048, P, 1, 1, 1, 0);
+  a.in = c->dlogits_pad; a.wt = c->fc_wtr; a.out = c->dpooled;
+  MI355_TRY(launch_igemm(MI355_F32, a, 1, s));
+  const Block& last = c->blocks.back();
+  c->cur_dout = c->gbuf[0];
+  return launch_gap_bwd(c->dtype, c->dpooled, c->cur_dout, N, last.Hout * last.Wout, last.Cout, s);
+}
+
+void* other_buf(mi355_ctx* c, const void* a, const void* b, const void* d) {
+  for (int i = 0; i < 4; ++i)
+    if (c->gbuf[i] != a && c->gbuf[i] != b && c->gbuf[i] != d) return c->gbuf[i];
+  return nullptr;
+}
+
+int backward_block(mi355_ctx* c, Block& b, float beta_acc, hipStream_t s) {
+  void* G = c->cur_dout;  // gradient wrt block output (pre-mask); becomes dz in place
+  void* B1 = other_buf(c, G, nullptr, nullptr);
+  void* B2 = other_buf(c, G, B1, nullptr);
+  void* B3 = other_buf(c, G, B1, B2);
+  // bn3 (+ReLU mask of the block output); dz written back into G
+  MI355_TRY(bn_backward(c, b.c3, G, b.out, G, B1, beta_acc, s));  // B1 = dy3
+  if (b.has_ds) MI355_TRY(bn_backward(c, b.ds, G, nullptr, nullptr, B2, beta_acc, s));  // B2 = dyd
+  MI355_TRY(conv_wgrad(c, b.c3, B1, b.a2, beta_acc, s));
+  MI355_TRY(conv_dgrad(c, b.c3, B1, B3, nullptr, s));  // B3 = da2
+  MI355_TRY(bn_backward(c, b.c2, B3, b.a2, nullptr, B3, beta_acc, s));  // B3 = dy2
+  MI355_TRY(conv_wgrad(c, b.c2, B3, b.a1, beta_acc, s));
+  MI355_TRY(conv_dgrad(c, b.c2, B3, B1, nullptr, s));  // B1 = da1
+  MI355_TRY(bn_backward(c, b.c1, B1, b.a1, nullptr, B1, beta_acc, s));  // B1 = dy1
+  MI355_TRY(conv_wgrad(c, b.c1, B1, b.in, beta_acc, s));
+  if (b.has_ds) {
+    MI355_TRY(conv_wgrad(c, b.ds, B2, b.in, beta_acc, s));
+    MI355_TRY(conv_dgrad(c, b.ds, B2, B3, nullptr, s));  // B3 = shortcut gradient
+    MI355_TRY(conv_dgrad(c, b.c1, B1, B3, B3, s));       // B3 = dx_in
+    c->cur_dout = B3;
+  } else {
+    MI355_TRY(conv_dgrad(c, b.c1, B1, G, G, s));  // G = dx_in = conv1 dgrad + dz
+    c->cur_dout = G;
+  }
+  return 0;
+}
+
+int backward_stem(mi355_ctx* c, float beta_acc, hipStream_t s) {
+  void* G = c->cur_dout;  // gradient wrt maxpool output
+  void* B1 = other_buf(c, G, nullptr, nullptr);
+  ConvBN& l = c->stem;
+  {
+    Prof p(c, PC_OTHER, 0, 0, s);
+    MI355_TRY(launch_maxpool_bwd(c->dtype, G, c->pool_idx, B1, c->N, l.Hout, l.Wout, 64, s));
+  }
+  MI355_TRY(bn_backward(c, l, B1, c->a0, nullptr, B1, beta_acc, s));
+  WgradArgs a;
+  build_stem_wgrad_args(a, c->N, c->H, c->W);
+  a.dy = B1; a.x = c->xpad; a.partial = c->wg_partial;
+  {
+    Prof p(c, PC_CONV_WGRAD, conv_flops(c, l), 0, s);
+    MI355_TRY(launch_wgrad(c->dtype, a, l.splits, s));
+  }
+  return launch_stem_unpack(c->wg_partial, l.splits, c->grads + l.w_off, beta_acc, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, int W, int num_classes) {
+  MI355_ARG(out, "create: null out");
+  MI355_ARG(dtype == MI355_F32 || dtype == MI355_BF16, "create: bad dtype %d", dtype);
+  MI355_ARG(N >= 1 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0, "create: N=%d H=%d W=%d (H,W multiples of 32)",
+            N, H, W);
+  MI355_ARG(num_classes >= 1 && num_classes <= 65536, "create: num_classes=%d", num_classes);
+  MI355_HIP(hipSetDevice(device));
+  mi355_ctx* c = new mi355_ctx();
+  c->device = device; c->dtype = dtype; c->N = N; c->H = H; c->W = W; c->num_classes = num_classes;
+  c->fc_pad = (int)align_up((size_t)num_classes, 128);
+  c->es = dtype_size(dtype);
+
+  // ---- network description ----
+  init_conv(c->stem, "conv1", "bn1", 3, 64, 7, 2, H, W);
+  c->stem.is_stem = true;
+  int h = c->stem.Hout / 2, w = c->stem.Wout / 2, cin = 64;
+  const int nblk[4] = {3, 4, 6, 3};
+  const int planes[4] = {64, 128, 256, 512};
+  for (int st = 0; st < 4; ++st) {
+    for (int i = 0; i < nblk[st]; ++i) {
+      Block b;
+      const int p = planes[st];
+      const int stride = (i == 0 && st > 0) ? 2 : 1;
+      const std::string pre = "layer" + std::to_string(st + 1) + "." + std::to_string(i) + ".";
+      b.Hin = h; b.Win = w; b.Cin = cin; b.Cout = 4 * p;
+      init_conv(b.c1, pre + "conv1", pre + "bn1", cin, p, 1, 1, h, w);
+      init_conv(b.c2, pre + "conv2", pre + "bn2", p, p, 3, stride, h, w);
+      init_conv(b.c3, pre + "conv3", pre + "bn3", p, 4 * p, 1, 1, b.c2.Hout, b.c2.Wout);
+      b.has_ds = (i == 0);
+      if (b.has_ds) init_conv(b.ds, pre + "downsample.0", pre + "downsample.1", cin, 4 * p, 1, stride, h, w);
+      b.Hout = b.c2.Hout; b.Wout = b.c2.Wout;
+      h = b.Hout; w = b.Wout; cin = 4 * p;
+      c->blocks.push_back(b);
+    }
+  }
+  // ---- flat parameter layout, reverse execution order ----
+  std::vector<TensorInfo> rev;
+  c->fc_grad_begin = c->param_elems;
+  add_param(c, rev, "fc.bias", &c->fc_b_off, 1, num_classes);
+  add_param(c, rev, "fc.weight", &c->fc_w_off, 2, num_classes, 2048, 0, 0,
+            (size_t)(c->fc_pad - num_classes) * 2048);
+  c->fc_grad_end = c->param_elems;
+  for (int i = (int)c->blocks.size() - 1; i >= 0; --i) {
+    Block& b = c->blocks[i];
+    b.grad_begin = c->param_elems;
+    if (b.has_ds) register_convbn(c, rev, b.ds);
+    register_convbn(c, rev, b.c3);
+    register_convbn(c, rev, b.c2);
+    register_convbn(c, rev, b.c1);
+    b.grad_end = c->param_elems;
+  }
+  c->stem_grad_begin = c->param_elems;
+  register_convbn(c, rev, c->stem);
+  c->stem_grad_end = c->param_elems;
+  // expose tensors in torchvision (forward) order
+  c->tensors.assign(rev.rbegin(), rev.rend());
+
+  // ---- FLOPs ----
+  double f = conv_flops(c, c->stem), bw = 2 * conv_flops(c, c->stem) - conv_flops(c, c->stem);  // stem: no dgrad
+  double tr = 2 * conv_flops(c, c->stem);
+  (void)bw;
+  for (auto& b : c->blocks) {
+    const double fb = conv_flops(c, b.c1) + conv_flops(c, b.c2) + conv_flops(c, b.c3) + (b.has_ds ? conv_flops(c, b.ds) : 0);
+    f += fb;
+    tr += 3 * fb;
+  }
+  const double ffc = 2.0 * N * 2048 * num_classes;
+  c->fwd_flops = f + ffc;
+  c->train_flops = tr + 3 * ffc;
+
+  // ---- workspace ----
+  Arena ar;
+  plan_arena(c, ar);
+  c->arena_bytes = ar.size;
+  hipError_t e = hipMalloc((void**)&c->arena, ar.size);
+  if (e != hipSuccess) {
+    set_error("create: hipMalloc(%zu bytes) -> %s", ar.size, hipGetErrorString(e));
+    delete c;
+    return MI355_E_NOMEM;
+  }
+  for (auto& sl : ar.slots) *sl.first = c->arena + sl.second;
+  e = hipMemset(c->arena, 0, ar.size);
+  if (e != hipSuccess) {
+    set_error("create: hipMemset -> %s", hipGetErrorString(e));
+    (void)hipFree(c->arena);
+    delete c;
+    return MI355_E_HIP;
+  }
+  // block inputs
+  const void* prev = c->p0;
+  for (auto& b : c->blocks) {
+    b.in = prev;
+    prev = b.out;
+  }
+  *out = c;
+  return 0;
+}
+
+int mi355_resnet50_destroy(mi355_ctx* c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  for (auto e : c->ev) (void)hipEventDestroy(e);
+  if (c->arena) (void)hipFree(c->arena);
+  delete c;
+  return 0;
+}
+
+int mi355_resnet50_num_tensors(const mi355_ctx* c) { return c ? (int)c->tensors.size() : 0; }
+
+int mi355_resnet50_tensor_info(const mi355_ctx* c, int idx, char* name, int name_cap, int* kind, size_t* offset,
+                               int* ndim, int shape[4]) {
+  MI355_ARG(c && idx >= 0 && idx < (int)c->tensors.size(), "tensor_info: bad index %d", idx);
+  const TensorInfo& t = c->tensors[idx];
+  if (name && name_cap > 0) {
+    strncpy(name, t.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (kind) *kind = t.kind;
+  if (offset) *offset = t.offset;
+  if (ndim) *ndim = t.ndim;
+  if (shape)
+    for (int i = 0; i < 4; ++i) shape[i] = t.shape[i];
+  return 0;
+}
+
+size_t mi355_resnet50_flat_param_elems(const mi355_ctx* c) { return c ? c->param_elems : 0; }
+size_t mi355_resnet50_flat_buffer_elems(const mi355_ctx* c) { return c ? c->buffer_elems : 0; }
+size_t mi355_resnet50_workspace_bytes(const mi355_ctx* c) { return c ? c->arena_bytes : 0; }
+
+int mi355_resnet50_bind(mi355_ctx* c, float* params, float* grads, float* buffers) {
+  MI355_ARG(c && params && buffers, "bind: null pointer");
+  MI355_ARG(((uintptr_t)params % 256 == 0) && ((uintptr_t)buffers % 256 == 0) && ((uintptr_t)grads % 256 == 0),
+            "bind: flat arrays must be 256-byte aligned");
+  c->params = params; c->grads = grads; c->buffers = buffers;
+  return 0;
+}
+
+int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int training, float bn_momentum,
+                           void* stream) {
+  MI355_ARG(c && x_nchw && logits, "forward: null pointer");
+  if (!c->params) {
+    set_error("forward: parameters not bound");
+    return MI355_E_STATE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int N = c->N;
+  c->fwd_training_done = false;
+  MI355_TRY(weight_prep_all(c, training != 0, s));
+  {
+    Prof p(c, PC_OTHER, 0, 0, s);
+    MI355_TRY(launch_stem_ingest(c->dtype, x_nchw, c->xpad, N, c->H, c->W, s));
+  }
+  // stem
+  {
+    IgemmArgs a;
+    build_stem_fwd_args(a, N, c->H, c->W);
+    a.in = c->xpad; a.wt = c->stem_pack; a.out = c->stem.y;
+    Prof p(c, PC_CONV_FWD, conv_flops(c, c->stem), 0, s);
+    MI355_TRY(launch_igemm(c->dtype, a, 1, s));
+  }
+  MI355_TRY(bn_prepare(c, c->stem, training, bn_momentum, s));
+  MI355_TRY(bn_apply(c, c->stem, nullptr, nullptr, c->a0, 1, s));
+  {
+    Prof p(c, PC_OTHER, 0, 0, s);
+    MI355_TRY(launch_maxpool_fwd(c->dtype, c->a0, c->p0, c->pool_idx, N, c->stem.Hout, c->stem.Wout, 64, s));
+  }
+  for (auto& b : c->blocks) {
+    MI355_TRY(conv_forward(c, b.c1, b.in, s));
+    MI355_TRY(bn_prepare(c, b.c1, training, bn_momentum, s));
+    MI355_TRY(bn_apply(c, b.c1, nullptr, nullptr, b.a1, 1, s));
+    MI355_TRY(conv_forward(c, b.c2, b.a1, s));
+    MI355_TRY(bn_prepare(c, b.c2, training, bn_momentum, s));
+    MI355_TRY(bn_apply(c, b.c2, nullptr, nullptr, b.a2, 1, s));
+    MI355_TRY(conv_forward(c, b.c3, b.a2, s));
+    MI355_TRY(bn_prepare(c, b.c3, training, bn_momentum, s));
+    if (b.has_ds) {
+      MI355_TRY(conv_forward(c, b.ds, b.in, s));
+      MI355_TRY(bn_prepare(c, b.ds, training, bn_momentum, s));
+      MI355_TRY(bn_apply(c, b.c3, nullptr, &b.ds, b.out, 1, s));
+    } else {
+      MI355_TRY(bn_apply(c, b.c3, b.in, nullptr, b.out, 1, s));
+    }
+  }
+  const Block& last = c->blocks.back();
+  {
+    Prof p(c, PC_OTHER, 0, 0, s);
+    MI355_TRY(launch_gap_fwd(c->dtype, last.out, c->pooled, N, last.Hout * last.Wout, last.Cout, s));
+    IgemmArgs a;
+    build_fwd_args(a, N, 1, 1, 2048, c->fc_pad, 1, 1, 1, 0);
+    a.in = c->pooled; a.wt = c->params + c->fc_w_off; a.out = c->fc_tmp;
+    MI355_TRY(launch_igemm(MI355_F32, a, 1, s));
+    MI355_TRY(launch_bias_slice(c->fc_tmp, c->fc_pad, c->params + c->fc_b_off, logits, N, c->num_classes, s));
+  }
+  c->fwd_training_done = training != 0;
+  c->next_seg = 0;
+  return 0;
+}
+
+int mi355_resnet50_num_segments(const mi355_ctx* c) { return c ? (int)c->blocks.size() + 2 : 0; }
+
+int mi355_resnet50_segment_range(const mi355_ctx* c, int seg, size_t* gb, size_t* ge) {
+  MI355_ARG(c && seg >= 0 && seg < (int)c->blocks.size() + 2, "segment_range: bad segment %d", seg);
+  const int nb = (int)c->blocks.size();
+  size_t b, e;
+  if (seg == 0) {
+    b = c->fc_grad_begin; e = c->fc_grad_end;
+  } else if (seg == nb + 1) {
+    b = c->stem_grad_begin; e = c->stem_grad_end;
+  } else {
+    const Block& blk = c->blocks[nb - seg];
+    b = blk.grad_begin; e = blk.grad_end;
+  }
+  if (gb) *gb = b;
+  if (ge) *ge = e;
+  return 0;
+}
+
+int mi355_resnet50_backward(mi355_ctx* c, const float* dlogits, int seg_begin, int seg_end, int accumulate,
+                            void* stream) {
+  MI355_ARG(c, "backward: null ctx");
+  const int nseg = (int)c->blocks.size() + 2;
+  MI355_ARG(seg_begin >= 0 && seg_end <= nseg && seg_begin < seg_end, "backward: bad segment range [%d,%d)", seg_begin,
+            seg_end);
+  if (!c->fwd_training_done || !c->grads) {
+    set_error("backward: needs a training forward and bound gradients first");
+    return MI355_E_STATE;
+  }
+  if (seg_begin != c->next_seg) {
+    set_error("backward: segments must run in order (expected %d, got %d)", c->next_seg, seg_begin);
+    return MI355_E_STATE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const float beta_acc = accumulate ? 1.f : 0.f;
+  const int nb = (int)c->blocks.size();
+  for (int seg = seg_begin; seg < seg_end; ++seg) {
+    if (seg == 0) {
+      MI355_ARG(dlogits, "backward: dlogits is null");
+      MI355_TRY(backward_fc(c, dlogits, beta_acc, s));
+    } else if (seg == nb + 1) {
+      MI355_TRY(backward_stem(c, beta_acc, s));
+    } else {
+      MI355_TRY(backward_block(c, c->blocks[nb - seg], beta_acc, s));
+    }
+    c->next_seg = seg + 1;
+  }
+  if (c->next_seg == nseg) c->fwd_training_done = false;
+  return 0;
+}
+
+int mi355_resnet50_flops(const mi355_ctx* c, double* fwd, double* train) {
+  MI355_ARG(c, "flops: null ctx");
+  if (fwd) *fwd = c->fwd_flops;
+  if (train) *train = c->train_flops;
+  return 0;
+}
+
+int mi355_resnet50_profile(mi355_ctx* c, int class_mask) {
+  MI355_ARG(c, "profile: null ctx");
+  MI355_HIP(hipSetDevice(c->device));
+  if (class_mask && c->ev.empty()) {
+    c->ev.resize(MAX_EVENTS);
+    for (auto& e : c->ev) MI355_HIP(hipEventCreate(&e));
+  }
+  c->prof_mask = (unsigned)class_mask;
+  c->recs.clear();
+  return 0;
+}
+
+int mi355_resnet50_profile_read(mi355_ctx* c, int kind, double* total_ms, int* launches, double* alg_flops,
+                                double* alg_bytes) {
+  MI355_ARG(c && kind >= 0 && kind < 32, "profile_read: bad arguments");
+  double ms = 0, fl = 0, by = 0;
+  int n = 0;
+  for (size_t i = 0; i < c->recs.size(); ++i) {
+    if (c->recs[i].cls != kind) continue;
+    float t = 0;
+    MI355_HIP(hipEventSynchronize(c->ev[2 * i + 1]));
+    MI355_HIP(hipEventElapsedTime(&t, c->ev[2 * i], c->ev[2 * i + 1]));
+    ms += t; fl += c->recs[i].flops; by += c->recs[i].bytes;
+    ++n;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
+  if (alg_flops) *alg_flops = fl;
+  if (alg_bytes) *alg_bytes = by;
+  return 0;
+}
+
+}  // extern "C"

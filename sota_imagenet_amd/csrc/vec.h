@@ -1,0 +1,43 @@
+// vec.h — 16-byte vector load/store of NHWC channel groups as fp32 lanes (fp32: 4 channels, bf16: 8).
+#pragma once
+#include "common.h"
+
+namespace mi355 {
+
+template <typename T>
+struct Vec16;
+
+template <>
+struct Vec16<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  }
+};
+
+template <>
+struct Vec16<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16_t)v[i];  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+    *reinterpret_cast<bf16x8*>(p) = t;
+  }
+};
+
+}  // namespace mi355

@@ -1,0 +1,89 @@
+// weights.hip — per-step weight preparation: fp32 KRSC master -> the operand images the conv kernels read.
+//   * cast copy      [Cout][taps][Cin]  in the compute dtype (bf16 path only)
+//   * transposed copy [Cin][taps][Cout] in the compute dtype (the K-contiguous B operand of dgrad)
+//   * stem pack      [64][7][7][3] -> [64][7][16 px * 4 ch] zero padded (the stem runs as 7 row-taps of 64)
+// ~94 MB of reads per step for ResNet-50: HBM-trivial, and it keeps the master weights in the layout
+// torch's state_dict exposes (reference interchange: train.py:101,184).
+#include "common.h"
+
+namespace mi355 {
+namespace {
+
+template <typename T, typename Tin = float>
+__global__ void weight_prep_kernel(const Tin* __restrict__ w, T* __restrict__ w_cast, T* __restrict__ w_tr,
+                                   int Cout, int taps, int Cin) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const size_t src = ((size_t)(co0 + r) * taps + t) * Cin + ci0 + tx;
+    const float v = (float)w[src];
+    tile[r][tx] = v;
+    if (w_cast) w_cast[src] = (T)v;
+  }
+  __syncthreads();
+  if (w_tr) {
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const size_t dst = ((size_t)(ci0 + r) * taps + t) * Cout + co0 + tx;
+      w_tr[dst] = (T)tile[tx][r];
+    }
+  }
+}
+
+template <typename T>
+__global__ void stem_pack_kernel(const float* __restrict__ w, T* __restrict__ packed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 64 * 7 * 64) return;
+  const int e = i & 63;
+  const int kw = e >> 2, c = e & 3;
+  const int kh = (i >> 6) % 7;
+  const int co = (i >> 6) / 7;
+  float v = 0.f;
+  if (kw < 7 && c < 3) v = w[((co * 7 + kh) * 7 + kw) * 3 + c];
+  packed[i] = (T)v;
+}
+
+}  // namespace
+
+int launch_weight_prep(int dtype, const float* w, void* w_cast, void* w_tr, int Cout, int taps, int Cin,
+                       hipStream_t stream) {
+  MI355_ARG(Cout % 32 == 0 && Cin % 32 == 0, "weight_prep: Cout=%d Cin=%d must be multiples of 32", Cout, Cin);
+  if (!w_cast && !w_tr) return 0;
+  dim3 grid(Cin / 32, Cout / 32, taps);
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL((weight_prep_kernel<float, float>), grid, dim3(256), 0, stream, w, (float*)w_cast, (float*)w_tr, Cout,
+                       taps, Cin);
+  else
+    hipLaunchKernelGGL((weight_prep_kernel<bf16_t, float>), grid, dim3(256), 0, stream, w, (bf16_t*)w_cast, (bf16_t*)w_tr,
+                       Cout, taps, Cin);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_transpose_any(int dtype, const void* w, void* wt, int Cout, int taps, int Cin, hipStream_t stream) {
+  MI355_ARG(Cout % 32 == 0 && Cin % 32 == 0, "transpose: Cout=%d Cin=%d must be multiples of 32", Cout, Cin);
+  dim3 grid(Cin / 32, Cout / 32, taps);
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL((weight_prep_kernel<float, float>), grid, dim3(256), 0, stream, (const float*)w,
+                       (float*)nullptr, (float*)wt, Cout, taps, Cin);
+  else
+    hipLaunchKernelGGL((weight_prep_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)w,
+                       (bf16_t*)nullptr, (bf16_t*)wt, Cout, taps, Cin);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_stem_pack(int dtype, const float* w, void* packed, hipStream_t stream) {
+  const int n = 64 * 7 * 64;
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL(stem_pack_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, stream, w, (float*)packed);
+  else
+    hipLaunchKernelGGL(stem_pack_kernel<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, stream, w, (bf16_t*)packed);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace mi355

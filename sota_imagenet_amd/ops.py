@@ -1,0 +1,186 @@
+"""Per-op Python entry points over the C-ABI (include/mi355rn.h) on PyTorch-ROCm tensors.
+
+These are the unit-level handles the parity tests use; the training path goes through the whole-network
+executor (sota_imagenet_amd/models.py).  Tensors are NHWC (`[N,H,W,C]`), conv weights KRSC (`[Cout,KH,KW,Cin]`).
+Every function enqueues on torch's current stream and raises RuntimeError on any native failure.
+"""
+import torch
+
+from . import native
+from .native import check, cur_stream, dtype_code, ptr
+
+
+def _L():
+    return native.lib()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not (t.is_cuda and t.is_contiguous()):
+            raise ValueError("tensors must be contiguous CUDA (ROCm) tensors")
+
+
+def _out_dim(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+def conv2d_fwd(x, w, stride=1, pad=0):
+    _need_cuda(x, w)
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w.shape
+    y = torch.empty((N, _out_dim(H, KH, stride, pad), _out_dim(W, KW, stride, pad), Cout), dtype=x.dtype, device=x.device)
+    check(_L().mi355_conv2d_fwd(dtype_code(x.dtype), ptr(x), ptr(w), ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, cur_stream()))
+    return y
+
+
+def _conv_ws(dt, N, H, W, Cin, Cout, KH, KW, stride, pad, device):
+    n = _L().mi355_conv2d_workspace_bytes(dt, N, H, W, Cin, Cout, KH, KW, stride, pad)
+    return torch.empty(n, dtype=torch.uint8, device=device), n
+
+
+def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None):
+    _need_cuda(dy, w, addend)
+    N, H, W, Cin = x_shape
+    Cout, KH, KW, _ = w.shape
+    dt = dtype_code(dy.dtype)
+    ws, n = _conv_ws(dt, N, H, W, Cin, Cout, KH, KW, stride, pad, dy.device)
+    dx = torch.empty((N, H, W, Cin), dtype=dy.dtype, device=dy.device)
+    check(_L().mi355_conv2d_dgrad(dt, ptr(dy), ptr(w), ptr(dx), ptr(addend), N, H, W, Cin, Cout, KH, KW, stride, pad, ptr(ws), n, cur_stream()))
+    return dx
+
+
+def conv2d_wgrad(dy, x, KH, KW, stride=1, pad=0, dw=None, beta=0.0):
+    _need_cuda(dy, x, dw)
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[-1]
+    dt = dtype_code(dy.dtype)
+    ws, n = _conv_ws(dt, N, H, W, Cin, Cout, KH, KW, stride, pad, dy.device)
+    if dw is None:
+        dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=dy.device)
+    check(_L().mi355_conv2d_wgrad(dt, ptr(dy), ptr(x), ptr(dw), beta, N, H, W, Cin, Cout, KH, KW, stride, pad, ptr(ws), n, cur_stream()))
+    return dw
+
+
+def stem_ingest(x_nchw, dtype):
+    _need_cuda(x_nchw)
+    N, _, H, W = x_nchw.shape
+    dt = dtype_code(dtype)
+    nbytes = _L().mi355_stem_xpad_bytes(dt, N, H, W)
+    xpad = torch.zeros(nbytes, dtype=torch.uint8, device=x_nchw.device)
+    check(_L().mi355_stem_ingest(dt, ptr(x_nchw), ptr(xpad), N, H, W, cur_stream()))
+    return xpad
+
+
+def stem_fwd(xpad, w, N, H, W, dtype):
+    """w: [64,7,7,3] fp32 (KRSC)."""
+    _need_cuda(xpad, w)
+    dt = dtype_code(dtype)
+    n = _L().mi355_stem_workspace_bytes(dt, N, H, W)
+    ws = torch.empty(n, dtype=torch.uint8, device=w.device)
+    y = torch.empty((N, H // 2, W // 2, 64), dtype=dtype, device=w.device)
+    check(_L().mi355_stem_fwd(dt, ptr(xpad), ptr(w), ptr(y), N, H, W, ptr(ws), n, cur_stream()))
+    return y
+
+
+def stem_wgrad(dy, xpad, N, H, W):
+    _need_cuda(dy, xpad)
+    dt = dtype_code(dy.dtype)
+    n = _L().mi355_stem_workspace_bytes(dt, N, H, W)
+    ws = torch.empty(n, dtype=torch.uint8, device=dy.device)
+    dw = torch.empty((64, 7, 7, 3), dtype=torch.float32, device=dy.device)
+    check(_L().mi355_stem_wgrad(dt, ptr(dy), ptr(xpad), ptr(dw), 0.0, N, H, W, ptr(ws), n, cur_stream()))
+    return dw
+
+
+def _bn_ws(C, device):
+    n = _L().mi355_bn_workspace_bytes(C)
+    return torch.empty(n, dtype=torch.uint8, device=device), n
+
+
+def bn_fwd_train(x, gamma, beta, running_mean, running_var, residual=None, relu=True, eps=1e-5, momentum=0.1):
+    """x: [..., C] NHWC.  Updates running stats in place.  Returns (out, save_mean, save_invstd)."""
+    _need_cuda(x, gamma, beta, running_mean, running_var, residual)
+    C = x.shape[-1]
+    M = x.numel() // C
+    out = torch.empty_like(x)
+    sm = torch.empty(C, dtype=torch.float32, device=x.device)
+    si = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws, n = _bn_ws(C, x.device)
+    check(_L().mi355_bn_fwd_train(dtype_code(x.dtype), ptr(x), ptr(residual), ptr(out), ptr(gamma), ptr(beta), ptr(running_mean),
+                                  ptr(running_var), ptr(sm), ptr(si), M, C, eps, momentum, int(relu), ptr(ws), n, cur_stream()))
+    return out, sm, si
+
+
+def bn_fwd_eval(x, gamma, beta, running_mean, running_var, residual=None, relu=True, eps=1e-5):
+    _need_cuda(x, gamma, beta, running_mean, running_var, residual)
+    C = x.shape[-1]
+    M = x.numel() // C
+    out = torch.empty_like(x)
+    ws, n = _bn_ws(C, x.device)
+    check(_L().mi355_bn_fwd_eval(dtype_code(x.dtype), ptr(x), ptr(residual), ptr(out), ptr(gamma), ptr(beta), ptr(running_mean),
+                                 ptr(running_var), M, C, eps, int(relu), ptr(ws), n, cur_stream()))
+    return out
+
+
+def bn_bwd(dout, out, x, gamma, save_mean, save_invstd, relu=True, want_dz=False):
+    """Returns (dx, dgamma, dbeta, dz or None)."""
+    _need_cuda(dout, out, x, gamma, save_mean, save_invstd)
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = torch.empty_like(x)
+    dz = torch.empty_like(x) if want_dz else None
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws, n = _bn_ws(C, x.device)
+    check(_L().mi355_bn_bwd(dtype_code(x.dtype), ptr(dout), ptr(out), ptr(x), ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(dx),
+                            ptr(dz), ptr(dg), ptr(db), 0.0, M, C, int(relu), ptr(ws), n, cur_stream()))
+    return dx, dg, db, dz
+
+
+def maxpool_fwd(x):
+    _need_cuda(x)
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+    idx = torch.empty((N, H // 2, W // 2, C), dtype=torch.uint8, device=x.device)
+    check(_L().mi355_maxpool_fwd(dtype_code(x.dtype), ptr(x), ptr(y), ptr(idx), N, H, W, C, cur_stream()))
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, x_shape):
+    _need_cuda(dy, idx)
+    N, H, W, C = x_shape
+    dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+    check(_L().mi355_maxpool_bwd(dtype_code(dy.dtype), ptr(dy), ptr(idx), ptr(dx), N, H, W, C, cur_stream()))
+    return dx
+
+
+def gap_fwd(x):
+    _need_cuda(x)
+    N, H, W, C = x.shape
+    pooled = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    check(_L().mi355_gap_fwd(dtype_code(x.dtype), ptr(x), ptr(pooled), N, H * W, C, cur_stream()))
+    return pooled
+
+
+def gap_bwd(dpooled, x_shape, dtype):
+    _need_cuda(dpooled)
+    N, H, W, C = x_shape
+    dx = torch.empty((N, H, W, C), dtype=dtype, device=dpooled.device)
+    check(_L().mi355_gap_bwd(dtype_code(dtype), ptr(dpooled), ptr(dx), N, H * W, C, cur_stream()))
+    return dx
+
+
+def ce_loss(logits, target, smoothing=0.0, grad_scale=1.0, need_grad=True):
+    """Returns (loss scalar tensor on device, dlogits or None)."""
+    _need_cuda(logits, target)
+    N, C = logits.shape
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    row = torch.empty(N, dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if need_grad else None
+    check(_L().mi355_ce_loss(ptr(logits), ptr(target), smoothing, grad_scale, ptr(loss), ptr(row), ptr(dl), N, C, cur_stream()))
+    return loss, dl
+
+
+def sgd_step(p, g, m, lr, momentum=0.0, weight_decay=0.0, grad_scale=1.0):
+    _need_cuda(p, g, m)
+    check(_L().mi355_sgd_step(ptr(p), ptr(g), ptr(m), p.numel(), lr, momentum, weight_decay, grad_scale, cur_stream()))
