@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of the ResNet-50 training hot path on N MI355X (one process per GPU over RCCL).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one synthetic batch already resident in HBM: forward (conv+BN+ReLU blocks,
+GAP, FC), label-smoothed CE, backward, gradient all-reduce (N > 1), SGD-momentum update — nothing skipped.
+Workload = BASELINE.json metric config: ResNet-50, bs 256 per GPU, 224 px (configs[1] fp32 with --dtype fp32,
+configs[2] bf16 by default), weak scaling.  Rank 0 prints ONE JSON line; besides the contract fields it carries
+  roofline     — the dominant conv kernel (by HIP-event time inside the timed region, on the launch stream):
+                 algorithmic FLOPs / measured time against the dense MFMA peak of the dtype
+  cpu_baseline — the torch-CPU oracle (oracle/resnet50_ref.py) timed on this host's cores on a bounded sample
+                 (BASELINE.json configs[0]: bs 32, fp32, 224 px), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2516.6}  # MI355X_MICROARCH.md: dense MFMA peaks (no sparsity)
+KERNEL_NAMES = {0: "igemm_kernel<{T},128>", 1: "igemm_kernel<{T},64>", 2: "wgrad_kernel<{T},128>", 3: "wgrad_kernel<{T},64>"}
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """oracle train step (fwd + CE + bwd + SGD) on the host cores; bounded sample of the same workload."""
+    from oracle import resnet50_ref as O
+    from sota_imagenet_amd.synth import init_state_dict, synthetic_batch
+
+    ref = O.ResNet50Ref()
+    shapes = [(k, tuple(v.shape)) for k, v in ref.state_dict().items()]
+    ref.load_state_dict(init_state_dict(shapes, seed=0))
+    O.patch_bn_mom(ref, 0.1)
+    bs = 32
+    batch = synthetic_batch(bs, 224, seed=0, index=0)
+    opt = torch.optim.SGD(ref.parameters(), lr=0.001, momentum=0.9, weight_decay=3e-5)
+    ref.train()
+
+    def step():
+        loss = O.smooth_ce(ref(batch[0]), batch[1], 0.1)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    step()  # warm-up
+    t0 = time.time()
+    n = 0
+    while True:
+        step()
+        n += 1
+        el = time.time() - t0
+        if n >= 2 and (el > seconds_budget or n >= 10):
+            break
+    return {"value": round(n * bs / el, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} fp32 train steps of bs={bs} @224px (BASELINE configs[0]) with the torch-CPU oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default=os.environ.get("BENCH_DTYPE", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from sota_imagenet_amd.losses import CrossEntropyLoss
+    from sota_imagenet_amd.models import resnet50
+    from sota_imagenet_amd.optim import SGD
+    from sota_imagenet_amd.synth import synthetic_batch
+
+    N, S = args.batch, args.size
+    model = resnet50(dtype=args.dtype).cuda()
+    criterion = CrossEntropyLoss(smoothing=0.1).cuda()
+    opt = SGD([{"params": list(model.parameters())}], lr=0.0, momentum=0.9, weight_decay=3e-5)
+    opt.attach_model(model)
+    net = model
+    if world > 1:
+        from sota_imagenet_amd.parallel import FlatBucketDDP
+
+        net = FlatBucketDDP(model, device_ids=[local_rank])
+    pool = [synthetic_batch(N, S, seed=0, stream=rank, index=i, device="cuda") for i in range(4)]
+    model.train()
+
+    def step(i):
+        data, target = pool[i % len(pool)]
+        lr = 0.001 + 0.0001 * (i % 8)  # the scheduler writes a new LR every batch (train.py:131)
+        for g in opt.param_groups:
+            g["lr"] = lr
+        loss = criterion(net(data), target)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    shape = (N, S, S)
+    want_roof = (not args.no_roofline) and rank == 0
+    if want_roof:
+        model.profile(shape, 0b1111)  # the four conv kernel symbols
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = loss.item()
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * N * args.steps / dt
+        roof = None
+        if want_roof:
+            best = None
+            for k in range(4):
+                tot_ms, launches, flops, _ = model.profile_read(shape, k)
+                if launches and (best is None or tot_ms > best[1]):
+                    best = (k, tot_ms, launches, flops)
+            model.profile(shape, 0)
+            if best:
+                k, tot_ms, launches, flops = best
+                ach = flops / (tot_ms * 1e-3) / 1e12
+                peak = PEAK_TFLOPS[args.dtype]
+                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        "traffic": None, "kernel": KERNEL_NAMES[k].format(T="float" if args.dtype == "fp32" else "__bf16"),
+                        "launches": launches, "avg_launch_ms": round(tot_ms / launches, 4),
+                        "alg_gflop_per_launch": round(flops / launches / 1e9, 3)}
+        _, train_flops = model.flops(N, S, S)
+        out = {
+            "metric": "images/sec (whole node) ResNet-50 bs=256/GPU @224px",
+            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"ResNet-50 v1.5 train step (fwd+CE+bwd+allreduce+SGD), bs={N}/GPU, {S}px, "
+                                   f"{'configs[2] bf16 activations / fp32 accumulate+master' if args.dtype == 'bf16' else 'configs[1] fp32'}",
+                       "global_batch": world * N, "image_size": S, "parallelism": f"dp{world}",
+                       "step_tflops": round(train_flops / (dt / args.steps) / 1e12, 2), "final_loss": round(final_loss, 4)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -146,7 +146,9 @@ int mi355_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float
 typedef struct mi355_ctx mi355_ctx;
 
 /* N = per-GPU batch, H = W = image size (multiple of 32), dtype = activation/compute dtype of the convs
- * (accumulation, BN statistics, FC, loss and optimizer state are always fp32).                      */
+ * (accumulation, BN statistics, FC, loss and optimizer state are always fp32).
+ * device < 0 creates a LAYOUT-ONLY ctx (no HIP call, no memory): the tensor table, flat sizes, segment
+ * ranges and FLOP counts can be queried on a GPU-less host; bind/forward/backward fail with E_STATE.  */
 int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, int W, int num_classes);
 int mi355_resnet50_destroy(mi355_ctx* ctx);
 
@@ -183,11 +185,20 @@ int mi355_resnet50_backward(mi355_ctx* ctx, const float* dlogits, int seg_begin,
 /* algorithmic work of the ctx's conv/FC kernels (2 FLOP/MAC, padding-free): forward and fwd+bwd */
 int mi355_resnet50_flops(const mi355_ctx* ctx, double* fwd_flops, double* train_flops);
 
+/* Test hook: device pointer / shape of an internal tensor of the last step, by name:
+ *   "<conv>.y" raw conv output, "<block>.a1|a2|out" post-activation tensors (e.g. "layer1.0.out"),
+ *   "<bn>.save_mean|save_invstd", "stem.a0", "stem.p0", "pooled", "dpooled", "gbuf0".."gbuf3".
+ * shape is NHWC (ndim 4) or [n] / [N,C]; dtype is MI355_F32 or the ctx dtype.  Read-only use.     */
+int mi355_resnet50_debug_tensor(const mi355_ctx* ctx, const char* name, void** ptr, int* dtype, int* ndim,
+                                int shape[4]);
+
 /* HIP-event timing of kernel classes inside a step, recorded on the stream the kernels are launched on.
  * mi355_resnet50_profile(ctx, class_mask): bit k set => every launch of class k is bracketed by a pair of
  * hipEvents from now on (mask 0 switches it off; calling it also clears earlier records).  Classes:
- *   0 conv fwd (igemm)   1 conv dgrad (igemm)   2 conv wgrad   3 BN fwd (stats+apply)   4 BN bwd
- *   5 other (ingest, pools, FC, weight prep)   6 conv 3x3 fwd only
+ *   0 igemm_kernel<T,128> (conv fwd + dgrad, >=128 output channels)   1 igemm_kernel<T,64> (incl. stem)
+ *   2 wgrad_kernel<T,128>   3 wgrad_kernel<T,64> (incl. stem)   4 bn_reduce_kernel (stats + bwd sums)
+ *   5 bn_apply_kernel   6 other (ingest, pools, FC, weight prep)   7 bn_bwd_apply_kernel
+ * (one class = one kernel symbol, so the averages can be checked against rocprofv3 --kernel-trace --stats)
  * mi355_resnet50_profile_read(ctx, k, ...) waits for the recorded events of class k and returns their
  * summed duration (ms), launch count and the algorithmic FLOPs / bytes those launches represent.    */
 int mi355_resnet50_profile(mi355_ctx* ctx, int class_mask);

@@ -26,6 +26,7 @@ struct ReduceArgs {
   const float* mean;  // [C] (bwd)
   const float* invstd;
   float* partial;     // [gridDim.x][2][C]
+  float* pivot;       // [C] (stats): per-channel shift = the channel's value in row 0
   int M, C;
 };
 
@@ -59,6 +60,14 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
       mu[e] = p.mean[c0 + e];
       is[e] = p.invstd[c0 + e];
     }
+  } else {
+    // shifted sums: var = E[(x-p)^2] - E[x-p]^2 with p a sample of the channel => no catastrophic
+    // cancellation when |mean| >> std (the oracle's torch-CPU path accumulates in fp64)
+    Vec16<T>::load(x + c0, mu);
+    if (blockIdx.x == 0 && r == 0) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) p.pivot[c0 + e] = mu[e];
+    }
   }
   const int step = gridDim.x * rpp;
 #pragma unroll 2
@@ -69,8 +78,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
     if (MODE == 0) {
 #pragma unroll
       for (int e = 0; e < V; ++e) {
-        s1[e] += xv[e];
-        s2[e] += xv[e] * xv[e];
+        const float d = xv[e] - mu[e];
+        s1[e] += d;
+        s2[e] += d * d;
       }
     } else {
       float gv[V];
@@ -135,6 +145,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
 // 16 channels x 16 slices of the block partials per workgroup; fp64 sums in fixed order.
 struct FinalizeArgs {
   const float* partial;
+  const float* pivot;
   int nblk, M, C;
   const float* gamma;
   const float* beta;
@@ -174,8 +185,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const FinalizeArgs p) 
     }
     const double M = (double)p.M;
     if (MODE == 0) {
-      const double mean = s1 / M;
-      double var = s2 / M - mean * mean;
+      const double dm = s1 / M;  // mean of (x - pivot)
+      const double mean = (double)p.pivot[c] + dm;
+      double var = s2 / M - dm * dm;
       if (var < 0.0) var = 0.0;
       const float invstd = (float)(1.0 / sqrt(var + (double)p.eps));
       const float meanf = (float)mean;
@@ -350,11 +362,13 @@ int check_c(int dtype, int C) {
 
 int bn_max_blocks() { return MAXBLK; }
 
-int launch_bn_stats(int dtype, const void* x, float* partial, int* nblk_out, int M, int C, hipStream_t s) {
+int launch_bn_stats(int dtype, const void* x, float* partial, float* pivot, int* nblk_out, int M, int C,
+                    hipStream_t s) {
   MI355_TRY(check_c(dtype, C));
   ReduceArgs a{};
   a.x = x;
   a.partial = partial;
+  a.pivot = pivot;
   a.M = M;
   a.C = C;
   dim3 grid;
@@ -367,11 +381,13 @@ int launch_bn_stats(int dtype, const void* x, float* partial, int* nblk_out, int
   return 0;
 }
 
-int launch_bn_finalize(const float* partial, int nblk, int M, int C, const float* gamma, const float* beta,
+int launch_bn_finalize(const float* partial, const float* pivot, int nblk, int M, int C, const float* gamma,
+                       const float* beta,
                        float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                        float* scale, float* shift, float eps, float momentum, hipStream_t s) {
   FinalizeArgs a{};
   a.partial = partial;
+  a.pivot = pivot;
   a.nblk = nblk;
   a.M = M;
   a.C = C;

@@ -128,8 +128,8 @@ static inline int stem_hp(int H) { return H + 2 * STEM_PAD; }
 static inline int stem_wp(int W) { return W + STEM_RPAD; }  // 2*(W/2-1)+16 = W+14 <= Wp, Wp even
 
 // BN (bn.hip)
-int launch_bn_stats(int dtype, const void* x, float* partial, int* nblk_out, int M, int C, hipStream_t s);
-int launch_bn_finalize(const float* partial, int nblk, int M, int C, const float* gamma, const float* beta,
+int launch_bn_stats(int dtype, const void* x, float* partial, float* pivot, int* nblk_out, int M, int C, hipStream_t s);
+int launch_bn_finalize(const float* partial, const float* pivot, int nblk, int M, int C, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                        float* scale, float* shift, float eps, float momentum, hipStream_t s);
 int launch_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float* scale,

@@ -248,9 +248,10 @@ int mi355_bn_fwd_train(int dtype, const void* x, const void* residual, void* out
   float* partial = (float*)ws;
   float* scale = partial + (size_t)bn_max_blocks() * 2 * C;
   float* shift = scale + C;
+  float* pivot = shift + C;
   int nblk = 0;
-  MI355_TRY(launch_bn_stats(dtype, x, partial, &nblk, M, C, s));
-  MI355_TRY(launch_bn_finalize(partial, nblk, M, C, gamma, beta, running_mean, running_var, save_mean, save_invstd,
+  MI355_TRY(launch_bn_stats(dtype, x, partial, pivot, &nblk, M, C, s));
+  MI355_TRY(launch_bn_finalize(partial, pivot, nblk, M, C, gamma, beta, running_mean, running_var, save_mean, save_invstd,
                                scale, shift, eps, momentum, s));
   return launch_bn_apply(dtype, x, scale, shift, residual, nullptr, nullptr, nullptr, out, M, C, relu, s);
 }

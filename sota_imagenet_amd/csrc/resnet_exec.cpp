@@ -23,7 +23,6 @@ namespace {
 
 constexpr float BN_EPS = 1e-5f;
 constexpr size_t PARAM_ALIGN = 64;  // floats (256 B)
-constexpr int NPROF = 8;            // profile classes
 constexpr int MAX_EVENTS = 8192;
 
 struct TensorInfo {
@@ -162,7 +161,11 @@ struct Prof {
 };
 
 // profile classes
-enum { PC_CONV_FWD = 0, PC_CONV_DGRAD = 1, PC_CONV_WGRAD = 2, PC_BN_FWD = 3, PC_BN_BWD = 4, PC_OTHER = 5, PC_CONV3_FWD = 6 };
+// profile classes = kernel symbols (so HIP-event averages can be checked against rocprofv3 --stats)
+enum { PC_IGEMM128 = 0, PC_IGEMM64 = 1, PC_WGRAD128 = 2, PC_WGRAD64 = 3, PC_BN_REDUCE = 4, PC_BN_APPLY = 5, PC_OTHER = 6,
+       PC_BN_BWD_APPLY = 7 };
+inline int igemm_class(int ncols) { return ncols % 128 == 0 ? PC_IGEMM128 : PC_IGEMM64; }
+inline int wgrad_class(int cout) { return cout % 128 == 0 ? PC_WGRAD128 : PC_WGRAD64; }
 
 double conv_flops(const mi355_ctx* c, const ConvBN& l) {
   return 2.0 * c->N * l.Hout * l.Wout * (double)l.Cout * l.Cin * l.K * l.K;
@@ -176,8 +179,7 @@ int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, hipStream_t s) {
   a.out = l.y;
   const double fl = conv_flops(c, l);
   const double by = ((double)c->N * l.Hin * l.Win * l.Cin + (double)c->N * l.Hout * l.Wout * l.Cout) * c->es;
-  Prof p(c, PC_CONV_FWD, fl, by, s);
-  Prof p3(c, l.K == 3 ? PC_CONV3_FWD : 31, fl, by, s);
+  Prof p(c, igemm_class(l.Cout), fl, by, s);
   return launch_igemm(c->dtype, a, 1, s);
 }
 
@@ -193,10 +195,10 @@ int bn_prepare(mi355_ctx* c, ConvBN& l, int training, float momentum, hipStream_
   if (training) {
     int nblk = 0;
     {
-      Prof p(c, PC_BN_FWD, 0, (double)M * C * c->es, s);
-      MI355_TRY(launch_bn_stats(c->dtype, l.y, c->bn_partial, &nblk, M, C, s));
+      Prof p(c, PC_BN_REDUCE, 0, (double)M * C * c->es, s);
+      MI355_TRY(launch_bn_stats(c->dtype, l.y, c->bn_partial, c->bn_coef, &nblk, M, C, s));
     }
-    return launch_bn_finalize(c->bn_partial, nblk, M, C, gamma, beta, c->buffers + l.rm_off, c->buffers + l.rv_off,
+    return launch_bn_finalize(c->bn_partial, c->bn_coef, nblk, M, C, gamma, beta, c->buffers + l.rm_off, c->buffers + l.rv_off,
                               save_mean, save_invstd, scale, shift, BN_EPS, momentum, s);
   }
   return launch_bn_eval_coeffs(gamma, beta, c->buffers + l.rm_off, c->buffers + l.rv_off, scale, shift, C, BN_EPS, s);
@@ -205,7 +207,7 @@ int bn_prepare(mi355_ctx* c, ConvBN& l, int training, float momentum, hipStream_
 int bn_apply(mi355_ctx* c, ConvBN& l, const void* residual, ConvBN* l2, void* out, int relu, hipStream_t s) {
   const int M = c->N * l.Hout * l.Wout, C = l.Cout;
   const int nin = 1 + (residual ? 1 : 0) + (l2 ? 1 : 0);
-  Prof p(c, PC_BN_FWD, 0, (double)M * C * c->es * (nin + 1), s);
+  Prof p(c, PC_BN_APPLY, 0, (double)M * C * c->es * (nin + 1), s);
   return launch_bn_apply(c->dtype, l.y, l.stat + 2 * C, l.stat + 3 * C, residual, l2 ? l2->y : nullptr,
                          l2 ? l2->stat + 2 * C : nullptr, l2 ? l2->stat + 3 * C : nullptr, out, M, C, relu, s);
 }
@@ -218,7 +220,7 @@ int bn_backward(mi355_ctx* c, ConvBN& l, const void* g, const void* mask, void* 
   int nblk = 0;
   const int nrd = 2 + (mask ? 1 : 0);
   {
-    Prof p(c, PC_BN_BWD, 0, (double)M * C * c->es * (nrd + (dz_out ? 1 : 0)), s);
+    Prof p(c, PC_BN_REDUCE, 0, (double)M * C * c->es * (nrd + (dz_out ? 1 : 0)), s);
     MI355_TRY(launch_bn_bwd_reduce(c->dtype, g, mask, l.y, l.stat, l.stat + C, dz_out, c->bn_partial, &nblk, M, C, s));
   }
   MI355_TRY(launch_bn_bwd_finalize(c->bn_partial, nblk, M, C, c->params + l.gamma_off, l.stat + C,
@@ -226,7 +228,7 @@ int bn_backward(mi355_ctx* c, ConvBN& l, const void* g, const void* mask, void* 
   // after an in-place masked write-back the mask is already applied
   const void* mask2 = dz_out ? nullptr : mask;
   const void* g2 = dz_out ? dz_out : g;
-  Prof p(c, PC_BN_BWD, 0, (double)M * C * c->es * (3 + (mask2 ? 1 : 0)), s);
+  Prof p(c, PC_BN_BWD_APPLY, 0, (double)M * C * c->es * (3 + (mask2 ? 1 : 0)), s);
   return launch_bn_bwd_apply(c->dtype, g2, mask2, l.y, l.stat, l.stat + C, c->bn_coef, dx, M, C, s);
 }
 
@@ -237,7 +239,7 @@ int conv_wgrad(mi355_ctx* c, ConvBN& l, const void* dy, const void* x, float bet
   const size_t n = (size_t)l.Cout * l.K * l.K * l.Cin;
   const double by = ((double)c->N * l.Hin * l.Win * l.Cin + (double)c->N * l.Hout * l.Wout * l.Cout) * c->es;
   {
-    Prof p(c, PC_CONV_WGRAD, conv_flops(c, l), by, s);
+    Prof p(c, wgrad_class(l.Cout), conv_flops(c, l), by, s);
     MI355_TRY(launch_wgrad(c->dtype, a, l.splits, s));
   }
   return launch_splitk_reduce(c->wg_partial, l.splits, n, c->grads + l.w_off, n, beta_acc, s);
@@ -249,7 +251,7 @@ int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* ad
   if (nclass < 0) return nclass;
   a.in = dy; a.wt = l.w_tr; a.out = dx; a.addend = addend;
   const double by = ((double)c->N * l.Hin * l.Win * l.Cin * (addend ? 2 : 1) + (double)c->N * l.Hout * l.Wout * l.Cout) * c->es;
-  Prof p(c, PC_CONV_DGRAD, conv_flops(c, l), by, s);
+  Prof p(c, igemm_class(l.Cin), conv_flops(c, l), by, s);
   return launch_igemm(c->dtype, a, nclass, s);
 }
 
@@ -390,7 +392,7 @@ int backward_stem(mi355_ctx* c, float beta_acc, hipStream_t s) {
   build_stem_wgrad_args(a, c->N, c->H, c->W);
   a.dy = B1; a.x = c->xpad; a.partial = c->wg_partial;
   {
-    Prof p(c, PC_CONV_WGRAD, conv_flops(c, l), 0, s);
+    Prof p(c, PC_WGRAD64, conv_flops(c, l), 0, s);
     MI355_TRY(launch_wgrad(c->dtype, a, l.splits, s));
   }
   return launch_stem_unpack(c->wg_partial, l.splits, c->grads + l.w_off, beta_acc, s);
@@ -406,7 +408,7 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
   MI355_ARG(N >= 1 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0, "create: N=%d H=%d W=%d (H,W multiples of 32)",
             N, H, W);
   MI355_ARG(num_classes >= 1 && num_classes <= 65536, "create: num_classes=%d", num_classes);
-  MI355_HIP(hipSetDevice(device));
+  if (device >= 0) MI355_HIP(hipSetDevice(device));
   mi355_ctx* c = new mi355_ctx();
   c->device = device; c->dtype = dtype; c->N = N; c->H = H; c->W = W; c->num_classes = num_classes;
   c->fc_pad = (int)align_up((size_t)num_classes, 128);
@@ -474,6 +476,10 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
   Arena ar;
   plan_arena(c, ar);
   c->arena_bytes = ar.size;
+  if (device < 0) {  // layout-only ctx: parameter table / sizes / FLOPs, no device memory
+    *out = c;
+    return 0;
+  }
   hipError_t e = hipMalloc((void**)&c->arena, ar.size);
   if (e != hipSuccess) {
     set_error("create: hipMalloc(%zu bytes) -> %s", ar.size, hipGetErrorString(e));
@@ -500,7 +506,7 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
 
 int mi355_resnet50_destroy(mi355_ctx* c) {
   if (!c) return 0;
-  (void)hipSetDevice(c->device);
+  if (c->device >= 0) (void)hipSetDevice(c->device);
   for (auto e : c->ev) (void)hipEventDestroy(e);
   if (c->arena) (void)hipFree(c->arena);
   delete c;
@@ -531,6 +537,10 @@ size_t mi355_resnet50_workspace_bytes(const mi355_ctx* c) { return c ? c->arena_
 
 int mi355_resnet50_bind(mi355_ctx* c, float* params, float* grads, float* buffers) {
   MI355_ARG(c && params && buffers, "bind: null pointer");
+  if (c->device < 0) {
+    set_error("bind: layout-only ctx (created with device < 0)");
+    return MI355_E_STATE;
+  }
   MI355_ARG(((uintptr_t)params % 256 == 0) && ((uintptr_t)buffers % 256 == 0) && ((uintptr_t)grads % 256 == 0),
             "bind: flat arrays must be 256-byte aligned");
   c->params = params; c->grads = grads; c->buffers = buffers;
@@ -557,7 +567,7 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
     IgemmArgs a;
     build_stem_fwd_args(a, N, c->H, c->W);
     a.in = c->xpad; a.wt = c->stem_pack; a.out = c->stem.y;
-    Prof p(c, PC_CONV_FWD, conv_flops(c, c->stem), 0, s);
+    Prof p(c, PC_IGEMM64, conv_flops(c, c->stem), 0, s);
     MI355_TRY(launch_igemm(c->dtype, a, 1, s));
   }
   MI355_TRY(bn_prepare(c, c->stem, training, bn_momentum, s));
@@ -647,6 +657,49 @@ int mi355_resnet50_backward(mi355_ctx* c, const float* dlogits, int seg_begin, i
   }
   if (c->next_seg == nseg) c->fwd_training_done = false;
   return 0;
+}
+
+int mi355_resnet50_debug_tensor(const mi355_ctx* c, const char* name, void** ptr, int* dtype, int* ndim,
+                                int shape[4]) {
+  MI355_ARG(c && name && ptr && dtype && ndim && shape, "debug_tensor: null argument");
+  const std::string n(name);
+  auto set4 = [&](void* p, int dt, int h, int w, int ch) {
+    *ptr = p; *dtype = dt; *ndim = 4;
+    shape[0] = c->N; shape[1] = h; shape[2] = w; shape[3] = ch;
+    return 0;
+  };
+  auto set1 = [&](void* p, int len) {
+    *ptr = p; *dtype = MI355_F32; *ndim = 1;
+    shape[0] = len; shape[1] = shape[2] = shape[3] = 0;
+    return 0;
+  };
+  auto conv_match = [&](const ConvBN& l) -> int {
+    if (n == l.conv_name + ".y") return set4(l.y, c->dtype, l.Hout, l.Wout, l.Cout);
+    if (n == l.bn_name + ".save_mean") return set1(l.stat, l.Cout);
+    if (n == l.bn_name + ".save_invstd") return set1(l.stat + l.Cout, l.Cout);
+    return 1;
+  };
+  if (conv_match(c->stem) == 0) return 0;
+  if (n == "stem.a0") return set4(c->a0, c->dtype, c->stem.Hout, c->stem.Wout, 64);
+  if (n == "stem.p0") return set4(c->p0, c->dtype, c->stem.Hout / 2, c->stem.Wout / 2, 64);
+  for (const auto& b : c->blocks) {
+    if (conv_match(b.c1) == 0 || conv_match(b.c2) == 0 || conv_match(b.c3) == 0) return 0;
+    if (b.has_ds && conv_match(b.ds) == 0) return 0;
+    const std::string pre = b.c1.conv_name.substr(0, b.c1.conv_name.size() - 5);  // strip "conv1"
+    if (n == pre + "a1") return set4(b.a1, c->dtype, b.c1.Hout, b.c1.Wout, b.c1.Cout);
+    if (n == pre + "a2") return set4(b.a2, c->dtype, b.c2.Hout, b.c2.Wout, b.c2.Cout);
+    if (n == pre + "out") return set4(b.out, c->dtype, b.Hout, b.Wout, b.Cout);
+  }
+  const Block& last = c->blocks.back();
+  if (n == "pooled" || n == "dpooled") {
+    *ptr = n == "pooled" ? c->pooled : c->dpooled; *dtype = MI355_F32; *ndim = 2;
+    shape[0] = c->N; shape[1] = 2048; shape[2] = shape[3] = 0;
+    return 0;
+  }
+  for (int i = 0; i < 4; ++i)
+    if (n == "gbuf" + std::to_string(i)) return set4(c->gbuf[i], c->dtype, last.Hout, last.Wout, last.Cout);
+  set_error("debug_tensor: unknown tensor '%s'", name);
+  return MI355_E_ARG;
 }
 
 int mi355_resnet50_flops(const mi355_ctx* c, double* fwd, double* train) {

@@ -1,0 +1,338 @@
+"""`resnet50` plugin: a torch.nn.Module facade over the native MI355X executor (csrc/resnet_exec.cpp).
+
+Drop-in for the reference's model plugin call `hydra.utils.call(cfg.model)` with
+`_target_: pytorch_tools.models.resnet50` (train.py:64; configs/hydra_exp/1.r50_baseline.yaml:22-23):
+callable `(data NCHW fp32) -> logits`, `.cuda()`, `.parameters()`, `.state_dict()` /
+`.load_state_dict(strict=False)` with torchvision names and shapes (train.py:73,86,101,184), `.modules()`
+walk with BatchNorm-like `.momentum` (train.py:76 -> patch_bn_mom), `.train()/.eval()`.
+
+All 161 parameters are views into ONE flat fp32 buffer (gradients likewise), laid out by the native library
+in reverse execution order so DDP buckets complete front to back; conv weights are torch `[Cout,Cin,KH,KW]`
+tensors in channels_last memory (= the KRSC layout the kernels read).  Nothing here computes: forward and
+backward are single C-ABI calls; without the HIP library / a GPU they raise.
+"""
+import ctypes
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import native
+from .native import check, ptr
+
+_DTYPES = {
+    None: torch.float32, "fp32": torch.float32, "float32": torch.float32, "f32": torch.float32,
+    "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
+    torch.float32: torch.float32, torch.bfloat16: torch.bfloat16,
+}
+
+
+class _Leaf(nn.Module):
+    """container node giving parameters their torchvision names (conv1, bn1, layer1.0.conv1, ...)"""
+
+
+class _BNLeaf(_Leaf):
+    """BatchNorm-like leaf: carries `.momentum` / `.eps` so pt.utils.misc.patch_bn_mom (train.py:76) has something to patch."""
+
+    def __init__(self):
+        super().__init__()
+        self.momentum = 0.1
+        self.eps = 1e-5
+
+
+def _layout(dtype_code, N, H, W, num_classes):
+    """tensor table of the native executor: [(name, kind, offset, shape)], sizes, segment ranges (no GPU needed)."""
+    L = native.lib()
+    ctx = ctypes.c_void_p()
+    check(L.mi355_resnet50_create(ctypes.byref(ctx), -1, dtype_code, N, H, W, num_classes))
+    try:
+        table = []
+        for i in range(L.mi355_resnet50_num_tensors(ctx)):
+            name = ctypes.create_string_buffer(128)
+            kind, off, nd, sh = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_int(), (ctypes.c_int * 4)()
+            check(L.mi355_resnet50_tensor_info(ctx, i, name, 128, ctypes.byref(kind), ctypes.byref(off), ctypes.byref(nd), sh))
+            table.append((name.value.decode(), kind.value, off.value, tuple(sh[j] for j in range(nd.value))))
+        segs = []
+        for s in range(L.mi355_resnet50_num_segments(ctx)):
+            b, e = ctypes.c_size_t(), ctypes.c_size_t()
+            check(L.mi355_resnet50_segment_range(ctx, s, ctypes.byref(b), ctypes.byref(e)))
+            segs.append((b.value, e.value))
+        return table, L.mi355_resnet50_flat_param_elems(ctx), L.mi355_resnet50_flat_buffer_elems(ctx), segs
+    finally:
+        L.mi355_resnet50_destroy(ctx)
+
+
+class _ResNetFn(torch.autograd.Function):
+    """autograd bridge so reference-style `loss.backward()` (callbacks.py:317) drives the native backward."""
+
+    @staticmethod
+    def forward(ctx, x, hook, model):
+        ctx.model = model
+        return model._native_forward(x, training=True)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.model._native_backward(dlogits)
+        return None, None, None
+
+
+class ResNet50(nn.Module):
+    def __init__(self, num_classes=1000, dtype=None, pretrained=None, **unsupported):
+        super().__init__()
+        if pretrained:
+            raise ValueError("pretrained weights are not available offline")
+        # architecture kwargs of pytorch_tools.models.resnet50 that would change the graph are rejected loudly
+        for k, v in unsupported.items():
+            if v not in (None, False, "", 0, 0.0, "relu", "abn"):
+                raise NotImplementedError(f"resnet50({k}={v!r}) is outside the MI355X hot path (SURVEY.md §8f)")
+        self.num_classes = int(num_classes)
+        self.compute_dtype = _DTYPES[dtype]
+        self._dt = native.dtype_code(self.compute_dtype)
+        table, self._nparam, self._nbuf, self._segments = _layout(self._dt, 1, 32, 32, self.num_classes)
+        self._table = table
+        self._flat_params = torch.zeros(self._nparam, dtype=torch.float32)
+        self._flat_grads = torch.zeros(self._nparam, dtype=torch.float32)
+        self._flat_buffers = torch.zeros(self._nbuf, dtype=torch.float32)
+        self._hook = torch.zeros(1, requires_grad=True)  # gives autograd an edge into _ResNetFn
+        self._ctxs = OrderedDict()  # (N,H,W) -> native ctx
+        self._grads_dirty = False
+        self._grad_sync = None  # set by parallel.FlatBucketDDP: callable(segment, begin, end)
+        self._bn_leaves = []
+        self._build_modules()
+        self._rebind_views()
+        self.reset_parameters()
+
+    # ---- module tree with torchvision names --------------------------------------------------------------
+    def _canonical_order(self):
+        """torchvision registration order: conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var."""
+        by_name = {t[0]: t for t in self._table}
+        convs = [n[: -len(".weight")] for n, k, _, sh in self._table if k == 0 and len(sh) == 4]
+        order = []
+
+        def convbn(conv, bn):
+            order.append(by_name[conv + ".weight"])
+            for suffix in ("weight", "bias", "running_mean", "running_var"):
+                order.append(by_name[f"{bn}.{suffix}"])
+
+        convbn("conv1", "bn1")
+        blocks = sorted({c.rsplit(".", 1)[0] for c in convs if c.startswith("layer") and "downsample" not in c},
+                        key=lambda s: (int(s[5]), int(s.split(".")[1])))
+        for b in blocks:
+            for i in (1, 2, 3):
+                convbn(f"{b}.conv{i}", f"{b}.bn{i}")
+            if f"{b}.downsample.0.weight" in by_name:
+                convbn(f"{b}.downsample.0", f"{b}.downsample.1")
+        order.append(by_name["fc.weight"])
+        order.append(by_name["fc.bias"])
+        assert len(order) == len(self._table)
+        return order
+
+    def _leaf(self, dotted, bn=False):
+        node = self
+        parts = dotted.split(".")
+        for i, p in enumerate(parts):
+            if p not in node._modules:
+                last = i == len(parts) - 1
+                node.add_module(p, _BNLeaf() if (bn and last) else _Leaf())
+            node = node._modules[p]
+        return node
+
+    def _build_modules(self):
+        self._entries = []  # (leaf, attr, kind, offset, shape)
+        for name, kind, off, shape in self._canonical_order():
+            mod, attr = name.rsplit(".", 1)
+            is_bn = kind == 1 or (len(shape) == 1 and not mod.startswith("fc"))
+            leaf = self._leaf(mod, bn=is_bn)
+            if is_bn and leaf not in self._bn_leaves:
+                self._bn_leaves.append(leaf)
+            self._entries.append((leaf, attr, kind, off, shape))
+            (leaf._parameters if kind == 0 else leaf._buffers)[attr] = None  # fixes the registration order
+        for leaf in self._bn_leaves:
+            leaf.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.int64))
+
+    @staticmethod
+    def _view(flat, off, shape):
+        n = 1
+        for s in shape:
+            n *= s
+        v = flat[off: off + n]
+        if len(shape) == 4:  # torch OIHW logical shape over KRSC memory (channels_last)
+            co, ci, kh, kw = shape
+            return v.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return v.view(*shape)
+
+    def _rebind_views(self):
+        """(re)creates every Parameter / buffer as a view of the flat arrays (after construction or a device move)."""
+        for leaf, attr, kind, off, shape in self._entries:
+            if kind == 0:
+                p = nn.Parameter(self._view(self._flat_params, off, shape), requires_grad=True)
+                p.grad = self._view(self._flat_grads, off, shape)
+                leaf._parameters[attr] = p
+            else:
+                leaf._buffers[attr] = self._view(self._flat_buffers, off, shape)
+
+    def _attach_grads(self):
+        for leaf, attr, kind, off, shape in self._entries:
+            if kind == 0:
+                p = leaf._parameters[attr]
+                if p.grad is None or p.grad.data_ptr() != self._flat_grads.data_ptr() + off * 4:
+                    p.grad = self._view(self._flat_grads, off, shape)
+
+    def _apply(self, fn, recurse=True):
+        # move the flat arrays, then re-create the views; native contexts belong to the old device
+        self._destroy_ctxs()
+        self._flat_params = fn(self._flat_params)
+        self._flat_grads = fn(self._flat_grads)
+        self._flat_buffers = fn(self._flat_buffers)
+        self._hook = fn(self._hook.detach()).requires_grad_(True)
+        for leaf in self._bn_leaves:
+            leaf._buffers["num_batches_tracked"] = fn(leaf._buffers["num_batches_tracked"])
+        if self._flat_params.dtype != torch.float32:
+            raise TypeError("master parameters stay fp32; choose the compute dtype with resnet50(dtype='bf16')")
+        self._rebind_views()
+        return self
+
+    def reset_parameters(self, seed=0, gamma=1.72):
+        from .synth import init_state_dict
+
+        shapes = [(f"{self._name_of(leaf)}.{attr}", shape) for leaf, attr, kind, off, shape in self._entries]
+        sd = init_state_dict(shapes, seed=seed, gamma=gamma)
+        with torch.no_grad():
+            for (leaf, attr, kind, off, shape), (name, _) in zip(self._entries, shapes):
+                tgt = leaf._parameters[attr] if kind == 0 else leaf._buffers[attr]
+                tgt.copy_(sd[name].to(tgt.device))
+
+    def _name_of(self, leaf):
+        for n, m in self.named_modules():
+            if m is leaf:
+                return n
+        raise KeyError
+
+    # ---- flat access (optimizer / DDP) ---------------------------------------------------------------------
+    @property
+    def flat_params(self):
+        return self._flat_params
+
+    @property
+    def flat_grads(self):
+        return self._flat_grads
+
+    @property
+    def grad_segments(self):
+        """[(begin, end)] element ranges of the flat gradient array, in backward completion order."""
+        return list(self._segments)
+
+    def mark_grads_clean(self):
+        """the next backward overwrites the flat gradients instead of accumulating (optimizer.zero_grad())."""
+        self._grads_dirty = False
+
+    # ---- native contexts -------------------------------------------------------------------------------------
+    def _destroy_ctxs(self):
+        if self._ctxs:
+            L = native.lib()
+            for c in self._ctxs.values():
+                L.mi355_resnet50_destroy(c)
+            self._ctxs.clear()
+
+    def __del__(self):
+        try:
+            self._destroy_ctxs()
+        except Exception:
+            pass
+
+    def _ctx(self, N, H, W):
+        key = (N, H, W)
+        c = self._ctxs.get(key)
+        if c is None:
+            if not self._flat_params.is_cuda:
+                raise RuntimeError("resnet50: the MI355X hot path has no CPU fallback — call .cuda() first")
+            if len(self._ctxs) >= 3:  # progressive resize / val batch: keep the 3 most recent shapes
+                _, old = self._ctxs.popitem(last=False)
+                native.lib().mi355_resnet50_destroy(old)
+            L = native.lib()
+            c = ctypes.c_void_p()
+            dev = self._flat_params.device.index or 0
+            check(L.mi355_resnet50_create(ctypes.byref(c), dev, self._dt, N, H, W, self.num_classes))
+            check(L.mi355_resnet50_bind(c, ptr(self._flat_params), ptr(self._flat_grads), ptr(self._flat_buffers)))
+            self._ctxs[key] = c
+        else:
+            self._ctxs.move_to_end(key)
+        return c
+
+    def bn_momentum(self):
+        return float(self._bn_leaves[0].momentum) if self._bn_leaves else 0.1
+
+    def _native_forward(self, x, training):
+        if not x.is_cuda:
+            raise RuntimeError("resnet50: the MI355X hot path has no CPU fallback — move the model and the batch to CUDA")
+        if not (x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3):
+            raise ValueError("resnet50 expects a CUDA float32 NCHW batch [N,3,H,W] (dali_dataloader.py:113-122 contract)")
+        x = x.contiguous()
+        N, _, H, W = x.shape
+        c = self._ctx(N, H, W)
+        logits = torch.empty((N, self.num_classes), dtype=torch.float32, device=x.device)
+        check(native.lib().mi355_resnet50_forward(c, ptr(x), ptr(logits), int(training), self.bn_momentum(), native.cur_stream()))
+        self._last = (c, x)  # keep the input alive until backward
+        if training:
+            for leaf in self._bn_leaves:
+                leaf._buffers["num_batches_tracked"] += 1
+        return logits
+
+    def _native_backward(self, dlogits):
+        c, _ = self._last
+        L = native.lib()
+        dlogits = dlogits.contiguous()
+        self._attach_grads()
+        acc = int(self._grads_dirty)
+        nseg = len(self._segments)
+        if self._grad_sync is None:
+            check(L.mi355_resnet50_backward(c, ptr(dlogits), 0, nseg, acc, native.cur_stream()))
+        else:
+            for s in range(nseg):
+                check(L.mi355_resnet50_backward(c, ptr(dlogits), s, s + 1, acc, native.cur_stream()))
+                self._grad_sync(s, *self._segments[s])
+        self._grads_dirty = True
+
+    def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            return _ResNetFn.apply(x, self._hook, self)
+        return self._native_forward(x, training=self.training)
+
+    def flops(self, N, H, W):
+        """(forward, training) algorithmic FLOPs of one step at this shape (2 FLOP/MAC, conv + FC)."""
+        L = native.lib()
+        ctx = ctypes.c_void_p()
+        check(L.mi355_resnet50_create(ctypes.byref(ctx), -1, self._dt, N, H, W, self.num_classes))
+        f, t = ctypes.c_double(), ctypes.c_double()
+        check(L.mi355_resnet50_flops(ctx, ctypes.byref(f), ctypes.byref(t)))
+        L.mi355_resnet50_destroy(ctx)
+        return f.value, t.value
+
+    def debug_tensor(self, shape, name):
+        """copy of an internal tensor of the last step at batch shape (N,H,W) — test hook (mi355_resnet50_debug_tensor)."""
+        L = native.lib()
+        p, dt, nd, sh = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int(), (ctypes.c_int * 4)()
+        check(L.mi355_resnet50_debug_tensor(self._ctx(*shape), name.encode(), ctypes.byref(p), ctypes.byref(dt), ctypes.byref(nd), sh))
+        dims = [sh[i] for i in range(nd.value)]
+        out = torch.empty(dims, dtype=torch.float32 if dt.value == native.F32 else torch.bfloat16, device=self._flat_params.device)
+        torch.cuda.synchronize()
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        rc = hip.hipMemcpy(ctypes.c_void_p(out.data_ptr()), p, out.numel() * out.element_size(), 3)
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpy failed ({rc})")
+        return out
+
+    # profiling passthrough (bench.py)
+    def profile(self, shape, class_mask):
+        check(native.lib().mi355_resnet50_profile(self._ctx(*shape), int(class_mask)))
+
+    def profile_read(self, shape, kind):
+        ms, n, fl, by = ctypes.c_double(), ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+        check(native.lib().mi355_resnet50_profile_read(self._ctx(*shape), kind, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by)))
+        return ms.value, n.value, fl.value, by.value
+
+
+def resnet50(**kwargs):
+    """plugin entry point — same name as the reference's `_target_: pytorch_tools.models.resnet50`."""
+    return ResNet50(**kwargs)

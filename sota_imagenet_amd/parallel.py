@@ -1,0 +1,90 @@
+"""Data parallelism for the flat-buffer model: bucketed gradient all-reduce over RCCL/xGMI on a side HIP stream.
+
+Replaces `torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])` at the reference's train.py:113-114
+(process group from train.py:58-61, `init_process_group("nccl", "env://")` — on ROCm that backend IS RCCL).
+What DDP does there, restated for one flat gradient array laid out in backward-completion order:
+  * construction: rank-0 parameters and BN buffers are broadcast once (C2 of SURVEY §2.3);
+  * backward: the native executor reports every finished segment (fc, then block by block, then the stem);
+    consecutive segments form buckets of >= `bucket_cap_mb`; when a bucket's last segment has been ENQUEUED, an event
+    is recorded on the compute stream, the side stream waits on it and issues ONE all-reduce (mean) over the bucket's
+    contiguous slice — so the collective overlaps the rest of backward (C3);
+  * after the last bucket the compute stream waits for the side stream, so optimizer.step() sees reduced gradients.
+BN running statistics stay rank-local (the reference's per-forward buffer broadcast, C4, is dropped on purpose: it
+does not influence training; rank 0's buffers are the ones checkpointed).
+xGMI is point-to-point (7 links/GPU): few large buckets keep each ring step per-link efficient.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def plan_buckets(segments, cap_elems):
+    """[(begin, end)] per backward segment -> [(begin, end, last_segment_index)] buckets of >= cap_elems elements."""
+    buckets = []
+    start = None
+    for i, (b, e) in enumerate(segments):
+        if start is None:
+            start = b
+        if e - start >= cap_elems or i == len(segments) - 1:
+            buckets.append((start, e, i))
+            start = None
+    return buckets
+
+
+class FlatBucketDDP(nn.Module):
+    def __init__(self, module, device_ids=None, bucket_cap_mb=32.0, process_group=None, broadcast=True):
+        super().__init__()
+        if not dist.is_initialized():
+            raise RuntimeError("FlatBucketDDP needs torch.distributed.init_process_group first (train.py:61)")
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        flat = module.flat_grads
+        self._cuda = flat.is_cuda
+        self._buckets = plan_buckets(module.grad_segments, int(bucket_cap_mb * (1 << 20) / 4))
+        self._by_last = {last: (b, e) for b, e, last in self._buckets}
+        self._nseg = len(module.grad_segments)
+        self._side = torch.cuda.Stream(device=flat.device) if self._cuda else None
+        backend = dist.get_backend(process_group)
+        self._avg = backend == "nccl"  # ReduceOp.AVG is an (R)CCL op; gloo sums and we scale
+        if broadcast:
+            self.broadcast_state()
+        module._grad_sync = self._on_segment
+
+    # ---- C2: rank 0 -> everyone, once ----------------------------------------------------------------------
+    def broadcast_state(self):
+        with torch.no_grad():
+            dist.broadcast(self.module.flat_params, 0, group=self.group)
+            bufs = getattr(self.module, "_flat_buffers", None)
+            if bufs is not None:
+                dist.broadcast(bufs, 0, group=self.group)
+
+    @property
+    def buckets(self):
+        return list(self._buckets)
+
+    # ---- C3: called by the model's backward right after a segment's kernels were enqueued ---------------------
+    def _on_segment(self, seg, begin, end):
+        rng = self._by_last.get(seg)
+        if rng is not None:
+            view = self.module.flat_grads[rng[0]: rng[1]]
+            if self._cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(ev)
+                    self._reduce(view)
+            else:
+                self._reduce(view)
+        if seg == self._nseg - 1 and self._cuda:
+            torch.cuda.current_stream().wait_stream(self._side)
+
+    def _reduce(self, view):
+        if self._avg:
+            dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            view.div_(self.world)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)

@@ -1,0 +1,66 @@
+"""Host-side (no GPU) checks of the model plugin: torchvision names/shapes/order, parameter count, flat aliasing."""
+import torch
+
+from oracle.resnet50_ref import ResNet50Ref
+from sota_imagenet_amd.models import resnet50
+
+
+def test_state_dict_matches_torchvision_layout():
+    m = resnet50()
+    ref = ResNet50Ref()
+    sd, rsd = m.state_dict(), ref.state_dict()
+    assert list(sd.keys()) == list(rsd.keys())
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(rsd[k].shape), k
+    # "25.56M" — configs/hydra_exp/1.r50_baseline.yaml:11
+    assert sum(p.numel() for p in m.parameters()) == 25_557_032
+    assert len(list(m.parameters())) == 161
+
+
+def test_parameters_alias_flat_buffer_and_roundtrip():
+    m = resnet50()
+    ref = ResNet50Ref()
+    m.load_state_dict(ref.state_dict(), strict=False)  # train.py:101 uses strict=False
+    for k, v in m.state_dict().items():
+        assert torch.equal(v.float(), ref.state_dict()[k].float()), k
+    base = m.flat_params.data_ptr()
+    n = m.flat_params.numel() * 4
+    for p in m.parameters():
+        assert base <= p.data_ptr() < base + n
+        assert p.grad is not None and p.grad.shape == p.shape
+    # conv weights are KRSC in memory (channels_last strides)
+    w = m.layer1[0].conv2.weight if hasattr(m, "layer1") and isinstance(m.layer1, list) else dict(m.named_parameters())["layer1.0.conv2.weight"]
+    assert w.shape == (64, 64, 3, 3) and w.stride() == (576, 1, 192, 64)
+    # writes through a parameter land in the flat array
+    with torch.no_grad():
+        dict(m.named_parameters())["fc.bias"].fill_(3.0)
+    assert (m.flat_params == 3.0).sum().item() == 1000
+
+
+def test_grad_segments_cover_flat_array_in_backward_order():
+    m = resnet50()
+    segs = m.grad_segments
+    assert len(segs) == 18 and segs[0][0] == 0
+    for (b0, e0), (b1, e1) in zip(segs, segs[1:]):
+        assert e0 == b1 and e0 > b0
+    assert segs[-1][1] == m.flat_grads.numel()
+
+
+def test_bn_leaves_expose_momentum_for_patch_bn_mom():
+    m = resnet50()
+    n = 0
+    for mod in m.modules():  # what pt.utils.misc.patch_bn_mom (train.py:76) walks
+        if hasattr(mod, "momentum") and hasattr(mod, "running_mean"):
+            mod.momentum = 0.05
+            n += 1
+    assert n == 53 and abs(m.bn_momentum() - 0.05) < 1e-12
+
+
+def test_cpu_forward_fails_loudly():
+    import pytest
+
+    m = resnet50()
+    with pytest.raises(RuntimeError, match="no CPU fallback|CUDA"):
+        m.eval()(torch.zeros(1, 3, 32, 32))
+    with pytest.raises((RuntimeError, ValueError)):
+        m.train()(torch.zeros(1, 3, 32, 32))
