@@ -80,7 +80,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_ddp = world > 1 or os.environ.get("BENCH_FORCE_DDP") == "1"  # the latter: 1-rank rehearsal of the RCCL path
+    if use_ddp:
         import torch.distributed as dist
 
         dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
@@ -97,7 +98,7 @@ def main():
     opt = SGD([{"params": list(model.parameters())}], lr=0.0, momentum=0.9, weight_decay=3e-5)
     opt.attach_model(model)
     net = model
-    if world > 1:
+    if use_ddp:
         from sota_imagenet_amd.parallel import FlatBucketDDP
 
         net = FlatBucketDDP(model, device_ids=[local_rank])
@@ -116,7 +117,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if use_ddp:
             import torch.distributed as dist
 
             dist.barrier()
@@ -134,7 +135,7 @@ def main():
         loss = step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_ddp:
         import torch.distributed as dist
 
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -176,7 +177,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_ddp:
         import torch.distributed as dist
 
         dist.barrier()

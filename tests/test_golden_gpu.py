@@ -1,0 +1,105 @@
+"""The native path against the COMMITTED fixtures (tests/golden/*.npz) — no oracle code runs in these tests."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from sota_imagenet_amd.synth import synthetic_batch, uniform_tensor
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+spec = importlib.util.spec_from_file_location("make_golden_consts", os.path.join(HERE, "golden", "make_golden.py"))
+OPS = np.load(os.path.join(HERE, "golden", "ops_small.npz"))
+NET = np.load(os.path.join(HERE, "golden", "resnet50_small.npz"))
+STRIDE = 7
+CONV_CASES = [("c1x1", 2, 8, 8, 64, 64, 1, 1), ("c3x3", 2, 8, 8, 64, 128, 3, 1), ("c3x3s2", 2, 8, 8, 128, 64, 3, 2), ("c1x1s2", 1, 8, 8, 64, 128, 1, 2)]
+
+
+def close(name, t, tol, G=OPS):
+    a = t.detach().float().cpu().numpy()
+    g = G[name]
+    if name + "__abs_sum" in G.files:
+        a = a.reshape(-1)[::STRIDE]
+    assert a.shape == g.shape, (name, a.shape, g.shape)
+    err = np.abs(a.astype(np.float64) - g).max() / max(np.abs(g).max(), 1e-30)
+    assert err <= tol, (name, err)
+
+
+def test_conv_golden(dev):
+    from sota_imagenet_amd import ops
+
+    for name, N, H, W, Cin, Cout, K, s in CONV_CASES:
+        x = uniform_tensor((N, H, W, Cin), 1.0, 101).to(dev)
+        w = uniform_tensor((Cout, K, K, Cin), 0.1, 102).to(dev)
+        Ho = (H + 2 * (K // 2) - K) // s + 1
+        dy = uniform_tensor((N, Ho, Ho, Cout), 1.0, 103).to(dev)
+        close(name + "_y", ops.conv2d_fwd(x, w, s, K // 2), 2e-5)
+        close(name + "_dx", ops.conv2d_dgrad(dy, w, (N, H, W, Cin), s, K // 2), 2e-5)
+        close(name + "_dw", ops.conv2d_wgrad(dy, x, K, K, s, K // 2), 2e-5)
+
+
+def test_ce_sgd_golden(dev):
+    from sota_imagenet_amd import ops
+
+    logits = uniform_tensor((5, 1000), 6.0, 131).to(dev)
+    lab = torch.tensor([3, 999, 0, 512, 77])
+    onehot = torch.nn.functional.one_hot(lab, 1000).float()
+    soft = 0.7 * onehot + 0.3 * torch.nn.functional.one_hot((lab + 11) % 1000, 1000).float()
+    for nm, t in (("hard", onehot), ("soft", soft)):
+        for s in (0.0, 0.1):
+            loss, dl = ops.ce_loss(logits, t.to(dev), s)
+            assert abs(loss.item() - float(OPS[f"ce_{nm}_{s}_loss"])) < 1e-5
+            close(f"ce_{nm}_{s}_dl", dl, 1e-5)
+    p = uniform_tensor((1003,), 1.0, 141).to(dev)
+    m = torch.zeros_like(p)
+    for i in range(3):
+        ops.sgd_step(p, uniform_tensor((1003,), 1.0, 142 + i).to(dev), m, 0.1, 0.9, 3e-5)
+    close("sgd_p", p, 1e-6)
+    close("sgd_m", m, 1e-6)
+
+
+@pytest.mark.parametrize("S", [64, 224])
+def test_resnet50_logits_golden(dev, S):
+    from sota_imagenet_amd.losses import CrossEntropyLoss
+    from sota_imagenet_amd.models import resnet50
+
+    m = resnet50(dtype="fp32").cuda()  # resnet50() initialises from the same seeded generator as the fixture
+    m.train()
+    data, target = synthetic_batch(2, S, seed=0, index=3)
+    logits = m(data.cuda())
+    loss = CrossEntropyLoss(smoothing=0.1)(logits, target.cuda())
+    loss.backward()
+    close(f"logits_{S}", logits, 1e-3, NET)  # north_star: fp32 logits within 1e-3 rel of the CPU forward
+    assert abs(loss.item() - float(NET[f"loss_{S}"])) < 1e-4 * float(NET[f"loss_{S}"])
+    close(f"bn1_running_var_{S}", dict(m.named_buffers())["bn1.running_var"], 1e-4, NET)
+    close(f"fc_weight_grad_{S}", dict(m.named_parameters())["fc.weight"].grad[:8, :64], 1e-3, NET)
+
+
+def test_loss_curve_golden(dev):
+    """same seeds / schedule as make_golden.CURVE; the fp64-vs-fp32 gap of the stored oracle curves is the yardstick."""
+    from sota_imagenet_amd.losses import CrossEntropyLoss
+    from sota_imagenet_amd.models import resnet50
+    from sota_imagenet_amd.optim import SGD
+
+    l32, l64, lrs = NET["curve_fp32"], NET["curve_fp64"], NET["curve_lrs"]
+    m = resnet50(dtype="fp32").cuda()
+    crit = CrossEntropyLoss(smoothing=0.1)
+    opt = SGD([{"params": list(m.parameters())}], lr=0.0, momentum=0.9, weight_decay=3e-5)
+    opt.attach_model(m)
+    m.train()
+    losses = []
+    for i, lr in enumerate(lrs):
+        data, target = synthetic_batch(8, 64, seed=0, index=i)
+        for g in opt.param_groups:
+            g["lr"] = float(lr)
+        loss = crit(m(data.cuda()), target.cuda())
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert abs(losses[0] - l64[0]) < 1e-5 * l64[0]
+    for i in range(len(lrs)):
+        yard = abs(l32[i] - l64[i]) / l64[i]
+        assert abs(losses[i] - l64[i]) / l64[i] < 3 * yard + 2e-3 * (1 + i), (i, losses, l32.tolist(), l64.tolist())

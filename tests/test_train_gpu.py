@@ -1,0 +1,72 @@
+"""End-to-end drop-in surface on the GPU: train.py with a YAML config (Runner + callbacks + synthetic loader + native
+model / loss / optimizer), evaluate-only + resume in the reference's checkpoint format, and the RCCL gradient path."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_train_py_runs_the_smoke_config(dev, tmp_path):
+    sys.path.insert(0, ROOT)
+    import train
+
+    logdir = os.path.relpath(str(tmp_path), ROOT)
+    val_loss, metrics = train.main(["+hydra_exp=test", f"log.dir={logdir}", "run.fp16=false", "random_seed=0",
+                                    "data.pool=2", "log.save_optim=true"])
+    assert val_loss == val_loss and 0.0 <= metrics["Acc@1"].avg <= 100.0 and metrics["Acc@5"].avg >= metrics["Acc@1"].avg
+    run = glob.glob(os.path.join(str(tmp_path), "*_test", "*"))[0]
+    logs = open(os.path.join(run, "logs.txt")).read()
+    assert "Train loss:" in logs and "Acc@1:" in logs and "Model params: 25.56M" in logs  # line formats of the reference
+    ck = torch.load(os.path.join(run, "model.chpn"), map_location="cpu")
+    assert {"epoch", "state_dict", "optimizer"} <= set(ck) and "layer4.2.bn3.running_var" in ck["state_dict"]
+    last = torch.load(os.path.join(run, "model_last.chpn"), map_location="cpu")
+    assert last["conv1.weight"].shape == (64, 3, 7, 7)
+    # evaluate-only from the checkpoint (train.py:158-162) in bf16 this time
+    loss2, m2 = train.main(["+hydra_exp=test", f"log.dir={logdir}", f"run.resume={os.path.join(run, 'model.chpn')}",
+                            "run.evaluate=true", "data.pool=2"])
+    assert loss2 == loss2 and 0.0 <= m2["Acc@1"].avg <= 100.0
+
+
+def test_legacy_config_and_wd_filter_param_groups(dev, tmp_path):
+    """legacy flat schema + `filter_from_wd` (train.py:83-86): BN / bias parameters land in a wd-0 group and the fused
+    optimizer must not touch them with weight decay."""
+    from sota_imagenet_amd.models import resnet50
+    from sota_imagenet_amd.optim import SGD
+
+    sys.path.insert(0, ROOT)
+    import train
+
+    m = resnet50(dtype="fp32").cuda()
+    groups = train.filter_from_weight_decay(m, ["bn", "bias"])
+    assert len(groups[1]["params"]) == 53 * 2 + 1 and len(groups[0]["params"]) == 54
+    opt = SGD(groups, lr=0.1, momentum=0.0, weight_decay=0.5)
+    m.flat_grads.zero_()
+    before = m.flat_params.clone()
+    opt.step()
+    p = dict(m.named_parameters())
+    assert torch.equal(p["bn1.weight"], torch.ones_like(p["bn1.weight"]))  # wd 0 group, zero grad: untouched
+    exp = 1.0 - 0.1 * 0.5
+    ref = resnet50(dtype="fp32")
+    assert torch.allclose(p["conv1.weight"].cpu(), dict(ref.named_parameters())["conv1.weight"].detach() * exp, rtol=1e-6, atol=0)
+    # the padding rows behind fc.weight stay exactly zero
+    assert torch.count_nonzero(m.flat_params[1024 + 1000 * 2048: 1024 + 1024 * 2048]) == 0
+
+
+def test_bench_with_rccl_ddp_single_rank(dev):
+    """the flat-bucket all-reduce path (side stream, events, ReduceOp.AVG over RCCL) with a 1-rank process group."""
+    env = dict(os.environ, BENCH_FORCE_DDP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                          "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
+                          "--warmup", "1", "--batch", "16", "--size", "64", "--dtype", "bf16", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["parallelism"] == "dp1"
