@@ -8,6 +8,7 @@ with mean 127.5 / std 51.0 (:27-29), one-hot float labels) and from its un-vendo
 weights are therefore an explicit INPUT of both paths, generated here).
 """
 import math
+import zlib
 
 import torch
 
@@ -59,8 +60,8 @@ def init_state_dict(named_shapes, seed=0, gamma=1.72):
     The law is this repo's choice (the reference's initialiser is not in its tree); both paths load the result.
     """
     out = {}
-    for i, (name, shape) in enumerate(named_shapes):
-        key = (seed + 1) * 7919 + i
+    for name, shape in named_shapes:
+        key = (zlib.crc32(name.encode()) + 7919 * (seed + 1)) & 0x7FFFFFFF  # depends on the NAME, not on list order
         if name.endswith("num_batches_tracked"):
             out[name] = torch.zeros((), dtype=torch.int64)
         elif name.endswith("running_mean"):
