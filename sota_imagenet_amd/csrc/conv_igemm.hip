@@ -16,6 +16,7 @@
 //   Because k is only a summation index, an fp32 lane fetches 4 consecutive k with one ds_read_b128 and
 //   feeds them to 4 successive 32x32x2 MFMAs (A and B use the same permutation).
 #include "common.h"
+#include "vec.h"
 
 namespace mi355 {
 
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][e], bv[ni][e], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[ni][e], av[mi][e], acc[mi][ni], 0, 0, 0);
       } else {
         bf16x8 av[2], bv[NI];
 #pragma unroll
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[ni], av[mi], acc[mi][ni], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -166,8 +167,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------
-  // output pixel index of each of the 128 tile rows, through LDS (the main loop is done with it)
-  int* row_pix = reinterpret_cast<int*>(smem);
+  // The MFMAs ran with swapped operands (D^T = W * A^T), so a lane holds ONE pixel (lane&31) and, per group of 4
+  // accumulator registers, 4 CONSECUTIVE channels: 8*g + 4*(lane>>5) + {0..3}.  Each wave stages its 32 x BN/2
+  // sub-tile in fp32 through a private LDS region (ds_write_b128) and reads it back row-contiguous, so every
+  // global store / addend load is 16 bytes per lane and 64..256 contiguous bytes per pixel row.
+  constexpr int WN = BN / 2;                    // channels per wave
+  constexpr int ST_ROW = WN * 4 + 16;           // staged fp32 row + pad (bytes)
+  constexpr int VEC = 16 / (int)sizeof(T);      // output elements per 16-byte store
+  constexpr int CPR = WN / VEC;                 // 16-byte chunks per staged row
+  constexpr int RPI = 64 / CPR;                 // rows covered by one wave-instruction
+  int* row_pix = reinterpret_cast<int*>(smem + 4 * 32 * ST_ROW);
+  char* stage = smem + wave * 32 * ST_ROW;
   if (tid < BM) {
     int m = m0 + tid;
     int pix = -1;
@@ -180,25 +190,41 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     }
     row_pix[tid] = pix;
   }
-  __syncthreads();
 
   T* out = reinterpret_cast<T*>(p.out);
   const T* addend = reinterpret_cast<const T*>(p.addend);
+  const int prow = lane & 31, hh = lane >> 5;
+  const int rr = lane / CPR, ch = lane % CPR;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
+    __syncthreads();  // previous pass fully read (and, first time, row_pix written / main loop done with LDS)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int pix = row_pix[row];
-      if (pix < 0) continue;
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int col = n0 + wn * (BN / 2) + ni * 32 + (lane & 31);
-        const size_t o = (size_t)pix * p.Ncols + col;
-        float v = acc[mi][ni][r];
-        if (addend) v += (float)addend[o];
-        out[o] = (T)v;
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(stage + prow * ST_ROW + (ni * 32 + 8 * g + 4 * hh) * 4) = v;
       }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 32 / RPI; ++ps) {
+      const int row = ps * RPI + rr;
+      const int pix = row_pix[wm * 64 + mi * 32 + row];
+      if (pix < 0) continue;
+      const size_t o = (size_t)pix * p.Ncols + n0 + wn * WN + ch * VEC;
+      float v[VEC];
+#pragma unroll
+      for (int q = 0; q < VEC / 4; ++q) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(stage + row * ST_ROW + (ch * VEC + 4 * q) * 4);
+        v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+      }
+      if (addend) {
+        float a[VEC];
+        Vec16<T>::load(addend + o, a);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] += a[e];
+      }
+      Vec16<T>::store(out + o, v);
     }
   }
 }
@@ -207,7 +233,9 @@ template <typename T, int BN>
 int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream) {
   const int Msub = a.N * a.Hsub * a.Wsub;
   dim3 grid(cdiv(Msub, BM), a.Ncols / BN, nclass);
-  const size_t lds = (size_t)(BM + BN) * LDS_ROW;
+  size_t lds = (size_t)(BM + BN) * LDS_ROW;
+  const size_t lds_epi = (size_t)4 * 32 * ((BN / 2) * 4 + 16) + BM * sizeof(int);
+  if (lds_epi > lds) lds = lds_epi;
   hipLaunchKernelGGL((igemm_kernel<T, BN>), grid, dim3(256), lds, stream, a);
   MI355_LAUNCH_CHECK();
   return 0;

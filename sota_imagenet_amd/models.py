@@ -147,8 +147,10 @@ class ResNet50(nn.Module):
                 self._bn_leaves.append(leaf)
             self._entries.append((leaf, attr, kind, off, shape))
             (leaf._parameters if kind == 0 else leaf._buffers)[attr] = None  # fixes the registration order
-        for leaf in self._bn_leaves:
-            leaf.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.int64))
+        # one int64 array for all 53 counters (a single `+= 1` per step); each leaf's buffer is a 0-dim view of it
+        self._nbt = torch.zeros(len(self._bn_leaves), dtype=torch.int64)
+        for i, leaf in enumerate(self._bn_leaves):
+            leaf.register_buffer("num_batches_tracked", self._nbt[i])
 
     @staticmethod
     def _view(flat, off, shape):
@@ -185,8 +187,9 @@ class ResNet50(nn.Module):
         self._flat_grads = fn(self._flat_grads)
         self._flat_buffers = fn(self._flat_buffers)
         self._hook = fn(self._hook.detach()).requires_grad_(True)
-        for leaf in self._bn_leaves:
-            leaf._buffers["num_batches_tracked"] = fn(leaf._buffers["num_batches_tracked"])
+        self._nbt = fn(self._nbt)
+        for i, leaf in enumerate(self._bn_leaves):
+            leaf._buffers["num_batches_tracked"] = self._nbt[i]
         if self._flat_params.dtype != torch.float32:
             raise TypeError("master parameters stay fp32; choose the compute dtype with resnet50(dtype='bf16')")
         self._rebind_views()
@@ -274,8 +277,7 @@ class ResNet50(nn.Module):
         check(native.lib().mi355_resnet50_forward(c, ptr(x), ptr(logits), int(training), self.bn_momentum(), native.cur_stream()))
         self._last = (c, x)  # keep the input alive until backward
         if training:
-            for leaf in self._bn_leaves:
-                leaf._buffers["num_batches_tracked"] += 1
+            self._nbt += 1
         return logits
 
     def _native_backward(self, dlogits):
