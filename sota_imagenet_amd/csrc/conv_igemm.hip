@@ -3,18 +3,23 @@
 // Replaces the cuDNN conv fwd / dgrad kernels that run beneath `model(data)` and `loss.backward()` in the
 // reference (call form sota_imagenet/callbacks.py:316-317; model built at train.py:64).
 //
-// One kernel serves forward, dgrad (stride 1 and, through four output-parity classes, stride 2) and the
-// 7x7 stem (as 7 row-taps over a zero-padded NHWC4 image): see IgemmArgs in common.h.
+// One kernel serves forward, dgrad (stride 1 and, through four output-parity classes, stride 2), the 7x7 stem
+// (7 row-taps over a zero-padded NHWC4 image) and the FC layer: see IgemmArgs in common.h.
 //
-//   block tile  128 (pixels) x BN (channels), BN = 128 | 64;   K step = 128 bytes of the tap's channel run
-//   4 waves (2x2), each 64 x BN/2, built from 32x32 MFMA tiles:
-//       fp32 : v_mfma_f32_32x32x2_f32   (exact fp32 fma chain — the parity path)
-//       bf16 : v_mfma_f32_32x32x16_bf16 (fp32 accumulate)
-//   A rows are gathered pixel runs (NHWC => the tap's Cin run is contiguous), staged global -> VGPR -> LDS
-//   with the next tile's loads in flight during the MFMAs of the current one (register double buffer).
-//   LDS rows are 128 B + 16 B pad: conflict-free for ds_write_b128 staging and ds_read_b128 fragments.
-//   Because k is only a summation index, an fp32 lane fetches 4 consecutive k with one ds_read_b128 and
-//   feeds them to 4 successive 32x32x2 MFMAs (A and B use the same permutation).
+//   tile        128 pixels x BN channels (BN = 128 | 64); K advances in 128-byte slabs of the tap's channel run
+//   MFMA        4 waves (2x2), each 64 x BN/2 from 32x32 tiles: v_mfma_f32_32x32x2_f32 (exact fp32, the parity
+//               path) / v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  Operands are swapped (D^T = W * A^T) so a
+//               lane ends up holding 4 consecutive channels of one pixel.
+//   staging     direct-to-LDS loads (global_load_lds_dwordx4): every lane supplies its own source address (the A rows
+//               are gathered pixel runs; out-of-image rows read a zero page), the LDS image stays lane-linear
+//               ([row][128 B], no padding) and the bank-conflict fix is an XOR of the 16-byte chunk index with
+//               (row>>1)&7 applied to the SOURCE address and again on the fragment ds_read_b128.
+//   pipeline    persistent workgroups walk (row-tile, n-tile, k-slab) as ONE stream through a 2-stage LDS ring:
+//               the loads of the next slab — also across tile boundaries, i.e. under the previous tile's epilogue —
+//               are in flight while the current slab feeds the MFMAs; counted `s_waitcnt vmcnt(N)` + raw s_barrier
+//               (never __syncthreads, whose fence would drain the LDS-DMA queue).  2 workgroups per CU (64.5 KiB each).
+//   epilogue    each wave stages its 32 x BN/2 fp32 sub-tile through (XOR-swizzled) LDS and writes 16 bytes per lane,
+//               64..256 contiguous bytes per pixel; the optional addend (residual gradient) is read the same way.
 #include "common.h"
 #include "vec.h"
 
@@ -23,220 +28,338 @@ namespace mi355 {
 namespace {
 
 constexpr int BM = 128;
-constexpr int BKB = 128;           // bytes of K per step
-constexpr int LDS_ROW = BKB + 16;  // padded LDS row, bytes
+constexpr int BKB = 128;  // bytes of K per slab (= one LDS row)
+constexpr int MAX_WG = 512;
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+__device__ __attribute__((aligned(256))) unsigned char g_trash[256 * 16];
+
+struct IgemmKArgs {
+  IgemmArgs a;
+  int mtiles, ny, nclass, ngroups, ntpg, items;
+};
+
+#define MI355_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define MI355_LDS_BARRIER()                                \
+  do {                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();                          \
+    asm volatile("" ::: "memory");                         \
+  } while (0)
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One 1 KiB LDS-DMA piece: lane l's 16 bytes at `src` land at LDS byte address lds_dst + 16*l (lds_dst wave-uniform).
+// Inline asm on purpose: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the first VALU write of the address
+// registers of a __builtin_amdgcn_global_load_lds, which serialises the very loads this pipeline keeps in flight;
+// the hardware reads the address at issue, so no wait is needed.  M0 is saved/restored around the instruction.
+__device__ __forceinline__ void glds16(const void* src, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_dst)
+      : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(lptr_t)p;
+}
 
 template <typename T, int BN>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
-  constexpr int BK = BKB / (int)sizeof(T);
-  constexpr int NI = BN / 64;       // 32-col MFMA tiles per wave along N
-  constexpr int NB_LD = BN / 32;    // B staging chunks per thread
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
+  const IgemmArgs& p = kp.a;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int BK = BKB / ES;
+  constexpr int NI = BN / 64;              // 32-channel MFMA tiles per wave
+  constexpr int PB = BN / 32;              // B pieces (1 KiB wave-instructions) per wave per slab
+  constexpr int A_BYTES = BM * BKB;        // 16 KiB
+  constexpr int STAGE = (BM + BN) * BKB;   // one ring stage
+  constexpr int WN = BN / 2;               // channels per wave
+  constexpr int VEC = 16 / ES;             // output elements per 16-byte store
+  constexpr int CPR = WN / VEC;            // 16-byte output chunks per staged row
+  constexpr int RPI = 64 / CPR;            // rows per wave-instruction in the read-back
+  constexpr int NST = 2 * (32 / RPI);      // global stores per thread per tile
+  constexpr int SCH = WN / 4;              // 16-byte fp32 chunks per staged row
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* As = smem;
-  char* Bs = smem + BM * LDS_ROW;
+  int* row_pix = reinterpret_cast<int*>(smem + 2 * STAGE);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-
-  const TapClass& cls = p.cls[blockIdx.z];
+  const int G = gridDim.x;
   const int Msub = p.N * p.Hsub * p.Wsub;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
-
-  // ---- per-thread staging rows ------------------------------------------------------------------
-  const int srow = tid >> 3;    // 0..31
-  const int schunk = tid & 7;   // 16-byte chunk within the 128-byte K slab
-  int a_hb[4], a_h[4], a_w[4];  // (n*Hin), i*IS, j*IS ; a_hb < 0 marks an out-of-range row
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int m = m0 + srow + 32 * i;
-    if (m < Msub) {
-      int j = m % p.Wsub;
-      int t = m / p.Wsub;
-      int ii = t % p.Hsub;
-      int n = t / p.Hsub;
-      a_hb[i] = n * p.Hin;
-      a_h[i] = ii * p.IS;
-      a_w[i] = j * p.IS;
-    } else {
-      a_hb[i] = -1;
-      a_h[i] = 0;
-      a_w[i] = 0;
-    }
-  }
-
-  f32x16 acc[2][NI];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
   const int kc_per_tap = p.Ck / BK;
-  const int nk = cls.ntaps * kc_per_tap;
-
-  uint4 ra[4], rb[NB_LD];
   const char* in_base = (const char*)p.in;
   const char* wt_base = (const char*)p.wt;
 
-  auto load_tile = [&](int kt) {
-    const int t = kt / kc_per_tap;
-    const int c0 = (kt - t * kc_per_tap) * BK;
-    const Tap tp = cls.taps[t];
+  // ---- loader cursor: runs one slab ahead of the MFMAs ------------------------------------------------------------
+  const int prow = lane >> 3;  // row within a 1 KiB piece
+  const int pch = lane & 7;    // physical 16-byte chunk
+  int L_item = blockIdx.x, L_nt = 0, L_kt = 0, L_nk = 0, L_cls = 0, L_grp = 0;
+  int a_hb[4], a_h[4], a_w[4];
+  auto L_setup = [&]() {  // decode the rows this lane stages for item L_item; skips items without taps
+    while (L_item < kp.items) {
+      const int rowtile = L_item / kp.ngroups;
+      L_grp = L_item - rowtile * kp.ngroups;
+      L_cls = rowtile / kp.mtiles;
+      const int mt = rowtile - L_cls * kp.mtiles;
+      L_nk = p.cls[L_cls].ntaps * kc_per_tap;
+      if (L_nk == 0) {
+        L_item += G;
+        continue;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mt * BM + 32 * wave + 8 * i + prow;
+        if (m < Msub) {
+          const int j = m % p.Wsub;
+          const int t = m / p.Wsub;
+          const int ii = t % p.Hsub;
+          a_hb[i] = (t / p.Hsub) * p.Hin;
+          a_h[i] = ii * p.IS;
+          a_w[i] = j * p.IS;
+        } else {
+          a_hb[i] = -1;
+          a_h[i] = 0;
+          a_w[i] = 0;
+        }
+      }
+      L_nt = 0;
+      L_kt = 0;
+      return;
+    }
+  };
+  auto L_issue = [&](int stage) {
+    const unsigned As = __builtin_amdgcn_readfirstlane(lds_addr(smem) + stage * STAGE);
+    const unsigned Bs = As + A_BYTES;
+    // the cursor is wave-uniform by construction; say so, or hipcc fetches the tap with a VECTOR load from the kernarg
+    // segment and then waits vmcnt(0) for it in the middle of the LDS-DMA burst
+    const int kt_u = __builtin_amdgcn_readfirstlane(L_kt);
+    const int cls_u = __builtin_amdgcn_readfirstlane(L_cls);
+    const int t = kt_u / kc_per_tap;
+    const int c0 = (kt_u - t * kc_per_tap) * BK;
+    const Tap tp = p.cls[cls_u].taps[t];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      const int r = 32 * wave + 8 * i + prow;
+      const int c = pch ^ ((r >> 1) & 7);
       const int ih = a_h[i] + tp.dh;
       const int iw = a_w[i] + tp.dw;
       const bool ok = (a_hb[i] >= 0) && ((unsigned)ih < (unsigned)p.Hin) && ((unsigned)iw < (unsigned)p.Win);
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) {
-        const size_t pix = (size_t)(a_hb[i] + ih) * p.Win + iw;
-        const char* src = in_base + (pix * p.pix_stride + c0) * sizeof(T) + schunk * 16;
-        v = *reinterpret_cast<const uint4*>(src);
-      }
-      ra[i] = v;
+      const long long pix = (long long)(a_hb[i] + ih) * p.Win + iw;  // garbage when !ok, never dereferenced
+      const char* real = in_base + (pix * p.pix_stride + c0) * ES + c * 16;
+      const char* src = ok ? real : (const char*)g_zero_page + c * 16;
+      glds16(src, As + (32 * wave + 8 * i) * BKB);
     }
+    const int n0 = __builtin_amdgcn_readfirstlane((L_grp * kp.ntpg + L_nt) * BN);
 #pragma unroll
-    for (int i = 0; i < NB_LD; ++i) {
-      const int col = n0 + srow + 32 * i;
-      const char* src = wt_base + (((size_t)col * p.wtaps + tp.wtap) * p.Ck + c0) * sizeof(T) + schunk * 16;
-      rb[i] = *reinterpret_cast<const uint4*>(src);
+    for (int i = 0; i < PB; ++i) {
+      const int r = PB * 8 * wave + 8 * i + prow;
+      const int c = pch ^ ((r >> 1) & 7);
+      const char* src = wt_base + (((size_t)(n0 + r) * p.wtaps + tp.wtap) * p.Ck + c0) * ES + c * 16;
+      glds16(src, Bs + (PB * 8 * wave + 8 * i) * BKB);
     }
   };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<uint4*>(As + (srow + 32 * i) * LDS_ROW + schunk * 16) = ra[i];
-#pragma unroll
-    for (int i = 0; i < NB_LD; ++i)
-      *reinterpret_cast<uint4*>(Bs + (srow + 32 * i) * LDS_ROW + schunk * 16) = rb[i];
+  auto L_advance = [&]() {
+    if (++L_kt < L_nk) return;
+    L_kt = 0;
+    if (++L_nt < kp.ntpg) return;
+    L_item += G;
+    L_setup();
   };
 
-  // fragment row bases (bytes)
-  const int frag_k = (lane >> 5) * 16;  // lane half -> which 16 bytes of each 32-byte k group
-  int a_off[2], b_off[NI];
+  // ---- fragment addresses (constant over the whole kernel) -------------------------------------------------------
+  const int hh = lane >> 5;
+  int a_row[2], a_sw[2], b_row[NI], b_sw[NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) a_off[mi] = (wm * 64 + mi * 32 + (lane & 31)) * LDS_ROW + frag_k;
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) b_off[ni] = (wn * (BN / 2) + ni * 32 + (lane & 31)) * LDS_ROW + frag_k;
-
-  if (nk > 0) {
-    load_tile(0);
-    store_tile();
+  for (int mi = 0; mi < 2; ++mi) {
+    const int r = wm * 64 + mi * 32 + (lane & 31);
+    a_row[mi] = r * BKB;
+    a_sw[mi] = (r >> 1) & 7;
   }
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {  // four 32-byte k groups per 128-byte slab
-      if constexpr (sizeof(T) == 4) {
-        f32x4 av[2], bv[NI];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) av[mi] = *reinterpret_cast<const f32x4*>(As + a_off[mi] + g * 32);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bv[ni] = *reinterpret_cast<const f32x4*>(Bs + b_off[ni] + g * 32);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[ni][e], av[mi][e], acc[mi][ni], 0, 0, 0);
-      } else {
-        bf16x8 av[2], bv[NI];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) av[mi] = *reinterpret_cast<const bf16x8*>(As + a_off[mi] + g * 32);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bv[ni] = *reinterpret_cast<const bf16x8*>(Bs + b_off[ni] + g * 32);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[ni], av[mi], acc[mi][ni], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      store_tile();
-      __syncthreads();
-    }
+  for (int ni = 0; ni < NI; ++ni) {
+    const int r = wn * WN + ni * 32 + (lane & 31);
+    b_row[ni] = A_BYTES + r * BKB;
+    b_sw[ni] = (r >> 1) & 7;
   }
 
-  // ---- epilogue ---------------------------------------------------------------------------------
-  // The MFMAs ran with swapped operands (D^T = W * A^T), so a lane holds ONE pixel (lane&31) and, per group of 4
-  // accumulator registers, 4 CONSECUTIVE channels: 8*g + 4*(lane>>5) + {0..3}.  Each wave stages its 32 x BN/2
-  // sub-tile in fp32 through a private LDS region (ds_write_b128) and reads it back row-contiguous, so every
-  // global store / addend load is 16 bytes per lane and 64..256 contiguous bytes per pixel row.
-  constexpr int WN = BN / 2;                    // channels per wave
-  constexpr int ST_ROW = WN * 4 + 16;           // staged fp32 row + pad (bytes)
-  constexpr int VEC = 16 / (int)sizeof(T);      // output elements per 16-byte store
-  constexpr int CPR = WN / VEC;                 // 16-byte chunks per staged row
-  constexpr int RPI = 64 / CPR;                 // rows covered by one wave-instruction
-  int* row_pix = reinterpret_cast<int*>(smem + 4 * 32 * ST_ROW);
-  char* stage = smem + wave * 32 * ST_ROW;
-  if (tid < BM) {
-    int m = m0 + tid;
-    int pix = -1;
-    if (m < Msub) {
-      int j = m % p.Wsub;
-      int t = m / p.Wsub;
-      int ii = t % p.Hsub;
-      int n = t / p.Hsub;
-      pix = (n * p.Hout + ii * p.OS + cls.ph) * p.Wout + j * p.OS + cls.pw;
-    }
-    row_pix[tid] = pix;
+  // ---- prologue ---------------------------------------------------------------------------------------------------
+  L_setup();
+  int stage = 0;
+  if (L_item < kp.items) {
+    L_issue(0);
+    L_advance();
   }
+  int pending_st = 0;
 
   T* out = reinterpret_cast<T*>(p.out);
   const T* addend = reinterpret_cast<const T*>(p.addend);
-  const int prow = lane & 31, hh = lane >> 5;
-  const int rr = lane / CPR, ch = lane % CPR;
+
+  for (int item = blockIdx.x; item < kp.items; item += G) {
+    const int rowtile = item / kp.ngroups;
+    const int grp = item - rowtile * kp.ngroups;
+    const int ci = rowtile / kp.mtiles;
+    const int mt = rowtile - ci * kp.mtiles;
+    const TapClass& cls = p.cls[ci];
+    const int nk = cls.ntaps * kc_per_tap;
+    const int m0 = mt * BM;
+    for (int nti = 0; nti < kp.ntpg; ++nti) {
+      const int n0 = (grp * kp.ntpg + nti) * BN;
+      f32x16 acc[2][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    __syncthreads();  // previous pass fully read (and, first time, row_pix written / main loop done with LDS)
+      for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-        *reinterpret_cast<f32x4*>(stage + prow * ST_ROW + (ni * 32 + 8 * g + 4 * hh) * 4) = v;
+          for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+      for (int kt = 0; kt < nk; ++kt) {
+        // the slab for this step was issued one step ago; epilogue stores issued since then may stay in flight
+        if (pending_st == NST) {
+          if constexpr (NST == 16) MI355_WAIT_VM(16);
+          else if constexpr (NST == 8) MI355_WAIT_VM(8);
+          else MI355_WAIT_VM(4);
+        } else {
+          MI355_WAIT_VM(0);
+        }
+        pending_st = 0;
+        MI355_LDS_BARRIER();  // slab landed for every wave; everyone is done reading the other stage
+        if (L_item < kp.items) {
+          L_issue(stage ^ 1);
+          L_advance();
+        }
+        const char* base = smem + stage * STAGE;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // four 32-byte k groups per slab; lane half hh takes one 16-byte chunk of each
+          if constexpr (ES == 4) {
+            f32x4 av[2], bv[NI];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+              av[mi] = *reinterpret_cast<const f32x4*>(base + a_row[mi] + (((2 * g + hh) ^ a_sw[mi]) << 4));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              bv[ni] = *reinterpret_cast<const f32x4*>(base + b_row[ni] + (((2 * g + hh) ^ b_sw[ni]) << 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[ni][e], av[mi][e], acc[mi][ni], 0, 0, 0);
+          } else {
+            bf16x8 av[2], bv[NI];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+              av[mi] = *reinterpret_cast<const bf16x8*>(base + a_row[mi] + (((2 * g + hh) ^ a_sw[mi]) << 4));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              bv[ni] = *reinterpret_cast<const bf16x8*>(base + b_row[ni] + (((2 * g + hh) ^ b_sw[ni]) << 4));
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[ni], av[mi], acc[mi][ni], 0, 0, 0);
+          }
+        }
+        stage ^= 1;
       }
-    __syncthreads();
-#pragma unroll
-    for (int ps = 0; ps < 32 / RPI; ++ps) {
-      const int row = ps * RPI + rr;
-      const int pix = row_pix[wm * 64 + mi * 32 + row];
-      if (pix < 0) continue;
-      const size_t o = (size_t)pix * p.Ncols + n0 + wn * WN + ch * VEC;
-      float v[VEC];
-#pragma unroll
-      for (int q = 0; q < VEC / 4; ++q) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(stage + row * ST_ROW + (ch * VEC + 4 * q) * 4);
-        v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+
+      // ---- epilogue: stage^1 (the slab buffer just consumed) is free once every wave has passed the barrier -------
+      char* stg = smem + (stage ^ 1) * STAGE + wave * (32 * WN * 4);
+      MI355_LDS_BARRIER();
+      if (tid < BM) {
+        const int m = m0 + tid;
+        int pix = -1;
+        if (m < Msub) {
+          const int j = m % p.Wsub;
+          const int t = m / p.Wsub;
+          const int ii = t % p.Hsub;
+          const int n = t / p.Hsub;
+          pix = (n * p.Hout + ii * p.OS + cls.ph) * p.Wout + j * p.OS + cls.pw;
+        }
+        row_pix[tid] = pix;
       }
-      if (addend) {
-        float a[VEC];
-        Vec16<T>::load(addend + o, a);
+      const int prw = lane & 31;
+      const int rr = lane / CPR, ch = lane % CPR;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) v[e] += a[e];
+      for (int mi = 0; mi < 2; ++mi) {
+        // a lane holds pixel prw and, per register group g, channels ni*32 + 8g + 4hh + {0..3}
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+            const int sc = (ni * 8 + 2 * g + hh) ^ (prw & (SCH - 1));
+            *reinterpret_cast<f32x4*>(stg + prw * (WN * 4) + sc * 16) = v;
+          }
+        if (mi == 0) {
+          MI355_LDS_BARRIER();  // row_pix visible to all waves (the staging region itself is wave-private)
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        constexpr int NP = 32 / RPI;
+        int pixs[NP];
+        uint4 araw[NP];
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {  // all addend loads of this pass first: one round trip, not NP
+          pixs[ps] = row_pix[wm * 64 + mi * 32 + ps * RPI + rr];
+          if (addend) {
+            const size_t o = (size_t)(pixs[ps] < 0 ? 0 : pixs[ps]) * p.Ncols + n0 + wn * WN + ch * VEC;
+            araw[ps] = *reinterpret_cast<const uint4*>(pixs[ps] < 0 ? reinterpret_cast<const T*>(g_zero_page) : addend + o);
+          }
+        }
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+          const int row = ps * RPI + rr;
+          const int pix = pixs[ps];
+          float v[VEC];
+#pragma unroll
+          for (int q = 0; q < VEC / 4; ++q) {
+            const int sc = (ch * (VEC / 4) + q) ^ (row & (SCH - 1));
+            const f32x4 t = *reinterpret_cast<const f32x4*>(stg + row * (WN * 4) + sc * 16);
+            v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+          }
+          const size_t o = (size_t)(pix < 0 ? 0 : pix) * p.Ncols + n0 + wn * WN + ch * VEC;
+          if (addend) {
+            float a[VEC];
+            Vec16<T>::unpack(araw[ps], a);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] += a[e];
+          }
+          // rows past the end of the problem go to a trash page so that every thread issues exactly NST stores
+          T* dst = pix < 0 ? reinterpret_cast<T*>(g_trash + tid * 16) : out + o;
+          Vec16<T>::store(dst, v);
+        }
+        asm volatile("" ::: "memory");
       }
-      Vec16<T>::store(out + o, v);
+      pending_st += NST;
     }
   }
 }
 
 template <typename T, int BN>
 int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream) {
+  IgemmKArgs k;
+  k.a = a;
   const int Msub = a.N * a.Hsub * a.Wsub;
-  dim3 grid(cdiv(Msub, BM), a.Ncols / BN, nclass);
-  size_t lds = (size_t)(BM + BN) * LDS_ROW;
-  const size_t lds_epi = (size_t)4 * 32 * ((BN / 2) * 4 + 16) + BM * sizeof(int);
-  if (lds_epi > lds) lds = lds_epi;
-  hipLaunchKernelGGL((igemm_kernel<T, BN>), grid, dim3(256), lds, stream, a);
+  k.mtiles = cdiv(Msub, BM);
+  k.ny = a.Ncols / BN;
+  k.nclass = nclass;
+  const int R = nclass * k.mtiles;
+  int ng = k.ny;
+  for (int d = 1; d <= k.ny; ++d)
+    if (k.ny % d == 0 && R * d >= MAX_WG) {
+      ng = d;
+      break;
+    }
+  k.ngroups = ng;
+  k.ntpg = k.ny / ng;
+  k.items = R * ng;
+  const int grid = k.items < MAX_WG ? k.items : MAX_WG;
+  const size_t lds = (size_t)2 * (BM + BN) * BKB + BM * sizeof(int);
+  hipLaunchKernelGGL((igemm_kernel<T, BN>), dim3(grid), dim3(256), lds, stream, k);
   MI355_LAUNCH_CHECK();
   return 0;
 }
@@ -250,6 +373,7 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream) 
   MI355_ARG(a.Ncols % 64 == 0, "igemm: Ncols=%d not a multiple of 64", a.Ncols);
   MI355_ARG(nclass >= 1 && nclass <= 4, "igemm: nclass=%d", nclass);
   MI355_ARG(((size_t)a.pix_stride * dtype_size(dtype)) % 8 == 0, "igemm: pixel stride not 8-byte aligned");
+  MI355_ARG(a.N > 0 && a.Hsub > 0 && a.Wsub > 0, "igemm: empty problem");
   const bool wide = (a.Ncols % 128 == 0);
   if (dtype == MI355_F32) return wide ? launch_t<float, 128>(a, nclass, stream) : launch_t<float, 64>(a, nclass, stream);
   if (dtype == MI355_BF16)

@@ -14,6 +14,9 @@ struct Vec16<float> {
     const f32x4 t = *reinterpret_cast<const f32x4*>(p);
     v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
   }
+  static __device__ __forceinline__ void unpack(const uint4& t, float (&v)[4]) {
+    v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+  }
   static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
     f32x4 t = {v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(p) = t;
@@ -24,7 +27,9 @@ template <>
 struct Vec16<bf16_t> {
   static constexpr int N = 8;
   static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
-    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    unpack(*reinterpret_cast<const uint4*>(p), v);
+  }
+  static __device__ __forceinline__ void unpack(const uint4& t, float (&v)[8]) {
     const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
