@@ -157,12 +157,9 @@ def test_loss_curve_matches_cpu(dev, dtype):
     l64, _ = O.train_steps(O.make_reference(sd).double(), [(d.double(), t.double()) for d, t in batches], lrs,
                            momentum=0.9, weight_decay=3e-5, smoothing=0.1)
     losses = _native_curve(m, batches, lrs)
-    floor = 2e-3 if dtype == "fp32" else 3e-2
-    assert abs(losses[0] - l64[0]) < (1e-5 if dtype == "fp32" else 2e-2) * l64[0]
-    for i in range(steps):
-        yard = abs(l32[i] - l64[i]) / l64[i]
-        got = abs(losses[i] - l64[i]) / l64[i]
-        assert got < 3 * yard + floor * (1 + i), f"step {i}: native {losses} / cpu fp32 {l32} / fp64 {l64}"
+    from test_golden_gpu import check_curve
+
+    check_curve(losses, l32, l64, dtype)
 
 
 def test_bf16_forward_backward_vs_cpu_yardstick(dev):
