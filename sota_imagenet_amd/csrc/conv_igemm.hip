@@ -283,12 +283,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
       }
       const int prw = lane & 31;
       const int rr = lane / CPR, ch = lane % CPR;
-      float s1[VEC], s2[VEC];  // BN statistics of this tile's outputs (as stored, i.e. after rounding to T)
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        s1[e] = 0.f;
-        s2[e] = 0.f;
-      }
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         // a lane holds pixel prw and, per register group g, channels ni*32 + 8g + 4hh + {0..3}
@@ -337,40 +331,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
           // rows past the end of the problem go to a trash page so that every thread issues exactly NST stores
           T* dst = pix < 0 ? reinterpret_cast<T*>(g_trash + tid * 16) : out + o;
           Vec16<T>::store(dst, v);
-          if (p.stat_partial && pix >= 0) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-              const float xr = (float)(T)v[e];
-              s1[e] += xr;
-              s2[e] += xr * xr;
-            }
-          }
         }
         asm volatile("" ::: "memory");
-      }
-      if (p.stat_partial) {
-        // rows of one wave that share a channel chunk sit CPR lanes apart: xor-shuffle them together, then lane `ch`
-        // (rr == 0) adds the wave's sums into ITS OWN partial row (row = 2*workgroup + wm): plain read-modify-write by
-        // one fixed lane per channel => deterministic, no atomics.  The first tile a workgroup sees for an n-tile
-        // writes instead of adding when every workgroup covers all channels (ngroups == 1); otherwise the host zeroed
-        // the buffer.
-#pragma unroll
-        for (int off = CPR; off < 64; off <<= 1) {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            s1[e] += __shfl_xor(s1[e], off);
-            s2[e] += __shfl_xor(s2[e], off);
-          }
-        }
-        if (lane < CPR) {
-          float* prow_ = p.stat_partial + (size_t)(blockIdx.x * 2 + wm) * 2 * p.Ncols + n0 + wn * WN + lane * VEC;
-          const bool first = (kp.ngroups == 1) && (item == (int)blockIdx.x);
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            prow_[e] = (first ? 0.f : prow_[e]) + s1[e];
-            prow_[p.Ncols + e] = (first ? 0.f : prow_[p.Ncols + e]) + s2[e];
-          }
-        }
       }
       pending_st += NST;
     }
@@ -378,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
 }
 
 template <typename T, int BN>
-int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
+int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream) {
   IgemmKArgs k;
   k.a = a;
   const int Msub = a.N * a.Hsub * a.Wsub;
@@ -396,12 +358,6 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
   k.ntpg = k.ny / ng;
   k.items = R * ng;
   const int grid = k.items < MAX_WG ? k.items : MAX_WG;
-  if (a.stat_partial) {
-    if (k.ngroups != 1) MI355_HIP(hipMemsetAsync(a.stat_partial, 0, (size_t)grid * 2 * 2 * a.Ncols * sizeof(float), stream));
-    if (stat_rows) *stat_rows = grid * 2;
-  } else if (stat_rows) {
-    *stat_rows = 0;
-  }
   const size_t lds = (size_t)2 * (BM + BN) * BKB + BM * sizeof(int);
   hipLaunchKernelGGL((igemm_kernel<T, BN>), dim3(grid), dim3(256), lds, stream, k);
   MI355_LAUNCH_CHECK();
@@ -410,7 +366,7 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
 
 }  // namespace
 
-int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
+int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream) {
   const int bk = BKB / (int)dtype_size(dtype);
   MI355_ARG(a.in && a.wt && a.out, "igemm: null pointer");
   MI355_ARG(a.Ck % bk == 0, "igemm: Ck=%d not a multiple of %d", a.Ck, bk);
@@ -419,9 +375,9 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
   MI355_ARG(((size_t)a.pix_stride * dtype_size(dtype)) % 8 == 0, "igemm: pixel stride not 8-byte aligned");
   MI355_ARG(a.N > 0 && a.Hsub > 0 && a.Wsub > 0, "igemm: empty problem");
   const bool wide = (a.Ncols % 128 == 0);
-  if (dtype == MI355_F32) return wide ? launch_t<float, 128>(a, nclass, stream, stat_rows) : launch_t<float, 64>(a, nclass, stream, stat_rows);
+  if (dtype == MI355_F32) return wide ? launch_t<float, 128>(a, nclass, stream) : launch_t<float, 64>(a, nclass, stream);
   if (dtype == MI355_BF16)
-    return wide ? launch_t<bf16_t, 128>(a, nclass, stream, stat_rows) : launch_t<bf16_t, 64>(a, nclass, stream, stat_rows);
+    return wide ? launch_t<bf16_t, 128>(a, nclass, stream) : launch_t<bf16_t, 64>(a, nclass, stream);
   set_error("igemm: bad dtype %d", dtype);
   return MI355_E_ARG;
 }
