@@ -166,23 +166,40 @@ struct FinalizeArgs {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const FinalizeArgs p) {
-  __shared__ double red[2][16][17];
-  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  // 4 channels x 64 slices per workgroup: every thread has <= 8 independent partial rows to add (nblk <= 512), then a
+  // fixed-shape LDS tree — the summation order depends only on nblk, so results are bitwise reproducible.
+  __shared__ double red[2][64][4];
+  const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
   double a = 0.0, b = 0.0;
-  for (int k = sl; k < p.nblk; k += 16) {
-    a += (double)p.partial[((size_t)k * 2 + 0) * p.C + c];
-    b += (double)p.partial[((size_t)k * 2 + 1) * p.C + c];
+  for (int k0 = sl; k0 < p.nblk; k0 += 64 * 8) {
+    float va[8], vb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + 64 * u;
+      const bool in = k < p.nblk;
+      va[u] = in ? p.partial[((size_t)k * 2 + 0) * p.C + c] : 0.f;
+      vb[u] = in ? p.partial[((size_t)k * 2 + 1) * p.C + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a += (double)va[u];
+      b += (double)vb[u];
+    }
   }
   red[0][sl][cl] = a;
   red[1][sl][cl] = b;
   __syncthreads();
-  if (threadIdx.x < 16) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < 16; ++k) {
-      s1 += red[0][k][cl];
-      s2 += red[1][k][cl];
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    if (sl < s) {
+      red[0][sl][cl] += red[0][sl + s][cl];
+      red[1][sl][cl] += red[1][sl + s][cl];
     }
+    __syncthreads();
+  }
+  if (sl == 0) {
+    const double s1 = red[0][0][cl], s2 = red[1][0][cl];
     const double M = (double)p.M;
     if (MODE == 0) {
       const double dm = s1 / M;  // mean of (x - pivot)
@@ -401,7 +418,7 @@ int launch_bn_finalize(const float* partial, const float* pivot, int nblk, int M
   a.shift = shift;
   a.eps = eps;
   a.momentum = momentum;
-  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(C / 16), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(C / 4), dim3(256), 0, s, a);
   MI355_LAUNCH_CHECK();
   return 0;
 }
@@ -477,7 +494,7 @@ int launch_bn_bwd_finalize(const float* partial, int nblk, int M, int C, const f
   a.dbeta = dbeta;
   a.beta_acc = beta_acc;
   a.coef = coef;
-  hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(C / 16), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(C / 4), dim3(256), 0, s, a);
   MI355_LAUNCH_CHECK();
   return 0;
 }

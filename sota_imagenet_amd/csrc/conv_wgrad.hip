@@ -3,22 +3,28 @@
 // Replaces the cuDNN wgrad kernels under `loss.backward()` in the reference (sota_imagenet/callbacks.py:317).
 //
 //   dW[co][tap][ci] = sum over output pixels m of dy[m][co] * x[src(m,tap)][ci]
-// is a GEMM whose reduction index (the pixel) is the SLOW index of both operands in NHWC memory, so both
-// MFMA operands are "transposed".  Tiles are staged in their natural [pixel][channel] layout
-// (coalesced 16-byte loads, zero-filled halo) and read transposed out of LDS:
+// is a GEMM whose reduction index (the pixel) is the SLOW index of both operands in NHWC memory, so both MFMA
+// operands are "transposed".  Slabs of BKP pixels are staged in their natural [pixel][channel] layout by direct-to-LDS
+// loads (global_load_lds_dwordx4; per-lane source address = the tap's gathered pixel, out-of-image rows read a zero
+// page) and read TRANSPOSED out of LDS:
 //   fp32 : ds_read_b32 (a lane holds ONE k per v_mfma_f32_32x32x2_f32 operand, lanes run along channels)
-//   bf16 : ds_read_b64_tr_b16 x2 per v_mfma_f32_32x32x16_bf16 operand (row stride == 16 dwords mod 64
-//          => the 4 k-rows x 32 columns of a half-wave cover all 64 banks exactly once)
-// Block tile: BMC (128|64) output channels x 64 input channels of ONE tap; the pixel range is split
-// over blockIdx.y; fp32 partial slabs are summed in split order by splitk_reduce (bitwise reproducible,
-// no float atomics).
+//   bf16 : ds_read_b64_tr_b16 x2 per v_mfma_f32_32x32x16_bf16 operand; the LDS image stays lane-linear and the four
+//          pixel rows a half-wave touches are spread over all 64 banks by XOR-ing the 16-byte chunk index with
+//          (row&3)<<2 (256-byte rows) / ((row>>1)&1)<<2 (128-byte rows) on the SOURCE address and on the read.
+// Tile: BMC (128|64) output channels x BNC (128|64) input channels of ONE tap, 4 waves (2x2), swapped MFMA operands
+// so a lane ends with 4 consecutive input channels of one output channel (16-byte stores).  Persistent workgroups
+// walk (tile, pixel-split, slab) as one stream through a 2-stage LDS ring with the next slab always in flight
+// (counted s_waitcnt vmcnt + raw s_barrier, as in conv_igemm.hip).  fp32 partial slabs are summed in split order by
+// splitk_reduce (bitwise reproducible, no float atomics).
 #include "common.h"
 
 namespace mi355 {
 
 namespace {
 
-constexpr int BNC = 64;
+constexpr int MAX_WG = 512;
+
+__device__ __attribute__((aligned(256))) unsigned char g_wzero_page[1024];
 
 struct FastDiv {
   uint32_t mul, sh;
@@ -38,169 +44,239 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
 struct WgradKArgs {
   WgradArgs a;
   FastDiv dWo, dHo;
-  int M;
+  int M, tiles, splits, items, pix_per_split;
 };
 
-template <typename T, int BMC>
+#define MI355_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define MI355_LDS_BARRIER()                                \
+  do {                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();                          \
+    asm volatile("" ::: "memory");                         \
+  } while (0)
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// see conv_igemm.hip: inline asm so that hipcc does not wait vmcnt(0) on the address registers of an LDS-DMA load
+__device__ __forceinline__ void glds16(const void* src, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_dst)
+      : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long long)(lptr_t)p; }
+
+// XOR applied to the 16-byte chunk index of a staged row (bf16 only; fp32 reads are conflict-free as they are)
+template <int ES, int ROW_BYTES>
+__device__ __forceinline__ int row_swz(int row) {
+  if constexpr (ES == 4) return 0;
+  else if constexpr (ROW_BYTES == 256) return (row & 3) << 2;
+  else return ((row >> 1) & 1) << 2;
+}
+
+template <typename T, int BMC, int BNC>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
   const WgradArgs& p = kp.a;
   constexpr int ES = (int)sizeof(T);
-  constexpr int BKP = 128 / ES;                 // pixels per chunk: 32 fp32, 64 bf16
-  constexpr int SA = BMC * ES + 64;             // LDS row strides (bytes), == 16 dwords (mod 64) for bf16
-  constexpr int SB = BNC * ES + 64;
-  constexpr int CPR_A = BMC * ES / 16;          // 16-byte chunks per dy row
-  constexpr int CPR_B = BNC * ES / 16;
-  constexpr int NLD_A = BKP * CPR_A / 256;
-  constexpr int NLD_B = BKP * CPR_B / 256;
-  constexpr int MI = BMC / 64;
+  constexpr int BKP = 128 / ES;             // pixels per slab: 32 fp32, 64 bf16
+  constexpr int RB_A = BMC * ES;            // bytes of one staged dy row
+  constexpr int RB_B = BNC * ES;            // bytes of one staged x row
+  constexpr int A_BYTES = BKP * RB_A;
+  constexpr int STAGE = BKP * (RB_A + RB_B);
+  constexpr int LPR_A = RB_A / 16, LPR_B = RB_B / 16;  // lanes (16-byte chunks) per row
+  constexpr int RPP_A = 64 / LPR_A, RPP_B = 64 / LPR_B;  // rows per 1 KiB piece
+  constexpr int PW_A = BMC / 32, PW_B = BNC / 32;        // pieces per wave per slab
+  constexpr int MI = BMC / 64, NI = BNC / 64;            // 32x32 tiles per wave (cout / cin)
+  constexpr int NST = MI * NI * 4;                       // 16-byte stores per thread per item
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ad = smem;
-  char* Bx = smem + BKP * SA;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-
-  // tile decode: x = ((cb * ntaps + t) * ckb + cib)
+  const int G = gridDim.x;
   const int ckb = p.Ck / BNC;
-  int tile = blockIdx.x;
-  const int cib = tile % ckb;
-  tile /= ckb;
-  const int t = tile % p.ntaps;
-  const int cb = tile / p.ntaps;
-  const Tap tp = p.taps[t];
-  const int co0 = cb * BMC;
-  const int ci0 = cib * BNC;
-  const int split = blockIdx.y;
-
-  const int chunk0 = split * p.chunks_per_split;
-  const int mbeg = chunk0 * BKP;
-  int mend = mbeg + p.chunks_per_split * BKP;
-  if (mend > kp.M) mend = kp.M;
-
-  f32x16 acc[MI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
-
-  uint4 ra[NLD_A], rb[NLD_B];
   const char* dy_base = (const char*)p.dy;
   const char* x_base = (const char*)p.x;
 
-  auto load_chunk = [&](int m0) {
+  // ---- loader cursor (one slab ahead) -----------------------------------------------------------------------------
+  int L_item = blockIdx.x, L_m = 0, L_mend = 0, L_co0 = 0, L_ci0 = 0, L_dh = 0, L_dw = 0;
+  auto L_setup = [&]() {
+    if (L_item >= kp.items) return;
+    const int tile = L_item % kp.tiles;
+    const int split = L_item / kp.tiles;
+    const int cib = tile % ckb;
+    const int r1 = tile / ckb;
+    const int t = r1 % p.ntaps;
+    const int cb = r1 / p.ntaps;
+    const Tap tp = p.taps[__builtin_amdgcn_readfirstlane(t)];
+    L_dh = tp.dh;
+    L_dw = tp.dw;
+    L_co0 = cb * BMC;
+    L_ci0 = cib * BNC;
+    L_m = split * kp.pix_per_split;
+    L_mend = L_m + kp.pix_per_split;
+    if (L_mend > kp.M) L_mend = kp.M;
+  };
+  auto L_issue = [&](int stage) {
+    const unsigned As = __builtin_amdgcn_readfirstlane(lds_addr(smem) + stage * STAGE);
+    const unsigned Bs = As + A_BYTES;
+    const int m0 = __builtin_amdgcn_readfirstlane(L_m);
 #pragma unroll
-    for (int i = 0; i < NLD_A; ++i) {
-      const int idx = tid + 256 * i;
-      const int row = idx / CPR_A, ch = idx % CPR_A;
+    for (int i = 0; i < PW_A; ++i) {
+      const int piece = wave * PW_A + i;
+      const int row = piece * RPP_A + lane / LPR_A;
+      const int c = (lane % LPR_A) ^ row_swz<ES, RB_A>(row);
       const int m = m0 + row;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (m < mend) v = *reinterpret_cast<const uint4*>(dy_base + ((size_t)m * p.Cout + co0) * ES + ch * 16);
-      ra[i] = v;
+      const char* real = dy_base + ((size_t)m * p.Cout + L_co0) * ES + c * 16;
+      const char* src = m < L_mend ? real : (const char*)g_wzero_page + c * 16;
+      glds16(src, As + piece * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < NLD_B; ++i) {
-      const int idx = tid + 256 * i;
-      const int row = idx / CPR_B, ch = idx % CPR_B;
+    for (int i = 0; i < PW_B; ++i) {
+      const int piece = wave * PW_B + i;
+      const int row = piece * RPP_B + lane / LPR_B;
+      const int c = (lane % LPR_B) ^ row_swz<ES, RB_B>(row);
       const int m = m0 + row;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (m < mend) {
-        const uint32_t q1 = fdiv((uint32_t)m, kp.dWo);
-        const int ow = m - (int)q1 * p.Wo;
-        const uint32_t n = fdiv(q1, kp.dHo);
-        const int oh = (int)q1 - (int)n * p.Ho;
-        const int ih = oh * p.IS + tp.dh;
-        const int iw = ow * p.IS + tp.dw;
-        if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) {
-          const size_t pix = ((size_t)n * p.Hin + ih) * p.Win + iw;
-          v = *reinterpret_cast<const uint4*>(x_base + (pix * p.pix_stride + ci0) * ES + ch * 16);
-        }
-      }
-      rb[i] = v;
+      const uint32_t q1 = fdiv((uint32_t)m, kp.dWo);
+      const int ow = m - (int)q1 * p.Wo;
+      const uint32_t n = fdiv(q1, kp.dHo);
+      const int oh = (int)q1 - (int)n * p.Ho;
+      const int ih = oh * p.IS + L_dh;
+      const int iw = ow * p.IS + L_dw;
+      const bool ok = m < L_mend && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+      const long long pix = ((long long)n * p.Hin + ih) * p.Win + iw;  // garbage when !ok, never dereferenced
+      const char* real = x_base + (pix * p.pix_stride + L_ci0) * ES + c * 16;
+      const char* src = ok ? real : (const char*)g_wzero_page + c * 16;
+      glds16(src, Bs + piece * 1024);
     }
   };
-  auto store_chunk = [&]() {
-#pragma unroll
-    for (int i = 0; i < NLD_A; ++i) {
-      const int idx = tid + 256 * i;
-      *reinterpret_cast<uint4*>(Ad + (idx / CPR_A) * SA + (idx % CPR_A) * 16) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NLD_B; ++i) {
-      const int idx = tid + 256 * i;
-      *reinterpret_cast<uint4*>(Bx + (idx / CPR_B) * SB + (idx % CPR_B) * 16) = rb[i];
-    }
+  auto L_advance = [&]() {
+    L_m += BKP;
+    if (L_m < L_mend) return;
+    L_item += G;
+    L_setup();
   };
 
-  const int ibase = wm * (BMC / 2);  // + mi*32
-  const int jbase = wn * 32;
+  // ---- per-lane fragment coordinates -------------------------------------------------------------------------------
+  const int cobase = wm * (BMC / 2);  // + mi*32 : output channels, on the lanes of D
+  const int cibase = wn * (BNC / 2);  // + ni*32 : input channels, in the registers of D
+  const int hh = lane >> 5, c31 = lane & 31;
+  // bf16 transposed reads: group g = lane>>4 reads k rows 8*(g>>1)+q (+4), columns 16*(g&1) + 4*pp
+  const int tg = lane >> 4, tw = lane & 15, tq = tw >> 2, tpp = tw & 3;
+  const int t_krow = 8 * (tg >> 1) + tq;
+  const int t_col = 16 * (tg & 1) + 4 * tpp;  // element column inside the 32-wide tile
 
-  if (mbeg < mend) {
-    load_chunk(mbeg);
-    store_chunk();
+  L_setup();
+  int stage = 0;
+  if (L_item < kp.items) {
+    L_issue(0);
+    L_advance();
   }
-  __syncthreads();
+  int pending_st = 0;
 
-  for (int m0 = mbeg; m0 < mend; m0 += BKP) {
-    const bool more = (m0 + BKP) < mend;
-    if (more) load_chunk(m0 + BKP);
-    if constexpr (ES == 4) {
-      const int h = lane >> 5, c = lane & 31;
+  for (int item = blockIdx.x; item < kp.items; item += G) {
+    const int tile = item % kp.tiles;
+    const int split = item / kp.tiles;
+    const int cib = tile % ckb;
+    const int r1 = tile / ckb;
+    const int t = r1 % p.ntaps;
+    const int cb = r1 / p.ntaps;
+    const int wtap = p.taps[__builtin_amdgcn_readfirstlane(t)].wtap;
+    const int mbeg = split * kp.pix_per_split;
+    int mend = mbeg + kp.pix_per_split;
+    if (mend > kp.M) mend = kp.M;
+
+    f32x16 acc[MI][NI];
 #pragma unroll
-      for (int kk = 0; kk < BKP / 2; ++kk) {
-        const int k = 2 * kk + h;
-        const float b = *reinterpret_cast<const float*>(Bx + k * SB + (jbase + c) * 4);
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const float a = *reinterpret_cast<const float*>(Ad + k * SA + (ibase + mi * 32 + c) * 4);
-          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi], 0, 0, 0);
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    for (int m0 = mbeg; m0 < mend; m0 += BKP) {
+      if (pending_st == NST) {
+        if constexpr (NST == 16) MI355_WAIT_VM(16);
+        else if constexpr (NST == 8) MI355_WAIT_VM(8);
+        else MI355_WAIT_VM(4);
+      } else {
+        MI355_WAIT_VM(0);
+      }
+      pending_st = 0;
+      MI355_LDS_BARRIER();
+      if (L_item < kp.items) {
+        L_issue(stage ^ 1);
+        L_advance();
+      }
+      const char* Ad = smem + stage * STAGE;
+      const char* Bx = Ad + A_BYTES;
+      if constexpr (ES == 4) {
+#pragma unroll
+        for (int kk = 0; kk < BKP / 2; ++kk) {
+          const int k = 2 * kk + hh;
+          float xv[NI], dv[MI];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) xv[ni] = *reinterpret_cast<const float*>(Bx + k * RB_B + (cibase + ni * 32 + c31) * 4);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) dv[mi] = *reinterpret_cast<const float*>(Ad + k * RB_A + (cobase + mi * 32 + c31) * 4);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[ni], dv[mi], acc[mi][ni], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < BKP / 16; ++ks) {
+          const int k0 = ks * 16 + t_krow;  // rows k0 and k0+4 share (row&3) and ((row>>1)&1): same swizzle
+          bf16x8 xf[NI], df[MI];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const int byte = (cibase + ni * 32 + t_col) * 2;
+            const char* ap = Bx + k0 * RB_B + ((((byte >> 4) ^ row_swz<ES, RB_B>(k0)) << 4) | (byte & 15));
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap + 4 * RB_B));
+            const s16x8 tmp = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            xf[ni] = __builtin_bit_cast(bf16x8, tmp);
+          }
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const int byte = (cobase + mi * 32 + t_col) * 2;
+            const char* ap = Ad + k0 * RB_A + ((((byte >> 4) ^ row_swz<ES, RB_A>(k0)) << 4) | (byte & 15));
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap + 4 * RB_A));
+            const s16x8 tmp = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            df[mi] = __builtin_bit_cast(bf16x8, tmp);
+          }
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ni], df[mi], acc[mi][ni], 0, 0, 0);
         }
       }
-    } else {
-      const int g = lane >> 4, w = lane & 15, q = w >> 2, pp = w & 3;
-      const int krow = 8 * (g >> 1) + q;
-      const int coff = 16 * (g & 1) + 4 * pp;
-#pragma unroll
-      for (int ks = 0; ks < BKP / 16; ++ks) {
-        const int k0 = ks * 16 + krow;
-        typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
-        const char* bp = Bx + k0 * SB + (jbase + coff) * 2;
-        s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bp));
-        s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bp + 4 * SB));
-        bf16x8 bfrag;
-        {
-          typedef short s16x8 __attribute__((ext_vector_type(8)));
-          s16x8 tmp = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
-          bfrag = __builtin_bit_cast(bf16x8, tmp);
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const char* ap = Ad + k0 * SA + (ibase + mi * 32 + coff) * 2;
-          s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap));
-          s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap + 4 * SA));
-          typedef short s16x8 __attribute__((ext_vector_type(8)));
-          s16x8 tmp = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
-          bf16x8 afrag = __builtin_bit_cast(bf16x8, tmp);
-          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[mi], 0, 0, 0);
-        }
-      }
+      stage ^= 1;
     }
-    __syncthreads();
-    if (more) {
-      store_chunk();
-      __syncthreads();
-    }
-  }
 
-  // partial[split][co][wtap][ck]
-  float* outp = p.partial + (size_t)split * p.Cout * p.wtaps * p.Ck;
+    // partial[split][co][wtap][ci]: D rows (registers) = input channels, D columns (lanes) = output channels
+    float* outp = p.partial + (size_t)split * p.Cout * p.wtaps * p.Ck;
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
+      const int co = cb * BMC + cobase + mi * 32 + c31;
+      float* rowp = outp + ((size_t)co * p.wtaps + wtap) * p.Ck + cib * BNC + cibase;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + ibase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int ci = ci0 + jbase + (lane & 31);
-      outp[((size_t)co * p.wtaps + tp.wtap) * p.Ck + ci] = acc[mi][r];
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(rowp + ni * 32 + 8 * g + 4 * hh) = v;
+        }
     }
+    pending_st += NST;
   }
 }
 
@@ -208,7 +284,18 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int spli
                                      float* __restrict__ dst, size_t n4, float beta) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(partial + (size_t)k * stride + i * 4);
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {  // 4 slabs in flight; the order of the adds stays k = 0,1,2,...
+      const f32x4 a = *reinterpret_cast<const f32x4*>(partial + (size_t)k * stride + i * 4);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(partial + (size_t)(k + 1) * stride + i * 4);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(partial + (size_t)(k + 2) * stride + i * 4);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(partial + (size_t)(k + 3) * stride + i * 4);
+      s += a;
+      s += b;
+      s += c;
+      s += d;
+    }
+    for (; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(partial + (size_t)k * stride + i * 4);
     f32x4* d = reinterpret_cast<f32x4*>(dst + i * 4);
     if (beta != 0.f) s += beta * (*d);
     *d = s;
@@ -231,7 +318,10 @@ __global__ void stem_unpack_kernel(const float* __restrict__ partial, int splits
   dw[i] = (beta != 0.f ? beta * dw[i] : 0.f) + s;
 }
 
-template <typename T, int BMC>
+inline int wg_bmc(int Cout) { return Cout % 128 == 0 ? 128 : 64; }
+inline int wg_bnc(int Ck) { return Ck % 128 == 0 ? 128 : 64; }
+
+template <typename T, int BMC, int BNC>
 int launch_t(const WgradArgs& a, int splits, hipStream_t stream) {
   constexpr int ES = (int)sizeof(T);
   constexpr int BKP = 128 / ES;
@@ -240,41 +330,47 @@ int launch_t(const WgradArgs& a, int splits, hipStream_t stream) {
   k.M = a.N * a.Ho * a.Wo;
   k.dWo = make_fastdiv((uint32_t)a.Wo);
   k.dHo = make_fastdiv((uint32_t)a.Ho);
-  const int tiles = (a.Cout / BMC) * a.ntaps * (a.Ck / BNC);
-  const size_t lds = (size_t)BKP * ((BMC * ES + 64) + (BNC * ES + 64));
-  hipLaunchKernelGGL((wgrad_kernel<T, BMC>), dim3(tiles, splits), dim3(256), lds, stream, k);
+  k.tiles = (a.Cout / BMC) * a.ntaps * (a.Ck / BNC);
+  k.splits = splits;
+  k.items = k.tiles * splits;
+  // splits are planned in 64-pixel units so that fp32 (32-pixel slabs) and bf16 (64) cut the pixels identically
+  k.pix_per_split = cdiv(cdiv(k.M, 64), splits) * 64;
+  static_assert(64 % BKP == 0, "slab size must divide the planning unit");
+  const int grid = k.items < MAX_WG ? k.items : MAX_WG;
+  const size_t lds = (size_t)2 * BKP * (BMC + BNC) * ES;
+  hipLaunchKernelGGL((wgrad_kernel<T, BMC, BNC>), dim3(grid), dim3(256), lds, stream, k);
   MI355_LAUNCH_CHECK();
   return 0;
+}
+
+template <typename T>
+int launch_d(const WgradArgs& a, int splits, hipStream_t stream) {
+  const int bmc = wg_bmc(a.Cout), bnc = wg_bnc(a.Ck);
+  if (bmc == 128) return bnc == 128 ? launch_t<T, 128, 128>(a, splits, stream) : launch_t<T, 128, 64>(a, splits, stream);
+  return bnc == 128 ? launch_t<T, 64, 128>(a, splits, stream) : launch_t<T, 64, 64>(a, splits, stream);
 }
 
 }  // namespace
 
 int plan_wgrad_splits(int M, int Cout, int ntaps, int Ck) {
-  const int bmc = (Cout % 128 == 0) ? 128 : 64;
-  const int tiles = (Cout / bmc) * ntaps * (Ck / BNC);
-  // chunk granularity must hold for both dtypes: plan in 64-pixel units
+  const int tiles = (Cout / wg_bmc(Cout)) * ntaps * (Ck / wg_bnc(Ck));
   const int chunks = cdiv(M, 64);
-  int splits = cdiv(1024, tiles);
-  if (splits > chunks) splits = chunks;
+  // aim at ~2 items per persistent workgroup, but keep >= 8 slabs of 64 pixels per item so the pipeline has a body
+  int splits = cdiv(2 * MAX_WG, tiles);
+  const int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;
+  if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   const int cps = cdiv(chunks, splits);
   return cdiv(chunks, cps);
 }
 
-int launch_wgrad(int dtype, const WgradArgs& a0, int splits, hipStream_t stream) {
-  MI355_ARG(a0.dy && a0.x && a0.partial, "wgrad: null pointer");
-  MI355_ARG(a0.Cout % 64 == 0 && a0.Ck % 64 == 0, "wgrad: Cout=%d Ck=%d must be multiples of 64", a0.Cout, a0.Ck);
+int launch_wgrad(int dtype, const WgradArgs& a, int splits, hipStream_t stream) {
+  MI355_ARG(a.dy && a.x && a.partial, "wgrad: null pointer");
+  MI355_ARG(a.Cout % 64 == 0 && a.Ck % 64 == 0, "wgrad: Cout=%d Ck=%d must be multiples of 64", a.Cout, a.Ck);
   MI355_ARG(splits >= 1, "wgrad: splits=%d", splits);
-  WgradArgs a = a0;
-  const int M = a.N * a.Ho * a.Wo;
-  const int bkp = 128 / (int)dtype_size(dtype);
-  // splits were planned in 64-pixel units; convert to this dtype's chunk size
-  const int cps64 = cdiv(cdiv(M, 64), splits);
-  a.chunks_per_split = cps64 * (64 / bkp);
-  const bool wide = (a.Cout % 128 == 0);
-  if (dtype == MI355_F32) return wide ? launch_t<float, 128>(a, splits, stream) : launch_t<float, 64>(a, splits, stream);
-  if (dtype == MI355_BF16)
-    return wide ? launch_t<bf16_t, 128>(a, splits, stream) : launch_t<bf16_t, 64>(a, splits, stream);
+  MI355_ARG(((size_t)a.pix_stride * dtype_size(dtype)) % 8 == 0, "wgrad: pixel stride not 8-byte aligned");
+  if (dtype == MI355_F32) return launch_d<float>(a, splits, stream);
+  if (dtype == MI355_BF16) return launch_d<bf16_t>(a, splits, stream);
   set_error("wgrad: bad dtype %d", dtype);
   return MI355_E_ARG;
 }
