@@ -10,10 +10,13 @@
 //   MFMA        4 waves (2x2), each 64 x BN/2 from 32x32 tiles: v_mfma_f32_32x32x2_f32 (exact fp32, the parity
 //               path) / v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  Operands are swapped (D^T = W * A^T) so a
 //               lane ends up holding 4 consecutive channels of one pixel.
-//   staging     direct-to-LDS loads (global_load_lds_dwordx4): every lane supplies its own source address (the A rows
-//               are gathered pixel runs; out-of-image rows read a zero page), the LDS image stays lane-linear
+//   staging     direct-to-LDS buffer loads (buffer_load_dwordx4 ... offen lds): every lane supplies its own 32-bit byte
+//               offset into the tensor's buffer descriptor (the A rows are gathered pixel runs; out-of-image rows get
+//               an out-of-range offset and the hardware range check returns zeros), the LDS image stays lane-linear
 //               ([row][128 B], no padding) and the bank-conflict fix is an XOR of the 16-byte chunk index with
-//               (row>>1)&7 applied to the SOURCE address and again on the fragment ds_read_b128.
+//               (row>>1)&7 applied to the SOURCE offset and again on the fragment ds_read_b128.  The 6-8 loads of
+//               the NEXT slab are issued in pairs between the four MFMA groups of the current slab, so the matrix
+//               pipe keeps running while the loader computes offsets.
 //   pipeline    persistent workgroups walk (row-tile, n-tile, k-slab) as ONE stream through a 2-stage LDS ring:
 //               the loads of the next slab — also across tile boundaries, i.e. under the previous tile's epilogue —
 //               are in flight while the current slab feeds the MFMAs; counted `s_waitcnt vmcnt(N)` + raw s_barrier
@@ -21,6 +24,7 @@
 //   epilogue    each wave stages its 32 x BN/2 fp32 sub-tile through (XOR-swizzled) LDS and writes 16 bytes per lane,
 //               64..256 contiguous bytes per pixel; the optional addend (residual gradient) is read the same way.
 #include "common.h"
+#include "lds_dma.h"
 #include "vec.h"
 
 namespace mi355 {
@@ -37,33 +41,8 @@ __device__ __attribute__((aligned(256))) unsigned char g_trash[256 * 16];
 struct IgemmKArgs {
   IgemmArgs a;
   int mtiles, ny, nclass, ngroups, ntpg, items;
+  unsigned bytes_in, bytes_wt;
 };
-
-#define MI355_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-#define MI355_LDS_BARRIER()                                \
-  do {                                                     \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
-    __builtin_amdgcn_s_barrier();                          \
-    asm volatile("" ::: "memory");                         \
-  } while (0)
-
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// One 1 KiB LDS-DMA piece: lane l's 16 bytes at `src` land at LDS byte address lds_dst + 16*l (lds_dst wave-uniform).
-// Inline asm on purpose: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the first VALU write of the address
-// registers of a __builtin_amdgcn_global_load_lds, which serialises the very loads this pipeline keeps in flight;
-// the hardware reads the address at issue, so no wait is needed.  M0 is saved/restored around the instruction.
-__device__ __forceinline__ void glds16(const void* src, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(src), "s"(lds_dst)
-      : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-  return (unsigned)(unsigned long long)(lptr_t)p;
-}
 
 template <typename T, int BN>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
@@ -90,14 +69,21 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
   const int G = gridDim.x;
   const int Msub = p.N * p.Hsub * p.Wsub;
   const int kc_per_tap = p.Ck / BK;
-  const char* in_base = (const char*)p.in;
-  const char* wt_base = (const char*)p.wt;
 
   // ---- loader cursor: runs one slab ahead of the MFMAs ------------------------------------------------------------
   const int prow = lane >> 3;  // row within a 1 KiB piece
   const int pch = lane & 7;    // physical 16-byte chunk
   int L_item = blockIdx.x, L_nt = 0, L_kt = 0, L_nk = 0, L_cls = 0, L_grp = 0;
-  int a_hb[4], a_h[4], a_w[4];
+  const i32x4 srdA = make_srd(p.in, kp.bytes_in);
+  const i32x4 srdB = make_srd(p.wt, kp.bytes_wt);
+  unsigned a_off[4];   // byte offset of (row's pixel at tap offset (0,0)) + this lane's swizzled 16-byte chunk
+  int a_h[4], a_w[4];  // i*IS, j*IS of the row (a_h very negative => row beyond the problem)
+  unsigned b_off[PB];  // byte offset of this lane's weight row (n-tile 0, tap 0) + swizzled chunk
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int r = PB * 8 * wave + 8 * i + prow;
+    b_off[i] = (unsigned)r * p.wtaps * p.Ck * ES + (unsigned)((pch ^ ((r >> 1) & 7)) * 16);
+  }
   auto L_setup = [&]() {  // decode the rows this lane stages for item L_item; skips items without taps
     while (L_item < kp.items) {
       const int rowtile = L_item / kp.ngroups;
@@ -111,18 +97,21 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int m = mt * BM + 32 * wave + 8 * i + prow;
+        const int r = 32 * wave + 8 * i + prow;
+        const int m = mt * BM + r;
         if (m < Msub) {
           const int j = m % p.Wsub;
           const int t = m / p.Wsub;
           const int ii = t % p.Hsub;
-          a_hb[i] = (t / p.Hsub) * p.Hin;
+          const int n = t / p.Hsub;
           a_h[i] = ii * p.IS;
           a_w[i] = j * p.IS;
+          a_off[i] = (unsigned)((n * p.Hin + a_h[i]) * p.Win + a_w[i]) * (unsigned)(p.pix_stride * ES) +
+                     (unsigned)((pch ^ ((r >> 1) & 7)) * 16);
         } else {
-          a_hb[i] = -1;
-          a_h[i] = 0;
+          a_h[i] = -(1 << 20);
           a_w[i] = 0;
+          a_off[i] = 0;
         }
       }
       L_nt = 0;
@@ -130,35 +119,33 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
       return;
     }
   };
-  auto L_issue = [&](int stage) {
-    const unsigned As = __builtin_amdgcn_readfirstlane(lds_addr(smem) + stage * STAGE);
-    const unsigned Bs = As + A_BYTES;
+  // per-slab uniform state of the loader, set by L_begin and consumed by L_piece
+  int S_dh = 0, S_dw = 0, S_dA = 0;
+  unsigned S_dB = 0, S_As = 0;
+  auto L_begin = [&](int stage) {
     // the cursor is wave-uniform by construction; say so, or hipcc fetches the tap with a VECTOR load from the kernarg
-    // segment and then waits vmcnt(0) for it in the middle of the LDS-DMA burst
+    // segment and waits vmcnt(0) for it in the middle of the LDS-DMA burst
     const int kt_u = __builtin_amdgcn_readfirstlane(L_kt);
     const int cls_u = __builtin_amdgcn_readfirstlane(L_cls);
     const int t = kt_u / kc_per_tap;
     const int c0 = (kt_u - t * kc_per_tap) * BK;
     const Tap tp = p.cls[cls_u].taps[t];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = 32 * wave + 8 * i + prow;
-      const int c = pch ^ ((r >> 1) & 7);
-      const int ih = a_h[i] + tp.dh;
-      const int iw = a_w[i] + tp.dw;
-      const bool ok = (a_hb[i] >= 0) && ((unsigned)ih < (unsigned)p.Hin) && ((unsigned)iw < (unsigned)p.Win);
-      const long long pix = (long long)(a_hb[i] + ih) * p.Win + iw;  // garbage when !ok, never dereferenced
-      const char* real = in_base + (pix * p.pix_stride + c0) * ES + c * 16;
-      const char* src = ok ? real : (const char*)g_zero_page + c * 16;
-      glds16(src, As + (32 * wave + 8 * i) * BKB);
-    }
+    S_dh = tp.dh;
+    S_dw = tp.dw;
+    S_dA = ((tp.dh * p.Win + tp.dw) * p.pix_stride + c0) * ES;
     const int n0 = __builtin_amdgcn_readfirstlane((L_grp * kp.ntpg + L_nt) * BN);
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const int r = PB * 8 * wave + 8 * i + prow;
-      const int c = pch ^ ((r >> 1) & 7);
-      const char* src = wt_base + (((size_t)(n0 + r) * p.wtaps + tp.wtap) * p.Ck + c0) * ES + c * 16;
-      glds16(src, Bs + (PB * 8 * wave + 8 * i) * BKB);
+    S_dB = ((unsigned)n0 * p.wtaps + tp.wtap) * (unsigned)(p.Ck * ES) + (unsigned)(c0 * ES);
+    S_As = __builtin_amdgcn_readfirstlane(lds_addr(smem) + stage * STAGE);
+  };
+  auto L_piece = [&](int j) {  // j < 4: A piece j;  j >= 4: B piece j-4
+    if (j < 4) {
+      const int ih = a_h[j] + S_dh;
+      const int iw = a_w[j] + S_dw;
+      const bool ok = ((unsigned)ih < (unsigned)p.Hin) && ((unsigned)iw < (unsigned)p.Win);
+      blds16(srdA, ok ? a_off[j] + (unsigned)S_dA : 0x80000000u, S_As + (32 * wave + 8 * j) * BKB);
+    } else {
+      const int i = j - 4;
+      blds16(srdB, b_off[i] + S_dB, S_As + A_BYTES + (PB * 8 * wave + 8 * i) * BKB);
     }
   };
   auto L_advance = [&]() {
@@ -189,7 +176,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
   L_setup();
   int stage = 0;
   if (L_item < kp.items) {
-    L_issue(0);
+    L_begin(0);
+#pragma unroll
+    for (int j = 0; j < 4 + PB; ++j) L_piece(j);
     L_advance();
   }
   int pending_st = 0;
@@ -226,10 +215,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
         }
         pending_st = 0;
         MI355_LDS_BARRIER();  // slab landed for every wave; everyone is done reading the other stage
-        if (L_item < kp.items) {
-          L_issue(stage ^ 1);
-          L_advance();
-        }
+        const bool lv = L_item < kp.items;
+        if (lv) L_begin(stage ^ 1);
         const char* base = smem + stage * STAGE;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {  // four 32-byte k groups per slab; lane half hh takes one 16-byte chunk of each
@@ -241,6 +228,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
               bv[ni] = *reinterpret_cast<const f32x4*>(base + b_row[ni] + (((2 * g + hh) ^ b_sw[ni]) << 4));
+            if (lv) {  // two of the next slab's pieces go out between this group's LDS reads and its MFMAs
+              if (2 * g < 4 + PB) L_piece(2 * g);
+              if (2 * g + 1 < 4 + PB) L_piece(2 * g + 1);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -256,6 +247,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
               bv[ni] = *reinterpret_cast<const bf16x8*>(base + b_row[ni] + (((2 * g + hh) ^ b_sw[ni]) << 4));
+            if (lv) {
+              if (2 * g < 4 + PB) L_piece(2 * g);
+              if (2 * g + 1 < 4 + PB) L_piece(2 * g + 1);
+            }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -263,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[ni], av[mi], acc[mi][ni], 0, 0, 0);
           }
         }
+        if (lv) L_advance();
         stage ^= 1;
       }
 
@@ -357,6 +353,11 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream) {
   k.ngroups = ng;
   k.ntpg = k.ny / ng;
   k.items = R * ng;
+  const size_t bytes_in = (size_t)a.N * a.Hin * a.Win * a.pix_stride * sizeof(T);
+  const size_t bytes_wt = (size_t)a.Ncols * a.wtaps * a.Ck * sizeof(T);
+  MI355_ARG(bytes_in < 0x80000000ull && bytes_wt < 0x80000000ull, "igemm: tensor exceeds the 2 GiB buffer-offset range");
+  k.bytes_in = (unsigned)bytes_in;
+  k.bytes_wt = (unsigned)bytes_wt;
   const int grid = k.items < MAX_WG ? k.items : MAX_WG;
   const size_t lds = (size_t)2 * (BM + BN) * BKB + BM * sizeof(int);
   hipLaunchKernelGGL((igemm_kernel<T, BN>), dim3(grid), dim3(256), lds, stream, k);

@@ -5,8 +5,8 @@
 //   dW[co][tap][ci] = sum over output pixels m of dy[m][co] * x[src(m,tap)][ci]
 // is a GEMM whose reduction index (the pixel) is the SLOW index of both operands in NHWC memory, so both MFMA
 // operands are "transposed".  Slabs of BKP pixels are staged in their natural [pixel][channel] layout by direct-to-LDS
-// loads (global_load_lds_dwordx4; per-lane source address = the tap's gathered pixel, out-of-image rows read a zero
-// page) and read TRANSPOSED out of LDS:
+// buffer loads (buffer_load_dwordx4 ... offen lds; per-lane byte offset = the tap's gathered pixel, out-of-image rows
+// get an out-of-range offset and read zeros) and read TRANSPOSED out of LDS:
 //   fp32 : ds_read_b32 (a lane holds ONE k per v_mfma_f32_32x32x2_f32 operand, lanes run along channels)
 //   bf16 : ds_read_b64_tr_b16 x2 per v_mfma_f32_32x32x16_bf16 operand; the LDS image stays lane-linear and the four
 //          pixel rows a half-wave touches are spread over all 64 banks by XOR-ing the 16-byte chunk index with
@@ -17,14 +17,13 @@
 // (counted s_waitcnt vmcnt + raw s_barrier, as in conv_igemm.hip).  fp32 partial slabs are summed in split order by
 // splitk_reduce (bitwise reproducible, no float atomics).
 #include "common.h"
+#include "lds_dma.h"
 
 namespace mi355 {
 
 namespace {
 
 constexpr int MAX_WG = 512;
-
-__device__ __attribute__((aligned(256))) unsigned char g_wzero_page[1024];
 
 struct FastDiv {
   uint32_t mul, sh;
@@ -45,30 +44,11 @@ struct WgradKArgs {
   WgradArgs a;
   FastDiv dWo, dHo;
   int M, tiles, splits, items, pix_per_split;
+  unsigned bytes_dy, bytes_x;
 };
 
-#define MI355_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-#define MI355_LDS_BARRIER()                                \
-  do {                                                     \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
-    __builtin_amdgcn_s_barrier();                          \
-    asm volatile("" ::: "memory");                         \
-  } while (0)
-
-typedef __attribute__((address_space(3))) void* lptr_t;
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 typedef short s16x8 __attribute__((ext_vector_type(8)));
-
-// see conv_igemm.hip: inline asm so that hipcc does not wait vmcnt(0) on the address registers of an LDS-DMA load
-__device__ __forceinline__ void glds16(const void* src, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(src), "s"(lds_dst)
-      : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long long)(lptr_t)p; }
 
 // XOR applied to the 16-byte chunk index of a staged row (bf16 only; fp32 reads are conflict-free as they are)
 template <int ES, int ROW_BYTES>
@@ -99,11 +79,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
   const int wm = wave >> 1, wn = wave & 1;
   const int G = gridDim.x;
   const int ckb = p.Ck / BNC;
-  const char* dy_base = (const char*)p.dy;
-  const char* x_base = (const char*)p.x;
+  const i32x4 srdA = make_srd(p.dy, kp.bytes_dy);
+  const i32x4 srdB = make_srd(p.x, kp.bytes_x);
 
   // ---- loader cursor (one slab ahead) -----------------------------------------------------------------------------
-  int L_item = blockIdx.x, L_m = 0, L_mend = 0, L_co0 = 0, L_ci0 = 0, L_dh = 0, L_dw = 0;
+  // per-lane constants: row of each piece inside the slab and its swizzled 16-byte chunk
+  int L_item = blockIdx.x, L_m = 0, L_mend = 0, L_dh = 0, L_dw = 0;
+  unsigned L_aoff = 0, L_boff = 0;  // uniform byte offsets: co0*ES / ci0*ES
   auto L_setup = [&]() {
     if (L_item >= kp.items) return;
     const int tile = L_item % kp.tiles;
@@ -115,43 +97,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
     const Tap tp = p.taps[__builtin_amdgcn_readfirstlane(t)];
     L_dh = tp.dh;
     L_dw = tp.dw;
-    L_co0 = cb * BMC;
-    L_ci0 = cib * BNC;
+    L_aoff = (unsigned)(cb * BMC * ES);
+    L_boff = (unsigned)(cib * BNC * ES);
     L_m = split * kp.pix_per_split;
     L_mend = L_m + kp.pix_per_split;
     if (L_mend > kp.M) L_mend = kp.M;
   };
-  auto L_issue = [&](int stage) {
-    const unsigned As = __builtin_amdgcn_readfirstlane(lds_addr(smem) + stage * STAGE);
-    const unsigned Bs = As + A_BYTES;
-    const int m0 = __builtin_amdgcn_readfirstlane(L_m);
-#pragma unroll
-    for (int i = 0; i < PW_A; ++i) {
-      const int piece = wave * PW_A + i;
+  int S_m0 = 0, S_mend = 0;
+  unsigned S_As = 0;
+  auto L_begin = [&](int stage) {
+    S_As = __builtin_amdgcn_readfirstlane(lds_addr(smem) + stage * STAGE);
+    S_m0 = __builtin_amdgcn_readfirstlane(L_m);
+    S_mend = __builtin_amdgcn_readfirstlane(L_mend);
+  };
+  auto L_piece = [&](int j) {  // j < PW_A: dy piece j;  else x piece j-PW_A
+    if (j < PW_A) {
+      const int piece = wave * PW_A + j;
       const int row = piece * RPP_A + lane / LPR_A;
       const int c = (lane % LPR_A) ^ row_swz<ES, RB_A>(row);
-      const int m = m0 + row;
-      const char* real = dy_base + ((size_t)m * p.Cout + L_co0) * ES + c * 16;
-      const char* src = m < L_mend ? real : (const char*)g_wzero_page + c * 16;
-      glds16(src, As + piece * 1024);
-    }
-#pragma unroll
-    for (int i = 0; i < PW_B; ++i) {
-      const int piece = wave * PW_B + i;
+      const int m = S_m0 + row;
+      const unsigned off = (unsigned)m * (unsigned)(p.Cout * ES) + L_aoff + (unsigned)(c * 16);
+      blds16(srdA, m < S_mend ? off : 0x80000000u, S_As + piece * 1024);
+    } else {
+      const int piece = wave * PW_B + (j - PW_A);
       const int row = piece * RPP_B + lane / LPR_B;
       const int c = (lane % LPR_B) ^ row_swz<ES, RB_B>(row);
-      const int m = m0 + row;
+      const int m = S_m0 + row;
       const uint32_t q1 = fdiv((uint32_t)m, kp.dWo);
       const int ow = m - (int)q1 * p.Wo;
       const uint32_t n = fdiv(q1, kp.dHo);
       const int oh = (int)q1 - (int)n * p.Ho;
       const int ih = oh * p.IS + L_dh;
       const int iw = ow * p.IS + L_dw;
-      const bool ok = m < L_mend && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
-      const long long pix = ((long long)n * p.Hin + ih) * p.Win + iw;  // garbage when !ok, never dereferenced
-      const char* real = x_base + (pix * p.pix_stride + L_ci0) * ES + c * 16;
-      const char* src = ok ? real : (const char*)g_wzero_page + c * 16;
-      glds16(src, Bs + piece * 1024);
+      const bool ok = m < S_mend && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+      const unsigned off = (unsigned)(((int)n * p.Hin + ih) * p.Win + iw) * (unsigned)(p.pix_stride * ES) + L_boff +
+                           (unsigned)(c * 16);
+      blds16(srdB, ok ? off : 0x80000000u, S_As + A_BYTES + piece * 1024);
     }
   };
   auto L_advance = [&]() {
@@ -160,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
     L_item += G;
     L_setup();
   };
+  constexpr int NPC = PW_A + PW_B;  // pieces per wave per slab
 
   // ---- per-lane fragment coordinates -------------------------------------------------------------------------------
   const int cobase = wm * (BMC / 2);  // + mi*32 : output channels, on the lanes of D
@@ -173,7 +155,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
   L_setup();
   int stage = 0;
   if (L_item < kp.items) {
-    L_issue(0);
+    L_begin(0);
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) L_piece(j);
     L_advance();
   }
   int pending_st = 0;
@@ -208,10 +192,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
       }
       pending_st = 0;
       MI355_LDS_BARRIER();
-      if (L_item < kp.items) {
-        L_issue(stage ^ 1);
-        L_advance();
-      }
+      const bool lv = L_item < kp.items;
+      if (lv) L_begin(stage ^ 1);
       const char* Ad = smem + stage * STAGE;
       const char* Bx = Ad + A_BYTES;
       if constexpr (ES == 4) {
@@ -223,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
           for (int ni = 0; ni < NI; ++ni) xv[ni] = *reinterpret_cast<const float*>(Bx + k * RB_B + (cibase + ni * 32 + c31) * 4);
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) dv[mi] = *reinterpret_cast<const float*>(Ad + k * RB_A + (cobase + mi * 32 + c31) * 4);
+          if (lv && (kk & 1) == 0 && (kk >> 1) < NPC) L_piece(kk >> 1);  // one piece of the next slab every other k pair
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -252,6 +235,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
             const s16x8 tmp = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             df[mi] = __builtin_bit_cast(bf16x8, tmp);
           }
+          if (lv) {  // two of the next slab's pieces go out between this k-step's LDS reads and its MFMAs
+            if (2 * ks < NPC) L_piece(2 * ks);
+            if (2 * ks + 1 < NPC) L_piece(2 * ks + 1);
+          }
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -259,6 +246,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ni], df[mi], acc[mi][ni], 0, 0, 0);
         }
       }
+      if (lv) L_advance();
       stage ^= 1;
     }
 
@@ -336,6 +324,11 @@ int launch_t(const WgradArgs& a, int splits, hipStream_t stream) {
   // splits are planned in 64-pixel units so that fp32 (32-pixel slabs) and bf16 (64) cut the pixels identically
   k.pix_per_split = cdiv(cdiv(k.M, 64), splits) * 64;
   static_assert(64 % BKP == 0, "slab size must divide the planning unit");
+  const size_t bytes_dy = (size_t)k.M * a.Cout * ES;
+  const size_t bytes_x = (size_t)a.N * a.Hin * a.Win * a.pix_stride * ES;
+  MI355_ARG(bytes_dy < 0x80000000ull && bytes_x < 0x80000000ull, "wgrad: tensor exceeds the 2 GiB buffer-offset range");
+  k.bytes_dy = (unsigned)bytes_dy;
+  k.bytes_x = (unsigned)bytes_x;
   const int grid = k.items < MAX_WG ? k.items : MAX_WG;
   const size_t lds = (size_t)2 * BKP * (BMC + BNC) * ES;
   hipLaunchKernelGGL((wgrad_kernel<T, BMC, BNC>), dim3(grid), dim3(256), lds, stream, k);
