@@ -10,7 +10,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmi355rn.so")
+# MI355RN_LIB lets a benchmark A/B two builds of the library in one process-per-variant run (never a fallback)
+LIB_PATH = os.environ.get("MI355RN_LIB") or os.path.join(_HERE, "lib", "libmi355rn.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mi355rn.h")
 
 F32, BF16 = 0, 1
