@@ -26,7 +26,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2516.6}  # MI355X_MICROARCH.md: dense MFMA peaks (no sparsity)
-KERNEL_NAMES = {0: "igemm_kernel<{T},128>", 1: "igemm_kernel<{T},64>", 2: "wgrad_kernel<{T},128>", 3: "wgrad_kernel<{T},64>"}
+KERNEL_NAMES = {0: "igemm_kernel<{T},128>", 1: "igemm_kernel<{T},64>", 2: "wgrad_kernel<{T},128,*>", 3: "wgrad_kernel<{T},64,*>"}
+
+
+def pmc_traffic(kernel, dtype, batch, size):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/*_pmc_traffic_<dtype>.json, made by tools/pmc_traffic.py; PMC cannot be collected from inside the timed
+    run).  Only valid for the default workload; None otherwise."""
+    import glob
+
+    if (batch, size) != (256, 224):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_traffic_{dtype}.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        rec = json.load(f)["kernels"].get(kernel)
+    return rec["hbm_bytes_per_launch"] if rec else None
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -150,18 +166,20 @@ def main():
         if want_roof:
             best = None
             for k in range(4):
-                tot_ms, launches, flops, _ = model.profile_read(shape, k)
+                tot_ms, launches, flops, nbytes = model.profile_read(shape, k)
                 if launches and (best is None or tot_ms > best[1]):
-                    best = (k, tot_ms, launches, flops)
+                    best = (k, tot_ms, launches, flops, nbytes)
             model.profile(shape, 0)
             if best:
-                k, tot_ms, launches, flops = best
+                k, tot_ms, launches, flops, nbytes = best
                 ach = flops / (tot_ms * 1e-3) / 1e12
                 peak = PEAK_TFLOPS[args.dtype]
+                kname = KERNEL_NAMES[k].format(T="float" if args.dtype == "fp32" else "__bf16")
                 roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": None, "kernel": KERNEL_NAMES[k].format(T="float" if args.dtype == "fp32" else "__bf16"),
+                        "traffic": pmc_traffic(kname, args.dtype, N, S), "kernel": kname,
                         "launches": launches, "avg_launch_ms": round(tot_ms / launches, 4),
-                        "alg_gflop_per_launch": round(flops / launches / 1e9, 3)}
+                        "alg_gflop_per_launch": round(flops / launches / 1e9, 3),
+                        "alg_bytes_per_launch": int(nbytes / launches)}
         _, train_flops = model.flops(N, S, S)
         out = {
             "metric": "images/sec (whole node) ResNet-50 bs=256/GPU @224px",

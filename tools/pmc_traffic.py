@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Condenses two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE — separate passes, TCC slots do not fit both) of
+`bench.py` into per-kernel HBM traffic per launch, as MI355X_MICROARCH.md (HBM / rocprofv3 section) prescribes:
+    hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
+(FETCH_SIZE/WRITE_SIZE count KiB; on gfx950 FETCH_SIZE reports exactly half of a 16-byte-per-lane coalesced read
+stream, which is what every kernel here issues — checked below on bn_reduce<.,0>, whose algorithmic read is exact).
+
+    cd /tmp && export TMPDIR=/tmp && cd $REPO
+    for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- \
+        python3 bench.py --steps 2 --warmup 1 --dtype bf16 --no-cpu-baseline --no-roofline; done
+    python tools/pmc_traffic.py gpurun_out bf16 > profiles/<round>_pmc_traffic_bf16.json
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def short(n):
+    m = re.search(r"(igemm_kernel|wgrad_kernel|bn_reduce_kernel|bn_apply_kernel|bn_bwd_apply_kernel|bn_finalize_kernel|"
+                  r"splitk_reduce_kernel|sgd_kernel|maxpool_\w+_kernel|gap_\w+_kernel|stem_ingest_kernel|weight_prep_kernel)", n)
+    if not m:
+        return None
+    base = m.group(1)
+    if "bool _Accum" in n:  # rocprofv3's demangler garbles <__bf16, 1>
+        return f"{base}<__bf16,1>"
+    if "<" in n:  # demangled
+        t = re.search(base + r"<([^>]*)>", n)
+        return f"{base}<{t.group(1).replace(' ', '')}>" if t else base
+    t = re.search(base + r"I(.*?)EEv", n)  # Itanium-mangled template arguments
+    if not t:
+        return base
+    args, rest = [], t.group(1) + "E"
+    while rest:
+        if rest.startswith("DF16b"):
+            args.append("__bf16"); rest = rest[5:]
+        elif rest.startswith("f"):
+            args.append("float"); rest = rest[1:]
+        elif rest.startswith("Li"):
+            m2 = re.match(r"Li(\d+)E", rest)
+            args.append(m2.group(1)); rest = rest[m2.end():]
+        else:
+            rest = rest[1:]
+    return f"{base}<{','.join(args)}>"
+
+
+def load(root, counter):
+    f = glob.glob(f"{root}/pmc_{counter}/*/*_counter_collection.csv")[0]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if k and r["Counter_Name"] == counter:
+            agg[k][0] += 1
+            agg[k][1] += float(r["Counter_Value"])
+    return agg
+
+
+def main():
+    root, dtype = sys.argv[1], sys.argv[2]
+    fe, wr = load(root, "FETCH_SIZE"), load(root, "WRITE_SIZE")
+    out = {"dtype": dtype, "formula": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch (gfx950 half-count correction)",
+           "kernels": {}}
+    for k in sorted(fe, key=lambda k: -fe[k][1]):
+        n = fe[k][0]
+        f_kib = fe[k][1] / n
+        w_kib = wr[k][1] / max(wr[k][0], 1) if k in wr else 0.0
+        out["kernels"][k] = {"launches": n, "fetch_kib_raw_per_launch": round(f_kib, 1), "write_kib_per_launch": round(w_kib, 1),
+                             "hbm_bytes_per_launch": int((2 * f_kib + w_kib) * 1024)}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
