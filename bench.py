@@ -50,6 +50,11 @@ def cpu_baseline(seconds_budget=25.0):
     from oracle import resnet50_ref as O
     from sota_imagenet_amd.synth import init_state_dict, synthetic_batch
 
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, ncpu)))  # a one-GPU box owns a 16-core share of the host
     ref = O.ResNet50Ref()
     shapes = [(k, tuple(v.shape)) for k, v in ref.state_dict().items()]
     ref.load_state_dict(init_state_dict(shapes, seed=0))
@@ -88,6 +93,7 @@ def main():
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the extra fp32 (configs[1]) measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,28 +115,6 @@ def main():
     from sota_imagenet_amd.synth import synthetic_batch
 
     N, S = args.batch, args.size
-    model = resnet50(dtype=args.dtype).cuda()
-    criterion = CrossEntropyLoss(smoothing=0.1).cuda()
-    opt = SGD([{"params": list(model.parameters())}], lr=0.0, momentum=0.9, weight_decay=3e-5)
-    opt.attach_model(model)
-    net = model
-    if use_ddp:
-        from sota_imagenet_amd.parallel import FlatBucketDDP
-
-        net = FlatBucketDDP(model, device_ids=[local_rank])
-    pool = [synthetic_batch(N, S, seed=0, stream=rank, index=i, device="cuda") for i in range(4)]
-    model.train()
-
-    def step(i):
-        data, target = pool[i % len(pool)]
-        lr = 0.001 + 0.0001 * (i % 8)  # the scheduler writes a new LR every batch (train.py:131)
-        for g in opt.param_groups:
-            g["lr"] = lr
-        loss = criterion(net(data), target)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        return loss
 
     def fence():
         if use_ddp:
@@ -139,25 +123,52 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    def run(dtype, steps, warmup, want_roof):
+        """W untimed + exactly K timed training steps in `dtype`; returns (seconds, final loss, model)."""
+        model = resnet50(dtype=dtype).cuda()
+        criterion = CrossEntropyLoss(smoothing=0.1).cuda()
+        opt = SGD([{"params": list(model.parameters())}], lr=0.0, momentum=0.9, weight_decay=3e-5)
+        opt.attach_model(model)
+        net = model
+        if use_ddp:
+            from sota_imagenet_amd.parallel import FlatBucketDDP
+
+            net = FlatBucketDDP(model, device_ids=[local_rank])
+        pool = [synthetic_batch(N, S, seed=0, stream=rank, index=i, device="cuda") for i in range(4)]
+        model.train()
+
+        def step(i):
+            data, target = pool[i % len(pool)]
+            lr = 0.001 + 0.0001 * (i % 8)  # the scheduler writes a new LR every batch (train.py:131)
+            for g in opt.param_groups:
+                g["lr"] = lr
+            loss = criterion(net(data), target)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss
+
+        for i in range(warmup):
+            step(i)
+        if want_roof:
+            model.profile((N, S, S), 0b1111)  # the four conv kernel symbols
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = step(warmup + i)
+        fence()
+        dt = time.perf_counter() - t0
+        if use_ddp:
+            import torch.distributed as dist
+
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt, loss.item(), model
+
     shape = (N, S, S)
     want_roof = (not args.no_roofline) and rank == 0
-    if want_roof:
-        model.profile(shape, 0b1111)  # the four conv kernel symbols
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    if use_ddp:
-        import torch.distributed as dist
-
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    final_loss = loss.item()
+    dt, final_loss, model = run(args.dtype, args.steps, args.warmup, want_roof)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -192,6 +203,16 @@ def main():
                        "step_tflops": round(train_flops / (dt / args.steps) / 1e12, 2), "final_loss": round(final_loss, 4)},
             "roofline": roof,
         }
+        if world == 1 and not use_ddp and args.dtype == "bf16" and not args.no_secondary:
+            # BASELINE.json configs[1] (fp32, single MI355X) measured in the same process, for reference next to `value`
+            del model
+            torch.cuda.empty_cache()
+            dt2, loss2, m2 = run("fp32", max(3, args.steps // 4), 2, False)
+            k2 = max(3, args.steps // 4)
+            out["secondary"] = {"dtype": "fp32", "workload": "BASELINE configs[1]: ResNet-50 fp32 single MI355X bs=256 224px",
+                                "value": round(N * k2 / dt2, 1), "unit": "images/sec", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 3),
+                                "final_loss": round(loss2, 4)}
+            del m2
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
