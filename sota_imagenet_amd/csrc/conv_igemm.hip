@@ -23,6 +23,8 @@
 //               (never __syncthreads, whose fence would drain the LDS-DMA queue).  2 workgroups per CU (64.5 KiB each).
 //   epilogue    each wave stages its 32 x BN/2 fp32 sub-tile through (XOR-swizzled) LDS and writes 16 bytes per lane,
 //               64..256 contiguous bytes per pixel; the optional addend (residual gradient) is read the same way.
+#include <type_traits>
+
 #include "common.h"
 #include "lds_dma.h"
 #include "vec.h"
@@ -218,44 +220,41 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
         const bool lv = L_item < kp.items;
         if (lv) L_begin(stage ^ 1);
         const char* base = smem + stage * STAGE;
+        // Four 32-byte k groups per slab; lane half hh takes one 16-byte chunk of each.  The fragments of group g+1 are
+        // read from LDS BEFORE the MFMAs of group g are issued (two register sets, static indices), and two of the next
+        // slab's LDS-DMA pieces go out in between, so LDS latency and offset arithmetic hide under the matrix pipe.
+        typedef typename std::conditional<ES == 4, f32x4, bf16x8>::type frag_t;
+        frag_t av[2][2], bv[2][NI];
+        auto read_frags = [&](int g, int set) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {  // four 32-byte k groups per slab; lane half hh takes one 16-byte chunk of each
+          for (int mi = 0; mi < 2; ++mi)
+            av[set][mi] = *reinterpret_cast<const frag_t*>(base + a_row[mi] + (((2 * g + hh) ^ a_sw[mi]) << 4));
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            bv[set][ni] = *reinterpret_cast<const frag_t*>(base + b_row[ni] + (((2 * g + hh) ^ b_sw[ni]) << 4));
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (g + 1 < 4) read_frags(g + 1, (g + 1) & 1);
+          if (lv) {
+            if (2 * g < 4 + PB) L_piece(2 * g);
+            if (2 * g + 1 < 4 + PB) L_piece(2 * g + 1);
+          }
           if constexpr (ES == 4) {
-            f32x4 av[2], bv[NI];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-              av[mi] = *reinterpret_cast<const f32x4*>(base + a_row[mi] + (((2 * g + hh) ^ a_sw[mi]) << 4));
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-              bv[ni] = *reinterpret_cast<const f32x4*>(base + b_row[ni] + (((2 * g + hh) ^ b_sw[ni]) << 4));
-            if (lv) {  // two of the next slab's pieces go out between this group's LDS reads and its MFMAs
-              if (2 * g < 4 + PB) L_piece(2 * g);
-              if (2 * g + 1 < 4 + PB) L_piece(2 * g + 1);
-            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
               for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[ni][e], av[mi][e], acc[mi][ni], 0, 0, 0);
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[g & 1][ni][e], av[g & 1][mi][e], acc[mi][ni], 0, 0, 0);
           } else {
-            bf16x8 av[2], bv[NI];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-              av[mi] = *reinterpret_cast<const bf16x8*>(base + a_row[mi] + (((2 * g + hh) ^ a_sw[mi]) << 4));
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-              bv[ni] = *reinterpret_cast<const bf16x8*>(base + b_row[ni] + (((2 * g + hh) ^ b_sw[ni]) << 4));
-            if (lv) {
-              if (2 * g < 4 + PB) L_piece(2 * g);
-              if (2 * g + 1 < 4 + PB) L_piece(2 * g + 1);
-            }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
               for (int ni = 0; ni < NI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[ni], av[mi], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[g & 1][ni], av[g & 1][mi], acc[mi][ni], 0, 0, 0);
           }
         }
         if (lv) L_advance();
