@@ -18,6 +18,17 @@ namespace {
 
 constexpr int MAXBLK = 512;
 
+// V (4 or 8) consecutive per-channel constants with 16-byte loads (c0 is a multiple of V): one or two load
+// instructions instead of V — the per-thread prologue matters for the small late-layer tensors
+template <int V>
+__device__ __forceinline__ void load_consts(const float* __restrict__ p, int c0, float (&v)[V]) {
+#pragma unroll
+  for (int q = 0; q < V / 4; ++q) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p + c0 + 4 * q);
+    v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+  }
+}
+
 struct ReduceArgs {
   const void* x;      // pre-BN tensor [M][C]
   const void* g;      // upstream gradient (bwd) or null
@@ -55,11 +66,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
     is[e] = 0.f;
   }
   if (MODE == 1) {
-#pragma unroll
-    for (int e = 0; e < V; ++e) {
-      mu[e] = p.mean[c0 + e];
-      is[e] = p.invstd[c0 + e];
-    }
+    load_consts<V>(p.mean, c0, mu);
+    load_consts<V>(p.invstd, c0, is);
   } else {
     // shifted sums: var = E[(x-p)^2] - E[x-p]^2 with p a sample of the channel => no catastrophic
     // cancellation when |mean| >> std (the oracle's torch-CPU path accumulates in fp64)
@@ -263,12 +271,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int c0 = (int)(i % p.cvecs) * V;
   float sc[V], sh[V], sc2[V], sh2[V];
+  load_consts<V>(p.scale, c0, sc);
+  load_consts<V>(p.shift, c0, sh);
+  if (x2) {
+    load_consts<V>(p.scale2, c0, sc2);
+    load_consts<V>(p.shift2, c0, sh2);
+  } else {
 #pragma unroll
-  for (int e = 0; e < V; ++e) {
-    sc[e] = p.scale[c0 + e];
-    sh[e] = p.shift[c0 + e];
-    sc2[e] = x2 ? p.scale2[c0 + e] : 0.f;
-    sh2[e] = x2 ? p.shift2[c0 + e] : 0.f;
+    for (int e = 0; e < V; ++e) {
+      sc2[e] = 0.f;
+      sh2[e] = 0.f;
+    }
   }
 #pragma unroll 2
   for (; i < p.nvec; i += stride) {
@@ -319,14 +332,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p)
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int c0 = (int)(i % p.cvecs) * V;
   float mu[V], is[V], k0[V], k1[V], k2[V];
-#pragma unroll
-  for (int e = 0; e < V; ++e) {
-    mu[e] = p.mean[c0 + e];
-    is[e] = p.invstd[c0 + e];
-    k0[e] = p.coef[c0 + e];
-    k1[e] = p.coef[p.C + c0 + e];
-    k2[e] = p.coef[2 * p.C + c0 + e];
-  }
+  load_consts<V>(p.mean, c0, mu);
+  load_consts<V>(p.invstd, c0, is);
+  load_consts<V>(p.coef, c0, k0);
+  load_consts<V>(p.coef + p.C, c0, k1);
+  load_consts<V>(p.coef + 2 * p.C, c0, k2);
 #pragma unroll 2
   for (; i < p.nvec; i += stride) {
     float gv[V], xv[V];
@@ -361,8 +371,9 @@ int reduce_grid(int dtype, int M, int C, dim3* grid) {
 }
 
 int elementwise_blocks(size_t nvec, int cvecs) {
-  size_t b = (nvec + 255) / 256;
+  size_t b = (nvec + 4 * 256 - 1) / (4 * 256);  // >= 4 vectors per thread: amortises the per-channel constant loads
   if (b > 4096) b = 4096;
+  if (b < 4) b = 4;
   // stride = b*256 must be a multiple of cvecs (a power of two <= 1024): make b a multiple of 4
   b = (b + 3) / 4 * 4;
   (void)cvecs;
