@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
     }
   }
   const int step = gridDim.x * rpp;
-#pragma unroll 2
+#pragma unroll 4
   for (int m = blockIdx.x * rpp + r; m < p.M; m += step) {
     const size_t off = (size_t)m * p.C + c0;
     float xv[V];
