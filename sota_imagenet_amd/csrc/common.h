@@ -97,7 +97,7 @@ struct WgradArgs {
 // ---- kernel launchers (all enqueue on `stream`, return mi355_status) -------------------------------
 int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream);
 // splits chosen by plan_wgrad_splits(); partial must hold splits*Cout*wtaps*Ck floats
-int plan_wgrad_splits(int M, int Cout, int ntaps, int Ck);
+int plan_wgrad_splits(int dtype, int M, int Cout, int ntaps, int Ck);
 int launch_wgrad(int dtype, const WgradArgs& a, int splits, hipStream_t stream);
 // dst[i] = beta*dst[i] + sum_s partial[s][i], i < n  (n multiple of 4); deterministic order
 int launch_splitk_reduce(const float* partial, int splits, size_t stride, float* dst, size_t n, float beta,

@@ -153,7 +153,7 @@ size_t mi355_conv2d_workspace_bytes(int dtype, int N, int H, int W, int Cin, int
   const size_t es = dtype_size(dtype);
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   const size_t wbytes = align_up((size_t)Cin * KH * KW * Cout * es, 256);
-  const int splits = plan_wgrad_splits(N * Ho * Wo, Cout, KH * KW, Cin);
+  const int splits = plan_wgrad_splits(dtype, N * Ho * Wo, Cout, KH * KW, Cin);
   const size_t pbytes = align_up((size_t)splits * Cout * KH * KW * Cin * 4, 256);
   return wbytes + pbytes + wbytes;  // transposed + partials + cast copy
 }
@@ -189,7 +189,7 @@ int mi355_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw, floa
   MI355_TRY(check_conv(dtype, Cin, Cout, KH, KW, stride));
   WgradArgs a;
   build_wgrad_args(a, N, H, W, Cin, Cout, KH, KW, stride, pad);
-  const int splits = plan_wgrad_splits(a.N * a.Ho * a.Wo, Cout, KH * KW, Cin);
+  const int splits = plan_wgrad_splits(dtype, a.N * a.Ho * a.Wo, Cout, KH * KW, Cin);
   const size_t n = (size_t)Cout * KH * KW * Cin;
   MI355_ARG(ws && ws_bytes >= (size_t)splits * n * 4, "wgrad: workspace too small (%zu < %zu)", ws_bytes,
             (size_t)splits * n * 4);
@@ -204,7 +204,7 @@ size_t mi355_stem_xpad_bytes(int dtype, int N, int H, int W) {
 }
 
 size_t mi355_stem_workspace_bytes(int dtype, int N, int H, int W) {
-  const int splits = plan_wgrad_splits(N * (H / 2) * (W / 2), 64, 7, STEM_CK);
+  const int splits = plan_wgrad_splits(dtype, N * (H / 2) * (W / 2), 64, 7, STEM_CK);
   return align_up((size_t)64 * 7 * 64 * dtype_size(dtype), 256) + (size_t)splits * 64 * 7 * 64 * 4;
 }
 
@@ -229,7 +229,7 @@ int mi355_stem_wgrad(int dtype, const void* dy, const void* xpad, float* dw, flo
                      size_t ws_bytes, void* stream) {
   WgradArgs a;
   build_stem_wgrad_args(a, N, H, W);
-  const int splits = plan_wgrad_splits(a.N * a.Ho * a.Wo, 64, 7, STEM_CK);
+  const int splits = plan_wgrad_splits(dtype, a.N * a.Ho * a.Wo, 64, 7, STEM_CK);
   MI355_ARG(ws && ws_bytes >= (size_t)splits * 64 * 7 * 64 * 4, "stem_wgrad: workspace too small");
   a.dy = dy; a.x = xpad; a.partial = (float*)ws;
   hipStream_t s = (hipStream_t)stream;

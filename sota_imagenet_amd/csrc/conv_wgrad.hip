@@ -345,11 +345,13 @@ int launch_d(const WgradArgs& a, int splits, hipStream_t stream) {
 
 }  // namespace
 
-int plan_wgrad_splits(int M, int Cout, int ntaps, int Ck) {
+int plan_wgrad_splits(int dtype, int M, int Cout, int ntaps, int Ck) {
   const int tiles = (Cout / wg_bmc(Cout)) * ntaps * (Ck / wg_bnc(Ck));
   const int chunks = cdiv(M, 64);
-  // aim at ~2 items per persistent workgroup, but keep >= 8 slabs of 64 pixels per item so the pipeline has a body
-  int splits = cdiv(2 * MAX_WG, tiles);
+  // items per persistent workgroup: ~1 in bf16 (halves the fp32 partial-slab traffic, which is what bounds the small
+  // layers there), ~2 in fp32 (compute-bound: the finer grain evens out the tail) — measured same-box A/B; keep >= 8
+  // slabs of 64 pixels per item so the pipeline has a body
+  int splits = cdiv((dtype == MI355_F32 ? 2 : 1) * MAX_WG, tiles);
   const int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

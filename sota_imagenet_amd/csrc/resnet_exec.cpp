@@ -268,10 +268,10 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
       const size_t wn = (size_t)l.Cout * l.K * l.K * l.Cin;
       if (c->dtype != MI355_F32) ar.add(&l.w_cast, wn * c->es);
       ar.add(&l.w_tr, wn * c->es);
-      l.splits = plan_wgrad_splits(N * l.Hout * l.Wout, l.Cout, l.K * l.K, l.Cin);
+      l.splits = plan_wgrad_splits(c->dtype, N * l.Hout * l.Wout, l.Cout, l.K * l.K, l.Cin);
       max_wg = std::max(max_wg, (size_t)l.splits * wn * 4);
     } else {
-      l.splits = plan_wgrad_splits(N * l.Hout * l.Wout, 64, 7, STEM_CK);
+      l.splits = plan_wgrad_splits(c->dtype, N * l.Hout * l.Wout, 64, 7, STEM_CK);
       max_wg = std::max(max_wg, (size_t)l.splits * 64 * 7 * 64 * 4);
     }
   };
@@ -297,7 +297,7 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
   ar.add((void**)&c->dpooled, (size_t)N * 2048 * 4);
   ar.add((void**)&c->fc_wtr, (size_t)fcp * 2048 * 4);
   {
-    const int fsplits = plan_wgrad_splits(N, fcp, 1, 2048);
+    const int fsplits = plan_wgrad_splits(MI355_F32, N, fcp, 1, 2048);
     max_wg = std::max(max_wg, (size_t)fsplits * fcp * 2048 * 4);
   }
   ar.add((void**)&c->bn_partial, (size_t)bn_max_blocks() * 2 * max_c * 4);
@@ -332,7 +332,7 @@ int backward_fc(mi355_ctx* c, const float* dlogits, float beta_acc, hipStream_t 
   WgradArgs w;
   build_wgrad_args(w, N, 1, 1, 2048, P, 1, 1, 1, 0);
   w.dy = c->dlogits_pad; w.x = c->pooled; w.partial = c->wg_partial;
-  const int splits = plan_wgrad_splits(N, P, 1, 2048);
+  const int splits = plan_wgrad_splits(MI355_F32, N, P, 1, 2048);
   MI355_TRY(launch_wgrad(MI355_F32, w, splits, s));
   MI355_TRY(launch_splitk_reduce(c->wg_partial, splits, (size_t)P * 2048, c->grads + c->fc_w_off, (size_t)O * 2048,
                                  beta_acc, s));
