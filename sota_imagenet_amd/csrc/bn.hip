@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const FinalizeArgs p) 
     const double M = (double)p.M;
     if (MODE == 0) {
       const double dm = s1 / M;  // mean of (x - pivot)
-      const double mean = (double)p.pivot[c] + dm;
+      const double mean = (p.pivot ? (double)p.pivot[c] : 0.0) + dm;
       double var = s2 / M - dm * dm;
       if (var < 0.0) var = 0.0;
       const float invstd = (float)(1.0 / sqrt(var + (double)p.eps));
@@ -388,7 +388,7 @@ int check_c(int dtype, int C) {
 
 }  // namespace
 
-int bn_max_blocks() { return MAXBLK; }
+int bn_max_blocks() { return 2 * MAXBLK; }  // conv-epilogue statistics use 2 partial rows per workgroup (<= 1024)
 
 int launch_bn_stats(int dtype, const void* x, float* partial, float* pivot, int* nblk_out, int M, int C,
                     hipStream_t s) {

@@ -74,6 +74,7 @@ struct IgemmArgs {
   const void* wt;      // [Ncols][wtaps][Ck], K-contiguous
   void* out;           // [N][Hout][Wout][Ncols]
   const void* addend;  // optional, laid out like out
+  float* stat_partial; // optional [2*workgroups][2][Ncols]: per (workgroup, wave-row) sums of out and out^2 (BN statistics)
   int N, Hin, Win, pix_stride;
   int Hsub, Wsub, IS;
   int Hout, Wout, OS;
@@ -95,7 +96,8 @@ struct WgradArgs {
 };
 
 // ---- kernel launchers (all enqueue on `stream`, return mi355_status) -------------------------------
-int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream);
+// stat_rows (optional): number of partial rows written to a.stat_partial, 0 if the statistics were not produced
+int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows = nullptr);
 // splits chosen by plan_wgrad_splits(); partial must hold splits*Cout*wtaps*Ck floats
 int plan_wgrad_splits(int dtype, int M, int Cout, int ntaps, int Ck);
 int launch_wgrad(int dtype, const WgradArgs& a, int splits, hipStream_t stream);

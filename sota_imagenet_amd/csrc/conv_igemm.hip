@@ -46,7 +46,7 @@ struct IgemmKArgs {
   unsigned bytes_in, bytes_wt;
 };
 
-template <typename T, int BN>
+template <typename T, int BN, bool STATS>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
   const IgemmArgs& p = kp.a;
   constexpr int ES = (int)sizeof(T);
@@ -63,6 +63,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
   constexpr int SCH = WN / 4;              // 16-byte fp32 chunks per staged row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* row_pix = reinterpret_cast<int*>(smem + 2 * STAGE);
+  // STATS: per-workgroup BN statistics of the outputs, [wave-row wm][channel of this workgroup's n-tiles][sum, sum^2]
+  float* stat_acc = reinterpret_cast<float*>(smem + 2 * STAGE + BM * sizeof(int));
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -175,6 +177,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
   }
 
   // ---- prologue ---------------------------------------------------------------------------------------------------
+  if constexpr (STATS) {  // zeroed before the first barrier; first touched after the first epilogue barrier
+    for (int i = tid; i < 2 * kp.ntpg * BN * 2; i += 256) stat_acc[i] = 0.f;
+  }
   L_setup();
   int stage = 0;
   if (L_item < kp.items) {
@@ -278,6 +283,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
       }
       const int prw = lane & 31;
       const int rr = lane / CPR, ch = lane % CPR;
+      float s1[VEC], s2[VEC];  // STATS: this lane's share of sum / sum of squares of the tile's outputs AS STORED
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        s1[e] = 0.f;
+        s2[e] = 0.f;
+      }
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         // a lane holds pixel prw and, per register group g, channels ni*32 + 8g + 4hh + {0..3}
@@ -326,16 +337,66 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
           // rows past the end of the problem go to a trash page so that every thread issues exactly NST stores
           T* dst = pix < 0 ? reinterpret_cast<T*>(g_trash + tid * 16) : out + o;
           Vec16<T>::store(dst, v);
+          if constexpr (STATS) {
+            if (pix >= 0) {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) {
+                const float xr = (float)(T)v[e];
+                s1[e] += xr;
+                s2[e] += xr * xr;
+              }
+            }
+          }
         }
         asm volatile("" ::: "memory");
       }
+      if constexpr (STATS) {
+        // lanes with the same channel chunk sit CPR lanes apart (rows rr): park the per-lane sums in the wave-private
+        // staging region, let lane c add up channel c's RPI rows and add the result to THIS wave's accumulator slot
+        // (one fixed lane per slot, LDS is in-order per wave => deterministic, no atomics, nothing leaves the CU).
+        float* scr = reinterpret_cast<float*>(stg);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) {
+          const f32x4 a = {s1[4 * q], s1[4 * q + 1], s1[4 * q + 2], s1[4 * q + 3]};
+          const f32x4 b = {s2[4 * q], s2[4 * q + 1], s2[4 * q + 2], s2[4 * q + 3]};
+          *reinterpret_cast<f32x4*>(scr + rr * WN + ch * VEC + 4 * q) = a;
+          *reinterpret_cast<f32x4*>(scr + (RPI + rr) * WN + ch * VEC + 4 * q) = b;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < WN) {
+          float a = 0.f, b = 0.f;
+#pragma unroll
+          for (int r = 0; r < RPI; ++r) {
+            a += scr[r * WN + lane];
+            b += scr[(RPI + r) * WN + lane];
+          }
+          float* slot = stat_acc + ((wm * kp.ntpg + nti) * BN + wn * WN + lane) * 2;
+          slot[0] += a;
+          slot[1] += b;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
       pending_st += NST;
+    }
+  }
+  if constexpr (STATS) {
+    // flush: partial[2*workgroup + wm][0|1][channel]; every item of a workgroup has the same n-tile group because
+    // gridDim.x is a multiple of ngroups, so the workgroup owns channels [grp*chan, (grp+1)*chan)
+    MI355_LDS_BARRIER();
+    const int chan = kp.ntpg * BN;
+    const int grp = blockIdx.x % kp.ngroups;
+    for (int i = tid; i < 2 * chan; i += 256) {
+      const int wmi = i / chan, c = i - wmi * chan;
+      float* row = p.stat_partial + (size_t)(2 * blockIdx.x + wmi) * 2 * p.Ncols + grp * chan + c;
+      row[0] = stat_acc[(wmi * chan + c) * 2];
+      row[p.Ncols] = stat_acc[(wmi * chan + c) * 2 + 1];
     }
   }
 }
 
 template <typename T, int BN>
-int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream) {
+int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
   IgemmKArgs k;
   k.a = a;
   const int Msub = a.N * a.Hsub * a.Wsub;
@@ -358,15 +419,26 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream) {
   k.bytes_in = (unsigned)bytes_in;
   k.bytes_wt = (unsigned)bytes_wt;
   const int grid = k.items < MAX_WG ? k.items : MAX_WG;
-  const size_t lds = (size_t)2 * (BM + BN) * BKB + BM * sizeof(int);
-  hipLaunchKernelGGL((igemm_kernel<T, BN>), dim3(grid), dim3(256), lds, stream, k);
+  size_t lds = (size_t)2 * (BM + BN) * BKB + BM * sizeof(int);
+  // BN statistics in the epilogue need [2][channels per workgroup][2] floats of LDS; beyond 512 channels per workgroup
+  // the kernel would drop to one workgroup per CU, so the caller falls back to the standalone statistics kernel
+  const int chan = k.ntpg * BN;
+  const bool stats = a.stat_partial != nullptr && chan <= 512 && grid % ng == 0;
+  if (stat_rows) *stat_rows = stats ? 2 * grid : 0;
+  if (stats) {
+    if (ng > 1) MI355_HIP(hipMemsetAsync(a.stat_partial, 0, (size_t)2 * grid * 2 * a.Ncols * sizeof(float), stream));
+    lds += (size_t)2 * chan * 2 * sizeof(float);
+    hipLaunchKernelGGL((igemm_kernel<T, BN, true>), dim3(grid), dim3(256), lds, stream, k);
+  } else {
+    hipLaunchKernelGGL((igemm_kernel<T, BN, false>), dim3(grid), dim3(256), lds, stream, k);
+  }
   MI355_LAUNCH_CHECK();
   return 0;
 }
 
 }  // namespace
 
-int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream) {
+int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
   const int bk = BKB / (int)dtype_size(dtype);
   MI355_ARG(a.in && a.wt && a.out, "igemm: null pointer");
   MI355_ARG(a.Ck % bk == 0, "igemm: Ck=%d not a multiple of %d", a.Ck, bk);
@@ -375,9 +447,9 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream) 
   MI355_ARG(((size_t)a.pix_stride * dtype_size(dtype)) % 8 == 0, "igemm: pixel stride not 8-byte aligned");
   MI355_ARG(a.N > 0 && a.Hsub > 0 && a.Wsub > 0, "igemm: empty problem");
   const bool wide = (a.Ncols % 128 == 0);
-  if (dtype == MI355_F32) return wide ? launch_t<float, 128>(a, nclass, stream) : launch_t<float, 64>(a, nclass, stream);
+  if (dtype == MI355_F32) return wide ? launch_t<float, 128>(a, nclass, stream, stat_rows) : launch_t<float, 64>(a, nclass, stream, stat_rows);
   if (dtype == MI355_BF16)
-    return wide ? launch_t<bf16_t, 128>(a, nclass, stream) : launch_t<bf16_t, 64>(a, nclass, stream);
+    return wide ? launch_t<bf16_t, 128>(a, nclass, stream, stat_rows) : launch_t<bf16_t, 64>(a, nclass, stream, stat_rows);
   set_error("igemm: bad dtype %d", dtype);
   return MI355_E_ARG;
 }

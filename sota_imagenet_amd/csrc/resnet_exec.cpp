@@ -44,6 +44,7 @@ struct ConvBN {
   void* w_tr = nullptr;                           // transposed copy for dgrad
   float* stat = nullptr;                          // [4][Cout]: save_mean, save_invstd, scale, shift
   int splits = 1;
+  int stat_rows = 0;  // partial rows the last forward conv left in bn_partial (0: none)
   bool is_stem = false;
 };
 
@@ -171,16 +172,19 @@ double conv_flops(const mi355_ctx* c, const ConvBN& l) {
   return 2.0 * c->N * l.Hout * l.Wout * (double)l.Cout * l.Cin * l.K * l.K;
 }
 
-int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, hipStream_t s) {
+// conv forward; in training the epilogue also leaves the BN statistics partials of its output in c->bn_partial
+// (l.stat_rows > 0), unless the shape does not allow it (then bn_prepare runs the standalone statistics kernel)
+int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, hipStream_t s) {
   IgemmArgs a;
   build_fwd_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
   a.in = in;
+  a.stat_partial = training ? c->bn_partial : nullptr;
   a.wt = c->dtype == MI355_F32 ? (const void*)(c->params + l.w_off) : (const void*)l.w_cast;
   a.out = l.y;
   const double fl = conv_flops(c, l);
   const double by = ((double)c->N * l.Hin * l.Win * l.Cin + (double)c->N * l.Hout * l.Wout * l.Cout) * c->es;
   Prof p(c, igemm_class(l.Cout), fl, by, s);
-  return launch_igemm(c->dtype, a, 1, s);
+  return launch_igemm(c->dtype, a, 1, s, &l.stat_rows);
 }
 
 // BN statistics + finalize for one layer (training) or eval coefficients
@@ -193,12 +197,14 @@ int bn_prepare(mi355_ctx* c, ConvBN& l, int training, float momentum, hipStream_
   const float* gamma = c->params + l.gamma_off;
   const float* beta = c->params + l.beta_off;
   if (training) {
-    int nblk = 0;
-    {
+    int nblk = l.stat_rows;
+    const float* pivot = nullptr;  // conv-epilogue partials are plain sums
+    if (nblk == 0) {
       Prof p(c, PC_BN_REDUCE, 0, (double)M * C * c->es, s);
       MI355_TRY(launch_bn_stats(c->dtype, l.y, c->bn_partial, c->bn_coef, &nblk, M, C, s));
+      pivot = c->bn_coef;
     }
-    return launch_bn_finalize(c->bn_partial, c->bn_coef, nblk, M, C, gamma, beta, c->buffers + l.rm_off, c->buffers + l.rv_off,
+    return launch_bn_finalize(c->bn_partial, pivot, nblk, M, C, gamma, beta, c->buffers + l.rm_off, c->buffers + l.rv_off,
                               save_mean, save_invstd, scale, shift, BN_EPS, momentum, s);
   }
   return launch_bn_eval_coeffs(gamma, beta, c->buffers + l.rm_off, c->buffers + l.rv_off, scale, shift, C, BN_EPS, s);
@@ -567,8 +573,9 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
     IgemmArgs a;
     build_stem_fwd_args(a, N, c->H, c->W);
     a.in = c->xpad; a.wt = c->stem_pack; a.out = c->stem.y;
+    a.stat_partial = training ? c->bn_partial : nullptr;
     Prof p(c, PC_IGEMM64, conv_flops(c, c->stem), 0, s);
-    MI355_TRY(launch_igemm(c->dtype, a, 1, s));
+    MI355_TRY(launch_igemm(c->dtype, a, 1, s, &c->stem.stat_rows));
   }
   MI355_TRY(bn_prepare(c, c->stem, training, bn_momentum, s));
   MI355_TRY(bn_apply(c, c->stem, nullptr, nullptr, c->a0, 1, s));
@@ -577,16 +584,16 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
     MI355_TRY(launch_maxpool_fwd(c->dtype, c->a0, c->p0, c->pool_idx, N, c->stem.Hout, c->stem.Wout, 64, s));
   }
   for (auto& b : c->blocks) {
-    MI355_TRY(conv_forward(c, b.c1, b.in, s));
+    MI355_TRY(conv_forward(c, b.c1, b.in, training, s));
     MI355_TRY(bn_prepare(c, b.c1, training, bn_momentum, s));
     MI355_TRY(bn_apply(c, b.c1, nullptr, nullptr, b.a1, 1, s));
-    MI355_TRY(conv_forward(c, b.c2, b.a1, s));
+    MI355_TRY(conv_forward(c, b.c2, b.a1, training, s));
     MI355_TRY(bn_prepare(c, b.c2, training, bn_momentum, s));
     MI355_TRY(bn_apply(c, b.c2, nullptr, nullptr, b.a2, 1, s));
-    MI355_TRY(conv_forward(c, b.c3, b.a2, s));
+    MI355_TRY(conv_forward(c, b.c3, b.a2, training, s));
     MI355_TRY(bn_prepare(c, b.c3, training, bn_momentum, s));
     if (b.has_ds) {
-      MI355_TRY(conv_forward(c, b.ds, b.in, s));
+      MI355_TRY(conv_forward(c, b.ds, b.in, training, s));
       MI355_TRY(bn_prepare(c, b.ds, training, bn_momentum, s));
       MI355_TRY(bn_apply(c, b.c3, nullptr, &b.ds, b.out, 1, s));
     } else {
