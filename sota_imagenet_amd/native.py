@@ -80,6 +80,10 @@ def lib():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the MI355X hot path)"
         )
+    # torch ships its own copy of the HIP runtime: it must be in the process BEFORE libmi355rn.so is loaded so that
+    # both bind to the same runtime instance (loading ours first leaves the library with a second, device-less one)
+    import torch  # noqa: F401
+
     L = ctypes.CDLL(LIB_PATH)
     _protos = parse_header()
     for name, (ret, params) in _protos.items():
