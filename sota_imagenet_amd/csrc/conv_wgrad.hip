@@ -44,6 +44,7 @@ struct WgradKArgs {
   WgradArgs a;
   FastDiv dWo, dHo;
   int M, tiles, splits, items, pix_per_split;
+  int xcd;  // 1: workgroups of one XCD (blockIdx & 7) take consecutive items, so the tiles of one pixel split share its L2
   unsigned bytes_dy, bytes_x;
 };
 
@@ -81,6 +82,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
   const int ckb = p.Ck / BNC;
   const i32x4 srdA = make_srd(p.dy, kp.bytes_dy);
   const i32x4 srdB = make_srd(p.x, kp.bytes_x);
+  // item index of this workgroup in the round that starts at i - blockIdx.x (the ragged last round stays linear)
+  auto remap = [&](int i) {
+    const int r0 = i - (int)blockIdx.x;
+    if (!kp.xcd || r0 + G > kp.items) return i;
+    return r0 + (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
+  };
 
   // ---- loader cursor (one slab ahead) -----------------------------------------------------------------------------
   // per-lane constants: row of each piece inside the slab and its swizzled 16-byte chunk
@@ -88,8 +95,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
   unsigned L_aoff = 0, L_boff = 0;  // uniform byte offsets: co0*ES / ci0*ES
   auto L_setup = [&]() {
     if (L_item >= kp.items) return;
-    const int tile = L_item % kp.tiles;
-    const int split = L_item / kp.tiles;
+    const int v = remap(L_item);
+    const int tile = v % kp.tiles;
+    const int split = v / kp.tiles;
     const int cib = tile % ckb;
     const int r1 = tile / ckb;
     const int t = r1 % p.ntaps;
@@ -163,8 +171,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
   int pending_st = 0;
 
   for (int item = blockIdx.x; item < kp.items; item += G) {
-    const int tile = item % kp.tiles;
-    const int split = item / kp.tiles;
+    const int v = remap(item);
+    const int tile = v % kp.tiles;
+    const int split = v / kp.tiles;
     const int cib = tile % ckb;
     const int r1 = tile / ckb;
     const int t = r1 % p.ntaps;
@@ -330,6 +339,9 @@ int launch_t(const WgradArgs& a, int splits, hipStream_t stream) {
   k.bytes_dy = (unsigned)bytes_dy;
   k.bytes_x = (unsigned)bytes_x;
   const int grid = k.items < MAX_WG ? k.items : MAX_WG;
+  // few tiles per split (small-channel layers): the same dy / x slabs are fetched by every tile of the split, so keep
+  // them on one XCD; with many tiles the round-robin order measured faster
+  k.xcd = (k.tiles <= 16 && k.tiles > 1 && grid % 8 == 0) ? 1 : 0;
   const size_t lds = (size_t)2 * BKP * (BMC + BNC) * ES;
   hipLaunchKernelGGL((wgrad_kernel<T, BMC, BNC>), dim3(grid), dim3(256), lds, stream, k);
   MI355_LAUNCH_CHECK();

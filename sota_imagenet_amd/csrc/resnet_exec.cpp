@@ -9,6 +9,7 @@
 // Schedule (torchvision layout): stem 7x7/2 -> BN -> ReLU -> maxpool 3x3/2 -> 16 bottlenecks
 // (1x1 -> 3x3(stride) -> 1x1, BN after each, ReLU after the first two, residual add + ReLU at the end,
 // 1x1(stride)+BN downsample on the first block of each stage) -> global average pool -> FC.
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -91,7 +92,20 @@ struct mi355_ctx {
   uint8_t* pool_idx = nullptr;
   float *pooled = nullptr, *fc_tmp = nullptr, *dlogits_pad = nullptr, *dpooled = nullptr, *fc_wtr = nullptr;
   float *bn_partial = nullptr, *bn_coef = nullptr, *wg_partial = nullptr;
-  void* gbuf[4] = {nullptr, nullptr, nullptr, nullptr};
+  // backward gradients: gG[2] carry the gradient wrt a block output down the network; gset[p] holds the per-layer
+  // gradients (dy3, dy_ds, dy2, dy1) of the blocks of parity p — two sets so that the weight-gradient stream may
+  // still be reading block k's gradients while block k+1 is written
+  void* gG[2] = {nullptr, nullptr};
+  void* gset[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+  // weight-gradient side stream (wgrad + split-K reduce run beside the BN-backward / dgrad chain of the main stream)
+  bool overlap = false;
+  hipStream_t wstream = nullptr;
+  std::vector<hipEvent_t> fork_ev;
+  size_t fork_next = 0;
+  hipEvent_t w_done[2] = {nullptr, nullptr};
+  bool w_pending[2] = {false, false};
+  bool w_dirty = false;
+  int bwd_parity = 0;
   bool fwd_training_done = false;
   int next_seg = 0;
   void* cur_dout = nullptr;  // gradient wrt the current block output during backward
@@ -309,7 +323,9 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
   ar.add((void**)&c->bn_partial, (size_t)bn_max_blocks() * 2 * max_c * 4);
   ar.add((void**)&c->bn_coef, (size_t)3 * max_c * 4);
   ar.add((void**)&c->wg_partial, max_wg);
-  for (int i = 0; i < 4; ++i) ar.add(&c->gbuf[i], max_act);
+  for (int i = 0; i < 2; ++i) ar.add(&c->gG[i], max_act);
+  for (int p = 0; p < 2; ++p)
+    for (int i = 0; i < 4; ++i) ar.add(&c->gset[p][i], max_act);
   return 0;
 }
 
@@ -331,6 +347,46 @@ int weight_prep_all(mi355_ctx* c, bool need_tr, hipStream_t s) {
   return 0;
 }
 
+// ---- weight-gradient side stream ----------------------------------------------------------------------------------
+// fork(): the stream the next wgrad goes to, ordered after everything issued to `s` so far.
+int fork(mi355_ctx* c, hipStream_t s, hipStream_t* w) {
+  if (!c->overlap) {
+    *w = s;
+    return 0;
+  }
+  hipEvent_t e = c->fork_ev[c->fork_next++ % c->fork_ev.size()];
+  MI355_HIP(hipEventRecord(e, s));
+  MI355_HIP(hipStreamWaitEvent(c->wstream, e, 0));
+  c->w_dirty = true;
+  *w = c->wstream;
+  return 0;
+}
+// before the main stream overwrites gradient set p: the wgrads of the block that used it last must have read it
+int acquire_set(mi355_ctx* c, int p, hipStream_t s) {
+  if (c->overlap && c->w_pending[p]) {
+    MI355_HIP(hipStreamWaitEvent(s, c->w_done[p], 0));
+    c->w_pending[p] = false;
+  }
+  return 0;
+}
+int release_set(mi355_ctx* c, int p) {
+  if (c->overlap) {
+    MI355_HIP(hipEventRecord(c->w_done[p], c->wstream));
+    c->w_pending[p] = true;
+  }
+  return 0;
+}
+// join(): everything on the side stream becomes visible to `s` (end of a backward call: the caller reads the gradients)
+int join(mi355_ctx* c, hipStream_t s) {
+  if (!c->overlap || !c->w_dirty) return 0;
+  hipEvent_t e = c->fork_ev[c->fork_next++ % c->fork_ev.size()];
+  MI355_HIP(hipEventRecord(e, c->wstream));
+  MI355_HIP(hipStreamWaitEvent(s, e, 0));
+  c->w_dirty = false;
+  c->w_pending[0] = c->w_pending[1] = false;
+  return 0;
+}
+
 int backward_fc(mi355_ctx* c, const float* dlogits, float beta_acc, hipStream_t s) {
   const int N = c->N, O = c->num_classes, P = c->fc_pad;
   MI355_TRY(launch_pad_dlogits(dlogits, c->dlogits_pad, P, c->grads + c->fc_b_off, beta_acc, N, O, s));
@@ -339,56 +395,66 @@ int backward_fc(mi355_ctx* c, const float* dlogits, float beta_acc, hipStream_t 
   build_wgrad_args(w, N, 1, 1, 2048, P, 1, 1, 1, 0);
   w.dy = c->dlogits_pad; w.x = c->pooled; w.partial = c->wg_partial;
   const int splits = plan_wgrad_splits(MI355_F32, N, P, 1, 2048);
-  MI355_TRY(launch_wgrad(MI355_F32, w, splits, s));
+  hipStream_t ws;
+  MI355_TRY(fork(c, s, &ws));
+  MI355_TRY(launch_wgrad(MI355_F32, w, splits, ws));
   MI355_TRY(launch_splitk_reduce(c->wg_partial, splits, (size_t)P * 2048, c->grads + c->fc_w_off, (size_t)O * 2048,
-                                 beta_acc, s));
+                                 beta_acc, ws));
   // dgrad: dpooled[n][k] = sum_o dlogits[n][o] * W[o][k]
   IgemmArgs a;
   build_dgrad_args(a, N, 1, 1, 2048, P, 1, 1, 1, 0);
   a.in = c->dlogits_pad; a.wt = c->fc_wtr; a.out = c->dpooled;
   MI355_TRY(launch_igemm(MI355_F32, a, 1, s));
   const Block& last = c->blocks.back();
-  c->cur_dout = c->gbuf[0];
+  c->cur_dout = c->gG[0];
+  c->bwd_parity = 0;
   return launch_gap_bwd(c->dtype, c->dpooled, c->cur_dout, N, last.Hout * last.Wout, last.Cout, s);
-}
-
-void* other_buf(mi355_ctx* c, const void* a, const void* b, const void* d) {
-  for (int i = 0; i < 4; ++i)
-    if (c->gbuf[i] != a && c->gbuf[i] != b && c->gbuf[i] != d) return c->gbuf[i];
-  return nullptr;
 }
 
 int backward_block(mi355_ctx* c, Block& b, float beta_acc, hipStream_t s) {
   void* G = c->cur_dout;  // gradient wrt block output (pre-mask); becomes dz in place
-  void* B1 = other_buf(c, G, nullptr, nullptr);
-  void* B2 = other_buf(c, G, B1, nullptr);
-  void* B3 = other_buf(c, G, B1, B2);
+  void* Gn = G == c->gG[0] ? c->gG[1] : c->gG[0];
+  const int par = c->bwd_parity;
+  c->bwd_parity ^= 1;
+  void** S = c->gset[par];
+  void *B1 = S[0], *B2 = S[1], *B3 = S[2], *B4 = S[3];
+  hipStream_t ws;
+  MI355_TRY(acquire_set(c, par, s));
   // bn3 (+ReLU mask of the block output); dz written back into G
   MI355_TRY(bn_backward(c, b.c3, G, b.out, G, B1, beta_acc, s));  // B1 = dy3
-  if (b.has_ds) MI355_TRY(bn_backward(c, b.ds, G, nullptr, nullptr, B2, beta_acc, s));  // B2 = dyd
-  MI355_TRY(conv_wgrad(c, b.c3, B1, b.a2, beta_acc, s));
-  MI355_TRY(conv_dgrad(c, b.c3, B1, B3, nullptr, s));  // B3 = da2
-  MI355_TRY(bn_backward(c, b.c2, B3, b.a2, nullptr, B3, beta_acc, s));  // B3 = dy2
-  MI355_TRY(conv_wgrad(c, b.c2, B3, b.a1, beta_acc, s));
-  MI355_TRY(conv_dgrad(c, b.c2, B3, B1, nullptr, s));  // B1 = da1
-  MI355_TRY(bn_backward(c, b.c1, B1, b.a1, nullptr, B1, beta_acc, s));  // B1 = dy1
-  MI355_TRY(conv_wgrad(c, b.c1, B1, b.in, beta_acc, s));
+  MI355_TRY(fork(c, s, &ws));
+  MI355_TRY(conv_wgrad(c, b.c3, B1, b.a2, beta_acc, ws));
   if (b.has_ds) {
-    MI355_TRY(conv_wgrad(c, b.ds, B2, b.in, beta_acc, s));
-    MI355_TRY(conv_dgrad(c, b.ds, B2, B3, nullptr, s));  // B3 = shortcut gradient
-    MI355_TRY(conv_dgrad(c, b.c1, B1, B3, B3, s));       // B3 = dx_in
-    c->cur_dout = B3;
+    MI355_TRY(bn_backward(c, b.ds, G, nullptr, nullptr, B2, beta_acc, s));  // B2 = dyd
+    MI355_TRY(fork(c, s, &ws));
+    MI355_TRY(conv_wgrad(c, b.ds, B2, b.in, beta_acc, ws));
+  }
+  MI355_TRY(conv_dgrad(c, b.c3, B1, B3, nullptr, s));                   // B3 = da2
+  MI355_TRY(bn_backward(c, b.c2, B3, b.a2, nullptr, B3, beta_acc, s));  // B3 = dy2
+  MI355_TRY(fork(c, s, &ws));
+  MI355_TRY(conv_wgrad(c, b.c2, B3, b.a1, beta_acc, ws));
+  MI355_TRY(conv_dgrad(c, b.c2, B3, B4, nullptr, s));                   // B4 = da1
+  MI355_TRY(bn_backward(c, b.c1, B4, b.a1, nullptr, B4, beta_acc, s));  // B4 = dy1
+  MI355_TRY(fork(c, s, &ws));
+  MI355_TRY(conv_wgrad(c, b.c1, B4, b.in, beta_acc, ws));
+  if (b.has_ds) {
+    MI355_TRY(conv_dgrad(c, b.ds, B2, Gn, nullptr, s));  // Gn = shortcut gradient
+    MI355_TRY(conv_dgrad(c, b.c1, B4, Gn, Gn, s));       // Gn = dx_in
+    c->cur_dout = Gn;
   } else {
-    MI355_TRY(conv_dgrad(c, b.c1, B1, G, G, s));  // G = dx_in = conv1 dgrad + dz
+    MI355_TRY(conv_dgrad(c, b.c1, B4, G, G, s));  // G = dx_in = conv1 dgrad + dz
     c->cur_dout = G;
   }
-  return 0;
+  return release_set(c, par);
 }
 
 int backward_stem(mi355_ctx* c, float beta_acc, hipStream_t s) {
   void* G = c->cur_dout;  // gradient wrt maxpool output
-  void* B1 = other_buf(c, G, nullptr, nullptr);
+  const int par = c->bwd_parity;
+  c->bwd_parity ^= 1;
+  void* B1 = c->gset[par][0];
   ConvBN& l = c->stem;
+  MI355_TRY(acquire_set(c, par, s));
   {
     Prof p(c, PC_OTHER, 0, 0, s);
     MI355_TRY(launch_maxpool_bwd(c->dtype, G, c->pool_idx, B1, c->N, l.Hout, l.Wout, 64, s));
@@ -397,11 +463,14 @@ int backward_stem(mi355_ctx* c, float beta_acc, hipStream_t s) {
   WgradArgs a;
   build_stem_wgrad_args(a, c->N, c->H, c->W);
   a.dy = B1; a.x = c->xpad; a.partial = c->wg_partial;
+  hipStream_t ws;
+  MI355_TRY(fork(c, s, &ws));
   {
-    Prof p(c, PC_WGRAD64, conv_flops(c, l), 0, s);
-    MI355_TRY(launch_wgrad(c->dtype, a, l.splits, s));
+    Prof p(c, PC_WGRAD64, conv_flops(c, l), 0, ws);
+    MI355_TRY(launch_wgrad(c->dtype, a, l.splits, ws));
   }
-  return launch_stem_unpack(c->wg_partial, l.splits, c->grads + l.w_off, beta_acc, s);
+  MI355_TRY(launch_stem_unpack(c->wg_partial, l.splits, c->grads + l.w_off, beta_acc, ws));
+  return release_set(c, par);
 }
 
 }  // namespace
@@ -500,6 +569,20 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
     delete c;
     return MI355_E_HIP;
   }
+  // weight-gradient side stream (MI355_WGRAD_STREAM=0 keeps everything on the caller's stream)
+  const char* ov = getenv("MI355_WGRAD_STREAM");
+  c->overlap = !(ov && ov[0] == '0');
+  if (c->overlap) {
+    bool ok = hipStreamCreateWithFlags(&c->wstream, hipStreamNonBlocking) == hipSuccess;
+    c->fork_ev.resize(16);
+    for (auto& ev : c->fork_ev) ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+    for (auto& ev : c->w_done) ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      set_error("create: side stream / events -> %s", hipGetErrorString(hipGetLastError()));
+      mi355_resnet50_destroy(c);
+      return MI355_E_HIP;
+    }
+  }
   // block inputs
   const void* prev = c->p0;
   for (auto& b : c->blocks) {
@@ -514,6 +597,11 @@ int mi355_resnet50_destroy(mi355_ctx* c) {
   if (!c) return 0;
   if (c->device >= 0) (void)hipSetDevice(c->device);
   for (auto e : c->ev) (void)hipEventDestroy(e);
+  for (auto e : c->fork_ev)
+    if (e) (void)hipEventDestroy(e);
+  for (auto e : c->w_done)
+    if (e) (void)hipEventDestroy(e);
+  if (c->wstream) (void)hipStreamDestroy(c->wstream);
   if (c->arena) (void)hipFree(c->arena);
   delete c;
   return 0;
@@ -662,6 +750,7 @@ int mi355_resnet50_backward(mi355_ctx* c, const float* dlogits, int seg_begin, i
     }
     c->next_seg = seg + 1;
   }
+  MI355_TRY(join(c, s));
   if (c->next_seg == nseg) c->fwd_training_done = false;
   return 0;
 }
@@ -703,8 +792,8 @@ int mi355_resnet50_debug_tensor(const mi355_ctx* c, const char* name, void** ptr
     shape[0] = c->N; shape[1] = 2048; shape[2] = shape[3] = 0;
     return 0;
   }
-  for (int i = 0; i < 4; ++i)
-    if (n == "gbuf" + std::to_string(i)) return set4(c->gbuf[i], c->dtype, last.Hout, last.Wout, last.Cout);
+  for (int i = 0; i < 2; ++i)
+    if (n == "gG" + std::to_string(i)) return set4(c->gG[i], c->dtype, last.Hout, last.Wout, last.Cout);
   set_error("debug_tensor: unknown tensor '%s'", name);
   return MI355_E_ARG;
 }
