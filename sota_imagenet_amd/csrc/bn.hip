@@ -33,6 +33,7 @@ struct ReduceArgs {
   const void* x;      // pre-BN tensor [M][C]
   const void* g;      // upstream gradient (bwd) or null
   const void* mask;   // post-activation tensor for the ReLU mask, or null
+  const uint8_t* bits;  // or: the ReLU mask as one byte per 16-byte vector (bit e = element e was > 0), from bn_apply
   void* dz_out;       // optional masked gradient output
   const float* mean;  // [C] (bwd)
   const float* invstd;
@@ -93,7 +94,11 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
     } else {
       float gv[V];
       Vec16<T>::load(g + off, gv);
-      if (mk) {
+      if (p.bits) {
+        const unsigned b = p.bits[off / V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) gv[e] = (b >> e) & 1u ? gv[e] : 0.f;
+      } else if (mk) {
         float mv[V];
         Vec16<T>::load(mk + off, mv);
 #pragma unroll
@@ -255,8 +260,9 @@ struct ApplyArgs {
   const float* scale2;
   const float* shift2;
   void* out;
-  size_t nvec;  // M*C/V
-  int cvecs;    // C/V
+  uint8_t* bits;  // optional ReLU mask output: one byte per 16-byte vector
+  size_t nvec;    // M*C/V
+  int cvecs;      // C/V
   int relu;
 };
 
@@ -302,6 +308,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
       for (int e = 0; e < V; ++e) v[e] += fmaf(rv[e], sc2[e], sh2[e]);
     }
     if (p.relu) {
+      if (p.bits) {
+        unsigned b = 0;
+#pragma unroll
+        for (int e = 0; e < V; ++e) b |= (v[e] > 0.f ? 1u : 0u) << e;
+        p.bits[i] = (uint8_t)b;
+      }
 #pragma unroll
       for (int e = 0; e < V; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
     }
@@ -312,6 +324,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
 struct BwdApplyArgs {
   const void* g;
   const void* mask;
+  const uint8_t* bits;
   const void* x;
   const float* mean;
   const float* invstd;
@@ -342,7 +355,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p)
     float gv[V], xv[V];
     Vec16<T>::load(g + i * V, gv);
     Vec16<T>::load(x + i * V, xv);
-    if (mk) {
+    if (p.bits) {
+      const unsigned b = p.bits[i];
+#pragma unroll
+      for (int e = 0; e < V; ++e) gv[e] = (b >> e) & 1u ? gv[e] : 0.f;
+    } else if (mk) {
       float mv[V];
       Vec16<T>::load(mk + i * V, mv);
 #pragma unroll
@@ -444,7 +461,7 @@ int launch_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm
 
 int launch_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
                     const void* x2, const float* scale2, const float* shift2, void* out, int M, int C, int relu,
-                    hipStream_t s) {
+                    hipStream_t s, uint8_t* relu_bits) {
   MI355_TRY(check_c(dtype, C));
   const int V = 16 / (int)dtype_size(dtype);
   ApplyArgs a{};
@@ -456,6 +473,7 @@ int launch_bn_apply(int dtype, const void* x, const float* scale, const float* s
   a.scale2 = scale2;
   a.shift2 = shift2;
   a.out = out;
+  a.bits = relu_bits;
   a.nvec = (size_t)M * C / V;
   a.cvecs = C / V;
   a.relu = relu;
@@ -470,12 +488,13 @@ int launch_bn_apply(int dtype, const void* x, const float* scale, const float* s
 
 int launch_bn_bwd_reduce(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
                          const float* invstd, void* dz_out, float* partial, int* nblk_out, int M, int C,
-                         hipStream_t s) {
+                         hipStream_t s, const uint8_t* relu_bits) {
   MI355_TRY(check_c(dtype, C));
   ReduceArgs a{};
   a.x = x;
   a.g = g;
   a.mask = mask_src;
+  a.bits = relu_bits;
   a.dz_out = dz_out;
   a.mean = mean;
   a.invstd = invstd;
@@ -511,12 +530,14 @@ int launch_bn_bwd_finalize(const float* partial, int nblk, int M, int C, const f
 }
 
 int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
-                        const float* invstd, const float* coef, void* dx, int M, int C, hipStream_t s) {
+                        const float* invstd, const float* coef, void* dx, int M, int C, hipStream_t s,
+                        const uint8_t* relu_bits) {
   MI355_TRY(check_c(dtype, C));
   const int V = 16 / (int)dtype_size(dtype);
   BwdApplyArgs a{};
   a.g = g;
   a.mask = mask_src;
+  a.bits = relu_bits;
   a.x = x;
   a.mean = mean;
   a.invstd = invstd;

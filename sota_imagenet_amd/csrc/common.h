@@ -139,14 +139,17 @@ int launch_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm
 // out = act(x*scale+shift (+ residual) (+ x2*scale2+shift2))
 int launch_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
                     const void* x2, const float* scale2, const float* shift2, void* out, int M, int C, int relu,
-                    hipStream_t s);
+                    hipStream_t s, uint8_t* relu_bits = nullptr);
+// relu_bits: the ReLU mask as one byte per 16-byte vector of the tensor (bit e = element e of the vector was > 0);
+// written by launch_bn_apply, read by the two backward kernels in place of the post-activation tensor
 int launch_bn_bwd_reduce(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
                          const float* invstd, void* dz_out, float* partial, int* nblk_out, int M, int C,
-                         hipStream_t s);
+                         hipStream_t s, const uint8_t* relu_bits = nullptr);
 int launch_bn_bwd_finalize(const float* partial, int nblk, int M, int C, const float* gamma, const float* invstd,
                            float* dgamma, float* dbeta, float beta_acc, float* coef /*[3][C]*/, hipStream_t s);
 int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
-                        const float* invstd, const float* coef, void* dx, int M, int C, hipStream_t s);
+                        const float* invstd, const float* coef, void* dx, int M, int C, hipStream_t s,
+                        const uint8_t* relu_bits = nullptr);
 int bn_max_blocks();
 
 // pooling / head / loss / optimizer

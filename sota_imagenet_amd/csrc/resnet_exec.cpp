@@ -56,6 +56,7 @@ struct Block {
   void* a1 = nullptr;
   void* a2 = nullptr;
   void* out = nullptr;
+  uint8_t *a1_bits = nullptr, *a2_bits = nullptr, *out_bits = nullptr;  // ReLU masks, 1 byte per 16-byte vector
   int Hin, Win, Hout, Wout, Cin, Cout;
   size_t grad_begin = 0, grad_end = 0;
 };
@@ -90,6 +91,7 @@ struct mi355_ctx {
   size_t arena_bytes = 0;
   void *xpad = nullptr, *stem_pack = nullptr, *a0 = nullptr, *p0 = nullptr;
   uint8_t* pool_idx = nullptr;
+  uint8_t* a0_bits = nullptr;
   float *pooled = nullptr, *fc_tmp = nullptr, *dlogits_pad = nullptr, *dpooled = nullptr, *fc_wtr = nullptr;
   float *bn_partial = nullptr, *bn_coef = nullptr, *wg_partial = nullptr;
   // backward gradients: gG[2] carry the gradient wrt a block output down the network; gset[p] holds the per-layer
@@ -224,32 +226,34 @@ int bn_prepare(mi355_ctx* c, ConvBN& l, int training, float momentum, hipStream_
   return launch_bn_eval_coeffs(gamma, beta, c->buffers + l.rm_off, c->buffers + l.rv_off, scale, shift, C, BN_EPS, s);
 }
 
-int bn_apply(mi355_ctx* c, ConvBN& l, const void* residual, ConvBN* l2, void* out, int relu, hipStream_t s) {
+int bn_apply(mi355_ctx* c, ConvBN& l, const void* residual, ConvBN* l2, void* out, int relu, hipStream_t s,
+             uint8_t* bits) {
   const int M = c->N * l.Hout * l.Wout, C = l.Cout;
   const int nin = 1 + (residual ? 1 : 0) + (l2 ? 1 : 0);
   Prof p(c, PC_BN_APPLY, 0, (double)M * C * c->es * (nin + 1), s);
   return launch_bn_apply(c->dtype, l.y, l.stat + 2 * C, l.stat + 3 * C, residual, l2 ? l2->y : nullptr,
-                         l2 ? l2->stat + 2 * C : nullptr, l2 ? l2->stat + 3 * C : nullptr, out, M, C, relu, s);
+                         l2 ? l2->stat + 2 * C : nullptr, l2 ? l2->stat + 3 * C : nullptr, out, M, C, relu, s, bits);
 }
 
-// BN backward of layer l: g (gradient wrt the activation), mask (post-activation tensor or null),
-// optional in-place masked write-back; dx written to `dx` (may alias g).
-int bn_backward(mi355_ctx* c, ConvBN& l, const void* g, const void* mask, void* dz_out, void* dx, float beta_acc,
+// BN backward of layer l: g (gradient wrt the activation), bits (ReLU mask of the activation, 1 byte per 16-byte
+// vector, or null), optional in-place masked write-back; dx written to `dx` (may alias g).
+int bn_backward(mi355_ctx* c, ConvBN& l, const void* g, const uint8_t* bits, void* dz_out, void* dx, float beta_acc,
                 hipStream_t s) {
   const int M = c->N * l.Hout * l.Wout, C = l.Cout;
   int nblk = 0;
-  const int nrd = 2 + (mask ? 1 : 0);
+  const double mask_bytes = bits ? (double)M * C * c->es / 16 : 0.0;
   {
-    Prof p(c, PC_BN_REDUCE, 0, (double)M * C * c->es * (nrd + (dz_out ? 1 : 0)), s);
-    MI355_TRY(launch_bn_bwd_reduce(c->dtype, g, mask, l.y, l.stat, l.stat + C, dz_out, c->bn_partial, &nblk, M, C, s));
+    Prof p(c, PC_BN_REDUCE, 0, (double)M * C * c->es * (2 + (dz_out ? 1 : 0)) + mask_bytes, s);
+    MI355_TRY(launch_bn_bwd_reduce(c->dtype, g, nullptr, l.y, l.stat, l.stat + C, dz_out, c->bn_partial, &nblk, M, C, s,
+                                   bits));
   }
   MI355_TRY(launch_bn_bwd_finalize(c->bn_partial, nblk, M, C, c->params + l.gamma_off, l.stat + C,
                                    c->grads + l.gamma_off, c->grads + l.beta_off, beta_acc, c->bn_coef, s));
   // after an in-place masked write-back the mask is already applied
-  const void* mask2 = dz_out ? nullptr : mask;
+  const uint8_t* bits2 = dz_out ? nullptr : bits;
   const void* g2 = dz_out ? dz_out : g;
-  Prof p(c, PC_BN_BWD_APPLY, 0, (double)M * C * c->es * (3 + (mask2 ? 1 : 0)), s);
-  return launch_bn_bwd_apply(c->dtype, g2, mask2, l.y, l.stat, l.stat + C, c->bn_coef, dx, M, C, s);
+  Prof p(c, PC_BN_BWD_APPLY, 0, (double)M * C * c->es * 3 + (bits2 ? mask_bytes : 0.0), s);
+  return launch_bn_bwd_apply(c->dtype, g2, nullptr, l.y, l.stat, l.stat + C, c->bn_coef, dx, M, C, s, bits2);
 }
 
 int conv_wgrad(mi355_ctx* c, ConvBN& l, const void* dy, const void* x, float beta_acc, hipStream_t s) {
@@ -299,16 +303,20 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
   ar.add(&c->stem_pack, (size_t)64 * 7 * 64 * c->es);
   conv_ws(c->stem);
   ar.add(&c->a0, act_bytes(c, c->stem.Hout, c->stem.Wout, 64));
+  ar.add((void**)&c->a0_bits, act_bytes(c, c->stem.Hout, c->stem.Wout, 64) / 16);
   ar.add(&c->p0, act_bytes(c, c->stem.Hout / 2, c->stem.Wout / 2, 64));
   ar.add((void**)&c->pool_idx, (size_t)N * (c->stem.Hout / 2) * (c->stem.Wout / 2) * 64);
   for (auto& b : c->blocks) {
     conv_ws(b.c1);
     ar.add(&b.a1, act_bytes(c, b.c1.Hout, b.c1.Wout, b.c1.Cout));
+    ar.add((void**)&b.a1_bits, act_bytes(c, b.c1.Hout, b.c1.Wout, b.c1.Cout) / 16);
     conv_ws(b.c2);
     ar.add(&b.a2, act_bytes(c, b.c2.Hout, b.c2.Wout, b.c2.Cout));
+    ar.add((void**)&b.a2_bits, act_bytes(c, b.c2.Hout, b.c2.Wout, b.c2.Cout) / 16);
     conv_ws(b.c3);
     if (b.has_ds) conv_ws(b.ds);
     ar.add(&b.out, act_bytes(c, b.Hout, b.Wout, b.Cout));
+    ar.add((void**)&b.out_bits, act_bytes(c, b.Hout, b.Wout, b.Cout) / 16);
   }
   const int fcp = c->fc_pad;
   ar.add((void**)&c->pooled, (size_t)N * 2048 * 4);
@@ -421,7 +429,7 @@ int backward_block(mi355_ctx* c, Block& b, float beta_acc, hipStream_t s) {
   hipStream_t ws;
   MI355_TRY(acquire_set(c, par, s));
   // bn3 (+ReLU mask of the block output); dz written back into G
-  MI355_TRY(bn_backward(c, b.c3, G, b.out, G, B1, beta_acc, s));  // B1 = dy3
+  MI355_TRY(bn_backward(c, b.c3, G, b.out_bits, G, B1, beta_acc, s));  // B1 = dy3
   MI355_TRY(fork(c, s, &ws));
   MI355_TRY(conv_wgrad(c, b.c3, B1, b.a2, beta_acc, ws));
   if (b.has_ds) {
@@ -430,11 +438,11 @@ int backward_block(mi355_ctx* c, Block& b, float beta_acc, hipStream_t s) {
     MI355_TRY(conv_wgrad(c, b.ds, B2, b.in, beta_acc, ws));
   }
   MI355_TRY(conv_dgrad(c, b.c3, B1, B3, nullptr, s));                   // B3 = da2
-  MI355_TRY(bn_backward(c, b.c2, B3, b.a2, nullptr, B3, beta_acc, s));  // B3 = dy2
+  MI355_TRY(bn_backward(c, b.c2, B3, b.a2_bits, nullptr, B3, beta_acc, s));  // B3 = dy2
   MI355_TRY(fork(c, s, &ws));
   MI355_TRY(conv_wgrad(c, b.c2, B3, b.a1, beta_acc, ws));
   MI355_TRY(conv_dgrad(c, b.c2, B3, B4, nullptr, s));                   // B4 = da1
-  MI355_TRY(bn_backward(c, b.c1, B4, b.a1, nullptr, B4, beta_acc, s));  // B4 = dy1
+  MI355_TRY(bn_backward(c, b.c1, B4, b.a1_bits, nullptr, B4, beta_acc, s));  // B4 = dy1
   MI355_TRY(fork(c, s, &ws));
   MI355_TRY(conv_wgrad(c, b.c1, B4, b.in, beta_acc, ws));
   if (b.has_ds) {
@@ -459,7 +467,7 @@ int backward_stem(mi355_ctx* c, float beta_acc, hipStream_t s) {
     Prof p(c, PC_OTHER, 0, 0, s);
     MI355_TRY(launch_maxpool_bwd(c->dtype, G, c->pool_idx, B1, c->N, l.Hout, l.Wout, 64, s));
   }
-  MI355_TRY(bn_backward(c, l, B1, c->a0, nullptr, B1, beta_acc, s));
+  MI355_TRY(bn_backward(c, l, B1, c->a0_bits, nullptr, B1, beta_acc, s));
   WgradArgs a;
   build_stem_wgrad_args(a, c->N, c->H, c->W);
   a.dy = B1; a.x = c->xpad; a.partial = c->wg_partial;
@@ -666,7 +674,7 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
     MI355_TRY(launch_igemm(c->dtype, a, 1, s, &c->stem.stat_rows));
   }
   MI355_TRY(bn_prepare(c, c->stem, training, bn_momentum, s));
-  MI355_TRY(bn_apply(c, c->stem, nullptr, nullptr, c->a0, 1, s));
+  MI355_TRY(bn_apply(c, c->stem, nullptr, nullptr, c->a0, 1, s, training ? c->a0_bits : nullptr));
   {
     Prof p(c, PC_OTHER, 0, 0, s);
     MI355_TRY(launch_maxpool_fwd(c->dtype, c->a0, c->p0, c->pool_idx, N, c->stem.Hout, c->stem.Wout, 64, s));
@@ -674,18 +682,18 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
   for (auto& b : c->blocks) {
     MI355_TRY(conv_forward(c, b.c1, b.in, training, s));
     MI355_TRY(bn_prepare(c, b.c1, training, bn_momentum, s));
-    MI355_TRY(bn_apply(c, b.c1, nullptr, nullptr, b.a1, 1, s));
+    MI355_TRY(bn_apply(c, b.c1, nullptr, nullptr, b.a1, 1, s, training ? b.a1_bits : nullptr));
     MI355_TRY(conv_forward(c, b.c2, b.a1, training, s));
     MI355_TRY(bn_prepare(c, b.c2, training, bn_momentum, s));
-    MI355_TRY(bn_apply(c, b.c2, nullptr, nullptr, b.a2, 1, s));
+    MI355_TRY(bn_apply(c, b.c2, nullptr, nullptr, b.a2, 1, s, training ? b.a2_bits : nullptr));
     MI355_TRY(conv_forward(c, b.c3, b.a2, training, s));
     MI355_TRY(bn_prepare(c, b.c3, training, bn_momentum, s));
     if (b.has_ds) {
       MI355_TRY(conv_forward(c, b.ds, b.in, training, s));
       MI355_TRY(bn_prepare(c, b.ds, training, bn_momentum, s));
-      MI355_TRY(bn_apply(c, b.c3, nullptr, &b.ds, b.out, 1, s));
+      MI355_TRY(bn_apply(c, b.c3, nullptr, &b.ds, b.out, 1, s, training ? b.out_bits : nullptr));
     } else {
-      MI355_TRY(bn_apply(c, b.c3, b.in, nullptr, b.out, 1, s));
+      MI355_TRY(bn_apply(c, b.c3, b.in, nullptr, b.out, 1, s, training ? b.out_bits : nullptr));
     }
   }
   const Block& last = c->blocks.back();

@@ -97,6 +97,7 @@ class ResNet50(nn.Module):
         self._ctxs = OrderedDict()  # (N,H,W) -> native ctx
         self._grads_dirty = False
         self._grad_sync = None  # set by parallel.FlatBucketDDP: callable(segment, begin, end)
+        self._grad_sync_points = None  # optional set of segments the hook acts on (None: after every segment)
         self._bn_leaves = []
         self._build_modules()
         self._rebind_views()
@@ -290,9 +291,16 @@ class ResNet50(nn.Module):
         if self._grad_sync is None:
             check(L.mi355_resnet50_backward(c, ptr(dlogits), 0, nseg, acc, native.cur_stream()))
         else:
+            # one native call per run of segments up to the next segment the hook acts on (a bucket boundary): every
+            # call ends by joining the weight-gradient side stream, so fewer calls keep more of that overlap
+            points = self._grad_sync_points
+            s0 = 0
             for s in range(nseg):
-                check(L.mi355_resnet50_backward(c, ptr(dlogits), s, s + 1, acc, native.cur_stream()))
-                self._grad_sync(s, *self._segments[s])
+                if points is None or s in points or s == nseg - 1:
+                    check(L.mi355_resnet50_backward(c, ptr(dlogits), s0, s + 1, acc, native.cur_stream()))
+                    for k in range(s0, s + 1):
+                        self._grad_sync(k, *self._segments[k])
+                    s0 = s + 1
         self._grads_dirty = True
 
     def forward(self, x):

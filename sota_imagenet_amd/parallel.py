@@ -50,6 +50,7 @@ class FlatBucketDDP(nn.Module):
         if broadcast:
             self.broadcast_state()
         module._grad_sync = self._on_segment
+        module._grad_sync_points = set(self._by_last)
 
     # ---- C2: rank 0 -> everyone, once ----------------------------------------------------------------------
     def broadcast_state(self):
