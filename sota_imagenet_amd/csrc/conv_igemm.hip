@@ -308,12 +308,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
         constexpr int NP = 32 / RPI;
         int pixs[NP];
         uint4 araw[NP];
+        unsigned abits[NP];
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {  // all addend loads of this pass first: one round trip, not NP
           pixs[ps] = row_pix[wm * 64 + mi * 32 + ps * RPI + rr];
           if (addend) {
             const size_t o = (size_t)(pixs[ps] < 0 ? 0 : pixs[ps]) * p.Ncols + n0 + wn * WN + ch * VEC;
             araw[ps] = *reinterpret_cast<const uint4*>(pixs[ps] < 0 ? reinterpret_cast<const T*>(g_zero_page) : addend + o);
+            abits[ps] = p.addend_bits ? (unsigned)p.addend_bits[pixs[ps] < 0 ? 0 : o / VEC] : 0xffu;
           }
         }
 #pragma unroll
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
             float a[VEC];
             Vec16<T>::unpack(araw[ps], a);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) v[e] += a[e];
+            for (int e = 0; e < VEC; ++e) v[e] += (abits[ps] >> e) & 1u ? a[e] : 0.f;
           }
           // rows past the end of the problem go to a trash page so that every thread issues exactly NST stores
           T* dst = pix < 0 ? reinterpret_cast<T*>(g_trash + tid * 16) : out + o;

@@ -269,11 +269,12 @@ int conv_wgrad(mi355_ctx* c, ConvBN& l, const void* dy, const void* x, float bet
   return launch_splitk_reduce(c->wg_partial, l.splits, n, c->grads + l.w_off, n, beta_acc, s);
 }
 
-int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* addend, hipStream_t s) {
+int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* addend, hipStream_t s,
+               const uint8_t* addend_bits = nullptr) {
   IgemmArgs a;
   const int nclass = build_dgrad_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
   if (nclass < 0) return nclass;
-  a.in = dy; a.wt = l.w_tr; a.out = dx; a.addend = addend;
+  a.in = dy; a.wt = l.w_tr; a.out = dx; a.addend = addend; a.addend_bits = addend_bits;
   const double by = ((double)c->N * l.Hin * l.Win * l.Cin * (addend ? 2 : 1) + (double)c->N * l.Hout * l.Wout * l.Cout) * c->es;
   Prof p(c, igemm_class(l.Cin), conv_flops(c, l), by, s);
   return launch_igemm(c->dtype, a, nclass, s);
@@ -420,7 +421,8 @@ int backward_fc(mi355_ctx* c, const float* dlogits, float beta_acc, hipStream_t 
 }
 
 int backward_block(mi355_ctx* c, Block& b, float beta_acc, hipStream_t s) {
-  void* G = c->cur_dout;  // gradient wrt block output (pre-mask); becomes dz in place
+  void* G = c->cur_dout;  // gradient wrt the block output, BEFORE its ReLU mask (b.out_bits): the mask is applied on the
+                          // fly by the three consumers (bn3 / downsample-bn backward, the shortcut add of conv1's dgrad)
   void* Gn = G == c->gG[0] ? c->gG[1] : c->gG[0];
   const int par = c->bwd_parity;
   c->bwd_parity ^= 1;
@@ -428,12 +430,11 @@ int backward_block(mi355_ctx* c, Block& b, float beta_acc, hipStream_t s) {
   void *B1 = S[0], *B2 = S[1], *B3 = S[2], *B4 = S[3];
   hipStream_t ws;
   MI355_TRY(acquire_set(c, par, s));
-  // bn3 (+ReLU mask of the block output); dz written back into G
-  MI355_TRY(bn_backward(c, b.c3, G, b.out_bits, G, B1, beta_acc, s));  // B1 = dy3
+  MI355_TRY(bn_backward(c, b.c3, G, b.out_bits, nullptr, B1, beta_acc, s));  // B1 = dy3
   MI355_TRY(fork(c, s, &ws));
   MI355_TRY(conv_wgrad(c, b.c3, B1, b.a2, beta_acc, ws));
   if (b.has_ds) {
-    MI355_TRY(bn_backward(c, b.ds, G, nullptr, nullptr, B2, beta_acc, s));  // B2 = dyd
+    MI355_TRY(bn_backward(c, b.ds, G, b.out_bits, nullptr, B2, beta_acc, s));  // B2 = dyd
     MI355_TRY(fork(c, s, &ws));
     MI355_TRY(conv_wgrad(c, b.ds, B2, b.in, beta_acc, ws));
   }
@@ -450,7 +451,7 @@ int backward_block(mi355_ctx* c, Block& b, float beta_acc, hipStream_t s) {
     MI355_TRY(conv_dgrad(c, b.c1, B4, Gn, Gn, s));       // Gn = dx_in
     c->cur_dout = Gn;
   } else {
-    MI355_TRY(conv_dgrad(c, b.c1, B4, G, G, s));  // G = dx_in = conv1 dgrad + dz
+    MI355_TRY(conv_dgrad(c, b.c1, B4, G, G, s, b.out_bits));  // G = dx_in = conv1 dgrad + masked G
     c->cur_dout = G;
   }
   return release_set(c, par);
