@@ -80,6 +80,7 @@ struct IgemmArgs {
   int Hsub, Wsub, IS;
   int Hout, Wout, OS;
   int Ck, Ncols, wtaps;
+  int pair_delta;      // stem only: elements to skip between k = 31 and k = 32 of a tap (the next image row); else 0
   TapClass cls[4];     // blockIdx.z selects the class
 };
 
@@ -93,6 +94,7 @@ struct WgradArgs {
   int Hin, Win, pix_stride, IS;
   int Ck, wtaps, ntaps;
   int chunks_per_split;  // BKP-pixel chunks handled by one split
+  int pair_delta;        // stem only: elements to skip between staged elements 31 and 32 of a tap (next image row); else 0
   Tap taps[9];
 };
 
@@ -105,7 +107,7 @@ int launch_wgrad(int dtype, const WgradArgs& a, int splits, hipStream_t stream);
 // dst[i] = beta*dst[i] + sum_s partial[s][i], i < n  (n multiple of 4); deterministic order
 int launch_splitk_reduce(const float* partial, int splits, size_t stride, float* dst, size_t n, float beta,
                          hipStream_t stream);
-// stem unpack: dw[64][7][7][3] = beta*dw + sum_s partial[s][co][kh][kw*4+c]
+// stem unpack: dw[64][7][7][3] = beta*dw + sum_s partial[s][co][kh>>1][(kh&1)*32 + kw*4+c]
 int launch_stem_unpack(const float* partial, int splits, float* dw, float beta, hipStream_t stream);
 
 // weight preparation (weights.hip): fp32 KRSC master -> what the kernels consume
@@ -115,7 +117,7 @@ int launch_weight_prep(int dtype, const float* w, void* w_cast, void* w_tr, int 
                        hipStream_t stream);
 // same-dtype transpose [Cout][taps][Cin] -> [Cin][taps][Cout] (per-op API, weights already in `dtype`)
 int launch_transpose_any(int dtype, const void* w, void* wt, int Cout, int taps, int Cin, hipStream_t stream);
-// stem: w[64][7][7][3] fp32 -> packed [64][7][64] dtype (kw*4+c, zero padded)
+// stem: w[64][7][7][3] fp32 -> packed [64][4][64] dtype: row pair kh>>1, element (kh&1)*32 + kw*4+c, zero padded
 int launch_stem_pack(int dtype, const float* w, void* packed, hipStream_t stream);
 
 // conv geometry builders (conv_api.cpp)

@@ -101,13 +101,16 @@ void build_stem_fwd_args(IgemmArgs& a, int N, int H, int W) {
   a.N = N; a.Hin = stem_hp(H); a.Win = stem_wp(W); a.pix_stride = STEM_PS;
   a.Hsub = H / 2; a.Wsub = W / 2; a.IS = 2;
   a.Hout = H / 2; a.Wout = W / 2; a.OS = 1;
-  a.Ck = STEM_CK; a.Ncols = 64; a.wtaps = 7;
+  // a tap = TWO image rows: k in [0,32) is (kw*4+c) of row 2t, k in [32,64) the same of row 2t+1 (kh = 7 has zero
+  // weights; the padded image has the row)
+  a.Ck = STEM_CK; a.Ncols = 64; a.wtaps = 4;
+  a.pair_delta = stem_wp(W) * STEM_PS - 32;
   TapClass& c = a.cls[0];
-  c.ntaps = 7;
-  for (int kh = 0; kh < 7; ++kh) {
-    c.taps[kh].dh = (int8_t)kh;
-    c.taps[kh].dw = 0;
-    c.taps[kh].wtap = (int16_t)kh;
+  c.ntaps = 4;
+  for (int t = 0; t < 4; ++t) {
+    c.taps[t].dh = (int8_t)(2 * t);
+    c.taps[t].dw = 0;
+    c.taps[t].wtap = (int16_t)t;
   }
 }
 
@@ -115,11 +118,12 @@ void build_stem_wgrad_args(WgradArgs& a, int N, int H, int W) {
   memset(&a, 0, sizeof(a));
   a.N = N; a.Ho = H / 2; a.Wo = W / 2; a.Cout = 64;
   a.Hin = stem_hp(H); a.Win = stem_wp(W); a.pix_stride = STEM_PS; a.IS = 2;
-  a.Ck = STEM_CK; a.wtaps = 7; a.ntaps = 7;
-  for (int kh = 0; kh < 7; ++kh) {
-    a.taps[kh].dh = (int8_t)kh;
-    a.taps[kh].dw = 0;
-    a.taps[kh].wtap = (int16_t)kh;
+  a.Ck = STEM_CK; a.wtaps = 4; a.ntaps = 4;
+  a.pair_delta = stem_wp(W) * STEM_PS - 32;
+  for (int t = 0; t < 4; ++t) {
+    a.taps[t].dh = (int8_t)(2 * t);
+    a.taps[t].dw = 0;
+    a.taps[t].wtap = (int16_t)t;
   }
 }
 
@@ -204,8 +208,8 @@ size_t mi355_stem_xpad_bytes(int dtype, int N, int H, int W) {
 }
 
 size_t mi355_stem_workspace_bytes(int dtype, int N, int H, int W) {
-  const int splits = plan_wgrad_splits(dtype, N * (H / 2) * (W / 2), 64, 7, STEM_CK);
-  return align_up((size_t)64 * 7 * 64 * dtype_size(dtype), 256) + (size_t)splits * 64 * 7 * 64 * 4;
+  const int splits = plan_wgrad_splits(dtype, N * (H / 2) * (W / 2), 64, 4, STEM_CK);
+  return align_up((size_t)64 * 4 * 64 * dtype_size(dtype), 256) + (size_t)splits * 64 * 4 * 64 * 4;
 }
 
 int mi355_stem_ingest(int dtype, const float* x_nchw, void* xpad, int N, int H, int W, void* stream) {
@@ -215,7 +219,7 @@ int mi355_stem_ingest(int dtype, const float* x_nchw, void* xpad, int N, int H, 
 
 int mi355_stem_fwd(int dtype, const void* xpad, const float* w_krsc, void* y, int N, int H, int W, void* ws,
                    size_t ws_bytes, void* stream) {
-  const size_t pk = (size_t)64 * 7 * 64 * dtype_size(dtype);
+  const size_t pk = (size_t)64 * 4 * 64 * dtype_size(dtype);
   MI355_ARG(ws && ws_bytes >= pk, "stem_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   MI355_TRY(launch_stem_pack(dtype, w_krsc, ws, s));
@@ -229,8 +233,8 @@ int mi355_stem_wgrad(int dtype, const void* dy, const void* xpad, float* dw, flo
                      size_t ws_bytes, void* stream) {
   WgradArgs a;
   build_stem_wgrad_args(a, N, H, W);
-  const int splits = plan_wgrad_splits(dtype, a.N * a.Ho * a.Wo, 64, 7, STEM_CK);
-  MI355_ARG(ws && ws_bytes >= (size_t)splits * 64 * 7 * 64 * 4, "stem_wgrad: workspace too small");
+  const int splits = plan_wgrad_splits(dtype, a.N * a.Ho * a.Wo, 64, 4, STEM_CK);
+  MI355_ARG(ws && ws_bytes >= (size_t)splits * 64 * 4 * 64 * 4, "stem_wgrad: workspace too small");
   a.dy = dy; a.x = xpad; a.partial = (float*)ws;
   hipStream_t s = (hipStream_t)stream;
   MI355_TRY(launch_wgrad(dtype, a, splits, s));

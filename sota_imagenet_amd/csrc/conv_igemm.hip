@@ -110,8 +110,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
           const int n = t / p.Hsub;
           a_h[i] = ii * p.IS;
           a_w[i] = j * p.IS;
+          const int chunk = pch ^ ((r >> 1) & 7);  // source 16-byte chunk of the 128-byte slab row
           a_off[i] = (unsigned)((n * p.Hin + a_h[i]) * p.Win + a_w[i]) * (unsigned)(p.pix_stride * ES) +
-                     (unsigned)((pch ^ ((r >> 1) & 7)) * 16);
+                     (unsigned)(chunk * 16);
+          // stem row pairs: elements k >= 32 of a tap live in the next image row (bf16: chunks 4..7 of the slab;
+          // fp32: the tap's second slab, see L_begin)
+          if (ES == 2 && chunk >= 4) a_off[i] += (unsigned)(p.pair_delta * ES);
         } else {
           a_h[i] = -(1 << 20);
           a_w[i] = 0;
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
     const Tap tp = p.cls[cls_u].taps[t];
     S_dh = tp.dh;
     S_dw = tp.dw;
-    S_dA = ((tp.dh * p.Win + tp.dw) * p.pix_stride + c0) * ES;
+    S_dA = ((tp.dh * p.Win + tp.dw) * p.pix_stride + c0 + (ES == 4 && c0 >= 32 ? p.pair_delta : 0)) * ES;
     const int n0 = __builtin_amdgcn_readfirstlane((L_grp * kp.ntpg + L_nt) * BN);
     S_dB = ((unsigned)n0 * p.wtaps + tp.wtap) * (unsigned)(p.Ck * ES) + (unsigned)(c0 * ES);
     S_As = __builtin_amdgcn_readfirstlane(lds_addr(smem) + stage * STAGE);

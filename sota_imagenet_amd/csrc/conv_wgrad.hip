@@ -11,7 +11,9 @@
 //   bf16 : ds_read_b64_tr_b16 x2 per v_mfma_f32_32x32x16_bf16 operand; the LDS image stays lane-linear and the four
 //          pixel rows a half-wave touches are spread over all 64 banks by XOR-ing the 16-byte chunk index with
 //          (row&3)<<2 (256-byte rows) / ((row>>1)&1)<<2 (128-byte rows) on the SOURCE address and on the read.
-// Tile: BMC (128|64) output channels x BNC (128|64) input channels of ONE tap, 4 waves (2x2), swapped MFMA operands
+// Tile: BMC (128|64) output channels x BNC (128|64) input channels of TPI taps (1; 3 or 4 for the 64x64 tiles of the
+// small-channel layers, where one staged dy slab then feeds TPI x slabs: the 64x64 single-tap tile is fetch-bound),
+// 4 waves (2x2), swapped MFMA operands
 // so a lane ends with 4 consecutive input channels of one output channel (16-byte stores).  Persistent workgroups
 // walk (tile, pixel-split, slab) as one stream through a 2-stage LDS ring with the next slab always in flight
 // (counted s_waitcnt vmcnt + raw s_barrier, as in conv_igemm.hip).  fp32 partial slabs are summed in split order by
@@ -44,6 +46,7 @@ struct WgradKArgs {
   WgradArgs a;
   FastDiv dWo, dHo;
   int M, tiles, splits, items, pix_per_split;
+  int ntg;  // tap groups of TPI taps
   int xcd;  // 1: workgroups of one XCD (blockIdx & 7) take consecutive items, so the tiles of one pixel split share its L2
   unsigned bytes_dy, bytes_x;
 };
@@ -59,7 +62,7 @@ __device__ __forceinline__ int row_swz(int row) {
   else return ((row >> 1) & 1) << 2;
 }
 
-template <typename T, int BMC, int BNC>
+template <typename T, int BMC, int BNC, int TPI>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
   const WgradArgs& p = kp.a;
   constexpr int ES = (int)sizeof(T);
@@ -67,12 +70,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
   constexpr int RB_A = BMC * ES;            // bytes of one staged dy row
   constexpr int RB_B = BNC * ES;            // bytes of one staged x row
   constexpr int A_BYTES = BKP * RB_A;
-  constexpr int STAGE = BKP * (RB_A + RB_B);
+  constexpr int B_BYTES = BKP * RB_B;
+  constexpr int STAGE = A_BYTES + TPI * B_BYTES;
   constexpr int LPR_A = RB_A / 16, LPR_B = RB_B / 16;  // lanes (16-byte chunks) per row
   constexpr int RPP_A = 64 / LPR_A, RPP_B = 64 / LPR_B;  // rows per 1 KiB piece
   constexpr int PW_A = BMC / 32, PW_B = BNC / 32;        // pieces per wave per slab
   constexpr int MI = BMC / 64, NI = BNC / 64;            // 32x32 tiles per wave (cout / cin)
-  constexpr int NST = MI * NI * 4;                       // 16-byte stores per thread per item
+  constexpr int NST = TPI * MI * NI * 4;                 // 16-byte stores per thread per item
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -91,7 +95,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
 
   // ---- loader cursor (one slab ahead) -----------------------------------------------------------------------------
   // per-lane constants: row of each piece inside the slab and its swizzled 16-byte chunk
-  int L_item = blockIdx.x, L_m = 0, L_mend = 0, L_dh = 0, L_dw = 0;
+  int L_item = blockIdx.x, L_m = 0, L_mend = 0;
+  int L_dh[TPI], L_dw[TPI];
+  const unsigned pair_bytes = (unsigned)(p.pair_delta * ES);
   unsigned L_aoff = 0, L_boff = 0;  // uniform byte offsets: co0*ES / ci0*ES
   auto L_setup = [&]() {
     if (L_item >= kp.items) return;
@@ -100,11 +106,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
     const int split = v / kp.tiles;
     const int cib = tile % ckb;
     const int r1 = tile / ckb;
-    const int t = r1 % p.ntaps;
-    const int cb = r1 / p.ntaps;
-    const Tap tp = p.taps[__builtin_amdgcn_readfirstlane(t)];
-    L_dh = tp.dh;
-    L_dw = tp.dw;
+    const int t = r1 % kp.ntg;
+    const int cb = r1 / kp.ntg;
+#pragma unroll
+    for (int jt = 0; jt < TPI; ++jt) {
+      const Tap tp = p.taps[__builtin_amdgcn_readfirstlane(t * TPI + jt)];
+      L_dh[jt] = tp.dh;
+      L_dw[jt] = tp.dw;
+    }
     L_aoff = (unsigned)(cb * BMC * ES);
     L_boff = (unsigned)(cib * BNC * ES);
     L_m = split * kp.pix_per_split;
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
     S_m0 = __builtin_amdgcn_readfirstlane(L_m);
     S_mend = __builtin_amdgcn_readfirstlane(L_mend);
   };
-  auto L_piece = [&](int j) {  // j < PW_A: dy piece j;  else x piece j-PW_A
+  auto L_piece = [&](int j) {  // j < PW_A: dy piece j;  else x piece (j-PW_A) % PW_B of tap (j-PW_A) / PW_B
     if (j < PW_A) {
       const int piece = wave * PW_A + j;
       const int row = piece * RPP_A + lane / LPR_A;
@@ -127,7 +136,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
       const unsigned off = (unsigned)m * (unsigned)(p.Cout * ES) + L_aoff + (unsigned)(c * 16);
       blds16(srdA, m < S_mend ? off : 0x80000000u, S_As + piece * 1024);
     } else {
-      const int piece = wave * PW_B + (j - PW_A);
+      const int jt = (j - PW_A) / PW_B;
+      const int piece = wave * PW_B + (j - PW_A) % PW_B;
       const int row = piece * RPP_B + lane / LPR_B;
       const int c = (lane % LPR_B) ^ row_swz<ES, RB_B>(row);
       const int m = S_m0 + row;
@@ -135,12 +145,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
       const int ow = m - (int)q1 * p.Wo;
       const uint32_t n = fdiv(q1, kp.dHo);
       const int oh = (int)q1 - (int)n * p.Ho;
-      const int ih = oh * p.IS + L_dh;
-      const int iw = ow * p.IS + L_dw;
+      const int ih = oh * p.IS + L_dh[jt];
+      const int iw = ow * p.IS + L_dw[jt];
       const bool ok = m < S_mend && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+      // paired taps (stem): the upper half of the 64 staged "channels" comes from the next image row
+      const unsigned pair = c * (16 / ES) >= 32 ? pair_bytes : 0u;
       const unsigned off = (unsigned)(((int)n * p.Hin + ih) * p.Win + iw) * (unsigned)(p.pix_stride * ES) + L_boff +
-                           (unsigned)(c * 16);
-      blds16(srdB, ok ? off : 0x80000000u, S_As + A_BYTES + piece * 1024);
+                           (unsigned)(c * 16) + pair;
+      blds16(srdB, ok ? off : 0x80000000u, S_As + A_BYTES + jt * B_BYTES + piece * 1024);
     }
   };
   auto L_advance = [&]() {
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
     L_item += G;
     L_setup();
   };
-  constexpr int NPC = PW_A + PW_B;  // pieces per wave per slab
+  constexpr int NPC = PW_A + TPI * PW_B;  // pieces per wave per slab
 
   // ---- per-lane fragment coordinates -------------------------------------------------------------------------------
   const int cobase = wm * (BMC / 2);  // + mi*32 : output channels, on the lanes of D
@@ -176,24 +188,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
     const int split = v / kp.tiles;
     const int cib = tile % ckb;
     const int r1 = tile / ckb;
-    const int t = r1 % p.ntaps;
-    const int cb = r1 / p.ntaps;
-    const int wtap = p.taps[__builtin_amdgcn_readfirstlane(t)].wtap;
+    const int t = r1 % kp.ntg;
+    const int cb = r1 / kp.ntg;
     const int mbeg = split * kp.pix_per_split;
     int mend = mbeg + kp.pix_per_split;
     if (mend > kp.M) mend = kp.M;
 
-    f32x16 acc[MI][NI];
+    f32x16 acc[TPI][MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int jt = 0; jt < TPI; ++jt)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[jt][mi][ni][r] = 0.f;
 
     for (int m0 = mbeg; m0 < mend; m0 += BKP) {
       if (pending_st == NST) {
         if constexpr (NST == 16) MI355_WAIT_VM(16);
+        else if constexpr (NST == 12) MI355_WAIT_VM(12);
         else if constexpr (NST == 8) MI355_WAIT_VM(8);
         else MI355_WAIT_VM(4);
       } else {
@@ -205,36 +219,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
       if (lv) L_begin(stage ^ 1);
       const char* Ad = smem + stage * STAGE;
       const char* Bx = Ad + A_BYTES;
+      // the next slab's NPC pieces are spread evenly over the NS inner steps of this one
       if constexpr (ES == 4) {
+        constexpr int NS = BKP / 2;
 #pragma unroll
-        for (int kk = 0; kk < BKP / 2; ++kk) {
+        for (int kk = 0; kk < NS; ++kk) {
           const int k = 2 * kk + hh;
-          float xv[NI], dv[MI];
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) xv[ni] = *reinterpret_cast<const float*>(Bx + k * RB_B + (cibase + ni * 32 + c31) * 4);
+          float dv[MI];
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) dv[mi] = *reinterpret_cast<const float*>(Ad + k * RB_A + (cobase + mi * 32 + c31) * 4);
-          if (lv && (kk & 1) == 0 && (kk >> 1) < NPC) L_piece(kk >> 1);  // one piece of the next slab every other k pair
+          if (lv) {
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
+            for (int j = kk * NPC / NS; j < (kk + 1) * NPC / NS; ++j) L_piece(j);
+          }
+#pragma unroll
+          for (int jt = 0; jt < TPI; ++jt) {
+            float xv[NI];
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[ni], dv[mi], acc[mi][ni], 0, 0, 0);
+              xv[ni] = *reinterpret_cast<const float*>(Bx + jt * B_BYTES + k * RB_B + (cibase + ni * 32 + c31) * 4);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni)
+                acc[jt][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[ni], dv[mi], acc[jt][mi][ni], 0, 0, 0);
+          }
         }
       } else {
+        constexpr int NS = BKP / 16;
 #pragma unroll
-        for (int ks = 0; ks < BKP / 16; ++ks) {
+        for (int ks = 0; ks < NS; ++ks) {
           const int k0 = ks * 16 + t_krow;  // rows k0 and k0+4 share (row&3) and ((row>>1)&1): same swizzle
-          bf16x8 xf[NI], df[MI];
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            const int byte = (cibase + ni * 32 + t_col) * 2;
-            const char* ap = Bx + k0 * RB_B + ((((byte >> 4) ^ row_swz<ES, RB_B>(k0)) << 4) | (byte & 15));
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap + 4 * RB_B));
-            const s16x8 tmp = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            xf[ni] = __builtin_bit_cast(bf16x8, tmp);
-          }
+          bf16x8 df[MI];
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) {
             const int byte = (cobase + mi * 32 + t_col) * 2;
@@ -244,15 +260,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
             const s16x8 tmp = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             df[mi] = __builtin_bit_cast(bf16x8, tmp);
           }
-          if (lv) {  // two of the next slab's pieces go out between this k-step's LDS reads and its MFMAs
-            if (2 * ks < NPC) L_piece(2 * ks);
-            if (2 * ks + 1 < NPC) L_piece(2 * ks + 1);
+          if (lv) {  // the next slab's pieces go out between this k-step's LDS reads and its MFMAs
+#pragma unroll
+            for (int j = ks * NPC / NS; j < (ks + 1) * NPC / NS; ++j) L_piece(j);
           }
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
+          for (int jt = 0; jt < TPI; ++jt) {
+            bf16x8 xf[NI];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ni], df[mi], acc[mi][ni], 0, 0, 0);
+            for (int ni = 0; ni < NI; ++ni) {
+              const int byte = (cibase + ni * 32 + t_col) * 2;
+              const char* ap = Bx + jt * B_BYTES + k0 * RB_B + ((((byte >> 4) ^ row_swz<ES, RB_B>(k0)) << 4) | (byte & 15));
+              const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap));
+              const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap + 4 * RB_B));
+              const s16x8 tmp = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+              xf[ni] = __builtin_bit_cast(bf16x8, tmp);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni)
+                acc[jt][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ni], df[mi], acc[jt][mi][ni], 0, 0, 0);
+          }
         }
       }
       if (lv) L_advance();
@@ -262,16 +291,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
     // partial[split][co][wtap][ci]: D rows (registers) = input channels, D columns (lanes) = output channels
     float* outp = p.partial + (size_t)split * p.Cout * p.wtaps * p.Ck;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int co = cb * BMC + cobase + mi * 32 + c31;
-      float* rowp = outp + ((size_t)co * p.wtaps + wtap) * p.Ck + cib * BNC + cibase;
+    for (int jt = 0; jt < TPI; ++jt) {
+      const int wtap = p.taps[__builtin_amdgcn_readfirstlane(t * TPI + jt)].wtap;
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
+      for (int mi = 0; mi < MI; ++mi) {
+        const int co = cb * BMC + cobase + mi * 32 + c31;
+        float* rowp = outp + ((size_t)co * p.wtaps + wtap) * p.Ck + cib * BNC + cibase;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-          *reinterpret_cast<f32x4*>(rowp + ni * 32 + 8 * g + 4 * hh) = v;
-        }
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {acc[jt][mi][ni][4 * g], acc[jt][mi][ni][4 * g + 1], acc[jt][mi][ni][4 * g + 2],
+                             acc[jt][mi][ni][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(rowp + ni * 32 + 8 * g + 4 * hh) = v;
+          }
+      }
     }
     pending_st += NST;
   }
@@ -299,7 +333,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int spli
   }
 }
 
-// dw[64][7][7][3] <- partial[s][64][7][64] (kw*4 + c)
+// dw[64][7][7][3] <- partial[s][64][4][64]: tap pair kh>>1, element (kh&1)*32 + kw*4 + c
 __global__ void stem_unpack_kernel(const float* __restrict__ partial, int splits, float* __restrict__ dw, float beta) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 64 * 7 * 7 * 3) return;
@@ -309,16 +343,23 @@ __global__ void stem_unpack_kernel(const float* __restrict__ partial, int splits
   t /= 7;
   const int kh = t % 7;
   const int co = t / 7;
-  const size_t src = ((size_t)co * 7 + kh) * 64 + kw * 4 + c;
+  const size_t src = ((size_t)co * 4 + (kh >> 1)) * 64 + (kh & 1) * 32 + kw * 4 + c;
   float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += partial[(size_t)k * 64 * 7 * 64 + src];
+  for (int k = 0; k < splits; ++k) s += partial[(size_t)k * 64 * 4 * 64 + src];
   dw[i] = (beta != 0.f ? beta * dw[i] : 0.f) + s;
 }
 
 inline int wg_bmc(int Cout) { return Cout % 128 == 0 ? 128 : 64; }
 inline int wg_bnc(int Ck) { return Ck % 128 == 0 ? 128 : 64; }
+// taps per item: only the 64x64 tile has the registers (TPI*16 accumulators) and needs it (fetch-bound otherwise)
+inline int wg_tpi(int Cout, int Ck, int ntaps) {
+  if (wg_bmc(Cout) != 64 || wg_bnc(Ck) != 64) return 1;
+  if (ntaps % 4 == 0) return 4;
+  if (ntaps % 3 == 0) return 3;
+  return 1;
+}
 
-template <typename T, int BMC, int BNC>
+template <typename T, int BMC, int BNC, int TPI>
 int launch_t(const WgradArgs& a, int splits, hipStream_t stream) {
   constexpr int ES = (int)sizeof(T);
   constexpr int BKP = 128 / ES;
@@ -327,7 +368,8 @@ int launch_t(const WgradArgs& a, int splits, hipStream_t stream) {
   k.M = a.N * a.Ho * a.Wo;
   k.dWo = make_fastdiv((uint32_t)a.Wo);
   k.dHo = make_fastdiv((uint32_t)a.Ho);
-  k.tiles = (a.Cout / BMC) * a.ntaps * (a.Ck / BNC);
+  k.ntg = a.ntaps / TPI;
+  k.tiles = (a.Cout / BMC) * k.ntg * (a.Ck / BNC);
   k.splits = splits;
   k.items = k.tiles * splits;
   // splits are planned in 64-pixel units so that fp32 (32-pixel slabs) and bf16 (64) cut the pixels identically
@@ -342,8 +384,14 @@ int launch_t(const WgradArgs& a, int splits, hipStream_t stream) {
   // few tiles per split (small-channel layers): the same dy / x slabs are fetched by every tile of the split, so keep
   // them on one XCD; with many tiles the round-robin order measured faster
   k.xcd = (k.tiles <= 16 && k.tiles > 1 && grid % 8 == 0) ? 1 : 0;
-  const size_t lds = (size_t)2 * BKP * (BMC + BNC) * ES;
-  hipLaunchKernelGGL((wgrad_kernel<T, BMC, BNC>), dim3(grid), dim3(256), lds, stream, k);
+  const size_t lds = (size_t)2 * BKP * (BMC + TPI * BNC) * ES;
+  static bool attr_set = false;
+  if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
+    MI355_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<T, BMC, BNC, TPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_kernel<T, BMC, BNC, TPI>), dim3(grid), dim3(256), lds, stream, k);
   MI355_LAUNCH_CHECK();
   return 0;
 }
@@ -351,14 +399,19 @@ int launch_t(const WgradArgs& a, int splits, hipStream_t stream) {
 template <typename T>
 int launch_d(const WgradArgs& a, int splits, hipStream_t stream) {
   const int bmc = wg_bmc(a.Cout), bnc = wg_bnc(a.Ck);
-  if (bmc == 128) return bnc == 128 ? launch_t<T, 128, 128>(a, splits, stream) : launch_t<T, 128, 64>(a, splits, stream);
-  return bnc == 128 ? launch_t<T, 64, 128>(a, splits, stream) : launch_t<T, 64, 64>(a, splits, stream);
+  if (bmc == 128) return bnc == 128 ? launch_t<T, 128, 128, 1>(a, splits, stream) : launch_t<T, 128, 64, 1>(a, splits, stream);
+  if (bnc == 128) return launch_t<T, 64, 128, 1>(a, splits, stream);
+  switch (wg_tpi(a.Cout, a.Ck, a.ntaps)) {
+    case 4: return launch_t<T, 64, 64, 4>(a, splits, stream);
+    case 3: return launch_t<T, 64, 64, 3>(a, splits, stream);
+    default: return launch_t<T, 64, 64, 1>(a, splits, stream);
+  }
 }
 
 }  // namespace
 
 int plan_wgrad_splits(int dtype, int M, int Cout, int ntaps, int Ck) {
-  const int tiles = (Cout / wg_bmc(Cout)) * ntaps * (Ck / wg_bnc(Ck));
+  const int tiles = (Cout / wg_bmc(Cout)) * (ntaps / wg_tpi(Cout, Ck, ntaps)) * (Ck / wg_bnc(Ck));
   const int chunks = cdiv(M, 64);
   // items per persistent workgroup: ~1 in bf16 (halves the fp32 partial-slab traffic, which is what bounds the small
   // layers there), ~2 in fp32 (compute-bound: the finer grain evens out the tail) — measured same-box A/B; keep >= 8

@@ -296,12 +296,12 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
       l.splits = plan_wgrad_splits(c->dtype, N * l.Hout * l.Wout, l.Cout, l.K * l.K, l.Cin);
       max_wg = std::max(max_wg, (size_t)l.splits * wn * 4);
     } else {
-      l.splits = plan_wgrad_splits(c->dtype, N * l.Hout * l.Wout, 64, 7, STEM_CK);
-      max_wg = std::max(max_wg, (size_t)l.splits * 64 * 7 * 64 * 4);
+      l.splits = plan_wgrad_splits(c->dtype, N * l.Hout * l.Wout, 64, 4, STEM_CK);
+      max_wg = std::max(max_wg, (size_t)l.splits * 64 * 4 * 64 * 4);
     }
   };
   ar.add(&c->xpad, mi355_stem_xpad_bytes(c->dtype, N, c->H, c->W));
-  ar.add(&c->stem_pack, (size_t)64 * 7 * 64 * c->es);
+  ar.add(&c->stem_pack, (size_t)64 * 4 * 64 * c->es);
   conv_ws(c->stem);
   ar.add(&c->a0, act_bytes(c, c->stem.Hout, c->stem.Wout, 64));
   ar.add((void**)&c->a0_bits, act_bytes(c, c->stem.Hout, c->stem.Wout, 64) / 16);

@@ -36,13 +36,13 @@ __global__ void weight_prep_kernel(const Tin* __restrict__ w, T* __restrict__ w_
 template <typename T>
 __global__ void stem_pack_kernel(const float* __restrict__ w, T* __restrict__ packed) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 64 * 7 * 64) return;
-  const int e = i & 63;
+  if (i >= 64 * 4 * 64) return;
+  const int e = i & 31;  // element inside one image row's half of the 64-wide slab
   const int kw = e >> 2, c = e & 3;
-  const int kh = (i >> 6) % 7;
-  const int co = (i >> 6) / 7;
+  const int kh = 2 * ((i >> 6) & 3) + ((i >> 5) & 1);
+  const int co = i >> 8;
   float v = 0.f;
-  if (kw < 7 && c < 3) v = w[((co * 7 + kh) * 7 + kw) * 3 + c];
+  if (kh < 7 && kw < 7 && c < 3) v = w[((co * 7 + kh) * 7 + kw) * 3 + c];
   packed[i] = (T)v;
 }
 
@@ -77,7 +77,7 @@ int launch_transpose_any(int dtype, const void* w, void* wt, int Cout, int taps,
 }
 
 int launch_stem_pack(int dtype, const float* w, void* packed, hipStream_t stream) {
-  const int n = 64 * 7 * 64;
+  const int n = 64 * 4 * 64;
   if (dtype == MI355_F32)
     hipLaunchKernelGGL(stem_pack_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, stream, w, (float*)packed);
   else

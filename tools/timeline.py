@@ -4,6 +4,10 @@ import csv, glob, sys, collections
 d = sys.argv[1]
 f = (glob.glob(d + "/*/*_kernel_trace.csv") + glob.glob(d + "/*_kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
+import re
+def short(n):
+    m = re.search(r"(\w+_kernel)(I[^E]*E|<[^>]*>)?", n)
+    return (m.group(0) if m else n)[:60]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 sgd = [i for i, r in enumerate(rows) if "sgd" in r["Kernel_Name"]]
 lo, hi = sgd[-2] + 1, sgd[-1] + 1
@@ -21,7 +25,13 @@ for t, dlt in ev:
 print(f"step wall {(t1-t0)/1e6:.3f} ms, kernels {len(step)}, busy {busy/1e6:.3f} ms, idle {(t1-t0-busy)/1e6:.3f} ms, >=2 kernels {ovl/1e6:.3f} ms")
 by = collections.defaultdict(lambda: [0, 0.0])
 for r in step:
-    n = r["Kernel_Name"].split("(")[0][:70]
+    n = short(r["Kernel_Name"])
     by[n][0] += 1; by[n][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 for n, (k, ms) in sorted(by.items(), key=lambda kv: -kv[1][1]):
     print(f"{ms:8.3f} ms {k:4d}  {n}")
+
+if len(sys.argv) > 2:
+    k = int(sys.argv[2])
+    sel = step[:k] + step[-k:]
+    for r in sel:
+        print(f"{(int(r['Start_Timestamp'])-t0)/1e3:9.1f} us +{(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3:7.1f}  q{r.get('Queue_Id','?')} {short(r['Kernel_Name'])}")
