@@ -108,13 +108,23 @@ int launch_wgrad(int dtype, const WgradArgs& a, int splits, hipStream_t stream);
 int launch_splitk_reduce(const float* partial, int splits, size_t stride, float* dst, size_t n, float beta,
                          hipStream_t stream);
 // stem unpack: dw[64][7][7][3] = beta*dw + sum_s partial[s][co][kh>>1][(kh&1)*32 + kw*4+c]
-int launch_stem_unpack(const float* partial, int splits, float* dw, float beta, hipStream_t stream);
+int launch_stem_unpack(float* partial, int splits, float* dw, float beta, hipStream_t stream);  // reduces `partial` in place
 
 // weight preparation (weights.hip): fp32 KRSC master -> what the kernels consume
 //   wT (dtype) [Cout][taps][Cin]   (skipped when dtype==F32: the master is used directly; pass NULL)
 //   wTt(dtype) [Cin][taps][Cout]   transposed for dgrad (NULL to skip)
 int launch_weight_prep(int dtype, const float* w, void* w_cast, void* w_tr, int Cout, int taps, int Cin,
                        hipStream_t stream);
+// the same for every conv layer of a network in one launch; `table` (device memory) is sorted by tile_begin
+struct PrepDesc {
+  size_t w_off;    // offset of the fp32 master in `params` (elements)
+  void* w_cast;    // or null (cast copy not needed: fp32 ctx)
+  void* w_tr;      // or null (no dgrad: inference forward)
+  int Cout, taps, Cin;
+  int tile_begin;  // first block of this layer; a layer has (Cout/32)*(Cin/32)*taps blocks
+};
+int launch_weight_prep_batch(int dtype, const PrepDesc* table, int nlayers, int total_tiles, const float* params,
+                             hipStream_t stream);
 // same-dtype transpose [Cout][taps][Cin] -> [Cin][taps][Cout] (per-op API, weights already in `dtype`)
 int launch_transpose_any(int dtype, const void* w, void* wt, int Cout, int taps, int Cin, hipStream_t stream);
 // stem: w[64][7][7][3] fp32 -> packed [64][4][64] dtype: row pair kh>>1, element (kh&1)*32 + kw*4+c, zero padded

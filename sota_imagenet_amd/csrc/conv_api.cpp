@@ -238,7 +238,7 @@ int mi355_stem_wgrad(int dtype, const void* dy, const void* xpad, float* dw, flo
   a.dy = dy; a.x = xpad; a.partial = (float*)ws;
   hipStream_t s = (hipStream_t)stream;
   MI355_TRY(launch_wgrad(dtype, a, splits, s));
-  return launch_stem_unpack((const float*)ws, splits, dw, beta, s);
+  return launch_stem_unpack((float*)ws, splits, dw, beta, s);
 }
 
 size_t mi355_bn_workspace_bytes(int C) { return ((size_t)bn_max_blocks() * 2 * C + 8 * (size_t)C) * 4; }

@@ -311,25 +311,47 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
   }
 }
 
-__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int splits, size_t stride,
-                                     float* __restrict__ dst, size_t n4, float beta) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+// dst[i] = beta*dst[i] + sum_k partial[k][i].  A block is (256/SG) 16-byte columns x SG split groups: group g adds
+// slabs g, g+SG, ... in order (4 loads in flight), then the groups are added in order 0..SG-1 through LDS — the
+// summation order depends only on (splits, SG), never on timing.  SG > 1 is for small outputs, where one thread per
+// column would walk hundreds of slabs alone.
+template <int SG>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial, int splits, size_t stride,
+                                                            float* dst, size_t n4, float beta) {
+  constexpr int COLS = 256 / SG;
+  __shared__ f32x4 red[SG > 1 ? SG : 1][COLS];
+  const int col = threadIdx.x % COLS, sg = threadIdx.x / COLS;
+  for (size_t i0 = (size_t)blockIdx.x * COLS; i0 < n4; i0 += (size_t)gridDim.x * COLS) {
+    const size_t i = i0 + col;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 4 <= splits; k += 4) {  // 4 slabs in flight; the order of the adds stays k = 0,1,2,...
-      const f32x4 a = *reinterpret_cast<const f32x4*>(partial + (size_t)k * stride + i * 4);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(partial + (size_t)(k + 1) * stride + i * 4);
-      const f32x4 c = *reinterpret_cast<const f32x4*>(partial + (size_t)(k + 2) * stride + i * 4);
-      const f32x4 d = *reinterpret_cast<const f32x4*>(partial + (size_t)(k + 3) * stride + i * 4);
-      s += a;
-      s += b;
-      s += c;
-      s += d;
+    if (i < n4) {
+      int k = sg;
+      for (; k + 3 * SG < splits; k += 4 * SG) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(partial + (size_t)k * stride + i * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(partial + (size_t)(k + SG) * stride + i * 4);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(partial + (size_t)(k + 2 * SG) * stride + i * 4);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(partial + (size_t)(k + 3 * SG) * stride + i * 4);
+        s += a;
+        s += b;
+        s += c;
+        s += d;
+      }
+      for (; k < splits; k += SG) s += *reinterpret_cast<const f32x4*>(partial + (size_t)k * stride + i * 4);
     }
-    for (; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(partial + (size_t)k * stride + i * 4);
-    f32x4* d = reinterpret_cast<f32x4*>(dst + i * 4);
-    if (beta != 0.f) s += beta * (*d);
-    *d = s;
+    if constexpr (SG > 1) {
+      red[sg][col] = s;
+      __syncthreads();
+      if (sg == 0) {
+#pragma unroll
+        for (int g = 1; g < SG; ++g) s += red[g][col];
+      }
+    }
+    if (sg == 0 && i < n4) {
+      f32x4* d = reinterpret_cast<f32x4*>(dst + i * 4);
+      if (beta != 0.f) s += beta * (*d);
+      *d = s;
+    }
+    if constexpr (SG > 1) __syncthreads();
   }
 }
 
@@ -439,16 +461,28 @@ int launch_splitk_reduce(const float* partial, int splits, size_t stride, float*
                          hipStream_t stream) {
   MI355_ARG(n % 4 == 0 && stride % 4 == 0, "splitk_reduce: n=%zu stride=%zu must be multiples of 4", n, stride);
   const size_t n4 = n / 4;
-  int blocks = (int)((n4 + 255) / 256);
+  // small outputs with many slabs: several threads per column (see the kernel)
+  const int sg = (splits >= 64 && n4 < 16384) ? 16 : (splits >= 16 && n4 < 65536) ? 4 : 1;
+  const int cols = 256 / sg;
+  int blocks = (int)((n4 + cols - 1) / cols);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, splits, stride, dst, n4, beta);
+  if (sg == 16)
+    hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(blocks), dim3(256), 0, stream, partial, splits, stride, dst, n4, beta);
+  else if (sg == 4)
+    hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, stream, partial, splits, stride, dst, n4, beta);
+  else
+    hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, stream, partial, splits, stride, dst, n4, beta);
   MI355_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_stem_unpack(const float* partial, int splits, float* dw, float beta, hipStream_t stream) {
+int launch_stem_unpack(float* partial, int splits, float* dw, float beta, hipStream_t stream) {
   const int n = 64 * 7 * 7 * 3;
+  if (splits > 1) {  // slab 0 <- sum of the slabs (a column is read and written by the same threads: in place is safe)
+    MI355_TRY(launch_splitk_reduce(partial, splits, (size_t)64 * 4 * 64, partial, (size_t)64 * 4 * 64, 0.f, stream));
+    splits = 1;
+  }
   hipLaunchKernelGGL(stem_unpack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, partial, splits, dw, beta);
   MI355_LAUNCH_CHECK();
   return 0;

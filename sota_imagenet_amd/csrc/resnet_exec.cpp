@@ -94,6 +94,8 @@ struct mi355_ctx {
   uint8_t* a0_bits = nullptr;
   float *pooled = nullptr, *fc_tmp = nullptr, *dlogits_pad = nullptr, *dpooled = nullptr, *fc_wtr = nullptr;
   float *bn_partial = nullptr, *bn_coef = nullptr, *wg_partial = nullptr;
+  PrepDesc* prep_table[2] = {nullptr, nullptr};  // [0]: cast only (inference), [1]: cast + transposed (training)
+  int prep_layers = 0, prep_tiles = 0;
   // backward gradients: gG[2] carry the gradient wrt a block output down the network; gset[p] holds the per-layer
   // gradients (dy3, dy_ds, dy2, dy1) of the blocks of parity p — two sets so that the weight-gradient stream may
   // still be reading block k's gradients while block k+1 is written
@@ -329,6 +331,7 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
     const int fsplits = plan_wgrad_splits(MI355_F32, N, fcp, 1, 2048);
     max_wg = std::max(max_wg, (size_t)fsplits * fcp * 2048 * 4);
   }
+  for (int i = 0; i < 2; ++i) ar.add((void**)&c->prep_table[i], (size_t)64 * sizeof(PrepDesc));
   ar.add((void**)&c->bn_partial, (size_t)bn_max_blocks() * 2 * max_c * 4);
   ar.add((void**)&c->bn_coef, (size_t)3 * max_c * 4);
   ar.add((void**)&c->wg_partial, max_wg);
@@ -341,16 +344,8 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
 int weight_prep_all(mi355_ctx* c, bool need_tr, hipStream_t s) {
   Prof p(c, PC_OTHER, 0, 0, s);
   MI355_TRY(launch_stem_pack(c->dtype, c->params + c->stem.w_off, c->stem_pack, s));
-  auto prep = [&](ConvBN& l) -> int {
-    return launch_weight_prep(c->dtype, c->params + l.w_off, l.w_cast, need_tr ? l.w_tr : nullptr, l.Cout, l.K * l.K,
-                              l.Cin, s);
-  };
-  for (auto& b : c->blocks) {
-    MI355_TRY(prep(b.c1));
-    MI355_TRY(prep(b.c2));
-    MI355_TRY(prep(b.c3));
-    if (b.has_ds) MI355_TRY(prep(b.ds));
-  }
+  if (need_tr || c->dtype != MI355_F32)
+    MI355_TRY(launch_weight_prep_batch(c->dtype, c->prep_table[need_tr ? 1 : 0], c->prep_layers, c->prep_tiles, c->params, s));
   if (need_tr)
     MI355_TRY(launch_weight_prep(MI355_F32, c->params + c->fc_w_off, nullptr, c->fc_wtr, c->fc_pad, 1, 2048, s));
   return 0;
@@ -577,6 +572,34 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
     (void)hipFree(c->arena);
     delete c;
     return MI355_E_HIP;
+  }
+  // descriptor tables of the one-launch weight preparation
+  {
+    std::vector<PrepDesc> tab[2];
+    int tiles = 0;
+    auto add = [&](ConvBN& l) {
+      PrepDesc d;
+      d.w_off = l.w_off; d.w_cast = l.w_cast; d.w_tr = nullptr;
+      d.Cout = l.Cout; d.taps = l.K * l.K; d.Cin = l.Cin; d.tile_begin = tiles;
+      tab[0].push_back(d);
+      d.w_tr = l.w_tr;
+      tab[1].push_back(d);
+      tiles += (l.Cout / 32) * (l.Cin / 32) * l.K * l.K;
+    };
+    for (auto& b : c->blocks) {
+      add(b.c1); add(b.c2); add(b.c3);
+      if (b.has_ds) add(b.ds);
+    }
+    c->prep_layers = (int)tab[0].size();
+    c->prep_tiles = tiles;
+    bool ok = c->prep_layers <= 64;
+    for (int i = 0; i < 2 && ok; ++i)
+      ok = hipMemcpy(c->prep_table[i], tab[i].data(), tab[i].size() * sizeof(PrepDesc), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+      set_error("create: weight-prep table upload failed");
+      mi355_resnet50_destroy(c);
+      return MI355_E_HIP;
+    }
   }
   // weight-gradient side stream (MI355_WGRAD_STREAM=0 keeps everything on the caller's stream)
   const char* ov = getenv("MI355_WGRAD_STREAM");

@@ -33,6 +33,39 @@ __global__ void weight_prep_kernel(const Tin* __restrict__ w, T* __restrict__ w_
   }
 }
 
+// all conv layers of the network in ONE launch (53 tiny launches cost more in launch latency than in bytes): block b
+// finds its layer in the prefix table and does the same 32x32 tile as weight_prep_kernel
+template <typename T>
+__global__ void weight_prep_batch_kernel(const PrepDesc* __restrict__ table, int nlayers, const float* __restrict__ params) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.x;
+  int l = 0;
+  while (l + 1 < nlayers && table[l + 1].tile_begin <= b) ++l;  // uniform: scalar loads
+  const PrepDesc d = table[l];
+  const int local = b - d.tile_begin;
+  const int nci = d.Cin / 32, nco = d.Cout / 32;
+  const int ci0 = (local % nci) * 32, co0 = ((local / nci) % nco) * 32, t = local / (nci * nco);
+  const float* w = params + d.w_off;
+  T* w_cast = reinterpret_cast<T*>(d.w_cast);
+  T* w_tr = reinterpret_cast<T*>(d.w_tr);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const size_t src = ((size_t)(co0 + r) * d.taps + t) * d.Cin + ci0 + tx;
+    const float v = w[src];
+    tile[r][tx] = v;
+    if (w_cast) w_cast[src] = (T)v;
+  }
+  __syncthreads();
+  if (w_tr) {
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const size_t dst = ((size_t)(ci0 + r) * d.taps + t) * d.Cout + co0 + tx;
+      w_tr[dst] = (T)tile[tx][r];
+    }
+  }
+}
+
 template <typename T>
 __global__ void stem_pack_kernel(const float* __restrict__ w, T* __restrict__ packed) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -72,6 +105,16 @@ int launch_transpose_any(int dtype, const void* w, void* wt, int Cout, int taps,
   else
     hipLaunchKernelGGL((weight_prep_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)w,
                        (bf16_t*)nullptr, (bf16_t*)wt, Cout, taps, Cin);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_weight_prep_batch(int dtype, const PrepDesc* table, int nlayers, int total_tiles, const float* params,
+                             hipStream_t stream) {
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL(weight_prep_batch_kernel<float>, dim3(total_tiles), dim3(256), 0, stream, table, nlayers, params);
+  else
+    hipLaunchKernelGGL(weight_prep_batch_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, stream, table, nlayers, params);
   MI355_LAUNCH_CHECK();
   return 0;
 }
