@@ -94,6 +94,7 @@ struct mi355_ctx {
   uint8_t* a0_bits = nullptr;
   float *pooled = nullptr, *fc_tmp = nullptr, *dlogits_pad = nullptr, *dpooled = nullptr, *fc_wtr = nullptr;
   float *bn_partial = nullptr, *bn_coef = nullptr, *wg_partial = nullptr;
+  float *bn_partial2 = nullptr, *bn_coef2 = nullptr;  // the same for BN work issued to the side stream
   PrepDesc* prep_table[2] = {nullptr, nullptr};  // [0]: cast only (inference), [1]: cast + transposed (training)
   int prep_layers = 0, prep_tiles = 0;
   // backward gradients: gG[2] carry the gradient wrt a block output down the network; gset[p] holds the per-layer
@@ -107,6 +108,7 @@ struct mi355_ctx {
   std::vector<hipEvent_t> fork_ev;
   size_t fork_next = 0;
   hipEvent_t w_done[2] = {nullptr, nullptr};
+  hipEvent_t ds_done = nullptr;  // the downsample branch issued to the side stream has finished
   bool w_pending[2] = {false, false};
   bool w_dirty = false;
   int bwd_parity = 0;
@@ -186,6 +188,10 @@ enum { PC_IGEMM128 = 0, PC_IGEMM64 = 1, PC_WGRAD128 = 2, PC_WGRAD64 = 3, PC_BN_R
 inline int igemm_class(int ncols) { return ncols % 128 == 0 ? PC_IGEMM128 : PC_IGEMM64; }
 inline int wgrad_class(int cout) { return cout % 128 == 0 ? PC_WGRAD128 : PC_WGRAD64; }
 
+// BN scratch of the stream the work is issued to (the side stream has its own, the two run concurrently)
+inline float* bn_partial_of(mi355_ctx* c, hipStream_t s) { return (c->wstream && s == c->wstream) ? c->bn_partial2 : c->bn_partial; }
+inline float* bn_coef_of(mi355_ctx* c, hipStream_t s) { return (c->wstream && s == c->wstream) ? c->bn_coef2 : c->bn_coef; }
+
 double conv_flops(const mi355_ctx* c, const ConvBN& l) {
   return 2.0 * c->N * l.Hout * l.Wout * (double)l.Cout * l.Cin * l.K * l.K;
 }
@@ -196,7 +202,7 @@ int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, hipStrea
   IgemmArgs a;
   build_fwd_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
   a.in = in;
-  a.stat_partial = training ? c->bn_partial : nullptr;
+  a.stat_partial = training ? bn_partial_of(c, s) : nullptr;
   a.wt = c->dtype == MI355_F32 ? (const void*)(c->params + l.w_off) : (const void*)l.w_cast;
   a.out = l.y;
   const double fl = conv_flops(c, l);
@@ -219,10 +225,10 @@ int bn_prepare(mi355_ctx* c, ConvBN& l, int training, float momentum, hipStream_
     const float* pivot = nullptr;  // conv-epilogue partials are plain sums
     if (nblk == 0) {
       Prof p(c, PC_BN_REDUCE, 0, (double)M * C * c->es, s);
-      MI355_TRY(launch_bn_stats(c->dtype, l.y, c->bn_partial, c->bn_coef, &nblk, M, C, s));
-      pivot = c->bn_coef;
+      MI355_TRY(launch_bn_stats(c->dtype, l.y, bn_partial_of(c, s), bn_coef_of(c, s), &nblk, M, C, s));
+      pivot = bn_coef_of(c, s);
     }
-    return launch_bn_finalize(c->bn_partial, pivot, nblk, M, C, gamma, beta, c->buffers + l.rm_off, c->buffers + l.rv_off,
+    return launch_bn_finalize(bn_partial_of(c, s), pivot, nblk, M, C, gamma, beta, c->buffers + l.rm_off, c->buffers + l.rv_off,
                               save_mean, save_invstd, scale, shift, BN_EPS, momentum, s);
   }
   return launch_bn_eval_coeffs(gamma, beta, c->buffers + l.rm_off, c->buffers + l.rv_off, scale, shift, C, BN_EPS, s);
@@ -246,16 +252,16 @@ int bn_backward(mi355_ctx* c, ConvBN& l, const void* g, const uint8_t* bits, voi
   const double mask_bytes = bits ? (double)M * C * c->es / 16 : 0.0;
   {
     Prof p(c, PC_BN_REDUCE, 0, (double)M * C * c->es * (2 + (dz_out ? 1 : 0)) + mask_bytes, s);
-    MI355_TRY(launch_bn_bwd_reduce(c->dtype, g, nullptr, l.y, l.stat, l.stat + C, dz_out, c->bn_partial, &nblk, M, C, s,
+    MI355_TRY(launch_bn_bwd_reduce(c->dtype, g, nullptr, l.y, l.stat, l.stat + C, dz_out, bn_partial_of(c, s), &nblk, M, C, s,
                                    bits));
   }
-  MI355_TRY(launch_bn_bwd_finalize(c->bn_partial, nblk, M, C, c->params + l.gamma_off, l.stat + C,
-                                   c->grads + l.gamma_off, c->grads + l.beta_off, beta_acc, c->bn_coef, s));
+  MI355_TRY(launch_bn_bwd_finalize(bn_partial_of(c, s), nblk, M, C, c->params + l.gamma_off, l.stat + C,
+                                   c->grads + l.gamma_off, c->grads + l.beta_off, beta_acc, bn_coef_of(c, s), s));
   // after an in-place masked write-back the mask is already applied
   const uint8_t* bits2 = dz_out ? nullptr : bits;
   const void* g2 = dz_out ? dz_out : g;
   Prof p(c, PC_BN_BWD_APPLY, 0, (double)M * C * c->es * 3 + (bits2 ? mask_bytes : 0.0), s);
-  return launch_bn_bwd_apply(c->dtype, g2, nullptr, l.y, l.stat, l.stat + C, c->bn_coef, dx, M, C, s, bits2);
+  return launch_bn_bwd_apply(c->dtype, g2, nullptr, l.y, l.stat, l.stat + C, bn_coef_of(c, s), dx, M, C, s, bits2);
 }
 
 int conv_wgrad(mi355_ctx* c, ConvBN& l, const void* dy, const void* x, float beta_acc, hipStream_t s) {
@@ -334,6 +340,8 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
   for (int i = 0; i < 2; ++i) ar.add((void**)&c->prep_table[i], (size_t)64 * sizeof(PrepDesc));
   ar.add((void**)&c->bn_partial, (size_t)bn_max_blocks() * 2 * max_c * 4);
   ar.add((void**)&c->bn_coef, (size_t)3 * max_c * 4);
+  ar.add((void**)&c->bn_partial2, (size_t)bn_max_blocks() * 2 * max_c * 4);
+  ar.add((void**)&c->bn_coef2, (size_t)3 * max_c * 4);
   ar.add((void**)&c->wg_partial, max_wg);
   for (int i = 0; i < 2; ++i) ar.add(&c->gG[i], max_act);
   for (int p = 0; p < 2; ++p)
@@ -429,8 +437,10 @@ int backward_block(mi355_ctx* c, Block& b, float beta_acc, hipStream_t s) {
   MI355_TRY(fork(c, s, &ws));
   MI355_TRY(conv_wgrad(c, b.c3, B1, b.a2, beta_acc, ws));
   if (b.has_ds) {
-    MI355_TRY(bn_backward(c, b.ds, G, b.out_bits, nullptr, B2, beta_acc, s));  // B2 = dyd
-    MI355_TRY(fork(c, s, &ws));
+    // the whole downsample branch runs beside the conv3 -> conv1 chain (same fork: it only needs G)
+    MI355_TRY(bn_backward(c, b.ds, G, b.out_bits, nullptr, B2, beta_acc, ws));  // B2 = dyd
+    MI355_TRY(conv_dgrad(c, b.ds, B2, Gn, nullptr, ws));                        // Gn = shortcut gradient
+    if (c->overlap) MI355_HIP(hipEventRecord(c->ds_done, ws));
     MI355_TRY(conv_wgrad(c, b.ds, B2, b.in, beta_acc, ws));
   }
   MI355_TRY(conv_dgrad(c, b.c3, B1, B3, nullptr, s));                   // B3 = da2
@@ -442,8 +452,8 @@ int backward_block(mi355_ctx* c, Block& b, float beta_acc, hipStream_t s) {
   MI355_TRY(fork(c, s, &ws));
   MI355_TRY(conv_wgrad(c, b.c1, B4, b.in, beta_acc, ws));
   if (b.has_ds) {
-    MI355_TRY(conv_dgrad(c, b.ds, B2, Gn, nullptr, s));  // Gn = shortcut gradient
-    MI355_TRY(conv_dgrad(c, b.c1, B4, Gn, Gn, s));       // Gn = dx_in
+    if (c->overlap) MI355_HIP(hipStreamWaitEvent(s, c->ds_done, 0));
+    MI355_TRY(conv_dgrad(c, b.c1, B4, Gn, Gn, s));  // Gn = dx_in = conv1 dgrad + shortcut gradient
     c->cur_dout = Gn;
   } else {
     MI355_TRY(conv_dgrad(c, b.c1, B4, G, G, s, b.out_bits));  // G = dx_in = conv1 dgrad + masked G
@@ -609,6 +619,7 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
     c->fork_ev.resize(16);
     for (auto& ev : c->fork_ev) ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
     for (auto& ev : c->w_done) ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ds_done, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
       set_error("create: side stream / events -> %s", hipGetErrorString(hipGetLastError()));
       mi355_resnet50_destroy(c);
@@ -633,6 +644,7 @@ int mi355_resnet50_destroy(mi355_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   for (auto e : c->w_done)
     if (e) (void)hipEventDestroy(e);
+  if (c->ds_done) (void)hipEventDestroy(c->ds_done);
   if (c->wstream) (void)hipStreamDestroy(c->wstream);
   if (c->arena) (void)hipFree(c->arena);
   delete c;
@@ -704,6 +716,13 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
     MI355_TRY(launch_maxpool_fwd(c->dtype, c->a0, c->p0, c->pool_idx, N, c->stem.Hout, c->stem.Wout, 64, s));
   }
   for (auto& b : c->blocks) {
+    if (b.has_ds) {  // the downsample conv + its statistics run beside conv1..conv3
+      hipStream_t ws;
+      MI355_TRY(fork(c, s, &ws));
+      MI355_TRY(conv_forward(c, b.ds, b.in, training, ws));
+      MI355_TRY(bn_prepare(c, b.ds, training, bn_momentum, ws));
+      if (c->overlap) MI355_HIP(hipEventRecord(c->ds_done, ws));
+    }
     MI355_TRY(conv_forward(c, b.c1, b.in, training, s));
     MI355_TRY(bn_prepare(c, b.c1, training, bn_momentum, s));
     MI355_TRY(bn_apply(c, b.c1, nullptr, nullptr, b.a1, 1, s, training ? b.a1_bits : nullptr));
@@ -713,8 +732,7 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
     MI355_TRY(conv_forward(c, b.c3, b.a2, training, s));
     MI355_TRY(bn_prepare(c, b.c3, training, bn_momentum, s));
     if (b.has_ds) {
-      MI355_TRY(conv_forward(c, b.ds, b.in, training, s));
-      MI355_TRY(bn_prepare(c, b.ds, training, bn_momentum, s));
+      if (c->overlap) MI355_HIP(hipStreamWaitEvent(s, c->ds_done, 0));
       MI355_TRY(bn_apply(c, b.c3, nullptr, &b.ds, b.out, 1, s, training ? b.out_bits : nullptr));
     } else {
       MI355_TRY(bn_apply(c, b.c3, b.in, nullptr, b.out, 1, s, training ? b.out_bits : nullptr));

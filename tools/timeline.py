@@ -30,6 +30,10 @@ for r in step:
 for n, (k, ms) in sorted(by.items(), key=lambda kv: -kv[1][1]):
     print(f"{ms:8.3f} ms {k:4d}  {n}")
 
+for r in step:
+    if "ce_row" in r["Kernel_Name"]:
+        print(f"forward ends (ce_row starts) at {(int(r['Start_Timestamp'])-t0)/1e3:.1f} us")
+# per-phase busy time by kernel on the main queue
 if len(sys.argv) > 2:
     k = int(sys.argv[2])
     sel = step[:k] + step[-k:]
