@@ -43,7 +43,10 @@ struct ReduceArgs {
 };
 
 // MODE 0: s1 = sum x, s2 = sum x^2.   MODE 1: s1 = sum dz, s2 = sum dz*xhat.
-template <typename T, int MODE>
+// MASK (MODE 1): 0 none, 1 post-activation tensor, 2 bit mask;  DZ: also store the masked gradient.
+// The variants are template parameters, not runtime branches: a branch in the loop body keeps the compiler from
+// hoisting the loads of the unrolled iterations above the arithmetic, and these kernels live on loads in flight.
+template <typename T, int MODE, int MASK, bool DZ>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
   constexpr int V = Vec16<T>::N;
   __shared__ float red[2][256 * V];
@@ -94,17 +97,17 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
     } else {
       float gv[V];
       Vec16<T>::load(g + off, gv);
-      if (p.bits) {
+      if constexpr (MASK == 2) {
         const unsigned b = p.bits[off / V];
 #pragma unroll
         for (int e = 0; e < V; ++e) gv[e] = (b >> e) & 1u ? gv[e] : 0.f;
-      } else if (mk) {
+      } else if constexpr (MASK == 1) {
         float mv[V];
         Vec16<T>::load(mk + off, mv);
 #pragma unroll
         for (int e = 0; e < V; ++e) gv[e] = mv[e] > 0.f ? gv[e] : 0.f;
       }
-      if (dz_out) Vec16<T>::store(dz_out + off, gv);
+      if constexpr (DZ) Vec16<T>::store(dz_out + off, gv);
 #pragma unroll
       for (int e = 0; e < V; ++e) {
         const float xh = (xv[e] - mu[e]) * is[e];
@@ -266,7 +269,8 @@ struct ApplyArgs {
   int relu;
 };
 
-template <typename T>
+// RES: + residual;  X2: + second normalised tensor (downsample branch);  RELU: 0 none, 1 relu, 2 relu + bit mask out
+template <typename T, bool RES, bool X2, int RELU>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
   constexpr int V = Vec16<T>::N;
   const T* x = reinterpret_cast<const T*>(p.x);
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
   float sc[V], sh[V], sc2[V], sh2[V];
   load_consts<V>(p.scale, c0, sc);
   load_consts<V>(p.shift, c0, sh);
-  if (x2) {
+  if constexpr (X2) {
     load_consts<V>(p.scale2, c0, sc2);
     load_consts<V>(p.shift2, c0, sh2);
   } else {
@@ -295,20 +299,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
     Vec16<T>::load(x + i * V, v);
 #pragma unroll
     for (int e = 0; e < V; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
-    if (res) {
+    if constexpr (RES) {
       float rv[V];
       Vec16<T>::load(res + i * V, rv);
 #pragma unroll
       for (int e = 0; e < V; ++e) v[e] += rv[e];
     }
-    if (x2) {
+    if constexpr (X2) {
       float rv[V];
       Vec16<T>::load(x2 + i * V, rv);
 #pragma unroll
       for (int e = 0; e < V; ++e) v[e] += fmaf(rv[e], sc2[e], sh2[e]);
     }
-    if (p.relu) {
-      if (p.bits) {
+    if constexpr (RELU != 0) {
+      if constexpr (RELU == 2) {
         unsigned b = 0;
 #pragma unroll
         for (int e = 0; e < V; ++e) b |= (v[e] > 0.f ? 1u : 0u) << e;
@@ -334,7 +338,7 @@ struct BwdApplyArgs {
   int cvecs, C;
 };
 
-template <typename T>
+template <typename T, int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p) {
   constexpr int V = Vec16<T>::N;
   const T* g = reinterpret_cast<const T*>(p.g);
@@ -355,11 +359,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p)
     float gv[V], xv[V];
     Vec16<T>::load(g + i * V, gv);
     Vec16<T>::load(x + i * V, xv);
-    if (p.bits) {
+    if constexpr (MASK == 2) {
       const unsigned b = p.bits[i];
 #pragma unroll
       for (int e = 0; e < V; ++e) gv[e] = (b >> e) & 1u ? gv[e] : 0.f;
-    } else if (mk) {
+    } else if constexpr (MASK == 1) {
       float mv[V];
       Vec16<T>::load(mk + i * V, mv);
 #pragma unroll
@@ -419,9 +423,9 @@ int launch_bn_stats(int dtype, const void* x, float* partial, float* pivot, int*
   dim3 grid;
   *nblk_out = reduce_grid(dtype, M, C, &grid);
   if (dtype == MI355_F32)
-    hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((bn_reduce_kernel<float, 0, 0, false>), grid, dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0, 0, false>), grid, dim3(256), 0, s, a);
   MI355_LAUNCH_CHECK();
   return 0;
 }
@@ -478,10 +482,27 @@ int launch_bn_apply(int dtype, const void* x, const float* scale, const float* s
   a.cvecs = C / V;
   a.relu = relu;
   const int blocks = elementwise_blocks(a.nvec, a.cvecs);
-  if (dtype == MI355_F32)
-    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, a);
+  const int rl = relu ? (relu_bits ? 2 : 1) : 0;
+  const int variant = (residual ? 6 : 0) + (x2 ? 3 : 0) + rl;
+  MI355_ARG(!(residual && x2), "bn_apply: residual and second branch together are not supported");
+#define MI355_BN_APPLY(TT)                                                                                      \
+  switch (variant) {                                                                                            \
+    case 0: hipLaunchKernelGGL((bn_apply_kernel<TT, false, false, 0>), dim3(blocks), dim3(256), 0, s, a); break; \
+    case 1: hipLaunchKernelGGL((bn_apply_kernel<TT, false, false, 1>), dim3(blocks), dim3(256), 0, s, a); break; \
+    case 2: hipLaunchKernelGGL((bn_apply_kernel<TT, false, false, 2>), dim3(blocks), dim3(256), 0, s, a); break; \
+    case 3: hipLaunchKernelGGL((bn_apply_kernel<TT, false, true, 0>), dim3(blocks), dim3(256), 0, s, a); break;  \
+    case 4: hipLaunchKernelGGL((bn_apply_kernel<TT, false, true, 1>), dim3(blocks), dim3(256), 0, s, a); break;  \
+    case 5: hipLaunchKernelGGL((bn_apply_kernel<TT, false, true, 2>), dim3(blocks), dim3(256), 0, s, a); break;  \
+    case 6: hipLaunchKernelGGL((bn_apply_kernel<TT, true, false, 0>), dim3(blocks), dim3(256), 0, s, a); break;  \
+    case 7: hipLaunchKernelGGL((bn_apply_kernel<TT, true, false, 1>), dim3(blocks), dim3(256), 0, s, a); break;  \
+    default: hipLaunchKernelGGL((bn_apply_kernel<TT, true, false, 2>), dim3(blocks), dim3(256), 0, s, a); break; \
+  }
+  if (dtype == MI355_F32) {
+    MI355_BN_APPLY(float)
+  } else {
+    MI355_BN_APPLY(bf16_t)
+  }
+#undef MI355_BN_APPLY
   MI355_LAUNCH_CHECK();
   return 0;
 }
@@ -503,10 +524,23 @@ int launch_bn_bwd_reduce(int dtype, const void* g, const void* mask_src, const v
   a.C = C;
   dim3 grid;
   *nblk_out = reduce_grid(dtype, M, C, &grid);
-  if (dtype == MI355_F32)
-    hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), grid, dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1>), grid, dim3(256), 0, s, a);
+  const int mask = relu_bits ? 2 : mask_src ? 1 : 0;
+  const int variant = mask * 2 + (dz_out ? 1 : 0);
+#define MI355_BN_REDUCE(TT)                                                                                     \
+  switch (variant) {                                                                                            \
+    case 0: hipLaunchKernelGGL((bn_reduce_kernel<TT, 1, 0, false>), grid, dim3(256), 0, s, a); break;           \
+    case 1: hipLaunchKernelGGL((bn_reduce_kernel<TT, 1, 0, true>), grid, dim3(256), 0, s, a); break;            \
+    case 2: hipLaunchKernelGGL((bn_reduce_kernel<TT, 1, 1, false>), grid, dim3(256), 0, s, a); break;           \
+    case 3: hipLaunchKernelGGL((bn_reduce_kernel<TT, 1, 1, true>), grid, dim3(256), 0, s, a); break;            \
+    case 4: hipLaunchKernelGGL((bn_reduce_kernel<TT, 1, 2, false>), grid, dim3(256), 0, s, a); break;           \
+    default: hipLaunchKernelGGL((bn_reduce_kernel<TT, 1, 2, true>), grid, dim3(256), 0, s, a); break;           \
+  }
+  if (dtype == MI355_F32) {
+    MI355_BN_REDUCE(float)
+  } else {
+    MI355_BN_REDUCE(bf16_t)
+  }
+#undef MI355_BN_REDUCE
   MI355_LAUNCH_CHECK();
   return 0;
 }
@@ -547,10 +581,19 @@ int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const vo
   a.cvecs = C / V;
   a.C = C;
   const int blocks = elementwise_blocks(a.nvec, a.cvecs);
-  if (dtype == MI355_F32)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, a);
+  const int mask = relu_bits ? 2 : mask_src ? 1 : 0;
+#define MI355_BN_BWD_APPLY(TT)                                                                                  \
+  switch (mask) {                                                                                               \
+    case 0: hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, 0>), dim3(blocks), dim3(256), 0, s, a); break;          \
+    case 1: hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, 1>), dim3(blocks), dim3(256), 0, s, a); break;          \
+    default: hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, 2>), dim3(blocks), dim3(256), 0, s, a); break;         \
+  }
+  if (dtype == MI355_F32) {
+    MI355_BN_BWD_APPLY(float)
+  } else {
+    MI355_BN_BWD_APPLY(bf16_t)
+  }
+#undef MI355_BN_BWD_APPLY
   MI355_LAUNCH_CHECK();
   return 0;
 }

@@ -3,8 +3,9 @@
 import csv, glob, sys, ctypes
 sys.path.insert(0, '.')
 d = sys.argv[1]
-f = glob.glob(d + "/*/*_kernel_trace.csv")[0]
+f = (glob.glob(d + "/*/*_kernel_trace.csv") + glob.glob(d + "/*_kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))  # valid for single-stream runs (MI355_WGRAD_STREAM=0)
 conv = [r for r in rows if "igemm_kernel" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"]]
 # expected launch sequence of one training step (see csrc/resnet_exec.cpp)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 256
@@ -20,16 +21,16 @@ for st, (nb, p) in enumerate(zip((3, 4, 6, 3), (64, 128, 256, 512))):
         h, cin = ho, 4 * p
 seq.append(("igemm", "stem", fl(112, 3, 64, 7)))
 for name, hin, ho, ci, p, s, ds in blocks:
-    seq += [("igemm", name + ".c1", fl(hin, ci, p, 1)), ("igemm", name + ".c2", fl(ho, p, p, 3)), ("igemm", name + ".c3", fl(ho, p, 4 * p, 1))]
     if ds: seq.append(("igemm", name + ".ds", fl(ho, ci, 4 * p, 1)))
+    seq += [("igemm", name + ".c1", fl(hin, ci, p, 1)), ("igemm", name + ".c2", fl(ho, p, p, 3)), ("igemm", name + ".c3", fl(ho, p, 4 * p, 1))]
 seq.append(("igemm", "fc", 2.0 * N * 2048 * 1000))
 seq += [("wgrad", "fc.w", 2.0 * N * 2048 * 1000), ("igemm", "fc.d", 2.0 * N * 2048 * 1000)]
 for name, hin, ho, ci, p, s, ds in reversed(blocks):
-    seq += [("wgrad", name + ".c3.w", fl(ho, p, 4 * p, 1)), ("igemm", name + ".c3.d", fl(ho, p, 4 * p, 1)),
+    seq.append(("wgrad", name + ".c3.w", fl(ho, p, 4 * p, 1)))
+    if ds: seq += [("igemm", name + ".ds.d", fl(ho, ci, 4 * p, 1)), ("wgrad", name + ".ds.w", fl(ho, ci, 4 * p, 1))]
+    seq += [("igemm", name + ".c3.d", fl(ho, p, 4 * p, 1)),
             ("wgrad", name + ".c2.w", fl(ho, p, p, 3)), ("igemm", name + ".c2.d", fl(ho, p, p, 3)),
-            ("wgrad", name + ".c1.w", fl(hin, ci, p, 1))]
-    if ds: seq += [("wgrad", name + ".ds.w", fl(ho, ci, 4 * p, 1)), ("igemm", name + ".ds.d", fl(ho, ci, 4 * p, 1))]
-    seq.append(("igemm", name + ".c1.d", fl(hin, ci, p, 1)))
+            ("wgrad", name + ".c1.w", fl(hin, ci, p, 1)), ("igemm", name + ".c1.d", fl(hin, ci, p, 1))]
 seq.append(("wgrad", "stem.w", fl(112, 3, 64, 7)))
 n = len(seq)
 last = conv[-n:]
