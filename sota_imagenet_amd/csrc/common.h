@@ -75,7 +75,7 @@ struct IgemmArgs {
   void* out;           // [N][Hout][Wout][Ncols]
   const void* addend;  // optional, laid out like out
   const uint8_t* addend_bits = nullptr;  // optional ReLU mask of the addend (1 byte per 16-byte vector): masked before the add
-  float* stat_partial; // optional [2*workgroups][2][Ncols]: per (workgroup, wave-row) sums of out and out^2 (BN statistics)
+  float* stat_partial; // optional [stat_rows][2][Ncols]: per-workgroup-row sums of out and out^2 (BN statistics)
   int N, Hin, Win, pix_stride;
   int Hsub, Wsub, IS;
   int Hout, Wout, OS;

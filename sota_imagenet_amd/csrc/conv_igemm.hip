@@ -387,16 +387,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
     }
   }
   if constexpr (STATS) {
-    // flush: partial[2*workgroup + wm][0|1][channel]; every item of a workgroup has the same n-tile group because
-    // gridDim.x is a multiple of ngroups, so the workgroup owns channels [grp*chan, (grp+1)*chan)
+    // flush: partial[workgroup / ngroups][0|1][channel], the two wave rows added.  Every item of a workgroup has the
+    // same n-tile group because gridDim.x is a multiple of ngroups, so the workgroup owns channels
+    // [grp*chan, (grp+1)*chan) and the ngroups workgroups blockIdx.x/ngroups == r fill row r completely.
     MI355_LDS_BARRIER();
     const int chan = kp.ntpg * BN;
     const int grp = blockIdx.x % kp.ngroups;
-    for (int i = tid; i < 2 * chan; i += 256) {
-      const int wmi = i / chan, c = i - wmi * chan;
-      float* row = p.stat_partial + (size_t)(2 * blockIdx.x + wmi) * 2 * p.Ncols + grp * chan + c;
-      row[0] = stat_acc[(wmi * chan + c) * 2];
-      row[p.Ncols] = stat_acc[(wmi * chan + c) * 2 + 1];
+    float* row = p.stat_partial + (size_t)(blockIdx.x / kp.ngroups) * 2 * p.Ncols + grp * chan;
+    for (int c = tid; c < chan; c += 256) {
+      row[c] = stat_acc[c * 2] + stat_acc[(chan + c) * 2];
+      row[p.Ncols + c] = stat_acc[c * 2 + 1] + stat_acc[(chan + c) * 2 + 1];
     }
   }
 }
@@ -430,9 +430,8 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
   // the kernel would drop to one workgroup per CU, so the caller falls back to the standalone statistics kernel
   const int chan = k.ntpg * BN;
   const bool stats = a.stat_partial != nullptr && chan <= 512 && grid % ng == 0;
-  if (stat_rows) *stat_rows = stats ? 2 * grid : 0;
+  if (stat_rows) *stat_rows = stats ? grid / ng : 0;
   if (stats) {
-    if (ng > 1) MI355_HIP(hipMemsetAsync(a.stat_partial, 0, (size_t)2 * grid * 2 * a.Ncols * sizeof(float), stream));
     lds += (size_t)2 * chan * 2 * sizeof(float);
     hipLaunchKernelGGL((igemm_kernel<T, BN, true>), dim3(grid), dim3(256), lds, stream, k);
   } else {
