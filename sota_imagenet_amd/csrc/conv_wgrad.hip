@@ -435,14 +435,25 @@ int launch_d(const WgradArgs& a, int splits, hipStream_t stream) {
 int plan_wgrad_splits(int dtype, int M, int Cout, int ntaps, int Ck) {
   const int tiles = (Cout / wg_bmc(Cout)) * (ntaps / wg_tpi(Cout, Ck, ntaps)) * (Ck / wg_bnc(Ck));
   const int chunks = cdiv(M, 64);
-  // items per persistent workgroup: ~1 in bf16 (halves the fp32 partial-slab traffic, which is what bounds the small
-  // layers there), ~2 in fp32 (compute-bound: the finer grain evens out the tail) — measured same-box A/B; keep >= 8
-  // slabs of 64 pixels per item so the pipeline has a body
-  int splits = cdiv((dtype == MI355_F32 ? 2 : 1) * MAX_WG, tiles);
-  const int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  const int cps = cdiv(chunks, splits);
+  // The launch runs ceil(tiles*splits / MAX_WG) rounds of items of cdiv(chunks, splits) 64-pixel chunks each (+ ~2
+  // chunks worth of prologue/epilogue per item): take the split count that minimises rounds x item length.  fp32 is
+  // allowed two rounds (compute-bound: the finer grain evens out the tail; measured same-box A/B), bf16 one (the fp32
+  // partial slabs are what bounds the small layers there); keep >= 8 chunks per item so the pipeline has a body.
+  const int max_rounds = dtype == MI355_F32 ? 2 : 1;
+  int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;
+  if (max_splits > max_rounds * MAX_WG) max_splits = max_rounds * MAX_WG;
+  int best = 1;
+  long best_cost = -1;
+  for (int sp = 1; sp <= max_splits; ++sp) {
+    const int rounds = cdiv(tiles * sp, MAX_WG);
+    if (rounds > max_rounds && sp > 1) break;
+    const long cost = (long)rounds * (cdiv(chunks, sp) + 2);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best = sp;
+    }
+  }
+  const int cps = cdiv(chunks, best);
   return cdiv(chunks, cps);
 }
 
