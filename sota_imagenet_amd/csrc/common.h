@@ -75,7 +75,13 @@ struct IgemmArgs {
   void* out;           // [N][Hout][Wout][Ncols]
   const void* addend;  // optional, laid out like out
   const uint8_t* addend_bits = nullptr;  // optional ReLU mask of the addend (1 byte per 16-byte vector): masked before the add
-  float* stat_partial; // optional [stat_rows][2][Ncols]: per-workgroup-row sums of out and out^2 (BN statistics)
+  float* stat_partial; // optional [stat_rows][2][Ncols]: per-workgroup-row sums of out and out^2 (BN statistics), or,
+                       // when bn_y is set, of dz and dz*xhat (BN backward of the layer whose activation gradient `out`
+                       // is): dz = out under the ReLU mask bn_bits, xhat = (bn_y - bn_mean) * bn_invstd
+  const void* bn_y = nullptr;          // [N][Hout][Wout][Ncols], laid out like out
+  const uint8_t* bn_bits = nullptr;    // 1 byte per 16-byte vector of out
+  const float* bn_mean = nullptr;      // [Ncols]
+  const float* bn_invstd = nullptr;    // [Ncols]
   int N, Hin, Win, pix_stride;
   int Hsub, Wsub, IS;
   int Hout, Wout, OS;

@@ -46,7 +46,7 @@ struct IgemmKArgs {
   unsigned bytes_in, bytes_wt;
 };
 
-template <typename T, int BN, bool STATS>
+template <typename T, int BN, int STATS>  // STATS: 0 none, 1 forward BN statistics, 2 BN-backward sums (see common.h)
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
   const IgemmArgs& p = kp.a;
   constexpr int ES = (int)sizeof(T);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
   }
 
   // ---- prologue ---------------------------------------------------------------------------------------------------
-  if constexpr (STATS) {  // zeroed before the first barrier; first touched after the first epilogue barrier
+  if constexpr (STATS != 0) {  // zeroed before the first barrier; first touched after the first epilogue barrier
     for (int i = tid; i < 2 * kp.ntpg * BN * 2; i += 256) stat_acc[i] = 0.f;
   }
   L_setup();
@@ -287,7 +287,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
       }
       const int prw = lane & 31;
       const int rr = lane / CPR, ch = lane % CPR;
-      float s1[VEC], s2[VEC];  // STATS: this lane's share of sum / sum of squares of the tile's outputs AS STORED
+      // STATS 1: this lane's share of sum / sum of squares of the tile's outputs AS STORED
+      // STATS 2: of sum dz / sum dz*xhat, dz = stored output under the ReLU mask bn_bits, xhat from bn_y
+      float s1[VEC], s2[VEC];
+      float bmu[VEC], bis[VEC];
+      if constexpr (STATS == 2) {
+        const int c0 = n0 + wn * WN + ch * VEC;
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(p.bn_mean + c0 + 4 * q);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bn_invstd + c0 + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            bmu[4 * q + e] = a[e];
+            bis[4 * q + e] = b[e];
+          }
+        }
+      }
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         s1[e] = 0.f;
@@ -313,6 +329,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
         int pixs[NP];
         uint4 araw[NP];
         unsigned abits[NP];
+        uint4 yraw[NP];
+        unsigned ybits[NP];
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {  // all addend loads of this pass first: one round trip, not NP
           pixs[ps] = row_pix[wm * 64 + mi * 32 + ps * RPI + rr];
@@ -320,6 +338,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
             const size_t o = (size_t)(pixs[ps] < 0 ? 0 : pixs[ps]) * p.Ncols + n0 + wn * WN + ch * VEC;
             araw[ps] = *reinterpret_cast<const uint4*>(pixs[ps] < 0 ? reinterpret_cast<const T*>(g_zero_page) : addend + o);
             abits[ps] = p.addend_bits ? (unsigned)p.addend_bits[pixs[ps] < 0 ? 0 : o / VEC] : 0xffu;
+          }
+          if constexpr (STATS == 2) {
+            const size_t o = (size_t)(pixs[ps] < 0 ? 0 : pixs[ps]) * p.Ncols + n0 + wn * WN + ch * VEC;
+            yraw[ps] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.bn_y) + o);
+            ybits[ps] = (unsigned)p.bn_bits[o / VEC];
           }
         }
 #pragma unroll
@@ -343,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
           // rows past the end of the problem go to a trash page so that every thread issues exactly NST stores
           T* dst = pix < 0 ? reinterpret_cast<T*>(g_trash + tid * 16) : out + o;
           Vec16<T>::store(dst, v);
-          if constexpr (STATS) {
+          if constexpr (STATS == 1) {
             if (pix >= 0) {
 #pragma unroll
               for (int e = 0; e < VEC; ++e) {
@@ -353,10 +376,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
               }
             }
           }
+          if constexpr (STATS == 2) {
+            if (pix >= 0) {
+              float yv[VEC];
+              Vec16<T>::unpack(yraw[ps], yv);
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) {
+                const float dz = (ybits[ps] >> e) & 1u ? (float)(T)v[e] : 0.f;
+                s1[e] += dz;
+                s2[e] += dz * ((yv[e] - bmu[e]) * bis[e]);
+              }
+            }
+          }
         }
         asm volatile("" ::: "memory");
       }
-      if constexpr (STATS) {
+      if constexpr (STATS != 0) {
         // lanes with the same channel chunk sit CPR lanes apart (rows rr): park the per-lane sums in the wave-private
         // staging region, let lane c add up channel c's RPI rows and add the result to THIS wave's accumulator slot
         // (one fixed lane per slot, LDS is in-order per wave => deterministic, no atomics, nothing leaves the CU).
@@ -386,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
       pending_st += NST;
     }
   }
-  if constexpr (STATS) {
+  if constexpr (STATS != 0) {
     // flush: partial[workgroup / ngroups][0|1][channel], the two wave rows added.  Every item of a workgroup has the
     // same n-tile group because gridDim.x is a multiple of ngroups, so the workgroup owns channels
     // [grp*chan, (grp+1)*chan) and the ngroups workgroups blockIdx.x/ngroups == r fill row r completely.
@@ -433,9 +468,12 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
   if (stat_rows) *stat_rows = stats ? grid / ng : 0;
   if (stats) {
     lds += (size_t)2 * chan * 2 * sizeof(float);
-    hipLaunchKernelGGL((igemm_kernel<T, BN, true>), dim3(grid), dim3(256), lds, stream, k);
+    if (a.bn_y)
+      hipLaunchKernelGGL((igemm_kernel<T, BN, 2>), dim3(grid), dim3(256), lds, stream, k);
+    else
+      hipLaunchKernelGGL((igemm_kernel<T, BN, 1>), dim3(grid), dim3(256), lds, stream, k);
   } else {
-    hipLaunchKernelGGL((igemm_kernel<T, BN, false>), dim3(grid), dim3(256), lds, stream, k);
+    hipLaunchKernelGGL((igemm_kernel<T, BN, 0>), dim3(grid), dim3(256), lds, stream, k);
   }
   MI355_LAUNCH_CHECK();
   return 0;
