@@ -23,6 +23,9 @@
 //               (never __syncthreads, whose fence would drain the LDS-DMA queue).  2 workgroups per CU (64.5 KiB each).
 //   epilogue    each wave stages its 32 x BN/2 fp32 sub-tile through (XOR-swizzled) LDS and writes 16 bytes per lane,
 //               64..256 contiguous bytes per pixel; the optional addend (residual gradient) is read the same way.
+#include <cstdlib>
+#include <mutex>
+#include <set>
 #include <type_traits>
 
 #include "common.h"
@@ -33,9 +36,7 @@ namespace mi355 {
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int BKB = 128;  // bytes of K per slab (= one LDS row)
-constexpr int MAX_WG = 512;
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 __device__ __attribute__((aligned(256))) unsigned char g_trash[256 * 16];
@@ -46,20 +47,26 @@ struct IgemmKArgs {
   unsigned bytes_in, bytes_wt;
 };
 
-template <typename T, int BN, int STATS>  // STATS: 0 none, 1 forward BN statistics, 2 BN-backward sums (see common.h)
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
+// BM x BN: 128 x 64 | 128 x 128 (2 workgroups per CU) | 256 x 256 (1 per CU; a wave then owns 128 x 128 outputs, which
+// halves the LDS bytes moved per MFMA — the LDS port, DMA writes + fragment reads, is what bounds the smaller tiles)
+// STATS: 0 none, 1 forward BN statistics, 2 BN-backward sums (see common.h)
+template <typename T, int BM, int BN, int STATS>
+__global__ __launch_bounds__(256, (BM == 256 ? 1 : 2)) void igemm_kernel(const IgemmKArgs kp) {
   const IgemmArgs& p = kp.a;
   constexpr int ES = (int)sizeof(T);
   constexpr int BK = BKB / ES;
+  constexpr int MI = BM / 64;              // 32-pixel MFMA tiles per wave
   constexpr int NI = BN / 64;              // 32-channel MFMA tiles per wave
-  constexpr int PB = BN / 32;              // B pieces (1 KiB wave-instructions) per wave per slab
-  constexpr int A_BYTES = BM * BKB;        // 16 KiB
+  constexpr int PA = BM / 32;              // A pieces (1 KiB wave-instructions) per wave per slab
+  constexpr int PB = BN / 32;              // B pieces per wave per slab
+  constexpr int NPC = PA + PB;
+  constexpr int A_BYTES = BM * BKB;
   constexpr int STAGE = (BM + BN) * BKB;   // one ring stage
   constexpr int WN = BN / 2;               // channels per wave
   constexpr int VEC = 16 / ES;             // output elements per 16-byte store
   constexpr int CPR = WN / VEC;            // 16-byte output chunks per staged row
   constexpr int RPI = 64 / CPR;            // rows per wave-instruction in the read-back
-  constexpr int NST = 2 * (32 / RPI);      // global stores per thread per tile
+  constexpr int NST = MI * (32 / RPI);     // global stores per thread per tile
   constexpr int SCH = WN / 4;              // 16-byte fp32 chunks per staged row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* row_pix = reinterpret_cast<int*>(smem + 2 * STAGE);
@@ -80,8 +87,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
   int L_item = blockIdx.x, L_nt = 0, L_kt = 0, L_nk = 0, L_cls = 0, L_grp = 0;
   const i32x4 srdA = make_srd(p.in, kp.bytes_in);
   const i32x4 srdB = make_srd(p.wt, kp.bytes_wt);
-  unsigned a_off[4];   // byte offset of (row's pixel at tap offset (0,0)) + this lane's swizzled 16-byte chunk
-  int a_h[4], a_w[4];  // i*IS, j*IS of the row (a_h very negative => row beyond the problem)
+  unsigned a_off[PA];    // byte offset of (row's pixel at tap offset (0,0)) + this lane's swizzled 16-byte chunk
+  int a_h[PA], a_w[PA];  // i*IS, j*IS of the row (a_h very negative => row beyond the problem)
   unsigned b_off[PB];  // byte offset of this lane's weight row (n-tile 0, tap 0) + swizzled chunk
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
@@ -100,8 +107,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
         continue;
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = 32 * wave + 8 * i + prow;
+      for (int i = 0; i < PA; ++i) {
+        const int r = (BM / 4) * wave + 8 * i + prow;
         const int m = mt * BM + r;
         if (m < Msub) {
           const int j = m % p.Wsub;
@@ -145,14 +152,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
     S_dB = ((unsigned)n0 * p.wtaps + tp.wtap) * (unsigned)(p.Ck * ES) + (unsigned)(c0 * ES);
     S_As = __builtin_amdgcn_readfirstlane(lds_addr(smem) + stage * STAGE);
   };
-  auto L_piece = [&](int j) {  // j < 4: A piece j;  j >= 4: B piece j-4
-    if (j < 4) {
+  auto L_piece = [&](int j) {  // j < PA: A piece j;  j >= PA: B piece j-PA
+    if (j < PA) {
       const int ih = a_h[j] + S_dh;
       const int iw = a_w[j] + S_dw;
       const bool ok = ((unsigned)ih < (unsigned)p.Hin) && ((unsigned)iw < (unsigned)p.Win);
-      blds16(srdA, ok ? a_off[j] + (unsigned)S_dA : 0x80000000u, S_As + (32 * wave + 8 * j) * BKB);
+      blds16(srdA, ok ? a_off[j] + (unsigned)S_dA : 0x80000000u, S_As + ((BM / 4) * wave + 8 * j) * BKB);
     } else {
-      const int i = j - 4;
+      const int i = j - PA;
       blds16(srdB, b_off[i] + S_dB, S_As + A_BYTES + (PB * 8 * wave + 8 * i) * BKB);
     }
   };
@@ -166,10 +173,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
 
   // ---- fragment addresses (constant over the whole kernel) -------------------------------------------------------
   const int hh = lane >> 5;
-  int a_row[2], a_sw[2], b_row[NI], b_sw[NI];
+  int a_row[MI], a_sw[MI], b_row[NI], b_sw[NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int r = wm * 64 + mi * 32 + (lane & 31);
+  for (int mi = 0; mi < MI; ++mi) {
+    const int r = wm * (BM / 2) + mi * 32 + (lane & 31);
     a_row[mi] = r * BKB;
     a_sw[mi] = (r >> 1) & 7;
   }
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
   if (L_item < kp.items) {
     L_begin(0);
 #pragma unroll
-    for (int j = 0; j < 4 + PB; ++j) L_piece(j);
+    for (int j = 0; j < NPC; ++j) L_piece(j);
     L_advance();
   }
   int pending_st = 0;
@@ -207,9 +214,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
     const int m0 = mt * BM;
     for (int nti = 0; nti < kp.ntpg; ++nti) {
       const int n0 = (grp * kp.ntpg + nti) * BN;
-      f32x16 acc[2][NI];
+      f32x16 acc[MI][NI];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -218,7 +225,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
       for (int kt = 0; kt < nk; ++kt) {
         // the slab for this step was issued one step ago; epilogue stores issued since then may stay in flight
         if (pending_st == NST) {
-          if constexpr (NST == 16) MI355_WAIT_VM(16);
+          if constexpr (NST == 32) MI355_WAIT_VM(32);
+          else if constexpr (NST == 16) MI355_WAIT_VM(16);
           else if constexpr (NST == 8) MI355_WAIT_VM(8);
           else MI355_WAIT_VM(4);
         } else {
@@ -233,10 +241,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
         // read from LDS BEFORE the MFMAs of group g are issued (two register sets, static indices), and two of the next
         // slab's LDS-DMA pieces go out in between, so LDS latency and offset arithmetic hide under the matrix pipe.
         typedef typename std::conditional<ES == 4, f32x4, bf16x8>::type frag_t;
-        frag_t av[2][2], bv[2][NI];
+        frag_t av[2][MI], bv[2][NI];
         auto read_frags = [&](int g, int set) {
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
+          for (int mi = 0; mi < MI; ++mi)
             av[set][mi] = *reinterpret_cast<const frag_t*>(base + a_row[mi] + (((2 * g + hh) ^ a_sw[mi]) << 4));
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
@@ -247,20 +255,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
         for (int g = 0; g < 4; ++g) {
           if (g + 1 < 4) read_frags(g + 1, (g + 1) & 1);
           if (lv) {
-            if (2 * g < 4 + PB) L_piece(2 * g);
-            if (2 * g + 1 < 4 + PB) L_piece(2 * g + 1);
+#pragma unroll
+            for (int j = g * NPC / 4; j < (g + 1) * NPC / 4; ++j) L_piece(j);
           }
           if constexpr (ES == 4) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-              for (int mi = 0; mi < 2; ++mi)
+              for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
                   acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[g & 1][ni][e], av[g & 1][mi][e], acc[mi][ni], 0, 0, 0);
           } else {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
               for (int ni = 0; ni < NI; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[g & 1][ni], av[g & 1][mi], acc[mi][ni], 0, 0, 0);
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
         s2[e] = 0.f;
       }
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
+      for (int mi = 0; mi < MI; ++mi) {
         // a lane holds pixel prw and, per register group g, channels ni*32 + 8g + 4hh + {0..3}
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
         unsigned ybits[NP];
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {  // all addend loads of this pass first: one round trip, not NP
-          pixs[ps] = row_pix[wm * 64 + mi * 32 + ps * RPI + rr];
+          pixs[ps] = row_pix[wm * (BM / 2) + mi * 32 + ps * RPI + rr];
           if (addend) {
             const size_t o = (size_t)(pixs[ps] < 0 ? 0 : pixs[ps]) * p.Ncols + n0 + wn * WN + ch * VEC;
             araw[ps] = *reinterpret_cast<const uint4*>(pixs[ps] < 0 ? reinterpret_cast<const T*>(g_zero_page) : addend + o);
@@ -405,14 +413,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
           *reinterpret_cast<f32x4*>(scr + (RPI + rr) * WN + ch * VEC + 4 * q) = b;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane < WN) {
+#pragma unroll
+        for (int cc = lane; cc < WN; cc += 64) {
           float a = 0.f, b = 0.f;
 #pragma unroll
           for (int r = 0; r < RPI; ++r) {
-            a += scr[r * WN + lane];
-            b += scr[(RPI + r) * WN + lane];
+            a += scr[r * WN + cc];
+            b += scr[(RPI + r) * WN + cc];
           }
-          float* slot = stat_acc + ((wm * kp.ntpg + nti) * BN + wn * WN + lane) * 2;
+          float* slot = stat_acc + ((wm * kp.ntpg + nti) * BN + wn * WN + cc) * 2;
           slot[0] += a;
           slot[1] += b;
         }
@@ -436,8 +445,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKArgs kp) {
   }
 }
 
-template <typename T, int BN>
+// > 64 KiB of dynamic LDS needs an opt-in per kernel symbol (once)
+void lds_opt_in(const void* fn, size_t lds) {
+  if (lds <= 64 * 1024) return;
+  static std::mutex mu;
+  static std::set<const void*> done;
+  std::lock_guard<std::mutex> g(mu);
+  if (done.count(fn)) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  done.insert(fn);
+}
+
+template <typename T, int BM, int BN>
 int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
+  constexpr int MAX_WG = BM == 256 ? 256 : 512;  // persistent workgroups: 1 or 2 per CU
   IgemmKArgs k;
   k.a = a;
   const int Msub = a.N * a.Hsub * a.Wsub;
@@ -468,12 +489,15 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
   if (stat_rows) *stat_rows = stats ? grid / ng : 0;
   if (stats) {
     lds += (size_t)2 * chan * 2 * sizeof(float);
+    lds_opt_in((const void*)igemm_kernel<T, BM, BN, 1>, lds);
+    lds_opt_in((const void*)igemm_kernel<T, BM, BN, 2>, lds);
     if (a.bn_y)
-      hipLaunchKernelGGL((igemm_kernel<T, BN, 2>), dim3(grid), dim3(256), lds, stream, k);
+      hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 2>), dim3(grid), dim3(256), lds, stream, k);
     else
-      hipLaunchKernelGGL((igemm_kernel<T, BN, 1>), dim3(grid), dim3(256), lds, stream, k);
+      hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 1>), dim3(grid), dim3(256), lds, stream, k);
   } else {
-    hipLaunchKernelGGL((igemm_kernel<T, BN, 0>), dim3(grid), dim3(256), lds, stream, k);
+    lds_opt_in((const void*)igemm_kernel<T, BM, BN, 0>, lds);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 0>), dim3(grid), dim3(256), lds, stream, k);
   }
   MI355_LAUNCH_CHECK();
   return 0;
@@ -490,9 +514,22 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
   MI355_ARG(((size_t)a.pix_stride * dtype_size(dtype)) % 8 == 0, "igemm: pixel stride not 8-byte aligned");
   MI355_ARG(a.N > 0 && a.Hsub > 0 && a.Wsub > 0, "igemm: empty problem");
   const bool wide = (a.Ncols % 128 == 0);
-  if (dtype == MI355_F32) return wide ? launch_t<float, 128>(a, nclass, stream, stat_rows) : launch_t<float, 64>(a, nclass, stream, stat_rows);
-  if (dtype == MI355_BF16)
-    return wide ? launch_t<bf16_t, 128>(a, nclass, stream, stat_rows) : launch_t<bf16_t, 64>(a, nclass, stream, stat_rows);
+  if (dtype == MI355_F32)
+    return wide ? launch_t<float, 128, 128>(a, nclass, stream, stat_rows) : launch_t<float, 128, 64>(a, nclass, stream, stat_rows);
+  if (dtype == MI355_BF16) {
+    // 256 x 256 tiles (bf16 only: fp32 MFMAs are slow enough that the LDS port is not the limit).  Measured per layer
+    // shape at batch 256 (tools/one_conv.py): they win when the 256 single-workgroup CUs are still mostly filled
+    // (>= 192 tiles) and the reduction is long enough to amortise the larger epilogue (K >= 256); they lose on the
+    // HBM-bound layer-1/2 shapes and when layer 4's 98 row tiles leave most CUs idle.
+    static const int big_mode = [] { const char* e = getenv("MI355_IGEMM_BIG"); return e ? atoi(e) : -1; }();
+    const long items256 = (long)cdiv(a.N * a.Hsub * a.Wsub, 256) * nclass * (a.Ncols / 256);
+    int max_taps = 0;
+    for (int ci = 0; ci < nclass; ++ci) max_taps = a.cls[ci].ntaps > max_taps ? a.cls[ci].ntaps : max_taps;
+    // (not with the BN-backward sums: that epilogue needs more registers than the 256 x 256 tile leaves)
+    const bool big = a.Ncols % 256 == 0 && (big_mode < 0 ? (items256 >= 192 && max_taps * a.Ck >= 256 && !a.bn_y) : big_mode != 0);
+    if (big) return launch_t<bf16_t, 256, 256>(a, nclass, stream, stat_rows);
+    return wide ? launch_t<bf16_t, 128, 128>(a, nclass, stream, stat_rows) : launch_t<bf16_t, 128, 64>(a, nclass, stream, stat_rows);
+  }
   set_error("igemm: bad dtype %d", dtype);
   return MI355_E_ARG;
 }
