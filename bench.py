@@ -26,13 +26,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2516.6}  # MI355X_MICROARCH.md: dense MFMA peaks (no sparsity)
-KERNEL_NAMES = {0: "igemm_kernel<{T},128>", 1: "igemm_kernel<{T},64>", 2: "wgrad_kernel<{T},128,*>", 3: "wgrad_kernel<{T},64,*>"}
+# profile class -> kernel symbols (template instances of one source; names as tools/pmc_traffic.py writes them)
+KERNEL_NAMES = {0: ["igemm_kernel<{T},128,128>", "igemm_kernel<{T},256,256>"], 1: ["igemm_kernel<{T},128,64>"],
+                2: ["wgrad_kernel<{T},128,128>", "wgrad_kernel<{T},128,64>"], 3: ["wgrad_kernel<{T},64,128>", "wgrad_kernel<{T},64,64>"]}
 
 
-def pmc_traffic(kernel, dtype, batch, size):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/*_pmc_traffic_<dtype>.json, made by tools/pmc_traffic.py; PMC cannot be collected from inside the timed
-    run).  Only valid for the default workload; None otherwise."""
+def pmc_traffic(kernels, dtype, batch, size):
+    """HBM bytes per launch (launch-weighted over the symbols `kernels`) from the committed rocprofv3 --pmc passes of this
+    same command (profiles/*_pmc_traffic_<dtype>.json, made by tools/pmc_traffic.py; PMC cannot be collected from inside
+    the timed run).  Only valid for the default workload; None otherwise."""
     import glob
 
     if (batch, size) != (256, 224):
@@ -41,8 +43,10 @@ def pmc_traffic(kernel, dtype, batch, size):
     if not files:
         return None
     with open(files[-1]) as f:
-        rec = json.load(f)["kernels"].get(kernel)
-    return rec["hbm_bytes_per_launch"] if rec else None
+        table = json.load(f)["kernels"]
+    recs = [table[k] for k in kernels if k in table]
+    n = sum(r["launches"] for r in recs)
+    return int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in recs) / n) if n else None
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -148,13 +152,21 @@ def main():
             opt.step()
             return loss
 
+        dom = None
         for i in range(warmup):
+            if want_roof and i == warmup - 1:
+                model.profile((N, S, S), 0b1111)  # last warm-up step: which conv kernel class is the dominant one
             step(i)
         if want_roof:
-            model.profile((N, S, S), 0b1111)  # the four conv kernel symbols
+            tot = [model.profile_read((N, S, S), k)[0] for k in range(4)]
+            dom = max(range(4), key=lambda k: tot[k])
+            model.profile((N, S, S), 0)
+        nprof = min(4, steps)  # a timed event pair drains the queue around its kernel: sample the last few timed steps only
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
+            if want_roof and i == steps - nprof:
+                model.profile((N, S, S), 1 << dom)  # HIP events around the dominant class, inside the timed region
             loss = step(warmup + i)
         fence()
         dt = time.perf_counter() - t0
@@ -164,33 +176,34 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
-        return dt, loss.item(), model
+        return dt, loss.item(), model, dom
 
     shape = (N, S, S)
     want_roof = (not args.no_roofline) and rank == 0
-    dt, final_loss, model = run(args.dtype, args.steps, args.warmup, want_roof)
+    dt, final_loss, model, dom = run(args.dtype, args.steps, args.warmup, want_roof)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * N * args.steps / dt
         roof = None
+        roof_class = dom
         if want_roof:
-            best = None
-            for k in range(4):
-                tot_ms, launches, flops, nbytes = model.profile_read(shape, k)
-                if launches and (best is None or tot_ms > best[1]):
-                    best = (k, tot_ms, launches, flops, nbytes)
+            tot_ms, launches, flops, nbytes = model.profile_read(shape, dom)
+            best = (dom, tot_ms, launches, flops, nbytes) if launches else None
             model.profile(shape, 0)
             if best:
                 k, tot_ms, launches, flops, nbytes = best
                 ach = flops / (tot_ms * 1e-3) / 1e12
                 peak = PEAK_TFLOPS[args.dtype]
-                kname = KERNEL_NAMES[k].format(T="float" if args.dtype == "fp32" else "__bf16")
+                knames = [n.format(T="float" if args.dtype == "fp32" else "__bf16") for n in KERNEL_NAMES[k]]
                 roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": pmc_traffic(kname, args.dtype, N, S), "kernel": kname,
+                        "traffic": pmc_traffic(knames, args.dtype, N, S), "kernel": " + ".join(knames),
                         "launches": launches, "avg_launch_ms": round(tot_ms / launches, 4),
                         "alg_gflop_per_launch": round(flops / launches / 1e9, 3),
-                        "alg_bytes_per_launch": int(nbytes / launches)}
+                        "alg_bytes_per_launch": int(nbytes / launches),
+                        "event_steps": min(4, args.steps),
+                        "note": "timed with the weight-gradient side stream active: kernels of the two streams share the CUs, "
+                                "so a launch takes longer than it does alone (serial_frac: same kernels, side stream off)"}
         _, train_flops = model.flops(N, S, S)
         out = {
             "metric": "images/sec (whole node) ResNet-50 bs=256/GPU @224px",
@@ -203,11 +216,27 @@ def main():
                        "step_tflops": round(train_flops / (dt / args.steps) / 1e12, 2), "final_loss": round(final_loss, 4)},
             "roofline": roof,
         }
-        if world == 1 and not use_ddp and args.dtype == "bf16" and not args.no_secondary:
-            # BASELINE.json configs[1] (fp32, single MI355X) measured in the same process, for reference next to `value`
+        if roof is not None and world == 1 and not use_ddp:
+            # the same kernel class with every kernel on one stream (MI355_WGRAD_STREAM=0), untimed extra steps
             del model
             torch.cuda.empty_cache()
-            dt2, loss2, m2 = run("fp32", max(3, args.steps // 4), 2, False)
+            os.environ["MI355_WGRAD_STREAM"] = "0"
+            try:
+                _, _, ms_, dom_s = run(args.dtype, max(3, args.steps // 4), 2, True)
+                t_ms, n_l, fl, _ = ms_.profile_read(shape, dom_s)
+                ms_.profile(shape, 0)
+                if n_l and dom_s == roof_class:
+                    roof["serial_frac"] = round(fl / (t_ms * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4)
+                    roof["serial_avg_launch_ms"] = round(t_ms / n_l, 4)
+                del ms_
+            finally:
+                del os.environ["MI355_WGRAD_STREAM"]
+            model = None
+        if world == 1 and not use_ddp and args.dtype == "bf16" and not args.no_secondary:
+            # BASELINE.json configs[1] (fp32, single MI355X) measured in the same process, for reference next to `value`
+            model = None
+            torch.cuda.empty_cache()
+            dt2, loss2, m2, _ = run("fp32", max(3, args.steps // 4), 2, False)
             k2 = max(3, args.steps // 4)
             out["secondary"] = {"dtype": "fp32", "workload": "BASELINE configs[1]: ResNet-50 fp32 single MI355X bs=256 224px",
                                 "value": round(N * k2 / dt2, 1), "unit": "images/sec", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 3),

@@ -294,7 +294,10 @@ int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* ad
     a.stat_partial = bn_partial_of(c, s);
     a.bn_y = bn->y; a.bn_bits = bn_bits; a.bn_mean = bn->stat; a.bn_invstd = bn->stat + bn->Cout;
   }
-  const double by = ((double)c->N * l.Hin * l.Win * l.Cin * (addend ? 2 : 1) + (double)c->N * l.Hout * l.Wout * l.Cout) * c->es;
+  const double dx_elems = (double)c->N * l.Hin * l.Win * l.Cin;
+  // dy read, dx written, + the addend and (fused BN-backward sums) that layer's y read in the epilogue, masks at 1/16
+  const double by = (dx_elems * (1 + (addend ? 1 : 0) + (a.bn_y ? 1 : 0)) + (double)c->N * l.Hout * l.Wout * l.Cout) * c->es +
+                    dx_elems * c->es / 16 * ((addend_bits ? 1 : 0) + (a.bn_y ? 1 : 0));
   Prof p(c, igemm_class(l.Cin), conv_flops(c, l), by, s);
   return launch_igemm(c->dtype, a, nclass, s, bn && c->fuse_bn_bwd ? &bn->bwd_rows : nullptr);
 }

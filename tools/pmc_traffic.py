@@ -7,7 +7,7 @@ stream, which is what every kernel here issues — checked below on bn_reduce<.,
 
     cd /tmp && export TMPDIR=/tmp && cd $REPO
     for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- \
-        python3 bench.py --steps 2 --warmup 1 --dtype bf16 --no-cpu-baseline --no-roofline; done
+        python3 bench.py --steps 2 --warmup 1 --dtype bf16 --no-cpu-baseline --no-roofline --no-secondary; done   (MI355_WGRAD_STREAM=0)
     python tools/pmc_traffic.py gpurun_out bf16 > profiles/<round>_pmc_traffic_bf16.json
 """
 import collections
@@ -20,15 +20,20 @@ import sys
 
 def short(n):
     m = re.search(r"(igemm_kernel|wgrad_kernel|bn_reduce_kernel|bn_apply_kernel|bn_bwd_apply_kernel|bn_finalize_kernel|"
-                  r"splitk_reduce_kernel|sgd_kernel|maxpool_\w+_kernel|gap_\w+_kernel|stem_ingest_kernel|weight_prep_kernel)", n)
+                  r"splitk_reduce_kernel|sgd_kernel|maxpool_\w+_kernel|gap_\w+_kernel|stem_ingest_kernel|weight_prep_batch_kernel|weight_prep_kernel)", n)
     if not m:
         return None
     base = m.group(1)
-    if "bool _Accum" in n:  # rocprofv3's demangler garbles <__bf16, 1>
-        return f"{base}<__bf16,1>"
+    # keep the element type and the tile shape; drop the epilogue / mask variant parameters (one kernel source each)
+    keep = {"igemm_kernel": 3, "wgrad_kernel": 3}.get(base, 1)
+    if "bool _Accum" in n:  # rocprofv3's demangler garbles <__bf16, ...>
+        rest = re.search(base + r"<bool _Accum, (.*)>", n)
+        nums = re.findall(r"\d+", rest.group(1)) if rest else []
+        return f"{base}<{','.join(['__bf16'] + nums[:keep - 1])}>"
     if "<" in n:  # demangled
         t = re.search(base + r"<([^>]*)>", n)
-        return f"{base}<{t.group(1).replace(' ', '')}>" if t else base
+        args = [a.strip() for a in t.group(1).split(",")] if t else []
+        return f"{base}<{','.join(args[:keep])}>" if args else base
     t = re.search(base + r"I(.*?)EEv", n)  # Itanium-mangled template arguments
     if not t:
         return base
@@ -41,9 +46,12 @@ def short(n):
         elif rest.startswith("Li"):
             m2 = re.match(r"Li(\d+)E", rest)
             args.append(m2.group(1)); rest = rest[m2.end():]
+        elif rest.startswith("Lb"):
+            m2 = re.match(r"Lb(\d)E", rest)
+            args.append(m2.group(1)); rest = rest[m2.end():]
         else:
             rest = rest[1:]
-    return f"{base}<{','.join(args)}>"
+    return f"{base}<{','.join(args[:keep])}>"
 
 
 def load(root, counter):
@@ -68,6 +76,8 @@ def main():
         w_kib = wr[k][1] / max(wr[k][0], 1) if k in wr else 0.0
         out["kernels"][k] = {"launches": n, "fetch_kib_raw_per_launch": round(f_kib, 1), "write_kib_per_launch": round(w_kib, 1),
                              "hbm_bytes_per_launch": int((2 * f_kib + w_kib) * 1024)}
+    # note: with the weight-gradient side stream two kernels can be resident at once; the counters are still attributed
+    # per dispatch, so run the PMC passes with MI355_WGRAD_STREAM=0 (serial) for clean per-kernel numbers
     print(json.dumps(out, indent=1))
 
 
