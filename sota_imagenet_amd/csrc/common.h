@@ -173,6 +173,9 @@ int bn_max_blocks();
 
 // pooling / head / loss / optimizer
 int launch_maxpool_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, hipStream_t s);
+// p = maxpool3x3/2(relu(y*scale+shift)) + argmax + the ReLU bit mask of the (never stored) full-resolution activation
+int launch_bn_relu_maxpool(int dtype, const void* y, const float* scale, const float* shift, void* p, uint8_t* idx,
+                           uint8_t* bits, int N, int H, int W, int C, hipStream_t s);
 int launch_maxpool_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C,
                        hipStream_t s);
 int launch_gap_fwd(int dtype, const void* x, float* pooled, int N, int HW, int C, hipStream_t s);

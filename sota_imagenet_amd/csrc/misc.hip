@@ -80,6 +80,81 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, u
   }
 }
 
+// stem: p = maxpool3x3/2(relu(y*scale+shift)) straight from the raw conv output — the full-resolution activation is never
+// written (backward only needs its ReLU mask: one byte per 16-byte vector, written here by the window that owns the
+// pixel, (h>>1, w>>1), which always contains it).  Max/argmax semantics = maxpool_fwd_kernel on the rounded activation
+// (rounding is monotonic, so max-then-round gives the same value).
+template <typename T>
+__global__ void bn_relu_maxpool_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, T* __restrict__ p, uint8_t* __restrict__ idx,
+                                       uint8_t* __restrict__ bits, int N, int H, int W, int C, int Ho, int Wo) {
+  constexpr int V = Vec16<T>::N;
+  const int cv = C / V;
+  const size_t total = (size_t)N * Ho * Wo * cv;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cvi = (int)(i % cv);
+    const int c0 = cvi * V;
+    size_t t = i / cv;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float sc[V], sh[V];
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(scale + c0 + 4 * q);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(shift + c0 + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[4 * q + e] = a[e];
+        sh[4 * q + e] = b[e];
+      }
+    }
+    float best[V];
+    int bi[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      best[e] = -INFINITY;
+      bi[e] = -1;
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = oh * 2 - 1 + kh;
+      if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow * 2 - 1 + kw;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const size_t pix = ((size_t)n * H + ih) * W + iw;
+        float v[V];
+        Vec16<T>::load(y + pix * C + c0, v);
+        unsigned m = 0;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const float a = fmaf(v[e], sc[e], sh[e]);
+          m |= (a > 0.f ? 1u : 0u) << e;
+          v[e] = (float)(T)(a > 0.f ? a : 0.f);  // the value the unfused path would have stored
+          if (bi[e] < 0 || v[e] > best[e] || v[e] != v[e]) {
+            best[e] = v[e];
+            bi[e] = kh * 3 + kw;
+          }
+        }
+        if (kh >= 1 && kw >= 1) bits[pix * cv + cvi] = (uint8_t)m;  // pixels (2oh + kh-1, 2ow + kw-1): owned here
+      }
+    }
+    const size_t o = (((size_t)n * Ho + oh) * Wo + ow) * C + c0;
+    Vec16<T>::store(p + o, best);
+    if constexpr (V == 4) {
+      *reinterpret_cast<uint32_t*>(idx + o) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+    } else {
+      uint2 w;
+      w.x = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+      w.y = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
+      *reinterpret_cast<uint2*>(idx + o) = w;
+    }
+  }
+}
+
 template <typename T>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx,
                                    int N, int H, int W, int C, int Ho, int Wo) {
@@ -327,6 +402,22 @@ int launch_maxpool_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, i
   else
     hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N,
                        H, W, C, Ho, Wo);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_bn_relu_maxpool(int dtype, const void* y, const float* scale, const float* shift, void* p, uint8_t* idx,
+                           uint8_t* bits, int N, int H, int W, int C, hipStream_t s) {
+  MI355_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "bn_relu_maxpool: H=%d W=%d C=%d", H, W, C);
+  const int Ho = H / 2, Wo = W / 2;
+  const int V = 16 / (int)dtype_size(dtype);
+  const int grid = grid_for((size_t)N * Ho * Wo * (C / V));
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)y, scale, shift, (float*)p,
+                       idx, bits, N, H, W, C, Ho, Wo);
+  else
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, scale, shift,
+                       (bf16_t*)p, idx, bits, N, H, W, C, Ho, Wo);
   MI355_LAUNCH_CHECK();
   return 0;
 }

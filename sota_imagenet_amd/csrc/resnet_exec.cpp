@@ -91,7 +91,7 @@ struct mi355_ctx {
   // workspace
   char* arena = nullptr;
   size_t arena_bytes = 0;
-  void *xpad = nullptr, *stem_pack = nullptr, *a0 = nullptr, *p0 = nullptr;
+  void *xpad = nullptr, *stem_pack = nullptr, *p0 = nullptr;
   uint8_t* pool_idx = nullptr;
   uint8_t* a0_bits = nullptr;
   float *pooled = nullptr, *fc_tmp = nullptr, *dlogits_pad = nullptr, *dpooled = nullptr, *fc_wtr = nullptr;
@@ -325,7 +325,6 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
   ar.add(&c->xpad, mi355_stem_xpad_bytes(c->dtype, N, c->H, c->W));
   ar.add(&c->stem_pack, (size_t)64 * 4 * 64 * c->es);
   conv_ws(c->stem);
-  ar.add(&c->a0, act_bytes(c, c->stem.Hout, c->stem.Wout, 64));
   ar.add((void**)&c->a0_bits, act_bytes(c, c->stem.Hout, c->stem.Wout, 64) / 16);
   ar.add(&c->p0, act_bytes(c, c->stem.Hout / 2, c->stem.Wout / 2, 64));
   ar.add((void**)&c->pool_idx, (size_t)N * (c->stem.Hout / 2) * (c->stem.Wout / 2) * 64);
@@ -730,10 +729,12 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
     MI355_TRY(launch_igemm(c->dtype, a, 1, s, &c->stem.stat_rows));
   }
   MI355_TRY(bn_prepare(c, c->stem, training, bn_momentum, s));
-  MI355_TRY(bn_apply(c, c->stem, nullptr, nullptr, c->a0, 1, s, training ? c->a0_bits : nullptr));
   {
-    Prof p(c, PC_OTHER, 0, 0, s);
-    MI355_TRY(launch_maxpool_fwd(c->dtype, c->a0, c->p0, c->pool_idx, N, c->stem.Hout, c->stem.Wout, 64, s));
+    // BN + ReLU + 3x3/2 max pool in one pass over the raw stem output; the full-resolution activation is never stored
+    const int C = 64;
+    Prof p(c, PC_BN_APPLY, 0, (double)N * c->stem.Hout * c->stem.Wout * C * c->es * 1.25, s);
+    MI355_TRY(launch_bn_relu_maxpool(c->dtype, c->stem.y, c->stem.stat + 2 * C, c->stem.stat + 3 * C, c->p0, c->pool_idx,
+                                     c->a0_bits, N, c->stem.Hout, c->stem.Wout, C, s));
   }
   for (auto& b : c->blocks) {
     if (b.has_ds) {  // the downsample conv + its statistics run beside conv1..conv3
@@ -846,7 +847,6 @@ int mi355_resnet50_debug_tensor(const mi355_ctx* c, const char* name, void** ptr
     return 1;
   };
   if (conv_match(c->stem) == 0) return 0;
-  if (n == "stem.a0") return set4(c->a0, c->dtype, c->stem.Hout, c->stem.Wout, 64);
   if (n == "stem.p0") return set4(c->p0, c->dtype, c->stem.Hout / 2, c->stem.Wout / 2, 64);
   for (const auto& b : c->blocks) {
     if (conv_match(b.c1) == 0 || conv_match(b.c2) == 0 || conv_match(b.c3) == 0) return 0;

@@ -208,10 +208,12 @@ def test_teacher_forced_layers(dev, dtype, tol):
     x0 = R.nchw_to_nhwc(q(data))
     y = T("conv1.y")
     assert nerr(y, R.conv2d_fwd(x0, q(R.oihw_to_krsc(P["conv1.weight"])), 2, 3)) < tol, "stem conv"
-    a0 = T("stem.a0")
-    check_bn("bn1", y, a0)
+    # the stem's BN + ReLU + max pool are one kernel: the full-resolution activation is never stored
+    a0, _, _, mean, invstd = R.bn_train(y, P["bn1.weight"], P["bn1.bias"], torch.zeros_like(P["bn1.bias"]),
+                                        torch.ones_like(P["bn1.bias"]), None, True)
+    assert nerr(T("bn1.save_mean"), mean) < 1e-4 and nerr(T("bn1.save_invstd"), invstd) < 1e-4, "bn1"
     p0 = T("stem.p0")
-    assert torch.equal(p0, R.maxpool(a0)[0]), "maxpool"
+    assert nerr(p0, R.maxpool(q(a0))[0]) < max(tol, 1e-5), "bn1 + maxpool"
     prev = p0
     for st, nb in zip((1, 2, 3, 4), (3, 4, 6, 3)):
         for i in range(nb):
