@@ -26,6 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2516.6}  # MI355X_MICROARCH.md: dense MFMA peaks (no sparsity)
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+HBM_CLASS = 7  # executor profile class of bn_bwd_apply_kernel, the largest HBM-bound kernel of the step
 # profile class -> kernel symbols (template instances of one source; names as tools/pmc_traffic.py writes them)
 KERNEL_NAMES = {0: ["igemm_kernel<{T},128,128>", "igemm_kernel<{T},256,256>"], 1: ["igemm_kernel<{T},128,64>"],
                 2: ["wgrad_kernel<{T},128,128>", "wgrad_kernel<{T},128,64>"], 3: ["wgrad_kernel<{T},64,128>", "wgrad_kernel<{T},64,64>"]}
@@ -166,7 +168,8 @@ def main():
         t0 = time.perf_counter()
         for i in range(steps):
             if want_roof and i == steps - nprof:
-                model.profile((N, S, S), 1 << dom)  # HIP events around the dominant class, inside the timed region
+                # HIP events around the dominant conv class and the largest HBM-bound kernel, inside the timed region
+                model.profile((N, S, S), (1 << dom) | (1 << HBM_CLASS))
             loss = step(warmup + i)
         fence()
         dt = time.perf_counter() - t0
@@ -190,7 +193,6 @@ def main():
         if want_roof:
             tot_ms, launches, flops, nbytes = model.profile_read(shape, dom)
             best = (dom, tot_ms, launches, flops, nbytes) if launches else None
-            model.profile(shape, 0)
             if best:
                 k, tot_ms, launches, flops, nbytes = best
                 ach = flops / (tot_ms * 1e-3) / 1e12
@@ -204,6 +206,17 @@ def main():
                         "event_steps": min(4, args.steps),
                         "note": "timed with the weight-gradient side stream active: kernels of the two streams share the CUs, "
                                 "so a launch takes longer than it does alone (serial_frac: same kernels, side stream off)"}
+        roof_hbm = None
+        if want_roof:
+            t_ms, n_l, _, nbytes = model.profile_read(shape, HBM_CLASS)
+            if n_l:
+                gbs = nbytes / (t_ms * 1e-3) / 1e9
+                tdt = "float" if args.dtype == "fp32" else "__bf16"
+                roof_hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": pmc_traffic([f"bn_bwd_apply_kernel<{tdt}>"], args.dtype, N, S),
+                            "kernel": f"bn_bwd_apply_kernel<{tdt}>", "launches": n_l, "avg_launch_ms": round(t_ms / n_l, 4),
+                            "alg_bytes_per_launch": int(nbytes / n_l)}
+            model.profile(shape, 0)
         _, train_flops = model.flops(N, S, S)
         out = {
             "metric": "images/sec (whole node) ResNet-50 bs=256/GPU @224px",
@@ -215,6 +228,7 @@ def main():
                        "global_batch": world * N, "image_size": S, "parallelism": f"dp{world}",
                        "step_tflops": round(train_flops / (dt / args.steps) / 1e12, 2), "final_loss": round(final_loss, 4)},
             "roofline": roof,
+            "roofline_hbm": roof_hbm,
         }
         if roof is not None and world == 1 and not use_ddp:
             # the same kernel class with every kernel on one stream (MI355_WGRAD_STREAM=0), untimed extra steps
