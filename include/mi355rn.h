@@ -168,7 +168,11 @@ size_t mi355_resnet50_workspace_bytes(const mi355_ctx* ctx);
 int mi355_resnet50_bind(mi355_ctx* ctx, float* params, float* grads, float* buffers);
 
 /* logits[N,num_classes] fp32 = model(x_nchw[N,3,H,W] fp32).  training!=0: batch statistics, running
- * stats updated with `bn_momentum`, activations saved for backward.  training==0: running stats.     */
+ * stats updated with `bn_momentum`, activations saved for backward.  training==0: running stats.
+ * Streams: the dependent kernel chain is issued to `stream`; independent work (weight gradients, the
+ * downsample branch) goes to a side stream the ctx owns, forked from / joined to `stream` with events, so
+ * on return everything is ordered on `stream` as if it had run there (MI355_WGRAD_STREAM=0 in the
+ * environment at create time keeps every kernel on `stream`).  Results are bit-identical either way.   */
 int mi355_resnet50_forward(mi355_ctx* ctx, const float* x_nchw, float* logits, int training,
                            float bn_momentum, void* stream);
 
@@ -176,7 +180,8 @@ int mi355_resnet50_forward(mi355_ctx* ctx, const float* x_nchw, float* logits, i
  * from layer4.2 down to layer1.0, last = stem) so the caller can launch a gradient all-reduce on a side
  * stream as soon as a segment's slice [grad_begin, grad_end) of the flat gradient array is complete.
  * Segments must be run in order 0..n-1 after a training forward.  Gradients OVERWRITE the flat array
- * (accumulate != 0: add into it, for accumulate_steps > 1 — arg_parser.py:85-86).                   */
+ * (accumulate != 0: add into it, for accumulate_steps > 1 — arg_parser.py:85-86).  Every call ends by
+ * joining the side stream: prefer one call per gradient bucket over one call per segment.            */
 int mi355_resnet50_num_segments(const mi355_ctx* ctx);
 int mi355_resnet50_segment_range(const mi355_ctx* ctx, int seg, size_t* grad_begin, size_t* grad_end);
 int mi355_resnet50_backward(mi355_ctx* ctx, const float* dlogits, int seg_begin, int seg_end,
@@ -187,7 +192,8 @@ int mi355_resnet50_flops(const mi355_ctx* ctx, double* fwd_flops, double* train_
 
 /* Test hook: device pointer / shape of an internal tensor of the last step, by name:
  *   "<conv>.y" raw conv output, "<block>.a1|a2|out" post-activation tensors (e.g. "layer1.0.out"),
- *   "<bn>.save_mean|save_invstd", "stem.a0", "stem.p0", "pooled", "dpooled", "gbuf0".."gbuf3".
+ *   "<bn>.save_mean|save_invstd", "stem.p0" (the stem's BN+ReLU+maxpool output; the 112x112 activation itself
+ *   is never stored), "pooled", "dpooled", "gG0".."gG1" (block-output gradients of the last backward).
  * shape is NHWC (ndim 4) or [n] / [N,C]; dtype is MI355_F32 or the ctx dtype.  Read-only use.     */
 int mi355_resnet50_debug_tensor(const mi355_ctx* ctx, const char* name, void** ptr, int* dtype, int* ndim,
                                 int shape[4]);
@@ -195,8 +201,8 @@ int mi355_resnet50_debug_tensor(const mi355_ctx* ctx, const char* name, void** p
 /* HIP-event timing of kernel classes inside a step, recorded on the stream the kernels are launched on.
  * mi355_resnet50_profile(ctx, class_mask): bit k set => every launch of class k is bracketed by a pair of
  * hipEvents from now on (mask 0 switches it off; calling it also clears earlier records).  Classes:
- *   0 igemm_kernel<T,128> (conv fwd + dgrad, >=128 output channels)   1 igemm_kernel<T,64> (incl. stem)
- *   2 wgrad_kernel<T,128>   3 wgrad_kernel<T,64> (incl. stem)   4 bn_reduce_kernel (stats + bwd sums)
+ *   0 igemm_kernel<T,128|256,128|256,*> (conv fwd + dgrad, >=128 output channels)   1 igemm_kernel<T,128,64,*> (incl. stem)
+ *   2 wgrad_kernel<T,128,*>   3 wgrad_kernel<T,64,*> (incl. stem)   4 bn_reduce_kernel (stats + bwd sums)
  *   5 bn_apply_kernel   6 other (ingest, pools, FC, weight prep)   7 bn_bwd_apply_kernel
  * (one class = one kernel symbol, so the averages can be checked against rocprofv3 --kernel-trace --stats)
  * mi355_resnet50_profile_read(ctx, k, ...) waits for the recorded events of class k and returns their
