@@ -32,14 +32,13 @@ __device__ __forceinline__ i32x4 make_srd(const void* p, unsigned bytes) {
 // (lds_dst wave-uniform); voff >= num_records => zeros (verified on MI355X by tools/micro/blds_test.hip).
 // Inline asm on purpose: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the first VALU write of the address
 // registers of a __builtin_amdgcn_*_load_lds, which serialises the very loads this pipeline keeps in flight; the
-// hardware reads the offset at issue, so no wait is needed.  M0 is saved/restored around the instruction.
+// hardware reads the offset at issue, so no wait is needed.
 __device__ __forceinline__ void blds16(i32x4 srd, unsigned voff, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(srd), "s"(lds_dst)
-      : "memory");
+  // M0 (the LDS base of the DMA) is declared clobbered instead of saved/restored: two scalar instructions less per piece
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+               :
+               : "v"(voff), "s"(srd), "s"(lds_dst)
+               : "memory", "m0");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(unsigned long long)(lptr_t)p;
