@@ -521,7 +521,8 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
     // shape at batch 256 (tools/one_conv.py): they win when the 256 single-workgroup CUs are still mostly filled
     // (>= 192 tiles) and the reduction is long enough to amortise the larger epilogue (K >= 256); they lose on the
     // HBM-bound layer-1/2 shapes and when layer 4's 98 row tiles leave most CUs idle.
-    static const int big_mode = [] { const char* e = getenv("MI355_IGEMM_BIG"); return e ? atoi(e) : -1; }();
+    const char* big_env = getenv("MI355_IGEMM_BIG");  // 0 never / 1 wherever N % 256 == 0 (tests, A/B); unset: the rule
+    const int big_mode = big_env ? atoi(big_env) : -1;
     const long items256 = (long)cdiv(a.N * a.Hsub * a.Wsub, 256) * nclass * (a.Ncols / 256);
     int max_taps = 0;
     for (int ci = 0; ci < nclass; ++ci) max_taps = a.cls[ci].ntaps > max_taps ? a.cls[ci].ntaps : max_taps;

@@ -182,10 +182,12 @@ def test_bf16_forward_backward_vs_cpu_yardstick(dev):
     assert l2err(g, g64) < 1.5 * l2err(gb, g64) + 5e-2
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
-def test_teacher_forced_layers(dev, dtype, tol):
+@pytest.mark.parametrize("dtype,tol,big", [("fp32", 2e-5, None), ("bf16", 2e-2, None), ("bf16", 2e-2, "1")])
+def test_teacher_forced_layers(dev, dtype, tol, big, monkeypatch):
     """Every forward stage of the executor, re-derived by the oracle FROM THE EXECUTOR'S OWN INPUT to that stage
     (saved activations read back through the debug hook): conv, BN(+ReLU), residual add, maxpool, GAP, FC."""
+    if big is not None:  # force the 256x256 conv tiles (normally chosen only at training-size batches) on every layer
+        monkeypatch.setenv("MI355_IGEMM_BIG", big)  # with N % 256 == 0 output channels
     tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
     N, S = 4, 64
     key = (N, S, S)
@@ -337,4 +339,34 @@ def test_fused_bn_backward_sums_match_standalone_reduce(dev):
     assert errs[0] == 0.0, "fc gradients do not depend on any BN backward"
     assert errs[1] < 1e-4, f"layer4.2: {errs[1]:.3e}"
     assert max(errs[:4]) < 2e-2, f"layer4: {errs[:4]}"  # measured 2e-6, 8e-4, 4e-3: bf16 rounding flips, amplified
+    assert max(errs) < 0.3, f"per-segment drift {['%.1e' % x for x in errs]}"
+
+
+@pytest.mark.parametrize("fuse", ["0", "1"])
+def test_256_wide_conv_tiles_in_backward_match_128_wide(dev, fuse, monkeypatch):
+    """The 256x256 igemm tile is chosen by a rule that only fires at training-size batches.  Forward coverage is
+    test_teacher_forced_layers[bf16-big]; here the SAME forward (128-wide) is followed by a backward with the 256-wide
+    tile forced on every dgrad whose output has N % 256 == 0 channels (with and without the BN-backward epilogue) and by
+    one with 128-wide tiles.  A dgrad output element sums its k-steps in the same order in both; only the grouping of the
+    fused BN sums differs, so the gradients must agree tightly at the top of the network and drift only by bf16 rounding
+    flips further down."""
+    from sota_imagenet_amd.losses import CrossEntropyLoss
+
+    monkeypatch.setenv("MI355_FUSE_BN_BWD", fuse)
+    grads = []
+    for big in ("1", "0"):
+        monkeypatch.setenv("MI355_IGEMM_BIG", "0")
+        m, _ = build("bf16")
+        m.train()
+        data, target = synthetic_batch(8, 64, seed=11, index=0)
+        loss = CrossEntropyLoss(smoothing=0.1).cuda()(m(data.cuda()), target.cuda())
+        monkeypatch.setenv("MI355_IGEMM_BIG", big)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append(m.flat_grads.detach().clone().cpu())
+        segs = m.grad_segments
+    errs = [l2err(grads[0][b:e], grads[1][b:e]) for b, e in segs]
+    # fc: exact; layer4.2: exact without the fused sums, ~2e-6 with them (its bn1/bn2 sums are grouped differently)
+    assert errs[0] == 0.0 and errs[1] < 1e-5, f"fc / layer4.2: {errs[:2]}"
+    assert errs[2] < 5e-3, f"layer4.1: {errs[2]:.3e}"
     assert max(errs) < 0.3, f"per-segment drift {['%.1e' % x for x in errs]}"
