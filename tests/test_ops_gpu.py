@@ -38,6 +38,12 @@ CONV_CASES = [
     (3, 7, 7, 256, 128, 3, 1),      # M=147: ragged last row tile
     (1, 56, 56, 64, 64, 3, 1),
     (2, 16, 16, 192, 320, 3, 2),    # Cout not a multiple of 128, Cin 3 k-slabs in fp32
+    # mid-size: more items than persistent workgroups (several rounds per workgroup), 3-tap wgrad items with many splits
+    (32, 56, 56, 64, 64, 3, 1),
+    # 196 tiles of 256 rows, N % 256 == 0, K = 256: the 256x256 tile is chosen by the rule (bf16); wgrad: 4 tiles x 128
+    # splits = 512 workgroups, XCD-local item order
+    (64, 28, 28, 256, 256, 1, 1),
+    (16, 28, 28, 128, 128, 3, 2),   # stride-2 3x3: four dgrad parity classes, several row tiles each
 ]
 
 
