@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
 #pragma unroll 2
   for (; i < p.nvec; i += stride) {
     float v[V];
-    Vec16<T>::load(x + i * V, v);
+    Vec16<T>::load_nt(x + i * V, v);  // y is not read again before backward
 #pragma unroll
     for (int e = 0; e < V; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
     if constexpr (RES) {
@@ -357,8 +357,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p)
 #pragma unroll 2
   for (; i < p.nvec; i += stride) {
     float gv[V], xv[V];
-    Vec16<T>::load(g + i * V, gv);
-    Vec16<T>::load(x + i * V, xv);
+    Vec16<T>::load_nt(g + i * V, gv);  // last use of g and of y
+    Vec16<T>::load_nt(x + i * V, xv);
     if constexpr (MASK == 2) {
       const unsigned b = p.bits[i];
 #pragma unroll

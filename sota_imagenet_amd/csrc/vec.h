@@ -14,6 +14,11 @@ struct Vec16<float> {
     const f32x4 t = *reinterpret_cast<const f32x4*>(p);
     v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
   }
+  // last use of the data: do not keep the lines in L2 / Infinity Cache
+  static __device__ __forceinline__ void load_nt(const float* p, float (&v)[4]) {
+    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
   static __device__ __forceinline__ void unpack(const uint4& t, float (&v)[4]) {
     v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
   }
@@ -28,6 +33,12 @@ struct Vec16<bf16_t> {
   static constexpr int N = 8;
   static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
     unpack(*reinterpret_cast<const uint4*>(p), v);
+  }
+  static __device__ __forceinline__ void load_nt(const bf16_t* p, float (&v)[8]) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    const uint4 u = {t[0], t[1], t[2], t[3]};
+    unpack(u, v);
   }
   static __device__ __forceinline__ void unpack(const uint4& t, float (&v)[8]) {
     const uint32_t w[4] = {t.x, t.y, t.z, t.w};
