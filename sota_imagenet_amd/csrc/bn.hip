@@ -301,13 +301,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
     for (int e = 0; e < V; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
     if constexpr (RES) {
       float rv[V];
-      Vec16<T>::load(res + i * V, rv);
+      Vec16<T>::load_nt(res + i * V, rv);  // the block input: next read in backward
 #pragma unroll
       for (int e = 0; e < V; ++e) v[e] += rv[e];
     }
     if constexpr (X2) {
       float rv[V];
-      Vec16<T>::load(x2 + i * V, rv);
+      Vec16<T>::load_nt(x2 + i * V, rv);
 #pragma unroll
       for (int e = 0; e < V; ++e) v[e] += fmaf(rv[e], sc2[e], sh2[e]);
     }
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
         unsigned b = 0;
 #pragma unroll
         for (int e = 0; e < V; ++e) b |= (v[e] > 0.f ? 1u : 0u) << e;
-        p.bits[i] = (uint8_t)b;
+        __builtin_nontemporal_store((uint8_t)b, p.bits + i);  // read in backward only
       }
 #pragma unroll
       for (int e = 0; e < V; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
