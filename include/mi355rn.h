@@ -204,6 +204,7 @@ int mi355_resnet50_debug_tensor(const mi355_ctx* ctx, const char* name, void** p
  *   0 igemm_kernel<T,128|256,128|256,*> (conv fwd + dgrad, >=128 output channels)   1 igemm_kernel<T,128,64,*> (incl. stem)
  *   2 wgrad_kernel<T,128,*>   3 wgrad_kernel<T,64,*> (incl. stem)   4 bn_reduce_kernel (stats + bwd sums)
  *   5 bn_apply_kernel   6 other (ingest, pools, FC, weight prep)   7 bn_bwd_apply_kernel
+ *   profile_read kind 8: the 3x3 convolutions (fwd + dgrad) among the recorded launches of classes 0 and 1
  * (one class = one kernel symbol, so the averages can be checked against rocprofv3 --kernel-trace --stats)
  * mi355_resnet50_profile_read(ctx, k, ...) waits for the recorded events of class k and returns their
  * summed duration (ms), launch count and the algorithmic FLOPs / bytes those launches represent.    */

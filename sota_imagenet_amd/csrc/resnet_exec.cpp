@@ -125,6 +125,7 @@ struct mi355_ctx {
   std::vector<hipEvent_t> ev;
   struct Rec {
     int cls;
+    int tag;  // 1: a 3x3 convolution (profile_read kind 8 = the 3x3 launches of classes 0 and 1)
     double flops, bytes;
   };
   std::vector<Rec> recs;
@@ -172,11 +173,11 @@ struct Prof {
   mi355_ctx* c;
   hipStream_t stream;
   int idx = -1;
-  Prof(mi355_ctx* ctx, int cls, double flops, double bytes, hipStream_t s) : c(ctx), stream(s) {
+  Prof(mi355_ctx* ctx, int cls, double flops, double bytes, hipStream_t s, int tag = 0) : c(ctx), stream(s) {
     if (!(c->prof_mask & (1u << cls))) return;
     if ((c->recs.size() + 1) * 2 > c->ev.size()) return;
     idx = (int)c->recs.size();
-    c->recs.push_back({cls, flops, bytes});
+    c->recs.push_back({cls, tag, flops, bytes});
     (void)hipEventRecord(c->ev[2 * idx], stream);
   }
   ~Prof() {
@@ -210,7 +211,7 @@ int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, hipStrea
   a.out = l.y;
   const double fl = conv_flops(c, l);
   const double by = ((double)c->N * l.Hin * l.Win * l.Cin + (double)c->N * l.Hout * l.Wout * l.Cout) * c->es;
-  Prof p(c, igemm_class(l.Cout), fl, by, s);
+  Prof p(c, igemm_class(l.Cout), fl, by, s, l.K == 3 ? 1 : 0);
   return launch_igemm(c->dtype, a, 1, s, &l.stat_rows);
 }
 
@@ -298,7 +299,7 @@ int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* ad
   // dy read, dx written, + the addend and (fused BN-backward sums) that layer's y read in the epilogue, masks at 1/16
   const double by = (dx_elems * (1 + (addend ? 1 : 0) + (a.bn_y ? 1 : 0)) + (double)c->N * l.Hout * l.Wout * l.Cout) * c->es +
                     dx_elems * c->es / 16 * ((addend_bits ? 1 : 0) + (a.bn_y ? 1 : 0));
-  Prof p(c, igemm_class(l.Cin), conv_flops(c, l), by, s);
+  Prof p(c, igemm_class(l.Cin), conv_flops(c, l), by, s, l.K == 3 ? 1 : 0);
   return launch_igemm(c->dtype, a, nclass, s, bn && c->fuse_bn_bwd ? &bn->bwd_rows : nullptr);
 }
 
@@ -893,7 +894,8 @@ int mi355_resnet50_profile_read(mi355_ctx* c, int kind, double* total_ms, int* l
   double ms = 0, fl = 0, by = 0;
   int n = 0;
   for (size_t i = 0; i < c->recs.size(); ++i) {
-    if (c->recs[i].cls != kind) continue;
+    const bool match = kind == 8 ? (c->recs[i].tag == 1 && c->recs[i].cls <= 1) : c->recs[i].cls == kind;
+    if (!match) continue;
     float t = 0;
     MI355_HIP(hipEventSynchronize(c->ev[2 * i + 1]));
     MI355_HIP(hipEventElapsedTime(&t, c->ev[2 * i], c->ev[2 * i + 1]));
