@@ -513,7 +513,10 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
   MI355_ARG(nclass >= 1 && nclass <= 4, "igemm: nclass=%d", nclass);
   MI355_ARG(((size_t)a.pix_stride * dtype_size(dtype)) % 8 == 0, "igemm: pixel stride not 8-byte aligned");
   MI355_ARG(a.N > 0 && a.Hsub > 0 && a.Wsub > 0, "igemm: empty problem");
-  const bool wide = (a.Ncols % 128 == 0);
+  // BN = 128 unless that leaves most of the 256 CUs without a tile (the FC layer: 256 rows): then 64-wide tiles double
+  // the workgroups
+  const long tiles128 = (long)cdiv(a.N * a.Hsub * a.Wsub, 128) * nclass * (a.Ncols / 128);
+  const bool wide = (a.Ncols % 128 == 0) && tiles128 >= 128;
   if (dtype == MI355_F32)
     return wide ? launch_t<float, 128, 128>(a, nclass, stream, stat_rows) : launch_t<float, 128, 64>(a, nclass, stream, stat_rows);
   if (dtype == MI355_BF16) {
