@@ -51,7 +51,7 @@ struct IgemmKArgs {
 // halves the LDS bytes moved per MFMA — the LDS port, DMA writes + fragment reads, is what bounds the smaller tiles)
 // STATS: 0 none, 1 forward BN statistics, 2 BN-backward sums (see common.h)
 template <typename T, int BM, int BN, int STATS>
-__global__ __launch_bounds__(256, (BM == 256 ? 1 : 2)) void igemm_kernel(const IgemmKArgs kp) {
+__global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void igemm_kernel(const IgemmKArgs kp) {
   const IgemmArgs& p = kp.a;
   constexpr int ES = (int)sizeof(T);
   constexpr int BK = BKB / ES;
@@ -458,7 +458,7 @@ void lds_opt_in(const void* fn, size_t lds) {
 
 template <typename T, int BM, int BN>
 int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
-  constexpr int MAX_WG = BM == 256 ? 256 : 512;  // persistent workgroups: 1 or 2 per CU
+  constexpr int MAX_WG = BM == 256 ? 256 : (BN == 64 ? 768 : 512);  // persistent workgroups: 1, 3 or 2 per CU
   IgemmKArgs k;
   k.a = a;
   const int Msub = a.N * a.Hsub * a.Wsub;
