@@ -78,6 +78,8 @@ struct IgemmArgs {
   float* stat_partial; // optional [stat_rows][2][Ncols]: per-workgroup-row sums of out and out^2 (BN statistics), or,
                        // when bn_y is set, of dz and dz*xhat (BN backward of the layer whose activation gradient `out`
                        // is): dz = out under the ReLU mask bn_bits, xhat = (bn_y - bn_mean) * bn_invstd
+  void* sk_ws = nullptr;               // optional igemm_sk_ws_bytes() of zero-initialised scratch, owned by ONE stream:
+                                       // lets the kernel cut the tiles of a partial last round along K (stream-K)
   const void* bn_y = nullptr;          // [N][Hout][Wout][Ncols], laid out like out
   const uint8_t* bn_bits = nullptr;    // 1 byte per 16-byte vector of out
   const float* bn_mean = nullptr;      // [Ncols]
@@ -107,6 +109,8 @@ struct WgradArgs {
 // ---- kernel launchers (all enqueue on `stream`, return mi355_status) -------------------------------
 // stat_rows (optional): number of partial rows written to a.stat_partial, 0 if the statistics were not produced
 int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows = nullptr);
+static constexpr size_t IGEMM_SK_FLAG_BYTES = 4096;  // 512 flags + an error word, padded
+size_t igemm_sk_ws_bytes();
 // splits chosen by plan_wgrad_splits(); partial must hold splits*Cout*wtaps*Ck floats
 int plan_wgrad_splits(int dtype, int M, int Cout, int ntaps, int Ck);
 int launch_wgrad(int dtype, const WgradArgs& a, int splits, hipStream_t stream);

@@ -23,6 +23,7 @@
 //               (never __syncthreads, whose fence would drain the LDS-DMA queue).  2 workgroups per CU (64.5 KiB each).
 //   epilogue    each wave stages its 32 x BN/2 fp32 sub-tile through (XOR-swizzled) LDS and writes 16 bytes per lane,
 //               64..256 contiguous bytes per pixel; the optional addend (residual gradient) is read the same way.
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <set>
@@ -45,6 +46,17 @@ struct IgemmKArgs {
   IgemmArgs a;
   int mtiles, ny, nclass, ngroups, ntpg, items;
   unsigned bytes_in, bytes_wt;
+  // stream-K over the last, partial round (sk_tail > 0; needs nclass == 1 and ntpg == 1): per n-tile group the row tiles
+  // [sk_rf * Gg, sk_rf * Gg + sk_tail) are not handed out whole — their sk_tail * nk k-steps are cut into Gg = G/ngroups
+  // equal ranges, one per workgroup of the group.  The workgroup that starts a tile (k = 0) owns it: it adds the fp32
+  // partial tiles the following workgroups leave in sk_partial (one 16-byte-per-lane slot per workgroup, published
+  // through sk_flags with the launch's epoch) in workgroup order, then runs the normal epilogue.
+  int sk_rf, sk_tail, sk_nk, sk_gshift;  // sk_gshift = log2(G / ngroups)
+  int sk_tshift;                         // log2 of the workgroups per group that share the tail (<= G / ngroups: a tile
+                                         // is cut into at most ~4 parts, each hand-off costs its owner ~10 us)
+  unsigned sk_epoch;
+  float* sk_partial;
+  unsigned* sk_flags;
 };
 
 // BM x BN: 128 x 64 | 128 x 128 (2 workgroups per CU) | 256 x 256 (1 per CU; a wave then owns 128 x 128 outputs, which
@@ -84,7 +96,56 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
   // ---- loader cursor: runs one slab ahead of the MFMAs ------------------------------------------------------------
   const int prow = lane >> 3;  // row within a 1 KiB piece
   const int pch = lane & 7;    // physical 16-byte chunk
-  int L_item = blockIdx.x, L_nt = 0, L_kt = 0, L_nk = 0, L_cls = 0, L_grp = 0;
+  int L_seq = 0, L_item = 0, L_nt = 0, L_kt = 0, L_kend = 0, L_cls = 0, L_grp = 0;
+  bool L_valid = true;
+  // the seq-th unit of work of this workgroup: item (row tile x n-tile group) and k-step range [k0, k1) (k1 < 0: all).
+  // With stream-K the (at most two) tail units of the workgroup are worked out once, in 32-bit scalar arithmetic
+  // (sk_tail * sk_nk * G < 2^31; G / ngroups is a power of two).
+  constexpr bool SKC = BM == 128 && BN == 128 && ES == 4;  // stream-K is compiled into the fp32 128 x 128 kernel only
+  int sk_bg = 0, sk_n = 0, sk_item0 = 0, sk_k00 = 0, sk_k10 = 0, sk_k11 = 0;
+  if constexpr (SKC) {
+    if (kp.sk_tail != 0) {
+      sk_bg = (int)blockIdx.x / kp.ngroups;
+      const int g = (int)blockIdx.x - sk_bg * kp.ngroups;
+      const unsigned TK = (unsigned)(kp.sk_tail * kp.sk_nk);
+      const unsigned lo = ((unsigned)sk_bg * TK) >> kp.sk_tshift, hi = ((unsigned)(sk_bg + 1) * TK) >> kp.sk_tshift;
+      if (lo < hi && sk_bg < (1 << kp.sk_tshift)) {
+        const int t0 = (int)(lo / (unsigned)kp.sk_nk);
+        sk_item0 = ((kp.sk_rf << kp.sk_gshift) + t0) * kp.ngroups + g;
+        sk_k00 = (int)lo - t0 * kp.sk_nk;
+        const int e = sk_k00 + (int)(hi - lo);
+        sk_k10 = e < kp.sk_nk ? e : kp.sk_nk;
+        sk_k11 = (int)hi - (t0 + 1) * kp.sk_nk;  // > 0: the range runs into the next tile, which this workgroup owns
+        sk_n = sk_k11 > 0 ? 2 : 1;
+      }
+      sk_bg = __builtin_amdgcn_readfirstlane(sk_bg);
+      sk_n = __builtin_amdgcn_readfirstlane(sk_n);
+      sk_item0 = __builtin_amdgcn_readfirstlane(sk_item0);
+      sk_k00 = __builtin_amdgcn_readfirstlane(sk_k00);
+      sk_k10 = __builtin_amdgcn_readfirstlane(sk_k10);
+      sk_k11 = __builtin_amdgcn_readfirstlane(sk_k11);
+    }
+  }
+  auto unit_at = [&](int seq, int& item, int& k0, int& k1) -> bool {
+    if (!SKC || kp.sk_tail == 0) {
+      item = (int)blockIdx.x + seq * G;
+      k0 = 0;
+      k1 = -1;
+      return item < kp.items;
+    }
+    const int u = seq - kp.sk_rf;
+    if (u < 0) {
+      item = (int)blockIdx.x + seq * G;
+      k0 = 0;
+      k1 = -1;
+      return true;
+    }
+    if (u >= sk_n) return false;
+    item = sk_item0 + u * kp.ngroups;
+    k0 = u == 0 ? sk_k00 : 0;
+    k1 = u == 0 ? sk_k10 : sk_k11;
+    return true;
+  };
   const i32x4 srdA = make_srd(p.in, kp.bytes_in);
   const i32x4 srdB = make_srd(p.wt, kp.bytes_wt);
   unsigned a_off[PA];    // byte offset of (row's pixel at tap offset (0,0)) + this lane's swizzled 16-byte chunk
@@ -95,15 +156,16 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
     const int r = PB * 8 * wave + 8 * i + prow;
     b_off[i] = (unsigned)r * p.wtaps * p.Ck * ES + (unsigned)((pch ^ ((r >> 1) & 7)) * 16);
   }
-  auto L_setup = [&]() {  // decode the rows this lane stages for item L_item; skips items without taps
-    while (L_item < kp.items) {
+  auto L_setup = [&]() {  // decode the rows this lane stages for unit L_seq; skips items without taps
+    int uk0, uk1;
+    while ((L_valid = unit_at(L_seq, L_item, uk0, uk1))) {
       const int rowtile = L_item / kp.ngroups;
       L_grp = L_item - rowtile * kp.ngroups;
       L_cls = rowtile / kp.mtiles;
       const int mt = rowtile - L_cls * kp.mtiles;
-      L_nk = p.cls[L_cls].ntaps * kc_per_tap;
-      if (L_nk == 0) {
-        L_item += G;
+      const int nk_all = p.cls[L_cls].ntaps * kc_per_tap;
+      if (nk_all == 0) {
+        ++L_seq;
         continue;
       }
 #pragma unroll
@@ -130,7 +192,8 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
         }
       }
       L_nt = 0;
-      L_kt = 0;
+      L_kt = uk0;
+      L_kend = uk1 < 0 ? nk_all : uk1;
       return;
     }
   };
@@ -164,10 +227,12 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
     }
   };
   auto L_advance = [&]() {
-    if (++L_kt < L_nk) return;
-    L_kt = 0;
-    if (++L_nt < kp.ntpg) return;
-    L_item += G;
+    if (++L_kt < L_kend) return;
+    if (++L_nt < kp.ntpg) {  // (never with stream-K units: ntpg == 1 there)
+      L_kt = 0;
+      return;
+    }
+    ++L_seq;
     L_setup();
   };
 
@@ -193,7 +258,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
   }
   L_setup();
   int stage = 0;
-  if (L_item < kp.items) {
+  if (L_valid) {
     L_begin(0);
 #pragma unroll
     for (int j = 0; j < NPC; ++j) L_piece(j);
@@ -204,7 +269,8 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
   T* out = reinterpret_cast<T*>(p.out);
   const T* addend = reinterpret_cast<const T*>(p.addend);
 
-  for (int item = blockIdx.x; item < kp.items; item += G) {
+  int item, uk0, uk1;
+  for (int seq = 0; unit_at(seq, item, uk0, uk1); ++seq) {
     const int rowtile = item / kp.ngroups;
     const int grp = item - rowtile * kp.ngroups;
     const int ci = rowtile / kp.mtiles;
@@ -222,7 +288,8 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-      for (int kt = 0; kt < nk; ++kt) {
+      const int kbeg = uk0, kend = uk1 < 0 ? nk : uk1;
+      for (int kt = kbeg; kt < kend; ++kt) {
         // the slab for this step was issued one step ago; epilogue stores issued since then may stay in flight
         if (pending_st == NST) {
           if constexpr (NST == 32) MI355_WAIT_VM(32);
@@ -234,7 +301,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
         }
         pending_st = 0;
         MI355_LDS_BARRIER();  // slab landed for every wave; everyone is done reading the other stage
-        const bool lv = L_item < kp.items;
+        const bool lv = L_valid;
         if (lv) L_begin(stage ^ 1);
         const char* base = smem + stage * STAGE;
         // Four 32-byte k groups per slab; lane half hh takes one 16-byte chunk of each.  The fragments of group g+1 are
@@ -276,6 +343,72 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
         }
         if (lv) L_advance();
         stage ^= 1;
+      }
+
+      // ---- stream-K: a partial tile is either handed to its owner or completed with the others' partials ----------
+      if (SKC && kp.sk_tail != 0 && (kbeg > 0 || kend < nk)) {
+        constexpr int SLOT = BM * BN;  // floats per workgroup slot, [MI*NI*4 register groups][256 threads][4]
+        if (kbeg > 0) {
+          // not the owner: write-through (sc1) stores, every wave drains them, one lane publishes the epoch
+          const i32x4 srdP = make_srd(kp.sk_partial, (unsigned)((size_t)G * SLOT * 4));
+          const unsigned base = ((unsigned)blockIdx.x * SLOT + tid * 4) * 4u;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+                const unsigned off = base + (unsigned)(((mi * NI + ni) * 4 + g) * 256 * 16);
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1" ::"v"(v), "v"(off), "s"(srdP) : "memory");
+              }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (tid == 0)
+            __hip_atomic_store(kp.sk_flags + blockIdx.x, kp.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pending_st = 0;
+          continue;  // no epilogue for this unit
+        }
+        // owner: the rest of the tile's k range was cut into the ranges of the following workgroups of this group
+        const unsigned TK = (unsigned)(kp.sk_tail * kp.sk_nk);
+        const int tt = rowtile - (kp.sk_rf << kp.sk_gshift);   // tail tile index
+        const unsigned tile_end = (unsigned)((tt + 1) * kp.sk_nk);
+        int bgj = sk_bg + 1;
+        int covered = kend;
+        while (covered < nk && bgj < (1 << kp.sk_tshift)) {
+          const unsigned lo_j = ((unsigned)bgj * TK) >> kp.sk_tshift, hi_j = ((unsigned)(bgj + 1) * TK) >> kp.sk_tshift;
+          const int cnt = (int)((hi_j < tile_end ? hi_j : tile_end) - lo_j);
+          if (cnt > 0) {
+            const int j = bgj * kp.ngroups + grp;
+            if (tid == 0) {
+              unsigned spins = 0;
+              while (__hip_atomic_load(kp.sk_flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kp.sk_epoch) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 24)) {  // never on a healthy run; do not hang the device
+                  __hip_atomic_store(kp.sk_flags + G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  break;
+                }
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const float* slot = kp.sk_partial + (size_t)j * SLOT + tid * 4;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                  const f32x4 v = *reinterpret_cast<const f32x4*>(slot + ((mi * NI + ni) * 4 + g) * 256 * 4);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) acc[mi][ni][4 * g + e] += v[e];
+                }
+            covered += cnt;
+            pending_st = 0;  // the wait above drained every store
+          }
+          ++bgj;
+        }
       }
 
       // ---- epilogue: stage^1 (the slab buffer just consumed) is free once every wave has passed the barrier -------
@@ -488,6 +621,36 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
         break;
       }
   }
+  // stream-K over the partial last round: one n-tile per item (ng = ny), and only where it pays — a tail that leaves
+  // >= 15 % of the slots idle and a reduction long enough to cut (see IgemmKArgs)
+  k.sk_rf = k.sk_tail = k.sk_nk = k.sk_gshift = k.sk_tshift = 0;
+  k.sk_epoch = 0;
+  k.sk_partial = nullptr;
+  k.sk_flags = nullptr;
+  bool sk = false;
+  // (fp32 only: a hand-off costs the owner ~10 us, nothing beside a 150-300 us fp32 tile, but most of what the cut
+  // saves on a 30-60 us bf16 tile — measured)
+  if (BM == 128 && BN == 128 && sizeof(T) == 4 && a.sk_ws && nclass == 1 && MAX_WG % k.ny == 0) {
+    const int Gg = MAX_WG / k.ny;
+    const int rf = R / Gg, rt = R - rf * Gg;
+    const int nk = a.cls[0].ntaps * (a.Ck / (BKB / (int)sizeof(T)));
+    if (rt > 0 && rt * 100 <= Gg * 85 && nk >= 8 && (Gg & (Gg - 1)) == 0 && (long)rt * nk * MAX_WG < (1l << 31)) {
+      sk = true;
+      ng = k.ny;
+      k.sk_rf = rf;
+      k.sk_tail = rt;
+      k.sk_nk = nk;
+      k.sk_gshift = 0;
+      while ((1 << k.sk_gshift) < Gg) ++k.sk_gshift;
+      k.sk_tshift = 0;  // largest power of two <= min(Gg, 4 * rt)
+      while ((2 << k.sk_tshift) <= Gg && (2 << k.sk_tshift) <= 4 * rt) ++k.sk_tshift;
+      static std::atomic<unsigned> epoch{0};
+      k.sk_epoch = ++epoch;
+      if (k.sk_epoch == 0) k.sk_epoch = ++epoch;  // 0 is the initial state of the flags
+      k.sk_flags = reinterpret_cast<unsigned*>(a.sk_ws);
+      k.sk_partial = reinterpret_cast<float*>(reinterpret_cast<char*>(a.sk_ws) + IGEMM_SK_FLAG_BYTES);
+    }
+  }
   k.ngroups = ng;
   k.ntpg = k.ny / ng;
   k.items = R * ng;
@@ -496,7 +659,7 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
   MI355_ARG(bytes_in < 0x80000000ull && bytes_wt < 0x80000000ull, "igemm: tensor exceeds the 2 GiB buffer-offset range");
   k.bytes_in = (unsigned)bytes_in;
   k.bytes_wt = (unsigned)bytes_wt;
-  const int grid = k.items < MAX_WG ? k.items : MAX_WG;
+  const int grid = sk ? MAX_WG : (k.items < MAX_WG ? k.items : MAX_WG);
   size_t lds = (size_t)2 * (BM + BN) * BKB + BM * sizeof(int);
   // BN statistics in the epilogue need [2][channels per workgroup][2] floats of LDS; beyond 512 channels per workgroup
   // the kernel would drop to one workgroup per CU, so the caller falls back to the standalone statistics kernel
@@ -520,6 +683,8 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
 }
 
 }  // namespace
+
+size_t igemm_sk_ws_bytes() { return IGEMM_SK_FLAG_BYTES + (size_t)512 * 128 * 128 * sizeof(float); }
 
 int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
   const int bk = BKB / (int)dtype_size(dtype);

@@ -97,6 +97,8 @@ struct mi355_ctx {
   float *pooled = nullptr, *fc_tmp = nullptr, *dlogits_pad = nullptr, *dpooled = nullptr, *fc_wtr = nullptr;
   float *bn_partial = nullptr, *bn_coef = nullptr, *wg_partial = nullptr;
   float *bn_partial2 = nullptr, *bn_coef2 = nullptr;  // the same for BN work issued to the side stream
+  void* sk_ws[2] = {nullptr, nullptr};                // stream-K scratch of the conv kernel, main / side stream
+  bool stream_k = true;
   PrepDesc* prep_table[2] = {nullptr, nullptr};  // [0]: cast only (inference), [1]: cast + transposed (training)
   int prep_layers = 0, prep_tiles = 0;
   // backward gradients: gG[2] carry the gradient wrt a block output down the network; gset[p] holds the per-layer
@@ -194,6 +196,9 @@ inline int wgrad_class(int cout) { return cout % 128 == 0 ? PC_WGRAD128 : PC_WGR
 
 // BN scratch of the stream the work is issued to (the side stream has its own, the two run concurrently)
 inline float* bn_partial_of(mi355_ctx* c, hipStream_t s) { return (c->wstream && s == c->wstream) ? c->bn_partial2 : c->bn_partial; }
+inline void* sk_ws_of(mi355_ctx* c, hipStream_t s) {
+  return c->stream_k ? c->sk_ws[(c->wstream && s == c->wstream) ? 1 : 0] : nullptr;
+}
 inline float* bn_coef_of(mi355_ctx* c, hipStream_t s) { return (c->wstream && s == c->wstream) ? c->bn_coef2 : c->bn_coef; }
 
 double conv_flops(const mi355_ctx* c, const ConvBN& l) {
@@ -207,6 +212,7 @@ int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, hipStrea
   build_fwd_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
   a.in = in;
   a.stat_partial = training ? bn_partial_of(c, s) : nullptr;
+  a.sk_ws = sk_ws_of(c, s);
   a.wt = c->dtype == MI355_F32 ? (const void*)(c->params + l.w_off) : (const void*)l.w_cast;
   a.out = l.y;
   const double fl = conv_flops(c, l);
@@ -291,6 +297,7 @@ int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* ad
   const int nclass = build_dgrad_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
   if (nclass < 0) return nclass;
   a.in = dy; a.wt = l.w_tr; a.out = dx; a.addend = addend; a.addend_bits = addend_bits;
+  a.sk_ws = sk_ws_of(c, s);
   if (bn && c->fuse_bn_bwd) {
     a.stat_partial = bn_partial_of(c, s);
     a.bn_y = bn->y; a.bn_bits = bn_bits; a.bn_mean = bn->stat; a.bn_invstd = bn->stat + bn->Cout;
@@ -354,6 +361,7 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
   for (int i = 0; i < 2; ++i) ar.add((void**)&c->prep_table[i], (size_t)64 * sizeof(PrepDesc));
   ar.add((void**)&c->bn_partial, (size_t)bn_max_blocks() * 2 * max_c * 4);
   ar.add((void**)&c->bn_coef, (size_t)3 * max_c * 4);
+  for (int i = 0; i < 2; ++i) ar.add(&c->sk_ws[i], igemm_sk_ws_bytes());
   ar.add((void**)&c->bn_partial2, (size_t)bn_max_blocks() * 2 * max_c * 4);
   ar.add((void**)&c->bn_coef2, (size_t)3 * max_c * 4);
   ar.add((void**)&c->wg_partial, max_wg);
@@ -628,6 +636,8 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
     }
   }
   // weight-gradient side stream (MI355_WGRAD_STREAM=0 keeps everything on the caller's stream)
+  const char* skv = getenv("MI355_STREAM_K");
+  c->stream_k = !(skv && skv[0] == '0');
   const char* fb = getenv("MI355_FUSE_BN_BWD");
   // measured same-box: -0.6 ms/step in bf16, +0.9 ms in fp32 (the fp32 epilogue is already register-heavy)
   c->fuse_bn_bwd = fb ? fb[0] != '0' : dtype == MI355_BF16;
