@@ -79,6 +79,15 @@ int build_dgrad_args(IgemmArgs& a, int N, int H, int W, int Cin, int Cout, int K
         }
       }
     }
+  // longest classes first: the persistent workgroups take items in class order, so the last (partial) round is then
+  // made of the short items (3x3: 4, 2, 2, 1 taps) instead of the long ones
+  for (int i = 0; i < 4; ++i)
+    for (int j = i + 1; j < 4; ++j)
+      if (a.cls[j].ntaps > a.cls[i].ntaps) {
+        const TapClass t = a.cls[i];
+        a.cls[i] = a.cls[j];
+        a.cls[j] = t;
+      }
   return 4;
 }
 
