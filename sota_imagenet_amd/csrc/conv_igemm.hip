@@ -40,6 +40,16 @@ namespace {
 constexpr int BKB = 128;  // bytes of K per slab (= one LDS row)
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+// -DMI355_STAMP: cycle stamps of workgroup 0 inside the main loop, read back by tools/stamp_conv.py (profiling builds only)
+#ifdef MI355_STAMP
+__device__ unsigned long long g_stamps[8 * 4096];  // [wave 0..3 of workgroup 0][k-step][8 stamps]
+#define STAMP(slot)                                                                                   \
+  do {                                                                                                \
+    if (blockIdx.x == 0 && lane == 0 && stamp_k < 1024) g_stamps[(wave * 1024 + stamp_k) * 8 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define STAMP(slot)
+#endif
 __device__ __attribute__((aligned(256))) unsigned char g_trash[256 * 16];
 
 struct IgemmKArgs {
@@ -265,6 +275,9 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
     L_advance();
   }
   int pending_st = 0;
+#ifdef MI355_STAMP
+  int stamp_k = 0;
+#endif
 
   T* out = reinterpret_cast<T*>(p.out);
   const T* addend = reinterpret_cast<const T*>(p.addend);
@@ -291,6 +304,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
       const int kbeg = uk0, kend = uk1 < 0 ? nk : uk1;
       for (int kt = kbeg; kt < kend; ++kt) {
         // the slab for this step was issued one step ago; epilogue stores issued since then may stay in flight
+        STAMP(0);
         if (pending_st == NST) {
           if constexpr (NST == 32) MI355_WAIT_VM(32);
           else if constexpr (NST == 16) MI355_WAIT_VM(16);
@@ -300,7 +314,9 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
           MI355_WAIT_VM(0);
         }
         pending_st = 0;
+        STAMP(1);
         MI355_LDS_BARRIER();  // slab landed for every wave; everyone is done reading the other stage
+        STAMP(2);
         const bool lv = L_valid;
         if (lv) L_begin(stage ^ 1);
         const char* base = smem + stage * STAGE;
@@ -341,7 +357,12 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[g & 1][ni], av[g & 1][mi], acc[mi][ni], 0, 0, 0);
           }
         }
+        STAMP(3);
         if (lv) L_advance();
+        STAMP(4);
+#ifdef MI355_STAMP
+        ++stamp_k;
+#endif
         stage ^= 1;
       }
 
@@ -720,3 +741,14 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
 }
 
 }  // namespace mi355
+
+#ifdef MI355_STAMP
+extern "C" int mi355_debug_stamps(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mi355::g_stamps), (size_t)n * sizeof(unsigned long long), 0,
+                                  hipMemcpyDeviceToHost);
+}
+extern "C" int mi355_debug_stamps_clear(void) {
+  static unsigned long long z[8 * 4096];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(mi355::g_stamps), z, sizeof(z), 0, hipMemcpyHostToDevice);
+}
+#endif
