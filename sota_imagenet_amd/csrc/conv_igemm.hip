@@ -45,12 +45,12 @@ __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 __device__ unsigned long long g_stamps[8 * 4096];  // [wave 0..3 of workgroup 0][k-step][8 stamps]
 #define STAMP(slot)                                                                                   \
   do {                                                                                                \
-    if (blockIdx.x == 0 && lane == 0 && stamp_k < 1024) g_stamps[(wave * 1024 + stamp_k) * 8 + (slot)] = __builtin_readcyclecounter(); \
+    if (blockIdx.x == 0 && lane == 0 && wave < 4 && stamp_k < 1024) g_stamps[(wave * 1024 + stamp_k) * 8 + (slot)] = __builtin_readcyclecounter(); \
   } while (0)
 #else
 #define STAMP(slot)
 #endif
-__device__ __attribute__((aligned(256))) unsigned char g_trash[256 * 16];
+__device__ __attribute__((aligned(256))) unsigned char g_trash[512 * 16];
 
 struct IgemmKArgs {
   IgemmArgs a;
@@ -69,18 +69,29 @@ struct IgemmKArgs {
   unsigned* sk_flags;
 };
 
-// BM x BN: 128 x 64 | 128 x 128 (2 workgroups per CU) | 256 x 256 (1 per CU; a wave then owns 128 x 128 outputs, which
-// halves the LDS bytes moved per MFMA — the LDS port, DMA writes + fragment reads, is what bounds the smaller tiles)
+// BM x BN tile, WMW x 2 waves (a wave owns BM/WMW x BN/2 outputs), NSTG-stage LDS ring:
+//   128 x 64 (3 workgroups per CU), 128 x 128 (2 per CU): 2 x 2 waves, 2 stages
+//   256 x 256: 2 x 2 waves, 2 stages, 1 per CU; a wave owns 128 x 128 outputs, which halves the LDS bytes moved per MFMA
+//   256 x 128: 4 x 2 waves, 3 stages, 1 per CU: the same per-wave work as the 128 x 128 tile, one weight slab feeds 256
+//              rows (6 instead of 8 LDS-DMA pieces per wave and k-step) and the loader runs TWO slabs ahead, which is what
+//              the ~700 cycles a 128 x 128 workgroup waits for its slab every k-step ask for (stamps)
 // STATS: 0 none, 1 forward BN statistics, 2 BN-backward sums (see common.h)
-template <typename T, int BM, int BN, int STATS>
-__global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void igemm_kernel(const IgemmKArgs kp) {
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int WMW, int NSTG, int STATS>
+__global__ __launch_bounds__(128 * WMW, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void igemm_kernel(const IgemmKArgs kp) {
   const IgemmArgs& p = kp.a;
   constexpr int ES = (int)sizeof(T);
   constexpr int BK = BKB / ES;
-  constexpr int MI = BM / 64;              // 32-pixel MFMA tiles per wave
+  constexpr int NW = 2 * WMW;              // waves
+  constexpr int NT = 64 * NW;              // threads
+  constexpr int MI = BM / (32 * WMW);      // 32-pixel MFMA tiles per wave
   constexpr int NI = BN / 64;              // 32-channel MFMA tiles per wave
-  constexpr int PA = BM / 32;              // A pieces (1 KiB wave-instructions) per wave per slab
-  constexpr int PB = BN / 32;              // B pieces per wave per slab
+  constexpr int PA = BM / NW / 8;          // A pieces (1 KiB wave-instructions) per wave per slab
+  constexpr int PB = BN / NW / 8;          // B pieces per wave per slab
   constexpr int NPC = PA + PB;
   constexpr int A_BYTES = BM * BKB;
   constexpr int STAGE = (BM + BN) * BKB;   // one ring stage
@@ -91,9 +102,16 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
   constexpr int NST = MI * (32 / RPI);     // global stores per thread per tile
   constexpr int SCH = WN / 4;              // 16-byte fp32 chunks per staged row
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* row_pix = reinterpret_cast<int*>(smem + 2 * STAGE);
+  // epilogue staging: 32 x WN fp32 per wave inside the stage consumed last; when the waves do not all fit there (8 waves
+  // on the 256 x 128 tile) they take turns, EPI_TURNS groups of EPI_WAVES waves
+  constexpr int STG_WAVE = 32 * (BN / 2) * 4;
+  constexpr int EPI_FIT = STAGE / STG_WAVE;  // staging blocks that fit into one stage
+  constexpr int EPI_WAVES = NW <= EPI_FIT ? NW : (EPI_FIT >= 4 ? 4 : (EPI_FIT >= 2 ? 2 : 1));
+  constexpr int EPI_TURNS = NW / EPI_WAVES;
+  static_assert(NW % EPI_WAVES == 0, "epilogue turns");
+  int* row_pix = reinterpret_cast<int*>(smem + NSTG * STAGE);
   // STATS: per-workgroup BN statistics of the outputs, [wave-row wm][channel of this workgroup's n-tiles][sum, sum^2]
-  float* stat_acc = reinterpret_cast<float*>(smem + 2 * STAGE + BM * sizeof(int));
+  float* stat_acc = reinterpret_cast<float*>(smem + NSTG * STAGE + BM * sizeof(int));
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -180,7 +198,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
       }
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
-        const int r = (BM / 4) * wave + 8 * i + prow;
+        const int r = (BM / NW) * wave + 8 * i + prow;
         const int m = mt * BM + r;
         if (m < Msub) {
           const int j = m % p.Wsub;
@@ -230,7 +248,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
       const int ih = a_h[j] + S_dh;
       const int iw = a_w[j] + S_dw;
       const bool ok = ((unsigned)ih < (unsigned)p.Hin) && ((unsigned)iw < (unsigned)p.Win);
-      blds16(srdA, ok ? a_off[j] + (unsigned)S_dA : 0x80000000u, S_As + ((BM / 4) * wave + 8 * j) * BKB);
+      blds16(srdA, ok ? a_off[j] + (unsigned)S_dA : 0x80000000u, S_As + ((BM / NW) * wave + 8 * j) * BKB);
     } else {
       const int i = j - PA;
       blds16(srdB, b_off[i] + S_dB, S_As + A_BYTES + (PB * 8 * wave + 8 * i) * BKB);
@@ -251,7 +269,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
   int a_row[MI], a_sw[MI], b_row[NI], b_sw[NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    const int r = wm * (BM / 2) + mi * 32 + (lane & 31);
+    const int r = wm * (BM / WMW) + mi * 32 + (lane & 31);
     a_row[mi] = r * BKB;
     a_sw[mi] = (r >> 1) & 7;
   }
@@ -264,16 +282,22 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
 
   // ---- prologue ---------------------------------------------------------------------------------------------------
   if constexpr (STATS != 0) {  // zeroed before the first barrier; first touched after the first epilogue barrier
-    for (int i = tid; i < 2 * kp.ntpg * BN * 2; i += 256) stat_acc[i] = 0.f;
+    for (int i = tid; i < WMW * kp.ntpg * BN * 2; i += NT) stat_acc[i] = 0.f;
   }
   L_setup();
-  int stage = 0;
-  if (L_valid) {
-    L_begin(0);
+  int stage = 0;     // the ring stage the MFMAs read
+  int L_stage = 0;   // the ring stage the loader fills next (NSTG - 1 slabs ahead)
+  int inflight = 0;  // slabs issued and not yet consumed
 #pragma unroll
-    for (int j = 0; j < NPC; ++j) L_piece(j);
-    L_advance();
-  }
+  for (int pre = 0; pre < NSTG - 1; ++pre)
+    if (L_valid) {
+      L_begin(L_stage);
+#pragma unroll
+      for (int j = 0; j < NPC; ++j) L_piece(j);
+      L_advance();
+      L_stage = L_stage + 1 == NSTG ? 0 : L_stage + 1;
+      ++inflight;
+    }
   int pending_st = 0;
 #ifdef MI355_STAMP
   int stamp_k = 0;
@@ -305,20 +329,27 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
       for (int kt = kbeg; kt < kend; ++kt) {
         // the slab for this step was issued one step ago; epilogue stores issued since then may stay in flight
         STAMP(0);
-        if (pending_st == NST) {
-          if constexpr (NST == 32) MI355_WAIT_VM(32);
-          else if constexpr (NST == 16) MI355_WAIT_VM(16);
-          else if constexpr (NST == 8) MI355_WAIT_VM(8);
-          else MI355_WAIT_VM(4);
+        if constexpr (NSTG == 2) {
+          if (pending_st == NST) {
+            wait_vm<NST>();
+          } else {
+            wait_vm<0>();
+          }
         } else {
-          MI355_WAIT_VM(0);
+          // the slab needed now is the OLDEST in flight; one younger slab (NPC pieces of this wave) and the epilogue
+          // stores issued since may stay outstanding
+          const bool younger = inflight >= 2;
+          if (younger && pending_st == NST) wait_vm<NPC + NST>();
+          else if (younger) wait_vm<NPC>();
+          else if (pending_st == NST) wait_vm<NST>();
+          else wait_vm<0>();
         }
         pending_st = 0;
         STAMP(1);
         MI355_LDS_BARRIER();  // slab landed for every wave; everyone is done reading the other stage
         STAMP(2);
         const bool lv = L_valid;
-        if (lv) L_begin(stage ^ 1);
+        if (lv) L_begin(L_stage);
         const char* base = smem + stage * STAGE;
         // Four 32-byte k groups per slab; lane half hh takes one 16-byte chunk of each.  The fragments of group g+1 are
         // read from LDS BEFORE the MFMAs of group g are issued (two register sets, static indices), and two of the next
@@ -358,12 +389,17 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
           }
         }
         STAMP(3);
-        if (lv) L_advance();
+        if (lv) {
+          L_advance();
+          L_stage = L_stage + 1 == NSTG ? 0 : L_stage + 1;
+          ++inflight;
+        }
+        --inflight;
         STAMP(4);
 #ifdef MI355_STAMP
         ++stamp_k;
 #endif
-        stage ^= 1;
+        stage = stage + 1 == NSTG ? 0 : stage + 1;
       }
 
       // ---- stream-K: a partial tile is either handed to its owner or completed with the others' partials ----------
@@ -432,8 +468,9 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
         }
       }
 
-      // ---- epilogue: stage^1 (the slab buffer just consumed) is free once every wave has passed the barrier -------
-      char* stg = smem + (stage ^ 1) * STAGE + wave * (32 * WN * 4);
+      // ---- epilogue: the slab buffer just consumed is free once every wave has passed the barrier -------------------
+      const int done_stage = stage == 0 ? NSTG - 1 : stage - 1;
+      char* stg = smem + done_stage * STAGE + (wave % EPI_WAVES) * STG_WAVE;
       MI355_LDS_BARRIER();
       if (tid < BM) {
         const int m = m0 + tid;
@@ -447,139 +484,146 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
         }
         row_pix[tid] = pix;
       }
-      const int prw = lane & 31;
-      const int rr = lane / CPR, ch = lane % CPR;
-      // STATS 1: this lane's share of sum / sum of squares of the tile's outputs AS STORED
-      // STATS 2: of sum dz / sum dz*xhat, dz = stored output under the ReLU mask bn_bits, xhat from bn_y
-      float s1[VEC], s2[VEC];
-      float bmu[VEC], bis[VEC];
-      if constexpr (STATS == 2) {
-        const int c0 = n0 + wn * WN + ch * VEC;
+      if constexpr (EPI_TURNS > 1) MI355_LDS_BARRIER();  // row_pix visible (the turns below have no barrier inside)
 #pragma unroll
-        for (int q = 0; q < VEC / 4; ++q) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(p.bn_mean + c0 + 4 * q);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bn_invstd + c0 + 4 * q);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            bmu[4 * q + e] = a[e];
-            bis[4 * q + e] = b[e];
+      for (int turn = 0; turn < EPI_TURNS; ++turn) {
+        if (EPI_TURNS == 1 || wave / EPI_WAVES == turn) {
+        const int prw = lane & 31;
+        const int rr = lane / CPR, ch = lane % CPR;
+        // STATS 1: this lane's share of sum / sum of squares of the tile's outputs AS STORED
+        // STATS 2: of sum dz / sum dz*xhat, dz = stored output under the ReLU mask bn_bits, xhat from bn_y
+        float s1[VEC], s2[VEC];
+        float bmu[VEC], bis[VEC];
+        if constexpr (STATS == 2) {
+          const int c0 = n0 + wn * WN + ch * VEC;
+  #pragma unroll
+          for (int q = 0; q < VEC / 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.bn_mean + c0 + 4 * q);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.bn_invstd + c0 + 4 * q);
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              bmu[4 * q + e] = a[e];
+              bis[4 * q + e] = b[e];
+            }
           }
         }
-      }
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        s1[e] = 0.f;
-        s2[e] = 0.f;
-      }
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        // a lane holds pixel prw and, per register group g, channels ni*32 + 8g + 4hh + {0..3}
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-            const int sc = (ni * 8 + 2 * g + hh) ^ (prw & (SCH - 1));
-            *reinterpret_cast<f32x4*>(stg + prw * (WN * 4) + sc * 16) = v;
+  #pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          s1[e] = 0.f;
+          s2[e] = 0.f;
+        }
+  #pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          // a lane holds pixel prw and, per register group g, channels ni*32 + 8g + 4hh + {0..3}
+  #pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+  #pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+              const int sc = (ni * 8 + 2 * g + hh) ^ (prw & (SCH - 1));
+              *reinterpret_cast<f32x4*>(stg + prw * (WN * 4) + sc * 16) = v;
+            }
+          if (mi == 0 && EPI_TURNS == 1) {
+            MI355_LDS_BARRIER();  // row_pix visible to all waves (the staging region itself is wave-private)
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           }
-        if (mi == 0) {
-          MI355_LDS_BARRIER();  // row_pix visible to all waves (the staging region itself is wave-private)
-        } else {
+          constexpr int NP = 32 / RPI;
+          int pixs[NP];
+          uint4 araw[NP];
+          unsigned abits[NP];
+          uint4 yraw[NP];
+          unsigned ybits[NP];
+  #pragma unroll
+          for (int ps = 0; ps < NP; ++ps) {  // all addend loads of this pass first: one round trip, not NP
+            pixs[ps] = row_pix[wm * (BM / WMW) + mi * 32 + ps * RPI + rr];
+            if (addend) {
+              const size_t o = (size_t)(pixs[ps] < 0 ? 0 : pixs[ps]) * p.Ncols + n0 + wn * WN + ch * VEC;
+              araw[ps] = *reinterpret_cast<const uint4*>(pixs[ps] < 0 ? reinterpret_cast<const T*>(g_zero_page) : addend + o);
+              abits[ps] = p.addend_bits ? (unsigned)p.addend_bits[pixs[ps] < 0 ? 0 : o / VEC] : 0xffu;
+            }
+            if constexpr (STATS == 2) {
+              const size_t o = (size_t)(pixs[ps] < 0 ? 0 : pixs[ps]) * p.Ncols + n0 + wn * WN + ch * VEC;
+              yraw[ps] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.bn_y) + o);
+              ybits[ps] = (unsigned)p.bn_bits[o / VEC];
+            }
+          }
+  #pragma unroll
+          for (int ps = 0; ps < NP; ++ps) {
+            const int row = ps * RPI + rr;
+            const int pix = pixs[ps];
+            float v[VEC];
+  #pragma unroll
+            for (int q = 0; q < VEC / 4; ++q) {
+              const int sc = (ch * (VEC / 4) + q) ^ (row & (SCH - 1));
+              const f32x4 t = *reinterpret_cast<const f32x4*>(stg + row * (WN * 4) + sc * 16);
+              v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+            }
+            const size_t o = (size_t)(pix < 0 ? 0 : pix) * p.Ncols + n0 + wn * WN + ch * VEC;
+            if (addend) {
+              float a[VEC];
+              Vec16<T>::unpack(araw[ps], a);
+  #pragma unroll
+              for (int e = 0; e < VEC; ++e) v[e] += (abits[ps] >> e) & 1u ? a[e] : 0.f;
+            }
+            // rows past the end of the problem go to a trash page so that every thread issues exactly NST stores
+            T* dst = pix < 0 ? reinterpret_cast<T*>(g_trash + tid * 16) : out + o;
+            Vec16<T>::store(dst, v);
+            if constexpr (STATS == 1) {
+              if (pix >= 0) {
+  #pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                  const float xr = (float)(T)v[e];
+                  s1[e] += xr;
+                  s2[e] += xr * xr;
+                }
+              }
+            }
+            if constexpr (STATS == 2) {
+              if (pix >= 0) {
+                float yv[VEC];
+                Vec16<T>::unpack(yraw[ps], yv);
+  #pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                  const float dz = (ybits[ps] >> e) & 1u ? (float)(T)v[e] : 0.f;
+                  s1[e] += dz;
+                  s2[e] += dz * ((yv[e] - bmu[e]) * bis[e]);
+                }
+              }
+            }
+          }
+          asm volatile("" ::: "memory");
+        }
+        if constexpr (STATS != 0) {
+          // lanes with the same channel chunk sit CPR lanes apart (rows rr): park the per-lane sums in the wave-private
+          // staging region, let lane c add up channel c's RPI rows and add the result to THIS wave's accumulator slot
+          // (one fixed lane per slot, LDS is in-order per wave => deterministic, no atomics, nothing leaves the CU).
+          float* scr = reinterpret_cast<float*>(stg);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  #pragma unroll
+          for (int q = 0; q < VEC / 4; ++q) {
+            const f32x4 a = {s1[4 * q], s1[4 * q + 1], s1[4 * q + 2], s1[4 * q + 3]};
+            const f32x4 b = {s2[4 * q], s2[4 * q + 1], s2[4 * q + 2], s2[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(scr + rr * WN + ch * VEC + 4 * q) = a;
+            *reinterpret_cast<f32x4*>(scr + (RPI + rr) * WN + ch * VEC + 4 * q) = b;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  #pragma unroll
+          for (int cc = lane; cc < WN; cc += 64) {
+            float a = 0.f, b = 0.f;
+  #pragma unroll
+            for (int r = 0; r < RPI; ++r) {
+              a += scr[r * WN + cc];
+              b += scr[(RPI + r) * WN + cc];
+            }
+            float* slot = stat_acc + ((wm * kp.ntpg + nti) * BN + wn * WN + cc) * 2;
+            slot[0] += a;
+            slot[1] += b;
+          }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        constexpr int NP = 32 / RPI;
-        int pixs[NP];
-        uint4 araw[NP];
-        unsigned abits[NP];
-        uint4 yraw[NP];
-        unsigned ybits[NP];
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {  // all addend loads of this pass first: one round trip, not NP
-          pixs[ps] = row_pix[wm * (BM / 2) + mi * 32 + ps * RPI + rr];
-          if (addend) {
-            const size_t o = (size_t)(pixs[ps] < 0 ? 0 : pixs[ps]) * p.Ncols + n0 + wn * WN + ch * VEC;
-            araw[ps] = *reinterpret_cast<const uint4*>(pixs[ps] < 0 ? reinterpret_cast<const T*>(g_zero_page) : addend + o);
-            abits[ps] = p.addend_bits ? (unsigned)p.addend_bits[pixs[ps] < 0 ? 0 : o / VEC] : 0xffu;
-          }
-          if constexpr (STATS == 2) {
-            const size_t o = (size_t)(pixs[ps] < 0 ? 0 : pixs[ps]) * p.Ncols + n0 + wn * WN + ch * VEC;
-            yraw[ps] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.bn_y) + o);
-            ybits[ps] = (unsigned)p.bn_bits[o / VEC];
-          }
         }
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-          const int row = ps * RPI + rr;
-          const int pix = pixs[ps];
-          float v[VEC];
-#pragma unroll
-          for (int q = 0; q < VEC / 4; ++q) {
-            const int sc = (ch * (VEC / 4) + q) ^ (row & (SCH - 1));
-            const f32x4 t = *reinterpret_cast<const f32x4*>(stg + row * (WN * 4) + sc * 16);
-            v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
-          }
-          const size_t o = (size_t)(pix < 0 ? 0 : pix) * p.Ncols + n0 + wn * WN + ch * VEC;
-          if (addend) {
-            float a[VEC];
-            Vec16<T>::unpack(araw[ps], a);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) v[e] += (abits[ps] >> e) & 1u ? a[e] : 0.f;
-          }
-          // rows past the end of the problem go to a trash page so that every thread issues exactly NST stores
-          T* dst = pix < 0 ? reinterpret_cast<T*>(g_trash + tid * 16) : out + o;
-          Vec16<T>::store(dst, v);
-          if constexpr (STATS == 1) {
-            if (pix >= 0) {
-#pragma unroll
-              for (int e = 0; e < VEC; ++e) {
-                const float xr = (float)(T)v[e];
-                s1[e] += xr;
-                s2[e] += xr * xr;
-              }
-            }
-          }
-          if constexpr (STATS == 2) {
-            if (pix >= 0) {
-              float yv[VEC];
-              Vec16<T>::unpack(yraw[ps], yv);
-#pragma unroll
-              for (int e = 0; e < VEC; ++e) {
-                const float dz = (ybits[ps] >> e) & 1u ? (float)(T)v[e] : 0.f;
-                s1[e] += dz;
-                s2[e] += dz * ((yv[e] - bmu[e]) * bis[e]);
-              }
-            }
-          }
-        }
-        asm volatile("" ::: "memory");
-      }
-      if constexpr (STATS != 0) {
-        // lanes with the same channel chunk sit CPR lanes apart (rows rr): park the per-lane sums in the wave-private
-        // staging region, let lane c add up channel c's RPI rows and add the result to THIS wave's accumulator slot
-        // (one fixed lane per slot, LDS is in-order per wave => deterministic, no atomics, nothing leaves the CU).
-        float* scr = reinterpret_cast<float*>(stg);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int q = 0; q < VEC / 4; ++q) {
-          const f32x4 a = {s1[4 * q], s1[4 * q + 1], s1[4 * q + 2], s1[4 * q + 3]};
-          const f32x4 b = {s2[4 * q], s2[4 * q + 1], s2[4 * q + 2], s2[4 * q + 3]};
-          *reinterpret_cast<f32x4*>(scr + rr * WN + ch * VEC + 4 * q) = a;
-          *reinterpret_cast<f32x4*>(scr + (RPI + rr) * WN + ch * VEC + 4 * q) = b;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int cc = lane; cc < WN; cc += 64) {
-          float a = 0.f, b = 0.f;
-#pragma unroll
-          for (int r = 0; r < RPI; ++r) {
-            a += scr[r * WN + cc];
-            b += scr[(RPI + r) * WN + cc];
-          }
-          float* slot = stat_acc + ((wm * kp.ntpg + nti) * BN + wn * WN + cc) * 2;
-          slot[0] += a;
-          slot[1] += b;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (EPI_TURNS > 1) MI355_LDS_BARRIER();  // the next group of waves takes the staging blocks
       }
       pending_st += NST;
     }
@@ -592,9 +636,15 @@ __global__ __launch_bounds__(256, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void ige
     const int chan = kp.ntpg * BN;
     const int grp = blockIdx.x % kp.ngroups;
     float* row = p.stat_partial + (size_t)(blockIdx.x / kp.ngroups) * 2 * p.Ncols + grp * chan;
-    for (int c = tid; c < chan; c += 256) {
-      row[c] = stat_acc[c * 2] + stat_acc[(chan + c) * 2];
-      row[p.Ncols + c] = stat_acc[c * 2 + 1] + stat_acc[(chan + c) * 2 + 1];
+    for (int c = tid; c < chan; c += NT) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WMW; ++w) {  // the wave rows, in order
+        a += stat_acc[(w * chan + c) * 2];
+        b += stat_acc[(w * chan + c) * 2 + 1];
+      }
+      row[c] = a;
+      row[p.Ncols + c] = b;
     }
   }
 }
@@ -610,8 +660,9 @@ void lds_opt_in(const void* fn, size_t lds) {
   done.insert(fn);
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int WMW = 2, int NSTG = 2>
 int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
+  constexpr int NT = 128 * WMW;
   constexpr int MAX_WG = BM == 256 ? 256 : (BN == 64 ? 768 : 512);  // persistent workgroups: 1, 3 or 2 per CU
   IgemmKArgs k;
   k.a = a;
@@ -681,23 +732,23 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
   k.bytes_in = (unsigned)bytes_in;
   k.bytes_wt = (unsigned)bytes_wt;
   const int grid = sk ? MAX_WG : (k.items < MAX_WG ? k.items : MAX_WG);
-  size_t lds = (size_t)2 * (BM + BN) * BKB + BM * sizeof(int);
+  size_t lds = (size_t)NSTG * (BM + BN) * BKB + BM * sizeof(int);
   // BN statistics in the epilogue need [2][channels per workgroup][2] floats of LDS; beyond 512 channels per workgroup
   // the kernel would drop to one workgroup per CU, so the caller falls back to the standalone statistics kernel
   const int chan = k.ntpg * BN;
   const bool stats = a.stat_partial != nullptr && chan <= 512 && grid % ng == 0;
   if (stat_rows) *stat_rows = stats ? grid / ng : 0;
   if (stats) {
-    lds += (size_t)2 * chan * 2 * sizeof(float);
-    lds_opt_in((const void*)igemm_kernel<T, BM, BN, 1>, lds);
-    lds_opt_in((const void*)igemm_kernel<T, BM, BN, 2>, lds);
+    lds += (size_t)WMW * chan * 2 * sizeof(float);
+    lds_opt_in((const void*)igemm_kernel<T, BM, BN, WMW, NSTG, 1>, lds);
+    lds_opt_in((const void*)igemm_kernel<T, BM, BN, WMW, NSTG, 2>, lds);
     if (a.bn_y)
-      hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 2>), dim3(grid), dim3(256), lds, stream, k);
+      hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WMW, NSTG, 2>), dim3(grid), dim3(NT), lds, stream, k);
     else
-      hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 1>), dim3(grid), dim3(256), lds, stream, k);
+      hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WMW, NSTG, 1>), dim3(grid), dim3(NT), lds, stream, k);
   } else {
-    lds_opt_in((const void*)igemm_kernel<T, BM, BN, 0>, lds);
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 0>), dim3(grid), dim3(256), lds, stream, k);
+    lds_opt_in((const void*)igemm_kernel<T, BM, BN, WMW, NSTG, 0>, lds);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WMW, NSTG, 0>), dim3(grid), dim3(NT), lds, stream, k);
   }
   MI355_LAUNCH_CHECK();
   return 0;
@@ -732,8 +783,15 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
     int max_taps = 0;
     for (int ci = 0; ci < nclass; ++ci) max_taps = a.cls[ci].ntaps > max_taps ? a.cls[ci].ntaps : max_taps;
     // (not with the BN-backward sums: that epilogue needs more registers than the 256 x 256 tile leaves)
-    const bool big = a.Ncols % 256 == 0 && (big_mode < 0 ? (items256 >= 192 && max_taps * a.Ck >= 256 && !a.bn_y) : big_mode != 0);
+    const bool big = a.Ncols % 256 == 0 && (big_mode < 0 ? (items256 >= 192 && max_taps * a.Ck >= 256 && !a.bn_y) : big_mode == 1);
     if (big) return launch_t<bf16_t, 256, 256>(a, nclass, stream, stat_rows);
+    // 256 x 128, 8 waves, 3-stage ring: per CU and k-step 8 % faster than two 128 x 128 workgroups (the slab wait drops
+    // from ~700 to ~200 cycles), but a partial round costs it a full one where the 2-workgroup form speeds up when a CU
+    // holds a single workgroup — so only where all its tiles fit into one round, and the reduction is long
+    const long items3 = (long)cdiv(a.N * a.Hsub * a.Wsub, 256) * nclass * (a.Ncols / 128);
+    const bool tall = a.Ncols % 128 == 0 &&
+                      (big_mode < 0 ? (items3 <= 256 && items3 >= 128 && max_taps * a.Ck >= 512) : big_mode == 3);
+    if (tall) return launch_t<bf16_t, 256, 128, 4, 3>(a, nclass, stream, stat_rows);
     return wide ? launch_t<bf16_t, 128, 128>(a, nclass, stream, stat_rows) : launch_t<bf16_t, 128, 64>(a, nclass, stream, stat_rows);
   }
   set_error("igemm: bad dtype %d", dtype);
