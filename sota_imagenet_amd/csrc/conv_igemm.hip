@@ -736,7 +736,8 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
   // BN statistics in the epilogue need [2][channels per workgroup][2] floats of LDS; beyond 512 channels per workgroup
   // the kernel would drop to one workgroup per CU, so the caller falls back to the standalone statistics kernel
   const int chan = k.ntpg * BN;
-  const bool stats = a.stat_partial != nullptr && chan <= 512 && grid % ng == 0;
+  const bool stats = a.stat_partial != nullptr && chan <= 512 && grid % ng == 0 &&
+                     lds + (size_t)WMW * chan * 2 * sizeof(float) <= 160 * 1024;
   if (stat_rows) *stat_rows = stats ? grid / ng : 0;
   if (stats) {
     lds += (size_t)WMW * chan * 2 * sizeof(float);
