@@ -791,7 +791,7 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
     // holds a single workgroup — so only where all its tiles fit into one round, and the reduction is long
     const long items3 = (long)cdiv(a.N * a.Hsub * a.Wsub, 256) * nclass * (a.Ncols / 128);
     const bool tall = a.Ncols % 128 == 0 &&
-                      (big_mode < 0 ? (items3 <= 256 && items3 >= 128 && max_taps * a.Ck >= 512) : big_mode == 3);
+                      (big_mode < 0 ? ((items3 <= 256 && items3 >= 128 && max_taps * a.Ck >= 512) || (items3 <= 512 && max_taps == 1 && a.Ck >= 1024)) : big_mode == 3);
     if (tall) return launch_t<bf16_t, 256, 128, 4, 3>(a, nclass, stream, stat_rows);
     return wide ? launch_t<bf16_t, 128, 128>(a, nclass, stream, stat_rows) : launch_t<bf16_t, 128, 64>(a, nclass, stream, stat_rows);
   }
