@@ -182,12 +182,12 @@ def test_bf16_forward_backward_vs_cpu_yardstick(dev):
     assert l2err(g, g64) < 1.5 * l2err(gb, g64) + 5e-2
 
 
-@pytest.mark.parametrize("dtype,tol,big", [("fp32", 2e-5, None), ("bf16", 2e-2, None), ("bf16", 2e-2, "1")])
+@pytest.mark.parametrize("dtype,tol,big", [("fp32", 2e-5, None), ("bf16", 2e-2, None), ("bf16", 2e-2, "1"), ("bf16", 2e-2, "3")])
 def test_teacher_forced_layers(dev, dtype, tol, big, monkeypatch):
     """Every forward stage of the executor, re-derived by the oracle FROM THE EXECUTOR'S OWN INPUT to that stage
     (saved activations read back through the debug hook): conv, BN(+ReLU), residual add, maxpool, GAP, FC."""
-    if big is not None:  # force the 256x256 conv tiles (normally chosen only at training-size batches) on every layer
-        monkeypatch.setenv("MI355_IGEMM_BIG", big)  # with N % 256 == 0 output channels
+    if big is not None:  # force the 256x256 ("1") / 256x128 8-wave 3-stage ("3") conv tiles, normally chosen only at
+        monkeypatch.setenv("MI355_IGEMM_BIG", big)  # training-size batches, on every layer whose channel count allows
     tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
     N, S = 4, 64
     key = (N, S, S)
@@ -342,19 +342,20 @@ def test_fused_bn_backward_sums_match_standalone_reduce(dev):
     assert max(errs) < 0.3, f"per-segment drift {['%.1e' % x for x in errs]}"
 
 
+@pytest.mark.parametrize("forced", ["1", "3"])
 @pytest.mark.parametrize("fuse", ["0", "1"])
-def test_256_wide_conv_tiles_in_backward_match_128_wide(dev, fuse, monkeypatch):
+def test_256_wide_conv_tiles_in_backward_match_128_wide(dev, fuse, forced, monkeypatch):
     """The 256x256 igemm tile is chosen by a rule that only fires at training-size batches.  Forward coverage is
     test_teacher_forced_layers[bf16-big]; here the SAME forward (128-wide) is followed by a backward with the 256-wide
-    tile forced on every dgrad whose output has N % 256 == 0 channels (with and without the BN-backward epilogue) and by
-    one with 128-wide tiles.  A dgrad output element sums its k-steps in the same order in both; only the grouping of the
+    tile ("1": 256x256; "3": 256x128, 8 waves, 3-stage ring) forced on every dgrad whose channel count allows (with and
+    without the BN-backward epilogue) and by one with 128-wide tiles.  A dgrad output element sums its k-steps in the same order in both; only the grouping of the
     fused BN sums differs, so the gradients must agree tightly at the top of the network and drift only by bf16 rounding
     flips further down."""
     from sota_imagenet_amd.losses import CrossEntropyLoss
 
     monkeypatch.setenv("MI355_FUSE_BN_BWD", fuse)
     grads = []
-    for big in ("1", "0"):
+    for big in (forced, "0"):
         monkeypatch.setenv("MI355_IGEMM_BIG", "0")
         m, _ = build("bf16")
         m.train()
