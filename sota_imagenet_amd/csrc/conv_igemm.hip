@@ -82,7 +82,7 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 template <typename T, int BM, int BN, int WMW, int NSTG, int STATS>
-__global__ __launch_bounds__(128 * WMW, (BM == 256 ? 1 : (BN == 64 ? 3 : 2))) void igemm_kernel(const IgemmKArgs kp) {
+__global__ __launch_bounds__(128 * WMW, (BM == 256 ? 1 : (BN == 64 && NSTG == 2 ? 3 : 2))) void igemm_kernel(const IgemmKArgs kp) {
   const IgemmArgs& p = kp.a;
   constexpr int ES = (int)sizeof(T);
   constexpr int BK = BKB / ES;
@@ -663,7 +663,7 @@ void lds_opt_in(const void* fn, size_t lds) {
 template <typename T, int BM, int BN, int WMW = 2, int NSTG = 2>
 int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
   constexpr int NT = 128 * WMW;
-  constexpr int MAX_WG = BM == 256 ? 256 : (BN == 64 ? 768 : 512);  // persistent workgroups: 1, 3 or 2 per CU
+  constexpr int MAX_WG = BM == 256 ? 256 : (BN == 64 && NSTG == 2 ? 768 : 512);  // persistent workgroups: 1, 3 or 2 per CU
   IgemmKArgs k;
   k.a = a;
   const int Msub = a.N * a.Hsub * a.Wsub;
