@@ -29,7 +29,7 @@ PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2516.6}  # MI355X_MICROARCH.md: dense MFMA
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 HBM_CLASS = 7  # executor profile class of bn_bwd_apply_kernel, the largest HBM-bound kernel of the step
 # profile class -> kernel symbols (template instances of one source; names as tools/pmc_traffic.py writes them)
-KERNEL_NAMES = {0: ["igemm_kernel<{T},128,128>", "igemm_kernel<{T},256,256>"], 1: ["igemm_kernel<{T},128,64>"],
+KERNEL_NAMES = {0: ["igemm_kernel<{T},128,128>", "igemm_kernel<{T},256,256>", "igemm_kernel<{T},256,128>"], 1: ["igemm_kernel<{T},128,64>"],
                 2: ["wgrad_kernel<{T},128,128>", "wgrad_kernel<{T},128,64>"], 3: ["wgrad_kernel<{T},64,128>", "wgrad_kernel<{T},64,64>"]}
 
 

@@ -201,7 +201,7 @@ int mi355_resnet50_debug_tensor(const mi355_ctx* ctx, const char* name, void** p
 /* HIP-event timing of kernel classes inside a step, recorded on the stream the kernels are launched on.
  * mi355_resnet50_profile(ctx, class_mask): bit k set => every launch of class k is bracketed by a pair of
  * hipEvents from now on (mask 0 switches it off; calling it also clears earlier records).  Classes:
- *   0 igemm_kernel<T,128|256,128|256,*> (conv fwd + dgrad, >=128 output channels)   1 igemm_kernel<T,128,64,*> (incl. stem)
+ *   0 igemm_kernel<T,128|256,128|256,...> (conv fwd + dgrad, >=128 output channels)   1 igemm_kernel<T,128,64,...> (incl. stem)
  *   2 wgrad_kernel<T,128,*>   3 wgrad_kernel<T,64,*> (incl. stem)   4 bn_reduce_kernel (stats + bwd sums)
  *   5 bn_apply_kernel   6 other (ingest, pools, FC, weight prep)   7 bn_bwd_apply_kernel
  *   profile_read kind 8: the 3x3 convolutions (fwd + dgrad) among the recorded launches of classes 0 and 1
