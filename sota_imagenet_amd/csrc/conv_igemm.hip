@@ -4,25 +4,31 @@
 // reference (call form sota_imagenet/callbacks.py:316-317; model built at train.py:64).
 //
 // One kernel serves forward, dgrad (stride 1 and, through four output-parity classes, stride 2), the 7x7 stem
-// (7 row-taps over a zero-padded NHWC4 image) and the FC layer: see IgemmArgs in common.h.
+// (4 row-pair taps over a zero-padded NHWC4 image) and the FC layer: see IgemmArgs in common.h.
 //
-//   tile        128 pixels x BN channels (BN = 128 | 64); K advances in 128-byte slabs of the tap's channel run
-//   MFMA        4 waves (2x2), each 64 x BN/2 from 32x32 tiles: v_mfma_f32_32x32x2_f32 (exact fp32, the parity
-//               path) / v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  Operands are swapped (D^T = W * A^T) so a
+//   tile        BM pixels x BN channels; K advances in 128-byte slabs of the tap's channel run.  Instantiations (see the
+//               kernel's own comment for why each exists): 128 x 64 and 128 x 128 (4 waves, 2-stage ring, 3 resp. 2
+//               workgroups per CU — the default), 256 x 256 (4 waves, 1 per CU) and 256 x 128 (8 waves, 3-stage ring,
+//               1 per CU) for the bf16 launches the rules in launch_igemm() select.
+//   MFMA        waves in a WMW x 2 grid, each BM/WMW x BN/2 from 32x32 tiles: v_mfma_f32_32x32x2_f32 (exact fp32, the
+//               parity path) / v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  Operands are swapped (D^T = W * A^T) so a
 //               lane ends up holding 4 consecutive channels of one pixel.
 //   staging     direct-to-LDS buffer loads (buffer_load_dwordx4 ... offen lds): every lane supplies its own 32-bit byte
 //               offset into the tensor's buffer descriptor (the A rows are gathered pixel runs; out-of-image rows get
 //               an out-of-range offset and the hardware range check returns zeros), the LDS image stays lane-linear
 //               ([row][128 B], no padding) and the bank-conflict fix is an XOR of the 16-byte chunk index with
-//               (row>>1)&7 applied to the SOURCE offset and again on the fragment ds_read_b128.  The 6-8 loads of
-//               the NEXT slab are issued in pairs between the four MFMA groups of the current slab, so the matrix
-//               pipe keeps running while the loader computes offsets.
-//   pipeline    persistent workgroups walk (row-tile, n-tile, k-slab) as ONE stream through a 2-stage LDS ring:
-//               the loads of the next slab — also across tile boundaries, i.e. under the previous tile's epilogue —
-//               are in flight while the current slab feeds the MFMAs; counted `s_waitcnt vmcnt(N)` + raw s_barrier
-//               (never __syncthreads, whose fence would drain the LDS-DMA queue).  2 workgroups per CU (64.5 KiB each).
+//               (row>>1)&7 applied to the SOURCE offset and again on the fragment ds_read_b128.  The loads of a later
+//               slab are issued between the four MFMA groups of the current one, so the matrix pipe keeps running
+//               while the loader computes offsets.
+//   pipeline    persistent workgroups walk (row-tile, n-tile, k-slab) as ONE stream through an NSTG-stage LDS ring:
+//               the loads of the next NSTG-1 slabs — also across tile boundaries, i.e. under the previous tile's
+//               epilogue — are in flight while the current slab feeds the MFMAs; counted `s_waitcnt vmcnt(N)` + raw
+//               s_barrier (never __syncthreads, whose fence would drain the LDS-DMA queue).
 //   epilogue    each wave stages its 32 x BN/2 fp32 sub-tile through (XOR-swizzled) LDS and writes 16 bytes per lane,
-//               64..256 contiguous bytes per pixel; the optional addend (residual gradient) is read the same way.
+//               64..256 contiguous bytes per pixel; the optional addend (residual gradient, under a ReLU bit mask) is
+//               read the same way; optionally BN statistics of the output / the BN-backward sums of the layer the
+//               output is the activation gradient of (per-workgroup LDS accumulators, one flush per workgroup).
+//   fp32 only   stream-K over the partial last round of the 128 x 128 launches (see IgemmKArgs).
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
