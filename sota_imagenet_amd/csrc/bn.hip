@@ -9,7 +9,10 @@
 // and walks pixels, so every wave-instruction moves 1 KiB of contiguous NHWC memory.  Per-channel sums:
 // registers -> wavefront __shfl_xor across the pixel rows that share a wave -> LDS across waves -> one
 // partial row per block -> a finalize kernel that adds the (<= 512) block partials in fp64 in block order
-// (bitwise reproducible; no float atomics).
+// (bitwise reproducible; no float atomics).  In the training step most partial rows come from the conv kernels'
+// epilogues instead (conv_igemm.hip, STATS 1 / 2) and only the finalize + apply kernels of this file run; the ReLU mask
+// travels as one byte per 16-byte vector (written by bn_apply, read by both backward kernels); mask / residual /
+// second-branch variants are template parameters and last-use streams are loaded non-temporally.
 #include "common.h"
 #include "vec.h"
 

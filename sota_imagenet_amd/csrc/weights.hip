@@ -1,7 +1,8 @@
 // weights.hip — per-step weight preparation: fp32 KRSC master -> the operand images the conv kernels read.
 //   * cast copy      [Cout][taps][Cin]  in the compute dtype (bf16 path only)
 //   * transposed copy [Cin][taps][Cout] in the compute dtype (the K-contiguous B operand of dgrad)
-//   * stem pack      [64][7][7][3] -> [64][7][16 px * 4 ch] zero padded (the stem runs as 7 row-taps of 64)
+//   * stem pack      [64][7][7][3] -> [64][4 row pairs][2 x (8 px * 4 ch)] zero padded (the stem runs as 4 row-pair taps of 64)
+//   all conv layers of the network are prepared by ONE launch (weight_prep_batch_kernel, device-side layer table)
 // ~94 MB of reads per step for ResNet-50: HBM-trivial, and it keeps the master weights in the layout
 // torch's state_dict exposes (reference interchange: train.py:101,184).
 #include "common.h"
