@@ -30,6 +30,7 @@
 //               output is the activation gradient of (per-workgroup LDS accumulators, one flush per workgroup).
 //   fp32 only   stream-K over the partial last round of the 128 x 128 launches (see IgemmKArgs).
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <set>
@@ -765,6 +766,51 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
 
 size_t igemm_sk_ws_bytes() { return IGEMM_SK_FLAG_BYTES + (size_t)512 * 128 * 128 * sizeof(float); }
 
+// conv_igemm8.hip
+bool igemm8_legal(const IgemmArgs& a, int nclass, int bn);
+int launch_igemm8(const IgemmArgs& a, int nclass, int bm, int bn, int korder, int fat, hipStream_t stream, int* stat_rows);
+
+// Which bf16 launches go to the 8-wave ping-pong kernel, and with which tile.  MI355_IGEMM8 in the environment:
+//   "0" never;  "<BM>x<BN>[k][f]" (e.g. 256x256, 224x128kf) forces that tile wherever it is legal (k: channel chunks
+//   outer, taps inner; f: the fat-phase form);  unset: the measured rule below.
+static bool choose_igemm8(const IgemmArgs& a, int nclass, int* bm, int* bn, int* korder, int* fat) {
+  const char* env = getenv("MI355_IGEMM8");
+  if (env && env[0] == '0') return false;
+  if (env && env[0]) {
+    int m = 0, n = 0;
+    char k1 = 0, k2 = 0;
+    if (sscanf(env, "%dx%d%c%c", &m, &n, &k1, &k2) >= 2 && (m == 256 || m == 224) && (n == 256 || n == 128) && igemm8_legal(a, nclass, n)) {
+      *bm = m; *bn = n; *korder = k1 == 'k' || k2 == 'k'; *fat = k1 == 'f' || k2 == 'f';
+      return true;
+    }
+    return false;
+  }
+  // Measured per layer shape at batch 256 (tools/conv8_check.py, same-process A/B against the 4-wave tiles):
+  //  - >= 256 output columns and a reduction of >= 256: the 224 x 256 tile wins on every layer-3/4 shape as long as its
+  //    tile count still covers most of the 256 CUs (it is bound by fragment reads + LDS-DMA issue, not by MFMAs, and a
+  //    224-row tile has 1/8 fewer A reads than a 256-row one; 224 divides the 49 * 2^k * N pixel counts);
+  //  - the 512-column layer-4 3x3 (98 tiles of 256 x 256, 112 of 224 x 256): 256 x 128 fat phases, 196 tiles.
+  int max_taps = 0;
+  for (int ci = 0; ci < nclass; ++ci) max_taps = a.cls[ci].ntaps > max_taps ? a.cls[ci].ntaps : max_taps;
+  const long K = (long)max_taps * a.Ck;
+  const long M = (long)a.N * a.Hsub * a.Wsub;
+  if (a.Ncols % 256 == 0 && K >= 256 && igemm8_legal(a, nclass, 256)) {
+    const long tiles = ((M + 223) / 224) * nclass * (a.Ncols / 256);
+    if (tiles >= 180) {
+      *bm = 224; *bn = 256; *korder = 0; *fat = 0;
+      return true;
+    }
+  }
+  if (a.Ncols % 128 == 0 && K >= 4096 && igemm8_legal(a, nclass, 128)) {
+    const long tiles = ((M + 255) / 256) * nclass * (a.Ncols / 128);
+    if (tiles >= 180 && tiles <= 256) {
+      *bm = 256; *bn = 128; *korder = 0; *fat = 1;
+      return true;
+    }
+  }
+  return false;
+}
+
 int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
   const int bk = BKB / (int)dtype_size(dtype);
   MI355_ARG(a.in && a.wt && a.out, "igemm: null pointer");
@@ -780,6 +826,10 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
   if (dtype == MI355_F32)
     return wide ? launch_t<float, 128, 128>(a, nclass, stream, stat_rows) : launch_t<float, 128, 64>(a, nclass, stream, stat_rows);
   if (dtype == MI355_BF16) {
+    {
+      int bm8 = 0, bn8 = 0, ko8 = 0, fat8 = 0;
+      if (choose_igemm8(a, nclass, &bm8, &bn8, &ko8, &fat8)) return launch_igemm8(a, nclass, bm8, bn8, ko8, fat8, stream, stat_rows);
+    }
     // 256 x 256 tiles (bf16 only: fp32 MFMAs are slow enough that the LDS port is not the limit).  Measured per layer
     // shape at batch 256 (tools/one_conv.py): they win when the 256 single-workgroup CUs are still mostly filled
     // (>= 192 tiles) and the reduction is long enough to amortise the larger epilogue (K >= 256); they lose on the

@@ -40,6 +40,22 @@ __device__ __forceinline__ void blds16(i32x4 srd, unsigned voff, unsigned lds_ds
                : "v"(voff), "s"(srd), "s"(lds_dst)
                : "memory", "m0");
 }
+// The same with the source offset split into per-lane `voff` + wave-uniform `soff` (the instruction's scalar offset: no
+// VALU add) and the LDS destination formed as lds_base + IMM by the s_add that writes M0.
+template <int IMM>
+__device__ __forceinline__ void blds16o(i32x4 srd, unsigned voff, unsigned soff, unsigned lds_base) {
+  asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+               :
+               : "v"(voff), "s"(srd), "s"(soff), "s"(lds_base), "i"(IMM)
+               : "memory", "m0", "scc");
+}
+template <int IMM>
+__device__ __forceinline__ void blds16z(i32x4 srd, unsigned voff, unsigned lds_base) {
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+               :
+               : "v"(voff), "s"(srd), "s"(lds_base), "i"(IMM)
+               : "memory", "m0", "scc");
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(unsigned long long)(lptr_t)p;
 }

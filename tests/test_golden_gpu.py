@@ -60,6 +60,39 @@ def test_ce_sgd_golden(dev):
     close("sgd_m", m, 1e-6)
 
 
+def test_bn_pool_accuracy_golden(dev):
+    """the committed bn_* / mp_* / acc* vectors (same inputs as tests/golden/make_golden.py) against the HIP kernels"""
+    from sota_imagenet_amd import ops
+    from sota_imagenet_amd.fit_wrapper import Accuracy
+
+    x = (uniform_tensor((2, 6, 6, 64), 2.0, 111) + 0.3).to(dev)
+    res = uniform_tensor((2, 6, 6, 64), 1.0, 112).to(dev)
+    g, b = (uniform_tensor((64,), 0.5, 113) + 1.5).to(dev), uniform_tensor((64,), 1.0, 114).to(dev)
+    rm, rv = uniform_tensor((64,), 1.0, 115).to(dev), (uniform_tensor((64,), 0.5, 116).abs() + 0.5).to(dev)
+    dout = uniform_tensor((2, 6, 6, 64), 1.0, 117).to(dev)
+    out, mean, invstd = ops.bn_fwd_train(x, g, b, rm, rv, residual=res, relu=True)
+    close("bn_out", out, 1e-5)
+    close("bn_rm", rm, 1e-5)
+    close("bn_rv", rv, 1e-5)
+    close("bn_mean", mean, 1e-5)
+    close("bn_invstd", invstd, 1e-5)
+    dx, dg, db, dz = ops.bn_bwd(dout, out, x, g, mean, invstd, relu=True, want_dz=True)
+    close("bn_dx", dx, 1e-4)
+    close("bn_dg", dg, 1e-4)
+    close("bn_db", db, 1e-4)
+    close("bn_dres", dz, 0)  # the residual branch's gradient is the masked incoming gradient: exact
+    xp = torch.relu(uniform_tensor((1, 8, 8, 64), 1.0, 121)).to(dev)
+    yp, idx = ops.maxpool_fwd(xp)
+    close("mp_y", yp, 0)
+    close("mp_dx", ops.maxpool_bwd(uniform_tensor(tuple(yp.shape), 1.0, 122).to(dev), idx, tuple(xp.shape)), 0)
+    lg = uniform_tensor((32, 1000), 4.0, 151)
+    tg = torch.nn.functional.one_hot((torch.arange(32) * 31) % 1000, 1000).float()
+    lg[torch.arange(0, 32, 3), tg.argmax(1)[::3]] += 5.0
+    for k, name in ((1, "acc1"), (5, "acc5")):
+        acc = Accuracy(k)(lg.to(dev), tg.to(dev))
+        assert abs(float(acc) - float(OPS[name])) < 1e-4, name
+
+
 @pytest.mark.parametrize("S", [64, 224])
 def test_resnet50_logits_golden(dev, S):
     from sota_imagenet_amd.losses import CrossEntropyLoss

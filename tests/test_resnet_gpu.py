@@ -182,11 +182,18 @@ def test_bf16_forward_backward_vs_cpu_yardstick(dev):
     assert l2err(g, g64) < 1.5 * l2err(gb, g64) + 5e-2
 
 
-@pytest.mark.parametrize("dtype,tol,big", [("fp32", 2e-5, None), ("bf16", 2e-2, None), ("bf16", 2e-2, "1"), ("bf16", 2e-2, "3")])
+IGEMM8_TILES = ["224x256", "256x256f", "256x128f", "224x128", "256x256k", "224x128kf"]  # MI355_IGEMM8 values (conv_igemm8.hip)
+
+
+@pytest.mark.parametrize("dtype,tol,big", [("fp32", 2e-5, None), ("bf16", 2e-2, None), ("bf16", 2e-2, "1"), ("bf16", 2e-2, "3")] +
+                         [("bf16", 2e-2, "8:" + t) for t in IGEMM8_TILES])
 def test_teacher_forced_layers(dev, dtype, tol, big, monkeypatch):
     """Every forward stage of the executor, re-derived by the oracle FROM THE EXECUTOR'S OWN INPUT to that stage
     (saved activations read back through the debug hook): conv, BN(+ReLU), residual add, maxpool, GAP, FC."""
-    if big is not None:  # force the 256x256 ("1") / 256x128 8-wave 3-stage ("3") conv tiles, normally chosen only at
+    if big is not None and big.startswith("8:"):  # the 8-wave ping-pong kernel, that tile wherever it is legal
+        monkeypatch.setenv("MI355_IGEMM8", big[2:])
+    elif big is not None:  # force the 256x256 ("1") / 256x128 8-wave 3-stage ("3") conv tiles, normally chosen only at
+        monkeypatch.setenv("MI355_IGEMM8", "0")
         monkeypatch.setenv("MI355_IGEMM_BIG", big)  # training-size batches, on every layer whose channel count allows
     tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
     N, S = 4, 64
@@ -370,6 +377,115 @@ def test_256_wide_conv_tiles_in_backward_match_128_wide(dev, fuse, forced, monke
     # fc: exact; layer4.2: exact without the fused sums, ~2e-6 with them (its bn1/bn2 sums are grouped differently)
     assert errs[0] == 0.0 and errs[1] < 1e-5, f"fc / layer4.2: {errs[:2]}"
     assert errs[2] < 5e-3, f"layer4.1: {errs[2]:.3e}"
+    assert max(errs) < 0.3, f"per-segment drift {['%.1e' % x for x in errs]}"
+
+
+@pytest.mark.parametrize("tile", IGEMM8_TILES)
+@pytest.mark.parametrize("fuse", ["0", "1"])
+def test_igemm8_tiles_in_backward_match_128_wide(dev, fuse, tile, monkeypatch):
+    """The same for the 8-wave ping-pong kernel (conv_igemm8.hip): identical forward, then a backward with `tile` forced on
+    every dgrad whose shape allows (plain, + shortcut addend under the ReLU mask, + BN-backward sums) against one with
+    the 4-wave 128-wide tiles.  Both sum a dgrad element's k-steps in one fixed order each (different between the two:
+    MFMA shape and, with the k suffix, tap order), so fc is exact and the top block agrees to fp32 rounding of the sums."""
+    from sota_imagenet_amd.losses import CrossEntropyLoss
+
+    monkeypatch.setenv("MI355_FUSE_BN_BWD", fuse)
+    monkeypatch.setenv("MI355_IGEMM_BIG", "0")
+    grads = []
+    for t in (tile, "0"):
+        monkeypatch.setenv("MI355_IGEMM8", "0")
+        m, _ = build("bf16")
+        m.train()
+        data, target = synthetic_batch(8, 64, seed=11, index=0)
+        loss = CrossEntropyLoss(smoothing=0.1).cuda()(m(data.cuda()), target.cuda())
+        monkeypatch.setenv("MI355_IGEMM8", t)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append(m.flat_grads.detach().clone().cpu())
+        segs = m.grad_segments
+    errs = [l2err(grads[0][b:e], grads[1][b:e]) for b, e in segs]
+    assert errs[0] == 0.0 and errs[1] < 2e-3, f"fc / layer4.2: {errs[:2]}"
+    assert max(errs[:4]) < 2e-2, f"layer4: {errs[:4]}"
+    assert max(errs) < 0.3, f"per-segment drift {['%.1e' % x for x in errs]}"
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_baseline_batch_rule_selected_variants(dev, dtype, monkeypatch):
+    """BASELINE.json's batch (N = 256, 224 px), default environment: the kernel variants the launch rules pick only at
+    training size (bf16: the 8-wave 224x256 / 256x128 tiles, the 4-wave 256x256 / 256x128-3-stage / 128x64 tiles;
+    fp32: the stream-K tail; split-K plans of the weight gradients).
+      forward   teacher forced: conv outputs of layers that hit each variant, recomputed by the oracle from the executor's
+                own input on a subset of the images (a conv is per-image); BN statistics over the whole batch
+      loss      step-0 loss against the torch-CPU oracle's forward of the same batch
+      backward  the same backward with every rule switched to the small tiles (checked against the oracle at small N by
+                the tests above): fc exact, top block tight, gradual drift below"""
+    from sota_imagenet_amd.losses import CrossEntropyLoss
+
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    tol = 2e-5 if dtype == "fp32" else 2e-2
+    N, S = 256, 224
+    key = (N, S, S)
+    m, sd = build(dtype)
+    data, target = synthetic_batch(N, S, seed=0, index=0)
+    m.train()
+    crit = CrossEntropyLoss(smoothing=0.1).cuda()
+    out = m(data.cuda())
+    loss = crit(out, target.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    g_rule = m.flat_grads.detach().clone().cpu()
+    P = {k: v.float() for k, v in sd.items()}
+    T = lambda name: m.debug_tensor(key, name)
+    q = lambda t: t.to(tdt).float()
+    img = [0, 1, 100, 255]
+    # (conv, its input tensor, stride, pad): 3x3 of every stage (layer1: 128x64 tile; layer2: 128x128; layer3: 224x256;
+    # layer4: 256x128 fat), long 1x1s (layer3/4 conv1, conv3: 224x256), a stride-2 3x3 and a stride-2 downsample
+    checks = [("layer1.1.conv2", "layer1.1.a1", 1, 1), ("layer2.2.conv2", "layer2.2.a1", 1, 1), ("layer3.3.conv2", "layer3.3.a1", 1, 1),
+              ("layer4.1.conv2", "layer4.1.a1", 1, 1), ("layer3.2.conv1", "layer3.1.out", 1, 0), ("layer3.4.conv3", "layer3.4.a2", 1, 0),
+              ("layer4.2.conv1", "layer4.1.out", 1, 0), ("layer4.2.conv3", "layer4.2.a2", 1, 0), ("layer3.0.conv2", "layer3.0.a1", 2, 1),
+              ("layer4.0.downsample.0", "layer3.5.out", 2, 0), ("layer2.0.conv1", "layer1.2.out", 1, 0)]
+    for conv, src, stride, pad in checks:
+        x = T(src)[img].float().cpu()
+        y = T(conv + ".y").float().cpu()
+        w = q(R.oihw_to_krsc(P[conv + ".weight"]))
+        assert nerr(y[img], R.conv2d_fwd(x, w, stride, pad)) < tol, conv
+        bn = conv.replace("conv", "bn") if "downsample" not in conv else conv.replace("downsample.0", "downsample.1")
+        y2 = y.reshape(-1, y.shape[-1]).double()
+        mean, var = y2.mean(0), y2.var(0, unbiased=False)
+        assert nerr(T(bn + ".save_mean").cpu(), mean.float()) < 1e-4, bn
+        assert nerr(T(bn + ".save_invstd").cpu(), (var + 1e-5).rsqrt().float()) < 1e-4, bn
+    # step-0 loss against the oracle's own forward (fp32: tight; bf16: the stored-activation rounding, 2e-2 as elsewhere)
+    ref = O.make_reference(sd)
+    ref.train()
+    with torch.no_grad():
+        loss_ref = O.smooth_ce(ref(data), target, 0.1).item()
+    assert abs(loss.item() - loss_ref) < (1e-4 if dtype == "fp32" else 2e-2) * loss_ref, (loss.item(), loss_ref)
+    # backward: rule-selected variants against the small tiles.  bf16: the tile rules are read per launch, so the SAME
+    # model repeats the forward (rule tiles, identical saved activations) and only the backward switches.  fp32: stream-K
+    # is a property of the executor, so a second model runs the whole step without it (forward differs by fp32 summation
+    # order only; bounds as in test_fp32_stream_k_tail_matches_whole_tiles).
+    if dtype == "bf16":
+        m.mark_grads_clean()
+        loss2 = crit(m(data.cuda()), target.cuda())
+        assert loss2.item() == loss.item()
+        monkeypatch.setenv("MI355_IGEMM8", "0")
+        monkeypatch.setenv("MI355_IGEMM_BIG", "0")
+        loss2.backward()
+        torch.cuda.synchronize()
+        g_small = m.flat_grads.detach().clone().cpu()
+        top, l4 = 2e-3, 2e-2
+    else:
+        monkeypatch.setenv("MI355_STREAM_K", "0")
+        m2, _ = build(dtype)
+        m2.train()
+        loss2 = crit(m2(data.cuda()), target.cuda())
+        loss2.backward()
+        torch.cuda.synchronize()
+        assert abs(loss2.item() - loss.item()) < 1e-5 * abs(loss.item())
+        g_small = m2.flat_grads.detach().clone().cpu()
+        top, l4 = 1e-4, 5e-2
+    errs = [l2err(g_rule[b:e], g_small[b:e]) for b, e in m.grad_segments]
+    assert errs[0] < top and max(errs[:4]) < l4, f"fc / layer4: {errs[:4]}"
     assert max(errs) < 0.3, f"per-segment drift {['%.1e' % x for x in errs]}"
 
 
