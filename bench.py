@@ -29,7 +29,8 @@ PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2516.6}  # MI355X_MICROARCH.md: dense MFMA
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 HBM_CLASS = 7  # executor profile class of bn_bwd_apply_kernel, the largest HBM-bound kernel of the step
 # profile class -> kernel symbols (template instances of one source; names as tools/pmc_traffic.py writes them)
-KERNEL_NAMES = {0: ["igemm_kernel<{T},128,128>", "igemm_kernel<{T},256,256>", "igemm_kernel<{T},256,128>"], 1: ["igemm_kernel<{T},128,64>"],
+KERNEL_NAMES = {0: ["igemm_kernel<{T},128,128>", "igemm_kernel<{T},256,256>", "igemm_kernel<{T},256,128>", "igemm8_kernel<224,256>", "igemm8_kernel<256,128>"],
+                1: ["igemm_kernel<{T},128,64>"],
                 2: ["wgrad_kernel<{T},128,128>", "wgrad_kernel<{T},128,64>"], 3: ["wgrad_kernel<{T},64,128>", "wgrad_kernel<{T},64,64>"]}
 
 
@@ -51,8 +52,11 @@ def pmc_traffic(kernels, dtype, batch, size):
     return int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in recs) / n) if n else None
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """oracle train step (fwd + CE + bwd + SGD) on the host cores; bounded sample of the same workload."""
+def cpu_baseline():
+    """BASELINE.md §3 protocol: the oracle's train step (fwd + CE + bwd + SGD) and its forward alone on the host cores,
+    BASELINE.json configs[0] (bs 32, fp32, 224 px): 3 warm-up + 10 timed steps each, median; threads printed."""
+    import statistics
+
     from oracle import resnet50_ref as O
     from sota_imagenet_amd.synth import init_state_dict, synthetic_batch
 
@@ -76,17 +80,26 @@ def cpu_baseline(seconds_budget=25.0):
         loss.backward()
         opt.step()
 
-    step()  # warm-up
-    t0 = time.time()
-    n = 0
-    while True:
-        step()
-        n += 1
-        el = time.time() - t0
-        if n >= 2 and (el > seconds_budget or n >= 10):
-            break
-    return {"value": round(n * bs / el, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} fp32 train steps of bs={bs} @224px (BASELINE configs[0]) with the torch-CPU oracle"}
+    def fwd():
+        with torch.no_grad():
+            O.smooth_ce(ref(batch[0]), batch[1], 0.1)
+
+    def timed(fn, warm=3, n=10):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+
+    t_train = timed(step)
+    t_fwd = timed(fwd)
+    return {"value": round(bs / t_train, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "forward_only_value": round(bs / t_fwd, 2),
+            "sample": f"median of 10 (after 3 warm-up) fp32 train steps of bs={bs} @224px (BASELINE configs[0]) with the torch-CPU "
+                      f"oracle; forward_only_value: the same for the forward + loss alone"}
 
 
 def main():
@@ -140,7 +153,7 @@ def main():
             from sota_imagenet_amd.parallel import FlatBucketDDP
 
             net = FlatBucketDDP(model, device_ids=[local_rank])
-        pool = [synthetic_batch(N, S, seed=0, stream=rank, index=i, device="cuda") for i in range(4)]
+        pool = [synthetic_batch(N, S, seed=0, stream=rank, index=i, device="cuda") for i in range(8)]  # a pool of 8
         model.train()
 
         def step(i):
@@ -185,43 +198,63 @@ def main():
     want_roof = (not args.no_roofline) and rank == 0
     dt, final_loss, model, dom = run(args.dtype, args.steps, args.warmup, want_roof)
 
+    def roof_of(model, dom, dtype):
+        """(roofline, roofline_hbm) dicts from the HIP events recorded in the last timed steps of `model`"""
+        roof = roof_hbm = None
+        tot_ms, launches, flops, nbytes = model.profile_read(shape, dom)
+        tdt = "float" if dtype == "fp32" else "__bf16"
+        if launches:
+            ach = flops / (tot_ms * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[dtype]
+            knames = [n.format(T=tdt) for n in KERNEL_NAMES[dom]]
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": pmc_traffic(knames, dtype, N, S), "kernel": " + ".join(knames),
+                    "launches": launches, "avg_launch_ms": round(tot_ms / launches, 4),
+                    "alg_gflop_per_launch": round(flops / launches / 1e9, 3),
+                    "alg_bytes_per_launch": int(nbytes / launches),
+                    "event_steps": min(4, args.steps),
+                    "note": "timed with the weight-gradient side stream active: kernels of the two streams share the CUs, "
+                            "so a launch takes longer than it does alone (serial_frac: same kernels, side stream off)"}
+        t_ms, n_l, _, nbytes = model.profile_read(shape, HBM_CLASS)
+        if n_l:
+            gbs = nbytes / (t_ms * 1e-3) / 1e9
+            roof_hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": pmc_traffic([f"bn_bwd_apply_kernel<{tdt}>"], dtype, N, S),
+                        "kernel": f"bn_bwd_apply_kernel<{tdt}>", "launches": n_l, "avg_launch_ms": round(t_ms / n_l, 4),
+                        "alg_bytes_per_launch": int(nbytes / n_l)}
+        # BASELINE's conv target is quoted on the 3x3 convolutions: the same events, restricted to those launches
+        t_ms, n_l, fl3, _ = model.profile_read(shape, 8)
+        if n_l and roof is not None:
+            roof["conv3x3"] = {"achieved": round(fl3 / (t_ms * 1e-3) / 1e12, 2), "frac": round(fl3 / (t_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 4),
+                               "launches": n_l, "avg_launch_ms": round(t_ms / n_l, 4)}
+        model.profile(shape, 0)
+        return roof, roof_hbm
+
+    def add_serial(roof, roof_class, dtype, steps):
+        """the same kernel class with every kernel on one stream (MI355_WGRAD_STREAM=0), untimed extra steps"""
+        os.environ["MI355_WGRAD_STREAM"] = "0"
+        try:
+            _, _, ms_, dom_s = run(dtype, steps, 2, True)
+            t_ms, n_l, fl, _ = ms_.profile_read(shape, dom_s)
+            t3, n3, fl3, _ = ms_.profile_read(shape, 8)
+            ms_.profile(shape, 0)
+            if n_l and dom_s == roof_class:
+                roof["serial_frac"] = round(fl / (t_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 4)
+                roof["serial_avg_launch_ms"] = round(t_ms / n_l, 4)
+            if n3 and "conv3x3" in roof:
+                roof["conv3x3"]["serial_frac"] = round(fl3 / (t3 * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 4)
+            del ms_
+        finally:
+            del os.environ["MI355_WGRAD_STREAM"]
+        torch.cuda.empty_cache()
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * N * args.steps / dt
-        roof = None
+        roof = roof_hbm = None
         roof_class = dom
         if want_roof:
-            tot_ms, launches, flops, nbytes = model.profile_read(shape, dom)
-            best = (dom, tot_ms, launches, flops, nbytes) if launches else None
-            if best:
-                k, tot_ms, launches, flops, nbytes = best
-                ach = flops / (tot_ms * 1e-3) / 1e12
-                peak = PEAK_TFLOPS[args.dtype]
-                knames = [n.format(T="float" if args.dtype == "fp32" else "__bf16") for n in KERNEL_NAMES[k]]
-                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": pmc_traffic(knames, args.dtype, N, S), "kernel": " + ".join(knames),
-                        "launches": launches, "avg_launch_ms": round(tot_ms / launches, 4),
-                        "alg_gflop_per_launch": round(flops / launches / 1e9, 3),
-                        "alg_bytes_per_launch": int(nbytes / launches),
-                        "event_steps": min(4, args.steps),
-                        "note": "timed with the weight-gradient side stream active: kernels of the two streams share the CUs, "
-                                "so a launch takes longer than it does alone (serial_frac: same kernels, side stream off)"}
-        roof_hbm = None
-        if want_roof:
-            t_ms, n_l, _, nbytes = model.profile_read(shape, HBM_CLASS)
-            if n_l:
-                gbs = nbytes / (t_ms * 1e-3) / 1e9
-                tdt = "float" if args.dtype == "fp32" else "__bf16"
-                roof_hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": pmc_traffic([f"bn_bwd_apply_kernel<{tdt}>"], args.dtype, N, S),
-                            "kernel": f"bn_bwd_apply_kernel<{tdt}>", "launches": n_l, "avg_launch_ms": round(t_ms / n_l, 4),
-                            "alg_bytes_per_launch": int(nbytes / n_l)}
-            # BASELINE's conv target is quoted on the 3x3 convolutions: the same events, restricted to those launches
-            t_ms, n_l, fl3, _ = model.profile_read(shape, 8)
-            if n_l and roof is not None:
-                roof["conv3x3"] = {"achieved": round(fl3 / (t_ms * 1e-3) / 1e12, 2), "frac": round(fl3 / (t_ms * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4),
-                                   "launches": n_l, "avg_launch_ms": round(t_ms / n_l, 4)}
-            model.profile(shape, 0)
+            roof, roof_hbm = roof_of(model, dom, args.dtype)
         _, train_flops = model.flops(N, S, S)
         out = {
             "metric": "images/sec (whole node) ResNet-50 bs=256/GPU @224px",
@@ -236,34 +269,29 @@ def main():
             "roofline_hbm": roof_hbm,
         }
         if roof is not None and world == 1 and not use_ddp:
-            # the same kernel class with every kernel on one stream (MI355_WGRAD_STREAM=0), untimed extra steps
             del model
             torch.cuda.empty_cache()
-            os.environ["MI355_WGRAD_STREAM"] = "0"
-            try:
-                _, _, ms_, dom_s = run(args.dtype, max(3, args.steps // 4), 2, True)
-                t_ms, n_l, fl, _ = ms_.profile_read(shape, dom_s)
-                t3, n3, fl3, _ = ms_.profile_read(shape, 8)
-                ms_.profile(shape, 0)
-                if n_l and dom_s == roof_class:
-                    roof["serial_frac"] = round(fl / (t_ms * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4)
-                    roof["serial_avg_launch_ms"] = round(t_ms / n_l, 4)
-                if n3 and "conv3x3" in roof:
-                    roof["conv3x3"]["serial_frac"] = round(fl3 / (t3 * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4)
-                del ms_
-            finally:
-                del os.environ["MI355_WGRAD_STREAM"]
+            add_serial(roof, roof_class, args.dtype, max(3, args.steps // 4))
             model = None
         if world == 1 and not use_ddp and args.dtype == "bf16" and not args.no_secondary:
-            # BASELINE.json configs[1] (fp32, single MI355X) measured in the same process, for reference next to `value`
+            # BASELINE.json configs[1] (fp32, single MI355X) measured in the same process, with its own roofline
             model = None
             torch.cuda.empty_cache()
-            dt2, loss2, m2, _ = run("fp32", max(3, args.steps // 4), 2, False)
-            k2 = max(3, args.steps // 4)
+            k2 = max(4, args.steps // 4)
+            dt2, loss2, m2, dom2 = run("fp32", k2, 2, want_roof)
             out["secondary"] = {"dtype": "fp32", "workload": "BASELINE configs[1]: ResNet-50 fp32 single MI355X bs=256 224px",
                                 "value": round(N * k2 / dt2, 1), "unit": "images/sec", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 3),
                                 "final_loss": round(loss2, 4)}
-            del m2
+            if want_roof:
+                r2, h2 = roof_of(m2, dom2, "fp32")
+                del m2
+                torch.cuda.empty_cache()
+                if r2 is not None:
+                    add_serial(r2, dom2, "fp32", 3)
+                out["secondary"]["roofline"] = r2
+                out["secondary"]["roofline_hbm"] = h2
+            else:
+                del m2
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -172,7 +172,11 @@ int mi355_resnet50_bind(mi355_ctx* ctx, float* params, float* grads, float* buff
  * Streams: the dependent kernel chain is issued to `stream`; independent work (weight gradients, the
  * downsample branch) goes to a side stream the ctx owns, forked from / joined to `stream` with events, so
  * on return everything is ordered on `stream` as if it had run there (MI355_WGRAD_STREAM=0 in the
- * environment at create time keeps every kernel on `stream`).  Results are bit-identical either way.   */
+ * environment at create time keeps every kernel on `stream`).  Results are bit-identical either way.
+ * fp32 contexts cut the tiles of a partial last round along K across workgroups (stream-K, bounded spins).  Should a
+ * hand-off ever time out, the kernel raises an error word that is copied to pinned host memory behind the kernels
+ * of the call (no host wait): forward / backward / profile_read of that context then fail with MI355_E_STATE from
+ * the first call that finds it set — at the latest the call after the next host-device synchronisation.          */
 int mi355_resnet50_forward(mi355_ctx* ctx, const float* x_nchw, float* logits, int training,
                            float bn_momentum, void* stream);
 

@@ -110,6 +110,8 @@ struct WgradArgs {
 // stat_rows (optional): number of partial rows written to a.stat_partial, 0 if the statistics were not produced
 int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows = nullptr);
 static constexpr size_t IGEMM_SK_FLAG_BYTES = 4096;  // 512 flags + an error word, padded
+static constexpr int IGEMM_SK_ERR_WORD = 512;        // index of the error word in the flag block: nonzero = a stream-K
+                                                     // hand-off timed out in some launch that used this scratch
 size_t igemm_sk_ws_bytes();
 // splits chosen by plan_wgrad_splits(); partial must hold splits*Cout*wtaps*Ck floats
 int plan_wgrad_splits(int dtype, int M, int Cout, int ntaps, int Ck);

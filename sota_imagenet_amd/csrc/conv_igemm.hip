@@ -73,7 +73,9 @@ struct IgemmKArgs {
                                          // is cut into at most ~4 parts, each hand-off costs its owner ~10 us)
   unsigned sk_epoch;
   float* sk_partial;
-  unsigned* sk_flags;
+  unsigned* sk_flags;       // [G] epoch flags, then the error word at index IGEMM_SK_ERR_WORD (read by the executor)
+  unsigned sk_spin_limit;   // polls before an owner gives up on a hand-off and raises the error word
+  int sk_mute;              // debug (MI355_SK_DEBUG=mute): contributors never publish, so every owner times out
 };
 
 // BM x BN tile, WMW x 2 waves (a wave owns BM/WMW x BN/2 outputs), NSTG-stage LDS ring:
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(128 * WMW, (BM == 256 ? 1 : (BN == 64 && NSTG == 2 
               }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
-          if (tid == 0)
+          if (tid == 0 && !kp.sk_mute)
             __hip_atomic_store(kp.sk_flags + blockIdx.x, kp.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           pending_st = 0;
           continue;  // no epilogue for this unit
@@ -448,8 +450,9 @@ __global__ __launch_bounds__(128 * WMW, (BM == 256 ? 1 : (BN == 64 && NSTG == 2 
               unsigned spins = 0;
               while (__hip_atomic_load(kp.sk_flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kp.sk_epoch) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 24)) {  // never on a healthy run; do not hang the device
-                  __hip_atomic_store(kp.sk_flags + G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++spins > kp.sk_spin_limit) {  // never on a healthy run; do not hang the device.  The tile is then
+                  // completed WITHOUT that partial, i.e. wrong: the error word makes the executor fail the step
+                  __hip_atomic_store(kp.sk_flags + IGEMM_SK_ERR_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   break;
                 }
               }
@@ -706,6 +709,12 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
   k.sk_epoch = 0;
   k.sk_partial = nullptr;
   k.sk_flags = nullptr;
+  static const bool sk_mute = [] {
+    const char* e = getenv("MI355_SK_DEBUG");
+    return e && strcmp(e, "mute") == 0;
+  }();
+  k.sk_mute = sk_mute ? 1 : 0;
+  k.sk_spin_limit = sk_mute ? (1u << 8) : (1u << 24);
   bool sk = false;
   // (fp32 only: a hand-off costs the owner ~10 us, nothing beside a 150-300 us fp32 tile, but most of what the cut
   // saves on a 30-60 us bf16 tile — measured)

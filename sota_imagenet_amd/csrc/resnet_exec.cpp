@@ -99,6 +99,8 @@ struct mi355_ctx {
   float *bn_partial2 = nullptr, *bn_coef2 = nullptr;  // the same for BN work issued to the side stream
   void* sk_ws[2] = {nullptr, nullptr};                // stream-K scratch of the conv kernel, main / side stream
   bool stream_k = true;
+  unsigned* sk_err_host = nullptr;  // pinned copy of the two scratch blocks' error words, refreshed by an async copy at the
+                                    // end of every forward / backward call and looked at (no wait) at the start of the next
   PrepDesc* prep_table[2] = {nullptr, nullptr};  // [0]: cast only (inference), [1]: cast + transposed (training)
   int prep_layers = 0, prep_tiles = 0;
   // backward gradients: gG[2] carry the gradient wrt a block output down the network; gset[p] holds the per-layer
@@ -421,6 +423,25 @@ int join(mi355_ctx* c, hipStream_t s) {
   return 0;
 }
 
+// stream-K (fp32 conv): a hand-off that timed out leaves a wrong tile behind; the kernel raises an error word, which is
+// copied to pinned host memory behind the kernels of a call and checked at the start of the following calls
+int sk_check(mi355_ctx* c) {
+  if (c->sk_err_host && (c->sk_err_host[0] | c->sk_err_host[1])) {
+    set_error("a stream-K hand-off of an earlier convolution launch timed out (partial tile lost): the results of that "
+              "step are invalid; recreate the context (MI355_STREAM_K=0 disables the tile cutting)");
+    return MI355_E_STATE;
+  }
+  return 0;
+}
+int sk_snapshot(mi355_ctx* c, hipStream_t s) {
+  if (!c->sk_err_host || !c->stream_k) return 0;
+  for (int i = 0; i < 2; ++i)
+    if (c->sk_ws[i])
+      MI355_HIP(hipMemcpyAsync(c->sk_err_host + i, reinterpret_cast<unsigned*>(c->sk_ws[i]) + IGEMM_SK_ERR_WORD, sizeof(unsigned),
+                               hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
 int backward_fc(mi355_ctx* c, const float* dlogits, float beta_acc, hipStream_t s) {
   const int N = c->N, O = c->num_classes, P = c->fc_pad;
   MI355_TRY(launch_pad_dlogits(dlogits, c->dlogits_pad, P, c->grads + c->fc_b_off, beta_acc, N, O, s));
@@ -638,6 +659,14 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
   // weight-gradient side stream (MI355_WGRAD_STREAM=0 keeps everything on the caller's stream)
   const char* skv = getenv("MI355_STREAM_K");
   c->stream_k = !(skv && skv[0] == '0');
+  if (c->stream_k && dtype == MI355_F32) {
+    if (hipHostMalloc((void**)&c->sk_err_host, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
+      set_error("create: hipHostMalloc -> %s", hipGetErrorString(hipGetLastError()));
+      mi355_resnet50_destroy(c);
+      return MI355_E_HIP;
+    }
+    c->sk_err_host[0] = c->sk_err_host[1] = 0;
+  }
   const char* fb = getenv("MI355_FUSE_BN_BWD");
   // measured same-box: -0.6 ms/step in bf16, +0.9 ms in fp32 (the fp32 epilogue is already register-heavy)
   c->fuse_bn_bwd = fb ? fb[0] != '0' : dtype == MI355_BF16;
@@ -675,6 +704,7 @@ int mi355_resnet50_destroy(mi355_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   if (c->ds_done) (void)hipEventDestroy(c->ds_done);
   if (c->wstream) (void)hipStreamDestroy(c->wstream);
+  if (c->sk_err_host) (void)hipHostFree(c->sk_err_host);
   if (c->arena) (void)hipFree(c->arena);
   delete c;
   return 0;
@@ -723,6 +753,7 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
   }
   hipStream_t s = (hipStream_t)stream;
   const int N = c->N;
+  MI355_TRY(sk_check(c));
   c->fwd_training_done = false;
   for (auto& b : c->blocks) b.c1.bwd_rows = b.c2.bwd_rows = b.c3.bwd_rows = b.ds.bwd_rows = 0;
   MI355_TRY(weight_prep_all(c, training != 0, s));
@@ -782,7 +813,7 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
   }
   c->fwd_training_done = training != 0;
   c->next_seg = 0;
-  return 0;
+  return sk_snapshot(c, s);
 }
 
 int mi355_resnet50_num_segments(const mi355_ctx* c) { return c ? (int)c->blocks.size() + 2 : 0; }
@@ -819,6 +850,7 @@ int mi355_resnet50_backward(mi355_ctx* c, const float* dlogits, int seg_begin, i
     return MI355_E_STATE;
   }
   hipStream_t s = (hipStream_t)stream;
+  MI355_TRY(sk_check(c));
   const float beta_acc = accumulate ? 1.f : 0.f;
   const int nb = (int)c->blocks.size();
   for (int seg = seg_begin; seg < seg_end; ++seg) {
@@ -834,7 +866,7 @@ int mi355_resnet50_backward(mi355_ctx* c, const float* dlogits, int seg_begin, i
   }
   MI355_TRY(join(c, s));
   if (c->next_seg == nseg) c->fwd_training_done = false;
-  return 0;
+  return sk_snapshot(c, s);
 }
 
 int mi355_resnet50_debug_tensor(const mi355_ctx* c, const char* name, void** ptr, int* dtype, int* ndim,
@@ -912,6 +944,7 @@ int mi355_resnet50_profile_read(mi355_ctx* c, int kind, double* total_ms, int* l
     ms += t; fl += c->recs[i].flops; by += c->recs[i].bytes;
     ++n;
   }
+  MI355_TRY(sk_check(c));
   if (total_ms) *total_ms = ms;
   if (launches) *launches = n;
   if (alg_flops) *alg_flops = fl;

@@ -175,11 +175,29 @@ class ResNet50(nn.Module):
                 leaf._buffers[attr] = self._view(self._flat_buffers, off, shape)
 
     def _attach_grads(self):
+        """(re)binds every parameter's .grad to its slice of the flat gradient array.  A gradient that was set to None
+        since the last backward — model.zero_grad(), any torch optimizer's zero_grad(set_to_none=True) — counts as
+        zeroed: if all are None the next backward overwrites, otherwise the stale slices of the None ones are cleared."""
+        none, total = [], 0
         for leaf, attr, kind, off, shape in self._entries:
             if kind == 0:
                 p = leaf._parameters[attr]
+                total += 1
+                if p.grad is None:
+                    none.append((off, shape))
                 if p.grad is None or p.grad.data_ptr() != self._flat_grads.data_ptr() + off * 4:
                     p.grad = self._view(self._flat_grads, off, shape)
+        if self._grads_dirty and none:
+            if len(none) == total:
+                self._grads_dirty = False
+            else:
+                for off, shape in none:
+                    self._view(self._flat_grads, off, shape).zero_()
+
+    def zero_grad(self, set_to_none=True):
+        """nn.Module.zero_grad: the flat gradient array is simply overwritten by the next backward."""
+        super().zero_grad(set_to_none=set_to_none)
+        self.mark_grads_clean()
 
     def _apply(self, fn, recurse=True):
         # move the flat arrays, then re-create the views; native contexts belong to the old device

@@ -40,8 +40,10 @@ class SGD(Optimizer):
         self.grad_scale = 1.0  # e.g. 1/world_size when gradients were summed, not averaged
 
     def attach_model(self, model):
-        """lets zero_grad() tell the model that the next backward may overwrite its flat gradients."""
+        """lets zero_grad() tell the model that the next backward may overwrite its flat gradients, and the range
+        planner see every tensor of the model (which gaps between updated parameters are padding)."""
         self._models.append(model)
+        self._plans = None
 
     # one plan per param group: list of (p_flat_slice, g_flat_slice, m_flat_slice)
     def _build_plans(self):
@@ -56,13 +58,29 @@ class SGD(Optimizer):
                 if rp is None or rg is None or rp[1:] != rg[1:]:
                     raise RuntimeError("SGD: parameter and gradient must be dense and share their flat offset")
                 entries.append((rp[0], rg[0], rp[1], rp[2], gi, p))
-        # walk ALL parameters in memory order; neighbours merge only when they belong to the same group, so a gap
-        # that is merged over can hold nothing but alignment / FC row padding (zeros stay zeros under the update)
+        # Neighbours of one group merge into one launch only when the gap between them is PROVABLY padding (zeros stay
+        # zeros under the update): every tensor of the attached models that this optimizer does not update in the same
+        # group — frozen parameters, parameters of another group, parameters without a gradient — acts as a barrier.
+        # Without an attached model nothing is known about a gap, so only the 64-element alignment padding is bridged.
         entries.sort(key=lambda r: (r[0], r[2]))
+        mine = {id(e[5]) for e in entries}
+        barriers = {}  # storage base -> sorted [(first elem, end elem)] of tensors that must not be swept up
+        for mdl in self._models:
+            for q in mdl.parameters():
+                if id(q) in mine:
+                    continue
+                r = _dense_range(q.data)
+                if r is not None:
+                    barriers.setdefault(r[0], []).append((r[1], r[1] + r[2]))
+        max_gap = 64 * 2048 if self._models else 64
+
+        def gap_is_padding(pb, lo, hi):
+            return 0 <= hi - lo < max_gap and not any(b < hi and e > lo for b, e in barriers.get(pb, ()))
+
         merged = []
         for pb, gb, off, n, gi, p in entries:
             m = merged[-1] if merged else None
-            if m and m[0] == pb and m[1] == gb and m[5] == gi and 0 <= off - m[3] < 64 * 2048:
+            if m and m[0] == pb and m[1] == gb and m[5] == gi and gap_is_padding(pb, m[3], off):
                 m[3] = off + n
                 m[4].append(p)
             else:
@@ -77,7 +95,11 @@ class SGD(Optimizer):
             fm = torch.zeros(e - b, dtype=torch.float32, device=dev)
             for p in ps:  # expose momentum buffers per parameter (state_dict compatibility)
                 r = _dense_range(p.data)
-                self.state[p]["momentum_buffer"] = torch.as_strided(fm, p.shape, p.stride(), r[1] - b)
+                view = torch.as_strided(fm, p.shape, p.stride(), r[1] - b)
+                old = self.state[p].get("momentum_buffer")
+                if old is not None:  # loaded from a checkpoint (train.py:144) or kept across a re-plan: carry it over
+                    view.copy_(old.to(device=dev, dtype=torch.float32))
+                self.state[p]["momentum_buffer"] = view
             plans[gi].append((fp, fg, fm))
         self._plans = plans
 
@@ -104,4 +126,10 @@ class SGD(Optimizer):
 
     def add_param_group(self, group):
         super().add_param_group(group)
+        self._plans = None
+
+    def load_state_dict(self, state_dict):
+        """torch's loader replaces self.state[p]['momentum_buffer'] by fresh tensors: re-plan at the next step, which
+        copies them into the flat momentum array the kernel reads (resume path, train.py:140-146)."""
+        super().load_state_dict(state_dict)
         self._plans = None

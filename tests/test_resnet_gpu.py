@@ -509,3 +509,32 @@ def test_fp32_stream_k_tail_matches_whole_tiles(dev):
     # and the run-to-run reproducibility claim holds with the hand-offs in play
     c = _train_steps("fp32", {"MI355_STREAM_K": "1"}, steps=1, N=64, S=224)
     assert torch.equal(a[0][0], c[0][0]) and torch.equal(a[1][0], c[1][0])
+
+
+def test_stream_k_timeout_is_reported(dev, monkeypatch):
+    """a stream-K hand-off that times out leaves a wrong tile behind; the kernel's error word must surface as an error of
+    the context (MI355_E_STATE -> RuntimeError), not as silently wrong fp32 results.  MI355_SK_DEBUG=mute (read once per
+    process, hence the subprocess) makes every contributor withhold its flag, so every owner runs into the spin bound."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import torch
+from sota_imagenet_amd.models import resnet50
+from sota_imagenet_amd.losses import CrossEntropyLoss
+from sota_imagenet_amd.synth import synthetic_batch
+m = resnet50(dtype="fp32").cuda()
+m.train()
+data, target = synthetic_batch(64, 224, seed=1, index=0, device="cuda")
+loss = CrossEntropyLoss(smoothing=0.1)(m(data), target)   # layer-3/4 convs: partial last rounds, cut along K
+torch.cuda.synchronize()
+try:
+    m(data)
+    print("NO ERROR")
+except RuntimeError as e:
+    print("RAISED", "stream-K" in str(e))
+"""
+    env = dict(os.environ, MI355_SK_DEBUG="mute", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert "RAISED True" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])

@@ -122,3 +122,99 @@ def test_runner_with_cutmix_mixup_soft_targets(dev):
     runner.fit(Loader(), epochs=1)
     assert runner.state.train_loss.avg == runner.state.train_loss.avg  # finite
     assert not torch.equal(before, m.flat_params)
+
+
+def _tiny_steps(m, opt, idxs, N=4, S=64):
+    from sota_imagenet_amd.losses import CrossEntropyLoss
+    from sota_imagenet_amd.synth import synthetic_batch
+
+    crit = CrossEntropyLoss(smoothing=0.1)
+    m.train()
+    for i in idxs:
+        data, target = synthetic_batch(N, S, seed=21, index=i, device="cuda")
+        loss = crit(m(data), target)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+
+def test_sgd_resume_restores_momentum_bitwise(dev):
+    """train.py:140-146 resume: after load_state_dict the next step must equal the uninterrupted run bit for bit (the
+    loaded momentum buffers have to reach the flat momentum array the fused kernel reads)."""
+    import copy
+
+    from sota_imagenet_amd.models import resnet50
+    from sota_imagenet_amd.optim import SGD
+
+    def make():
+        m = resnet50(dtype="fp32").cuda()
+        opt = SGD([{"params": list(m.parameters())}], lr=0.05, momentum=0.9, weight_decay=3e-5)
+        opt.attach_model(m)
+        return m, opt
+
+    m, opt = make()
+    _tiny_steps(m, opt, [0, 1])
+    ck = {"state_dict": copy.deepcopy(m.state_dict()), "optimizer": copy.deepcopy(opt.state_dict())}
+    _tiny_steps(m, opt, [2])
+    want = m.flat_params.clone()
+    m2, opt2 = make()
+    m2.load_state_dict(ck["state_dict"])
+    opt2.load_state_dict(ck["optimizer"])
+    _tiny_steps(m2, opt2, [2])
+    assert torch.equal(m2.flat_params, want)
+    # and without the optimizer state the step differs (the momentum term is not negligible at this lr)
+    m3, opt3 = make()
+    m3.load_state_dict(ck["state_dict"])
+    _tiny_steps(m3, opt3, [2])
+    assert not torch.equal(m3.flat_params, want)
+
+
+def test_stock_torch_optimizer_and_module_zero_grad(dev):
+    """the `_target_` schema allows any torch optimizer: grads set to None by model.zero_grad() / a stock optimizer's
+    zero_grad(set_to_none=True) count as zeroed — the next backward must overwrite, not accumulate."""
+    from sota_imagenet_amd.losses import CrossEntropyLoss
+    from sota_imagenet_amd.models import resnet50
+    from sota_imagenet_amd.optim import SGD
+    from sota_imagenet_amd.synth import synthetic_batch
+
+    ma = resnet50(dtype="fp32").cuda()
+    mb = resnet50(dtype="fp32").cuda()
+    oa = SGD([{"params": list(ma.parameters())}], lr=0.01, momentum=0.9, weight_decay=3e-5)
+    oa.attach_model(ma)
+    ob = torch.optim.SGD(mb.parameters(), lr=0.01, momentum=0.9, weight_decay=3e-5)
+    crit = CrossEntropyLoss(smoothing=0.1)
+    ma.train(), mb.train()
+    for i in range(3):
+        data, target = synthetic_batch(4, 64, seed=22, index=i, device="cuda")
+        la = crit(ma(data), target)
+        oa.zero_grad()
+        la.backward()
+        oa.step()
+        lb = crit(mb(data), target)
+        if i % 2:
+            mb.zero_grad()  # nn.Module.zero_grad: set_to_none=True
+        else:
+            ob.zero_grad(set_to_none=True)
+        lb.backward()
+        assert torch.equal(ma.flat_grads, mb.flat_grads), f"step {i}: gradients accumulated instead of being overwritten"
+        ob.step()
+    err = ((ma.flat_params - mb.flat_params).abs().max() / ma.flat_params.abs().max()).item()
+    assert err < 1e-6, err
+
+
+def test_sgd_leaves_frozen_parameters_alone(dev):
+    """train.py:44 filters requires_grad=False parameters out of the optimizer: their slice of the flat array sits
+    between updated neighbours and must not be swept into a merged range."""
+    from sota_imagenet_amd.models import resnet50
+    from sota_imagenet_amd.optim import SGD
+
+    m = resnet50(dtype="fp32").cuda()
+    frozen = dict(m.named_parameters())["layer3.2.bn2.weight"]
+    frozen.requires_grad_(False)
+    opt = SGD([{"params": [p for p in m.parameters() if p.requires_grad]}], lr=0.05, momentum=0.9, weight_decay=1e-2)
+    opt.attach_model(m)
+    before = frozen.detach().clone()
+    other = dict(m.named_parameters())["layer3.2.bn2.bias"].detach().clone()
+    _tiny_steps(m, opt, [0, 1])
+    assert torch.equal(frozen.detach(), before)
+    assert not torch.equal(dict(m.named_parameters())["layer3.2.bn2.bias"].detach(), other)

@@ -19,17 +19,17 @@ import sys
 
 
 def short(n):
-    m = re.search(r"(igemm_kernel|wgrad_kernel|bn_reduce_kernel|bn_apply_kernel|bn_bwd_apply_kernel|bn_finalize_kernel|"
+    m = re.search(r"(igemm8_kernel|igemm_kernel|wgrad_kernel|bn_reduce_kernel|bn_apply_kernel|bn_bwd_apply_kernel|bn_finalize_kernel|"
                   r"splitk_reduce_kernel|sgd_kernel|maxpool_\w+_kernel|gap_\w+_kernel|stem_ingest_kernel|weight_prep_batch_kernel|weight_prep_kernel)", n)
     if not m:
         return None
     base = m.group(1)
     # keep the element type and the tile shape; drop the epilogue / mask variant parameters (one kernel source each)
-    keep = {"igemm_kernel": 3, "wgrad_kernel": 3}.get(base, 1)
+    keep = {"igemm_kernel": 3, "wgrad_kernel": 3, "igemm8_kernel": 2}.get(base, 1)
     if "bool _Accum" in n:  # rocprofv3's demangler garbles <__bf16, ...>
         rest = re.search(base + r"<bool _Accum, (.*)>", n)
         nums = re.findall(r"\d+", rest.group(1)) if rest else []
-        return f"{base}<{','.join(['__bf16'] + nums[:keep - 1])}>"
+        return f"{base}<{','.join(['__bf16'] + nums[:keep - 1])}>" if base != "igemm8_kernel" else f"{base}<{','.join(nums[:keep])}>"
     if "<" in n:  # demangled
         t = re.search(base + r"<([^>]*)>", n)
         args = [a.strip() for a in t.group(1).split(",")] if t else []
