@@ -803,9 +803,15 @@ static bool choose_igemm8(const IgemmArgs& a, int nclass, int* bm, int* bn, int*
   for (int ci = 0; ci < nclass; ++ci) max_taps = a.cls[ci].ntaps > max_taps ? a.cls[ci].ntaps : max_taps;
   const long K = (long)max_taps * a.Ck;
   const long M = (long)a.N * a.Hsub * a.Wsub;
-  if (a.Ncols % 256 == 0 && K >= 256 && igemm8_legal(a, nclass, 256)) {
+  //  - NOT the output-heavy launches: one workgroup per CU runs its epilogue with the matrix pipe idle, so a short
+  //    reduction under a long epilogue (conv1's dgrad: K = 256 / 512 into 1024 / 2048 columns, + shortcut addend + the
+  //    BN-backward sums) loses 10-65 us per launch against two independent 4-wave workgroups per CU, and so does a
+  //    multi-round launch of short tap classes (the stride-2 3x3 dgrad of layer 3) — measured in the executor,
+  //    profiles/r02a_conv_per_layer_bf16_serial_{old,rule}.txt.
+  const bool heavy_epilogue = (a.addend != nullptr && K < 1024);
+  if (a.Ncols % 256 == 0 && K >= 256 && !heavy_epilogue && igemm8_legal(a, nclass, 256)) {
     const long tiles = ((M + 223) / 224) * nclass * (a.Ncols / 256);
-    if (tiles >= 180) {
+    if (tiles >= 180 && !(nclass > 1 && tiles > 512 && max_taps > 1)) {
       *bm = 224; *bn = 256; *korder = 0; *fat = 0;
       return true;
     }

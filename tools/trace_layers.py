@@ -6,7 +6,7 @@ d = sys.argv[1]
 f = (glob.glob(d + "/*/*_kernel_trace.csv") + glob.glob(d + "/*_kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))  # valid for single-stream runs (MI355_WGRAD_STREAM=0)
-conv = [r for r in rows if "igemm_kernel" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"]]
+conv = [r for r in rows if "igemm_kernel" in r["Kernel_Name"] or "igemm8_kernel" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"]]
 # expected launch sequence of one training step (see csrc/resnet_exec.cpp)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 seq = []  # (kind, name, flops)
