@@ -140,6 +140,26 @@ int mi355_ce_loss(const float* logits, const float* target, float smoothing, flo
 int mi355_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float momentum,
                    float weight_decay, float grad_scale, void* stream);
 
+/* Mixup / CutMix with the previous batch, on the device (CutmixMixup — sota_imagenet/callbacks.py:232-247; the
+ * pytorch_tools Cutmix / Mixup bases it combines mix the batch with the PREVIOUS one under a random permutation).
+ *   mi355_mix_sample  draws one batch's decisions on the device from (seed, counter): apply at all (probability `prob`),
+ *                     CutMix or Mixup (coin, callbacks.py:242; `allow`: 1 Mixup only, 2 CutMix only, 3 both, 0 neither),
+ *                     lambda ~ Beta(alpha, alpha), the CutMix box, a permutation of the N <= 1024 samples; the result
+ *                     stays in `params` (mi355_mix_params_bytes(N) bytes of device memory: {int mode 0/1/2, float lambda,
+ *                     int y1, y2, x1, x2, float box_area_fraction, int pad, int perm[N]}) — no host round trip.
+ *   mi355_mix_apply   out / tout <- data[N,C,H,W] fp32 (the loader's NCHW batch) and target[N,classes] fp32 soft targets
+ *                     mixed with prev_in / tprev_in under perm (out may alias data, tout target: in place); the UNMIXED
+ *                     batch is stored to prev_out / tprev_out for the next step (double-buffered: pass the two buffers
+ *                     in alternating roles).
+ *                     Mixup: lambda*x + (1-lambda)*prev[perm]; CutMix: the box is pasted from prev[perm], the target
+ *                     weights are the real box area.  W and classes must be multiples of 4.                         */
+size_t mi355_mix_params_bytes(int N);
+int mi355_mix_sample(void* params, unsigned long long seed, unsigned long long counter, int N, int H, int W,
+                     float cutmix_alpha, float mixup_alpha, float prob, int allow, void* stream);
+int mi355_mix_apply(const float* data, float* out, const float* prev_in, float* prev_out, const float* target,
+                    float* tout, const float* tprev_in, float* tprev_out, const void* params, int N, int C, int H,
+                    int W, int num_classes, void* stream);
+
 /* ---- whole-network executor: torchvision-layout ResNet-50 v1.5 ----------------------------------
  * replaces hydra.utils.call(cfg.model) -> pytorch_tools.models.resnet50 (train.py:64,
  * configs/hydra_exp/1.r50_baseline.yaml:22-23) and everything autograd runs beneath it.            */
@@ -190,6 +210,37 @@ int mi355_resnet50_num_segments(const mi355_ctx* ctx);
 int mi355_resnet50_segment_range(const mi355_ctx* ctx, int seg, size_t* grad_begin, size_t* grad_end);
 int mi355_resnet50_backward(mi355_ctx* ctx, const float* dlogits, int seg_begin, int seg_end,
                             int accumulate, void* stream);
+
+/* ---- gradient collective inside the boundary: RCCL over xGMI, one process per GPU ---------------------------------
+ * replaces torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) — train.py:113-114, process group
+ * train.py:58-61 — i.e. the one-time rank-0 broadcast of parameters / buffers and the bucketed gradient MEAN all-reduce
+ * overlapped with backward.  RCCL is bound at run time (librccl.so.1); mi355_comm_available() says whether it was found.
+ *   bootstrap  rank 0 calls mi355_comm_unique_id(id) (MI355_COMM_ID_BYTES bytes) and hands `id` to the other ranks through
+ *              the launcher's own channel (the reference has one: init_process_group("nccl", "env://"), train.py:61);
+ *              every rank then calls mi355_comm_create(&comm, id, nranks, rank, device) (collective: ncclCommInitRank).
+ *   data path  mi355_resnet50_set_comm(ctx, comm, bucket_cap_mb): consecutive backward segments form buckets of at least
+ *              bucket_cap_mb MiB of the flat gradient array; mi355_resnet50_backward then launches, when a bucket's last
+ *              segment has been enqueued, ONE mean all-reduce over the bucket's contiguous slice on a HIP stream the
+ *              communicator owns, ordered by events behind the kernels that produce it (both executor streams), and makes
+ *              `stream` wait for the last one before it returns — so ONE backward call covers all segments, the collective
+ *              overlaps the rest of backward, and the caller's next kernel (the optimizer step) sees reduced gradients.
+ *              No host thread, no host wait.  comm == NULL detaches.  mi355_resnet50_bucket_plan reports the buckets a
+ *              cap would produce (works on a layout-only ctx; n_out = number of buckets, arrays filled up to `cap`).
+ *   xGMI is point-to-point (7 links per GPU, ring collectives are per-link bound): keep buckets few and large.      */
+#define MI355_COMM_ID_BYTES 128
+typedef struct mi355_comm mi355_comm;
+int mi355_comm_available(void);
+int mi355_comm_unique_id(void* id_out);
+int mi355_comm_create(mi355_comm** out, const void* id, int nranks, int rank, int device);
+int mi355_comm_destroy(mi355_comm* comm);
+int mi355_comm_nranks(const mi355_comm* comm);
+/* in-place collectives on fp32 device arrays, enqueued on `stream` (construction-time broadcast of rank `root`'s
+ * parameters / BN buffers; a plain mean all-reduce for callers that keep their own schedule) */
+int mi355_comm_broadcast(mi355_comm* comm, float* buf, size_t n, int root, void* stream);
+int mi355_comm_allreduce_mean(mi355_comm* comm, float* buf, size_t n, void* stream);
+int mi355_resnet50_set_comm(mi355_ctx* ctx, mi355_comm* comm, double bucket_cap_mb);
+int mi355_resnet50_bucket_plan(const mi355_ctx* ctx, double bucket_cap_mb, int cap, int* n_out, size_t* begins,
+                               size_t* ends, int* last_segs);
 
 /* algorithmic work of the ctx's conv/FC kernels (2 FLOP/MAC, padding-free): forward and fwd+bwd */
 int mi355_resnet50_flops(const mi355_ctx* ctx, double* fwd_flops, double* train_flops);

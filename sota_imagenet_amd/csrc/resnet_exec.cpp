@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "comm.h"
 #include "common.h"
 
 namespace mi355 {
@@ -99,6 +100,15 @@ struct mi355_ctx {
   float *bn_partial2 = nullptr, *bn_coef2 = nullptr;  // the same for BN work issued to the side stream
   void* sk_ws[2] = {nullptr, nullptr};                // stream-K scratch of the conv kernel, main / side stream
   bool stream_k = true;
+  // gradient collective inside the boundary (comm.cpp): buckets of consecutive backward segments, each reduced by one
+  // mean all-reduce on the communicator's stream as soon as its last segment has been enqueued
+  mi355_comm* comm = nullptr;
+  struct Bucket {
+    size_t begin, end;
+    int last_seg;
+  };
+  std::vector<Bucket> buckets;
+  bool comm_dirty = false;  // an all-reduce of this backward call is in flight on the communicator's stream
   unsigned* sk_err_host = nullptr;  // pinned copy of the two scratch blocks' error words, refreshed by an async copy at the
                                     // end of every forward / backward call and looked at (no wait) at the start of the next
   PrepDesc* prep_table[2] = {nullptr, nullptr};  // [0]: cast only (inference), [1]: cast + transposed (training)
@@ -440,6 +450,38 @@ int sk_snapshot(mi355_ctx* c, hipStream_t s) {
       MI355_HIP(hipMemcpyAsync(c->sk_err_host + i, reinterpret_cast<unsigned*>(c->sk_ws[i]) + IGEMM_SK_ERR_WORD, sizeof(unsigned),
                                hipMemcpyDeviceToHost, s));
   return 0;
+}
+
+void seg_range(const mi355_ctx* c, int seg, size_t* b, size_t* e) {
+  const int nb = (int)c->blocks.size();
+  if (seg == 0) {
+    *b = c->fc_grad_begin; *e = c->fc_grad_end;
+  } else if (seg == nb + 1) {
+    *b = c->stem_grad_begin; *e = c->stem_grad_end;
+  } else {
+    const Block& blk = c->blocks[nb - seg];
+    *b = blk.grad_begin; *e = blk.grad_end;
+  }
+}
+// consecutive segments (backward completion order = ascending offsets) form buckets of >= cap_elems gradient elements
+std::vector<mi355_ctx::Bucket> plan_buckets(const mi355_ctx* c, size_t cap_elems) {
+  std::vector<mi355_ctx::Bucket> out;
+  const int nseg = (int)c->blocks.size() + 2;
+  bool open = false;
+  size_t start = 0;
+  for (int i = 0; i < nseg; ++i) {
+    size_t b, e;
+    seg_range(c, i, &b, &e);
+    if (!open) {
+      start = b;
+      open = true;
+    }
+    if (e - start >= cap_elems || i == nseg - 1) {
+      out.push_back({start, e, i});
+      open = false;
+    }
+  }
+  return out;
 }
 
 int backward_fc(mi355_ctx* c, const float* dlogits, float beta_acc, hipStream_t s) {
@@ -820,18 +862,34 @@ int mi355_resnet50_num_segments(const mi355_ctx* c) { return c ? (int)c->blocks.
 
 int mi355_resnet50_segment_range(const mi355_ctx* c, int seg, size_t* gb, size_t* ge) {
   MI355_ARG(c && seg >= 0 && seg < (int)c->blocks.size() + 2, "segment_range: bad segment %d", seg);
-  const int nb = (int)c->blocks.size();
   size_t b, e;
-  if (seg == 0) {
-    b = c->fc_grad_begin; e = c->fc_grad_end;
-  } else if (seg == nb + 1) {
-    b = c->stem_grad_begin; e = c->stem_grad_end;
-  } else {
-    const Block& blk = c->blocks[nb - seg];
-    b = blk.grad_begin; e = blk.grad_end;
-  }
+  seg_range(c, seg, &b, &e);
   if (gb) *gb = b;
   if (ge) *ge = e;
+  return 0;
+}
+
+int mi355_resnet50_bucket_plan(const mi355_ctx* c, double bucket_cap_mb, int cap, int* n_out, size_t* begins, size_t* ends,
+                               int* last_segs) {
+  MI355_ARG(c && n_out && bucket_cap_mb > 0, "bucket_plan: bad arguments");
+  const auto bk = plan_buckets(c, (size_t)(bucket_cap_mb * (1 << 20) / 4));
+  *n_out = (int)bk.size();
+  for (int i = 0; i < (int)bk.size() && i < cap; ++i) {
+    if (begins) begins[i] = bk[i].begin;
+    if (ends) ends[i] = bk[i].end;
+    if (last_segs) last_segs[i] = bk[i].last_seg;
+  }
+  return 0;
+}
+
+int mi355_resnet50_set_comm(mi355_ctx* c, mi355_comm* comm, double bucket_cap_mb) {
+  MI355_ARG(c && (comm == nullptr || bucket_cap_mb > 0), "set_comm: bad arguments");
+  if (c->device < 0) {
+    set_error("set_comm: layout-only ctx (created with device < 0)");
+    return MI355_E_STATE;
+  }
+  c->comm = comm;
+  c->buckets = comm ? plan_buckets(c, (size_t)(bucket_cap_mb * (1 << 20) / 4)) : std::vector<mi355_ctx::Bucket>();
   return 0;
 }
 
@@ -863,8 +921,18 @@ int mi355_resnet50_backward(mi355_ctx* c, const float* dlogits, int seg_begin, i
       MI355_TRY(backward_block(c, c->blocks[nb - seg], nb - seg > 0 ? &c->blocks[nb - seg - 1] : nullptr, beta_acc, s));
     }
     c->next_seg = seg + 1;
+    if (c->comm)
+      for (const auto& bk : c->buckets)
+        if (bk.last_seg == seg) {  // the bucket's producers are all enqueued (main + weight-gradient stream): reduce it
+          MI355_TRY(comm_allreduce_bucket(c->comm, c->grads, bk.begin, bk.end, s, c->overlap && c->w_dirty ? c->wstream : nullptr));
+          c->comm_dirty = true;
+        }
   }
   MI355_TRY(join(c, s));
+  if (c->comm && c->comm_dirty) {
+    MI355_TRY(comm_join(c->comm, s));
+    c->comm_dirty = false;
+  }
   if (c->next_seg == nseg) c->fwd_training_done = false;
   return sk_snapshot(c, s);
 }

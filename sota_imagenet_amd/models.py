@@ -98,6 +98,7 @@ class ResNet50(nn.Module):
         self._grads_dirty = False
         self._grad_sync = None  # set by parallel.FlatBucketDDP: callable(segment, begin, end)
         self._grad_sync_points = None  # optional set of segments the hook acts on (None: after every segment)
+        self._comm = None  # (mi355_comm*, bucket cap in MiB) once a native communicator is attached
         self._bn_leaves = []
         self._build_modules()
         self._rebind_views()
@@ -244,6 +245,27 @@ class ResNet50(nn.Module):
         """[(begin, end)] element ranges of the flat gradient array, in backward completion order."""
         return list(self._segments)
 
+    def set_comm(self, comm, bucket_cap_mb=32.0):
+        """attaches a native RCCL communicator (mi355_comm*, parallel.FlatBucketDDP owns it): every backward then reduces
+        the flat gradient array bucket by bucket inside the ONE native backward call (mi355_resnet50_set_comm)."""
+        self._comm = None if comm is None else (comm, float(bucket_cap_mb))
+        L = native.lib()
+        for c in self._ctxs.values():
+            check(L.mi355_resnet50_set_comm(c, comm, float(bucket_cap_mb)))
+
+    def bucket_plan(self, bucket_cap_mb):
+        """[(begin, end, last_segment)] the native executor would reduce at this cap (layout-only: works on the CPU)."""
+        L = native.lib()
+        ctx = ctypes.c_void_p()
+        check(L.mi355_resnet50_create(ctypes.byref(ctx), -1, self._dt, 1, 32, 32, self.num_classes))
+        try:
+            n = ctypes.c_int()
+            B, E, S = (ctypes.c_size_t * 32)(), (ctypes.c_size_t * 32)(), (ctypes.c_int * 32)()
+            check(L.mi355_resnet50_bucket_plan(ctx, float(bucket_cap_mb), 32, ctypes.byref(n), B, E, S))
+            return [(B[i], E[i], S[i]) for i in range(n.value)]
+        finally:
+            L.mi355_resnet50_destroy(ctx)
+
     def mark_grads_clean(self):
         """the next backward overwrites the flat gradients instead of accumulating (optimizer.zero_grad())."""
         self._grads_dirty = False
@@ -276,6 +298,8 @@ class ResNet50(nn.Module):
             dev = self._flat_params.device.index or 0
             check(L.mi355_resnet50_create(ctypes.byref(c), dev, self._dt, N, H, W, self.num_classes))
             check(L.mi355_resnet50_bind(c, ptr(self._flat_params), ptr(self._flat_grads), ptr(self._flat_buffers)))
+            if self._comm is not None:
+                check(L.mi355_resnet50_set_comm(c, self._comm[0], float(self._comm[1])))
             self._ctxs[key] = c
         else:
             self._ctxs.move_to_end(key)

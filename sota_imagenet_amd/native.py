@@ -23,6 +23,8 @@ _BASE = {
     "double": ctypes.c_double,
     "size_t": ctypes.c_size_t,
     "uint8_t": ctypes.c_uint8,
+    "unsigned": ctypes.c_uint,
+    "unsigned long long": ctypes.c_ulonglong,
     "char": ctypes.c_char,
 }
 
@@ -38,8 +40,8 @@ def _ctype(decl):
         nptr = 0
     nptr += d.count("*")
     d = d.replace("*", " ").split()
-    base = d[0]
-    if base == "mi355_ctx":
+    base = " ".join(d) if d[0] == "unsigned" else d[0]
+    if base in ("mi355_ctx", "mi355_comm"):
         return ctypes.c_void_p  # opaque (any pointer depth)
     if base == "void" and nptr:
         return ctypes.c_void_p
@@ -59,6 +61,7 @@ def parse_header(path=HEADER_PATH):
     src = re.sub(r"//[^\n]*", " ", src)
     src = re.sub(r"#[^\n]*", " ", src)
     src = re.sub(r"typedef\s+enum\s+\w+\s*\{.*?\}\s*\w+\s*;", " ", src, flags=re.S)
+    src = re.sub(r"typedef\s+struct\s+\w+\s+\w+\s*;", " ", src)
     protos = {}
     for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(mi355_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, params = m.group(1).strip(), m.group(2), m.group(3).strip()

@@ -1,5 +1,11 @@
 """Data parallelism for the flat-buffer model: bucketed gradient all-reduce over RCCL/xGMI on a side HIP stream.
 
+On the GPU the collective lives INSIDE the C-ABI (csrc/comm.cpp: RCCL called directly): this class only bootstraps the
+communicator (the ncclUniqueId travels through the process group the reference already creates at train.py:58-61),
+broadcasts rank 0's state through it and attaches it to the model; every backward is then ONE native call that
+reduces bucket after bucket on the communicator's own HIP stream.  torch.distributed is not on the data path.
+The torch.distributed branch below serves the CPU stand-in of the world-size-2 gloo tests only.
+
 Replaces `torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])` at the reference's train.py:113-114
 (process group from train.py:58-61, `init_process_group("nccl", "env://")` — on ROCm that backend IS RCCL).
 What DDP does there, restated for one flat gradient array laid out in backward-completion order:
@@ -13,6 +19,8 @@ BN running statistics stay rank-local (the reference's per-forward buffer broadc
 does not influence training; rank 0's buffers are the ones checkpointed).
 xGMI is point-to-point (7 links/GPU): few large buckets keep each ring step per-link efficient.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -44,13 +52,55 @@ class FlatBucketDDP(nn.Module):
         self._buckets = plan_buckets(module.grad_segments, int(bucket_cap_mb * (1 << 20) / 4))
         self._by_last = {last: (b, e) for b, e, last in self._buckets}
         self._nseg = len(module.grad_segments)
-        self._side = torch.cuda.Stream(device=flat.device) if self._cuda else None
+        self._side = None
+        self._comm = None
         backend = dist.get_backend(process_group)
         self._avg = backend == "nccl"  # ReduceOp.AVG is an (R)CCL op; gloo sums and we scale
+        if self._cuda and hasattr(module, "set_comm"):
+            self._native_init(flat.device, bucket_cap_mb, broadcast)
+            return
+        if self._cuda:
+            self._side = torch.cuda.Stream(device=flat.device)
         if broadcast:
             self.broadcast_state()
         module._grad_sync = self._on_segment
         module._grad_sync_points = set(self._by_last)
+
+    # ---- GPU: the collective inside the C-ABI ------------------------------------------------------------------
+    def _native_init(self, device, bucket_cap_mb, broadcast):
+        from . import native
+
+        L = native.lib()
+        if not L.mi355_comm_available():
+            raise RuntimeError("FlatBucketDDP: librccl.so.1 not found (the MI355X data-parallel path has no fallback)")
+        rank = dist.get_rank(self.group)
+        uid = (ctypes.c_char * 128)()
+        if rank == 0:
+            native.check(L.mi355_comm_unique_id(uid))
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0, group=self.group)  # bootstrap only: 128 bytes through the launcher's group
+        comm = ctypes.c_void_p()
+        native.check(L.mi355_comm_create(ctypes.byref(comm), box[0], self.world, rank, device.index or 0))
+        self._comm = comm
+        if broadcast:
+            st = native.cur_stream()
+            m = self.module
+            native.check(L.mi355_comm_broadcast(comm, native.ptr(m.flat_params), m.flat_params.numel(), 0, st))
+            native.check(L.mi355_comm_broadcast(comm, native.ptr(m._flat_buffers), m._flat_buffers.numel(), 0, st))
+        self.module.set_comm(comm, bucket_cap_mb)
+        native_plan = self.module.bucket_plan(bucket_cap_mb)
+        assert native_plan == self._buckets, (native_plan, self._buckets)  # one plan, stated twice (C++ / plan_buckets)
+
+    def __del__(self):
+        try:
+            if self._comm is not None:
+                from . import native
+
+                self.module.set_comm(None)
+                native.lib().mi355_comm_destroy(self._comm)
+                self._comm = None
+        except Exception:
+            pass
 
     # ---- C2: rank 0 -> everyone, once ----------------------------------------------------------------------
     def broadcast_state(self):

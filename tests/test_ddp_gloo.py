@@ -15,7 +15,13 @@ class FakeFlatModel(torch.nn.Module):
 
     def __init__(self, rank):
         super().__init__()
-        sizes = [2_049_000 // 100] + [700 + 37 * i for i in range(16)] + [9536]
+        # the REAL executor's segment table (fc, 16 blocks, stem — a layout-only native context, no GPU), scaled down
+        # 1:64 so the stand-in's flat arrays stay small; boundaries keep their order and relative sizes
+        from sota_imagenet_amd.models import resnet50
+
+        real = resnet50().grad_segments
+        assert len(real) == 18
+        sizes = [max(16, (e - b) // 64) for b, e in real]
         self._segments, off = [], 0
         for s in sizes:
             self._segments.append((off, off + s))
@@ -48,7 +54,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         m = FakeFlatModel(rank)
-        ddp = FlatBucketDDP(m, bucket_cap_mb=0.01)
+        ddp = FlatBucketDDP(m, bucket_cap_mb=32.0 / 64)  # the default 32 MiB cap at the same 1:64 scale
         # C2: everyone holds rank 0's parameters and buffers after construction
         ok = bool((m.flat_params == 1.0).all()) and bool((m._flat_buffers == 10.0).all())
         m.backward()
@@ -82,6 +88,10 @@ def test_flat_bucket_ddp_world2_gloo():
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert all(nb > 1 for _, _, nb in res)
+    # the stand-in reduced the same number of buckets the native executor forms at the default cap
+    from sota_imagenet_amd.models import resnet50
+
+    assert all(nb == len(resnet50().bucket_plan(32.0)) for _, _, nb in res), res
 
 
 def test_bucket_plan_covers_every_segment_once():
@@ -97,3 +107,6 @@ def test_bucket_plan_covers_every_segment_once():
     assert bk[0][0] == 0 and bk[-1][1] == m.flat_grads.numel()
     for (b0, e0, _), (b1, e1, _) in zip(bk, bk[1:]):
         assert e0 == b1
+    # the executor's own plan (mi355_resnet50_bucket_plan: what backward reduces once a communicator is attached) is the same
+    for cap in (0.5, 8.0, 25.0, 32.0, 500.0):
+        assert m.bucket_plan(cap) == plan_buckets(m.grad_segments, int(cap * (1 << 20) / 4)), cap

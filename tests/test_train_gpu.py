@@ -72,6 +72,96 @@ def test_bench_with_rccl_ddp_single_rank(dev):
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["parallelism"] == "dp1"
 
 
+_DDP_CHECK = r"""
+import os, sys, torch, torch.distributed as dist
+from sota_imagenet_amd.losses import CrossEntropyLoss
+from sota_imagenet_amd.models import resnet50
+from sota_imagenet_amd.optim import SGD
+from sota_imagenet_amd.parallel import FlatBucketDDP
+from sota_imagenet_amd.synth import synthetic_batch
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
+crit = CrossEntropyLoss(smoothing=0.1)
+batches = [synthetic_batch(4, 64, seed=31, stream=r, index=0, device="cuda") for r in range(world)]
+# reference: every rank computes ALL ranks' gradients without DDP and averages them itself
+ref = resnet50(dtype="fp32").cuda()
+ref.train()
+gsum = torch.zeros_like(ref.flat_grads)
+for data, target in batches:
+    ref.mark_grads_clean()
+    crit(ref(data), target).backward()
+    gsum += ref.flat_grads
+gmean = gsum / world
+# the DDP path: different initial parameters per rank (so the broadcast matters), own shard of the batch
+m = resnet50(dtype="fp32").cuda()
+with torch.no_grad():
+    m.flat_params.mul_(1.0 + 0.1 * rank)
+ddp = FlatBucketDDP(m, device_ids=[torch.cuda.current_device()], bucket_cap_mb=8.0)
+assert torch.equal(m.flat_params, ref.flat_params), "rank-0 broadcast"
+opt = SGD([{"params": list(m.parameters())}], lr=0.01, momentum=0.9, weight_decay=3e-5)
+opt.attach_model(m)
+m.train()
+data, target = batches[rank]
+loss = crit(ddp(data), target)
+opt.zero_grad()
+loss.backward()
+torch.cuda.synchronize()
+err = ((m.flat_grads - gmean).abs().max() / gmean.abs().max()).item()
+assert err < 1e-6, f"all-reduced gradients vs the mean of the per-rank gradients: {err}"
+opt.step()
+torch.cuda.synchronize()
+mine = m.flat_params.clone()
+other = mine.clone()
+dist.broadcast(other, 0)
+assert torch.equal(mine, other), "parameters identical across ranks after the step"
+# a second step (the communicator's stream / events are reused; gradients overwrite)
+loss = crit(ddp(data), target)
+opt.zero_grad()
+loss.backward()
+opt.step()
+torch.cuda.synchronize()
+assert torch.isfinite(m.flat_params).all()
+print(f"DDP-OK rank {rank} err {err:.2e} buckets {len(ddp.buckets)}")
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def _run_ddp_check(nranks, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=ROOT)
+    return subprocess.run(
+                          [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr",
+                           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "_ddp_check.py")],
+                          capture_output=True, text=True, env=env, timeout=900)
+
+
+def test_native_rccl_allreduce_single_rank_numeric(dev, tmp_path):
+    """the collective inside the C-ABI (csrc/comm.cpp) on a 1-rank RCCL communicator: rank-0 broadcast, the bucketed
+    mean all-reduce chained behind backward on the communicator's stream, gradients == the mean (here: the gradient
+    itself), parameters finite after two steps — the event / stream ordering of the real path, with numbers."""
+    with open(os.path.join(ROOT, "tests", "_ddp_check.py"), "w") as f:
+        f.write(_DDP_CHECK)
+    try:
+        out = _run_ddp_check(1, 29531)
+    finally:
+        os.remove(os.path.join(ROOT, "tests", "_ddp_check.py"))
+    assert out.returncode == 0 and "DDP-OK rank 0" in out.stdout, (out.stdout[-800:], out.stderr[-2500:])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
+def test_native_rccl_allreduce_two_ranks_numeric(dev):
+    """2 ranks, different batches and different initial parameters: all-reduced gradients == mean of the two single-GPU
+    gradients (computed on each rank without DDP), parameters identical across ranks after the step."""
+    with open(os.path.join(ROOT, "tests", "_ddp_check.py"), "w") as f:
+        f.write(_DDP_CHECK)
+    try:
+        out = _run_ddp_check(2, 29533)
+    finally:
+        os.remove(os.path.join(ROOT, "tests", "_ddp_check.py"))
+    assert out.returncode == 0 and "DDP-OK rank 0" in out.stdout and "DDP-OK rank 1" in out.stdout, (out.stdout[-800:], out.stderr[-2500:])
+
+
 def test_progressive_resize_and_val_batch_shapes(dev):
     """stage change (dali_dataloader.py:213-239): the same model runs at 64 px and 96 px and at another batch size; each
     shape gets its own native context, parameters stay shared."""
