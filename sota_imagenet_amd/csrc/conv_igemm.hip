@@ -809,17 +809,21 @@ static bool choose_igemm8(const IgemmArgs& a, int nclass, int* bm, int* bn, int*
   //    multi-round launch of short tap classes (the stride-2 3x3 dgrad of layer 3) — measured in the executor,
   //    profiles/r02a_conv_per_layer_bf16_serial_{old,rule}.txt.
   const bool heavy_epilogue = (a.addend != nullptr && K < 1024);
+  // k order of a multi-tap launch: channel chunks outer, taps inner — the 9 taps of a 64-channel chunk re-read the same
+  // A rows back to back, so they are served from the XCD's L2 instead of being fetched again from beyond it (layer-4 3x3:
+  // 373 -> see 77 MB per launch for 25.7 MB of activations, profiles/r02c_pmc_per_conv_launch_bf16_serial.txt; same speed)
+  const int ko = (max_taps > 1 && a.Ck > 64) ? 1 : 0;
   if (a.Ncols % 256 == 0 && K >= 256 && !heavy_epilogue && igemm8_legal(a, nclass, 256)) {
     const long tiles = ((M + 223) / 224) * nclass * (a.Ncols / 256);
     if (tiles >= 180 && !(nclass > 1 && tiles > 512 && max_taps > 1)) {
-      *bm = 224; *bn = 256; *korder = 0; *fat = 0;
+      *bm = 224; *bn = 256; *korder = ko; *fat = 0;
       return true;
     }
   }
   if (a.Ncols % 128 == 0 && K >= 4096 && igemm8_legal(a, nclass, 128)) {
     const long tiles = ((M + 255) / 256) * nclass * (a.Ncols / 128);
     if (tiles >= 180 && tiles <= 256) {
-      *bm = 256; *bn = 128; *korder = 0; *fat = 1;
+      *bm = 256; *bn = 128; *korder = ko; *fat = 1;
       return true;
     }
   }

@@ -1,0 +1,534 @@
+// variant.hip — the small kernels of the BResNet-50 variant blocks (BASELINE configs[3]) for gfx950 (MI355X).
+//
+// The reference builds that model with `pytorch_tools.models.resnet50(stem_type="deep", antialias=True, attn_type="eca",
+// norm_layer="inplaceabn", norm_act="leaky_relu", drop_rate=0.2, drop_connect_rate=0.2)`
+// (configs/_old_configs/_first_attempts/BResNet50_encoder.yaml:41-51) and wraps every conv in weight standardisation
+// (train.py:66-67).  The convolutions / BN statistics reuse the kernels of the baseline path; this file adds what is new:
+//   blur pool      3x3 binomial [1,2,1] x [1,2,1] / 16, stride 2, reflect padding (anti-aliased down-sampling)
+//   avg pool 2x2   the anti-aliased shortcut of a stride-2 block
+//   max pool 3x3/1 the anti-aliased stem pool (max, then blur)
+//   ECA            global average pool -> 1-D conv of width k over the channel axis -> sigmoid -> channel-wise scale
+//   weight std     per output channel (w - mean) * rsqrt(var + eps) and its backward
+//   residual + act out = act(branch * keep_scale[n] + shortcut): drop-connect scale, shortcut add, (leaky) ReLU
+//   dropout        on the pooled features
+// All tensors NHWC; one thread handles one 16-byte channel vector (HBM-bound streaming, coalesced over channels).
+#include "common.h"
+#include "vec.h"
+
+namespace mi355 {
+namespace {
+
+constexpr float LEAKY = 0.01f;
+__device__ __forceinline__ float act_fwd(float v, int act) { return act == 0 ? v : (v > 0.f ? v : (act == 2 ? v * LEAKY : 0.f)); }
+__device__ __forceinline__ float act_slope(float out, int act) { return act == 0 ? 1.f : (out > 0.f ? 1.f : (act == 2 ? LEAKY : 0.f)); }
+
+#define GRID_STRIDE(i, total) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (size_t)gridDim.x * blockDim.x)
+
+static int grid_for(size_t total) { return (int)std::min<size_t>((total + 255) / 256, (size_t)256 * 8); }
+
+// ---- blur pool -----------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void blurpool_fwd_kernel(const T* x, T* y, int N, int H, int W, int C) {
+  constexpr int V = Vec16<T>::N;
+  const int Ho = H / 2, Wo = W / 2, CV = C / V;
+  const size_t total = (size_t)N * Ho * Wo * CV;
+  GRID_STRIDE(i, total) {
+    const int cv = (int)(i % CV);
+    size_t t = i / CV;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      int ih = 2 * oh - 1 + a;
+      ih = ih < 0 ? -ih : ih;  // reflect (H even: the bottom edge is never crossed)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        int iw = 2 * ow - 1 + b;
+        iw = iw < 0 ? -iw : iw;
+        const float f = (float)((a == 1 ? 2 : 1) * (b == 1 ? 2 : 1)) * (1.f / 16.f);
+        float v[V];
+        Vec16<T>::load(x + (((size_t)n * H + ih) * W + iw) * C + cv * V, v);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += f * v[e];
+      }
+    }
+    Vec16<T>::store(y + i * V, acc);
+  }
+}
+// gather form: dx[h][w] = sum over the (output, tap) pairs that read it — taps (oh, a) with 2*oh - 1 + a == h, and for
+// h == 1 additionally (oh = 0, a = 0), which reflects onto row 1
+template <typename T>
+__global__ __launch_bounds__(256) void blurpool_bwd_kernel(const T* dy, T* dx, int N, int H, int W, int C) {
+  constexpr int V = Vec16<T>::N;
+  const int Ho = H / 2, Wo = W / 2, CV = C / V;
+  const size_t total = (size_t)N * H * W * CV;
+  GRID_STRIDE(i, total) {
+    const int cv = (int)(i % CV);
+    size_t t = i / CV;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    // candidate (output index, filter weight) pairs along one axis
+    int ohs[3], ows[3];
+    float fh[3], fw[3];
+    int nh = 0, nw = 0;
+    for (int a = 0; a < 3; ++a) {
+      const int q = h + 1 - a;  // 2*oh
+      if (q >= 0 && (q & 1) == 0 && q / 2 < Ho) { ohs[nh] = q / 2; fh[nh++] = a == 1 ? 2.f : 1.f; }
+    }
+    if (h == 1) {  // tap a = 0 of oh = 0 reads row -1 -> 1
+      bool merged = false;
+      for (int k = 0; k < nh; ++k)
+        if (ohs[k] == 0) { fh[k] += 1.f; merged = true; }
+      if (!merged) { ohs[nh] = 0; fh[nh++] = 1.f; }
+    }
+    for (int b = 0; b < 3; ++b) {
+      const int q = w + 1 - b;
+      if (q >= 0 && (q & 1) == 0 && q / 2 < Wo) { ows[nw] = q / 2; fw[nw++] = b == 1 ? 2.f : 1.f; }
+    }
+    if (w == 1) {
+      bool merged = false;
+      for (int k = 0; k < nw; ++k)
+        if (ows[k] == 0) { fw[k] += 1.f; merged = true; }
+      if (!merged) { ows[nw] = 0; fw[nw++] = 1.f; }
+    }
+    for (int a = 0; a < nh; ++a)
+      for (int b = 0; b < nw; ++b) {
+        float v[V];
+        Vec16<T>::load(dy + (((size_t)n * Ho + ohs[a]) * Wo + ows[b]) * C + cv * V, v);
+        const float f = fh[a] * fw[b] * (1.f / 16.f);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += f * v[e];
+      }
+    Vec16<T>::store(dx + i * V, acc);
+  }
+}
+
+// ---- 2x2 average pool ---------------------------------------------------------------------------------------------
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void avgpool2_kernel(const T* in, T* out, int N, int H, int W, int C) {
+  constexpr int V = Vec16<T>::N;
+  const int Ho = H / 2, Wo = W / 2, CV = C / V;
+  const size_t total = (size_t)N * (BWD ? H * W : Ho * Wo) * CV;
+  GRID_STRIDE(i, total) {
+    const int cv = (int)(i % CV);
+    size_t t = i / CV;
+    float acc[V];
+    if (BWD) {
+      const int w = (int)(t % W); t /= W;
+      const int h = (int)(t % H);
+      const int n = (int)(t / H);
+      Vec16<T>::load(in + (((size_t)n * Ho + h / 2) * Wo + w / 2) * C + cv * V, acc);
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] *= 0.25f;
+    } else {
+      const int ow = (int)(t % Wo); t /= Wo;
+      const int oh = (int)(t % Ho);
+      const int n = (int)(t / Ho);
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float v[V];
+          Vec16<T>::load(in + (((size_t)n * H + 2 * oh + a) * W + 2 * ow + b) * C + cv * V, v);
+#pragma unroll
+          for (int e = 0; e < V; ++e) acc[e] += 0.25f * v[e];
+        }
+    }
+    Vec16<T>::store(out + i * V, acc);
+  }
+}
+
+// ---- 3x3 stride-1 max pool (pad 1): u8 index of the first maximum in window scan order --------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3s1_fwd_kernel(const T* x, T* y, uint8_t* idx, int N, int H, int W, int C) {
+  constexpr int V = Vec16<T>::N;
+  const int CV = C / V;
+  const size_t total = (size_t)N * H * W * CV;
+  GRID_STRIDE(i, total) {
+    const int cv = (int)(i % CV);
+    size_t t = i / CV;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    float best[V];
+    int bi[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { best[e] = -3.0e38f; bi[e] = 4; }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int ih = h - 1 + a;
+      if (ih < 0 || ih >= H) continue;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int iw = w - 1 + b;
+        if (iw < 0 || iw >= W) continue;
+        float v[V];
+        Vec16<T>::load(x + (((size_t)n * H + ih) * W + iw) * C + cv * V, v);
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          if (v[e] > best[e]) { best[e] = v[e]; bi[e] = a * 3 + b; }
+      }
+    }
+    Vec16<T>::store(y + i * V, best);
+#pragma unroll
+    for (int e = 0; e < V; ++e) idx[i * V + e] = (uint8_t)bi[e];
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3s1_bwd_kernel(const T* dy, const uint8_t* idx, T* dx, int N, int H, int W, int C) {
+  constexpr int V = Vec16<T>::N;
+  const int CV = C / V;
+  const size_t total = (size_t)N * H * W * CV;
+  GRID_STRIDE(i, total) {
+    const int cv = (int)(i % CV);
+    size_t t = i / CV;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {  // the window centred at (h + 1 - a, w + 1 - b) reads this pixel through tap (a, b)
+      const int oh = h + 1 - a;
+      if (oh < 0 || oh >= H) continue;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int ow = w + 1 - b;
+        if (ow < 0 || ow >= W) continue;
+        const size_t o = (((size_t)n * H + oh) * W + ow) * C + cv * V;
+        float v[V];
+        Vec16<T>::load(dy + o, v);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += idx[o + e] == a * 3 + b ? v[e] : 0.f;
+      }
+    }
+    Vec16<T>::store(dx + i * V, acc);
+  }
+}
+
+// ---- ECA ------------------------------------------------------------------------------------------------------------
+// gate[n][c] = sigmoid(sum_j w[j] * pooled[n][c + j - k/2])
+__global__ void eca_gate_kernel(const float* pooled, const float* w, int k, float* gate, int N, int C) {
+  GRID_STRIDE(i, (size_t)N * C) {
+    const int c = (int)(i % C), n = (int)(i / C);
+    float z = 0.f;
+    for (int j = 0; j < k; ++j) {
+      const int cc = c + j - k / 2;
+      if (cc >= 0 && cc < C) z += w[j] * pooled[(size_t)n * C + cc];
+    }
+    gate[i] = 1.f / (1.f + __expf(-z));
+  }
+}
+// y = x * gate[n][c]   (BWD: dx = dy * gate[n][c] + dpool[n][c])
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void eca_scale_kernel(const T* x, const float* gate, const float* dpool, T* y, int N, int HW, int C) {
+  constexpr int V = Vec16<T>::N;
+  const int CV = C / V;
+  const size_t total = (size_t)N * HW * CV;
+  GRID_STRIDE(i, total) {
+    const int cv = (int)(i % CV);
+    const int n = (int)(i / ((size_t)HW * CV));
+    float v[V];
+    Vec16<T>::load(x + i * V, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const size_t g = (size_t)n * C + cv * V + e;
+      v[e] = v[e] * gate[g] + (BWD ? dpool[g] : 0.f);
+    }
+    Vec16<T>::store(y + i * V, v);
+  }
+}
+// s[n][c] = sum_hw dy * x : one workgroup per (n, 64-channel slab), 256 threads = 4 pixel lanes x 64 channels
+template <typename T>
+__global__ __launch_bounds__(256) void eca_prod_reduce_kernel(const T* dy, const T* x, float* s, int N, int HW, int C) {
+  __shared__ float red[4][64];
+  const int slabs = C / 64;
+  const int n = blockIdx.x / slabs, c0 = (blockIdx.x % slabs) * 64;
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int p = r; p < HW; p += 4) {
+    const size_t o = ((size_t)n * HW + p) * C + c0 + c;
+    acc += (float)dy[o] * (float)x[o];
+  }
+  red[r][c] = acc;
+  __syncthreads();
+  if (r == 0) s[(size_t)n * C + c0 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+// dpre = s * g * (1 - g); dpool[n][c] = (sum_j w[j] * dpre[n][c - j + k/2]) / HW; dw[j] = sum_{n,c} dpre[n][c] * pooled[n][c + j - k/2]
+__global__ __launch_bounds__(256) void eca_gate_bwd_kernel(const float* s, const float* gate, const float* pooled, const float* w, int k,
+                                                          float* dpool, float* dw, float beta, int N, int C, float inv_hw) {
+  // single workgroup: the tensors are [N][C] (<= 256 x 2048 floats), the 1-D conv weight gradient is a full reduction
+  __shared__ float red[256];
+  float part[9];
+  for (int j = 0; j < 9; ++j) part[j] = 0.f;
+  for (size_t i = threadIdx.x; i < (size_t)N * C; i += 256) {
+    const int c = (int)(i % C), n = (int)(i / C);
+    float dp = 0.f;
+    for (int j = 0; j < k; ++j) {
+      const int cc = c - j + k / 2;  // dpre element that read pooled[n][c] through tap j
+      if (cc >= 0 && cc < C) {
+        const size_t o = (size_t)n * C + cc;
+        dp += w[j] * s[o] * gate[o] * (1.f - gate[o]);
+      }
+      const int cp = c + j - k / 2;
+      if (cp >= 0 && cp < C) part[j] += s[i] * gate[i] * (1.f - gate[i]) * pooled[(size_t)n * C + cp];
+    }
+    dpool[i] = dp * inv_hw;
+  }
+  for (int j = 0; j < k; ++j) {
+    red[threadIdx.x] = part[j];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) dw[j] = (beta != 0.f ? beta * dw[j] : 0.f) + red[0];
+    __syncthreads();
+  }
+}
+
+// ---- weight standardisation: one workgroup per output channel ---------------------------------------------------------
+__global__ __launch_bounds__(256) void weight_std_fwd_kernel(const float* w, float* w_hat, float* mean, float* invstd, int K, float eps) {
+  __shared__ double r1[256], r2[256];
+  const float* row = w + (size_t)blockIdx.x * K;
+  double a = 0, b = 0;
+  for (int i = threadIdx.x; i < K; i += 256) { a += row[i]; b += (double)row[i] * row[i]; }
+  r1[threadIdx.x] = a; r2[threadIdx.x] = b;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) { r1[threadIdx.x] += r1[threadIdx.x + st]; r2[threadIdx.x] += r2[threadIdx.x + st]; }
+    __syncthreads();
+  }
+  const double mu = r1[0] / K, var = fmax(r2[0] / K - mu * mu, 0.0);
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  if (threadIdx.x == 0) { mean[blockIdx.x] = (float)mu; invstd[blockIdx.x] = is; }
+  for (int i = threadIdx.x; i < K; i += 256) w_hat[(size_t)blockIdx.x * K + i] = (row[i] - (float)mu) * is;
+}
+// dw = invstd * (g - mean(g) - w_hat * mean(g * w_hat))
+__global__ __launch_bounds__(256) void weight_std_bwd_kernel(const float* g, const float* w_hat, const float* invstd, float* dw, float beta, int K) {
+  __shared__ double r1[256], r2[256];
+  const size_t base = (size_t)blockIdx.x * K;
+  double a = 0, b = 0;
+  for (int i = threadIdx.x; i < K; i += 256) { a += g[base + i]; b += (double)g[base + i] * w_hat[base + i]; }
+  r1[threadIdx.x] = a; r2[threadIdx.x] = b;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) { r1[threadIdx.x] += r1[threadIdx.x + st]; r2[threadIdx.x] += r2[threadIdx.x + st]; }
+    __syncthreads();
+  }
+  const float m1 = (float)(r1[0] / K), m2 = (float)(r2[0] / K), is = invstd[blockIdx.x];
+  for (int i = threadIdx.x; i < K; i += 256) {
+    const float v = is * (g[base + i] - m1 - w_hat[base + i] * m2);
+    dw[base + i] = (beta != 0.f ? beta * dw[base + i] : 0.f) + v;
+  }
+}
+
+// ---- residual + activation -------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void residual_act_fwd_kernel(const T* branch, const float* scale_n, const T* shortcut, T* out, int N, size_t HWC, int act) {
+  constexpr int V = Vec16<T>::N;
+  const size_t per = HWC / V, total = (size_t)N * per;
+  GRID_STRIDE(i, total) {
+    const float sc = scale_n ? scale_n[i / per] : 1.f;
+    float b[V], s[V];
+    Vec16<T>::load(branch + i * V, b);
+    if (shortcut) Vec16<T>::load(shortcut + i * V, s);
+#pragma unroll
+    for (int e = 0; e < V; ++e) b[e] = act_fwd(b[e] * sc + (shortcut ? s[e] : 0.f), act);
+    Vec16<T>::store(out + i * V, b);
+  }
+}
+// dz = dout * act'(out);  dbranch = dz * scale[n];  dshortcut = dz
+template <typename T>
+__global__ __launch_bounds__(256) void residual_act_bwd_kernel(const T* dout, const T* out, const float* scale_n, T* dbranch, T* dshortcut, int N, size_t HWC,
+                                                               int act) {
+  constexpr int V = Vec16<T>::N;
+  const size_t per = HWC / V, total = (size_t)N * per;
+  GRID_STRIDE(i, total) {
+    const float sc = scale_n ? scale_n[i / per] : 1.f;
+    float g[V], o[V], db[V];
+    Vec16<T>::load(dout + i * V, g);
+    Vec16<T>::load(out + i * V, o);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      g[e] *= act_slope(o[e], act);
+      db[e] = g[e] * sc;
+    }
+    Vec16<T>::store(dbranch + i * V, db);
+    if (dshortcut) Vec16<T>::store(dshortcut + i * V, g);
+  }
+}
+
+// ---- dropout / drop-connect masks from a counter-based generator -----------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+// keep[i] = u_i >= p ? 1 / (1 - p) : 0
+__global__ void keep_scale_kernel(float* keep, size_t n, float p, unsigned long long seed, unsigned long long counter) {
+  const unsigned long long base = splitmix64(seed ^ splitmix64(counter));
+  GRID_STRIDE(i, n) {
+    const float u = ((float)(splitmix64(base + 0x632BE59BD9B4E019ull * (i + 1)) >> 40) + 0.5f) * (1.0f / 16777216.0f);
+    keep[i] = u >= p ? 1.f / (1.f - p) : 0.f;
+  }
+}
+__global__ void mul_kernel(const float* a, const float* b, float* out, size_t n) {
+  GRID_STRIDE(i, n) out[i] = a[i] * b[i];
+}
+
+}  // namespace
+}  // namespace mi355
+
+using namespace mi355;
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16)                  \
+  do {                                                          \
+    if ((dtype) == MI355_F32) { CALL_F32; }                     \
+    else if ((dtype) == MI355_BF16) { CALL_BF16; }              \
+    else { set_error("bad dtype %d", (dtype)); return MI355_E_ARG; } \
+  } while (0)
+
+extern "C" {
+
+int mi355_blurpool_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream) {
+  MI355_ARG(x && y && N > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "blurpool: H=%d W=%d (even) C=%d (multiple of 8)", H, W, C);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(blurpool_fwd_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)x, (float*)y, N, H, W, C),
+             hipLaunchKernelGGL(blurpool_fwd_kernel<bf16_t>, dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, N, H, W, C));
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+int mi355_blurpool_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, void* stream) {
+  MI355_ARG(dy && dx && N > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "blurpool: H=%d W=%d (even) C=%d (multiple of 8)", H, W, C);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)N * H * W * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(blurpool_bwd_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)dy, (float*)dx, N, H, W, C),
+             hipLaunchKernelGGL(blurpool_bwd_kernel<bf16_t>, dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C));
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+int mi355_avgpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream) {
+  MI355_ARG(x && y && N > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "avgpool2: H=%d W=%d (even) C=%d (multiple of 8)", H, W, C);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((avgpool2_kernel<float, false>), dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)x, (float*)y, N, H, W, C),
+             hipLaunchKernelGGL((avgpool2_kernel<bf16_t, false>), dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, N, H, W, C));
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+int mi355_avgpool2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, void* stream) {
+  MI355_ARG(dy && dx && N > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "avgpool2: H=%d W=%d (even) C=%d (multiple of 8)", H, W, C);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)N * H * W * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((avgpool2_kernel<float, true>), dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)dy, (float*)dx, N, H, W, C),
+             hipLaunchKernelGGL((avgpool2_kernel<bf16_t, true>), dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C));
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+int mi355_maxpool3s1_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+  MI355_ARG(x && y && idx && N > 0 && H > 0 && W > 0 && C % 8 == 0, "maxpool3s1: C=%d (multiple of 8)", C);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)N * H * W * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool3s1_fwd_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)x, (float*)y, idx, N, H, W, C),
+             hipLaunchKernelGGL(maxpool3s1_fwd_kernel<bf16_t>, dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C));
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+int mi355_maxpool3s1_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C, void* stream) {
+  MI355_ARG(dy && dx && idx && N > 0 && H > 0 && W > 0 && C % 8 == 0, "maxpool3s1: C=%d (multiple of 8)", C);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)N * H * W * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool3s1_bwd_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)dy, idx, (float*)dx, N, H, W, C),
+             hipLaunchKernelGGL(maxpool3s1_bwd_kernel<bf16_t>, dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)dy, idx, (bf16_t*)dx, N, H, W, C));
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int mi355_eca_fwd(int dtype, const void* x, const float* w, int k, void* y, float* pooled, float* gate, int N, int HW, int C, void* stream) {
+  MI355_ARG(x && w && y && pooled && gate && k >= 1 && k <= 9 && (k & 1) && C % 64 == 0, "eca: k=%d (odd, <= 9) C=%d (multiple of 64)", k, C);
+  hipStream_t s = (hipStream_t)stream;
+  MI355_TRY(launch_gap_fwd(dtype, x, pooled, N, HW, C, s));
+  hipLaunchKernelGGL(eca_gate_kernel, dim3(grid_for((size_t)N * C)), dim3(256), 0, s, pooled, w, k, gate, N, C);
+  const size_t total = (size_t)N * HW * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((eca_scale_kernel<float, false>), dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)x, gate, nullptr, (float*)y, N, HW, C),
+             hipLaunchKernelGGL((eca_scale_kernel<bf16_t, false>), dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)x, gate, nullptr, (bf16_t*)y, N, HW, C));
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+int mi355_eca_bwd(int dtype, const void* dy, const void* x, const float* w, int k, const float* pooled, const float* gate, void* dx, float* dw,
+                  float beta, float* ws, int N, int HW, int C, void* stream) {
+  MI355_ARG(dy && x && w && pooled && gate && dx && dw && ws && k >= 1 && k <= 9 && (k & 1) && C % 64 == 0, "eca_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  float* sprod = ws;                    // [N][C]
+  float* dpool = ws + (size_t)N * C;    // [N][C]
+  DISPATCH_T(dtype, hipLaunchKernelGGL(eca_prod_reduce_kernel<float>, dim3(N * (C / 64)), dim3(256), 0, s, (const float*)dy, (const float*)x, sprod, N, HW, C),
+             hipLaunchKernelGGL(eca_prod_reduce_kernel<bf16_t>, dim3(N * (C / 64)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, sprod, N, HW, C));
+  hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3(1), dim3(256), 0, s, sprod, gate, pooled, w, k, dpool, dw, beta, N, C, 1.f / (float)HW);
+  const size_t total = (size_t)N * HW * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((eca_scale_kernel<float, true>), dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)dy, gate, dpool, (float*)dx, N, HW, C),
+             hipLaunchKernelGGL((eca_scale_kernel<bf16_t, true>), dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)dy, gate, dpool, (bf16_t*)dx, N, HW, C));
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int mi355_weight_std_fwd(const float* w, float* w_hat, float* mean, float* invstd, int Cout, int K, float eps, void* stream) {
+  MI355_ARG(w && w_hat && mean && invstd && Cout > 0 && K > 0, "weight_std: bad arguments");
+  hipLaunchKernelGGL(weight_std_fwd_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, w, w_hat, mean, invstd, K, eps);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+int mi355_weight_std_bwd(const float* dw_hat, const float* w_hat, const float* invstd, float* dw, float beta, int Cout, int K, void* stream) {
+  MI355_ARG(dw_hat && w_hat && invstd && dw && Cout > 0 && K > 0, "weight_std_bwd: bad arguments");
+  hipLaunchKernelGGL(weight_std_bwd_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, dw_hat, w_hat, invstd, dw, beta, K);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int mi355_residual_act_fwd(int dtype, const void* branch, const float* scale_n, const void* shortcut, void* out, int N, size_t HWC, int act, void* stream) {
+  MI355_ARG(branch && out && N > 0 && HWC % 8 == 0 && act >= 0 && act <= 2, "residual_act: HWC=%zu (multiple of 8) act=%d", HWC, act);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)N * HWC;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(residual_act_fwd_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)branch, scale_n, (const float*)shortcut, (float*)out, N, HWC, act),
+             hipLaunchKernelGGL(residual_act_fwd_kernel<bf16_t>, dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)branch, scale_n, (const bf16_t*)shortcut, (bf16_t*)out, N, HWC, act));
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+int mi355_residual_act_bwd(int dtype, const void* dout, const void* out, const float* scale_n, void* dbranch, void* dshortcut, int N, size_t HWC, int act,
+                           void* stream) {
+  MI355_ARG(dout && out && dbranch && N > 0 && HWC % 8 == 0 && act >= 0 && act <= 2, "residual_act_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)N * HWC;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(residual_act_bwd_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)dout, (const float*)out, scale_n, (float*)dbranch, (float*)dshortcut, N, HWC, act),
+             hipLaunchKernelGGL(residual_act_bwd_kernel<bf16_t>, dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, scale_n, (bf16_t*)dbranch, (bf16_t*)dshortcut, N, HWC, act));
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+int mi355_keep_scale(float* keep, size_t n, float p, unsigned long long seed, unsigned long long counter, void* stream) {
+  MI355_ARG(keep && n > 0 && p >= 0.f && p < 1.f, "keep_scale: p=%f must be in [0, 1)", p);
+  hipLaunchKernelGGL(keep_scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, keep, n, p, seed, counter);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+int mi355_mul_f32(const float* a, const float* b, float* out, size_t n, void* stream) {
+  MI355_ARG(a && b && out, "mul: null pointer");
+  hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"
