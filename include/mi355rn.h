@@ -92,7 +92,8 @@ size_t mi355_stem_workspace_bytes(int dtype, int N, int H, int W);
 /* BatchNorm2d, training mode, over x[M,C] (M = N*H*W rows, NHWC):
  *   mean/var over M (biased var to normalise, unbiased into running_var), eps inside the sqrt,
  *   running = (1-momentum)*running + momentum*batch.   Outputs save_mean/save_invstd [C] for backward.
- *   out = act(x_hat*gamma + beta (+ residual)),   act = ReLU if relu!=0.
+ *   out = act(x_hat*gamma + beta (+ residual)),   act by `relu`: 0 identity, 1 ReLU, 2 leaky ReLU (slope 0.01 — the
+ *   `norm_act: leaky_relu` of the BResNet-50 configs, BResNet50_encoder.yaml:49-50; same codes in mi355_bn_bwd).
  *   ws: >= mi355_bn_workspace_bytes(C) bytes.
  * replaces cuDNN BatchNormalizationForwardTraining + ATen relu/add — callbacks.py:316 (K3,K4);
  * momentum semantics: train.py:76 / arg_parser.py:132                                              */
@@ -139,6 +140,46 @@ int mi355_ce_loss(const float* logits, const float* target, float smoothing, flo
  * replaces torch.optim._multi_tensor.SGD.step — arg_parser.py:136-138, callbacks.py:309 (K10)       */
 int mi355_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float momentum,
                    float weight_decay, float grad_scale, void* stream);
+
+/* ---- BResNet-50 variant blocks (BASELINE configs[3]) ---------------------------------------------------------------
+ * The reference builds that model as pytorch_tools.models.resnet50(stem_type="deep", antialias=True, attn_type="eca",
+ * norm_layer="inplaceabn", norm_act="leaky_relu", drop_rate=0.2, drop_connect_rate=0.2) —
+ * configs/_old_configs/_first_attempts/BResNet50_encoder.yaml:41-51 — and wraps every conv in weight standardisation
+ * (train.py:66-67).  Convolutions and BN reuse the entry points above; these are the additional ops, all NHWC.
+ *   blurpool    3x3 binomial [1,2,1]x[1,2,1]/16, stride 2, reflect padding 1 (anti-aliased down-sampling); H, W even
+ *   avgpool2    2x2 average, stride 2 (the anti-aliased shortcut of a stride-2 block)
+ *   maxpool3s1  3x3 max, stride 1, pad 1 + u8 argmax (first maximum in window scan order): the anti-aliased stem pool
+ *   eca         y = x * sigmoid(conv1d_k(GAP(x)))[n][c]; k odd <= 9, zero padded over the channel axis.  pooled / gate
+ *               [N][C] fp32 are outputs kept for backward; eca_bwd returns dx and the k conv-weight gradients
+ *               (beta = 0 overwrite / 1 accumulate), ws = 2*N*C floats of scratch
+ *   weight_std  w_hat[o] = (w[o] - mean_o) * rsqrt(var_o + eps) over the K = KH*KW*Cin weights of output channel o
+ *               (biased variance) and its backward dw = invstd * (g - mean(g) - w_hat * mean(g * w_hat))
+ *   residual_act  out = act(branch * scale_n[n] + shortcut): drop-connect keep/scale per sample (scale_n may be NULL),
+ *               shortcut add (may be NULL), activation code as in mi355_bn_fwd_train; backward from `out`
+ *   keep_scale  keep[i] = u_i >= p ? 1/(1-p) : 0 from a counter-based generator (seed, counter): the drop-connect
+ *               sample scales and, multiplied onto the pooled features (mi355_mul_f32), dropout                     */
+int mi355_blurpool_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);
+int mi355_blurpool_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+int mi355_avgpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);
+int mi355_avgpool2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+int mi355_maxpool3s1_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, void* stream);
+int mi355_maxpool3s1_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C,
+                         void* stream);
+int mi355_eca_fwd(int dtype, const void* x, const float* w, int k, void* y, float* pooled, float* gate, int N,
+                  int HW, int C, void* stream);
+int mi355_eca_bwd(int dtype, const void* dy, const void* x, const float* w, int k, const float* pooled,
+                  const float* gate, void* dx, float* dw, float beta, float* ws, int N, int HW, int C, void* stream);
+int mi355_weight_std_fwd(const float* w, float* w_hat, float* mean, float* invstd, int Cout, int K, float eps,
+                         void* stream);
+int mi355_weight_std_bwd(const float* dw_hat, const float* w_hat, const float* invstd, float* dw, float beta,
+                         int Cout, int K, void* stream);
+int mi355_residual_act_fwd(int dtype, const void* branch, const float* scale_n, const void* shortcut, void* out,
+                           int N, size_t HWC, int act, void* stream);
+int mi355_residual_act_bwd(int dtype, const void* dout, const void* out, const float* scale_n, void* dbranch,
+                           void* dshortcut, int N, size_t HWC, int act, void* stream);
+int mi355_keep_scale(float* keep, size_t n, float p, unsigned long long seed, unsigned long long counter,
+                     void* stream);
+int mi355_mul_f32(const float* a, const float* b, float* out, size_t n, void* stream);
 
 /* Mixup / CutMix with the previous batch, on the device (CutmixMixup — sota_imagenet/callbacks.py:232-247; the
  * pytorch_tools Cutmix / Mixup bases it combines mix the batch with the PREVIOUS one under a random permutation).

@@ -145,3 +145,75 @@ def accuracy(logits, target_onehot, k):
     tgt = target_onehot.argmax(1)
     topk = logits.float().topk(k, dim=1).indices
     return (topk == tgt[:, None]).any(1).float().mean() * 100.0
+
+
+# ---- BResNet-50 variant blocks (BASELINE configs[3]; configs/_old_configs/_first_attempts/BResNet50_encoder.yaml:41-51) --------
+# The ops live in un-vendored pytorch_tools (modules/residual.py, modules/pooling.py BlurPool, modules/weight_standartization.py):
+# restated from their published definitions as SURVEY.md Appendix C records them — UPSTREAM-RECALLED, parity unpinned.
+LEAKY = 0.01
+
+
+def act(x, code):
+    """activation codes of the native path: 0 identity, 1 ReLU, 2 leaky ReLU (slope 0.01)"""
+    return x if code == 0 else (F.relu(x) if code == 1 else F.leaky_relu(x, LEAKY))
+
+
+def bn_act_train(x_nhwc, gamma, beta, running_mean, running_var, residual=None, code=1, eps=1e-5, momentum=0.1):
+    """bn_train with an activation code (ABN / InplaceABN with norm_act leaky_relu)"""
+    x = nhwc_to_nchw(x_nhwc.float())
+    rm, rv = running_mean.clone().float(), running_var.clone().float()
+    y = F.batch_norm(x, rm, rv, gamma.float(), beta.float(), training=True, momentum=momentum, eps=eps)
+    if residual is not None:
+        y = y + nhwc_to_nchw(residual.float())
+    return nchw_to_nhwc(act(y, code)), rm, rv
+
+
+def blurpool(x_nhwc):
+    """anti-aliased down-sampling (Zhang 2019, as pytorch_tools BlurPool): reflect pad 1, 3x3 binomial / 16, stride 2, depthwise"""
+    x = nhwc_to_nchw(x_nhwc.float())
+    C = x.shape[1]
+    f = torch.tensor([1.0, 2.0, 1.0])
+    k = (f[:, None] * f[None, :] / 16.0)[None, None].repeat(C, 1, 1, 1)
+    return nchw_to_nhwc(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), k, stride=2, groups=C))
+
+
+def avgpool2(x_nhwc):
+    return nchw_to_nhwc(F.avg_pool2d(nhwc_to_nchw(x_nhwc.float()), 2, 2))
+
+
+def maxpool3s1(x_nhwc):
+    return nchw_to_nhwc(F.max_pool2d(nhwc_to_nchw(x_nhwc.float()), 3, 1, 1))
+
+
+def eca(x_nhwc, w):
+    """ECA: GAP -> conv1d(k, zero pad, no bias) over the channel axis -> sigmoid -> scale"""
+    x = x_nhwc.float()
+    N, H, W, C = x.shape
+    pooled = x.mean(dim=(1, 2))
+    k = w.numel()
+    z = F.conv1d(pooled.view(N, 1, C), w.float().view(1, 1, k), padding=k // 2).view(N, C)
+    return x * torch.sigmoid(z).view(N, 1, 1, C)
+
+
+def weight_std(w_krsc, eps=1e-5):
+    """per output channel (w - mean) / sqrt(var + eps), biased variance over (KH, KW, Cin)"""
+    w = w_krsc.float()
+    var, mean = torch.var_mean(w, dim=(1, 2, 3), keepdim=True, unbiased=False)
+    return (w - mean) / torch.sqrt(var + eps)
+
+
+def residual_act(branch, scale_n, shortcut, code):
+    b = branch.float()
+    if scale_n is not None:
+        b = b * scale_n.float().view(-1, 1, 1, 1)
+    if shortcut is not None:
+        b = b + shortcut.float()
+    return act(b, code)
+
+
+def grads(fn, inputs, dout):
+    """autograd helper: gradients of fn(*inputs) w.r.t. every input under the upstream gradient dout"""
+    xs = [t.detach().float().clone().requires_grad_(True) for t in inputs]
+    y = fn(*xs)
+    y.backward(dout.float())
+    return [t.grad for t in xs]

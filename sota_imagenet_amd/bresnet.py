@@ -1,0 +1,312 @@
+"""BResNet-50 — the model of BASELINE.json configs[3] — on the native per-op C-ABI (HIP kernels for every tensor op).
+
+The reference builds it with `_target_: pytorch_tools.models.resnet50` and the model_params of
+configs/_old_configs/_first_attempts/BResNet50_encoder.yaml:41-51 (stem_type deep, antialias, attn_type eca, norm_layer
+inplaceabn, norm_act leaky_relu, drop_rate 0.2, drop_connect_rate 0.2) and wraps every conv in weight standardisation
+(train.py:66-67; `weight_standardization: True`, yaml:59).  pytorch_tools is not vendored: the block structure is restated
+from its published source as SURVEY.md Appendix C recalls it (the same statement as the oracle, oracle/bresnet50_ref.py):
+  deep stem   conv3x3(3,32,s2)+ABN, conv3x3(32,32)+ABN, conv3x3(32,64), bn1 = ABN(64); pool = maxpool 3x3/1 + BlurPool
+  bottleneck  conv1x1+ABN, conv3x3 (stride 1)+ABN [+BlurPool when the block strides], conv1x1+ABN(identity), ECA(k=3),
+              drop-connect(rate * i / 16) on the branch, + shortcut ([AvgPool 2x2] conv1x1 ABN(identity) where the block
+              strides / widens), leaky ReLU
+  head        GAP, dropout(drop_rate), FC
+Unlike models.ResNet50 (one static C++ executor call per step) this graph is driven from Python, one C-ABI call per op,
+through torch.autograd.Function nodes: conv fwd/dgrad/wgrad (conv_igemm*.hip, conv_wgrad.hip), BN+act (bn.hip), and the
+variant kernels of csrc/variant.hip.  Activations are NHWC in the compute dtype (bf16 | fp32); parameters are fp32 nn.Parameters
+with the names / shapes pytorch_tools gives them (conv1.0.weight, layer1.0.se_module.conv.weight, layer2.0.downsample.0.weight …).
+Channel counts below 64 (the 3 / 32-channel stem) run zero-padded to 64, the granule of the conv kernels.  There is no CPU
+path: a CPU tensor raises.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+LEAKY_ACT = 2  # activation code of the C-ABI: 0 identity, 1 ReLU, 2 leaky ReLU (0.01)
+
+
+def _pad_c(t, c, dim=-1):
+    """zero-pads dimension `dim` of t to c entries"""
+    if t.shape[dim] == c:
+        return t
+    shape = list(t.shape)
+    shape[dim] = c - t.shape[dim]
+    return torch.cat([t, torch.zeros(shape, dtype=t.dtype, device=t.device)], dim=dim)
+
+
+def _up64(c):
+    return (c + 63) // 64 * 64
+
+
+class _ConvFn(torch.autograd.Function):
+    """y = conv(x, WS(w)): weight standardisation (optional), channel padding, cast, conv — one node, weight gradient in fp32"""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, standardize):
+        cout, cin, k, _ = w.shape
+        wk = w.detach().permute(0, 2, 3, 1).contiguous()  # KRSC fp32
+        if standardize:
+            w_hat, invstd = ops.weight_std_fwd(wk)
+        else:
+            w_hat, invstd = wk, None
+        wp = _pad_c(_pad_c(w_hat, _up64(cin), 3), _up64(cout), 0).to(x.dtype).contiguous()
+        y = ops.conv2d_fwd(x, wp, stride, k // 2)
+        ctx.save_for_backward(x, wp, w_hat, invstd if invstd is not None else torch.empty(0))
+        ctx.meta = (cout, cin, k, stride, standardize)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wp, w_hat, invstd = ctx.saved_tensors
+        cout, cin, k, stride, standardize = ctx.meta
+        dy = dy.contiguous()
+        dx = ops.conv2d_dgrad(dy, wp, tuple(x.shape), stride, k // 2) if ctx.needs_input_grad[0] else None
+        dwp = ops.conv2d_wgrad(dy, x, k, k, stride, k // 2)  # fp32 [Cout_p, k, k, Cin_p]
+        dw_hat = dwp[:cout, :, :, :cin].contiguous()
+        dwk = ops.weight_std_bwd(dw_hat, w_hat, invstd) if standardize else dw_hat
+        return dx, dwk.permute(0, 3, 1, 2), None, None
+
+
+class _BNActFn(torch.autograd.Function):
+    """ABN: BatchNorm (batch statistics, running stats updated in place) + activation code"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, act, momentum, training):
+        C, Cp = gamma.numel(), x.shape[-1]
+        g, b = _pad_c(gamma.detach(), Cp).contiguous(), _pad_c(beta.detach(), Cp).contiguous()
+        rmp = _pad_c(rm, Cp).clone()
+        rvp = (rv if Cp == C else torch.cat([rv, torch.ones(Cp - C, device=rv.device)])).clone()  # padded channels: var 1
+        if not training:
+            return ops.bn_fwd_eval(x, g, b, rmp, rvp, relu=act)
+        out, mean, invstd = ops.bn_fwd_train(x, g, b, rmp, rvp, relu=act, momentum=momentum)
+        rm.copy_(rmp[:C])
+        rv.copy_(rvp[:C])
+        ctx.save_for_backward(x, out, g, mean, invstd)
+        ctx.meta = (C, act)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, out, g, mean, invstd = ctx.saved_tensors
+        C, act = ctx.meta
+        dx, dg, db, _ = ops.bn_bwd(dout.contiguous(), out, x, g, mean, invstd, relu=act)
+        return dx, dg[:C], db[:C], None, None, None, None, None
+
+
+class _BlurPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return ops.blurpool_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.blurpool_bwd(dy.contiguous(), ctx.shape)
+
+
+class _AvgPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return ops.avgpool2_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.avgpool2_bwd(dy.contiguous(), ctx.shape)
+
+
+class _MaxPool3s1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y, idx = ops.maxpool3s1_fwd(x)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return ops.maxpool3s1_bwd(dy.contiguous(), idx)
+
+
+class _ECAFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        wk = w.detach().reshape(-1).contiguous()
+        y, pooled, gate = ops.eca_fwd(x, wk)
+        ctx.save_for_backward(x, wk, pooled, gate)
+        ctx.wshape = tuple(w.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wk, pooled, gate = ctx.saved_tensors
+        dx, dw = ops.eca_bwd(dy.contiguous(), x, wk, pooled, gate)
+        return dx, dw.view(ctx.wshape)
+
+
+class _ResidualActFn(torch.autograd.Function):
+    """out = act(branch * keep[n] + shortcut)"""
+
+    @staticmethod
+    def forward(ctx, branch, shortcut, keep, act):
+        out = ops.residual_act_fwd(branch, shortcut, keep, act)
+        ctx.save_for_backward(out, keep if keep is not None else torch.empty(0))
+        ctx.act = act
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, keep = ctx.saved_tensors
+        db, ds = ops.residual_act_bwd(dout.contiguous(), out, keep if keep.numel() else None, ctx.act)
+        return db, ds, None, None
+
+
+class _GapFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape, ctx.dtype = tuple(x.shape), x.dtype
+        return ops.gap_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dp):
+        return ops.gap_bwd(dp.contiguous(), ctx.shape, ctx.dtype)
+
+
+class _Conv(nn.Module):
+    def __init__(self, cin, cout, k, stride, standardize):
+        super().__init__()
+        # OIHW shape in channels_last memory = KRSC, the kernels' weight layout (and what the gradient comes back in)
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last))
+        self.stride, self.standardize = stride, standardize
+
+    def forward(self, x):
+        return _ConvFn.apply(x, self.weight, self.stride, self.standardize)
+
+
+class _ABN(nn.Module):
+    """BN-like leaf for patch_bn_mom (train.py:76): has `.momentum`, weight / bias / running_mean / running_var / num_batches_tracked"""
+
+    def __init__(self, c, act):
+        super().__init__()
+        self.weight, self.bias = nn.Parameter(torch.ones(c)), nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long))
+        self.momentum, self.eps, self.act = 0.1, 1e-5, act
+
+    def forward(self, x):
+        if self.training:
+            self.num_batches_tracked += 1
+        return _BNActFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.act, self.momentum, self.training)
+
+
+class _ECA(nn.Module):
+    def __init__(self, k=3):
+        super().__init__()
+        self.conv = nn.Module()
+        self.conv.weight = nn.Parameter(torch.empty(1, 1, k))
+
+    def forward(self, x):
+        return _ECAFn.apply(x, self.conv.weight)
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, cin, planes, stride, has_ds, standardize):
+        super().__init__()
+        self.conv1, self.bn1 = _Conv(cin, planes, 1, 1, standardize), _ABN(planes, LEAKY_ACT)
+        self.conv2, self.bn2 = _Conv(planes, planes, 3, 1, standardize), _ABN(planes, LEAKY_ACT)
+        self.conv3, self.bn3 = _Conv(planes, planes * 4, 1, 1, standardize), _ABN(planes * 4, 0)
+        self.se_module = _ECA(3)
+        self.stride = stride
+        self.downsample = None
+        if has_ds:
+            self.downsample = nn.Sequential()
+            self.downsample.add_module("0", _Conv(cin, planes * 4, 1, 1, standardize))
+            self.downsample.add_module("1", _ABN(planes * 4, 0))
+
+    def forward(self, x, keep):
+        out = self.bn1(self.conv1(x))
+        out = self.bn2(self.conv2(out))
+        if self.stride == 2:
+            out = _BlurPoolFn.apply(out)
+        out = self.se_module(self.bn3(self.conv3(out)))
+        sc = x
+        if self.downsample is not None:
+            sc = _AvgPool2Fn.apply(x) if self.stride == 2 else x
+            sc = self.downsample[1](self.downsample[0](sc))
+        return _ResidualActFn.apply(out, sc, keep, LEAKY_ACT)
+
+
+class BResNet50(nn.Module):
+    def __init__(self, num_classes=1000, dtype="bf16", drop_rate=0.2, drop_connect_rate=0.2, weight_standardization=True, seed=0, **kw):
+        super().__init__()
+        unknown = set(kw) - {"pretrained", "stem_type", "antialias", "attn_type", "norm_layer", "norm_act"}
+        if unknown:
+            raise TypeError(f"bresnet50: unsupported arguments {sorted(unknown)}")
+        self._dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}[str(dtype)]
+        S = weight_standardization
+        self.num_classes, self.drop_rate, self.drop_connect_rate, self.seed = num_classes, float(drop_rate), float(drop_connect_rate), int(seed)
+        self.conv1 = nn.Sequential(_Conv(3, 32, 3, 2, S), _ABN(32, LEAKY_ACT), _Conv(32, 32, 3, 1, S), _ABN(32, LEAKY_ACT), _Conv(32, 64, 3, 1, S))
+        self.bn1 = _ABN(64, LEAKY_ACT)
+        cin = 64
+        for li, (nb, planes) in enumerate(zip((3, 4, 6, 3), (64, 128, 256, 512)), 1):
+            blocks = nn.ModuleList()
+            for i in range(nb):
+                blocks.append(_Bottleneck(cin, planes, 2 if (i == 0 and li > 1) else 1, i == 0, S))
+                cin = planes * 4
+            setattr(self, f"layer{li}", blocks)
+        self.fc = nn.Linear(2048, num_classes)
+        self._step = 0
+        self.masks = None  # test hook: {"dc": [per block [N] fp32 or None], "do": [N, 2048] fp32 or None} overrides the sampler
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        g = torch.Generator().manual_seed(self.seed)
+        for m in self.modules():
+            if isinstance(m, _Conv):
+                fan_out = m.weight.shape[0] * m.weight.shape[2] * m.weight.shape[3]
+                with torch.no_grad():
+                    m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / fan_out) ** 0.5)
+            elif isinstance(m, _ECA):
+                with torch.no_grad():
+                    m.conv.weight.copy_((torch.rand(m.conv.weight.shape, generator=g) * 2 - 1) * (1.0 / 3.0) ** 0.5)
+        with torch.no_grad():
+            self.fc.weight.copy_((torch.rand(self.fc.weight.shape, generator=g) * 2 - 1) / 2048 ** 0.5)
+            self.fc.bias.zero_()
+
+    def blocks(self):
+        return [b for li in range(1, 5) for b in getattr(self, f"layer{li}")]
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("bresnet50: the MI355X hot path has no CPU fallback — move the model and the batch to CUDA")
+        if not (x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3):
+            raise ValueError("bresnet50 expects a CUDA float32 NCHW batch [N,3,H,W] (dali_dataloader.py:113-122 contract)")
+        N = x.shape[0]
+        h = torch.zeros((N, x.shape[2], x.shape[3], 64), dtype=self._dtype, device=x.device)
+        h[..., :3] = x.permute(0, 2, 3, 1)  # the loader's NCHW batch -> zero-padded NHWC
+        h = self.bn1(self.conv1(h))
+        h = _BlurPoolFn.apply(_MaxPool3s1Fn.apply(h))
+        blocks = self.blocks()
+        train = self.training and torch.is_grad_enabled()
+        for i, b in enumerate(blocks):
+            keep = None
+            if self.masks is not None:
+                keep = self.masks["dc"][i]
+            elif train and self.drop_connect_rate > 0 and i > 0:
+                keep = ops.keep_scale(N, self.drop_connect_rate * i / len(blocks), self.seed, self._step * 64 + i, x.device)
+            h = b(h, keep)
+        p = _GapFn.apply(h)
+        if self.masks is not None:
+            if self.masks.get("do") is not None:
+                p = p * self.masks["do"]
+        elif train and self.drop_rate > 0:
+            p = p * ops.keep_scale(p.numel(), self.drop_rate, self.seed, self._step * 64 + 63, x.device).view_as(p)
+        if train:
+            self._step += 1
+        return torch.nn.functional.linear(p, self.fc.weight, self.fc.bias)
+
+
+def bresnet50(**kwargs):
+    """`_target_` plugin for the BResNet-50 recipes (BASELINE configs[3])."""
+    return BResNet50(**kwargs)

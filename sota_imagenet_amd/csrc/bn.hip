@@ -43,6 +43,7 @@ struct ReduceArgs {
   float* partial;     // [gridDim.x][2][C]
   float* pivot;       // [C] (stats): per-channel shift = the channel's value in row 0
   int M, C;
+  float slope;        // MASK == 1: gradient factor where the activation was <= 0 (0 ReLU, 0.01 leaky ReLU)
 };
 
 // MODE 0: s1 = sum x, s2 = sum x^2.   MODE 1: s1 = sum dz, s2 = sum dz*xhat.
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
         float mv[V];
         Vec16<T>::load(mk + off, mv);
 #pragma unroll
-        for (int e = 0; e < V; ++e) gv[e] = mv[e] > 0.f ? gv[e] : 0.f;
+        for (int e = 0; e < V; ++e) gv[e] = mv[e] > 0.f ? gv[e] : gv[e] * p.slope;  // slope 0: ReLU, 0.01: leaky ReLU
       }
       if constexpr (DZ) Vec16<T>::store(dz_out + off, gv);
 #pragma unroll
@@ -270,6 +271,7 @@ struct ApplyArgs {
   size_t nvec;    // M*C/V
   int cvecs;      // C/V
   int relu;
+  float slope;    // of the negative side (RELU == 1 only): 0 ReLU, 0.01 leaky ReLU
 };
 
 // RES: + residual;  X2: + second normalised tensor (downsample branch);  RELU: 0 none, 1 relu, 2 relu + bit mask out
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
         __builtin_nontemporal_store((uint8_t)b, p.bits + i);  // read in backward only
       }
 #pragma unroll
-      for (int e = 0; e < V; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      for (int e = 0; e < V; ++e) v[e] = v[e] > 0.f ? v[e] : (RELU == 1 ? v[e] * p.slope : 0.f);  // (bit-mask form: ReLU only)
     }
     Vec16<T>::store(out + i * V, v);
   }
@@ -339,6 +341,7 @@ struct BwdApplyArgs {
   void* dx;
   size_t nvec;
   int cvecs, C;
+  float slope;  // MASK == 1: gradient factor where the activation was <= 0
 };
 
 template <typename T, int MASK>
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p)
       float mv[V];
       Vec16<T>::load(mk + i * V, mv);
 #pragma unroll
-      for (int e = 0; e < V; ++e) gv[e] = mv[e] > 0.f ? gv[e] : 0.f;
+      for (int e = 0; e < V; ++e) gv[e] = mv[e] > 0.f ? gv[e] : gv[e] * p.slope;
     }
 #pragma unroll
     for (int e = 0; e < V; ++e) {
@@ -484,6 +487,7 @@ int launch_bn_apply(int dtype, const void* x, const float* scale, const float* s
   a.nvec = (size_t)M * C / V;
   a.cvecs = C / V;
   a.relu = relu;
+  a.slope = relu == 2 ? 0.01f : 0.f;  // activation code 2 = leaky ReLU (per-op path; the bit-mask path is ReLU)
   const int blocks = elementwise_blocks(a.nvec, a.cvecs);
   const int rl = relu ? (relu_bits ? 2 : 1) : 0;
   const int variant = (residual ? 6 : 0) + (x2 ? 3 : 0) + rl;
@@ -512,9 +516,10 @@ int launch_bn_apply(int dtype, const void* x, const float* scale, const float* s
 
 int launch_bn_bwd_reduce(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
                          const float* invstd, void* dz_out, float* partial, int* nblk_out, int M, int C,
-                         hipStream_t s, const uint8_t* relu_bits) {
+                         hipStream_t s, const uint8_t* relu_bits, float slope) {
   MI355_TRY(check_c(dtype, C));
   ReduceArgs a{};
+  a.slope = slope;
   a.x = x;
   a.g = g;
   a.mask = mask_src;
@@ -568,10 +573,11 @@ int launch_bn_bwd_finalize(const float* partial, int nblk, int M, int C, const f
 
 int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
                         const float* invstd, const float* coef, void* dx, int M, int C, hipStream_t s,
-                        const uint8_t* relu_bits) {
+                        const uint8_t* relu_bits, float slope) {
   MI355_TRY(check_c(dtype, C));
   const int V = 16 / (int)dtype_size(dtype);
   BwdApplyArgs a{};
+  a.slope = slope;
   a.g = g;
   a.mask = mask_src;
   a.bits = relu_bits;

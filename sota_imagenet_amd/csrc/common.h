@@ -169,12 +169,12 @@ int launch_bn_apply(int dtype, const void* x, const float* scale, const float* s
 // written by launch_bn_apply, read by the two backward kernels in place of the post-activation tensor
 int launch_bn_bwd_reduce(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
                          const float* invstd, void* dz_out, float* partial, int* nblk_out, int M, int C,
-                         hipStream_t s, const uint8_t* relu_bits = nullptr);
+                         hipStream_t s, const uint8_t* relu_bits = nullptr, float slope = 0.f);
 int launch_bn_bwd_finalize(const float* partial, int nblk, int M, int C, const float* gamma, const float* invstd,
                            float* dgamma, float* dbeta, float beta_acc, float* coef /*[3][C]*/, hipStream_t s);
 int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
                         const float* invstd, const float* coef, void* dx, int M, int C, hipStream_t s,
-                        const uint8_t* relu_bits = nullptr);
+                        const uint8_t* relu_bits = nullptr, float slope = 0.f);
 int bn_max_blocks();
 
 // pooling / head / loss / optimizer

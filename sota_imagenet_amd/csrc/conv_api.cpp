@@ -289,9 +289,10 @@ int mi355_bn_bwd(int dtype, const void* dout, const void* out, const void* x, co
   float* coef = partial + (size_t)bn_max_blocks() * 2 * C;
   int nblk = 0;
   const void* mask = relu ? out : nullptr;
-  MI355_TRY(launch_bn_bwd_reduce(dtype, dout, mask, x, save_mean, save_invstd, dz_out, partial, &nblk, M, C, s));
+  const float slope = relu == 2 ? 0.01f : 0.f;  // activation code 2: leaky ReLU
+  MI355_TRY(launch_bn_bwd_reduce(dtype, dout, mask, x, save_mean, save_invstd, dz_out, partial, &nblk, M, C, s, nullptr, slope));
   MI355_TRY(launch_bn_bwd_finalize(partial, nblk, M, C, gamma, save_invstd, dgamma, dbeta, beta_acc, coef, s));
-  return launch_bn_bwd_apply(dtype, dout, mask, x, save_mean, save_invstd, coef, dx, M, C, s);
+  return launch_bn_bwd_apply(dtype, dout, mask, x, save_mean, save_invstd, coef, dx, M, C, s, nullptr, slope);
 }
 
 int mi355_maxpool_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, void* stream) {

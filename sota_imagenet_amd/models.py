@@ -385,6 +385,31 @@ class ResNet50(nn.Module):
         return ms.value, n.value, fl.value, by.value
 
 
+_VARIANT_KEYS = ("stem_type", "antialias", "attn_type", "norm_layer", "norm_act", "drop_rate", "drop_connect_rate", "weight_standardization")
+
+
+def _is_variant(kw):
+    return any(kw.get(k) not in (None, False, "", 0, 0.0, "relu", "abn") for k in _VARIANT_KEYS)
+
+
+def _bresnet50(**kw):
+    """pytorch_tools.models.resnet50 with the BResNet-50 model_params (BResNet50_encoder.yaml:41-51): the one variant graph
+    that is built (deep stem, anti-aliasing, ECA, leaky-ReLU ABN, drop-connect / dropout, optional weight standardisation)."""
+    from .bresnet import BResNet50
+
+    want = dict(stem_type="deep", antialias=True, attn_type="eca", norm_act="leaky_relu")
+    for k, v in want.items():
+        if kw.get(k) != v:
+            raise NotImplementedError(f"resnet50({k}={kw.get(k)!r}): the variant graph on the MI355X path is the BResNet-50 of BASELINE configs[3] "
+                                      f"({', '.join(f'{a}={b!r}' for a, b in want.items())}, norm_layer inplaceabn|abn)")
+    if kw.get("norm_layer") not in ("inplaceabn", "abn", None):
+        raise NotImplementedError(f"resnet50(norm_layer={kw.get('norm_layer')!r}) is outside the MI355X hot path")
+    return BResNet50(**kw)
+
+
 def resnet50(**kwargs):
-    """plugin entry point — same name as the reference's `_target_: pytorch_tools.models.resnet50`."""
+    """plugin entry point — same name as the reference's `_target_: pytorch_tools.models.resnet50`.  Plain kwargs give the
+    torchvision-layout ResNet-50 on the static executor; the BResNet-50 model_params give the variant graph (bresnet.py)."""
+    if _is_variant(kwargs):
+        return _bresnet50(**kwargs)
     return ResNet50(**kwargs)

@@ -184,3 +184,119 @@ def ce_loss(logits, target, smoothing=0.0, grad_scale=1.0, need_grad=True):
 def sgd_step(p, g, m, lr, momentum=0.0, weight_decay=0.0, grad_scale=1.0):
     _need_cuda(p, g, m)
     check(_L().mi355_sgd_step(ptr(p), ptr(g), ptr(m), p.numel(), lr, momentum, weight_decay, grad_scale, cur_stream()))
+
+
+# ---- BResNet-50 variant blocks (include/mi355rn.h, csrc/variant.hip) ---------------------------------------------------
+def blurpool_fwd(x):
+    _need_cuda(x)
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+    check(_L().mi355_blurpool_fwd(dtype_code(x.dtype), ptr(x), ptr(y), N, H, W, C, cur_stream()))
+    return y
+
+
+def blurpool_bwd(dy, x_shape):
+    _need_cuda(dy)
+    N, H, W, C = x_shape
+    dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+    check(_L().mi355_blurpool_bwd(dtype_code(dy.dtype), ptr(dy), ptr(dx), N, H, W, C, cur_stream()))
+    return dx
+
+
+def avgpool2_fwd(x):
+    _need_cuda(x)
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+    check(_L().mi355_avgpool2_fwd(dtype_code(x.dtype), ptr(x), ptr(y), N, H, W, C, cur_stream()))
+    return y
+
+
+def avgpool2_bwd(dy, x_shape):
+    _need_cuda(dy)
+    N, H, W, C = x_shape
+    dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+    check(_L().mi355_avgpool2_bwd(dtype_code(dy.dtype), ptr(dy), ptr(dx), N, H, W, C, cur_stream()))
+    return dx
+
+
+def maxpool3s1_fwd(x):
+    _need_cuda(x)
+    N, H, W, C = x.shape
+    y = torch.empty_like(x)
+    idx = torch.empty((N, H, W, C), dtype=torch.uint8, device=x.device)
+    check(_L().mi355_maxpool3s1_fwd(dtype_code(x.dtype), ptr(x), ptr(y), ptr(idx), N, H, W, C, cur_stream()))
+    return y, idx
+
+
+def maxpool3s1_bwd(dy, idx):
+    _need_cuda(dy, idx)
+    N, H, W, C = dy.shape
+    dx = torch.empty_like(dy)
+    check(_L().mi355_maxpool3s1_bwd(dtype_code(dy.dtype), ptr(dy), ptr(idx), ptr(dx), N, H, W, C, cur_stream()))
+    return dx
+
+
+def eca_fwd(x, w):
+    """returns (y, pooled [N,C] fp32, gate [N,C] fp32)"""
+    _need_cuda(x, w)
+    N, H, W, C = x.shape
+    y = torch.empty_like(x)
+    pooled = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    gate = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    check(_L().mi355_eca_fwd(dtype_code(x.dtype), ptr(x), ptr(w), w.numel(), ptr(y), ptr(pooled), ptr(gate), N, H * W, C, cur_stream()))
+    return y, pooled, gate
+
+
+def eca_bwd(dy, x, w, pooled, gate):
+    """returns (dx, dw [k] fp32)"""
+    _need_cuda(dy, x, w, pooled, gate)
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(w)
+    ws = torch.empty((2, N, C), dtype=torch.float32, device=x.device)
+    check(_L().mi355_eca_bwd(dtype_code(x.dtype), ptr(dy), ptr(x), ptr(w), w.numel(), ptr(pooled), ptr(gate), ptr(dx), ptr(dw), 0.0, ptr(ws),
+                             N, H * W, C, cur_stream()))
+    return dx, dw
+
+
+def weight_std_fwd(w, eps=1e-5):
+    """w: [Cout, ...] fp32 contiguous.  returns (w_hat, invstd [Cout])"""
+    _need_cuda(w)
+    Cout = w.shape[0]
+    K = w.numel() // Cout
+    w_hat = torch.empty_like(w)
+    mean = torch.empty(Cout, dtype=torch.float32, device=w.device)
+    invstd = torch.empty(Cout, dtype=torch.float32, device=w.device)
+    check(_L().mi355_weight_std_fwd(ptr(w), ptr(w_hat), ptr(mean), ptr(invstd), Cout, K, eps, cur_stream()))
+    return w_hat, invstd
+
+
+def weight_std_bwd(dw_hat, w_hat, invstd):
+    _need_cuda(dw_hat, w_hat, invstd)
+    Cout = w_hat.shape[0]
+    dw = torch.empty_like(w_hat)
+    check(_L().mi355_weight_std_bwd(ptr(dw_hat), ptr(w_hat), ptr(invstd), ptr(dw), 0.0, Cout, w_hat.numel() // Cout, cur_stream()))
+    return dw
+
+
+def residual_act_fwd(branch, shortcut=None, scale_n=None, act=1):
+    _need_cuda(branch, shortcut, scale_n)
+    N = branch.shape[0]
+    out = torch.empty_like(branch)
+    check(_L().mi355_residual_act_fwd(dtype_code(branch.dtype), ptr(branch), ptr(scale_n), ptr(shortcut), ptr(out), N, branch.numel() // N, act, cur_stream()))
+    return out
+
+
+def residual_act_bwd(dout, out, scale_n=None, act=1, want_shortcut=True):
+    _need_cuda(dout, out, scale_n)
+    N = out.shape[0]
+    db = torch.empty_like(out)
+    ds = torch.empty_like(out) if want_shortcut else None
+    check(_L().mi355_residual_act_bwd(dtype_code(out.dtype), ptr(dout), ptr(out), ptr(scale_n), ptr(db), ptr(ds), N, out.numel() // N, act, cur_stream()))
+    return db, ds
+
+
+def keep_scale(n, p, seed, counter, device):
+    keep = torch.empty(n, dtype=torch.float32, device=device)
+    check(_L().mi355_keep_scale(ptr(keep), n, float(p), int(seed), int(counter), cur_stream()))
+    return keep

@@ -1,0 +1,191 @@
+"""BResNet-50 variant blocks (BASELINE configs[3]; csrc/variant.hip, bresnet.py) on the GPU against the torch-CPU oracle
+(oracle/ops_ref.py per op, oracle/bresnet50_ref.py whole model).  Tolerances as in test_ops_gpu.py: normalised max error
+fp32 2e-5 (1e-4 where a backward sums many terms), bf16 2e-2."""
+import pytest
+import torch
+
+from oracle import bresnet50_ref as B
+from oracle import ops_ref as R
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+def nerr(got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+
+
+def rnd(shape, seed, dtype, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(shape, generator=g) * 2 - 1) * scale).to(dtype).float()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 8, 8, 64), (3, 14, 6, 128), (1, 2, 2, 64)])
+def test_pools(dev, dtype, shape):
+    from sota_imagenet_amd import ops
+
+    x = rnd(shape, 1, dtype)
+    xd = x.to(dev, dtype)
+    for name, fwd, bwd, ref in (("blurpool", ops.blurpool_fwd, ops.blurpool_bwd, R.blurpool), ("avgpool2", ops.avgpool2_fwd, ops.avgpool2_bwd, R.avgpool2)):
+        y_ref = ref(x)
+        dy = rnd(tuple(y_ref.shape), 2, dtype)
+        assert nerr(fwd(xd), y_ref) < TOL[dtype], name
+        (dx_ref,) = R.grads(ref, [x], dy)
+        assert nerr(bwd(dy.to(dev, dtype), shape), dx_ref) < TOL[dtype], name + " bwd"
+    xr = torch.relu(x)  # ties inside windows
+    y, idx = ops.maxpool3s1_fwd(xr.to(dev, dtype))
+    assert nerr(y, R.maxpool3s1(xr)) == 0.0
+    dy = rnd(shape, 3, dtype)
+    dx = ops.maxpool3s1_bwd(dy.to(dev, dtype), idx)
+    assert abs(dx.float().sum().item() - dy.sum().item()) < 1e-2 * dy.abs().sum().item()  # every gradient lands exactly once
+    xu = rnd(shape, 4, dtype) + torch.arange(shape[1] * shape[2]).view(1, shape[1], shape[2], 1) * 1e-2  # no ties: unique argmax
+    xu = xu.to(dtype).float()
+    y, idx = ops.maxpool3s1_fwd(xu.to(dev, dtype))
+    (dx_ref,) = R.grads(R.maxpool3s1, [xu], dy)
+    assert nerr(ops.maxpool3s1_bwd(dy.to(dev, dtype), idx), dx_ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k", [3, 5])
+def test_eca(dev, dtype, k):
+    from sota_imagenet_amd import ops
+
+    x = rnd((3, 7, 7, 256), 5, dtype)
+    w = rnd((k,), 6, torch.float32, 0.8)
+    dy = rnd((3, 7, 7, 256), 7, dtype)
+    y, pooled, gate = ops.eca_fwd(x.to(dev, dtype), w.to(dev))
+    assert nerr(y, R.eca(x, w)) < TOL[dtype]
+    dx_ref, dw_ref = R.grads(R.eca, [x, w], dy)
+    dx, dw = ops.eca_bwd(dy.to(dev, dtype), x.to(dev, dtype), w.to(dev), pooled, gate)
+    assert nerr(dx, dx_ref) < max(TOL[dtype], 1e-4) and nerr(dw, dw_ref) < max(TOL[dtype], 1e-4)
+
+
+def test_weight_std(dev):
+    from sota_imagenet_amd import ops
+
+    for shape in [(64, 3, 3, 32), (256, 1, 1, 64), (512, 3, 3, 512)]:
+        w = rnd(shape, 8, torch.float32, 0.3) + 0.05
+        g = rnd(shape, 9, torch.float32)
+        w_hat, invstd = ops.weight_std_fwd(w.to(dev))
+        assert nerr(w_hat, R.weight_std(w)) < 2e-5
+        (dw_ref,) = R.grads(R.weight_std, [w], g)
+        assert nerr(ops.weight_std_bwd(g.to(dev), w_hat, invstd), dw_ref) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_residual_act_and_leaky_bn(dev, dtype, act):
+    from sota_imagenet_amd import ops
+
+    shape = (4, 6, 6, 128)
+    b, s, dout = rnd(shape, 10, dtype), rnd(shape, 11, dtype), rnd(shape, 12, dtype)
+    keep = torch.tensor([0.0, 1.25, 1.25, 0.0])
+    out = ops.residual_act_fwd(b.to(dev, dtype), s.to(dev, dtype), keep.to(dev), act)
+    ref = R.residual_act(b, keep, s, act)
+    assert nerr(out, ref) < TOL[dtype]
+    db_ref, ds_ref = R.grads(lambda u, v: R.residual_act(u, keep, v, act), [b, s], dout)
+    db, ds = ops.residual_act_bwd(dout.to(dev, dtype), ref.to(dev, dtype), keep.to(dev), act)
+    assert nerr(db, db_ref) < TOL[dtype] and nerr(ds, ds_ref) < TOL[dtype]
+    # ABN: batch norm + activation code (leaky ReLU = the norm_act of the BResNet-50 recipe)
+    x = rnd(shape, 13, dtype, 2.0) + 0.3
+    g, be = rnd((128,), 14, torch.float32, 0.5) + 1.5, rnd((128,), 15, torch.float32)
+    rm, rv = torch.zeros(128), torch.ones(128)
+    o_ref, rm_ref, rv_ref = R.bn_act_train(x, g, be, rm, rv, None, act)
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    o, mean, invstd = ops.bn_fwd_train(x.to(dev, dtype), g.to(dev), be.to(dev), rmd, rvd, relu=act)
+    assert nerr(o, o_ref) < TOL[dtype] and nerr(rvd, rv_ref) < 1e-4
+    dx_ref, dg_ref, db_ref = R.grads(lambda u, v, w: R.bn_act_train(u, v, w, rm, rv, None, act)[0], [x, g, be], dout)
+    dx, dg, dbe, _ = ops.bn_bwd(dout.to(dev, dtype), o_ref.to(dev, dtype), x.to(dev, dtype), g.to(dev), mean, invstd, relu=act)
+    assert nerr(dx, dx_ref) < max(TOL[dtype], 1e-4) and nerr(dg, dg_ref) < max(TOL[dtype], 1e-4) and nerr(dbe, db_ref) < max(TOL[dtype], 1e-4)
+
+
+def test_keep_scale_statistics(dev):
+    from sota_imagenet_amd import ops
+
+    k = ops.keep_scale(200000, 0.2, 3, 5, dev)
+    vals = set(torch.unique(k).cpu().tolist())
+    assert vals <= {0.0, 1.25} and abs((k > 0).float().mean().item() - 0.8) < 5e-3 and abs(k.mean().item() - 1.0) < 1e-2
+    assert torch.equal(k, ops.keep_scale(200000, 0.2, 3, 5, dev)) and not torch.equal(k, ops.keep_scale(200000, 0.2, 3, 6, dev))
+
+
+def _models(dtype):
+    from sota_imagenet_amd.models import resnet50
+
+    m = resnet50(stem_type="deep", antialias=True, attn_type="eca", norm_layer="inplaceabn", norm_act="leaky_relu", drop_rate=0.2,
+                 drop_connect_rate=0.2, weight_standardization=True, dtype=dtype)
+    ref = B.BResNet50Ref(standardize=True)
+    ref.load_state_dict({k: v.detach().clone().contiguous() for k, v in m.state_dict().items()})
+    return m.cuda(), ref
+
+
+def _masks(N, seed):
+    g = torch.Generator().manual_seed(seed)
+    dc = [None] + [((torch.rand(N, generator=g) >= 0.2 * i / 16).float() / (1 - 0.2 * i / 16)) for i in range(1, 16)]
+    do = (torch.rand(N, 2048, generator=g) >= 0.2).float() / 0.8
+    return {"dc": dc, "do": do}
+
+
+def test_bresnet50_fp32_matches_oracle(dev):
+    """whole model, training mode, given drop-connect / dropout masks: logits within 1e-3 rel (the north_star bar), loss,
+    running statistics, and gradients judged against an fp64 run with the oracle's own fp32 distance as yardstick"""
+    from sota_imagenet_amd.synth import synthetic_batch
+
+    N, S = 4, 64
+    m, ref = _models("fp32")
+    data, target = synthetic_batch(N, S, seed=0, index=1)
+    masks = _masks(N, 1)
+    m.masks = {"dc": [None if k is None else k.to(dev) for k in masks["dc"]], "do": masks["do"].to(dev)}
+    m.train(), ref.train()
+    out = m(data.cuda())
+    loss = R.smooth_ce(out, target.cuda(), 0.1)
+    loss.backward()
+    o32 = ref(data, masks)
+    l32 = R.smooth_ce(o32, target, 0.1)
+    l32.backward()
+    ref64 = B.BResNet50Ref(standardize=True).double()
+    ref64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in m.state_dict().items()}, strict=True)
+    ref64.load_state_dict({k: (v.detach().cpu().double() if v.is_floating_point() else v.cpu()) for k, v in ref.state_dict().items()})
+    assert nerr(out, o32) < 1e-3, "logits"
+    assert abs(loss.item() - l32.item()) < 1e-4 * l32.item()
+    assert nerr(m.bn1.running_var, ref.bn1.running_var) < 1e-4
+    gn = torch.cat([p.grad.detach().float().cpu().flatten() for p in m.parameters()])
+    gr = torch.cat([p.grad.detach().flatten() for p in ref.parameters()])
+    rel = ((gn - gr).norm() / gr.norm()).item()
+    assert rel < 2e-2, f"gradients vs the fp32 oracle: rel L2 {rel:.3e}"
+    for name in ("fc.weight", "layer4.2.se_module.conv.weight", "layer4.2.conv3.weight", "conv1.0.weight"):
+        a, b = dict(m.named_parameters())[name].grad, dict(ref.named_parameters())[name].grad
+        assert nerr(a, b) < 5e-2, name
+
+
+def test_bresnet50_bf16_trains(dev):
+    """bf16 compute, on-device drop-connect / dropout sampling, two SGD steps with the native optimizer; eval mode runs"""
+    from sota_imagenet_amd.losses import CrossEntropyLoss
+    from sota_imagenet_amd.optim import SGD
+    from sota_imagenet_amd.synth import synthetic_batch
+
+    m, ref = _models("bf16")
+    opt = SGD([{"params": list(m.parameters())}], lr=0.01, momentum=0.9, weight_decay=3e-5)
+    crit = CrossEntropyLoss(smoothing=0.1)
+    m.train()
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    for i in range(2):
+        data, target = synthetic_batch(4, 64, seed=0, index=i, device="cuda")
+        loss = crit(m(data), target)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        assert torch.isfinite(loss)
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+    assert not torch.equal(before["layer3.1.conv2.weight"], dict(m.named_parameters())["layer3.1.conv2.weight"].detach())
+    # no masks (rate 0 through eval): bf16 logits track the fp32 oracle of the same parameters
+    ref.load_state_dict({k: v.detach().cpu().clone().contiguous() for k, v in m.state_dict().items()})
+    m.eval(), ref.eval()
+    data, _ = synthetic_batch(4, 64, seed=0, index=7)
+    with torch.no_grad():
+        a, b = m(data.cuda()).float().cpu(), ref(data)
+    assert ((a - b).norm() / b.norm()).item() < 0.1

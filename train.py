@@ -113,9 +113,13 @@ def main(argv=None):
     model_cfg = C.to_plain(cfg.model)
     if "dtype" not in model_cfg and C.resolve_target(model_cfg["_target_"]).__module__.startswith("sota_imagenet_amd"):
         model_cfg["dtype"] = "bf16" if cfg.run.fp16 else "fp32"  # the AMP flag of the reference (arg_parser.py:89-90)
-    model = C.call(model_cfg)
     if cfg.weight_standardization:
-        raise NotImplementedError("weight standardisation is outside the hot path (SURVEY.md §8f next-2)")
+        # the reference converts the built model (conv_to_ws_conv, train.py:66-67); here standardisation is a property of
+        # the variant graph's conv nodes, so the flag travels into the model factory
+        if not C.resolve_target(model_cfg["_target_"]).__module__.startswith("sota_imagenet_amd"):
+            raise NotImplementedError("weight standardisation needs one of this package's model plugins")
+        model_cfg["weight_standardization"] = True
+    model = C.call(model_cfg)
     if cfg.init_gamma is not None and hasattr(model, "reset_parameters"):
         model.reset_parameters(seed=cfg.random_seed or 0, gamma=cfg.init_gamma)
     model = model.cuda()
