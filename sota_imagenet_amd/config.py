@@ -161,6 +161,8 @@ def legacy_to_hydra(d):
             extra["image_size"] = ph["sz"]
         if "bs" in ph:
             extra["batch_size"] = ph["bs"]
+        if "val_sz" in ph:  # e.g. BResNet50_encoder.yaml:63: validate on larger images than trained on
+            out.setdefault("val_loader", {})["image_size"] = ph["val_sz"]
         if ph["ep"] == 0:
             out["loader"].update(extra)
         else:  # a later data phase becomes extra_args of the stage that starts there (split the stage if needed)

@@ -47,13 +47,16 @@ class FlatBucketDDP(nn.Module):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group)
+        self._comm = None
+        if not hasattr(module, "flat_grads"):  # a model of separate parameter tensors (bresnet.BResNet50)
+            self._generic_init(bucket_cap_mb, broadcast)
+            return
         flat = module.flat_grads
         self._cuda = flat.is_cuda
         self._buckets = plan_buckets(module.grad_segments, int(bucket_cap_mb * (1 << 20) / 4))
         self._by_last = {last: (b, e) for b, e, last in self._buckets}
         self._nseg = len(module.grad_segments)
         self._side = None
-        self._comm = None
         backend = dist.get_backend(process_group)
         self._avg = backend == "nccl"  # ReduceOp.AVG is an (R)CCL op; gloo sums and we scale
         if self._cuda and hasattr(module, "set_comm"):
@@ -91,12 +94,75 @@ class FlatBucketDDP(nn.Module):
         native_plan = self.module.bucket_plan(bucket_cap_mb)
         assert native_plan == self._buckets, (native_plan, self._buckets)  # one plan, stated twice (C++ / plan_buckets)
 
+    # ---- models without a flat gradient array (the per-op BResNet-50 graph): gradients are coalesced into one fp32 buffer
+    # when backward has finished, reduced with ONE native mean all-reduce (RCCL through the C-ABI), and copied back.
+    # No overlap with backward — that graph is driven op by op from Python and is launch-bound anyway.
+    def _generic_init(self, bucket_cap_mb, broadcast):
+        from . import native
+
+        params = [p for p in self.module.parameters() if p.requires_grad]
+        dev = params[0].device
+        if not dev.type == "cuda":
+            raise RuntimeError("FlatBucketDDP: the model must be on the GPU (no CPU data-parallel path)")
+        L = native.lib()
+        if not L.mi355_comm_available():
+            raise RuntimeError("FlatBucketDDP: librccl.so.1 not found (the MI355X data-parallel path has no fallback)")
+        rank = dist.get_rank(self.group)
+        uid = (ctypes.c_char * 128)()
+        if rank == 0:
+            native.check(L.mi355_comm_unique_id(uid))
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0, group=self.group)
+        comm = ctypes.c_void_p()
+        native.check(L.mi355_comm_create(ctypes.byref(comm), box[0], self.world, rank, dev.index or 0))
+        self._comm = comm
+        self._params = params
+        self._gbuf = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+        self._buckets = [(0, self._gbuf.numel(), 0)]
+        self._pending = False
+        if broadcast:
+            state = [t for t in self.module.state_dict().values() if t.is_floating_point()]
+            flat = torch.cat([t.detach().reshape(-1).float() for t in state])
+            native.check(L.mi355_comm_broadcast(comm, native.ptr(flat), flat.numel(), 0, native.cur_stream()))
+            off = 0
+            with torch.no_grad():
+                for t in state:
+                    t.copy_(flat[off: off + t.numel()].view(t.shape))
+                    off += t.numel()
+        for p in params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _on_grad(self, _p):
+        if not self._pending:
+            self._pending = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._reduce_all)
+
+    @torch.no_grad()
+    def _reduce_all(self):
+        from . import native
+
+        self._pending = False
+        off = 0
+        for p in self._params:
+            n = p.numel()
+            if p.grad is not None:
+                self._gbuf[off: off + n].view(p.grad.shape).copy_(p.grad)  # same memory order as the parameter (strides kept)
+            off += n
+        native.check(native.lib().mi355_comm_allreduce_mean(self._comm, native.ptr(self._gbuf), self._gbuf.numel(), native.cur_stream()))
+        off = 0
+        for p in self._params:
+            n = p.numel()
+            if p.grad is not None:
+                p.grad.copy_(self._gbuf[off: off + n].view(p.grad.shape))
+            off += n
+
     def __del__(self):
         try:
             if self._comm is not None:
                 from . import native
 
-                self.module.set_comm(None)
+                if hasattr(self.module, "set_comm"):
+                    self.module.set_comm(None)
                 native.lib().mi355_comm_destroy(self._comm)
                 self._comm = None
         except Exception:

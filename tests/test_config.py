@@ -66,3 +66,23 @@ def test_target_aliases_resolve_to_native_plugins():
     assert isinstance(C.call({"_target_": "pytorch_tools.fit_wrapper.callbacks.Callback"}), fit_wrapper.Callback)
     crit = C.call({"_target_": "pytorch_tools.losses.smooth.CrossEntropyLoss", "smoothing": 0.1})
     assert crit.smoothing == 0.1
+
+
+def test_bresnet50_encoder_legacy_recipe_maps_onto_the_plugin_surface():
+    """BASELINE configs[3]: the legacy-schema recipe (reference configs/_old_configs/_first_attempts/BResNet50_encoder.yaml:41-71)"""
+    import os
+
+    from sota_imagenet_amd import config as C
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = C.compose(os.path.join(root, "configs", "bresnet50_encoder_legacy.yaml"), [])
+    m = C.to_plain(cfg.model)
+    assert m["_target_"] == "pytorch_tools.models.resnet50" and m["stem_type"] == "deep" and m["antialias"] is True and m["attn_type"] == "eca"
+    assert m["norm_act"] == "leaky_relu" and m["drop_rate"] == 0.2 and m["drop_connect_rate"] == 0.2
+    assert cfg.weight_standardization is True and cfg.run.ema_decay == 0.9999 and cfg.criterion.smoothing == 0.1
+    assert cfg.loader.image_size == 224 and cfg.loader.batch_size == 256 and cfg.val_loader.image_size == 288
+    assert [(s["start"], s["end"]) for s in C.to_plain(cfg.run.stages)] == [(0, 8), (8, 100), (100, 150), (150, 200)]
+    assert C.to_plain(cfg.run.extra_callbacks)[0]["_target_"].endswith("Cutmix")
+    # the plugin builds the variant graph for these model_params (no GPU needed to construct it)
+    model = C.call({k: v for k, v in m.items()}, weight_standardization=True, dtype="bf16")
+    assert type(model).__name__ == "BResNet50" and abs(sum(p.numel() for p in model.parameters()) - 25.58e6) < 0.02e6

@@ -162,6 +162,76 @@ def test_native_rccl_allreduce_two_ranks_numeric(dev):
     assert out.returncode == 0 and "DDP-OK rank 0" in out.stdout and "DDP-OK rank 1" in out.stdout, (out.stdout[-800:], out.stderr[-2500:])
 
 
+def test_train_py_runs_the_bresnet50_smoke_config(dev, tmp_path):
+    """BASELINE configs[3] end to end at toy size: the variant model_params + weight standardisation + EMA + CutmixMixup
+    through train.py / Runner, validation at a larger image size, checkpoint in the reference's format"""
+    sys.path.insert(0, ROOT)
+    import train
+
+    logdir = os.path.relpath(str(tmp_path), ROOT)
+    val_loss, metrics = train.main(["+hydra_exp=bresnet50_test", f"log.dir={logdir}", "run.fp16=true", "random_seed=0", "data.pool=2"])
+    assert val_loss == val_loss and 0.0 <= metrics["Acc@1"].avg <= 100.0
+    run = glob.glob(os.path.join(str(tmp_path), "*_bresnet50_test", "*"))[0]
+    logs = open(os.path.join(run, "logs.txt")).read()
+    assert "Train loss:" in logs and "Model params: 25.58M" in logs
+    ck = torch.load(os.path.join(run, "model.chpn"), map_location="cpu")
+    assert {"epoch", "state_dict"} <= set(ck) and "layer4.2.se_module.conv.weight" in ck["state_dict"] and "conv1.0.weight" in ck["state_dict"]
+
+
+_DDP_VARIANT_CHECK = r"""
+import os, torch, torch.distributed as dist
+from sota_imagenet_amd.losses import CrossEntropyLoss
+from sota_imagenet_amd.models import resnet50
+from sota_imagenet_amd.parallel import FlatBucketDDP
+from sota_imagenet_amd.synth import synthetic_batch
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
+kw = dict(stem_type="deep", antialias=True, attn_type="eca", norm_layer="inplaceabn", norm_act="leaky_relu", drop_rate=0.0, drop_connect_rate=0.0,
+          weight_standardization=True, dtype="fp32")
+crit = CrossEntropyLoss(smoothing=0.1)
+batches = [synthetic_batch(2, 64, seed=41, stream=r, index=0, device="cuda") for r in range(world)]
+ref = resnet50(**kw).cuda(); ref.train()
+gsum = None
+for data, target in batches:
+    ref.zero_grad()
+    crit(ref(data), target).backward()
+    g = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    gsum = g.clone() if gsum is None else gsum + g
+gmean = gsum / world
+m = resnet50(**kw).cuda(); m.train()
+with torch.no_grad():
+    for p in m.parameters():
+        p.mul_(1.0 + 0.1 * rank)
+ddp = FlatBucketDDP(m, device_ids=[torch.cuda.current_device()])
+assert all(torch.equal(a, b) for a, b in zip(m.parameters(), ref.parameters())), "rank-0 broadcast"
+data, target = batches[rank]
+crit(ddp(data), target).backward()
+torch.cuda.synchronize()
+g = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+err = ((g - gmean).abs().max() / gmean.abs().max()).item()
+assert err < 1e-6, err
+print(f"DDPV-OK rank {rank} err {err:.2e}")
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_native_rccl_allreduce_variant_model_single_rank(dev):
+    """the BResNet-50 graph has no flat gradient array: FlatBucketDDP coalesces, reduces through the native communicator and
+    scatters back after backward (1-rank RCCL rehearsal with numbers; 2 ranks where available)"""
+    path = os.path.join(ROOT, "tests", "_ddpv_check.py")
+    with open(path, "w") as f:
+        f.write(_DDP_VARIANT_CHECK)
+    try:
+        n = 2 if torch.cuda.device_count() >= 2 else 1
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", PYTHONPATH=ROOT)
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                              "--master-port", "29541", path], capture_output=True, text=True, env=env, timeout=900)
+    finally:
+        os.remove(path)
+    assert out.returncode == 0 and "DDPV-OK rank 0" in out.stdout, (out.stdout[-800:], out.stderr[-2500:])
+
+
 def test_progressive_resize_and_val_batch_shapes(dev):
     """stage change (dali_dataloader.py:213-239): the same model runs at 64 px and 96 px and at another batch size; each
     shape gets its own native context, parameters stay shared."""
