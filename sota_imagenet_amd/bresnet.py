@@ -260,13 +260,20 @@ class BResNet50(nn.Module):
         self.masks = None  # test hook: {"dc": [per block [N] fp32 or None], "do": [N, 2048] fp32 or None} overrides the sampler
         self.reset_parameters()
 
-    def reset_parameters(self):
-        g = torch.Generator().manual_seed(self.seed)
+    def reset_parameters(self, seed=None, gamma=1.41421356):
+        """train.py:69-71 `pt.utils.misc.initialize(model, cfg.init_gamma)`: kaiming-style conv init with gain `gamma`
+        (fan-out), BN weight 1 / bias 0.  The exact law of the un-vendored helper is unknown: initial
+        weights are an input of the parity tests, not a parity claim."""
+        g = torch.Generator().manual_seed(self.seed if seed is None else int(seed))
         for m in self.modules():
             if isinstance(m, _Conv):
                 fan_out = m.weight.shape[0] * m.weight.shape[2] * m.weight.shape[3]
                 with torch.no_grad():
-                    m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / fan_out) ** 0.5)
+                    m.weight.copy_(torch.randn(m.weight.shape, generator=g) * float(gamma) / fan_out ** 0.5)
+            elif isinstance(m, _ABN):
+                with torch.no_grad():
+                    m.weight.fill_(1.0)
+                    m.bias.zero_()
             elif isinstance(m, _ECA):
                 with torch.no_grad():
                     m.conv.weight.copy_((torch.rand(m.conv.weight.shape, generator=g) * 2 - 1) * (1.0 / 3.0) ** 0.5)
