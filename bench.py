@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra fp32 (configs[1]) measurement")
+    ap.add_argument("--model", default="resnet50", choices=["resnet50", "bresnet50"],
+                    help="bresnet50: BASELINE configs[3] (variant graph, CutmixMixup on) — reported with its own workload name, no roofline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,10 +146,19 @@ def main():
 
     def run(dtype, steps, warmup, want_roof):
         """W untimed + exactly K timed training steps in `dtype`; returns (seconds, final loss, model)."""
-        model = resnet50(dtype=dtype).cuda()
+        variant = args.model == "bresnet50"
+        kw = dict(stem_type="deep", antialias=True, attn_type="eca", norm_layer="inplaceabn", norm_act="leaky_relu", drop_rate=0.2,
+                  drop_connect_rate=0.2, weight_standardization=True) if variant else {}
+        model = resnet50(dtype=dtype, **kw).cuda()
         criterion = CrossEntropyLoss(smoothing=0.1).cuda()
-        opt = SGD([{"params": list(model.parameters())}], lr=0.0, momentum=0.9, weight_decay=3e-5)
-        opt.attach_model(model)
+        if variant:  # separate parameter tensors: torch's foreach SGD (one fused launch per group) instead of 177 native launches
+            opt = torch.optim.SGD(model.parameters(), lr=0.0, momentum=0.9, weight_decay=3e-5)
+            from sota_imagenet_amd.callbacks import CutmixMixup
+            mixer = CutmixMixup(1.0, 0.2, prob=0.5)
+        else:
+            opt = SGD([{"params": list(model.parameters())}], lr=0.0, momentum=0.9, weight_decay=3e-5)
+            opt.attach_model(model)
+            mixer = None
         net = model
         if use_ddp:
             from sota_imagenet_amd.parallel import FlatBucketDDP
@@ -158,6 +169,8 @@ def main():
 
         def step(i):
             data, target = pool[i % len(pool)]
+            if mixer is not None:  # BASELINE configs[3]: "mixup/cutmix on" — on-device sampling + one mix kernel per batch
+                data, target = mixer._dev(data, target, 1.0, 0.2, 0.5, 3)
             lr = 0.001 + 0.0001 * (i % 8)  # the scheduler writes a new LR every batch (train.py:131)
             for g in opt.param_groups:
                 g["lr"] = lr
@@ -195,6 +208,8 @@ def main():
         return dt, loss.item(), model, dom
 
     shape = (N, S, S)
+    if args.model == "bresnet50":
+        args.no_roofline = args.no_secondary = True
     want_roof = (not args.no_roofline) and rank == 0
     dt, final_loss, model, dom = run(args.dtype, args.steps, args.warmup, want_roof)
 
@@ -255,6 +270,19 @@ def main():
         roof_class = dom
         if want_roof:
             roof, roof_hbm = roof_of(model, dom, args.dtype)
+        if args.model == "bresnet50":
+            print(json.dumps({"metric": "images/sec (whole node) BResNet-50 bs=%d/GPU @%dpx" % (N, S), "value": round(value, 1), "unit": "images/sec",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                              "config": {"workload": "BASELINE configs[3]: BResNet-50 (deep stem, anti-alias, ECA, leaky ABN, WS, drop-connect) train step "
+                                                     "with CutmixMixup on, per-op C-ABI graph", "global_batch": world * N, "image_size": S,
+                                         "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)}, "roofline": None, "cpu_baseline": None}), flush=True)
+            if use_ddp:
+                import torch.distributed as dist
+
+                dist.barrier()
+                dist.destroy_process_group()
+            return
         _, train_flops = model.flops(N, S, S)
         out = {
             "metric": "images/sec (whole node) ResNet-50 bs=256/GPU @224px",
