@@ -44,7 +44,8 @@ typedef enum mi355_status {
   MI355_E_NOMEM = -4  /* workspace too small / allocation failed */
 } mi355_status;
 
-typedef enum mi355_dtype { MI355_F32 = 0, MI355_BF16 = 1 } mi355_dtype;
+/* MI355_FP8: OCP e4m3fn operand bytes — accepted by the *_fp8 entry points only (their outputs are bf16) */
+typedef enum mi355_dtype { MI355_F32 = 0, MI355_BF16 = 1, MI355_FP8 = 2 } mi355_dtype;
 
 /* ---- library ------------------------------------------------------------------------------------ */
 const char* mi355_last_error(void);
@@ -76,6 +77,19 @@ int mi355_conv2d_dgrad(int dtype, const void* dy, const void* w, void* dx, const
 int mi355_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw, float beta, int N, int H,
                        int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* ws,
                        size_t ws_bytes, void* stream);
+
+/* fp8 (OCP e4m3fn) operand path of the convolution — BASELINE.json configs[4] "fp8 MFMA convs" (the reference has no fp8
+ * path; the conv calls being replaced are the same as above, callbacks.py:316-317).  Per-tensor scaling:
+ *   q = mi355_quantize_fp8(x * scale)  (saturating, round to nearest even; n a multiple of 8; source f32 or bf16)
+ *   y_bf16 = conv(xq, wq) * oscale,  oscale = 1 / (scale_x * scale_w), fp32 accumulation on v_mfma_f32_16x16x32_fp8_fp8.
+ * Layouts as above with 1-byte elements (x NHWC, w KRSC; dgrad takes the weights already transposed to [Cin][KH][KW][Cout]);
+ * Cin and Cout multiples of 128, output width >= 2 (MI355_E_ARG otherwise: there is no second fp8 kernel to fall back on).
+ * Same 8-wave kernel as the bf16 path with half the operand bytes (conv_igemm8.hip).   */
+int mi355_quantize_fp8(int src_dtype, const void* x, void* q, float scale, size_t n, void* stream);
+int mi355_conv2d_fwd_fp8(const void* xq, const void* wq, void* y, float oscale, int N, int H, int W, int Cin, int Cout,
+                         int KH, int KW, int stride, int pad, void* stream);
+int mi355_conv2d_dgrad_fp8(const void* dyq, const void* wtq, void* dx, float oscale, int N, int H, int W, int Cin,
+                           int Cout, int KH, int KW, int stride, int pad, void* stream);
 
 /* the 7x7/2 stem on the loader's NCHW fp32 batch: ingest (NCHW fp32 -> zero-padded NHWC4 `dtype`),
  * forward y[N,H/2,W/2,64], and wgrad dw[64,7,7,3] fp32.  xpad is scratch of

@@ -217,3 +217,31 @@ def grads(fn, inputs, dout):
     y = fn(*xs)
     y.backward(dout.float())
     return [t.grad for t in xs]
+
+
+# ---- fp8 (OCP e4m3fn) operand form of the convolution (BASELINE.json configs[4]; csrc/fp8.hip) -----------------------------
+def quantize_e4m3(x, scale=1.0):
+    """saturating round-to-nearest-even of x*scale onto the e4m3fn grid (max 448, min subnormal 2^-9), returned as the fp32
+    VALUES on that grid.  Restated from the format definition (OCP 8-bit floating point spec v1.0 §5: bias 7, 3 mantissa
+    bits, no infinities); tests/test_fp8_oracle.py pins it to torch's own float8_e4m3fn cast."""
+    v = (x.float() * scale).double().clamp(-448.0, 448.0)  # the product is taken in fp32, then rounded ONCE onto the grid
+    a = v.abs()
+    e = torch.floor(torch.log2(a.clamp_min(2.0 ** -20))).clamp_min(-6.0)  # subnormals share the 2^-6 binade
+    step = torch.pow(2.0, e - 3.0)
+    q = torch.round(a / step) * step  # torch.round is half-to-even
+    return (torch.sign(v) * q).float()
+
+
+def e4m3_bits(vals):
+    """the byte encoding of values already on the e4m3fn grid"""
+    return vals.to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def conv2d_fwd_fp8(xq_vals, wq_vals, stride, pad, oscale):
+    """what mi355_conv2d_fwd_fp8 computes: products of grid values (exact in fp32), fp32 accumulation, * oscale"""
+    return conv2d_fwd(xq_vals, wq_vals, stride, pad) * oscale
+
+
+def conv2d_dgrad_fp8(dyq_vals, wq_vals, x_shape, stride, pad, oscale):
+    dx, _ = conv2d_bwd(torch.zeros(x_shape), wq_vals, dyq_vals, stride, pad)
+    return dx * oscale

@@ -63,6 +63,7 @@ struct Igemm8KArgs {
   unsigned bytes_in, bytes_wt;
   unsigned magW, magHW;  // floor(2^32 / d) + 1 for d = Wsub, Hsub * Wsub (exact quotients while m * d < 2^32)
   int HW;
+  float oscale;          // fp8 operands: 1 / (scale_x * scale_w), applied to the accumulators
   int korder;            // 0: taps outer, channel chunks inner;  1: channel chunks outer, taps inner (A re-reads stay close)
 };
 
@@ -79,6 +80,8 @@ __device__ unsigned long long g8_stamps[2 * 1024];
 #else
 #define STAMP8(slot)
 #endif
+
+typedef long i64x2 __attribute__((ext_vector_type(2)));
 
 constexpr std::integral_constant<int, 0> I0{};
 constexpr std::integral_constant<int, 1> I1{};
@@ -101,7 +104,9 @@ __device__ __forceinline__ float row_sum16(float x) {  // lane 15 of every 16-la
   return x;
 }
 
-template <int BM, int BN, int STATS, int FAT>
+// EB: bytes per operand element — 2: bf16;  1: OCP fp8 e4m3 operands (v_mfma_f32_16x16x32_fp8_fp8, same matrix rate, half
+// the operand bytes: a 128-byte LDS row holds 128 channels and one ds_read_b128 feeds TWO MFMAs), bf16 output scaled by oscale
+template <int BM, int BN, int STATS, int FAT, int EB = 2>
 __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
   const IgemmArgs& p = kp.a;
   // FAT: phases of up to 32 MFMAs per wave (2 per k-tile at BN 256, 1 at BN 128) — half the barriers of the 16-MFMA
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
   constexpr int GL = NPH == 4 ? 2 : 3;          // LDS-DMA pieces per wave per group
   constexpr int WAITN = FAT ? (BN == 256 ? 8 : 6) : 2 * GL;  // pieces younger than the group a wait retires
   constexpr int NST = MT * NT / 2;              // 16-byte stores per thread per tile
-  constexpr int BK = 64;
+  constexpr int BK = 128 / EB;                  // elements of K per k-tile (one 128-byte LDS row)
   static_assert(BM == 256 || BM == 224, "BM");
   static_assert(BN == 256 || BN == 128, "BN");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
   unsigned a_off[4];  // [h*2 + i]: byte offset of the row's pixel at tap offset (0,0) + this lane's (swizzled) 16-byte chunk
   unsigned a_inv[4];  // bit t set: tap t of the unit's class falls outside the image for this row (all set: no such row)
   unsigned b_off[2];  // [i]: this lane's weight row of piece i of quarter 0, n-tile 0, tap 0 (+ swizzled chunk)
-  const unsigned w_row = (unsigned)(p.wtaps * p.Ck * 2);  // bytes of one weight row
+  const unsigned w_row = (unsigned)(p.wtaps * p.Ck * EB);  // bytes of one weight row
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     int row, sw;
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
           aw[x] = jj * p.IS;
           inv[x] = 0;
           const int chunk = pch ^ ((prow >> 1) | (i << 2));
-          a_off[x] = (unsigned)((n * p.Hin + ah[x]) * p.Win + aw[x]) * (unsigned)(p.pix_stride * 2) + (unsigned)(chunk * 16);
+          a_off[x] = (unsigned)((n * p.Hin + ah[x]) * p.Win + aw[x]) * (unsigned)(p.pix_stride * EB) + (unsigned)(chunk * 16);
         }
       }
       const bool newcls = cls != L_cls;
@@ -268,8 +273,8 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
         if (t < ntaps) {
           const Tap tp = p.cls[cls].taps[t];
           if (newcls) {
-            const int dA = (tp.dh * p.Win + tp.dw) * p.pix_stride * 2;
-            const int dB = tp.wtap * p.Ck * 2;
+            const int dA = (tp.dh * p.Win + tp.dw) * p.pix_stride * EB;
+            const int dB = tp.wtap * p.Ck * EB;
             v_tabA0 = tp0 == t ? dA + ch0 * 128 : v_tabA0;
             v_tabA1 = tp1 == t ? dA + ch1 * 128 : v_tabA1;
             v_tabB0 = tp0 == t ? ((dB + ch0 * 128) | (31 - t)) : v_tabB0;
@@ -463,8 +468,18 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
             for (int mt = 0; mt < (mhalf == 0 ? MT0 : MT1); ++mt)
 #pragma unroll
               for (int nt = 0; nt < 2; ++nt)
-                acc[mhalf * MT0 + mt][nhalf * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    bf[nt][ks], af[base + mt][ks], acc[mhalf * MT0 + mt][nhalf * 2 + nt], 0, 0, 0);
+                if constexpr (EB == 2) {
+                  acc[mhalf * MT0 + mt][nhalf * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                      bf[nt][ks], af[base + mt][ks], acc[mhalf * MT0 + mt][nhalf * 2 + nt], 0, 0, 0);
+                } else {
+                  // the 16 bytes a lane read are the operands of two k-steps (the SAME bytes of the weight and the pixel row
+                  // on both sides, so the assignment of k values to lanes need not be known: k is a summation index)
+                  const i64x2 wv = __builtin_bit_cast(i64x2, bf[nt][ks]), xv = __builtin_bit_cast(i64x2, af[base + mt][ks]);
+                  f32x4 c = acc[mhalf * MT0 + mt][nhalf * 2 + nt];
+                  c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wv[0], xv[0], c, 0, 0, 0);
+                  c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wv[1], xv[1], c, 0, 0, 0);
+                  acc[mhalf * MT0 + mt][nhalf * 2 + nt] = c;
+                }
         };
         // one phase: [fragment reads][issue][counted wait] lgkmcnt(0) barrier [MFMAs] barrier
 #ifdef MI355_STAMP8
@@ -651,7 +666,11 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
             for (int u = 0; u < MB; ++u) {
               const int mt = mb + u;
               if (mt >= MT) continue;
-              const f32x4 a = acc[mt][2 * ntp], b = acc[mt][2 * ntp + 1];
+              f32x4 a = acc[mt][2 * ntp], b = acc[mt][2 * ntp + 1];
+              if constexpr (EB == 1) {  // undo the operands' quantisation scales
+                a *= kp.oscale;
+                b *= kp.oscale;
+              }
               float v[8];
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -737,8 +756,8 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
 
 unsigned magic32(unsigned d) { return (unsigned)((1ull << 32) / d + 1); }
 
-template <int BM, int BN, int FAT>
-int launch8_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows, int korder) {
+template <int BM, int BN, int FAT, int EB = 2>
+int launch8_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows, int korder, float oscale = 1.f) {
   constexpr int NSTG = BN == 256 ? 2 : 3;
   constexpr int MAX_WG = 256;
   Igemm8KArgs k;
@@ -760,8 +779,9 @@ int launch8_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
   k.magW = magic32((unsigned)a.Wsub);
   k.magHW = magic32((unsigned)k.HW);
   k.korder = korder;
-  const size_t bytes_in = (size_t)a.N * a.Hin * a.Win * a.pix_stride * 2;
-  const size_t bytes_wt = (size_t)a.Ncols * a.wtaps * a.Ck * 2;
+  k.oscale = oscale;
+  const size_t bytes_in = (size_t)a.N * a.Hin * a.Win * a.pix_stride * EB;
+  const size_t bytes_wt = (size_t)a.Ncols * a.wtaps * a.Ck * EB;
   MI355_ARG(bytes_in < 0x80000000ull && bytes_wt < 0x80000000ull, "igemm8: tensor exceeds the 2 GiB buffer-offset range");
   k.bytes_in = (unsigned)bytes_in;
   k.bytes_wt = (unsigned)bytes_wt;
@@ -786,15 +806,15 @@ int launch8_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
   if (stats) {
     lds += (size_t)2 * chan * 2 * sizeof(float);
     if (a.bn_y) {
-      lds_opt_in8((const void*)igemm8_kernel<BM, BN, 2, FAT>, lds);
-      hipLaunchKernelGGL((igemm8_kernel<BM, BN, 2, FAT>), dim3(grid), dim3(512), lds, stream, k);
+      lds_opt_in8((const void*)igemm8_kernel<BM, BN, 2, FAT, EB>, lds);
+      hipLaunchKernelGGL((igemm8_kernel<BM, BN, 2, FAT, EB>), dim3(grid), dim3(512), lds, stream, k);
     } else {
-      lds_opt_in8((const void*)igemm8_kernel<BM, BN, 1, FAT>, lds);
-      hipLaunchKernelGGL((igemm8_kernel<BM, BN, 1, FAT>), dim3(grid), dim3(512), lds, stream, k);
+      lds_opt_in8((const void*)igemm8_kernel<BM, BN, 1, FAT, EB>, lds);
+      hipLaunchKernelGGL((igemm8_kernel<BM, BN, 1, FAT, EB>), dim3(grid), dim3(512), lds, stream, k);
     }
   } else {
-    lds_opt_in8((const void*)igemm8_kernel<BM, BN, 0, FAT>, lds);
-    hipLaunchKernelGGL((igemm8_kernel<BM, BN, 0, FAT>), dim3(grid), dim3(512), lds, stream, k);
+    lds_opt_in8((const void*)igemm8_kernel<BM, BN, 0, FAT, EB>, lds);
+    hipLaunchKernelGGL((igemm8_kernel<BM, BN, 0, FAT, EB>), dim3(grid), dim3(512), lds, stream, k);
   }
   MI355_LAUNCH_CHECK();
   return 0;
@@ -811,6 +831,20 @@ bool igemm8_legal(const IgemmArgs& a, int nclass, int bn) {
   const unsigned long long hw = (unsigned long long)a.Hsub * a.Wsub;
   if (Msub * hw >= (1ull << 32) || Msub + 256 >= (1ull << 31)) return false;
   return true;
+}
+
+// fp8 (OCP e4m3) operands, bf16 output = conv(xq, wq) * oscale: the same kernel with EB = 1 (k-tiles of 128 channels)
+int launch_igemm8_fp8(const IgemmArgs& a, int nclass, int bm, int bn, int korder, float oscale, hipStream_t stream) {
+  MI355_ARG(a.pair_delta == 0 && a.Ck % 128 == 0 && a.Ncols % bn == 0 && a.Wsub >= 2, "igemm8 fp8: Ck=%d (multiple of 128), Ncols=%d (multiple of %d), output rows of %d pixels (at least 2)", a.Ck, a.Ncols, bn, a.Wsub);
+  MI355_ARG(a.stat_partial == nullptr && a.addend == nullptr, "igemm8 fp8: plain launches only");
+  for (int ci = 0; ci < nclass; ++ci) MI355_ARG(a.cls[ci].ntaps * (a.Ck / 128) <= 128, "igemm8 fp8: more than 128 k-tiles per class");
+  const unsigned long long Msub = (unsigned long long)a.N * a.Hsub * a.Wsub;
+  MI355_ARG(Msub * a.Hsub * a.Wsub < (1ull << 32), "igemm8 fp8: problem too large for the 32-bit index arithmetic");
+  if (bm == 224 && bn == 256) return launch8_t<224, 256, 0, 1>(a, nclass, stream, nullptr, korder, oscale);
+  if (bm == 256 && bn == 256) return launch8_t<256, 256, 0, 1>(a, nclass, stream, nullptr, korder, oscale);
+  if (bm == 256 && bn == 128) return launch8_t<256, 128, 1, 1>(a, nclass, stream, nullptr, korder, oscale);
+  set_error("igemm8 fp8: no %dx%d tile", bm, bn);
+  return MI355_E_ARG;
 }
 
 int launch_igemm8(const IgemmArgs& a, int nclass, int bm, int bn, int korder, int fat, hipStream_t stream, int* stat_rows) {

@@ -33,6 +33,36 @@ def conv2d_fwd(x, w, stride=1, pad=0):
     return y
 
 
+def quantize_fp8(x, scale=1.0):
+    """q = saturate_e4m3fn(x * scale) as a torch.float8_e4m3fn tensor of x's shape (x fp32 or bf16, numel % 8 == 0)."""
+    _need_cuda(x)
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(_L().mi355_quantize_fp8(dtype_code(x.dtype), ptr(x), ptr(q), float(scale), x.numel(), cur_stream()))
+    return q.view(torch.float8_e4m3fn)
+
+
+def conv2d_fwd_fp8(xq, wq, stride=1, pad=0, oscale=1.0):
+    """bf16 y = conv(xq NHWC e4m3, wq KRSC e4m3) * oscale on the fp8 MFMA path (Cin, Cout multiples of 128)."""
+    _need_cuda(xq, wq)
+    N, H, W, Cin = xq.shape
+    Cout, KH, KW, _ = wq.shape
+    y = torch.empty((N, _out_dim(H, KH, stride, pad), _out_dim(W, KW, stride, pad), Cout), dtype=torch.bfloat16, device=xq.device)
+    check(_L().mi355_conv2d_fwd_fp8(ptr(xq), ptr(wq), ptr(y), float(oscale), N, H, W, Cin, Cout, KH, KW, stride, pad, cur_stream()))
+    return y
+
+
+def conv2d_dgrad_fp8(dyq, wq, x_shape, stride=1, pad=0, oscale=1.0, wt=None):
+    """bf16 dx for the conv above from e4m3 dy and the KRSC e4m3 weights (transposed here to [Cin][KH][KW][Cout])."""
+    _need_cuda(dyq, wq)
+    N, H, W, Cin = x_shape
+    Cout, KH, KW, _ = wq.shape
+    if wt is None:
+        wt = wq.view(torch.uint8).permute(3, 1, 2, 0).contiguous()
+    dx = torch.empty((N, H, W, Cin), dtype=torch.bfloat16, device=dyq.device)
+    check(_L().mi355_conv2d_dgrad_fp8(ptr(dyq), ptr(wt), ptr(dx), float(oscale), N, H, W, Cin, Cout, KH, KW, stride, pad, cur_stream()))
+    return dx
+
+
 def _conv_ws(dt, N, H, W, Cin, Cout, KH, KW, stride, pad, device):
     n = _L().mi355_conv2d_workspace_bytes(dt, N, H, W, Cin, Cout, KH, KW, stride, pad)
     return torch.empty(n, dtype=torch.uint8, device=device), n

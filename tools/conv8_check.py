@@ -111,6 +111,12 @@ def timing():
                 got = run(kind, x, w, dy, None, (N, H, H, Cin), s, pad)
                 err = ((got.float() - ref.float()).norm() / ref.float().norm()).item()
                 res.append(f"{v or 'old':9s} {best[v] * 1e6:6.1f}us {fl / best[v] / 1e12:5.0f}TF" + ("" if err < 1e-3 else f" ERR{err:.0e}"))
+            if Cin % 128 == 0 and Cout % 128 == 0:  # fp8 operand form of the same 8-wave kernel (quantisation not timed)
+                xq, wq, dyq = ops.quantize_fp8(x, 16.0), ops.quantize_fp8(w, 256.0), ops.quantize_fp8(dy, 16.0)
+                wt8 = wq.view(torch.uint8).permute(3, 1, 2, 0).contiguous()
+                f8 = (lambda: ops.conv2d_fwd_fp8(xq, wq, s, pad)) if kind == "fwd" else (lambda: ops.conv2d_dgrad_fp8(dyq, wq, (N, H, H, Cin), s, pad, wt=wt8))
+                t8 = min(bench(f8), bench(f8))
+                res.append(f"fp8 {t8 * 1e6:6.1f}us {fl / t8 / 1e12:5.0f}TF")
             print(f"{name:8s} {kind:5s} | " + " | ".join(res), flush=True)
 
 
