@@ -841,7 +841,8 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
   // BN = 128 unless that leaves most of the 256 CUs without a tile (the FC layer: 256 rows): then 64-wide tiles double
   // the workgroups
   const long tiles128 = (long)cdiv(a.N * a.Hsub * a.Wsub, 128) * nclass * (a.Ncols / 128);
-  const bool wide = (a.Ncols % 128 == 0) && tiles128 >= 128;
+  static const int narrow_env = getenv("MI355_IGEMM_NARROW") ? atoi(getenv("MI355_IGEMM_NARROW")) : 0;  // A/B knob
+  const bool wide = (a.Ncols % 128 == 0) && tiles128 >= 128 && !narrow_env;
   if (dtype == MI355_F32)
     return wide ? launch_t<float, 128, 128>(a, nclass, stream, stat_rows) : launch_t<float, 128, 64>(a, nclass, stream, stat_rows);
   if (dtype == MI355_BF16) {

@@ -69,6 +69,17 @@ struct Igemm8KArgs {
 
 // -DMI355_STAMP8: cycle stamps of waves 0 and 4 of workgroup 0 (one of each wave row), 4 per phase, parked in LDS and
 // copied out at the end; read back by tools/stamp8.py (profiling builds only — the stamps' lgkmcnt(0) changes the overlap)
+// -DMI355_ITEMSTAMP: 100 MHz realtime stamps per workgroup and item (k-loop start, k-loop end, epilogue end) of wave 0,
+// read back by tools/items8.py (profiling builds only)
+#ifdef MI355_ITEMSTAMP
+__device__ unsigned long long g8_items[512 * 16 * 4];
+#define ITEMSTAMP(slot)                                                                                           \
+  do {                                                                                                            \
+    if (tid == 0 && item_n < 16) g8_items[((int)blockIdx.x * 16 + item_n) * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define ITEMSTAMP(slot)
+#endif
 #ifdef MI355_STAMP8
 __device__ unsigned long long g8_stamps[2 * 1024];
 #define STAMP8(slot)                                                                                         \
@@ -396,6 +407,9 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
 
   bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
   const bf16_t* addend = reinterpret_cast<const bf16_t*>(p.addend);
+#ifdef MI355_ITEMSTAMP
+  int item_n = 0;
+#endif
   int stage = 0;
   bool after_epi = false;  // the epilogue's NST stores are younger than the groups the next k-tile's waits retire
 
@@ -602,10 +616,12 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
         }
         stage = stage + 1 == NSTG ? 0 : stage + 1;
       };
+      ITEMSTAMP(0);
       for (int kt = 0; kt < nk; ++kt) {
         ktile(!L_valid ? 2 : (after_epi ? 1 : 0));
         after_epi = false;
       }
+      ITEMSTAMP(1);
 
       // ---- epilogue: both wave rows in the same barrier interval ---------------------------------------------------
       if (wr == 0) __builtin_amdgcn_s_barrier();
@@ -730,6 +746,12 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
       }
       after_epi = true;
       asm volatile("" ::: "memory");
+      ITEMSTAMP(2);
+#ifdef MI355_ITEMSTAMP
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // profiling build: how long the stores take to retire
+      ITEMSTAMP(3);
+      ++item_n;
+#endif
       if (wr == 1) __builtin_amdgcn_s_barrier();
     }
   }
@@ -858,6 +880,16 @@ int launch_igemm8(const IgemmArgs& a, int nclass, int bm, int bn, int korder, in
 }
 
 }  // namespace mi355
+
+#ifdef MI355_ITEMSTAMP
+extern "C" int mi355_debug_items8(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mi355::g8_items), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+extern "C" int mi355_debug_items8_clear(void) {
+  static unsigned long long z[512 * 16 * 4];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(mi355::g8_items), z, sizeof(z), 0, hipMemcpyHostToDevice);
+}
+#endif
 
 #ifdef MI355_STAMP8
 extern "C" int mi355_debug_stamps8(unsigned long long* host_out, int n) {

@@ -18,6 +18,8 @@
 // walk (tile, pixel-split, slab) as one stream through a 2-stage LDS ring with the next slab always in flight
 // (counted s_waitcnt vmcnt + raw s_barrier, as in conv_igemm.hip).  fp32 partial slabs are summed in split order by
 // splitk_reduce (bitwise reproducible, no float atomics).
+#include <cstdlib>
+
 #include "common.h"
 #include "lds_dma.h"
 
@@ -403,9 +405,12 @@ int launch_t(const WgradArgs& a, int splits, hipStream_t stream) {
   k.bytes_dy = (unsigned)bytes_dy;
   k.bytes_x = (unsigned)bytes_x;
   const int grid = k.items < MAX_WG ? k.items : MAX_WG;
-  // few tiles per split (small-channel layers): the same dy / x slabs are fetched by every tile of the split, so keep
-  // them on one XCD; with many tiles the round-robin order measured faster
-  k.xcd = (k.tiles <= 16 && k.tiles > 1 && grid % 8 == 0) ? 1 : 0;
+  // every tile of a pixel split fetches the same dy / x slabs: keep the tiles of a split on one XCD (one L2) wherever the
+  // grid divides over the 8 XCDs.  Same-box whole-step A/B at batch 256 (tools/ab_step.sh MI355_WGRAD_XCD): 20.46 -> 20.36 ms
+  // with it on for every layer (round 1 had it for <= 16 tiles only, from warm-cache per-op timings where the MALL hides
+  // the re-fetch).
+  static const int xcd_env = getenv("MI355_WGRAD_XCD") ? atoi(getenv("MI355_WGRAD_XCD")) : -1;  // A/B knob: 0 never, 1 always
+  k.xcd = (k.tiles > 1 && grid % 8 == 0 && (xcd_env < 0 || xcd_env == 1)) ? 1 : 0;
   const size_t lds = (size_t)2 * BKP * (BMC + TPI * BNC) * ES;
   static bool attr_set = false;
   if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in

@@ -489,6 +489,43 @@ def test_baseline_batch_rule_selected_variants(dev, dtype, monkeypatch):
     assert max(errs) < 0.3, f"per-segment drift {['%.1e' % x for x in errs]}"
 
 
+@pytest.mark.parametrize("S", [160, 224, 320])
+def test_config5_batch_512_progressive_sizes(dev, S):
+    """BASELINE.json configs[4]'s per-GPU shapes: batch 512 at the progressive-resize sizes 160 / 224 / 320 px, bf16, default
+    launch rules (the largest tensors of the path: 1.68 GB activations at 320 px, just inside the 2 GiB buffer-descriptor
+    range the kernels index with).  Teacher-forced like the N = 256 test: conv outputs of one layer per stage re-derived by the
+    oracle from the executor's own inputs on a few images (first, middle, last — the last row tiles are the ragged ones),
+    whole-batch BN statistics, a finite step-0 loss near ln(1000), finite gradients of every segment."""
+    from sota_imagenet_amd.losses import CrossEntropyLoss
+
+    N = 512
+    key = (N, S, S)
+    m, sd = build("bf16")
+    data, target = synthetic_batch(N, S, seed=2, index=S)
+    m.train()
+    loss = CrossEntropyLoss(smoothing=0.1).cuda()(m(data.cuda()), target.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - 6.9078) < 1.0, loss.item()
+    g = m.flat_grads.detach()
+    assert torch.isfinite(g).all()
+    for b, e in m.grad_segments:
+        assert g[b:e].abs().max().item() > 0, (b, e)
+    P = {k: v.float() for k, v in sd.items()}
+    T = lambda name: m.debug_tensor(key, name)
+    img = [0, 255, 511]
+    for conv, src, stride, pad in [("layer1.2.conv2", "layer1.2.a1", 1, 1), ("layer2.1.conv3", "layer2.1.a2", 1, 0), ("layer3.0.conv2", "layer3.0.a1", 2, 1),
+                                   ("layer3.5.conv1", "layer3.4.out", 1, 0), ("layer4.2.conv2", "layer4.2.a1", 1, 1)]:
+        x = T(src)[img].float().cpu()
+        y = T(conv + ".y")
+        w = R.oihw_to_krsc(P[conv + ".weight"]).bfloat16().float()
+        assert nerr(y[img].float().cpu(), R.conv2d_fwd(x, w, stride, pad)) < 2e-2, conv
+        y2 = y.reshape(-1, y.shape[-1]).double()
+        bn = conv.replace("conv", "bn")
+        assert nerr(T(bn + ".save_mean").cpu(), y2.mean(0).float().cpu()) < 1e-4, bn
+        assert nerr(T(bn + ".save_invstd").cpu(), (y2.var(0, unbiased=False) + 1e-5).rsqrt().float().cpu()) < 1e-4, bn
+
+
 def test_fp32_stream_k_tail_matches_whole_tiles(dev):
     """fp32 igemm cuts the row tiles of a partial last round along K across workgroups (stream-K) — only when a launch has
     >= 128 tiles, i.e. not at the small shapes of the other tests.  N=64 at 224 px puts the layer-3/4 convs (98 / 25 row

@@ -1,0 +1,30 @@
+"""igemm8 with the operand loads turned into zero-record reads (MI355_IGEMM8_DBG=3: no L2/HBM traffic on the load side):
+what remains is MFMA + epilogue + stores.  python tools/probe8.py"""
+import os, sys, time
+import torch
+sys.path.insert(0, ".")
+from sota_imagenet_amd import ops
+dt = torch.bfloat16
+N = 256
+for (name, H, Cin, Cout, K, tile) in [("l3.c3 fwd", 14, 256, 1024, 1, "224x256"), ("l3.c1 fwd", 14, 1024, 256, 1, "224x256"), ("l2.c3 fwd", 28, 128, 512, 1, "224x256"),
+                                     ("l2.c3 fwd", 28, 128, 512, 1, "256x128f"), ("l3.c2 fwd", 14, 256, 256, 3, "224x256"), ("l4.c3 fwd", 7, 512, 2048, 1, "224x256")]:
+    M = N * H * H
+    nset = max(3, int(1.6e9 // (M * (Cin + Cout) * 2)) + 1)
+    xs = [torch.randn(N, H, H, Cin, device="cuda").to(dt) for _ in range(nset)]
+    w = (torch.randn(Cout, K, K, Cin, device="cuda") * 0.05).to(dt)
+    os.environ["MI355_IGEMM8"] = tile
+    out = []
+    for dbg in ("0", "1", "2", "3"):
+        os.environ["MI355_IGEMM8_DBG"] = dbg
+        for i in range(nset):
+            ops.conv2d_fwd(xs[i], w, 1, K // 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            for i in range(nset):
+                ops.conv2d_fwd(xs[i], w, 1, K // 2)
+        torch.cuda.synchronize()
+        out.append(f"dbg{dbg} {(time.perf_counter() - t0) / (3 * nset) * 1e6:6.1f}us")
+    fl = 2.0 * M * Cin * Cout * K * K
+    print(f"{name:10s} {tile:9s} GF {fl/1e9:6.1f} | " + " | ".join(out), flush=True)
+    del xs
