@@ -50,6 +50,22 @@ class SyntheticLoader:
             yield self._pool[i % self._pool_n]
 
 
+def make_loader(cfg, size, seed, device, pool, is_val, source="auto"):
+    """`data.source`: "synthetic" (the benchmark feed), "folder" (JPEG folders under loader.root_data_dir/{train,val}, resized
+    on the GPU — image_loader.py), or "auto": folders when that directory exists, synthetic otherwise (no IMAGENET_DIR in
+    the benchmark environment)."""
+    import os
+
+    sub = os.path.join(str(cfg.get("root_data_dir") or ""), "val" if is_val else "train")
+    if source == "folder" or (source == "auto" and cfg.get("root_data_dir") and os.path.isdir(sub)):
+        from .image_loader import ImageFolderLoader
+
+        return ImageFolderLoader(cfg, is_val=is_val, seed=seed, device=device)
+    if source not in ("auto", "synthetic"):
+        raise ValueError(f"data.source = {source!r}: expected synthetic | folder | auto")
+    return SyntheticLoader(cfg, size, seed, device, pool, is_val=is_val)
+
+
 class SyntheticDataManager:
     def __init__(self, cfg, device=None):
         self.cfg = cfg
@@ -88,5 +104,9 @@ class SyntheticDataManager:
                 torch.cuda.empty_cache()
         d = self.cfg.get("data", {})
         seed = self.cfg.get("random_seed") or 0
-        self.loader = SyntheticLoader(train_cfg, d.get("train_size", 1281167), seed, self.device, d.get("pool", 8))
-        self.val_loader = SyntheticLoader(val_cfg, d.get("val_size", 50000), seed, self.device, min(d.get("pool", 8), 4), is_val=True)
+        self.loader = make_loader(train_cfg, d.get("train_size", 1281167), seed, self.device, d.get("pool", 8), False, d.get("source", "auto"))
+        self.val_loader = make_loader(val_cfg, d.get("val_size", 50000), seed, self.device, min(d.get("pool", 8), 4), True, d.get("source", "auto"))
+
+
+# the reference's name for the same object (sota_imagenet/dali_dataloader.py:189): configs / scripts that import it keep working
+DaliDataManager = DataManager = SyntheticDataManager

@@ -25,6 +25,7 @@ _BASE = {
     "uint8_t": ctypes.c_uint8,
     "unsigned": ctypes.c_uint,
     "unsigned long long": ctypes.c_ulonglong,
+    "unsigned char": ctypes.c_ubyte,
     "char": ctypes.c_char,
 }
 
@@ -41,8 +42,8 @@ def _ctype(decl):
     nptr += d.count("*")
     d = d.replace("*", " ").split()
     base = " ".join(d) if d[0] == "unsigned" else d[0]
-    if base in ("mi355_ctx", "mi355_comm"):
-        return ctypes.c_void_p  # opaque (any pointer depth)
+    if base in ("mi355_ctx", "mi355_comm", "mi355_crop"):
+        return ctypes.c_void_p  # opaque handles / descriptor tables (any pointer depth)
     if base == "void" and nptr:
         return ctypes.c_void_p
     if base == "char" and nptr == 1:
@@ -62,6 +63,7 @@ def parse_header(path=HEADER_PATH):
     src = re.sub(r"#[^\n]*", " ", src)
     src = re.sub(r"typedef\s+enum\s+\w+\s*\{.*?\}\s*\w+\s*;", " ", src, flags=re.S)
     src = re.sub(r"typedef\s+struct\s+\w+\s+\w+\s*;", " ", src)
+    src = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", " ", src, flags=re.S)
     protos = {}
     for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(mi355_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, params = m.group(1).strip(), m.group(2), m.group(3).strip()

@@ -63,6 +63,18 @@ def conv2d_dgrad_fp8(dyq, wq, x_shape, stride=1, pad=0, oscale=1.0, wt=None):
     return dx
 
 
+def ingest_u8(packed, table_host, table_dev, S, mean=127.5, std=51.0):
+    """decoded u8 RGB crops (packed device bytes + mi355_crop table as a numpy structured array and its device copy) ->
+    fp32 NCHW [N,3,S,S]: triangular-filter resize, window, mirror, normalise (csrc/ingest.hip)."""
+    _need_cuda(packed, table_dev)
+    N = int(table_host.shape[0])
+    if table_host.dtype.itemsize != 40 or table_dev.numel() * table_dev.element_size() != 40 * N or not table_host.flags["C_CONTIGUOUS"]:
+        raise ValueError("ingest_u8: the descriptor table must be N contiguous 40-byte mi355_crop records on both sides")
+    out = torch.empty((N, 3, S, S), dtype=torch.float32, device=packed.device)
+    check(_L().mi355_ingest_u8(ptr(packed), packed.numel(), table_host.ctypes.data, ptr(table_dev), N, int(S), float(mean), float(std), ptr(out), cur_stream()))
+    return out
+
+
 def _conv_ws(dt, N, H, W, Cin, Cout, KH, KW, stride, pad, device):
     n = _L().mi355_conv2d_workspace_bytes(dt, N, H, W, Cin, Cout, KH, KW, stride, pad)
     return torch.empty(n, dtype=torch.uint8, device=device), n
