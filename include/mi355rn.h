@@ -180,7 +180,7 @@ int mi355_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float
  *   maxpool3s1  3x3 max, stride 1, pad 1 + u8 argmax (first maximum in window scan order): the anti-aliased stem pool
  *   eca         y = x * sigmoid(conv1d_k(GAP(x)))[n][c]; k odd <= 9, zero padded over the channel axis.  pooled / gate
  *               [N][C] fp32 are outputs kept for backward; eca_bwd returns dx and the k conv-weight gradients
- *               (beta = 0 overwrite / 1 accumulate), ws = 2*N*C floats of scratch
+ *               (beta = 0 overwrite / 1 accumulate), ws = 2*N*C + 1152 floats of scratch
  *   weight_std  w_hat[o] = (w[o] - mean_o) * rsqrt(var_o + eps) over the K = KH*KW*Cin weights of output channel o
  *               (biased variance) and its backward dw = invstd * (g - mean(g) - w_hat * mean(g * w_hat))
  *   residual_act  out = act(branch * scale_n[n] + shortcut): drop-connect keep/scale per sample (scale_n may be NULL),

@@ -249,31 +249,54 @@ __global__ __launch_bounds__(256) void eca_scale_kernel(const T* x, const float*
     Vec16<T>::store(y + i * V, v);
   }
 }
-// s[n][c] = sum_hw dy * x : one workgroup per (n, 64-channel slab), 256 threads = 4 pixel lanes x 64 channels
+// s[n][c] = sum_hw dy * x : one workgroup per (image, slab of 8 channel vectors), 256 threads = 32 pixel lanes x 8 vectors of
+// 16 bytes; fixed-order accumulation + fixed-shape LDS tree (as gap_fwd_kernel)
 template <typename T>
 __global__ __launch_bounds__(256) void eca_prod_reduce_kernel(const T* dy, const T* x, float* s, int N, int HW, int C) {
-  __shared__ float red[4][64];
-  const int slabs = C / 64;
-  const int n = blockIdx.x / slabs, c0 = (blockIdx.x % slabs) * 64;
-  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
-  float acc = 0.f;
-  for (int p = r; p < HW; p += 4) {
-    const size_t o = ((size_t)n * HW + p) * C + c0 + c;
-    acc += (float)dy[o] * (float)x[o];
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[32][8 * V + 1];
+  const int slabs = C / (8 * V);
+  const int n = blockIdx.x / slabs, c0 = (blockIdx.x % slabs) * 8 * V;
+  const int cv = threadIdx.x & 7, r = threadIdx.x >> 3;
+  float acc[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) acc[e] = 0.f;
+  for (int p = r; p < HW; p += 32) {
+    const size_t o = ((size_t)n * HW + p) * C + c0 + cv * V;
+    float a[V], b[V];
+    Vec16<T>::load(dy + o, a);
+    Vec16<T>::load(x + o, b);
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] += a[e] * b[e];
   }
-  red[r][c] = acc;
+#pragma unroll
+  for (int e = 0; e < V; ++e) red[r][cv * V + e] = acc[e];
   __syncthreads();
-  if (r == 0) s[(size_t)n * C + c0 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+  for (int st = 16; st > 0; st >>= 1) {
+    if (r < st) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) red[r][cv * V + e] += red[r + st][cv * V + e];
+    }
+    __syncthreads();
+  }
+  if (r == 0) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) s[(size_t)n * C + c0 + cv * V + e] = red[0][cv * V + e];
+  }
 }
 // dpre = s * g * (1 - g); dpool[n][c] = (sum_j w[j] * dpre[n][c - j + k/2]) / HW; dw[j] = sum_{n,c} dpre[n][c] * pooled[n][c + j - k/2]
+// The tensors are [N][C] (up to 256 x 2048): ECA_GB workgroups walk them grid-stride, each leaves its k partial weight
+// gradients in dwpart[block][9]; eca_dw_finish adds the ECA_GB rows in block order (fixed grid => bitwise reproducible).
+constexpr int ECA_GB = 128;
 __global__ __launch_bounds__(256) void eca_gate_bwd_kernel(const float* s, const float* gate, const float* pooled, const float* w, int k,
-                                                          float* dpool, float* dw, float beta, int N, int C, float inv_hw) {
-  // single workgroup: the tensors are [N][C] (<= 256 x 2048 floats), the 1-D conv weight gradient is a full reduction
+                                                          float* dpool, float* dwpart, int N, int C, float inv_hw) {
   __shared__ float red[256];
   float part[9];
   for (int j = 0; j < 9; ++j) part[j] = 0.f;
-  for (size_t i = threadIdx.x; i < (size_t)N * C; i += 256) {
+  const size_t total = (size_t)N * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)ECA_GB * 256) {
     const int c = (int)(i % C), n = (int)(i / C);
+    const float dpre_i = s[i] * gate[i] * (1.f - gate[i]);
     float dp = 0.f;
     for (int j = 0; j < k; ++j) {
       const int cc = c - j + k / 2;  // dpre element that read pooled[n][c] through tap j
@@ -282,7 +305,7 @@ __global__ __launch_bounds__(256) void eca_gate_bwd_kernel(const float* s, const
         dp += w[j] * s[o] * gate[o] * (1.f - gate[o]);
       }
       const int cp = c + j - k / 2;
-      if (cp >= 0 && cp < C) part[j] += s[i] * gate[i] * (1.f - gate[i]) * pooled[(size_t)n * C + cp];
+      if (cp >= 0 && cp < C) part[j] += dpre_i * pooled[(size_t)n * C + cp];
     }
     dpool[i] = dp * inv_hw;
   }
@@ -293,9 +316,16 @@ __global__ __launch_bounds__(256) void eca_gate_bwd_kernel(const float* s, const
       if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
       __syncthreads();
     }
-    if (threadIdx.x == 0) dw[j] = (beta != 0.f ? beta * dw[j] : 0.f) + red[0];
+    if (threadIdx.x == 0) dwpart[blockIdx.x * 9 + j] = red[0];
     __syncthreads();
   }
+}
+__global__ void eca_dw_finish_kernel(const float* dwpart, float* dw, int k, float beta) {
+  const int j = threadIdx.x;
+  if (j >= k) return;
+  float a = 0.f;
+  for (int b = 0; b < ECA_GB; ++b) a += dwpart[b * 9 + j];
+  dw[j] = (beta != 0.f ? beta * dw[j] : 0.f) + a;
 }
 
 // ---- weight standardisation: one workgroup per output channel ---------------------------------------------------------
@@ -475,9 +505,11 @@ int mi355_eca_bwd(int dtype, const void* dy, const void* x, const float* w, int 
   hipStream_t s = (hipStream_t)stream;
   float* sprod = ws;                    // [N][C]
   float* dpool = ws + (size_t)N * C;    // [N][C]
-  DISPATCH_T(dtype, hipLaunchKernelGGL(eca_prod_reduce_kernel<float>, dim3(N * (C / 64)), dim3(256), 0, s, (const float*)dy, (const float*)x, sprod, N, HW, C),
+  float* dwpart = ws + (size_t)2 * N * C;  // [ECA_GB][9]
+  DISPATCH_T(dtype, hipLaunchKernelGGL(eca_prod_reduce_kernel<float>, dim3(N * (C / 32)), dim3(256), 0, s, (const float*)dy, (const float*)x, sprod, N, HW, C),
              hipLaunchKernelGGL(eca_prod_reduce_kernel<bf16_t>, dim3(N * (C / 64)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, sprod, N, HW, C));
-  hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3(1), dim3(256), 0, s, sprod, gate, pooled, w, k, dpool, dw, beta, N, C, 1.f / (float)HW);
+  hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3(ECA_GB), dim3(256), 0, s, sprod, gate, pooled, w, k, dpool, dwpart, N, C, 1.f / (float)HW);
+  hipLaunchKernelGGL(eca_dw_finish_kernel, dim3(1), dim3(64), 0, s, dwpart, dw, k, beta);
   const size_t total = (size_t)N * HW * C;
   DISPATCH_T(dtype, hipLaunchKernelGGL((eca_scale_kernel<float, true>), dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)dy, gate, dpool, (float*)dx, N, HW, C),
              hipLaunchKernelGGL((eca_scale_kernel<bf16_t, true>), dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)dy, gate, dpool, (bf16_t*)dx, N, HW, C));

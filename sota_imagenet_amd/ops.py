@@ -295,7 +295,7 @@ def eca_bwd(dy, x, w, pooled, gate):
     N, H, W, C = x.shape
     dx = torch.empty_like(x)
     dw = torch.empty_like(w)
-    ws = torch.empty((2, N, C), dtype=torch.float32, device=x.device)
+    ws = torch.empty(2 * N * C + 128 * 9, dtype=torch.float32, device=x.device)  # mi355_eca_bwd: sprod, dpool, dw partials
     check(_L().mi355_eca_bwd(dtype_code(x.dtype), ptr(dy), ptr(x), ptr(w), w.numel(), ptr(pooled), ptr(gate), ptr(dx), ptr(dw), 0.0, ptr(ws),
                              N, H * W, C, cur_stream()))
     return dx, dw

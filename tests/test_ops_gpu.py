@@ -187,6 +187,9 @@ def test_gap(dev, dtype):
     x = rnd((N, H, W, C), 51, dtype)
     p = ops.gap_fwd(x.to(dev, dtype))
     assert nerr(p, R.gap(x)) < 1e-5
+    for shape in [(2, 56, 56, 256), (5, 3, 5, 64), (1, 1, 1, 128)]:  # the maps ECA pools; HW below / not a multiple of the 32 pixel lanes
+        xs = rnd(shape, 53, dtype)
+        assert nerr(ops.gap_fwd(xs.to(dev, dtype)), R.gap(xs)) < 1e-5, shape
     dp = rnd((N, C), 52, torch.float32)
     dx = ops.gap_bwd(dp.to(dev), (N, H, W, C), dtype)
     assert nerr(dx, R.gap_bwd(dp, (N, H, W, C))) < TOL[dtype]
