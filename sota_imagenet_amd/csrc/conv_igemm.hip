@@ -76,6 +76,8 @@ struct IgemmKArgs {
   unsigned* sk_flags;       // [G] epoch flags, then the error word at index IGEMM_SK_ERR_WORD (read by the executor)
   unsigned sk_spin_limit;   // polls before an owner gives up on a hand-off and raises the error word
   int sk_mute;              // debug (MI355_SK_DEBUG=mute): contributors never publish, so every owner times out
+  int dbg;                  // timing probes (MI355_IGEMM_DBG): 1 = skip the epilogue, 2 = epilogue stores go to the trash page,
+                            // 4 = the addend is read from one cached zero page (no HBM latency in the epilogue)
 };
 
 // BM x BN tile, WMW x 2 waves (a wave owns BM/WMW x BN/2 outputs), NSTG-stage LDS ring:
@@ -482,6 +484,7 @@ __global__ __launch_bounds__(128 * WMW, (BM == 256 ? 1 : (BN == 64 && NSTG == 2 
       const int done_stage = stage == 0 ? NSTG - 1 : stage - 1;
       char* stg = smem + done_stage * STAGE + (wave % EPI_WAVES) * STG_WAVE;
       MI355_LDS_BARRIER();
+      if (kp.dbg & 1) continue;  // timing probe: results are not written
       if (tid < BM) {
         const int m = m0 + tid;
         int pix = -1;
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(128 * WMW, (BM == 256 ? 1 : (BN == 64 && NSTG == 2 
             pixs[ps] = row_pix[wm * (BM / WMW) + mi * 32 + ps * RPI + rr];
             if (addend) {
               const size_t o = (size_t)(pixs[ps] < 0 ? 0 : pixs[ps]) * p.Ncols + n0 + wn * WN + ch * VEC;
-              araw[ps] = *reinterpret_cast<const uint4*>(pixs[ps] < 0 ? reinterpret_cast<const T*>(g_zero_page) : addend + o);
+              araw[ps] = *reinterpret_cast<const uint4*>((pixs[ps] < 0 || (kp.dbg & 4)) ? reinterpret_cast<const T*>(g_zero_page) : addend + o);
               abits[ps] = p.addend_bits ? (unsigned)p.addend_bits[pixs[ps] < 0 ? 0 : o / VEC] : 0xffu;
             }
             if constexpr (STATS == 2) {
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(128 * WMW, (BM == 256 ? 1 : (BN == 64 && NSTG == 2 
               for (int e = 0; e < VEC; ++e) v[e] += (abits[ps] >> e) & 1u ? a[e] : 0.f;
             }
             // rows past the end of the problem go to a trash page so that every thread issues exactly NST stores
-            T* dst = pix < 0 ? reinterpret_cast<T*>(g_trash + tid * 16) : out + o;
+            T* dst = (pix < 0 || (kp.dbg & 2)) ? reinterpret_cast<T*>(g_trash + tid * 16) : out + o;
             Vec16<T>::store(dst, v);
             if constexpr (STATS == 1) {
               if (pix >= 0) {
@@ -714,6 +717,8 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
     return e && strcmp(e, "mute") == 0;
   }();
   k.sk_mute = sk_mute ? 1 : 0;
+  const char* dbg_env = getenv("MI355_IGEMM_DBG");  // read per launch: timing probes only, results are wrong with it set
+  k.dbg = dbg_env ? atoi(dbg_env) : 0;
   k.sk_spin_limit = sk_mute ? (1u << 8) : (1u << 24);
   bool sk = false;
   // (fp32 only: a hand-off costs the owner ~10 us, nothing beside a 150-300 us fp32 tile, but most of what the cut

@@ -59,6 +59,22 @@ def main():
             torch.cuda.synchronize()
             t = (time.perf_counter() - t0) / (reps * nset)
             res.append(f"{v or 'rule':8s} {t * 1e6:6.1f}us {by / t / 1e12:4.2f}TB/s")
+        os.environ["MI355_IGEMM8"] = "0"
+        for big in ("1", "3"):  # the 4-wave 256x256 tile / the 8-wave 3-stage 256x128 tile of conv_igemm.hip, forced
+            if big == "1" and ncols % 256:
+                continue
+            os.environ["MI355_IGEMM_BIG"] = big
+            for i in range(nset):
+                call(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                for i in range(nset):
+                    call(i)
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / (3 * nset)
+            res.append(f"big{big} {t * 1e6:6.1f}us {by / t / 1e12:4.2f}TB/s")
+        os.environ.pop("MI355_IGEMM_BIG", None)
         os.environ.pop("MI355_IGEMM8", None)
         # streaming yardstick with the same bytes: out = a + b style kernels over bf16 buffers
         n_el = by // 2 // 3

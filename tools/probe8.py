@@ -28,3 +28,52 @@ for (name, H, Cin, Cout, K, tile) in [("l3.c3 fwd", 14, 256, 1024, 1, "224x256")
     fl = 2.0 * M * Cin * Cout * K * K
     print(f"{name:10s} {tile:9s} GF {fl/1e9:6.1f} | " + " | ".join(out), flush=True)
     del xs
+
+# the 4-wave kernel (conv_igemm.hip): MI355_IGEMM_DBG 1 = no epilogue at all, 2 = full epilogue but its stores hit one trash page
+os.environ["MI355_IGEMM8"] = "0"
+os.environ.pop("MI355_IGEMM8_DBG", None)
+for (name, H, Cin, Cout, K) in [("l1.c3 fwd", 56, 64, 256, 1), ("l1.c1 fwd", 56, 256, 64, 1), ("l2.c3 fwd", 28, 128, 512, 1), ("l2.c1 fwd", 28, 512, 128, 1),
+                                ("l3.c3 fwd", 14, 256, 1024, 1), ("l1.c2 fwd", 56, 64, 64, 3), ("l2.c2 fwd", 28, 128, 128, 3)]:
+    M = N * H * H
+    nset = max(3, int(1.6e9 // (M * (Cin + Cout) * 2)) + 1)
+    xs = [torch.randn(N, H, H, Cin, device="cuda").to(dt) for _ in range(nset)]
+    w = (torch.randn(Cout, K, K, Cin, device="cuda") * 0.05).to(dt)
+    out = []
+    for dbg in ("0", "2", "1"):
+        os.environ["MI355_IGEMM_DBG"] = dbg
+        for i in range(nset):
+            ops.conv2d_fwd(xs[i], w, 1, K // 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            for i in range(nset):
+                ops.conv2d_fwd(xs[i], w, 1, K // 2)
+        torch.cuda.synchronize()
+        out.append(f"dbg{dbg} {(time.perf_counter() - t0) / (3 * nset) * 1e6:6.1f}us")
+    os.environ.pop("MI355_IGEMM_DBG", None)
+    print(f"4-wave {name:10s} | " + " | ".join(out), flush=True)
+    del xs
+
+# dgrad with the shortcut addend: how much of its cost is the addend's HBM latency inside the epilogue (probe 4 reads it from a cached page)
+for (name, H, Cin, Cout) in [("l3.c1 dgrad", 14, 1024, 256), ("l2.c1 dgrad", 28, 512, 128), ("l4.c1 dgrad", 7, 2048, 512)]:
+    M = N * H * H
+    nset = max(3, int(1.6e9 // (M * (2 * Cin + Cout) * 2)) + 1)
+    dys = [torch.randn(N, H, H, Cout, device="cuda").to(dt) for _ in range(nset)]
+    adds = [torch.randn(N, H, H, Cin, device="cuda").to(dt) for _ in range(nset)]
+    w = (torch.randn(Cout, 1, 1, Cin, device="cuda") * 0.05).to(dt)
+    out = []
+    for label, dbg, use_add in (("plain", "0", False), ("+addend", "0", True), ("+addend cached", "4", True), ("+addend, no stores", "2", True), ("no epilogue", "1", True)):
+        os.environ["MI355_IGEMM_DBG"] = dbg
+        f = lambda i: ops.conv2d_dgrad(dys[i], w, (N, H, H, Cin), 1, 0, addend=adds[i] if use_add else None)
+        for i in range(nset):
+            f(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            for i in range(nset):
+                f(i)
+        torch.cuda.synchronize()
+        out.append(f"{label} {(time.perf_counter() - t0) / (3 * nset) * 1e6:6.1f}us")
+    os.environ.pop("MI355_IGEMM_DBG", None)
+    print(f"4-wave {name:12s} | " + " | ".join(out), flush=True)
+    del dys, adds
