@@ -52,6 +52,24 @@ def pmc_traffic(kernels, dtype, batch, size):
     return int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in recs) / n) if n else None
 
 
+def step_traffic(dtype, batch, size):
+    """HBM bytes of ONE whole train step: every kernel of the committed PMC passes (launches x corrected bytes per launch),
+    divided by the steps those passes ran (= launches of the once-per-step SGD kernel).  None outside the default workload."""
+    import glob
+
+    if (batch, size) != (256, 224):
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_traffic_{dtype}.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        table = json.load(f)["kernels"]
+    steps = table.get("sgd_kernel", {}).get("launches", 0)
+    if not steps:
+        return None, None
+    return int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in table.values()) / steps), os.path.basename(files[-1])
+
+
 def cpu_baseline():
     """BASELINE.md §3 protocol: the oracle's train step (fwd + CE + bwd + SGD) and its forward alone on the host cores,
     BASELINE.json configs[0] (bs 32, fp32, 224 px): 3 warm-up + 10 timed steps each, median; threads printed."""
@@ -296,6 +314,13 @@ def main():
             "roofline": roof,
             "roofline_hbm": roof_hbm,
         }
+        if world == 1:
+            # the bf16 step as a whole is HBM-limited: all kernels' counter traffic of one step over the step time
+            tb, src = step_traffic(args.dtype, N, S)
+            if tb:
+                gbs = tb / (ms * 1e-3) / 1e9
+                out["step_hbm"] = {"bound": "hbm", "traffic": tb, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": round(gbs / PEAK_HBM_GBS, 4), "source": f"profiles/{src}: every kernel of a serial step, separate --pmc passes"}
         if roof is not None and world == 1 and not use_ddp:
             del model
             torch.cuda.empty_cache()
