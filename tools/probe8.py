@@ -77,3 +77,29 @@ for (name, H, Cin, Cout) in [("l3.c1 dgrad", 14, 1024, 256), ("l2.c1 dgrad", 28,
     os.environ.pop("MI355_IGEMM_DBG", None)
     print(f"4-wave {name:12s} | " + " | ".join(out), flush=True)
     del dys, adds
+
+# weight gradients: MI355_WGRAD_DBG=3 replaces both operand loads by zero-record reads (no L2 / HBM traffic)
+os.environ.pop("MI355_IGEMM8", None)
+for (name, H, Cin, Cout, K) in [("l3.c2.w", 14, 256, 256, 3), ("l3.c1.w", 14, 1024, 256, 1), ("l3.c3.w", 14, 256, 1024, 1), ("l4.c2.w", 7, 512, 512, 3),
+                                ("l2.c2.w", 28, 128, 128, 3), ("l2.c1.w", 28, 512, 128, 1), ("l1.c3.w", 56, 64, 256, 1), ("l1.c2.w", 56, 64, 64, 3)]:
+    M = N * H * H
+    nset = max(3, int(1.6e9 // (M * (Cin + Cout) * 2)) + 1)
+    xs = [torch.randn(N, H, H, Cin, device="cuda").to(dt) for _ in range(nset)]
+    dys = [torch.randn(N, H, H, Cout, device="cuda").to(dt) for _ in range(nset)]
+    out = []
+    for dbg in ("0", "3"):
+        os.environ["MI355_WGRAD_DBG"] = dbg
+        f = lambda i: ops.conv2d_wgrad(dys[i], xs[i], K, K, 1, K // 2)
+        for i in range(nset):
+            f(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            for i in range(nset):
+                f(i)
+        torch.cuda.synchronize()
+        out.append(f"dbg{dbg} {(time.perf_counter() - t0) / (3 * nset) * 1e6:6.1f}us")
+    os.environ.pop("MI355_WGRAD_DBG", None)
+    fl = 2.0 * M * Cin * Cout * K * K
+    print(f"wgrad {name:8s} GF {fl / 1e9:5.1f} MB {M * (Cin + Cout) * 2 / 1e6:5.0f} | " + " | ".join(out), flush=True)
+    del xs, dys
