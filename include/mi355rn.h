@@ -79,19 +79,32 @@ int mi355_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw, floa
                        size_t ws_bytes, void* stream);
 
 /* real-image ingest: the GPU half of the reference's DALI pipelines, after the JPEG decoder —
- * train sota_imagenet/dali_dataloader.py:69-78 (random crop at decode, fn.resize size=S INTERP_TRIANGULAR) + :111-120
+ * train sota_imagenet/dali_dataloader.py:69-83 (random crop at decode, fn.resize size=S INTERP_TRIANGULAR, or INTERP_CUBIC by
+ * coin), :85-114 (gaussian blur window 11, colour twist, grey via hsv saturation, random erasing with the mean), :116-125
  * (crop_mirror_normalize: mirror coin, mean 127.5 / std 51 (:27-29), FLOAT, NCHW); val :144-157 (resize_shorter, centre crop).
  * `packed` (device) holds the decoded u8 RGB crops of one batch back to back (HWC, tight rows); sample n is described by
- * crops[n]: resize its h x w rectangle to rh x rw with the triangular (antialiased bilinear) filter, take the S x S window at
- * (oy, ox), mirror it if asked, write (v - mean) / std to out_nchw[n] (fp32 [N,3,S,S], what mi355_resnet50_forward takes).
- * The table is passed twice: the host copy is validated against packed_bytes before the launch (MI355_E_ARG on a rectangle
- * that leaves the buffer or a window that leaves the resized image), the device copy is what the kernel reads.          */
+ * crops[n]: resize its h x w rectangle to rh x rw (filter 0: triangular = antialiased bilinear, 1: a = -0.5 cubic), take the
+ * S x S window at (oy, ox), [augment[n]: gaussian blur (sigma > 0), 3x4 colour matrix on 0..255 values + clamp, luma if gray,
+ * up to 4 rectangles y0,x0,y1,x1 (window coordinates before the mirror) filled with the mean], mirror if asked, write
+ * (v - mean) / std to out_nchw[n] (fp32 [N,3,S,S], what mi355_resnet50_forward takes).  Tables are passed twice: the host copy
+ * is validated against packed_bytes before the launch (MI355_E_ARG on a rectangle that leaves the buffer or a window that
+ * leaves the resized image), the device copy is what the kernels read.  `scratch` (N*3*S*S floats) is needed only when some
+ * sample of the batch has blur_sigma > 0 (two launches then), else NULL.                                                */
 typedef struct mi355_crop {
   unsigned long long offset;
-  int h, w, rh, rw, oy, ox, mirror, pad;
+  int h, w, rh, rw, oy, ox, mirror, filter;
 } mi355_crop;
+typedef struct mi355_augment {
+  float color[12];
+  float blur_sigma;
+  int gray, nbox, pad;
+  int box[4][4];
+} mi355_augment;
 int mi355_ingest_u8(const unsigned char* packed, size_t packed_bytes, const mi355_crop* crops_host, const mi355_crop* crops_dev,
                     int N, int S, float mean, float std, float* out_nchw, void* stream);
+int mi355_ingest_u8_aug(const unsigned char* packed, size_t packed_bytes, const mi355_crop* crops_host,
+                        const mi355_crop* crops_dev, const mi355_augment* aug_host, const mi355_augment* aug_dev, int N, int S,
+                        float mean, float std, float* scratch, float* out_nchw, void* stream);
 
 /* fp8 (OCP e4m3fn) operand path of the convolution — BASELINE.json configs[4] "fp8 MFMA convs" (the reference has no fp8
  * path; the conv calls being replaced are the same as above, callbacks.py:316-317).  Per-tensor scaling:

@@ -10,8 +10,11 @@ Split of the work (DALI's "mixed" decoder + GPU operators):
           buffer with a descriptor table
   device  ONE launch of mi355_ingest_u8 (csrc/ingest.hip): triangular-filter resize to S x S (train :78) or
           resize-shorter + centre window (val :144-149), mirror coin (:113-116), normalise with 127.5 / 51 (:27-29), NCHW fp32
-Augmentations that are off in every r50 recipe (blur, colour twist, grey, random erasing: :80-109, all `*_prob = 0` defaults,
-arg_parser.py:33-50) are not implemented: a non-zero probability raises instead of being ignored.
+The optional augmentations of the train pipeline (:78-114; all `*_prob = 0` by default, arg_parser.py:33-50; `ctwist: true` of
+the legacy recipes maps to color_twist_prob) are drawn per sample on the host and applied by the same launch(es): cubic-or-
+triangular resize by coin (`random_interpolation`), gaussian blur (window 11, sigma ~ U[0.5, 1.1]), colour twist (contrast /
+brightness ~ U[0.7, 1.3], hue ~ U[-20, 20] degrees, saturation ~ U[0.7, 1.3]), grey coin, random erasing (`re_count`
+rectangles, anchor ~ U[0, 1], side ~ U[0.05, 0.25] of the image, filled with the mean).  TFRecords are not supported.
 There is no GPU JPEG decoder in this image (no rocJPEG), so end-to-end real-data throughput is bound by the host decode
 (~150 img/s per core); the synthetic loader remains the benchmark feed (BASELINE.json: data = synthetic)."""
 import math
@@ -29,8 +32,24 @@ from .fit_wrapper import env_rank, env_world_size
 DATA_MEAN, DATA_STD = 127.5, 51.0
 IMG_EXT = (".jpeg", ".jpg", ".png", ".bmp", ".ppm", ".webp")
 CROP_DTYPE = np.dtype([("offset", "<u8"), ("h", "<i4"), ("w", "<i4"), ("rh", "<i4"), ("rw", "<i4"), ("oy", "<i4"), ("ox", "<i4"),
-                       ("mirror", "<i4"), ("pad", "<i4")])  # = mi355_crop (include/mi355rn.h), 40 bytes
-assert CROP_DTYPE.itemsize == 40
+                       ("mirror", "<i4"), ("filter", "<i4")])  # = mi355_crop (include/mi355rn.h), 40 bytes
+AUG_DTYPE = np.dtype([("color", "<f4", (12,)), ("blur_sigma", "<f4"), ("gray", "<i4"), ("nbox", "<i4"), ("pad", "<i4"),
+                      ("box", "<i4", (4, 4))])  # = mi355_augment, 128 bytes
+assert CROP_DTYPE.itemsize == 40 and AUG_DTYPE.itemsize == 128
+IDENTITY_COLOR = np.eye(3, 4, dtype=np.float32).reshape(12)
+_RGB2YIQ = np.array([[0.299, 0.587, 0.114], [0.596, -0.274, -0.321], [0.211, -0.523, 0.311]])
+_YIQ2RGB = np.array([[1.0, 0.956, 0.621], [1.0, -0.272, -0.647], [1.0, -1.107, 1.705]])
+
+
+def twist_matrix(brightness, contrast, hue_deg, saturation):
+    """fn.color_twist (:89-98) as one 3 x 4 matrix on 0..255 values: chroma rotated by `hue_deg` and scaled by `saturation` in
+    YIQ, contrast about 128, then brightness — v' = b * (128 + c * (HS v - 128))."""
+    h = math.radians(hue_deg)
+    rot = np.array([[1.0, 0.0, 0.0], [0.0, saturation * math.cos(h), -saturation * math.sin(h)], [0.0, saturation * math.sin(h), saturation * math.cos(h)]])
+    m = np.zeros((3, 4))
+    m[:, :3] = brightness * contrast * (_YIQ2RGB @ rot @ _RGB2YIQ)
+    m[:, 3] = brightness * (1.0 - contrast) * 128.0
+    return m.astype(np.float32).reshape(12)
 
 
 def list_image_folder(root):
@@ -82,11 +101,17 @@ class ImageFolderLoader:
         self.workers = max(1, int(cfg.get("workers", 6)))
         self.min_area = float(cfg.get("min_area", 0.08))
         self.full_crop = bool(cfg.get("full_crop", False))
-        for k in ("blur_prob", "gray_prob", "color_twist_prob", "re_prob"):
-            if float(cfg.get(k, 0) or 0) > 0:
-                raise NotImplementedError(f"loader.{k} > 0: this augmentation is not part of the MI355X ingest (defaults are 0)")
-        if cfg.get("random_interpolation") or cfg.get("use_tfrecords"):
-            raise NotImplementedError("random_interpolation / use_tfrecords are not supported by the MI355X ingest")
+        self.blur_prob, self.gray_prob = float(cfg.get("blur_prob", 0) or 0), float(cfg.get("gray_prob", 0) or 0)
+        self.color_twist_prob, self.re_prob = float(cfg.get("color_twist_prob", 0) or 0), float(cfg.get("re_prob", 0) or 0)
+        self.re_count = int(cfg.get("re_count", 3))
+        self.contrast_range = tuple(cfg.get("contrast_range", (0.7, 1.3)))
+        self.brightness_range = tuple(cfg.get("brightness_range", (0.7, 1.3)))
+        self.random_interpolation = bool(cfg.get("random_interpolation", False))
+        self.augmenting = not is_val and (self.blur_prob > 0 or self.gray_prob > 0 or self.color_twist_prob > 0 or self.re_prob > 0)
+        if self.re_prob > 0 and not 1 <= self.re_count <= 4:
+            raise ValueError(f"loader.re_count = {self.re_count}: the ingest kernel erases 1..4 rectangles per image")
+        if cfg.get("use_tfrecords"):
+            raise NotImplementedError("use_tfrecords is not supported by the MI355X ingest (folders only)")
         root = os.path.join(str(cfg["root_data_dir"]), "val" if is_val else "train")
         self.samples, self.classes = list_image_folder(root)
         if len(self.classes) > self.num_classes:
@@ -120,18 +145,39 @@ class ImageFolderLoader:
         with Image.open(path) as im:
             W, H = im.size
             if self.is_val:
-                box, mirror = (0, 0, W, H), 0
+                box, mirror, filt, aug = (0, 0, W, H), 0, 0, None
             else:
                 rng = np.random.default_rng(sample_seed)
                 box = random_crop_box(rng, W, H, self.min_area)
                 mirror = int(rng.integers(0, 2))
+                filt = int(rng.integers(0, 2)) if self.random_interpolation else 0
+                aug = self._draw_augment(rng) if self.augmenting else None
             px = np.asarray(im.convert("RGB").crop((box[0], box[1], box[0] + box[2], box[1] + box[3])), dtype=np.uint8)
         h, w = px.shape[:2]
         geo = val_geometry(h, w, S, self.full_crop) if self.is_val else (S, S, 0, 0)
-        return px, geo, mirror, label
+        return px, geo, mirror, label, filt, aug
+
+    def _draw_augment(self, rng):
+        """one mi355_augment record: the coins and uniform draws of dali_dataloader.py:85-114 for one image"""
+        S = self.image_size
+        a = np.zeros((), dtype=AUG_DTYPE)
+        a["color"] = IDENTITY_COLOR
+        if self.blur_prob > 0 and rng.random() < self.blur_prob:
+            a["blur_sigma"] = rng.uniform(0.5, 1.1)
+        if self.color_twist_prob > 0 and rng.random() < self.color_twist_prob:
+            a["color"] = twist_matrix(rng.uniform(*self.brightness_range), rng.uniform(*self.contrast_range), rng.uniform(-20.0, 20.0), rng.uniform(0.7, 1.3))
+        if self.gray_prob > 0 and rng.random() < self.gray_prob:
+            a["gray"] = 1
+        if self.re_prob > 0 and rng.random() < self.re_prob:
+            a["nbox"] = self.re_count
+            for k in range(self.re_count):
+                y0, x0 = int(rng.uniform(0.0, 1.0) * S), int(rng.uniform(0.0, 1.0) * S)
+                hh, ww = int(round(rng.uniform(0.05, 0.25) * S)), int(round(rng.uniform(0.05, 0.25) * S))
+                a["box"][k] = (y0, x0, min(y0 + hh, S), min(x0 + ww, S))
+        return a
 
     def host_batch(self, indices, epoch, batch_no, pool):
-        """decode + pack one batch: (packed u8 ndarray, CROP_DTYPE table, int64 labels)"""
+        """decode + pack one batch: (packed u8 ndarray, CROP_DTYPE table, int64 labels, AUG_DTYPE table or None)"""
         jobs = [(int(i), (self.seed, epoch, int(i))) for i in indices]
         out = list(pool.map(self._decode, jobs))
         table = np.zeros(len(out), dtype=CROP_DTYPE)
@@ -139,19 +185,27 @@ class ImageFolderLoader:
         offs = np.concatenate([[0], np.cumsum([(s + 15) // 16 * 16 for s in sizes])])  # 16-byte aligned starts
         packed = np.zeros(int(offs[-1]), dtype=np.uint8)
         labels = np.zeros(len(out), dtype=np.int64)
-        for n, (px, geo, mirror, label) in enumerate(out):
+        augs = np.zeros(len(out), dtype=AUG_DTYPE) if self.augmenting else None
+        for n, (px, geo, mirror, label, filt, aug) in enumerate(out):
             packed[offs[n]:offs[n] + px.size] = px.reshape(-1)
-            table[n] = (offs[n], px.shape[0], px.shape[1], geo[0], geo[1], geo[2], geo[3], mirror, 0)
+            table[n] = (offs[n], px.shape[0], px.shape[1], geo[0], geo[1], geo[2], geo[3], mirror, filt)
             labels[n] = label
-        return packed, table, labels
+            if augs is not None:
+                augs[n] = aug
+        return packed, table, labels, augs
 
     # ---- device half -------------------------------------------------------------------------------------------------
-    def to_device(self, packed, table, labels):
-        """upload + ONE ingest launch on the current stream -> (data NCHW fp32 [N,3,S,S], one-hot fp32 [N,num_classes])"""
+    def to_device(self, packed, table, labels, augs=None):
+        """upload + ONE ingest launch (two when a sample is blurred) on the current stream ->
+        (data NCHW fp32 [N,3,S,S], one-hot fp32 [N,num_classes])"""
         dev = self.device
         p = torch.from_numpy(packed).pin_memory().to(dev, non_blocking=True)
         t = torch.from_numpy(table.view(np.uint8)).pin_memory().to(dev, non_blocking=True)
-        data = ops.ingest_u8(p, table, t, self.image_size, DATA_MEAN, DATA_STD)
+        if augs is None:
+            data = ops.ingest_u8(p, table, t, self.image_size, DATA_MEAN, DATA_STD)
+        else:
+            a = torch.from_numpy(augs.view(np.uint8)).pin_memory().to(dev, non_blocking=True)
+            data = ops.ingest_u8(p, table, t, self.image_size, DATA_MEAN, DATA_STD, aug_host=augs, aug_dev=a)
         lab = torch.from_numpy(labels).to(dev, non_blocking=True)
         onehot = torch.zeros((len(labels), self.num_classes), dtype=torch.float32, device=dev).scatter_(1, lab[:, None], 1.0)
         return data, onehot

@@ -63,15 +63,22 @@ def conv2d_dgrad_fp8(dyq, wq, x_shape, stride=1, pad=0, oscale=1.0, wt=None):
     return dx
 
 
-def ingest_u8(packed, table_host, table_dev, S, mean=127.5, std=51.0):
+def ingest_u8(packed, table_host, table_dev, S, mean=127.5, std=51.0, aug_host=None, aug_dev=None):
     """decoded u8 RGB crops (packed device bytes + mi355_crop table as a numpy structured array and its device copy) ->
-    fp32 NCHW [N,3,S,S]: triangular-filter resize, window, mirror, normalise (csrc/ingest.hip)."""
-    _need_cuda(packed, table_dev)
+    fp32 NCHW [N,3,S,S]: resize, window, [augment table: blur / colour / grey / erase], mirror, normalise (csrc/ingest.hip)."""
+    _need_cuda(packed, table_dev, aug_dev)
     N = int(table_host.shape[0])
     if table_host.dtype.itemsize != 40 or table_dev.numel() * table_dev.element_size() != 40 * N or not table_host.flags["C_CONTIGUOUS"]:
         raise ValueError("ingest_u8: the descriptor table must be N contiguous 40-byte mi355_crop records on both sides")
     out = torch.empty((N, 3, S, S), dtype=torch.float32, device=packed.device)
-    check(_L().mi355_ingest_u8(ptr(packed), packed.numel(), table_host.ctypes.data, ptr(table_dev), N, int(S), float(mean), float(std), ptr(out), cur_stream()))
+    if aug_host is None:
+        check(_L().mi355_ingest_u8(ptr(packed), packed.numel(), table_host.ctypes.data, ptr(table_dev), N, int(S), float(mean), float(std), ptr(out), cur_stream()))
+        return out
+    if aug_host.dtype.itemsize != 128 or aug_host.shape[0] != N or aug_dev is None or aug_dev.numel() * aug_dev.element_size() != 128 * N or not aug_host.flags["C_CONTIGUOUS"]:
+        raise ValueError("ingest_u8: the augment table must be N contiguous 128-byte mi355_augment records on both sides")
+    scratch = torch.empty((N, 3, S, S), dtype=torch.float32, device=packed.device) if bool((aug_host["blur_sigma"] > 0).any()) else None
+    check(_L().mi355_ingest_u8_aug(ptr(packed), packed.numel(), table_host.ctypes.data, ptr(table_dev), aug_host.ctypes.data, ptr(aug_dev), N, int(S),
+                                   float(mean), float(std), ptr(scratch), ptr(out), cur_stream()))
     return out
 
 

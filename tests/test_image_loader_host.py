@@ -32,6 +32,65 @@ def test_oracle_resize_matches_pillow_bilinear(shape):
     assert np.abs(I.resize(const, rh, rw) - 137.0).max() < 1e-9
 
 
+@pytest.mark.parametrize("shape", [(300, 400, 224, 224), (100, 80, 224, 224), (37, 53, 64, 64), (224, 224, 224, 224), (700, 500, 128, 128)])
+def test_oracle_cubic_matches_pillow_bicubic(shape):
+    """the coin of `random_interpolation` (:79-83): the a = -0.5 cubic against Pillow's BICUBIC (mid-range pixels: Pillow clips
+    its 8-bit intermediate, the oracle only the result)"""
+    h, w, rh, rw = shape
+    img = np.random.default_rng(h + w).integers(64, 192, (h, w, 3), dtype=np.uint8)
+    ref = np.asarray(Image.fromarray(img).resize((rw, rh), Image.BICUBIC)).astype(np.float64)
+    assert np.abs(I.resize(img, rh, rw, 1) - ref).max() <= 1.1, shape
+
+
+def test_oracle_blur_colour_grey_erase():
+    import colorsys
+
+    import scipy.ndimage as ndi
+
+    rng = np.random.default_rng(5)
+    win = rng.uniform(0, 255, (40, 40, 3))
+    for sigma in (0.5, 0.8, 1.1):
+        d = np.arange(-5, 6)
+        w = np.exp(-0.5 * (d / sigma) ** 2)
+        w /= w.sum()
+        ref = ndi.correlate1d(ndi.correlate1d(win, w, axis=0, mode="mirror"), w, axis=1, mode="mirror")  # scipy "mirror" = reflect-101
+        assert np.abs(I.gaussian_blur(win, sigma) - ref).max() < 1e-9
+    # colour: the YIQ transform is the one of the standard library; neutral parameters are (nearly) the identity; saturation 0
+    # leaves luma only; contrast 0 gives uniform 128 * brightness; product and oracle agree
+    for rgb in [(0.2, 0.5, 0.9), (1.0, 0.0, 0.3)]:
+        assert np.allclose(I.RGB2YIQ @ np.array(rgb), colorsys.rgb_to_yiq(*rgb), atol=6e-3)
+    assert np.abs(I.twist_matrix()[:, :3] - np.eye(3)).max() < 2e-3 and not I.twist_matrix()[:, 3].any()
+    m0 = I.twist_matrix(saturation=0.0)
+    assert np.allclose(m0[:, :3], np.tile(I.LUMA, (3, 1)), atol=1e-9)
+    mc = I.twist_matrix(brightness=1.2, contrast=0.0)
+    assert np.allclose(mc[:, :3], 0.0) and np.allclose(mc[:, 3], 1.2 * 128.0)
+    assert np.allclose(L.twist_matrix(1.1, 0.8, 15.0, 1.2).reshape(3, 4), I.twist_matrix(1.1, 0.8, 15.0, 1.2), atol=1e-5)
+    out = I.augment(win, dict(color=I.twist_matrix(1.3, 1.3, 10.0, 1.3), gray=1, boxes=[(2, 3, 10, 12), (30, 30, 40, 40)]))
+    assert out.min() >= 0.0 and out.max() <= 255.0 and np.allclose(out[..., 0], out[..., 1])
+    assert np.all(out[2:10, 3:12] == I.DATA_MEAN) and np.all(out[30:, 30:] == I.DATA_MEAN) and not np.all(out[0, 0] == I.DATA_MEAN)
+
+
+def test_augment_draws_follow_the_recipe(tmp_path):
+    _make_folder(str(tmp_path), "train", n_classes=1, per_class=1)
+    cfg = dict(batch_size=1, image_size=64, num_classes=10, workers=1, root_data_dir=str(tmp_path), blur_prob=0.5, gray_prob=0.3, color_twist_prob=0.6,
+               re_prob=0.4, re_count=3, random_interpolation=True)
+    ld = L.ImageFolderLoader(cfg, device="cpu")
+    assert ld.augmenting
+    recs = [ld._draw_augment(np.random.default_rng(k)) for k in range(400)]
+    blur = np.array([float(r["blur_sigma"]) for r in recs])
+    assert 0.4 < (blur > 0).mean() < 0.6 and blur[blur > 0].min() >= 0.5 and blur.max() <= 1.1
+    assert 0.2 < np.mean([int(r["gray"]) for r in recs]) < 0.4
+    tw = np.array([not np.array_equal(r["color"], L.IDENTITY_COLOR) for r in recs])
+    assert 0.5 < tw.mean() < 0.7
+    er = [r for r in recs if r["nbox"]]
+    assert 0.3 < len(er) / 400 < 0.5 and all(int(r["nbox"]) == 3 for r in er)
+    for r in er:
+        for (y0, x0, y1, x1) in r["box"][:3]:
+            assert 0 <= y0 <= y1 <= 64 and 0 <= x0 <= x1 <= 64 and y1 - y0 <= 16 and x1 - x0 <= 16  # sides <= 0.25 * S
+    assert L.ImageFolderLoader(dict(cfg, blur_prob=0, gray_prob=0, color_twist_prob=0, re_prob=0), device="cpu").augmenting is False
+    assert L.ImageFolderLoader(cfg, is_val=False, device="cpu").random_interpolation
+
+
 def test_oracle_window_and_mirror_are_slices_of_the_full_resize():
     rng = np.random.default_rng(3)
     img = rng.integers(0, 256, (90, 130, 3), dtype=np.uint8)
@@ -90,8 +149,9 @@ def test_loader_protocol_and_packing(tmp_path, monkeypatch):
     assert sorted(order.tolist()) == list(range(15)) and not np.array_equal(order, np.arange(15))
     assert not np.array_equal(order, ld._shard_indices(1))  # reshuffled every epoch (random_shuffle=True :56)
     with ThreadPoolExecutor(2) as pool:
-        packed, table, labels = ld.host_batch(order[:4], 0, 0, pool)
-        packed2, table2, _ = ld.host_batch(order[:4], 0, 0, pool)
+        packed, table, labels, augs = ld.host_batch(order[:4], 0, 0, pool)
+        packed2, table2, _, _ = ld.host_batch(order[:4], 0, 0, pool)
+    assert augs is None and not table["filter"].any()  # every optional augmentation is off by default
     assert np.array_equal(packed, packed2) and np.array_equal(table, table2)  # crops are a function of (seed, epoch, sample)
     assert table.dtype.itemsize == 40 and table.shape == (4,)
     for n, idx in enumerate(order[:4]):
@@ -121,7 +181,7 @@ def test_loader_protocol_and_packing(tmp_path, monkeypatch):
     lv = L.ImageFolderLoader(dict(cfg, batch_size=3), is_val=True, seed=7, device="cpu")
     assert np.array_equal(lv._shard_indices(0), np.arange(6)) and len(lv) == 2
     with ThreadPoolExecutor(2) as pool:
-        packed, table, labels = lv.host_batch(np.arange(3), 0, 0, pool)
+        packed, table, labels, _ = lv.host_batch(np.arange(3), 0, 0, pool)
     for n in range(3):
         full = np.asarray(Image.open(lv.samples[n][0]).convert("RGB"))
         t = table[n]
@@ -134,8 +194,10 @@ def test_unsupported_augmentations_raise_and_source_selection(tmp_path):
 
     _make_folder(str(tmp_path), "train", n_classes=2, per_class=2)
     cfg = dict(batch_size=2, image_size=32, num_classes=10, workers=1, root_data_dir=str(tmp_path))
-    with pytest.raises(NotImplementedError, match="blur_prob"):
-        L.ImageFolderLoader(dict(cfg, blur_prob=0.3), device="cpu")
+    with pytest.raises(NotImplementedError, match="use_tfrecords"):
+        L.ImageFolderLoader(dict(cfg, use_tfrecords=True), device="cpu")
+    with pytest.raises(ValueError, match="re_count"):
+        L.ImageFolderLoader(dict(cfg, re_prob=0.5, re_count=7), device="cpu")
     with pytest.raises(ValueError, match="class directories"):
         L.ImageFolderLoader(dict(cfg, num_classes=1), device="cpu")
     assert isinstance(data.make_loader(cfg, 100, 0, "cpu", 2, False, "auto"), L.ImageFolderLoader)

@@ -22,7 +22,7 @@ def _pack(crops, descs):
     table = np.zeros(len(crops), dtype=CROP_DTYPE)
     off, parts = 0, []
     for n, (px, d) in enumerate(zip(crops, descs)):
-        table[n] = (off, px.shape[0], px.shape[1], d[0], d[1], d[2], d[3], d[4], 0)
+        table[n] = (off, px.shape[0], px.shape[1], d[0], d[1], d[2], d[3], d[4], d[5] if len(d) > 5 else 0)
         parts.append(px.reshape(-1))
         pad = (-px.size) % 16
         parts.append(np.zeros(pad, dtype=np.uint8))
@@ -30,13 +30,58 @@ def _pack(crops, descs):
     return np.concatenate(parts), table
 
 
-def _run(crops, descs, S, dev):
+def _run(crops, descs, S, dev, augs=None):
     from sota_imagenet_amd import ops
 
     packed, table = _pack(crops, descs)
     p = torch.from_numpy(packed).to(dev)
     t = torch.from_numpy(table.view(np.uint8)).to(dev)
-    return ops.ingest_u8(p, table, t, S).cpu().numpy(), (p, table, t)
+    a = None if augs is None else torch.from_numpy(augs.view(np.uint8)).to(dev)
+    return ops.ingest_u8(p, table, t, S, aug_host=augs, aug_dev=a).cpu().numpy(), (p, table, t)
+
+
+def test_ingest_cubic_filter_and_every_augmentation(dev):
+    """the optional operators of the train pipeline (dali_dataloader.py:78-114) against the oracle, alone and stacked; a batch
+    with a blurred sample takes the two-launch path, one without stays on the single launch — both must agree with the oracle"""
+    from sota_imagenet_amd.image_loader import AUG_DTYPE, IDENTITY_COLOR, twist_matrix
+
+    rng = np.random.default_rng(1)
+    S = 48
+    sizes = [(120, 160), (30, 30), (200, 90), (64, 64), (48, 48), (333, 500)]
+    crops = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    descs = [(S, S, 0, 0, n & 1, (n >> 1) & 1) for n in range(len(sizes))]  # mirror and filter in every combination
+    augs = np.zeros(len(sizes), dtype=AUG_DTYPE)
+    augs["color"] = IDENTITY_COLOR
+    augs[1]["color"] = twist_matrix(1.25, 0.75, -18.0, 1.3)
+    augs[2]["gray"] = 1
+    augs[3]["nbox"] = 3
+    augs[3]["box"][:3] = [(0, 0, 10, 7), (40, 20, 48, 48), (5, 30, 5, 40)]  # corner, clipped at the border, empty
+    augs[4]["color"] = twist_matrix(0.7, 1.3, 20.0, 0.7)
+    augs[4]["gray"] = 1
+    augs[4]["nbox"] = 1
+    augs[4]["box"][0] = (10, 10, 20, 30)
+
+    def as_dict(a):
+        return dict(color=np.asarray(a["color"], dtype=np.float64), blur_sigma=float(a["blur_sigma"]), gray=int(a["gray"]),
+                    boxes=[tuple(int(v) for v in a["box"][k]) for k in range(int(a["nbox"]))])
+
+    for blur in (False, True):
+        if blur:
+            augs[0]["blur_sigma"] = 0.8
+            augs[4]["blur_sigma"] = 1.1
+            augs[5]["blur_sigma"] = 0.5
+        got, _ = _run(crops, descs, S, dev, augs)
+        for n, (px, d) in enumerate(zip(crops, descs)):
+            ref = I.ingest_one(px, d[0], d[1], d[2], d[3], S, d[4], filt=d[5], aug=as_dict(augs[n]))
+            assert np.abs(got[n] - ref).max() < 3e-5, (blur, n)  # (the colour matrix is stored in fp32)
+    # filter alone, no augment table: plain entry point
+    got, _ = _run(crops, descs, S, dev)
+    for n in (2, 3, 5):
+        assert np.abs(got[n] - I.ingest_one(crops[n], S, S, 0, 0, S, descs[n][4], filt=descs[n][5])).max() < TOL
+    bad = augs.copy()
+    bad[0]["nbox"] = 5
+    with pytest.raises(RuntimeError, match="nbox"):
+        _run(crops, descs, S, dev, bad)
 
 
 def test_ingest_matches_oracle_train_and_val_geometries(dev):
@@ -78,7 +123,8 @@ def test_ingest_rejects_bad_descriptors(dev):
 
     px = np.zeros((8, 8, 3), dtype=np.uint8)
     _, (p, table, t) = _run([px], [(16, 16, 0, 0, 0)], 16, dev)
-    for field, value, msg in [("offset", 64, "past the packed buffer"), ("oy", 1, "leaves"), ("h", 0, "empty"), ("mirror", 2, "mirror"), ("rw", 15, "leaves")]:
+    for field, value, msg in [("offset", 64, "past the packed buffer"), ("oy", 1, "leaves"), ("h", 0, "empty"), ("mirror", 2, "mirror"), ("rw", 15, "leaves"),
+                              ("filter", 2, "filter")]:
         bad = table.copy()
         bad[field] = value
         with pytest.raises(RuntimeError, match=msg):
@@ -117,7 +163,7 @@ def test_folder_loader_end_to_end(dev, tmp_path):
         assert data.abs().max().item() <= 2.5 + 1e-6
     order = ld._shard_indices(0)
     with ThreadPoolExecutor(2) as pool:
-        packed, table, labels = ld.host_batch(order[:4], 0, 0, pool)
+        packed, table, labels, _ = ld.host_batch(order[:4], 0, 0, pool)
     assert torch.equal(batches[0][1].argmax(1).cpu(), torch.from_numpy(labels))
     for n in range(4):
         t = table[n]
@@ -126,6 +172,20 @@ def test_folder_loader_end_to_end(dev, tmp_path):
         assert np.abs(batches[0][0][n].cpu().numpy() - ref).max() < TOL
     second = list(ld)  # next epoch: reshuffled, re-cropped
     assert len(second) == len(batches) and not torch.equal(second[0][0], batches[0][0])
+    # the full augmentation recipe of the later experiment configs (hydra_exp/10.*: blur / grey / twist / erase / random interpolation)
+    la = L.ImageFolderLoader(dict(cfg, blur_prob=0.5, gray_prob=0.3, color_twist_prob=0.6, re_prob=0.5, re_count=3, random_interpolation=True), seed=3)
+    ab = list(la)
+    assert len(ab) == len(batches) and all(torch.isfinite(d).all() and d.abs().max().item() <= 2.5 + 1e-5 for d, _ in ab)
+    with ThreadPoolExecutor(2) as pool:
+        packed, table, labels, augs = la.host_batch(la._shard_indices(0)[:4], 0, 0, pool)
+    assert augs is not None and augs.shape == (4,)
+    for n in range(4):
+        t, a = table[n], augs[n]
+        o, h, w = int(t["offset"]), int(t["h"]), int(t["w"])
+        ad = dict(color=np.asarray(a["color"], dtype=np.float64), blur_sigma=float(a["blur_sigma"]), gray=int(a["gray"]),
+                  boxes=[tuple(int(v) for v in a["box"][k]) for k in range(int(a["nbox"]))])
+        ref = I.ingest_one(packed[o:o + h * w * 3].reshape(h, w, 3), 64, 64, 0, 0, 64, int(t["mirror"]), filt=int(t["filter"]), aug=ad)
+        assert np.abs(ab[0][0][n].cpu().numpy() - ref).max() < 3e-5
     lv = L.ImageFolderLoader(dict(cfg, batch_size=3), is_val=True, seed=3)
     vb = list(lv)
     assert len(vb) == 2 and vb[0][0].shape == (3, 3, 64, 64)
