@@ -1,5 +1,9 @@
 // conv_api.cpp — geometry builders and the per-op C-ABI entry points declared in include/mi355rn.h.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <set>
 #include <string>
 
 #include "common.h"
@@ -17,6 +21,19 @@ void set_error(const char* fmt, ...) {
   g_err = buf;
 }
 const char* get_error() { return g_err.c_str(); }
+
+int probe_env(const char* name) {
+  const char* v = getenv(name);
+  const int x = v ? atoi(v) : 0;
+  if (x != 0) {
+    static std::mutex mu;
+    static std::set<std::string> warned;
+    std::lock_guard<std::mutex> lock(mu);
+    if (warned.insert(name).second)
+      fprintf(stderr, "libmi355rn: %s=%d — timing probe active: kernels skip loads / stores, RESULTS ARE NOT VALID\n", name, x);
+  }
+  return x;
+}
 
 static int out_dim(int H, int K, int s, int p) { return (H + 2 * p - K) / s + 1; }
 

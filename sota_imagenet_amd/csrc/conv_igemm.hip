@@ -717,8 +717,7 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
     return e && strcmp(e, "mute") == 0;
   }();
   k.sk_mute = sk_mute ? 1 : 0;
-  const char* dbg_env = getenv("MI355_IGEMM_DBG");  // read per launch: timing probes only, results are wrong with it set
-  k.dbg = dbg_env ? atoi(dbg_env) : 0;
+  k.dbg = probe_env("MI355_IGEMM_DBG");  // read per launch: timing probes only, results are wrong with it set
   k.sk_spin_limit = sk_mute ? (1u << 8) : (1u << 24);
   bool sk = false;
   // (fp32 only: a hand-off costs the owner ~10 us, nothing beside a 150-300 us fp32 tile, but most of what the cut

@@ -807,13 +807,11 @@ int launch8_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
   MI355_ARG(bytes_in < 0x80000000ull && bytes_wt < 0x80000000ull, "igemm8: tensor exceeds the 2 GiB buffer-offset range");
   k.bytes_in = (unsigned)bytes_in;
   k.bytes_wt = (unsigned)bytes_wt;
-#ifdef MI355_STAMP8
   // timing-only probes: a descriptor with zero records drops every load through it (the instruction stream stays)
-  if (const char* dbg = getenv("MI355_IGEMM8_DBG")) {
-    if (atoi(dbg) & 1) k.bytes_in = 0;
-    if (atoi(dbg) & 2) k.bytes_wt = 0;
+  if (const int dbg = probe_env("MI355_IGEMM8_DBG")) {
+    if (dbg & 1) k.bytes_in = 0;
+    if (dbg & 2) k.bytes_wt = 0;
   }
-#endif
   int grid = k.items < MAX_WG ? k.items : MAX_WG;
   grid -= grid % ng;  // items is a multiple of ng; a workgroup then keeps one n-tile group (statistics rows, weight reuse per XCD)
   if (grid == 0) grid = ng;
