@@ -823,6 +823,7 @@ int launch8_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
 #endif
   const bool stats = a.stat_partial != nullptr && chan <= 512 && lds + (size_t)2 * chan * 2 * sizeof(float) <= 160 * 1024;
   if (stat_rows) *stat_rows = stats ? grid / ng : 0;
+  if constexpr (EB == 2) {  // (the fp8 entry points take plain launches only: no statistics instantiations for EB = 1)
   if (stats) {
     lds += (size_t)2 * chan * 2 * sizeof(float);
     if (a.bn_y) {
@@ -833,6 +834,11 @@ int launch8_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
       hipLaunchKernelGGL((igemm8_kernel<BM, BN, 1, FAT, EB>), dim3(grid), dim3(512), lds, stream, k);
     }
   } else {
+    lds_opt_in8((const void*)igemm8_kernel<BM, BN, 0, FAT, EB>, lds);
+    hipLaunchKernelGGL((igemm8_kernel<BM, BN, 0, FAT, EB>), dim3(grid), dim3(512), lds, stream, k);
+  }
+  } else {
+    MI355_ARG(!stats, "igemm8 fp8: plain launches only");
     lds_opt_in8((const void*)igemm8_kernel<BM, BN, 0, FAT, EB>, lds);
     hipLaunchKernelGGL((igemm8_kernel<BM, BN, 0, FAT, EB>), dim3(grid), dim3(512), lds, stream, k);
   }
