@@ -188,6 +188,7 @@ int launch_bn_relu_maxpool(int dtype, const void* y, const float* scale, const f
 int launch_maxpool_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C,
                        hipStream_t s);
 int launch_gap_fwd(int dtype, const void* x, float* pooled, int N, int HW, int C, hipStream_t s);
+int launch_fc(const float* x, const float* w, float* out, int M, int N, int K, hipStream_t s);  // fc.hip: out = x * w^T, fp32
 int launch_gap_bwd(int dtype, const float* dpooled, void* dx, int N, int HW, int C, hipStream_t s);
 int launch_ce(const float* logits, const float* target, float smoothing, float grad_scale, float* loss,
               float* row_loss, float* dlogits, int N, int C, hipStream_t s);

@@ -498,10 +498,7 @@ int backward_fc(mi355_ctx* c, const float* dlogits, float beta_acc, hipStream_t 
   MI355_TRY(launch_splitk_reduce(c->wg_partial, splits, (size_t)P * 2048, c->grads + c->fc_w_off, (size_t)O * 2048,
                                  beta_acc, ws));
   // dgrad: dpooled[n][k] = sum_o dlogits[n][o] * W[o][k]
-  IgemmArgs a;
-  build_dgrad_args(a, N, 1, 1, 2048, P, 1, 1, 1, 0);
-  a.in = c->dlogits_pad; a.wt = c->fc_wtr; a.out = c->dpooled;
-  MI355_TRY(launch_igemm(MI355_F32, a, 1, s));
+  MI355_TRY(launch_fc(c->dlogits_pad, c->fc_wtr, c->dpooled, N, 2048, P, s));
   const Block& last = c->blocks.back();
   c->cur_dout = c->gG[0];
   c->bwd_parity = 0;
@@ -847,10 +844,7 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
   {
     Prof p(c, PC_OTHER, 0, 0, s);
     MI355_TRY(launch_gap_fwd(c->dtype, last.out, c->pooled, N, last.Hout * last.Wout, last.Cout, s));
-    IgemmArgs a;
-    build_fwd_args(a, N, 1, 1, 2048, c->fc_pad, 1, 1, 1, 0);
-    a.in = c->pooled; a.wt = c->params + c->fc_w_off; a.out = c->fc_tmp;
-    MI355_TRY(launch_igemm(MI355_F32, a, 1, s));
+    MI355_TRY(launch_fc(c->pooled, c->params + c->fc_w_off, c->fc_tmp, N, c->fc_pad, 2048, s));
     MI355_TRY(launch_bias_slice(c->fc_tmp, c->fc_pad, c->params + c->fc_b_off, logits, N, c->num_classes, s));
   }
   c->fwd_training_done = training != 0;
