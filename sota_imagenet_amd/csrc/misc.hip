@@ -365,12 +365,22 @@ __global__ void pad_dlogits_kernel(const float* __restrict__ src, float* __restr
   dst[i] = o < O ? src[(size_t)n * O + o] : 0.f;
 }
 
-__global__ void dbias_kernel(const float* __restrict__ src, float* __restrict__ dbias, float beta, int N, int O) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= O) return;
+// dbias[o] = sum_n src[n][o]: 64 outputs per workgroup, 16 row lanes each adding every 16th row in order, then a fixed LDS tree
+// (one thread per output walking all N rows took 45 us at N = 256 on the critical path of the backward)
+__global__ __launch_bounds__(1024) void dbias_kernel(const float* __restrict__ src, float* __restrict__ dbias, float beta, int N, int O) {
+  __shared__ float red[16][64];
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int o = blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int n = 0; n < N; ++n) s += src[(size_t)n * O + o];
-  dbias[o] = (beta != 0.f ? beta * dbias[o] : 0.f) + s;
+  if (o < O)
+    for (int n = r; n < N; n += 16) s += src[(size_t)n * O + o];
+  red[r][c] = s;
+  __syncthreads();
+  for (int st = 8; st > 0; st >>= 1) {
+    if (r < st) red[r][c] += red[r + st][c];
+    __syncthreads();
+  }
+  if (r == 0 && o < O) dbias[o] = (beta != 0.f ? beta * dbias[o] : 0.f) + red[0][c];
 }
 
 int grid_for(size_t total, int cap = 8192) {
@@ -510,7 +520,7 @@ int launch_pad_dlogits(const float* src, float* dst, int ld, float* dbias, float
   hipLaunchKernelGGL(pad_dlogits_kernel, dim3(cdiv(N * ld, 256)), dim3(256), 0, s, src, dst, ld, N, O);
   MI355_LAUNCH_CHECK();
   if (dbias) {
-    hipLaunchKernelGGL(dbias_kernel, dim3(cdiv(O, 256)), dim3(256), 0, s, src, dbias, beta, N, O);
+    hipLaunchKernelGGL(dbias_kernel, dim3(cdiv(O, 64)), dim3(1024), 0, s, src, dbias, beta, N, O);
     MI355_LAUNCH_CHECK();
   }
   return 0;
