@@ -20,7 +20,7 @@ seq.append(("igemm", "stem", None))
 for name, hin, ho, ci, p, ds in blocks:
     if ds: seq.append(("igemm", name + ".ds", (el(hin, ci) if hin == ho else el(hin, ci) / 4) + el(ho, 4 * p)))
     seq += [("igemm", name + ".c1", el(hin, ci) + el(hin, p)), ("igemm", name + ".c2", el(hin, p) + el(ho, p)), ("igemm", name + ".c3", el(ho, p) + el(ho, 4 * p))]
-seq += [("igemm", "fc", None), ("wgrad", "fc.w", None), ("igemm", "fc.d", None)]
+seq += [("wgrad", "fc.w", None)]  # (the head's forward / input-gradient GEMMs run on fc_kernel: not conv launches)
 for name, hin, ho, ci, p, ds in reversed(blocks):
     seq.append(("wgrad", name + ".c3.w", el(ho, p) + el(ho, 4 * p)))
     if ds: seq += [("igemm", name + ".ds.d", el(ho, 4 * p) + el(hin, ci)), ("wgrad", name + ".ds.w", el(ho, 4 * p) + el(hin, ci))]

@@ -23,8 +23,8 @@ seq.append(("igemm", "stem", fl(112, 3, 64, 7)))
 for name, hin, ho, ci, p, s, ds in blocks:
     if ds: seq.append(("igemm", name + ".ds", fl(ho, ci, 4 * p, 1)))
     seq += [("igemm", name + ".c1", fl(hin, ci, p, 1)), ("igemm", name + ".c2", fl(ho, p, p, 3)), ("igemm", name + ".c3", fl(ho, p, 4 * p, 1))]
-seq.append(("igemm", "fc", 2.0 * N * 2048 * 1000))
-seq += [("wgrad", "fc.w", 2.0 * N * 2048 * 1000), ("igemm", "fc.d", 2.0 * N * 2048 * 1000)]
+# (the head's forward / input-gradient GEMMs run on fc_kernel since round 2: not conv launches)
+seq += [("wgrad", "fc.w", 2.0 * N * 2048 * 1000)]
 for name, hin, ho, ci, p, s, ds in reversed(blocks):
     seq.append(("wgrad", name + ".c3.w", fl(ho, p, 4 * p, 1)))
     if ds: seq += [("igemm", name + ".ds.d", fl(ho, ci, 4 * p, 1)), ("wgrad", name + ".ds.w", fl(ho, ci, 4 * p, 1))]
