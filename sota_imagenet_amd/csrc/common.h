@@ -131,12 +131,13 @@ int launch_stem_unpack(float* partial, int splits, float* dw, float beta, hipStr
 int launch_weight_prep(int dtype, const float* w, void* w_cast, void* w_tr, int Cout, int taps, int Cin,
                        hipStream_t stream);
 // the same for every conv layer of a network in one launch; `table` (device memory) is sorted by tile_begin
+constexpr int PREP_TILE = 64;  // channels per side of a weight-prep tile (every conv of the network has multiples of 64)
 struct PrepDesc {
   size_t w_off;    // offset of the fp32 master in `params` (elements)
   void* w_cast;    // or null (cast copy not needed: fp32 ctx)
   void* w_tr;      // or null (no dgrad: inference forward)
   int Cout, taps, Cin;
-  int tile_begin;  // first block of this layer; a layer has (Cout/32)*(Cin/32)*taps blocks
+  int tile_begin;  // first block of this layer; a layer has (Cout/PREP_TILE)*(Cin/PREP_TILE)*taps blocks
 };
 int launch_weight_prep_batch(int dtype, const PrepDesc* table, int nlayers, int total_tiles, const float* params,
                              hipStream_t stream);

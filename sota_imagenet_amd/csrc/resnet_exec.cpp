@@ -678,7 +678,7 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
       tab[0].push_back(d);
       d.w_tr = l.w_tr;
       tab[1].push_back(d);
-      tiles += (l.Cout / 32) * (l.Cin / 32) * l.K * l.K;
+      tiles += (l.Cout / PREP_TILE) * (l.Cin / PREP_TILE) * l.K * l.K;
     };
     for (auto& b : c->blocks) {
       add(b.c1); add(b.c2); add(b.c3);

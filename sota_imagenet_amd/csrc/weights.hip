@@ -37,21 +37,24 @@ __global__ void weight_prep_kernel(const Tin* __restrict__ w, T* __restrict__ w_
 // all conv layers of the network in ONE launch (53 tiny launches cost more in launch latency than in bytes): block b
 // finds its layer in the prefix table and does the same 32x32 tile as weight_prep_kernel
 template <typename T>
-__global__ void weight_prep_batch_kernel(const PrepDesc* __restrict__ table, int nlayers, const float* __restrict__ params) {
-  __shared__ float tile[32][33];
+__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const PrepDesc* __restrict__ table, int nlayers, const float* __restrict__ params) {
+  // PREP_TILE = 64: a row of the tile is 256 bytes of fp32 in, 128 bytes of bf16 out (cast copy and transposed copy) — the 32-wide
+  // tile of round 1 wrote 64-byte segments and ran at 2.4 TB/s
+  constexpr int PT = PREP_TILE;
+  __shared__ float tile[PT][PT + 1];
   const int b = blockIdx.x;
   int l = 0;
   while (l + 1 < nlayers && table[l + 1].tile_begin <= b) ++l;  // uniform: scalar loads
   const PrepDesc d = table[l];
   const int local = b - d.tile_begin;
-  const int nci = d.Cin / 32, nco = d.Cout / 32;
-  const int ci0 = (local % nci) * 32, co0 = ((local / nci) % nco) * 32, t = local / (nci * nco);
+  const int nci = d.Cin / PT, nco = d.Cout / PT;
+  const int ci0 = (local % nci) * PT, co0 = ((local / nci) % nco) * PT, t = local / (nci * nco);
   const float* w = params + d.w_off;
   T* w_cast = reinterpret_cast<T*>(d.w_cast);
   T* w_tr = reinterpret_cast<T*>(d.w_tr);
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-  for (int r = ty; r < 32; r += 8) {
+  const int tx = threadIdx.x & (PT - 1), ty = threadIdx.x / PT;
+#pragma unroll 4
+  for (int r = ty; r < PT; r += 256 / PT) {
     const size_t src = ((size_t)(co0 + r) * d.taps + t) * d.Cin + ci0 + tx;
     const float v = w[src];
     tile[r][tx] = v;
@@ -59,8 +62,8 @@ __global__ void weight_prep_batch_kernel(const PrepDesc* __restrict__ table, int
   }
   __syncthreads();
   if (w_tr) {
-#pragma unroll
-    for (int r = ty; r < 32; r += 8) {
+#pragma unroll 4
+    for (int r = ty; r < PT; r += 256 / PT) {
       const size_t dst = ((size_t)(ci0 + r) * d.taps + t) * d.Cout + co0 + tx;
       w_tr[dst] = (T)tile[tx][r];
     }
