@@ -155,51 +155,158 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ y, const float* __r
   }
 }
 
+// The same operator, one thread per 2 x 2 block of OUTPUT pixels (Ho, Wo even): the four windows share a 5 x 5 input patch, so
+// 25 loads + BN/ReLU evaluations serve what four independent threads do with 36; a patch row is consumed as soon as it is loaded
+// (40 live values), taps reach every window in the same (kh, kw) scan order as above => identical maxima and argmax codes.
+template <typename T>
+__global__ void bn_relu_maxpool2_kernel(const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                        T* __restrict__ p, uint8_t* __restrict__ idx, uint8_t* __restrict__ bits, int N, int H, int W, int C,
+                                        int Ho, int Wo) {
+  constexpr int V = Vec16<T>::N;
+  const int cv = C / V;
+  const int Hb = Ho / 2, Wb = Wo / 2;
+  const size_t total = (size_t)N * Hb * Wb * cv;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cvi = (int)(i % cv);
+    const int c0 = cvi * V;
+    size_t t = i / cv;
+    const int bw = (int)(t % Wb);
+    t /= Wb;
+    const int bh = (int)(t % Hb);
+    const int n = (int)(t / Hb);
+    float sc[V], sh[V];
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(scale + c0 + 4 * q);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(shift + c0 + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[4 * q + e] = a[e];
+        sh[4 * q + e] = b[e];
+      }
+    }
+    float best[4][V];
+    int bi[4][V];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        best[w][e] = -INFINITY;
+        bi[w][e] = -1;
+      }
+    const int ih0 = 4 * bh - 1, iw0 = 4 * bw - 1;  // top-left corner of the 5 x 5 patch
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int ih = ih0 + r;
+      if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const int iw = iw0 + c;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const size_t pix = ((size_t)n * H + ih) * W + iw;
+        float v[V];
+        Vec16<T>::load(y + pix * C + c0, v);
+        unsigned m = 0;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const float a = fmaf(v[e], sc[e], sh[e]);
+          m |= (a > 0.f ? 1u : 0u) << e;
+          v[e] = (float)(T)(a > 0.f ? a : 0.f);  // the value the unfused path would have stored
+        }
+        if (r >= 1 && c >= 1) bits[pix * cv + cvi] = (uint8_t)m;  // rows / columns 1..4 of the patch are owned by this block
+        // windows (dr, dc) of the block that contain patch element (r, c): kh = r - 2 dr, kw = c - 2 dc in 0..2
+#pragma unroll
+        for (int dr = 0; dr < 2; ++dr) {
+          const int kh = r - 2 * dr;
+          if (kh < 0 || kh > 2) continue;
+#pragma unroll
+          for (int dc = 0; dc < 2; ++dc) {
+            const int kw = c - 2 * dc;
+            if (kw < 0 || kw > 2) continue;
+            const int w = 2 * dr + dc;
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+              if (bi[w][e] < 0 || v[e] > best[w][e] || v[e] != v[e]) {
+                best[w][e] = v[e];
+                bi[w][e] = kh * 3 + kw;
+              }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const size_t o = (((size_t)n * Ho + 2 * bh + (w >> 1)) * Wo + 2 * bw + (w & 1)) * C + c0;
+      Vec16<T>::store(p + o, best[w]);
+      if constexpr (V == 4) {
+        *reinterpret_cast<uint32_t*>(idx + o) = (uint32_t)bi[w][0] | ((uint32_t)bi[w][1] << 8) | ((uint32_t)bi[w][2] << 16) | ((uint32_t)bi[w][3] << 24);
+      } else {
+        uint2 x;
+        x.x = (uint32_t)bi[w][0] | ((uint32_t)bi[w][1] << 8) | ((uint32_t)bi[w][2] << 16) | ((uint32_t)bi[w][3] << 24);
+        x.y = (uint32_t)bi[w][4] | ((uint32_t)bi[w][5] << 8) | ((uint32_t)bi[w][6] << 16) | ((uint32_t)bi[w][7] << 24);
+        *reinterpret_cast<uint2*>(idx + o) = x;
+      }
+    }
+  }
+}
+
+// Gather form (no atomics): one thread per 2 x 2 block of INPUT pixels and channel vector.  The four windows (a,b), (a,b+1), (a+1,b),
+// (a+1,b+1) are the only ones that touch the block (an even row / column lies in one window, an odd one in two), so 4 loads of
+// dy + argmax serve the 9 (pixel, window) pairs a thread per pixel fetched with 9 loads.  A pixel adds its windows in (oh, ow)
+// order, as the per-pixel form did (bitwise the same result).
 template <typename T>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx,
                                    int N, int H, int W, int C, int Ho, int Wo) {
   constexpr int V = Vec16<T>::N;
   const int cv = C / V;
-  const size_t total = (size_t)N * H * W * cv;
+  const size_t total = (size_t)N * Ho * Wo * cv;  // H = 2 Ho, W = 2 Wo
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c0 = (int)(i % cv) * V;
     size_t t = i / cv;
-    const int iw = (int)(t % W);
-    t /= W;
-    const int ih = (int)(t % H);
-    const int n = (int)(t / H);
-    float acc[V];
+    const int b = (int)(t % Wo);
+    t /= Wo;
+    const int a = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float g[4][V];
+    uint8_t id[4][V];
 #pragma unroll
-    for (int e = 0; e < V; ++e) acc[e] = 0.f;
-    const int oh_hi = (ih + 1) / 2 < Ho - 1 ? (ih + 1) / 2 : Ho - 1;
-    const int ow_hi = (iw + 1) / 2 < Wo - 1 ? (iw + 1) / 2 : Wo - 1;
-    for (int oh = ih / 2; oh <= oh_hi; ++oh) {
-      const int kh = ih - 2 * oh + 1;
-      for (int ow = iw / 2; ow <= ow_hi; ++ow) {
-        const int kw = iw - 2 * ow + 1;
-        const int pos = kh * 3 + kw;
-        const size_t o = (((size_t)n * Ho + oh) * Wo + ow) * C + c0;
-        float g[V];
-        Vec16<T>::load(dy + o, g);
-        uint8_t id[V];
-        if constexpr (V == 4) {
-          const uint32_t w = *reinterpret_cast<const uint32_t*>(idx + o);
+    for (int w = 0; w < 4; ++w) {
+      const int oh = a + (w >> 1), ow = b + (w & 1);
+      const bool ok = oh < Ho && ow < Wo;
+      const size_t o = (((size_t)n * Ho + (ok ? oh : a)) * Wo + (ok ? ow : b)) * C + c0;
+      Vec16<T>::load(dy + o, g[w]);
+      if constexpr (V == 4) {
+        const uint32_t x = *reinterpret_cast<const uint32_t*>(idx + o);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) id[e] = (uint8_t)(w >> (8 * e));
-        } else {
-          const uint2 w = *reinterpret_cast<const uint2*>(idx + o);
+        for (int e = 0; e < 4; ++e) id[w][e] = ok ? (uint8_t)(x >> (8 * e)) : (uint8_t)255;
+      } else {
+        const uint2 x = *reinterpret_cast<const uint2*>(idx + o);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            id[e] = (uint8_t)(w.x >> (8 * e));
-            id[4 + e] = (uint8_t)(w.y >> (8 * e));
-          }
+        for (int e = 0; e < 4; ++e) {
+          id[w][e] = ok ? (uint8_t)(x.x >> (8 * e)) : (uint8_t)255;
+          id[w][4 + e] = ok ? (uint8_t)(x.y >> (8 * e)) : (uint8_t)255;
         }
-#pragma unroll
-        for (int e = 0; e < V; ++e)
-          if (id[e] == pos) acc[e] += g[e];
       }
     }
-    Vec16<T>::store(dx + (((size_t)n * H + ih) * W + iw) * C + c0, acc);
+    // position (kh * 3 + kw) of block pixel (r, c) inside window w = 2 * dr + dc:  kh = r + 1 - 2 dr, kw = c + 1 - 2 dc
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int dr = 0; dr <= r; ++dr)
+#pragma unroll
+          for (int dc = 0; dc <= c; ++dc) {
+            const int pos = (r + 1 - 2 * dr) * 3 + (c + 1 - 2 * dc);
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+              if (id[2 * dr + dc][e] == pos) acc[e] += g[2 * dr + dc][e];
+          }
+        Vec16<T>::store(dx + (((size_t)n * H + 2 * a + r) * W + 2 * b + c) * C + c0, acc);
+      }
   }
 }
 
@@ -436,6 +543,17 @@ int launch_bn_relu_maxpool(int dtype, const void* y, const float* scale, const f
   MI355_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "bn_relu_maxpool: H=%d W=%d C=%d", H, W, C);
   const int Ho = H / 2, Wo = W / 2;
   const int V = 16 / (int)dtype_size(dtype);
+  if (Ho % 2 == 0 && Wo % 2 == 0) {  // 2 x 2 output blocks (every size the network is run at: H, W multiples of 32)
+    const int grid = grid_for((size_t)N * (Ho / 2) * (Wo / 2) * (C / V));
+    if (dtype == MI355_F32)
+      hipLaunchKernelGGL(bn_relu_maxpool2_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)y, scale, shift, (float*)p, idx, bits, N, H, W,
+                         C, Ho, Wo);
+    else
+      hipLaunchKernelGGL(bn_relu_maxpool2_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, scale, shift, (bf16_t*)p, idx, bits, N,
+                         H, W, C, Ho, Wo);
+    MI355_LAUNCH_CHECK();
+    return 0;
+  }
   const int grid = grid_for((size_t)N * Ho * Wo * (C / V));
   if (dtype == MI355_F32)
     hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)y, scale, shift, (float*)p,
@@ -452,7 +570,7 @@ int launch_maxpool_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, 
   MI355_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "maxpool: H=%d W=%d C=%d", H, W, C);
   const int Ho = H / 2, Wo = W / 2;
   const int V = 16 / (int)dtype_size(dtype);
-  const int grid = grid_for((size_t)N * H * W * (C / V));
+  const int grid = grid_for((size_t)N * Ho * Wo * (C / V));
   if (dtype == MI355_F32)
     hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, idx, (float*)dx, N, H,
                        W, C, Ho, Wo);
