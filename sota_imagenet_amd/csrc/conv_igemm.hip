@@ -58,6 +58,13 @@ __device__ unsigned long long g_stamps[8 * 4096];  // [wave 0..3 of workgroup 0]
 #define STAMP(slot)
 #endif
 __device__ __attribute__((aligned(256))) unsigned char g_trash[512 * 16];
+// -DMI355_PROBES (make PROBES=1 -> lib/variant_probes.so): the epilogue timing probes of tools/probe8.py (MI355_IGEMM_DBG); they cost
+// registers in the hottest epilogue, so the product build compiles them out
+#ifdef MI355_PROBES
+#define MI355_PROBE(bit) ((kp.dbg & (bit)) != 0)
+#else
+#define MI355_PROBE(bit) false
+#endif
 
 struct IgemmKArgs {
   IgemmArgs a;
@@ -484,7 +491,7 @@ __global__ __launch_bounds__(128 * WMW, (BM == 256 ? 1 : (BN == 64 && NSTG == 2 
       const int done_stage = stage == 0 ? NSTG - 1 : stage - 1;
       char* stg = smem + done_stage * STAGE + (wave % EPI_WAVES) * STG_WAVE;
       MI355_LDS_BARRIER();
-      if (kp.dbg & 1) continue;  // timing probe: results are not written
+      if (MI355_PROBE(1)) continue;  // timing probe: results are not written
       if (tid < BM) {
         const int m = m0 + tid;
         int pix = -1;
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(128 * WMW, (BM == 256 ? 1 : (BN == 64 && NSTG == 2 
             pixs[ps] = row_pix[wm * (BM / WMW) + mi * 32 + ps * RPI + rr];
             if (addend) {
               const size_t o = (size_t)(pixs[ps] < 0 ? 0 : pixs[ps]) * p.Ncols + n0 + wn * WN + ch * VEC;
-              araw[ps] = *reinterpret_cast<const uint4*>((pixs[ps] < 0 || (kp.dbg & 4)) ? reinterpret_cast<const T*>(g_zero_page) : addend + o);
+              araw[ps] = *reinterpret_cast<const uint4*>((pixs[ps] < 0 || MI355_PROBE(4)) ? reinterpret_cast<const T*>(g_zero_page) : addend + o);
               abits[ps] = p.addend_bits ? (unsigned)p.addend_bits[pixs[ps] < 0 ? 0 : o / VEC] : 0xffu;
             }
             if constexpr (STATS == 2) {
@@ -580,7 +587,7 @@ __global__ __launch_bounds__(128 * WMW, (BM == 256 ? 1 : (BN == 64 && NSTG == 2 
               for (int e = 0; e < VEC; ++e) v[e] += (abits[ps] >> e) & 1u ? a[e] : 0.f;
             }
             // rows past the end of the problem go to a trash page so that every thread issues exactly NST stores
-            T* dst = (pix < 0 || (kp.dbg & 2)) ? reinterpret_cast<T*>(g_trash + tid * 16) : out + o;
+            T* dst = (pix < 0 || MI355_PROBE(2)) ? reinterpret_cast<T*>(g_trash + tid * 16) : out + o;
             Vec16<T>::store(dst, v);
             if constexpr (STATS == 1) {
               if (pix >= 0) {
@@ -717,7 +724,11 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
     return e && strcmp(e, "mute") == 0;
   }();
   k.sk_mute = sk_mute ? 1 : 0;
+#ifdef MI355_PROBES
   k.dbg = probe_env("MI355_IGEMM_DBG");  // read per launch: timing probes only, results are wrong with it set
+#else
+  k.dbg = 0;
+#endif
   k.sk_spin_limit = sk_mute ? (1u << 8) : (1u << 24);
   bool sk = false;
   // (fp32 only: a hand-off costs the owner ~10 us, nothing beside a 150-300 us fp32 tile, but most of what the cut

@@ -30,6 +30,7 @@ for (name, H, Cin, Cout, K, tile) in [("l3.c3 fwd", 14, 256, 1024, 1, "224x256")
     del xs
 
 # the 4-wave kernel (conv_igemm.hip): MI355_IGEMM_DBG 1 = no epilogue at all, 2 = full epilogue but its stores hit one trash page
+# (compiled in only by `make -C sota_imagenet_amd/csrc probes`; run this script with MI355RN_LIB=sota_imagenet_amd/lib/variant_probes.so)
 os.environ["MI355_IGEMM8"] = "0"
 os.environ.pop("MI355_IGEMM8_DBG", None)
 for (name, H, Cin, Cout, K) in [("l1.c3 fwd", 56, 64, 256, 1), ("l1.c1 fwd", 56, 256, 64, 1), ("l2.c3 fwd", 28, 128, 512, 1), ("l2.c1 fwd", 28, 512, 128, 1),
