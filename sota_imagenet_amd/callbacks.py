@@ -5,7 +5,6 @@ Re-states sota_imagenet/callbacks.py:232-247 (`CutmixMixup`: coin flip between `
 `self.mixup(*input)` with Beta(alpha, alpha) samplers) and the un-vendored pt_clb.Cutmix / pt_clb.Mixup bases as
 SURVEY.md Appendix C records them (mix with the PREVIOUS batch, permuted; CutMix target weight = real box area).
 """
-import ctypes
 
 import numpy as np
 import torch

@@ -1,6 +1,6 @@
 """Per-launch view of the conv kernels in a rocprofv3 kernel trace: maps dispatches of the LAST step to layers
 (by launch order) and prints achieved TFLOP/s per launch."""
-import csv, glob, sys, ctypes
+import csv, glob, sys
 sys.path.insert(0, '.')
 d = sys.argv[1]
 f = (glob.glob(d + "/*/*_kernel_trace.csv") + glob.glob(d + "/*_kernel_trace.csv"))[0]
