@@ -68,6 +68,11 @@ int mi355_conv2d_fwd(int dtype, const void* x, const void* w, void* y, int N, in
 
 /* dx[N,H,W,Cin] = conv_transpose(dy[N,Ho,Wo,Cout], w) (+ addend[N,H,W,Cin] if non-null).
  * replaces cuDNN dgrad under loss.backward() — callbacks.py:317 (K8)                                */
+/* forward conv that also leaves the BatchNorm statistics of its output as per-workgroup partial rows ([nblk][2][Cout] floats:
+ * sum, sum of squares of the values AS STORED) — what the executor's convs do; *nblk = 0 when this launch shape cannot produce
+ * them (then run mi355_bn_fwd_train).  partial: >= 768 * 2 * Cout floats.  Consumed by mi355_bn_fwd_train_partial.          */
+int mi355_conv2d_fwd_stats(int dtype, const void* x, const void* w, void* y, float* partial, size_t partial_bytes, int* nblk,
+                           int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
 int mi355_conv2d_dgrad(int dtype, const void* dy, const void* w, void* dx, const void* addend, int N,
                        int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* ws,
                        size_t ws_bytes, void* stream);
@@ -145,6 +150,11 @@ int mi355_bn_fwd_train(int dtype, const void* x, const void* residual, void* out
                        float* save_invstd, int M, int C, float eps, float momentum, int relu, void* ws,
                        size_t ws_bytes, void* stream);
 /* inference mode: uses running stats */
+/* the same from partial rows a conv epilogue left (mi355_conv2d_fwd_stats): no pass over x for the statistics; ws: 2*C floats */
+int mi355_bn_fwd_train_partial(int dtype, const void* x, const void* residual, void* out, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float* save_mean,
+                               float* save_invstd, int M, int C, float eps, float momentum, int relu, const float* partial,
+                               int nblk, void* ws, size_t ws_bytes, void* stream);
 int mi355_bn_fwd_eval(int dtype, const void* x, const void* residual, void* out, const float* gamma,
                       const float* beta, const float* running_mean, const float* running_var, int M,
                       int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream);

@@ -50,7 +50,7 @@ class _ConvFn(torch.autograd.Function):
         else:
             w_hat, invstd = wk, None
         wp = _pad_c(_pad_c(w_hat, _up64(cin), 3), _up64(cout), 0).to(x.dtype).contiguous()
-        y = ops.conv2d_fwd(x, wp, stride, k // 2)
+        y = ops.conv2d_fwd(x, wp, stride, k // 2, stats=True)  # the BN that follows takes the sums from the epilogue
         ctx.save_for_backward(x, wp, w_hat, invstd if invstd is not None else torch.empty(0))
         ctx.meta = (cout, cin, k, stride, standardize)
         return y

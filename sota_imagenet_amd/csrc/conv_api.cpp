@@ -197,6 +197,17 @@ int mi355_conv2d_fwd(int dtype, const void* x, const void* w, void* y, int N, in
   return launch_igemm(dtype, a, 1, (hipStream_t)stream);
 }
 
+int mi355_conv2d_fwd_stats(int dtype, const void* x, const void* w, void* y, float* partial, size_t partial_bytes, int* nblk, int N,
+                           int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+  MI355_TRY(check_conv(dtype, Cin, Cout, KH, KW, stride));
+  MI355_ARG(partial && nblk && partial_bytes >= (size_t)768 * 2 * Cout * sizeof(float), "conv2d_fwd_stats: partial buffer needs 768 * 2 * Cout floats");
+  IgemmArgs a;
+  build_fwd_args(a, N, H, W, Cin, Cout, KH, KW, stride, pad);
+  a.in = x; a.wt = w; a.out = y;
+  a.stat_partial = partial;
+  return launch_igemm(dtype, a, 1, (hipStream_t)stream, nblk);
+}
+
 int mi355_conv2d_dgrad(int dtype, const void* dy, const void* w, void* dx, const void* addend, int N, int H, int W,
                        int Cin, int Cout, int KH, int KW, int stride, int pad, void* ws, size_t ws_bytes,
                        void* stream) {
@@ -283,6 +294,18 @@ int mi355_bn_fwd_train(int dtype, const void* x, const void* residual, void* out
   MI355_TRY(launch_bn_stats(dtype, x, partial, pivot, &nblk, M, C, s));
   MI355_TRY(launch_bn_finalize(partial, pivot, nblk, M, C, gamma, beta, running_mean, running_var, save_mean, save_invstd,
                                scale, shift, eps, momentum, s));
+  return launch_bn_apply(dtype, x, scale, shift, residual, nullptr, nullptr, nullptr, out, M, C, relu, s);
+}
+
+int mi355_bn_fwd_train_partial(int dtype, const void* x, const void* residual, void* out, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float* save_mean, float* save_invstd, int M, int C, float eps,
+                               float momentum, int relu, const float* partial, int nblk, void* ws, size_t ws_bytes, void* stream) {
+  MI355_ARG(ws && ws_bytes >= (size_t)2 * C * 4 && partial && nblk >= 1, "bn_fwd_train_partial: nblk=%d, workspace of 2*C floats", nblk);
+  hipStream_t s = (hipStream_t)stream;
+  float* scale = (float*)ws;
+  float* shift = scale + C;
+  MI355_TRY(launch_bn_finalize(partial, nullptr, nblk, M, C, gamma, beta, running_mean, running_var, save_mean, save_invstd, scale,
+                               shift, eps, momentum, s));
   return launch_bn_apply(dtype, x, scale, shift, residual, nullptr, nullptr, nullptr, out, M, C, relu, s);
 }
 

@@ -4,6 +4,8 @@ These are the unit-level handles the parity tests use; the training path goes th
 executor (sota_imagenet_amd/models.py).  Tensors are NHWC (`[N,H,W,C]`), conv weights KRSC (`[Cout,KH,KW,Cin]`).
 Every function enqueues on torch's current stream and raises RuntimeError on any native failure.
 """
+import ctypes
+
 import torch
 
 from . import native
@@ -24,12 +26,25 @@ def _out_dim(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
 
-def conv2d_fwd(x, w, stride=1, pad=0):
+# BN statistics the LAST conv2d_fwd(stats=True) left in its epilogue, for the BatchNorm that consumes its output next (the per-op
+# graph of bresnet.py runs conv -> BN back to back).  One slot: (address, shape, partial rows, nblk); every bn_fwd_train / bn_fwd_eval
+# call empties it, a bn_fwd_train whose input is that very tensor uses it instead of a reduction pass over x.
+_LAST_CONV_STATS = [None]
+
+
+def conv2d_fwd(x, w, stride=1, pad=0, stats=False):
     _need_cuda(x, w)
     N, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
     y = torch.empty((N, _out_dim(H, KH, stride, pad), _out_dim(W, KW, stride, pad), Cout), dtype=x.dtype, device=x.device)
-    check(_L().mi355_conv2d_fwd(dtype_code(x.dtype), ptr(x), ptr(w), ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, cur_stream()))
+    if not stats:
+        check(_L().mi355_conv2d_fwd(dtype_code(x.dtype), ptr(x), ptr(w), ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, cur_stream()))
+        return y
+    partial = torch.empty(768 * 2 * Cout, dtype=torch.float32, device=x.device)
+    nblk = ctypes.c_int(0)
+    check(_L().mi355_conv2d_fwd_stats(dtype_code(x.dtype), ptr(x), ptr(w), ptr(y), ptr(partial), partial.numel() * 4, ctypes.byref(nblk), N, H, W, Cin,
+                                      Cout, KH, KW, stride, pad, cur_stream()))
+    _LAST_CONV_STATS[0] = (y.data_ptr(), tuple(y.shape), partial, nblk.value) if nblk.value > 0 else None
     return y
 
 
@@ -154,6 +169,13 @@ def bn_fwd_train(x, gamma, beta, running_mean, running_var, residual=None, relu=
     out = torch.empty_like(x)
     sm = torch.empty(C, dtype=torch.float32, device=x.device)
     si = torch.empty(C, dtype=torch.float32, device=x.device)
+    left, _LAST_CONV_STATS[0] = _LAST_CONV_STATS[0], None
+    if left is not None and left[0] == x.data_ptr() and left[1] == tuple(x.shape):  # the conv that produced x already summed it
+        ws = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        check(_L().mi355_bn_fwd_train_partial(dtype_code(x.dtype), ptr(x), ptr(residual), ptr(out), ptr(gamma), ptr(beta), ptr(running_mean),
+                                              ptr(running_var), ptr(sm), ptr(si), M, C, eps, momentum, int(relu), ptr(left[2]), left[3], ptr(ws),
+                                              ws.numel() * 4, cur_stream()))
+        return out, sm, si
     ws, n = _bn_ws(C, x.device)
     check(_L().mi355_bn_fwd_train(dtype_code(x.dtype), ptr(x), ptr(residual), ptr(out), ptr(gamma), ptr(beta), ptr(running_mean),
                                   ptr(running_var), ptr(sm), ptr(si), M, C, eps, momentum, int(relu), ptr(ws), n, cur_stream()))
@@ -162,6 +184,7 @@ def bn_fwd_train(x, gamma, beta, running_mean, running_var, residual=None, relu=
 
 def bn_fwd_eval(x, gamma, beta, running_mean, running_var, residual=None, relu=True, eps=1e-5):
     _need_cuda(x, gamma, beta, running_mean, running_var, residual)
+    _LAST_CONV_STATS[0] = None
     C = x.shape[-1]
     M = x.numel() // C
     out = torch.empty_like(x)

@@ -194,3 +194,33 @@ def test_bresnet50_bf16_trains(dev):
     with torch.no_grad():
         e = m(data.cuda())
     assert e.shape == (4, 1000) and torch.isfinite(e).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_epilogue_statistics_feed_the_next_batchnorm(dev, dtype):
+    """ops.conv2d_fwd(stats=True) + ops.bn_fwd_train on its output: the BatchNorm takes the sums the conv epilogue left (no
+    reduction pass) and must give what the standalone path gives on the same tensor; any other tensor ignores the slot."""
+    from sota_imagenet_amd import ops
+
+    N, H, W, Cin, Cout = 8, 14, 14, 64, 128
+    x = rnd((N, H, W, Cin), 3, dtype).to(dev, dtype)
+    w = rnd((Cout, 3, 3, Cin), 4, dtype, 0.05).to(dev, dtype)
+    g = (rnd((Cout,), 5, torch.float32) + 1.5).to(dev)
+    b = rnd((Cout,), 6, torch.float32).to(dev)
+    outs = []
+    for stats in (False, True):
+        rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+        y = ops.conv2d_fwd(x, w, 1, 1, stats=stats)
+        assert (ops._LAST_CONV_STATS[0] is not None) == stats
+        out, mean, invstd = ops.bn_fwd_train(y, g, b, rm, rv, relu=True)
+        assert ops._LAST_CONV_STATS[0] is None
+        outs.append((y, out, mean, invstd, rm, rv))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, c in zip(outs[0][1:], outs[1][1:]):
+        assert nerr(c, a) < (1e-5 if dtype == torch.float32 else 1e-2)
+    # the slot belongs to ONE tensor: a different input (same shape) must not pick it up
+    y = ops.conv2d_fwd(x, w, 1, 1, stats=True)
+    other = (y.float() * 2 + 1).to(dtype)
+    rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+    _, mean2, _ = ops.bn_fwd_train(other, g, b, rm, rv, relu=False)
+    assert nerr(mean2, other.float().reshape(-1, Cout).mean(0)) < 1e-3
