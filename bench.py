@@ -120,6 +120,22 @@ def cpu_baseline():
                       f"oracle; forward_only_value: the same for the forward + loss alone"}
 
 
+def spawn_ranks(n):
+    """the driver's own launch form (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>) as
+    a child process; its stdout (rank 0's one JSON line) and stderr pass straight through.  Returns the child's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--spawn"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,7 +149,13 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra fp32 (configs[1]) measurement")
     ap.add_argument("--model", default="resnet50", choices=["resnet50", "bresnet50"],
                     help="bresnet50: BASELINE configs[3] (variant graph, CutmixMixup on) — reported with its own workload name, no roofline")
+    ap.add_argument("--spawn", action="store_true", help="launch the ranks from this process even for --gpus 1 (test hook)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        # `python bench.py --gpus N` without a launcher: this process starts N fresh rank processes (one per GPU, RCCL between
+        # them) BEFORE it touches HIP, waits for them and relays rank 0's JSON line.  Never an exec of a GPU-initialised process.
+        raise SystemExit(spawn_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -332,6 +332,16 @@ int mi355_comm_nranks(const mi355_comm* comm);
 int mi355_comm_broadcast(mi355_comm* comm, float* buf, size_t n, int root, void* stream);
 int mi355_comm_allreduce_mean(mi355_comm* comm, float* buf, size_t n, void* stream);
 int mi355_resnet50_set_comm(mi355_ctx* ctx, mi355_comm* comm, double bucket_cap_mb);
+/* DistributedDataParallel.no_sync() (gradient accumulation, accumulate_steps > 1 — arg_parser.py:85-86, the Runner's inner step):
+ * on == 0 makes the following backward calls of this ctx skip the bucket all-reduces (gradients stay rank-local and keep
+ * accumulating); the last micro-step runs with on != 0 (the default) and reduces the accumulated sums once.        */
+int mi355_resnet50_set_grad_sync(mi355_ctx* ctx, int on);
+/* Record of every collective issued through `comm` since creation / the last reset, in issue order (at most 4096 kept):
+ * kinds[i] 0 = bucket mean all-reduce issued by mi355_resnet50_backward over [begins[i], ends[i]) of the flat gradient array
+ * (elements), 1 = mi355_comm_broadcast of ends[i] elements, 2 = mi355_comm_allreduce_mean of ends[i] elements.
+ * n_out = number of records (arrays are filled up to `cap`); reset != 0 clears the record afterwards.  Host-side only —
+ * lets a test assert that one backward reduced every gradient element exactly once, in bucket order.              */
+int mi355_comm_stats(mi355_comm* comm, int reset, int cap, int* n_out, int* kinds, size_t* begins, size_t* ends);
 int mi355_resnet50_bucket_plan(const mi355_ctx* ctx, double bucket_cap_mb, int cap, int* n_out, size_t* begins,
                                size_t* ends, int* last_segs);
 

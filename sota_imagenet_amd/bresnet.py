@@ -42,7 +42,7 @@ class _ConvFn(torch.autograd.Function):
     """y = conv(x, WS(w)): weight standardisation (optional), channel padding, cast, conv — one node, weight gradient in fp32"""
 
     @staticmethod
-    def forward(ctx, x, w, stride, standardize):
+    def forward(ctx, x, w, stride, standardize, want_stats):
         cout, cin, k, _ = w.shape
         wk = w.detach().permute(0, 2, 3, 1).contiguous()  # KRSC fp32
         if standardize:
@@ -50,13 +50,17 @@ class _ConvFn(torch.autograd.Function):
         else:
             w_hat, invstd = wk, None
         wp = _pad_c(_pad_c(w_hat, _up64(cin), 3), _up64(cout), 0).to(x.dtype).contiguous()
-        y = ops.conv2d_fwd(x, wp, stride, k // 2, stats=True)  # the BN that follows takes the sums from the epilogue
+        # want_stats (training): the epilogue also sums y for the BN that follows — handed on as an explicit second output
+        y, st = ops.conv2d_fwd(x, wp, stride, k // 2, stats=True) if want_stats else (ops.conv2d_fwd(x, wp, stride, k // 2), None)
         ctx.save_for_backward(x, wp, w_hat, invstd if invstd is not None else torch.empty(0))
         ctx.meta = (cout, cin, k, stride, standardize)
-        return y
+        if st is None:
+            st = torch.empty(0, device=x.device)
+        ctx.mark_non_differentiable(st)
+        return y, st
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dst):
         x, wp, w_hat, invstd = ctx.saved_tensors
         cout, cin, k, stride, standardize = ctx.meta
         dy = dy.contiguous()
@@ -64,21 +68,21 @@ class _ConvFn(torch.autograd.Function):
         dwp = ops.conv2d_wgrad(dy, x, k, k, stride, k // 2)  # fp32 [Cout_p, k, k, Cin_p]
         dw_hat = dwp[:cout, :, :, :cin].contiguous()
         dwk = ops.weight_std_bwd(dw_hat, w_hat, invstd) if standardize else dw_hat
-        return dx, dwk.permute(0, 3, 1, 2), None, None
+        return dx, dwk.permute(0, 3, 1, 2), None, None, None
 
 
 class _BNActFn(torch.autograd.Function):
     """ABN: BatchNorm (batch statistics, running stats updated in place) + activation code"""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rm, rv, act, momentum, training):
+    def forward(ctx, x, gamma, beta, rm, rv, act, momentum, training, stats):
         C, Cp = gamma.numel(), x.shape[-1]
         g, b = _pad_c(gamma.detach(), Cp).contiguous(), _pad_c(beta.detach(), Cp).contiguous()
         rmp = _pad_c(rm, Cp).clone()
         rvp = (rv if Cp == C else torch.cat([rv, torch.ones(Cp - C, device=rv.device)])).clone()  # padded channels: var 1
         if not training:
             return ops.bn_fwd_eval(x, g, b, rmp, rvp, relu=act)
-        out, mean, invstd = ops.bn_fwd_train(x, g, b, rmp, rvp, relu=act, momentum=momentum)
+        out, mean, invstd = ops.bn_fwd_train(x, g, b, rmp, rvp, relu=act, momentum=momentum, stats=stats if stats is not None and stats.numel() else None)
         rm.copy_(rmp[:C])
         rv.copy_(rvp[:C])
         ctx.save_for_backward(x, out, g, mean, invstd)
@@ -90,7 +94,7 @@ class _BNActFn(torch.autograd.Function):
         x, out, g, mean, invstd = ctx.saved_tensors
         C, act = ctx.meta
         dx, dg, db, _ = ops.bn_bwd(dout.contiguous(), out, x, g, mean, invstd, relu=act)
-        return dx, dg[:C], db[:C], None, None, None, None, None
+        return dx, dg[:C], db[:C], None, None, None, None, None, None
 
 
 class _BlurPoolFn(torch.autograd.Function):
@@ -179,8 +183,10 @@ class _Conv(nn.Module):
         self.weight = nn.Parameter(torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last))
         self.stride, self.standardize = stride, standardize
 
-    def forward(self, x):
-        return _ConvFn.apply(x, self.weight, self.stride, self.standardize)
+    def forward(self, x, stats=False):
+        """stats=True (the caller feeds a BatchNorm next, in training): returns (y, partial statistics rows of y)"""
+        y, st = _ConvFn.apply(x, self.weight, self.stride, self.standardize, bool(stats))
+        return (y, st) if stats else y
 
 
 class _ABN(nn.Module):
@@ -194,10 +200,18 @@ class _ABN(nn.Module):
         self.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long))
         self.momentum, self.eps, self.act = 0.1, 1e-5, act
 
-    def forward(self, x):
+    def forward(self, x, stats=None):
         if self.training:
             self.num_batches_tracked += 1
-        return _BNActFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.act, self.momentum, self.training)
+        return _BNActFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.act, self.momentum, self.training, stats)
+
+
+def _conv_bn(conv, bn, x):
+    """conv -> ABN; in training the conv's epilogue statistics go to the BatchNorm as an explicit value"""
+    if bn.training:
+        y, st = conv(x, stats=True)
+        return bn(y, st)
+    return bn(conv(x))
 
 
 class _ECA(nn.Module):
@@ -225,20 +239,20 @@ class _Bottleneck(nn.Module):
             self.downsample.add_module("1", _ABN(planes * 4, 0))
 
     def forward(self, x, keep):
-        out = self.bn1(self.conv1(x))
-        out = self.bn2(self.conv2(out))
+        out = _conv_bn(self.conv1, self.bn1, x)
+        out = _conv_bn(self.conv2, self.bn2, out)
         if self.stride == 2:
             out = _BlurPoolFn.apply(out)
-        out = self.se_module(self.bn3(self.conv3(out)))
+        out = self.se_module(_conv_bn(self.conv3, self.bn3, out))
         sc = x
         if self.downsample is not None:
             sc = _AvgPool2Fn.apply(x) if self.stride == 2 else x
-            sc = self.downsample[1](self.downsample[0](sc))
+            sc = _conv_bn(self.downsample[0], self.downsample[1], sc)
         return _ResidualActFn.apply(out, sc, keep, LEAKY_ACT)
 
 
 class BResNet50(nn.Module):
-    def __init__(self, num_classes=1000, dtype="bf16", drop_rate=0.2, drop_connect_rate=0.2, weight_standardization=True, seed=0, **kw):
+    def __init__(self, num_classes=1000, dtype="bf16", drop_rate=0.0, drop_connect_rate=0.0, weight_standardization=False, seed=0, **kw):
         super().__init__()
         unknown = set(kw) - {"pretrained", "stem_type", "antialias", "attn_type", "norm_layer", "norm_act"}
         if unknown:
@@ -292,7 +306,10 @@ class BResNet50(nn.Module):
         N = x.shape[0]
         h = torch.zeros((N, x.shape[2], x.shape[3], 64), dtype=self._dtype, device=x.device)
         h[..., :3] = x.permute(0, 2, 3, 1)  # the loader's NCHW batch -> zero-padded NHWC
-        h = self.bn1(self.conv1(h))
+        st = self.conv1
+        h = _conv_bn(st[0], st[1], h)
+        h = _conv_bn(st[2], st[3], h)
+        h = _conv_bn(st[4], self.bn1, h)
         h = _BlurPoolFn.apply(_MaxPool3s1Fn.apply(h))
         blocks = self.blocks()
         train = self.training and torch.is_grad_enabled()

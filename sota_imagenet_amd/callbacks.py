@@ -21,6 +21,11 @@ class _DeviceMixer:
         self.counter = 0
         self.key = None
 
+    def reseed(self, random_seed, rank):
+        """one stream per (run seed, rank): the reference draws from per-process np.random / torch generators, so ranks must
+        not share their coins, lambdas, boxes and permutations"""
+        self.seed = (int(random_seed or 0) * 1000003 + int(rank) * 7919 + 12345) & 0x7FFFFFFF
+
     def params_tensor(self):
         return self.params
 
@@ -28,6 +33,8 @@ class _DeviceMixer:
         from . import native
 
         L = native.lib()
+        if data.dtype != torch.float32 or target.dtype != torch.float32:
+            raise TypeError(f"Mixup / CutMix on the device take float32 images and float32 soft targets (got {data.dtype}, {target.dtype})")
         data, target = data.contiguous(), target.contiguous()
         N, C, H, W = data.shape
         key = (tuple(data.shape), tuple(target.shape), data.device)
@@ -51,14 +58,25 @@ class _DeviceMixer:
 
 
 class Mixup(Callback):
-    def __init__(self, alpha, num_classes=1000, prob=0.5, seed=0):
+    def __init__(self, alpha, num_classes=1000, prob=0.5, seed=None):
         super().__init__()
+        self._seed_given = seed is not None
+        seed = seed or 0
         self.alpha = float(alpha)
         self.tb = torch.distributions.Beta(alpha, alpha)
         self.num_classes = num_classes
         self.prob = prob
         self.prev_input = None
         self._dev = _DeviceMixer(seed)
+
+    def on_begin(self):
+        if not self._seed_given:  # an explicit seed= stays; otherwise (run seed, rank) -> one stream per process
+            self._dev.reseed(getattr(self.state, "random_seed", 0), self.state.rank)
+
+    def on_loader_begin(self):
+        # the sampler's position is a function of (epoch, step): a resumed run continues the sequence instead of replaying it
+        if self.state.is_train and self.state.epoch_size:
+            self._dev.counter = int(self.state.epoch) * int(self.state.epoch_size)
 
     def _onehot(self, target):
         if target.dim() == 1:
@@ -122,7 +140,7 @@ class Cutmix(Mixup):
 class CutmixMixup(Cutmix):
     """sota_imagenet/callbacks.py:232-247."""
 
-    def __init__(self, cutmix_alpha, mixup_alpha, prob=0.5, num_classes=1000, seed=0):
+    def __init__(self, cutmix_alpha, mixup_alpha, prob=0.5, num_classes=1000, seed=None):
         super().__init__(cutmix_alpha, num_classes, prob, seed)
         self.cutmix_tb = torch.distributions.Beta(cutmix_alpha, cutmix_alpha)
         self.mixup_tb = torch.distributions.Beta(mixup_alpha, mixup_alpha)

@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 #include "comm.h"
@@ -78,6 +79,16 @@ struct mi355_comm {
   hipStream_t stream = nullptr;  // the collective stream
   hipEvent_t done = nullptr;     // last all-reduce of a backward call
   hipEvent_t ev[2] = {nullptr, nullptr};
+  // what has been issued through this communicator (mi355_comm_stats): kind 0 = bucket mean all-reduce of the flat gradient
+  // array (begin / end in elements of it), 1 = broadcast, 2 = whole-buffer mean all-reduce (begin 0, end n)
+  struct Op {
+    int kind;
+    size_t begin, end;
+  };
+  std::vector<Op> log;
+  void note(int kind, size_t b, size_t e) {
+    if (log.size() < 4096) log.push_back({kind, b, e});
+  }
 };
 
 namespace mi355 {
@@ -98,6 +109,7 @@ int comm_allreduce_bucket(mi355_comm* cm, float* grads, size_t begin, size_t end
     MI355_HIP(hipStreamWaitEvent(cm->stream, cm->ev[1], 0));
   }
   MI355_RCCL(r->AllReduce(grads + begin, grads + begin, end - begin, ncclFloat32, ncclAvg, cm->comm, cm->stream));
+  cm->note(0, begin, end);
   return 0;
 }
 // everything the communicator's stream has been given becomes visible to `s`
@@ -175,6 +187,7 @@ int mi355_comm_broadcast(mi355_comm* c, float* buf, size_t n, int root, void* st
   MI355_ARG(c && buf && root >= 0 && root < c->nranks, "comm_broadcast: bad arguments");
   if (n == 0) return 0;
   MI355_RCCL(rccl()->Broadcast(buf, buf, n, ncclFloat32, root, c->comm, (hipStream_t)stream));
+  c->note(1, 0, n);
   return 0;
 }
 
@@ -182,6 +195,19 @@ int mi355_comm_allreduce_mean(mi355_comm* c, float* buf, size_t n, void* stream)
   MI355_ARG(c && buf, "comm_allreduce_mean: bad arguments");
   if (n == 0) return 0;
   MI355_RCCL(rccl()->AllReduce(buf, buf, n, ncclFloat32, ncclAvg, c->comm, (hipStream_t)stream));
+  c->note(2, 0, n);
+  return 0;
+}
+
+int mi355_comm_stats(mi355_comm* c, int reset, int cap, int* n_out, int* kinds, size_t* begins, size_t* ends) {
+  MI355_ARG(c && n_out, "comm_stats: bad arguments");
+  *n_out = (int)c->log.size();
+  for (int i = 0; i < (int)c->log.size() && i < cap; ++i) {
+    if (kinds) kinds[i] = c->log[i].kind;
+    if (begins) begins[i] = c->log[i].begin;
+    if (ends) ends[i] = c->log[i].end;
+  }
+  if (reset) c->log.clear();
   return 0;
 }
 

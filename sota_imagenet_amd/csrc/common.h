@@ -87,6 +87,8 @@ struct IgemmArgs {
   const uint8_t* bn_bits = nullptr;    // 1 byte per 16-byte vector of out
   const float* bn_mean = nullptr;      // [Ncols]
   const float* bn_invstd = nullptr;    // [Ncols]
+  const float* q_scale_in = nullptr;   // fp8 operand launches (launch_igemm_fp8): the per-tensor quantisation scales of `in` and
+  const float* q_scale_wt = nullptr;   // `wt` in device memory — out = acc / (*q_scale_in * *q_scale_wt); null: plain oscale
   int N, Hin, Win, pix_stride;
   int Hsub, Wsub, IS;
   int Hout, Wout, OS;
@@ -116,6 +118,10 @@ static constexpr size_t IGEMM_SK_FLAG_BYTES = 4096;  // 512 flags + an error wor
 static constexpr int IGEMM_SK_ERR_WORD = 512;        // index of the error word in the flag block: nonzero = a stream-K
                                                      // hand-off timed out in some launch that used this scratch
 size_t igemm_sk_ws_bytes();
+// fp8 (e4m3) operands in `a.in` / `a.wt` (1-byte elements), bf16 output: the 8-wave kernel with 128-channel k-tiles (fp8.hip picks
+// the tile).  igemm_fp8_legal: geometry the kernel can run (Ck % 128, Ncols % 128, ...).
+bool igemm_fp8_legal(const IgemmArgs& a, int nclass);
+int launch_igemm_fp8(const IgemmArgs& a, int nclass, float oscale, hipStream_t stream, int* stat_rows = nullptr);
 // splits chosen by plan_wgrad_splits(); partial must hold splits*Cout*wtaps*Ck floats
 int plan_wgrad_splits(int dtype, int M, int Cout, int ntaps, int Ck);
 int launch_wgrad(int dtype, const WgradArgs& a, int splits, hipStream_t stream);
@@ -136,6 +142,10 @@ struct PrepDesc {
   size_t w_off;    // offset of the fp32 master in `params` (elements)
   void* w_cast;    // or null (cast copy not needed: fp32 ctx)
   void* w_tr;      // or null (no dgrad: inference forward)
+  void* w_q;       // fp8 ctx, layers whose forward runs on e4m3 operands: [Cout][taps][Cin] bytes = e4m3(bf16(w) * *q_scale), or null
+  void* w_trq;     // ... and the transposed [Cin][taps][Cout] bytes for dgrad, or null
+  const float* q_scale;  // device scalar used this step
+  unsigned* q_amax;      // device scalar: max |bf16(w)| as float bits, atomicMax'ed (the next step's scale)
   int Cout, taps, Cin;
   int tile_begin;  // first block of this layer; a layer has (Cout/PREP_TILE)*(Cin/PREP_TILE)*taps blocks
 };
@@ -166,9 +176,16 @@ int launch_bn_finalize(const float* partial, const float* pivot, int nblk, int M
 int launch_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float* scale,
                           float* shift, int C, float eps, hipStream_t s);
 // out = act(x*scale+shift (+ residual) (+ x2*scale2+shift2))
+// Quantised twin of an activation / gradient tensor (fp8 training step): q = e4m3(bf16(v) * *scale) beside the bf16 tensor the
+// kernel writes anyway, and max |bf16(v)| atomicMax'ed into *amax (float bits; seeds the NEXT step's scale).  q null: off.
+struct QuantOut {
+  uint8_t* q = nullptr;
+  const float* scale = nullptr;
+  unsigned* amax = nullptr;
+};
 int launch_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
                     const void* x2, const float* scale2, const float* shift2, void* out, int M, int C, int relu,
-                    hipStream_t s, uint8_t* relu_bits = nullptr);
+                    hipStream_t s, uint8_t* relu_bits = nullptr, QuantOut qo = QuantOut());
 // relu_bits: the ReLU mask as one byte per 16-byte vector of the tensor (bit e = element e of the vector was > 0);
 // written by launch_bn_apply, read by the two backward kernels in place of the post-activation tensor
 int launch_bn_bwd_reduce(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
@@ -178,8 +195,10 @@ int launch_bn_bwd_finalize(const float* partial, int nblk, int M, int C, const f
                            float* dgamma, float* dbeta, float beta_acc, float* coef /*[3][C]*/, hipStream_t s);
 int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
                         const float* invstd, const float* coef, void* dx, int M, int C, hipStream_t s,
-                        const uint8_t* relu_bits = nullptr, float slope = 0.f);
+                        const uint8_t* relu_bits = nullptr, float slope = 0.f, QuantOut qo = QuantOut());
 int bn_max_blocks();
+// fp8 step: scale[i] = amax[i] > 0 ? 448 / (headroom * amax[i]) : scale[i];  amax[i] = 0   (delayed per-tensor scaling)
+int launch_fp8_scale_update(float* scale, unsigned* amax, int n, float headroom, hipStream_t s);
 
 // pooling / head / loss / optimizer
 int launch_maxpool_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, hipStream_t s);

@@ -64,6 +64,8 @@ struct Igemm8KArgs {
   unsigned magW, magHW;  // floor(2^32 / d) + 1 for d = Wsub, Hsub * Wsub (exact quotients while m * d < 2^32)
   int HW;
   float oscale;          // fp8 operands: 1 / (scale_x * scale_w), applied to the accumulators
+  const float* sc_in;    // fp8 operands, executor path: per-tensor scales in device memory (the accumulators are multiplied
+  const float* sc_wt;    // by oscale / (*sc_in * *sc_wt)); null: oscale alone
   int korder;            // 0: taps outer, channel chunks inner;  1: channel chunks outer, taps inner (A re-reads stay close)
 };
 
@@ -157,6 +159,10 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
   const int Msub = p.N * p.Hsub * p.Wsub;
   const int kcpt = p.Ck / BK;  // k-tiles per tap
 
+  float oscale = kp.oscale;
+  if constexpr (EB == 1) {
+    if (kp.sc_in) oscale = kp.oscale / (kp.sc_in[0] * kp.sc_wt[0]);  // uniform: two scalar loads
+  }
   const i32x4 srdA = make_srd(p.in, kp.bytes_in);
   const i32x4 srdB = make_srd(p.wt, kp.bytes_wt);
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
@@ -684,8 +690,8 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
               if (mt >= MT) continue;
               f32x4 a = acc[mt][2 * ntp], b = acc[mt][2 * ntp + 1];
               if constexpr (EB == 1) {  // undo the operands' quantisation scales
-                a *= kp.oscale;
-                b *= kp.oscale;
+                a *= oscale;
+                b *= oscale;
               }
               float v[8];
 #pragma unroll
@@ -780,6 +786,7 @@ unsigned magic32(unsigned d) { return (unsigned)((1ull << 32) / d + 1); }
 
 template <int BM, int BN, int FAT, int EB = 2>
 int launch8_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows, int korder, float oscale = 1.f) {
+  static_assert(EB == 2 || EB == 1, "EB");
   constexpr int NSTG = BN == 256 ? 2 : 3;
   constexpr int MAX_WG = 256;
   Igemm8KArgs k;
@@ -802,16 +809,20 @@ int launch8_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
   k.magHW = magic32((unsigned)k.HW);
   k.korder = korder;
   k.oscale = oscale;
+  k.sc_in = a.q_scale_in;
+  k.sc_wt = a.q_scale_wt;
   const size_t bytes_in = (size_t)a.N * a.Hin * a.Win * a.pix_stride * EB;
   const size_t bytes_wt = (size_t)a.Ncols * a.wtaps * a.Ck * EB;
   MI355_ARG(bytes_in < 0x80000000ull && bytes_wt < 0x80000000ull, "igemm8: tensor exceeds the 2 GiB buffer-offset range");
   k.bytes_in = (unsigned)bytes_in;
   k.bytes_wt = (unsigned)bytes_wt;
-  // timing-only probes: a descriptor with zero records drops every load through it (the instruction stream stays)
+#ifdef MI355_PROBES
+  // timing-only probes (profiling build, `make probes`): a descriptor with zero records drops every load through it
   if (const int dbg = probe_env("MI355_IGEMM8_DBG")) {
     if (dbg & 1) k.bytes_in = 0;
     if (dbg & 2) k.bytes_wt = 0;
   }
+#endif
   int grid = k.items < MAX_WG ? k.items : MAX_WG;
   grid -= grid % ng;  // items is a multiple of ng; a workgroup then keeps one n-tile group (statistics rows, weight reuse per XCD)
   if (grid == 0) grid = ng;
@@ -823,7 +834,6 @@ int launch8_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
 #endif
   const bool stats = a.stat_partial != nullptr && chan <= 512 && lds + (size_t)2 * chan * 2 * sizeof(float) <= 160 * 1024;
   if (stat_rows) *stat_rows = stats ? grid / ng : 0;
-  if constexpr (EB == 2) {  // (the fp8 entry points take plain launches only: no statistics instantiations for EB = 1)
   if (stats) {
     lds += (size_t)2 * chan * 2 * sizeof(float);
     if (a.bn_y) {
@@ -834,11 +844,6 @@ int launch8_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
       hipLaunchKernelGGL((igemm8_kernel<BM, BN, 1, FAT, EB>), dim3(grid), dim3(512), lds, stream, k);
     }
   } else {
-    lds_opt_in8((const void*)igemm8_kernel<BM, BN, 0, FAT, EB>, lds);
-    hipLaunchKernelGGL((igemm8_kernel<BM, BN, 0, FAT, EB>), dim3(grid), dim3(512), lds, stream, k);
-  }
-  } else {
-    MI355_ARG(!stats, "igemm8 fp8: plain launches only");
     lds_opt_in8((const void*)igemm8_kernel<BM, BN, 0, FAT, EB>, lds);
     hipLaunchKernelGGL((igemm8_kernel<BM, BN, 0, FAT, EB>), dim3(grid), dim3(512), lds, stream, k);
   }
@@ -860,15 +865,23 @@ bool igemm8_legal(const IgemmArgs& a, int nclass, int bn) {
 }
 
 // fp8 (OCP e4m3) operands, bf16 output = conv(xq, wq) * oscale: the same kernel with EB = 1 (k-tiles of 128 channels)
-int launch_igemm8_fp8(const IgemmArgs& a, int nclass, int bm, int bn, int korder, float oscale, hipStream_t stream) {
+// true when the fp8 form of the 8-wave kernel can run this launch (k-tiles of 128 channels)
+bool igemm8_fp8_legal(const IgemmArgs& a, int nclass, int bn) {
+  if (a.pair_delta != 0 || a.Ck % 128 != 0 || a.Ncols % bn != 0 || a.Wsub < 2 || a.Hsub < 1) return false;
+  for (int ci = 0; ci < nclass; ++ci)
+    if (a.cls[ci].ntaps * (a.Ck / 128) > 128) return false;
+  const unsigned long long Msub = (unsigned long long)a.N * a.Hsub * a.Wsub;
+  return Msub * a.Hsub * a.Wsub < (1ull << 32) && Msub + 256 < (1ull << 31);
+}
+
+int launch_igemm8_fp8(const IgemmArgs& a, int nclass, int bm, int bn, int korder, float oscale, hipStream_t stream, int* stat_rows) {
   MI355_ARG(a.pair_delta == 0 && a.Ck % 128 == 0 && a.Ncols % bn == 0 && a.Wsub >= 2, "igemm8 fp8: Ck=%d (multiple of 128), Ncols=%d (multiple of %d), output rows of %d pixels (at least 2)", a.Ck, a.Ncols, bn, a.Wsub);
-  MI355_ARG(a.stat_partial == nullptr && a.addend == nullptr, "igemm8 fp8: plain launches only");
   for (int ci = 0; ci < nclass; ++ci) MI355_ARG(a.cls[ci].ntaps * (a.Ck / 128) <= 128, "igemm8 fp8: more than 128 k-tiles per class");
   const unsigned long long Msub = (unsigned long long)a.N * a.Hsub * a.Wsub;
   MI355_ARG(Msub * a.Hsub * a.Wsub < (1ull << 32), "igemm8 fp8: problem too large for the 32-bit index arithmetic");
-  if (bm == 224 && bn == 256) return launch8_t<224, 256, 0, 1>(a, nclass, stream, nullptr, korder, oscale);
-  if (bm == 256 && bn == 256) return launch8_t<256, 256, 0, 1>(a, nclass, stream, nullptr, korder, oscale);
-  if (bm == 256 && bn == 128) return launch8_t<256, 128, 1, 1>(a, nclass, stream, nullptr, korder, oscale);
+  if (bm == 224 && bn == 256) return launch8_t<224, 256, 0, 1>(a, nclass, stream, stat_rows, korder, oscale);
+  if (bm == 256 && bn == 256) return launch8_t<256, 256, 0, 1>(a, nclass, stream, stat_rows, korder, oscale);
+  if (bm == 256 && bn == 128) return launch8_t<256, 128, 1, 1>(a, nclass, stream, stat_rows, korder, oscale);
   set_error("igemm8 fp8: no %dx%d tile", bm, bn);
   return MI355_E_ARG;
 }

@@ -404,10 +404,12 @@ int launch_t(const WgradArgs& a, int splits, hipStream_t stream) {
   MI355_ARG(bytes_dy < 0x80000000ull && bytes_x < 0x80000000ull, "wgrad: tensor exceeds the 2 GiB buffer-offset range");
   k.bytes_dy = (unsigned)bytes_dy;
   k.bytes_x = (unsigned)bytes_x;
-  if (const int dbg = probe_env("MI355_WGRAD_DBG")) {  // timing probes (results are wrong): zero-record descriptors = no load traffic
+#ifdef MI355_PROBES
+  if (const int dbg = probe_env("MI355_WGRAD_DBG")) {  // timing probes (profiling build; results are wrong): zero-record descriptors = no load traffic
     if (dbg & 1) k.bytes_dy = 0;
     if (dbg & 2) k.bytes_x = 0;
   }
+#endif
   const int grid = k.items < MAX_WG ? k.items : MAX_WG;
   // every tile of a pixel split fetches the same dy / x slabs: keep the tiles of a split on one XCD (one L2) wherever the
   // grid divides over the 8 XCDs.  Same-box whole-step A/B at batch 256 (tools/ab_step.sh MI355_WGRAD_XCD): 20.46 -> 20.36 ms

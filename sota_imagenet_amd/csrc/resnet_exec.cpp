@@ -108,6 +108,7 @@ struct mi355_ctx {
     int last_seg;
   };
   std::vector<Bucket> buckets;
+  bool grad_sync = true;    // false: backward skips the bucket all-reduces (DDP.no_sync(): non-final accumulation micro-steps)
   bool comm_dirty = false;  // an all-reduce of this backward call is in flight on the communicator's stream
   unsigned* sk_err_host = nullptr;  // pinned copy of the two scratch blocks' error words, refreshed by an async copy at the
                                     // end of every forward / backward call and looked at (no wait) at the start of the next
@@ -887,6 +888,12 @@ int mi355_resnet50_set_comm(mi355_ctx* c, mi355_comm* comm, double bucket_cap_mb
   return 0;
 }
 
+int mi355_resnet50_set_grad_sync(mi355_ctx* c, int on) {
+  MI355_ARG(c, "set_grad_sync: null ctx");
+  c->grad_sync = on != 0;
+  return 0;
+}
+
 int mi355_resnet50_backward(mi355_ctx* c, const float* dlogits, int seg_begin, int seg_end, int accumulate,
                             void* stream) {
   MI355_ARG(c, "backward: null ctx");
@@ -915,7 +922,7 @@ int mi355_resnet50_backward(mi355_ctx* c, const float* dlogits, int seg_begin, i
       MI355_TRY(backward_block(c, c->blocks[nb - seg], nb - seg > 0 ? &c->blocks[nb - seg - 1] : nullptr, beta_acc, s));
     }
     c->next_seg = seg + 1;
-    if (c->comm)
+    if (c->comm && c->grad_sync)
       for (const auto& bk : c->buckets)
         if (bk.last_seg == seg) {  // the bucket's producers are all enqueued (main + weight-gradient stream): reduce it
           MI355_TRY(comm_allreduce_bucket(c->comm, c->grads, bk.begin, bk.end, s, c->overlap && c->w_dirty ? c->wstream : nullptr));

@@ -124,6 +124,7 @@ class RunnerState:
         self.epoch_log = 0
         self.world_size = env_world_size()
         self.rank = env_rank()
+        self.random_seed = 0  # train.py sets cfg.random_seed: device-side samplers (CutmixMixup) derive their stream from (seed, rank)
 
 
 class Callback:
@@ -463,7 +464,13 @@ class Runner:
         loss = self.state.criterion(output, target)
         self.state.output = output
         if self.state.is_train:
-            (loss / self.state.accumulate_steps).backward()
+            last_micro = (self.state.step + 1) % self.state.accumulate_steps == 0
+            no_sync = getattr(self.state.model, "no_sync", None)
+            if no_sync is not None and not last_micro:  # data parallel: reduce the accumulated gradients once, on the last micro-step
+                with no_sync():
+                    (loss / self.state.accumulate_steps).backward()
+            else:
+                (loss / self.state.accumulate_steps).backward()
             self.callbacks.on_after_backward()
             if (self.state.step + 1) % self.state.accumulate_steps == 0:
                 if self.gradient_clip_val is not None:

@@ -130,6 +130,10 @@ class ImageFolderLoader:
     def __len__(self):
         return math.ceil(self._size / self._bs)
 
+    def batches_per_epoch(self):
+        """full batches this loader yields per epoch — the same number on every rank"""
+        return (len(self.samples) // self.world) // self._bs
+
     # ---- host half ---------------------------------------------------------------------------------------------------
     def _shard_indices(self, epoch):
         n = len(self.samples)
@@ -214,7 +218,9 @@ class ImageFolderLoader:
         epoch = self.epoch
         self.epoch += 1
         order = self._shard_indices(epoch)
-        n_full = len(order) // self._bs  # LastBatchPolicy.DROP
+        # LastBatchPolicy.DROP — from the size every rank has in common: shards differ by one sample when the set does not
+        # divide by the world size, and a rank with one batch more than its peers would wait in a gradient all-reduce forever
+        n_full = self.batches_per_epoch()
         q = queue.Queue(maxsize=self.prefetch)
         stop = threading.Event()
 

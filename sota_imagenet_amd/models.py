@@ -99,6 +99,7 @@ class ResNet50(nn.Module):
         self._grad_sync = None  # set by parallel.FlatBucketDDP: callable(segment, begin, end)
         self._grad_sync_points = None  # optional set of segments the hook acts on (None: after every segment)
         self._comm = None  # (mi355_comm*, bucket cap in MiB) once a native communicator is attached
+        self._sync_grads = True  # False inside FlatBucketDDP.no_sync(): backward keeps the gradients rank-local
         self._bn_leaves = []
         self._build_modules()
         self._rebind_views()
@@ -253,6 +254,14 @@ class ResNet50(nn.Module):
         for c in self._ctxs.values():
             check(L.mi355_resnet50_set_comm(c, comm, float(bucket_cap_mb)))
 
+    def set_grad_sync(self, on):
+        """DDP.no_sync() for the native collective: off -> the following backwards skip the bucket all-reduces
+        (mi355_resnet50_set_grad_sync); the torch.distributed stand-in path honours the same flag."""
+        self._sync_grads = bool(on)
+        L = native.lib()
+        for c in self._ctxs.values():
+            check(L.mi355_resnet50_set_grad_sync(c, int(self._sync_grads)))
+
     def bucket_plan(self, bucket_cap_mb):
         """[(begin, end, last_segment)] the native executor would reduce at this cap (layout-only: works on the CPU)."""
         L = native.lib()
@@ -300,6 +309,8 @@ class ResNet50(nn.Module):
             check(L.mi355_resnet50_bind(c, ptr(self._flat_params), ptr(self._flat_grads), ptr(self._flat_buffers)))
             if self._comm is not None:
                 check(L.mi355_resnet50_set_comm(c, self._comm[0], float(self._comm[1])))
+            if not self._sync_grads:
+                check(L.mi355_resnet50_set_grad_sync(c, 0))
             self._ctxs[key] = c
         else:
             self._ctxs.move_to_end(key)
@@ -330,7 +341,7 @@ class ResNet50(nn.Module):
         self._attach_grads()
         acc = int(self._grads_dirty)
         nseg = len(self._segments)
-        if self._grad_sync is None:
+        if self._grad_sync is None or not self._sync_grads:
             check(L.mi355_resnet50_backward(c, ptr(dlogits), 0, nseg, acc, native.cur_stream()))
         else:
             # one native call per run of segments up to the next segment the hook acts on (a bucket boundary): every

@@ -26,13 +26,10 @@ def _out_dim(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
 
-# BN statistics the LAST conv2d_fwd(stats=True) left in its epilogue, for the BatchNorm that consumes its output next (the per-op
-# graph of bresnet.py runs conv -> BN back to back).  One slot: (address, shape, partial rows, nblk); every bn_fwd_train / bn_fwd_eval
-# call empties it, a bn_fwd_train whose input is that very tensor uses it instead of a reduction pass over x.
-_LAST_CONV_STATS = [None]
-
-
 def conv2d_fwd(x, w, stride=1, pad=0, stats=False):
+    """stats=True: returns (y, partial) — `partial` = the BN batch-statistics rows the conv epilogue summed over y, an fp32
+    tensor [nblk, 2, Cout] (or None where the launch could not carry them) to hand to bn_fwd_train(y, ..., stats=partial):
+    an explicit value owned by the caller, valid for exactly this y as long as y is not modified."""
     _need_cuda(x, w)
     N, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
@@ -44,8 +41,7 @@ def conv2d_fwd(x, w, stride=1, pad=0, stats=False):
     nblk = ctypes.c_int(0)
     check(_L().mi355_conv2d_fwd_stats(dtype_code(x.dtype), ptr(x), ptr(w), ptr(y), ptr(partial), partial.numel() * 4, ctypes.byref(nblk), N, H, W, Cin,
                                       Cout, KH, KW, stride, pad, cur_stream()))
-    _LAST_CONV_STATS[0] = (y.data_ptr(), tuple(y.shape), partial, nblk.value) if nblk.value > 0 else None
-    return y
+    return y, (partial[: nblk.value * 2 * Cout].view(nblk.value, 2, Cout) if nblk.value > 0 else None)
 
 
 def quantize_fp8(x, scale=1.0):
@@ -161,19 +157,22 @@ def _bn_ws(C, device):
     return torch.empty(n, dtype=torch.uint8, device=device), n
 
 
-def bn_fwd_train(x, gamma, beta, running_mean, running_var, residual=None, relu=True, eps=1e-5, momentum=0.1):
-    """x: [..., C] NHWC.  Updates running stats in place.  Returns (out, save_mean, save_invstd)."""
+def bn_fwd_train(x, gamma, beta, running_mean, running_var, residual=None, relu=True, eps=1e-5, momentum=0.1, stats=None):
+    """x: [..., C] NHWC.  Updates running stats in place.  Returns (out, save_mean, save_invstd).
+    stats: the partial rows conv2d_fwd(stats=True) returned for THIS x (no reduction pass over x then)."""
     _need_cuda(x, gamma, beta, running_mean, running_var, residual)
     C = x.shape[-1]
     M = x.numel() // C
     out = torch.empty_like(x)
     sm = torch.empty(C, dtype=torch.float32, device=x.device)
     si = torch.empty(C, dtype=torch.float32, device=x.device)
-    left, _LAST_CONV_STATS[0] = _LAST_CONV_STATS[0], None
-    if left is not None and left[0] == x.data_ptr() and left[1] == tuple(x.shape):  # the conv that produced x already summed it
+    if stats is not None:  # the conv that produced x already summed it
+        _need_cuda(stats)
+        if stats.dim() != 3 or stats.shape[1:] != (2, C) or stats.dtype != torch.float32:
+            raise ValueError(f"bn_fwd_train: stats must be the fp32 [nblk, 2, {C}] rows conv2d_fwd(stats=True) returned for this tensor")
         ws = torch.empty(2 * C, dtype=torch.float32, device=x.device)
         check(_L().mi355_bn_fwd_train_partial(dtype_code(x.dtype), ptr(x), ptr(residual), ptr(out), ptr(gamma), ptr(beta), ptr(running_mean),
-                                              ptr(running_var), ptr(sm), ptr(si), M, C, eps, momentum, int(relu), ptr(left[2]), left[3], ptr(ws),
+                                              ptr(running_var), ptr(sm), ptr(si), M, C, eps, momentum, int(relu), ptr(stats), stats.shape[0], ptr(ws),
                                               ws.numel() * 4, cur_stream()))
         return out, sm, si
     ws, n = _bn_ws(C, x.device)
@@ -184,7 +183,6 @@ def bn_fwd_train(x, gamma, beta, running_mean, running_var, residual=None, relu=
 
 def bn_fwd_eval(x, gamma, beta, running_mean, running_var, residual=None, relu=True, eps=1e-5):
     _need_cuda(x, gamma, beta, running_mean, running_var, residual)
-    _LAST_CONV_STATS[0] = None
     C = x.shape[-1]
     M = x.numel() // C
     out = torch.empty_like(x)

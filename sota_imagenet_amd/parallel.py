@@ -19,6 +19,7 @@ BN running statistics stay rank-local (the reference's per-forward buffer broadc
 does not influence training; rank 0's buffers are the ones checkpointed).
 xGMI is point-to-point (7 links/GPU): few large buckets keep each ring step per-link efficient.
 """
+import contextlib
 import ctypes
 
 import torch
@@ -133,6 +134,8 @@ class FlatBucketDDP(nn.Module):
             p.register_post_accumulate_grad_hook(self._on_grad)
 
     def _on_grad(self, _p):
+        if getattr(self, "_skip_sync", False):
+            return
         if not self._pending:
             self._pending = True
             torch.autograd.Variable._execution_engine.queue_callback(self._reduce_all)
@@ -179,6 +182,34 @@ class FlatBucketDDP(nn.Module):
     @property
     def buckets(self):
         return list(self._buckets)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """torch DDP's no_sync(): backwards inside keep their gradients rank-local (accumulate_steps > 1: every micro-step but
+        the last); the first backward outside reduces the accumulated sums once."""
+        if hasattr(self.module, "set_grad_sync"):
+            self.module.set_grad_sync(False)
+        else:
+            self._skip_sync = True
+        try:
+            yield
+        finally:
+            if hasattr(self.module, "set_grad_sync"):
+                self.module.set_grad_sync(True)
+            else:
+                self._skip_sync = False
+
+    def comm_stats(self, reset=True):
+        """[(kind, begin, end)] of every collective issued through the native communicator since the last reset
+        (mi355_comm_stats: kind 0 bucket all-reduce over flat-gradient elements, 1 broadcast, 2 whole-buffer all-reduce)."""
+        from . import native
+
+        if self._comm is None:
+            return []
+        cap = 4096
+        n, K, B, E = ctypes.c_int(), (ctypes.c_int * cap)(), (ctypes.c_size_t * cap)(), (ctypes.c_size_t * cap)()
+        native.check(native.lib().mi355_comm_stats(self._comm, int(reset), cap, ctypes.byref(n), K, B, E))
+        return [(K[i], B[i], E[i]) for i in range(min(n.value, cap))]
 
     # ---- C3: called by the model's backward right after a segment's kernels were enqueued ---------------------
     def _on_segment(self, seg, begin, end):

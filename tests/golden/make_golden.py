@@ -6,7 +6,8 @@ dependencies — hydra, loguru, pytorch_tools, nvidia.dali — are not installed
 SURVEY.md §8c), so these vectors pin the ORACLE (torch 2.10 CPU kernels), not the reference: "parity unpinned".
 Inputs are regenerated from seeds by sota_imagenet_amd.synth on both sides; only expected outputs are stored.
 
-    python tests/golden/make_golden.py        # rewrites ops_small.npz and resnet50_small.npz
+    python tests/golden/make_golden.py           # rewrites ops_small.npz, resnet50_small.npz and curve20.npz
+    python tests/golden/make_golden.py curve20   # only the 20-step bs 32 / 224 px loss curve
 """
 import os
 import sys
@@ -24,6 +25,11 @@ from sota_imagenet_amd.synth import init_state_dict, synthetic_batch, uniform_te
 # (name, N, H, W, Cin, Cout, K, stride)
 CONV_CASES = [("c1x1", 2, 8, 8, 64, 64, 1, 1), ("c3x3", 2, 8, 8, 64, 128, 3, 1), ("c3x3s2", 2, 8, 8, 128, 64, 3, 2), ("c1x1s2", 1, 8, 8, 64, 128, 1, 2)]
 CURVE = dict(N=8, S=64, steps=6, lr=(0.0005, 0.004))
+# 20 SGD steps, bs 32, 224 px, seed 0, the linear-warm-up + cosine SHAPE of the r50 recipe
+# (/root/reference/configs/hydra_exp/1.r50_baseline.yaml:41-44: lr [0.001, 1.0] linear over epochs 0-8, [1.0, 0] cos over 8-90)
+# compressed to 5 "epochs" of 4 steps, peak scaled by the linear rule 1.0 * 32 / 1024 = 0.031
+CURVE20 = dict(N=32, S=224, steps=20, epoch_size=4, peak=0.031,
+               stages=[dict(ep=(0, 2), lr=(0.001 * 0.031, 0.031), mode="linear"), dict(ep=(2, 5), lr=(0.031, 0.0), mode="cos")])
 
 
 def conv_inputs(case):
@@ -123,9 +129,29 @@ def make_net():
     np.savez_compressed(os.path.join(HERE, "resnet50_small.npz"), **out)
 
 
+def make_curve20():
+    """fixture (iii) at the size SURVEY 8(c) specifies; fp32 and fp64 runs of the same oracle (the gap between them is the
+    yardstick the GPU test scales its band with).  ~5 min on 8 host threads."""
+    torch.use_deterministic_algorithms(True)
+    torch.set_num_threads(8)
+    ref = O.ResNet50Ref()
+    sd = init_state_dict([(k, tuple(v.shape)) for k, v in ref.state_dict().items()], seed=0)
+    c = CURVE20
+    batches = [synthetic_batch(c["N"], c["S"], seed=0, index=i) for i in range(c["steps"])]
+    lrs = [O.phase_lr(c["stages"], i // c["epoch_size"], i % c["epoch_size"], c["epoch_size"]) for i in range(c["steps"])]
+    l32, _ = O.train_steps(O.make_reference(sd), batches, lrs)
+    l64, _ = O.train_steps(O.make_reference(sd).double(), [(d.double(), t.double()) for d, t in batches], lrs)
+    np.savez_compressed(os.path.join(HERE, "curve20.npz"), curve_fp32=np.array(l32), curve_fp64=np.array(l64), curve_lrs=np.array(lrs))
+    print("curve20 fp32", np.round(l32, 4), "\n        fp64", np.round(l64, 4))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if sys.argv[1:] == ["curve20"]:
+        make_curve20()
+        sys.exit(0)
     make_ops()
     make_net()
-    for f in ("ops_small.npz", "resnet50_small.npz"):
+    make_curve20()
+    for f in ("ops_small.npz", "resnet50_small.npz", "curve20.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

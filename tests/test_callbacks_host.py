@@ -69,3 +69,36 @@ def test_cutmixmixup_only_in_training_and_accepts_index_targets():
         clb.on_batch_begin()
         d, t = st.input
         assert t.shape == (6, 10) and torch.allclose(t.sum(1), torch.ones(6), atol=1e-6)
+
+
+def test_device_sampler_stream_is_per_seed_rank_and_epoch():
+    """the device-side sampler's stream: (run seed, rank) -> seed, (epoch, step) -> counter; explicit seed= stays."""
+    a, b = CutmixMixup(1.0, 0.2), CutmixMixup(1.0, 0.2)
+    sa, sb = _state(a, None), _state(b, None)
+    sa.random_seed = sb.random_seed = 42
+    sa.rank, sb.rank = 0, 1
+    a.on_begin(), b.on_begin()
+    assert a._dev.seed != b._dev.seed and a._dev.seed != 0  # ranks do not share their coins / boxes / permutations
+    sb.rank = 0
+    b.on_begin()
+    assert a._dev.seed == b._dev.seed
+    sa.epoch, sa.epoch_size = 3, 100
+    a.on_loader_begin()
+    assert a._dev.counter == 300  # a resumed run continues the sequence
+    sa.is_train = False
+    a._dev.counter = 7
+    a.on_loader_begin()
+    assert a._dev.counter == 7
+    c = Mixup(0.4, seed=5)
+    _state(c, None).random_seed = 42
+    c.on_begin()
+    assert c._dev.seed == 5
+
+
+def test_device_mixer_rejects_non_float32():
+    import pytest
+
+    from sota_imagenet_amd.callbacks import _DeviceMixer
+
+    with pytest.raises(TypeError):
+        _DeviceMixer(0)(torch.zeros(2, 3, 8, 8, dtype=torch.bfloat16), torch.zeros(2, 10), 1.0, 1.0, 0.5, 3)

@@ -86,3 +86,10 @@ def test_bresnet50_encoder_legacy_recipe_maps_onto_the_plugin_surface():
     # the plugin builds the variant graph for these model_params (no GPU needed to construct it)
     model = C.call({k: v for k, v in m.items()}, weight_standardization=True, dtype="bf16")
     assert type(model).__name__ == "BResNet50" and abs(sum(p.numel() for p in model.parameters()) - 25.58e6) < 0.02e6
+    assert all(c.standardize for c in model.modules() if type(c).__name__ == "_Conv") and model.drop_rate == 0.2
+    # a variant recipe WITHOUT the flag / the drop rates gets what pytorch_tools gives: no standardisation, no dropout
+    plain = C.call({k: v for k, v in m.items() if k not in ("drop_rate", "drop_connect_rate")}, dtype="bf16")
+    assert not any(c.standardize for c in plain.modules() if type(c).__name__ == "_Conv")
+    assert plain.drop_rate == 0.0 and plain.drop_connect_rate == 0.0
+    off = C.call({k: v for k, v in m.items()}, weight_standardization=False, dtype="bf16")
+    assert not any(c.standardize for c in off.modules() if type(c).__name__ == "_Conv")

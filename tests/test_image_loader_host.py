@@ -175,6 +175,16 @@ def test_loader_protocol_and_packing(tmp_path, monkeypatch):
         shards.append(set(lr._shard_indices(0).tolist()))
         assert len(lr) == math.ceil(math.ceil(15 / 2) / 4)
     assert shards[0] | shards[1] == set(range(15)) and not (shards[0] & shards[1])
+    # 15 images over 2 ranks: shards of 8 and 7 — every rank must yield the SAME number of batches (a rank with one batch more
+    # would sit in a gradient all-reduce without a peer); checked at every batch size around the boundary
+    for bs in (1, 2, 3, 4, 7, 8):
+        counts = []
+        for r in (0, 1):
+            monkeypatch.setenv("RANK", str(r))
+            lr = L.ImageFolderLoader(dict(cfg, batch_size=bs), is_val=False, seed=7, device="cpu")
+            counts.append(lr.batches_per_epoch())
+            assert counts[-1] * bs <= len(lr._shard_indices(0))
+        assert counts[0] == counts[1] == (15 // 2) // bs, (bs, counts)
     monkeypatch.setenv("WORLD_SIZE", "1")
     monkeypatch.setenv("RANK", "0")
     monkeypatch.setenv("LOCAL_RANK", "0")

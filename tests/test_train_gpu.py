@@ -72,6 +72,17 @@ def test_bench_with_rccl_ddp_single_rank(dev):
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["parallelism"] == "dp1"
 
 
+def test_bench_launches_its_own_ranks(dev):
+    """`python bench.py --gpus N` with no launcher around it (no WORLD_SIZE): the parent spawns the ranks before touching HIP and
+    relays rank 0's line — here N = 1 through the spawner (--spawn), the one-GPU rehearsal of the driver's 8-GPU command form."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--steps", "2", "--warmup", "1", "--batch", "16",
+                          "--size", "64", "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["parallelism"] == "dp1"
+
+
 _DDP_CHECK = r"""
 import os, sys, torch, torch.distributed as dist
 from sota_imagenet_amd.losses import CrossEntropyLoss
@@ -99,6 +110,9 @@ with torch.no_grad():
     m.flat_params.mul_(1.0 + 0.1 * rank)
 ddp = FlatBucketDDP(m, device_ids=[torch.cuda.current_device()], bucket_cap_mb=8.0)
 assert torch.equal(m.flat_params, ref.flat_params), "rank-0 broadcast"
+# what the communicator was actually asked to do (mi355_comm_stats): the broadcast covered parameters AND buffers
+log = ddp.comm_stats()
+assert log == [(1, 0, m.flat_params.numel()), (1, 0, m._flat_buffers.numel())], log
 opt = SGD([{"params": list(m.parameters())}], lr=0.01, momentum=0.9, weight_decay=3e-5)
 opt.attach_model(m)
 m.train()
@@ -109,6 +123,22 @@ loss.backward()
 torch.cuda.synchronize()
 err = ((m.flat_grads - gmean).abs().max() / gmean.abs().max()).item()
 assert err < 1e-6, f"all-reduced gradients vs the mean of the per-rank gradients: {err}"
+# ONE backward = every element of the flat gradient array reduced exactly once, bucket after bucket, in plan order — true
+# whatever the rank count (at 1 rank the numeric check above cannot see a wrong slice: ncclAvg is then the identity)
+log = ddp.comm_stats()
+plan = [(0, b, e) for b, e, _ in ddp.buckets]
+assert len(plan) >= 3 and log == plan, (log, plan)
+assert log[0][1] == 0 and log[-1][2] == m.flat_grads.numel() and all(a[2] == b[1] for a, b in zip(log, log[1:])), log
+# no_sync (accumulate_steps > 1): micro-step 1 issues no collective and leaves the local gradient, micro-step 2 reduces the sum once
+m.mark_grads_clean()
+with ddp.no_sync():
+    crit(ddp(data), target).backward()
+assert ddp.comm_stats() == []
+crit(ddp(data), target).backward()
+assert ddp.comm_stats() == plan
+torch.cuda.synchronize()
+err2 = ((m.flat_grads - 2 * gmean).abs().max() / gmean.abs().max()).item()
+assert err2 < 1e-5 * world, f"accumulated micro-steps, reduced once: {err2}"   # (same batch twice: local sum 2 g_r -> mean 2 gmean)
 opt.step()
 torch.cuda.synchronize()
 mine = m.flat_params.clone()

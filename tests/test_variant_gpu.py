@@ -198,8 +198,9 @@ def test_bresnet50_bf16_trains(dev):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_epilogue_statistics_feed_the_next_batchnorm(dev, dtype):
-    """ops.conv2d_fwd(stats=True) + ops.bn_fwd_train on its output: the BatchNorm takes the sums the conv epilogue left (no
-    reduction pass) and must give what the standalone path gives on the same tensor; any other tensor ignores the slot."""
+    """ops.conv2d_fwd(stats=True) returns (y, partial rows); ops.bn_fwd_train(y, ..., stats=partial) takes the sums the conv
+    epilogue left (no reduction pass) and must give what the standalone path gives on the same tensor.  The rows are an
+    explicit value: a BatchNorm that is not handed them reduces its own input, whatever ran before."""
     from sota_imagenet_amd import ops
 
     N, H, W, Cin, Cout = 8, 14, 14, 64, 128
@@ -210,17 +211,18 @@ def test_conv_epilogue_statistics_feed_the_next_batchnorm(dev, dtype):
     outs = []
     for stats in (False, True):
         rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
-        y = ops.conv2d_fwd(x, w, 1, 1, stats=stats)
-        assert (ops._LAST_CONV_STATS[0] is not None) == stats
-        out, mean, invstd = ops.bn_fwd_train(y, g, b, rm, rv, relu=True)
-        assert ops._LAST_CONV_STATS[0] is None
+        y, st = ops.conv2d_fwd(x, w, 1, 1, stats=True) if stats else (ops.conv2d_fwd(x, w, 1, 1), None)
+        assert (st is not None) == stats and (st is None or (st.dim() == 3 and st.shape[1:] == (2, Cout)))
+        out, mean, invstd = ops.bn_fwd_train(y, g, b, rm, rv, relu=True, stats=st)
         outs.append((y, out, mean, invstd, rm, rv))
     assert torch.equal(outs[0][0], outs[1][0])
     for a, c in zip(outs[0][1:], outs[1][1:]):
         assert nerr(c, a) < (1e-5 if dtype == torch.float32 else 1e-2)
-    # the slot belongs to ONE tensor: a different input (same shape) must not pick it up
-    y = ops.conv2d_fwd(x, w, 1, 1, stats=True)
-    other = (y.float() * 2 + 1).to(dtype)
+    # no hidden hand-off: the SAME storage modified in place after the conv, normalised without the rows, uses its own sums
+    y, st = ops.conv2d_fwd(x, w, 1, 1, stats=True)
+    y.mul_(2).add_(1)
     rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
-    _, mean2, _ = ops.bn_fwd_train(other, g, b, rm, rv, relu=False)
-    assert nerr(mean2, other.float().reshape(-1, Cout).mean(0)) < 1e-3
+    _, mean2, _ = ops.bn_fwd_train(y, g, b, rm, rv, relu=False)
+    assert nerr(mean2, y.float().reshape(-1, Cout).mean(0)) < 1e-3
+    with pytest.raises(ValueError):
+        ops.bn_fwd_train(y, g, b, rm, rv, relu=False, stats=st[:, :, : Cout // 2].contiguous())

@@ -3,8 +3,9 @@
 #   kernel stats (bf16 + fp32, default overlapped run), per-layer trace + timeline (serial and overlapped), PMC traffic (serial)
 TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?not on a gpurun box (GRAFT_REPO_ROOT is unset)}"
 mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B="python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bf16 -- $B --dtype bf16 > $OUT/bench_bf16.jsonl 2> $OUT/bench_bf16.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_fp32 -- $B --dtype fp32 --steps 6 > $OUT/bench_fp32.jsonl 2> $OUT/bench_fp32.err

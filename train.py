@@ -113,12 +113,13 @@ def main(argv=None):
     model_cfg = C.to_plain(cfg.model)
     if "dtype" not in model_cfg and C.resolve_target(model_cfg["_target_"]).__module__.startswith("sota_imagenet_amd"):
         model_cfg["dtype"] = "bf16" if cfg.run.fp16 else "fp32"  # the AMP flag of the reference (arg_parser.py:89-90)
-    if cfg.weight_standardization:
-        # the reference converts the built model (conv_to_ws_conv, train.py:66-67); here standardisation is a property of
-        # the variant graph's conv nodes, so the flag travels into the model factory
-        if not C.resolve_target(model_cfg["_target_"]).__module__.startswith("sota_imagenet_amd"):
-            raise NotImplementedError("weight standardisation needs one of this package's model plugins")
-        model_cfg["weight_standardization"] = True
+    # the reference converts the built model only when the flag is set (conv_to_ws_conv, train.py:66-67); here standardisation is
+    # a property of the variant graph's conv nodes, so the flag — on OR off — travels into the model factory
+    own_model = C.resolve_target(model_cfg["_target_"]).__module__.startswith("sota_imagenet_amd")
+    if cfg.weight_standardization and not own_model:
+        raise NotImplementedError("weight standardisation needs one of this package's model plugins")
+    if own_model:
+        model_cfg["weight_standardization"] = bool(cfg.weight_standardization)
     model = C.call(model_cfg)
     if cfg.init_gamma is not None and hasattr(model, "reset_parameters"):
         model.reset_parameters(seed=cfg.random_seed or 0, gamma=cfg.init_gamma)
@@ -180,6 +181,7 @@ def main(argv=None):
 
     runner = fw.Runner(net, optimizer, criterion, callbacks=callbacks, use_fp16=cfg.run.fp16,
                        accumulate_steps=cfg.run.accumulate_steps)
+    runner.state.random_seed = cfg.random_seed or 0
 
     data_manager = SyntheticDataManager(cfg)
 
