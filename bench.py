@@ -25,7 +25,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2516.6}  # MI355X_MICROARCH.md: dense MFMA peaks (no sparsity)
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2516.6, "fp8": 5033.2}  # MI355X_MICROARCH.md: dense MFMA peaks (no sparsity)
+FP8_KIND = 9  # profile_read kind: the conv launches that ran on e4m3 operands
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 HBM_CLASS = 7  # executor profile class of bn_bwd_apply_kernel, the largest HBM-bound kernel of the step
 # profile class -> kernel symbols (template instances of one source; names as tools/pmc_traffic.py writes them)
@@ -141,7 +142,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default=os.environ.get("BENCH_DTYPE", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default=os.environ.get("BENCH_DTYPE", "bf16"), choices=["bf16", "fp32", "fp8"])
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -256,12 +257,14 @@ def main():
     def roof_of(model, dom, dtype):
         """(roofline, roofline_hbm) dicts from the HIP events recorded in the last timed steps of `model`"""
         roof = roof_hbm = None
-        tot_ms, launches, flops, nbytes = model.profile_read(shape, dom)
+        # fp8: the launches that ran on e4m3 operands (igemm8_kernel<..., EB = 1>), against the fp8 peak
+        tot_ms, launches, flops, nbytes = model.profile_read(shape, FP8_KIND if dtype == "fp8" else dom)
         tdt = "float" if dtype == "fp32" else "__bf16"
         if launches:
             ach = flops / (tot_ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[dtype]
-            knames = [n.format(T=tdt) for n in KERNEL_NAMES[dom] if not (dtype == "fp32" and n.startswith("igemm8"))]
+            knames = ["igemm8_kernel<224,256,EB=1>", "igemm8_kernel<256,128,EB=1>"] if dtype == "fp8" else \
+                [n.format(T=tdt) for n in KERNEL_NAMES[dom] if not (dtype == "fp32" and n.startswith("igemm8"))]
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": pmc_traffic(knames, dtype, N, S), "kernel": " + ".join(knames),
                     "launches": launches, "avg_launch_ms": round(tot_ms / launches, 4),
@@ -290,10 +293,10 @@ def main():
         os.environ["MI355_WGRAD_STREAM"] = "0"
         try:
             _, _, ms_, dom_s = run(dtype, steps, 2, True)
-            t_ms, n_l, fl, _ = ms_.profile_read(shape, dom_s)
+            t_ms, n_l, fl, _ = ms_.profile_read(shape, FP8_KIND if dtype == "fp8" else dom_s)
             t3, n3, fl3, _ = ms_.profile_read(shape, 8)
             ms_.profile(shape, 0)
-            if n_l and dom_s == roof_class:
+            if n_l and (dom_s == roof_class or dtype == "fp8"):
                 roof["serial_frac"] = round(fl / (t_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 4)
                 roof["serial_avg_launch_ms"] = round(t_ms / n_l, 4)
             if n3 and "conv3x3" in roof:
@@ -325,12 +328,13 @@ def main():
             return
         _, train_flops = model.flops(N, S, S)
         out = {
-            "metric": "images/sec (whole node) ResNet-50 bs=256/GPU @224px",
+            "metric": "images/sec (whole node) ResNet-50 bs=256/GPU @224px" if args.dtype != "fp8" else f"images/sec (whole node) ResNet-50 bs={N}/GPU @{S}px, fp8 convs",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"ResNet-50 v1.5 train step (fwd+CE+bwd+allreduce+SGD), bs={N}/GPU, {S}px, "
-                                   f"{'configs[2] bf16 activations / fp32 accumulate+master' if args.dtype == 'bf16' else 'configs[1] fp32'}",
+                                   + {"bf16": "configs[2] bf16 activations / fp32 accumulate+master", "fp32": "configs[1] fp32",
+                                      "fp8": "configs[4] fp8 (e4m3) operands for the fwd / dgrad convs of layers 2-4, bf16 tensors + wgrad, delayed per-tensor scaling"}[args.dtype],
                        "global_batch": world * N, "image_size": S, "parallelism": f"dp{world}",
                        "step_tflops": round(train_flops / (dt / args.steps) / 1e12, 2), "final_loss": round(final_loss, 4)},
             "roofline": roof,

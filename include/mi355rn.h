@@ -44,7 +44,8 @@ typedef enum mi355_status {
   MI355_E_NOMEM = -4  /* workspace too small / allocation failed */
 } mi355_status;
 
-/* MI355_FP8: OCP e4m3fn operand bytes — accepted by the *_fp8 entry points only (their outputs are bf16) */
+/* MI355_FP8: OCP e4m3fn operand bytes — the *_fp8 entry points (their outputs are bf16) and the fp8 training step of the
+ * whole-network executor (mi355_resnet50_create) */
 typedef enum mi355_dtype { MI355_F32 = 0, MI355_BF16 = 1, MI355_FP8 = 2 } mi355_dtype;
 
 /* ---- library ------------------------------------------------------------------------------------ */
@@ -345,6 +346,20 @@ int mi355_comm_stats(mi355_comm* comm, int reset, int cap, int* n_out, int* kind
 int mi355_resnet50_bucket_plan(const mi355_ctx* ctx, double bucket_cap_mb, int cap, int* n_out, size_t* begins,
                                size_t* ends, int* last_segs);
 
+/* dtype MI355_FP8 in mi355_resnet50_create = BASELINE.json configs[4] "fp8 MFMA convs": every tensor stays bf16 (fp32 accumulation,
+ * statistics, master weights as in the bf16 step) and the forward / data-gradient convolutions of every layer whose channel counts
+ * are multiples of 128 on both sides (layers 2-4) read OCP e4m3 twins of their operands through v_mfma_f32_16x16x32_fp8_fp8; the
+ * weight gradients, the stem, layer 1 and the FC stay on bf16 operands.  No standalone quantise pass exists: the BN-apply /
+ * BN-backward-apply kernels that produce an activation / gradient tensor write its twin in the same pass (q = e4m3(bf16(v) *
+ * scale), saturating) and the weight preparation writes the weights' twins.  Scaling is per tensor and DELAYED: a producer also
+ * records max|v| (atomicMax), and scale(step k+1) = 448 / (2 * amax(step k)).  The first training step of a ctx has no amaxes
+ * yet: it runs bf16 operands and only records them (forward and backward); from the 2nd step on the convs read the twins.
+ * Inference forwards always read the bf16 tensors.  mi355_resnet50_fp8_state: whether the last training step's
+ * forward / backward convs read the twins, and how many layers do.  Conv call sites replaced: callbacks.py:316-317; stage
+ * schema this dtype is used with: arg_parser.py:65-72, dali_dataloader.py:213-239.
+ * debug_tensor names of an fp8 ctx: "<conv>.xq" / ".wq" / ".wtq" (e4m3 bytes, dtype MI355_FP8), "<conv>.sx" / ".sw" / ".sdy" (scales). */
+int mi355_resnet50_fp8_state(const mi355_ctx* ctx, int* fwd_on, int* bwd_on, int* n_fwd_layers, int* n_dgrad_layers);
+
 /* algorithmic work of the ctx's conv/FC kernels (2 FLOP/MAC, padding-free): forward and fwd+bwd */
 int mi355_resnet50_flops(const mi355_ctx* ctx, double* fwd_flops, double* train_flops);
 
@@ -363,6 +378,7 @@ int mi355_resnet50_debug_tensor(const mi355_ctx* ctx, const char* name, void** p
  *   2 wgrad_kernel<T,128,*>   3 wgrad_kernel<T,64,*> (incl. stem)   4 bn_reduce_kernel (stats + bwd sums)
  *   5 bn_apply_kernel   6 other (ingest, pools, FC, weight prep)   7 bn_bwd_apply_kernel
  *   profile_read kind 8: the 3x3 convolutions (fwd + dgrad) among the recorded launches of classes 0 and 1
+ *   profile_read kind 9: the launches that ran on e4m3 operands (fp8 ctx) among the recorded launches
  * (one class = one kernel symbol, so the averages can be checked against rocprofv3 --kernel-trace --stats)
  * mi355_resnet50_profile_read(ctx, k, ...) waits for the recorded events of class k and returns their
  * summed duration (ms), launch count and the algorithmic FLOPs / bytes those launches represent.    */

@@ -13,6 +13,8 @@
 // epilogues instead (conv_igemm.hip, STATS 1 / 2) and only the finalize + apply kernels of this file run; the ReLU mask
 // travels as one byte per 16-byte vector (written by bn_apply, read by both backward kernels); mask / residual /
 // second-branch variants are template parameters and last-use streams are loaded non-temporally.
+#include <hip/hip_fp8.h>
+
 #include "common.h"
 #include "vec.h"
 
@@ -20,6 +22,24 @@ namespace mi355 {
 namespace {
 
 constexpr int MAXBLK = 512;
+
+// fp8 training step: the e4m3 twin of the 8 bf16 values a thread has just computed (q = e4m3(bf16(v) * scale), saturating) and
+// their running max magnitude; the twin is what the next fp8 convolution reads, the max seeds the next step's scale
+__device__ __forceinline__ void quant8(const float (&v)[8], float scale, uint8_t* dst, float& amax) {
+  unsigned char o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float r = (float)(bf16_t)v[e];
+    amax = fmaxf(amax, fabsf(r));
+    o[e] = __hip_cvt_float_to_fp8(r * scale, __HIP_SATFINITE, __HIP_E4M3);
+  }
+  *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(o);
+}
+__device__ __forceinline__ void amax_flush(float amax, unsigned* dst) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(dst, __float_as_uint(amax));  // non-negative floats order like their bits
+}
 
 // V (4 or 8) consecutive per-channel constants with 16-byte loads (c0 is a multiple of V): one or two load
 // instructions instead of V — the per-thread prologue matters for the small late-layer tensors
@@ -272,12 +292,17 @@ struct ApplyArgs {
   int cvecs;      // C/V
   int relu;
   float slope;    // of the negative side (RELU == 1 only): 0 ReLU, 0.01 leaky ReLU
+  QuantOut qo;    // Q: e4m3 twin of `out`
 };
 
 // RES: + residual;  X2: + second normalised tensor (downsample branch);  RELU: 0 none, 1 relu, 2 relu + bit mask out
-template <typename T, bool RES, bool X2, int RELU>
+// Q (bf16 only): also the e4m3 twin of the output + its amax (fp8 training step)
+template <typename T, bool RES, bool X2, int RELU, bool Q = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
   constexpr int V = Vec16<T>::N;
+  static_assert(!Q || V == 8, "the quantised twin exists for bf16 tensors");
+  float qs = 1.f, amax = 0.f;
+  if constexpr (Q) qs = p.qo.scale[0];
   const T* x = reinterpret_cast<const T*>(p.x);
   const T* res = reinterpret_cast<const T*>(p.residual);
   const T* x2 = reinterpret_cast<const T*>(p.x2);
@@ -327,7 +352,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
       for (int e = 0; e < V; ++e) v[e] = v[e] > 0.f ? v[e] : (RELU == 1 ? v[e] * p.slope : 0.f);  // (bit-mask form: ReLU only)
     }
     Vec16<T>::store(out + i * V, v);
+    if constexpr (Q) quant8(v, qs, p.qo.q + i * V, amax);
   }
+  if constexpr (Q) amax_flush(amax, p.qo.amax);
 }
 
 struct BwdApplyArgs {
@@ -342,11 +369,15 @@ struct BwdApplyArgs {
   size_t nvec;
   int cvecs, C;
   float slope;  // MASK == 1: gradient factor where the activation was <= 0
+  QuantOut qo;  // Q: e4m3 twin of dx
 };
 
-template <typename T, int MASK>
+template <typename T, int MASK, bool Q = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p) {
   constexpr int V = Vec16<T>::N;
+  static_assert(!Q || V == 8, "the quantised twin exists for bf16 tensors");
+  float qs = 1.f, amax = 0.f;
+  if constexpr (Q) qs = p.qo.scale[0];
   const T* g = reinterpret_cast<const T*>(p.g);
   const T* mk = reinterpret_cast<const T*>(p.mask);
   const T* x = reinterpret_cast<const T*>(p.x);
@@ -381,7 +412,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p)
       gv[e] = k0[e] * (gv[e] - k1[e] - xh * k2[e]);
     }
     Vec16<T>::store(dx + i * V, gv);
+    if constexpr (Q) quant8(gv, qs, p.qo.q + i * V, amax);
   }
+  if constexpr (Q) amax_flush(amax, p.qo.amax);
 }
 
 int reduce_grid(int dtype, int M, int C, dim3* grid) {
@@ -471,7 +504,7 @@ int launch_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm
 
 int launch_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
                     const void* x2, const float* scale2, const float* shift2, void* out, int M, int C, int relu,
-                    hipStream_t s, uint8_t* relu_bits) {
+                    hipStream_t s, uint8_t* relu_bits, QuantOut qo) {
   MI355_TRY(check_c(dtype, C));
   const int V = 16 / (int)dtype_size(dtype);
   ApplyArgs a{};
@@ -488,7 +521,16 @@ int launch_bn_apply(int dtype, const void* x, const float* scale, const float* s
   a.cvecs = C / V;
   a.relu = relu;
   a.slope = relu == 2 ? 0.01f : 0.f;  // activation code 2 = leaky ReLU (per-op path; the bit-mask path is ReLU)
+  a.qo = qo;
   const int blocks = elementwise_blocks(a.nvec, a.cvecs);
+  if (qo.q) {  // fp8 training step: bf16, ReLU with bit mask (the executor's training forward)
+    MI355_ARG(dtype == MI355_BF16 && relu == 1 && relu_bits && qo.scale && qo.amax && !(residual && x2), "bn_apply: the e4m3 twin needs bf16 + ReLU bit mask");
+    if (residual) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true, false, 2, true>), dim3(blocks), dim3(256), 0, s, a);
+    else if (x2) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false, true, 2, true>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false, false, 2, true>), dim3(blocks), dim3(256), 0, s, a);
+    MI355_LAUNCH_CHECK();
+    return 0;
+  }
   const int rl = relu ? (relu_bits ? 2 : 1) : 0;
   const int variant = (residual ? 6 : 0) + (x2 ? 3 : 0) + rl;
   MI355_ARG(!(residual && x2), "bn_apply: residual and second branch together are not supported");
@@ -573,7 +615,7 @@ int launch_bn_bwd_finalize(const float* partial, int nblk, int M, int C, const f
 
 int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
                         const float* invstd, const float* coef, void* dx, int M, int C, hipStream_t s,
-                        const uint8_t* relu_bits, float slope) {
+                        const uint8_t* relu_bits, float slope, QuantOut qo) {
   MI355_TRY(check_c(dtype, C));
   const int V = 16 / (int)dtype_size(dtype);
   BwdApplyArgs a{};
@@ -591,6 +633,14 @@ int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const vo
   a.C = C;
   const int blocks = elementwise_blocks(a.nvec, a.cvecs);
   const int mask = relu_bits ? 2 : mask_src ? 1 : 0;
+  a.qo = qo;
+  if (qo.q) {
+    MI355_ARG(dtype == MI355_BF16 && mask != 1 && qo.scale && qo.amax, "bn_bwd_apply: the e4m3 twin needs bf16 and a bit mask (or none)");
+    if (mask == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 2, true>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0, true>), dim3(blocks), dim3(256), 0, s, a);
+    MI355_LAUNCH_CHECK();
+    return 0;
+  }
 #define MI355_BN_BWD_APPLY(TT)                                                                                  \
   switch (mask) {                                                                                               \
     case 0: hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, 0>), dim3(blocks), dim3(256), 0, s, a); break;          \

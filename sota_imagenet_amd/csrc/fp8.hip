@@ -12,7 +12,8 @@
 
 namespace mi355 {
 
-int launch_igemm8_fp8(const IgemmArgs& a, int nclass, int bm, int bn, int korder, float oscale, hipStream_t stream);
+int launch_igemm8_fp8(const IgemmArgs& a, int nclass, int bm, int bn, int korder, float oscale, hipStream_t stream, int* stat_rows);
+bool igemm8_fp8_legal(const IgemmArgs& a, int nclass, int bn);
 
 namespace {
 
@@ -33,16 +34,42 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* x, unsigned 
   }
 }
 
-int pick_tile(const IgemmArgs& a, int* bm, int* bn) {
+int pick_tile(const IgemmArgs& a, int nclass, int* bm, int* bn) {
   // the wide tile when it alone fills most of the 256 CUs (same threshold as the bf16 rule, conv_igemm.hip::choose_igemm8)
   const long long M = (long long)a.N * a.Hsub * a.Wsub;
-  if (a.Ncols % 256 == 0 && ((M + 223) / 224) * (a.Ncols / 256) >= 180) { *bm = 224; *bn = 256; return 0; }
+  if (a.Ncols % 256 == 0 && ((M + 223) / 224) * nclass * (a.Ncols / 256) >= 180) { *bm = 224; *bn = 256; return 0; }
   if (a.Ncols % 128 == 0) { *bm = 256; *bn = 128; return 0; }
   set_error("conv fp8: %d output columns (a multiple of 128 is needed)", a.Ncols);
   return MI355_E_ARG;
 }
 
+// delayed per-tensor scaling: the amax a tensor's producer recorded in the previous step sets this step's scale
+__global__ void fp8_scale_update_kernel(float* scale, unsigned* amax, int n, float headroom) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = __uint_as_float(amax[i]);
+  if (a > 0.f && a < 3.0e38f) scale[i] = 448.f / (headroom * a);
+  amax[i] = 0u;
+}
+
 }  // namespace
+
+bool igemm_fp8_legal(const IgemmArgs& a, int nclass) { return igemm8_fp8_legal(a, nclass, 128); }
+
+int launch_igemm_fp8(const IgemmArgs& a, int nclass, float oscale, hipStream_t stream, int* stat_rows) {
+  int bm, bn;
+  MI355_TRY(pick_tile(a, nclass, &bm, &bn));
+  int max_taps = 0;
+  for (int ci = 0; ci < nclass; ++ci) max_taps = a.cls[ci].ntaps > max_taps ? a.cls[ci].ntaps : max_taps;
+  return launch_igemm8_fp8(a, nclass, bm, bn, max_taps > 1 ? 1 : 0, oscale, stream, stat_rows);
+}
+
+int launch_fp8_scale_update(float* scale, unsigned* amax, int n, float headroom, hipStream_t s) {
+  hipLaunchKernelGGL(fp8_scale_update_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, scale, amax, n, headroom);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace mi355
 
 using namespace mi355;
@@ -72,9 +99,7 @@ int mi355_conv2d_fwd_fp8(const void* xq, const void* wq, void* y, float oscale, 
   IgemmArgs a;
   build_fwd_args(a, N, H, W, Cin, Cout, KH, KW, stride, pad);
   a.in = xq; a.wt = wq; a.out = y;
-  int bm, bn;
-  MI355_TRY(pick_tile(a, &bm, &bn));
-  return launch_igemm8_fp8(a, 1, bm, bn, KH * KW > 1 ? 1 : 0, oscale, (hipStream_t)stream);
+  return launch_igemm_fp8(a, 1, oscale, (hipStream_t)stream);
 }
 
 int mi355_conv2d_dgrad_fp8(const void* dyq, const void* wtq, void* dx, float oscale, int N, int H, int W, int Cin, int Cout, int KH, int KW,
@@ -84,9 +109,7 @@ int mi355_conv2d_dgrad_fp8(const void* dyq, const void* wtq, void* dx, float osc
   const int nclass = build_dgrad_args(a, N, H, W, Cin, Cout, KH, KW, stride, pad);
   if (nclass < 0) return nclass;
   a.in = dyq; a.wt = wtq; a.out = dx;
-  int bm, bn;
-  MI355_TRY(pick_tile(a, &bm, &bn));
-  return launch_igemm8_fp8(a, nclass, bm, bn, KH * KW > 1 ? 1 : 0, oscale, (hipStream_t)stream);
+  return launch_igemm_fp8(a, nclass, oscale, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -24,6 +24,7 @@ void build_stem_wgrad_args(WgradArgs& a, int N, int H, int W);
 namespace {
 
 constexpr float BN_EPS = 1e-5f;
+constexpr float FP8_HEADROOM = 2.f;  // scale = 448 / (FP8_HEADROOM * amax of the previous step): one binade of the e4m3 range
 constexpr size_t PARAM_ALIGN = 64;  // floats (256 B)
 constexpr int MAX_EVENTS = 8192;
 
@@ -50,6 +51,12 @@ struct ConvBN {
   int bwd_rows = 0;   // partial rows of THIS layer's BN-backward sums left in bn_partial by the dgrad that produced its
                       // activation gradient (0: none, bn_backward runs the standalone reduce kernel)
   bool is_stem = false;
+  // fp8 training step (ctx dtype MI355_FP8): forward / dgrad of this layer on e4m3 operands where the geometry allows it
+  bool fp8_fwd = false, fp8_dgrad = false;
+  void* w_q = nullptr;          // e4m3 [Cout][taps][Cin]
+  void* w_trq = nullptr;        // e4m3 [Cin][taps][Cout]
+  const void* in_q = nullptr;   // e4m3 twin of the layer's input activation (written by the bn_apply that produced it)
+  int qid_w = -1, qid_in = -1, qid_dy = -1;  // slots of the per-tensor scale / amax tables
 };
 
 struct Block {
@@ -60,6 +67,8 @@ struct Block {
   void* a2 = nullptr;
   void* out = nullptr;
   uint8_t *a1_bits = nullptr, *a2_bits = nullptr, *out_bits = nullptr;  // ReLU masks, 1 byte per 16-byte vector
+  uint8_t *a1_q = nullptr, *a2_q = nullptr, *out_q = nullptr;           // e4m3 twins (fp8 step; null where no fp8 conv reads them)
+  int qid_a1 = -1, qid_a2 = -1, qid_out = -1;
   int Hin, Win, Hout, Wout, Cin, Cout;
   size_t grad_begin = 0, grad_end = 0;
 };
@@ -108,6 +117,16 @@ struct mi355_ctx {
     int last_seg;
   };
   std::vector<Bucket> buckets;
+  // fp8 training step: bf16 tensors everywhere + e4m3 twins of the conv operands; delayed per-tensor scaling (a tensor's amax of
+  // step k sets its scale of step k + 1); the first training step of a ctx runs bf16 operands and only records the amaxes
+  bool fp8 = false;
+  int q_n = 0;
+  float* q_scale = nullptr;
+  unsigned* q_amax = nullptr;
+  void* gq[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // e4m3 twins of gset
+  bool fp8_fwd_cal = false, fp8_bwd_cal = false;  // a training forward / a whole backward has recorded its amaxes
+  bool fp8_fwd_on = false, fp8_bwd_on = false;    // this step's convs read the e4m3 twins
+  bool fp8_use_fwd = true, fp8_use_bwd = true;    // MI355_FP8_FWD=0 / MI355_FP8_BWD=0 (read at create): keep that direction on bf16 operands (A/B)
   bool grad_sync = true;    // false: backward skips the bucket all-reduces (DDP.no_sync(): non-final accumulation micro-steps)
   bool comm_dirty = false;  // an all-reduce of this backward call is in flight on the communicator's stream
   unsigned* sk_err_host = nullptr;  // pinned copy of the two scratch blocks' error words, refreshed by an async copy at the
@@ -140,7 +159,7 @@ struct mi355_ctx {
   std::vector<hipEvent_t> ev;
   struct Rec {
     int cls;
-    int tag;  // 1: a 3x3 convolution (profile_read kind 8 = the 3x3 launches of classes 0 and 1)
+    int tag;  // bit 0: a 3x3 convolution (profile_read kind 8 = the 3x3 launches of classes 0 and 1); bit 1: e4m3 operands (kind 9)
     double flops, bytes;
   };
   std::vector<Rec> recs;
@@ -229,8 +248,14 @@ int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, hipStrea
   a.wt = c->dtype == MI355_F32 ? (const void*)(c->params + l.w_off) : (const void*)l.w_cast;
   a.out = l.y;
   const double fl = conv_flops(c, l);
-  const double by = ((double)c->N * l.Hin * l.Win * l.Cin + (double)c->N * l.Hout * l.Wout * l.Cout) * c->es;
-  Prof p(c, igemm_class(l.Cout), fl, by, s, l.K == 3 ? 1 : 0);
+  const bool q = training && c->fp8_fwd_on && l.fp8_fwd;
+  const double by = (double)c->N * l.Hin * l.Win * l.Cin * (q ? 1 : c->es) + (double)c->N * l.Hout * l.Wout * l.Cout * c->es;
+  Prof p(c, igemm_class(l.Cout), fl, by, s, (l.K == 3 ? 1 : 0) | (q ? 2 : 0));
+  if (q) {
+    a.in = l.in_q; a.wt = l.w_q;
+    a.q_scale_in = c->q_scale + l.qid_in; a.q_scale_wt = c->q_scale + l.qid_w;
+    return launch_igemm_fp8(a, 1, 1.f, s, &l.stat_rows);
+  }
   return launch_igemm(c->dtype, a, 1, s, &l.stat_rows);
 }
 
@@ -258,12 +283,24 @@ int bn_prepare(mi355_ctx* c, ConvBN& l, int training, float momentum, hipStream_
 }
 
 int bn_apply(mi355_ctx* c, ConvBN& l, const void* residual, ConvBN* l2, void* out, int relu, hipStream_t s,
-             uint8_t* bits) {
+             uint8_t* bits, uint8_t* q = nullptr, int qid = -1) {
   const int M = c->N * l.Hout * l.Wout, C = l.Cout;
   const int nin = 1 + (residual ? 1 : 0) + (l2 ? 1 : 0);
-  Prof p(c, PC_BN_APPLY, 0, (double)M * C * c->es * (nin + 1), s);
+  QuantOut qo;
+  if (q && bits && qid >= 0) {  // training forward of the fp8 step: the e4m3 twin the next conv(s) read + its amax
+    qo.q = q; qo.scale = c->q_scale + qid; qo.amax = c->q_amax + qid;
+  }
+  Prof p(c, PC_BN_APPLY, 0, (double)M * C * (c->es * (nin + 1) + (qo.q ? 1 : 0)), s);
   return launch_bn_apply(c->dtype, l.y, l.stat + 2 * C, l.stat + 3 * C, residual, l2 ? l2->y : nullptr,
-                         l2 ? l2->stat + 2 * C : nullptr, l2 ? l2->stat + 3 * C : nullptr, out, M, C, relu, s, bits);
+                         l2 ? l2->stat + 2 * C : nullptr, l2 ? l2->stat + 3 * C : nullptr, out, M, C, relu, s, bits, qo);
+}
+
+// e4m3 twin of one of the per-layer gradient buffers (gset[p][i] -> gq[p][i]); null for any other pointer
+void* grad_twin(const mi355_ctx* c, const void* g) {
+  for (int p = 0; p < 2; ++p)
+    for (int i = 0; i < 4; ++i)
+      if (c->gset[p][i] == g) return c->gq[p][i];
+  return nullptr;
 }
 
 // BN backward of layer l: g (gradient wrt the activation), bits (ReLU mask of the activation, 1 byte per 16-byte
@@ -284,8 +321,12 @@ int bn_backward(mi355_ctx* c, ConvBN& l, const void* g, const uint8_t* bits, voi
   // after an in-place masked write-back the mask is already applied
   const uint8_t* bits2 = dz_out ? nullptr : bits;
   const void* g2 = dz_out ? dz_out : g;
-  Prof p(c, PC_BN_BWD_APPLY, 0, (double)M * C * c->es * 3 + (bits2 ? mask_bytes : 0.0), s);
-  return launch_bn_bwd_apply(c->dtype, g2, nullptr, l.y, l.stat, l.stat + C, bn_coef_of(c, s), dx, M, C, s, bits2);
+  QuantOut qo;
+  if (c->fp8 && l.fp8_dgrad) {  // dx = the gradient wrt this layer's conv output: the operand of its fp8 dgrad
+    qo.q = (uint8_t*)grad_twin(c, dx); qo.scale = c->q_scale + l.qid_dy; qo.amax = c->q_amax + l.qid_dy;
+  }
+  Prof p(c, PC_BN_BWD_APPLY, 0, (double)M * C * (c->es * 3 + (qo.q ? 1 : 0)) + (bits2 ? mask_bytes : 0.0), s);
+  return launch_bn_bwd_apply(c->dtype, g2, nullptr, l.y, l.stat, l.stat + C, bn_coef_of(c, s), dx, M, C, s, bits2, 0.f, qo);
 }
 
 int conv_wgrad(mi355_ctx* c, ConvBN& l, const void* dy, const void* x, float beta_acc, hipStream_t s) {
@@ -316,11 +357,18 @@ int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* ad
     a.bn_y = bn->y; a.bn_bits = bn_bits; a.bn_mean = bn->stat; a.bn_invstd = bn->stat + bn->Cout;
   }
   const double dx_elems = (double)c->N * l.Hin * l.Win * l.Cin;
+  void* dyq = c->fp8_bwd_on && l.fp8_dgrad ? grad_twin(c, dy) : nullptr;
   // dy read, dx written, + the addend and (fused BN-backward sums) that layer's y read in the epilogue, masks at 1/16
-  const double by = (dx_elems * (1 + (addend ? 1 : 0) + (a.bn_y ? 1 : 0)) + (double)c->N * l.Hout * l.Wout * l.Cout) * c->es +
+  const double by = dx_elems * (1 + (addend ? 1 : 0) + (a.bn_y ? 1 : 0)) * c->es + (double)c->N * l.Hout * l.Wout * l.Cout * (dyq ? 1 : c->es) +
                     dx_elems * c->es / 16 * ((addend_bits ? 1 : 0) + (a.bn_y ? 1 : 0));
-  Prof p(c, igemm_class(l.Cin), conv_flops(c, l), by, s, l.K == 3 ? 1 : 0);
-  return launch_igemm(c->dtype, a, nclass, s, bn && c->fuse_bn_bwd ? &bn->bwd_rows : nullptr);
+  Prof p(c, igemm_class(l.Cin), conv_flops(c, l), by, s, (l.K == 3 ? 1 : 0) | (dyq ? 2 : 0));
+  int* rows = bn && c->fuse_bn_bwd ? &bn->bwd_rows : nullptr;
+  if (dyq) {
+    a.in = dyq; a.wt = l.w_trq;
+    a.q_scale_in = c->q_scale + l.qid_dy; a.q_scale_wt = c->q_scale + l.qid_w;
+    return launch_igemm_fp8(a, nclass, 1.f, s, rows);
+  }
+  return launch_igemm(c->dtype, a, nclass, s, rows);
 }
 
 int plan_arena(mi355_ctx* c, Arena& ar) {
@@ -336,6 +384,10 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
       const size_t wn = (size_t)l.Cout * l.K * l.K * l.Cin;
       if (c->dtype != MI355_F32) ar.add(&l.w_cast, wn * c->es);
       ar.add(&l.w_tr, wn * c->es);
+      if (l.qid_w >= 0) {
+        ar.add(&l.w_q, wn);
+        ar.add(&l.w_trq, wn);
+      }
       l.splits = plan_wgrad_splits(c->dtype, N * l.Hout * l.Wout, l.Cout, l.K * l.K, l.Cin);
       max_wg = std::max(max_wg, (size_t)l.splits * wn * 4);
     } else {
@@ -360,6 +412,9 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
     if (b.has_ds) conv_ws(b.ds);
     ar.add(&b.out, act_bytes(c, b.Hout, b.Wout, b.Cout));
     ar.add((void**)&b.out_bits, act_bytes(c, b.Hout, b.Wout, b.Cout) / 16);
+    if (b.qid_a1 >= 0) ar.add((void**)&b.a1_q, act_bytes(c, b.c1.Hout, b.c1.Wout, b.c1.Cout) / c->es);
+    if (b.qid_a2 >= 0) ar.add((void**)&b.a2_q, act_bytes(c, b.c2.Hout, b.c2.Wout, b.c2.Cout) / c->es);
+    if (b.qid_out >= 0) ar.add((void**)&b.out_q, act_bytes(c, b.Hout, b.Wout, b.Cout) / c->es);
   }
   const int fcp = c->fc_pad;
   ar.add((void**)&c->pooled, (size_t)N * 2048 * 4);
@@ -381,7 +436,48 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
   for (int i = 0; i < 2; ++i) ar.add(&c->gG[i], max_act);
   for (int p = 0; p < 2; ++p)
     for (int i = 0; i < 4; ++i) ar.add(&c->gset[p][i], max_act);
+  if (c->fp8) {
+    for (int p = 0; p < 2; ++p)
+      for (int i = 0; i < 4; ++i) ar.add(&c->gq[p][i], max_act / c->es);
+    ar.add((void**)&c->q_scale, (size_t)c->q_n * 4);
+    ar.add((void**)&c->q_amax, (size_t)c->q_n * 4);
+  }
   return 0;
+}
+
+// fp8 step: which layers run on e4m3 operands (geometry the fp8 form of the 8-wave kernel accepts: channel counts in multiples of
+// 128 on both sides — layers 2-4 of the network; stem, layer 1 and FC stay bf16), the twins they read, and their scale slots.
+// MI355_FP8_LAYERS=<substring> restricts the set to layers whose conv name contains it (A/B, tests).
+void plan_fp8(mi355_ctx* c) {
+  const char* only = getenv("MI355_FP8_LAYERS");
+  int n = 0;
+  auto legal = [&](ConvBN& l) {
+    if (only && only[0] && l.conv_name.find(only) == std::string::npos) return;
+    IgemmArgs a;
+    build_fwd_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
+    l.fp8_fwd = igemm_fp8_legal(a, 1);
+    const int nclass = build_dgrad_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
+    l.fp8_dgrad = nclass > 0 && igemm_fp8_legal(a, nclass);
+    if (l.fp8_fwd || l.fp8_dgrad) l.qid_w = n++;
+    if (l.fp8_dgrad) l.qid_dy = n++;
+  };
+  for (size_t i = 0; i < c->blocks.size(); ++i) {
+    Block& b = c->blocks[i];
+    legal(b.c1); legal(b.c2); legal(b.c3);
+    if (b.has_ds) legal(b.ds);
+    if (i > 0 && (b.c1.fp8_fwd || (b.has_ds && b.ds.fp8_fwd))) {
+      Block& prev = c->blocks[i - 1];
+      prev.qid_out = n++;
+      b.c1.qid_in = b.c1.fp8_fwd ? prev.qid_out : -1;
+      b.ds.qid_in = b.has_ds && b.ds.fp8_fwd ? prev.qid_out : -1;
+    } else {
+      b.c1.fp8_fwd = false;  // (the first block reads the max-pool output, which has no twin)
+      b.ds.fp8_fwd = false;
+    }
+    if (b.c2.fp8_fwd) b.c2.qid_in = b.qid_a1 = n++;
+    if (b.c3.fp8_fwd) b.c3.qid_in = b.qid_a2 = n++;
+  }
+  c->q_n = (int)align_up((size_t)n, 64);
 }
 
 int weight_prep_all(mi355_ctx* c, bool need_tr, hipStream_t s) {
@@ -578,7 +674,9 @@ extern "C" {
 
 int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, int W, int num_classes) {
   MI355_ARG(out, "create: null out");
-  MI355_ARG(dtype == MI355_F32 || dtype == MI355_BF16, "create: bad dtype %d", dtype);
+  MI355_ARG(dtype == MI355_F32 || dtype == MI355_BF16 || dtype == MI355_FP8, "create: bad dtype %d", dtype);
+  const bool fp8 = dtype == MI355_FP8;  // bf16 tensors + e4m3 conv operands
+  if (fp8) dtype = MI355_BF16;
   MI355_ARG(N >= 1 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0, "create: N=%d H=%d W=%d (H,W multiples of 32)",
             N, H, W);
   MI355_ARG(num_classes >= 1 && num_classes <= 65536, "create: num_classes=%d", num_classes);
@@ -587,6 +685,7 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
   c->device = device; c->dtype = dtype; c->N = N; c->H = H; c->W = W; c->num_classes = num_classes;
   c->fc_pad = (int)align_up((size_t)num_classes, 128);
   c->es = dtype_size(dtype);
+  c->fp8 = fp8;
 
   // ---- network description ----
   init_conv(c->stem, "conv1", "bn1", 3, 64, 7, 2, H, W);
@@ -647,6 +746,13 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
   c->train_flops = tr + 3 * ffc;
 
   // ---- workspace ----
+  if (c->fp8) {
+    plan_fp8(c);
+    const char* e = getenv("MI355_FP8_FWD");
+    c->fp8_use_fwd = !(e && e[0] == '0');
+    e = getenv("MI355_FP8_BWD");
+    c->fp8_use_bwd = !(e && e[0] == '0');
+  }
   Arena ar;
   plan_arena(c, ar);
   c->arena_bytes = ar.size;
@@ -668,6 +774,20 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
     delete c;
     return MI355_E_HIP;
   }
+  if (c->fp8) {  // twins of the conv inputs (static graph) and unit scales until the first amaxes exist
+    for (size_t i = 0; i < c->blocks.size(); ++i) {
+      Block& b = c->blocks[i];
+      if (i > 0) b.c1.in_q = b.ds.in_q = c->blocks[i - 1].out_q;
+      b.c2.in_q = b.a1_q;
+      b.c3.in_q = b.a2_q;
+    }
+    std::vector<float> ones(c->q_n, 1.f);
+    if (hipMemcpy(c->q_scale, ones.data(), ones.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+      set_error("create: fp8 scale table upload failed");
+      mi355_resnet50_destroy(c);
+      return MI355_E_HIP;
+    }
+  }
   // descriptor tables of the one-launch weight preparation
   {
     std::vector<PrepDesc> tab[2];
@@ -675,9 +795,14 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
     auto add = [&](ConvBN& l) {
       PrepDesc d;
       d.w_off = l.w_off; d.w_cast = l.w_cast; d.w_tr = nullptr;
+      d.w_q = d.w_trq = nullptr; d.q_scale = nullptr; d.q_amax = nullptr;
       d.Cout = l.Cout; d.taps = l.K * l.K; d.Cin = l.Cin; d.tile_begin = tiles;
       tab[0].push_back(d);
       d.w_tr = l.w_tr;
+      if (l.qid_w >= 0) {
+        d.w_q = l.w_q; d.w_trq = l.w_trq;
+        d.q_scale = c->q_scale + l.qid_w; d.q_amax = c->q_amax + l.qid_w;
+      }
       tab[1].push_back(d);
       tiles += (l.Cout / PREP_TILE) * (l.Cin / PREP_TILE) * l.K * l.K;
     };
@@ -796,6 +921,13 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
   MI355_TRY(sk_check(c));
   c->fwd_training_done = false;
   for (auto& b : c->blocks) b.c1.bwd_rows = b.c2.bwd_rows = b.c3.bwd_rows = b.ds.bwd_rows = 0;
+  if (c->fp8 && training) {
+    // delayed scaling: the amaxes the previous step's producers recorded become this step's scales; the very first training
+    // step of a ctx has none yet and runs its convs on the bf16 tensors (the twins are still written: that records the amaxes)
+    c->fp8_fwd_on = c->fp8_fwd_cal && c->fp8_use_fwd;
+    c->fp8_bwd_on = c->fp8_fwd_cal && c->fp8_bwd_cal && c->fp8_use_bwd;
+    if (c->fp8_fwd_cal) MI355_TRY(launch_fp8_scale_update(c->q_scale, c->q_amax, c->q_n, FP8_HEADROOM, s));
+  }
   MI355_TRY(weight_prep_all(c, training != 0, s));
   {
     Prof p(c, PC_OTHER, 0, 0, s);
@@ -828,17 +960,17 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
     }
     MI355_TRY(conv_forward(c, b.c1, b.in, training, s));
     MI355_TRY(bn_prepare(c, b.c1, training, bn_momentum, s));
-    MI355_TRY(bn_apply(c, b.c1, nullptr, nullptr, b.a1, 1, s, training ? b.a1_bits : nullptr));
+    MI355_TRY(bn_apply(c, b.c1, nullptr, nullptr, b.a1, 1, s, training ? b.a1_bits : nullptr, b.a1_q, b.qid_a1));
     MI355_TRY(conv_forward(c, b.c2, b.a1, training, s));
     MI355_TRY(bn_prepare(c, b.c2, training, bn_momentum, s));
-    MI355_TRY(bn_apply(c, b.c2, nullptr, nullptr, b.a2, 1, s, training ? b.a2_bits : nullptr));
+    MI355_TRY(bn_apply(c, b.c2, nullptr, nullptr, b.a2, 1, s, training ? b.a2_bits : nullptr, b.a2_q, b.qid_a2));
     MI355_TRY(conv_forward(c, b.c3, b.a2, training, s));
     MI355_TRY(bn_prepare(c, b.c3, training, bn_momentum, s));
     if (b.has_ds) {
       if (c->overlap) MI355_HIP(hipStreamWaitEvent(s, c->ds_done, 0));
-      MI355_TRY(bn_apply(c, b.c3, nullptr, &b.ds, b.out, 1, s, training ? b.out_bits : nullptr));
+      MI355_TRY(bn_apply(c, b.c3, nullptr, &b.ds, b.out, 1, s, training ? b.out_bits : nullptr, b.out_q, b.qid_out));
     } else {
-      MI355_TRY(bn_apply(c, b.c3, b.in, nullptr, b.out, 1, s, training ? b.out_bits : nullptr));
+      MI355_TRY(bn_apply(c, b.c3, b.in, nullptr, b.out, 1, s, training ? b.out_bits : nullptr, b.out_q, b.qid_out));
     }
   }
   const Block& last = c->blocks.back();
@@ -849,6 +981,7 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
     MI355_TRY(launch_bias_slice(c->fc_tmp, c->fc_pad, c->params + c->fc_b_off, logits, N, c->num_classes, s));
   }
   c->fwd_training_done = training != 0;
+  if (training) c->fp8_fwd_cal = true;
   c->next_seg = 0;
   return sk_snapshot(c, s);
 }
@@ -934,7 +1067,10 @@ int mi355_resnet50_backward(mi355_ctx* c, const float* dlogits, int seg_begin, i
     MI355_TRY(comm_join(c->comm, s));
     c->comm_dirty = false;
   }
-  if (c->next_seg == nseg) c->fwd_training_done = false;
+  if (c->next_seg == nseg) {
+    c->fwd_training_done = false;
+    c->fp8_bwd_cal = true;
+  }
   return sk_snapshot(c, s);
 }
 
@@ -952,7 +1088,22 @@ int mi355_resnet50_debug_tensor(const mi355_ctx* c, const char* name, void** ptr
     shape[0] = len; shape[1] = shape[2] = shape[3] = 0;
     return 0;
   };
+  auto setq = [&](const void* p, int d0, int d1, int d2, int d3) {  // e4m3 bytes
+    if (!p) return 1;
+    *ptr = const_cast<void*>(p); *dtype = MI355_FP8; *ndim = 4;
+    shape[0] = d0; shape[1] = d1; shape[2] = d2; shape[3] = d3;
+    return 0;
+  };
   auto conv_match = [&](const ConvBN& l) -> int {
+    if (c->fp8 && l.qid_w >= 0) {  // fp8 step: the operands the layer's convs read and their scales of the last step
+      if (n == l.conv_name + ".xq" && l.fp8_fwd) return setq(l.in_q, c->N, l.Hin, l.Win, l.Cin);
+      if (n == l.conv_name + ".wq") return setq(l.w_q, l.Cout, l.K, l.K, l.Cin);
+      if (n == l.conv_name + ".wtq") return setq(l.w_trq, l.Cin, l.K, l.K, l.Cout);
+      if (n == l.conv_name + ".sx" && l.fp8_fwd) return set1(c->q_scale + l.qid_in, 1);
+      if (n == l.conv_name + ".sw") return set1(c->q_scale + l.qid_w, 1);
+      if (n == l.conv_name + ".sdy" && l.fp8_dgrad) return set1(c->q_scale + l.qid_dy, 1);
+      if (n == l.conv_name + ".amax_w") return set1(reinterpret_cast<float*>(c->q_amax + l.qid_w), 1);
+    }
     if (n == l.conv_name + ".y") return set4(l.y, c->dtype, l.Hout, l.Wout, l.Cout);
     if (n == l.bn_name + ".save_mean") return set1(l.stat, l.Cout);
     if (n == l.bn_name + ".save_invstd") return set1(l.stat + l.Cout, l.Cout);
@@ -980,6 +1131,24 @@ int mi355_resnet50_debug_tensor(const mi355_ctx* c, const char* name, void** ptr
   return MI355_E_ARG;
 }
 
+int mi355_resnet50_fp8_state(const mi355_ctx* c, int* fwd_on, int* bwd_on, int* n_fwd_layers, int* n_dgrad_layers) {
+  MI355_ARG(c, "fp8_state: null ctx");
+  int nf = 0, nd = 0;
+  auto count = [&](const ConvBN& l) {
+    nf += l.fp8_fwd ? 1 : 0;
+    nd += l.fp8_dgrad ? 1 : 0;
+  };
+  for (const auto& b : c->blocks) {
+    count(b.c1); count(b.c2); count(b.c3);
+    if (b.has_ds) count(b.ds);
+  }
+  if (fwd_on) *fwd_on = c->fp8 && c->fp8_fwd_on;
+  if (bwd_on) *bwd_on = c->fp8 && c->fp8_bwd_on;
+  if (n_fwd_layers) *n_fwd_layers = nf;
+  if (n_dgrad_layers) *n_dgrad_layers = nd;
+  return 0;
+}
+
 int mi355_resnet50_flops(const mi355_ctx* c, double* fwd, double* train) {
   MI355_ARG(c, "flops: null ctx");
   if (fwd) *fwd = c->fwd_flops;
@@ -1005,7 +1174,7 @@ int mi355_resnet50_profile_read(mi355_ctx* c, int kind, double* total_ms, int* l
   double ms = 0, fl = 0, by = 0;
   int n = 0;
   for (size_t i = 0; i < c->recs.size(); ++i) {
-    const bool match = kind == 8 ? (c->recs[i].tag == 1 && c->recs[i].cls <= 1) : c->recs[i].cls == kind;
+    const bool match = kind == 8 ? ((c->recs[i].tag & 1) && c->recs[i].cls <= 1) : kind == 9 ? (c->recs[i].tag & 2) != 0 : c->recs[i].cls == kind;
     if (!match) continue;
     float t = 0;
     MI355_HIP(hipEventSynchronize(c->ev[2 * i + 1]));

@@ -5,6 +5,8 @@
 //   all conv layers of the network are prepared by ONE launch (weight_prep_batch_kernel, device-side layer table)
 // ~94 MB of reads per step for ResNet-50: HBM-trivial, and it keeps the master weights in the layout
 // torch's state_dict exposes (reference interchange: train.py:101,184).
+#include <hip/hip_fp8.h>
+
 #include "common.h"
 
 namespace mi355 {
@@ -52,6 +54,11 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const PrepDesc* 
   const float* w = params + d.w_off;
   T* w_cast = reinterpret_cast<T*>(d.w_cast);
   T* w_tr = reinterpret_cast<T*>(d.w_tr);
+  // fp8 step: e4m3 twins of the bf16 copies (same two layouts) under the layer's scale of this step, + the layer's amax
+  unsigned char* w_q = reinterpret_cast<unsigned char*>(d.w_q);
+  unsigned char* w_trq = reinterpret_cast<unsigned char*>(d.w_trq);
+  const float qs = w_q ? d.q_scale[0] : 1.f;
+  float amax = 0.f;
   const int tx = threadIdx.x & (PT - 1), ty = threadIdx.x / PT;
 #pragma unroll 4
   for (int r = ty; r < PT; r += 256 / PT) {
@@ -59,6 +66,11 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const PrepDesc* 
     const float v = w[src];
     tile[r][tx] = v;
     if (w_cast) w_cast[src] = (T)v;
+    if (w_q) {
+      const float rv = (float)(T)v;
+      amax = fmaxf(amax, fabsf(rv));
+      w_q[src] = __hip_cvt_float_to_fp8(rv * qs, __HIP_SATFINITE, __HIP_E4M3);
+    }
   }
   __syncthreads();
   if (w_tr) {
@@ -66,7 +78,13 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const PrepDesc* 
     for (int r = ty; r < PT; r += 256 / PT) {
       const size_t dst = ((size_t)(ci0 + r) * d.taps + t) * d.Cout + co0 + tx;
       w_tr[dst] = (T)tile[tx][r];
+      if (w_trq) w_trq[dst] = __hip_cvt_float_to_fp8((float)(T)tile[tx][r] * qs, __HIP_SATFINITE, __HIP_E4M3);
     }
+  }
+  if (w_q) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(d.q_amax, __float_as_uint(amax));
   }
 }
 

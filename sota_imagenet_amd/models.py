@@ -24,7 +24,10 @@ _DTYPES = {
     None: torch.float32, "fp32": torch.float32, "float32": torch.float32, "f32": torch.float32,
     "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
     torch.float32: torch.float32, torch.bfloat16: torch.bfloat16,
+    # BASELINE configs[4] "fp8 MFMA convs": bf16 tensors, e4m3 operand twins for the forward / dgrad convs of layers 2-4
+    "fp8": torch.bfloat16, "float8": torch.bfloat16, "e4m3": torch.bfloat16,
 }
+_FP8_NAMES = ("fp8", "float8", "e4m3")
 
 
 class _Leaf(nn.Module):
@@ -87,7 +90,8 @@ class ResNet50(nn.Module):
                 raise NotImplementedError(f"resnet50({k}={v!r}) is outside the MI355X hot path (SURVEY.md §8f)")
         self.num_classes = int(num_classes)
         self.compute_dtype = _DTYPES[dtype]
-        self._dt = native.dtype_code(self.compute_dtype)
+        self.fp8 = isinstance(dtype, str) and dtype in _FP8_NAMES
+        self._dt = native.FP8 if self.fp8 else native.dtype_code(self.compute_dtype)
         table, self._nparam, self._nbuf, self._segments = _layout(self._dt, 1, 32, 32, self.num_classes)
         self._table = table
         self._flat_params = torch.zeros(self._nparam, dtype=torch.float32)
@@ -377,7 +381,8 @@ class ResNet50(nn.Module):
         p, dt, nd, sh = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int(), (ctypes.c_int * 4)()
         check(L.mi355_resnet50_debug_tensor(self._ctx(*shape), name.encode(), ctypes.byref(p), ctypes.byref(dt), ctypes.byref(nd), sh))
         dims = [sh[i] for i in range(nd.value)]
-        out = torch.empty(dims, dtype=torch.float32 if dt.value == native.F32 else torch.bfloat16, device=self._flat_params.device)
+        tdt = {native.F32: torch.float32, native.BF16: torch.bfloat16, native.FP8: torch.uint8}[dt.value]  # FP8: raw e4m3 bytes
+        out = torch.empty(dims, dtype=tdt, device=self._flat_params.device)
         torch.cuda.synchronize()
         hip = ctypes.CDLL("libamdhip64.so")
         hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
@@ -385,6 +390,13 @@ class ResNet50(nn.Module):
         if rc != 0:
             raise RuntimeError(f"hipMemcpy failed ({rc})")
         return out
+
+    def fp8_state(self, shape):
+        """(forward twins in use, gradient twins in use, fp8 forward layers, fp8 dgrad layers) of the last training step at
+        batch shape (N,H,W) — mi355_resnet50_fp8_state"""
+        v = [ctypes.c_int() for _ in range(4)]
+        check(native.lib().mi355_resnet50_fp8_state(self._ctx(*shape), *[ctypes.byref(x) for x in v]))
+        return bool(v[0].value), bool(v[1].value), v[2].value, v[3].value
 
     # profiling passthrough (bench.py)
     def profile(self, shape, class_mask):

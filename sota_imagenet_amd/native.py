@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355RN_LIB") or os.path.join(_HERE, "lib", "libmi355rn.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mi355rn.h")
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 
 _BASE = {
     "void": None,

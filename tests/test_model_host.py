@@ -64,3 +64,15 @@ def test_cpu_forward_fails_loudly():
         m.eval()(torch.zeros(1, 3, 32, 32))
     with pytest.raises((RuntimeError, ValueError)):
         m.train()(torch.zeros(1, 3, 32, 32))
+
+
+def test_fp8_model_keeps_the_bf16_parameter_table():
+    """resnet50(dtype="fp8") (BASELINE configs[4]): a layout-only fp8 ctx plans its e4m3 twins without a GPU and exposes the same
+    flat parameter table, segments and FLOPs as the bf16 model (the twins are workspace, not parameters)."""
+    from sota_imagenet_amd.models import resnet50
+
+    a, b = resnet50(dtype="fp8"), resnet50(dtype="bf16")
+    assert a.fp8 and not b.fp8 and a.compute_dtype == b.compute_dtype
+    assert [(n, tuple(p.shape)) for n, p in a.named_parameters()] == [(n, tuple(p.shape)) for n, p in b.named_parameters()]
+    assert a.grad_segments == b.grad_segments and a.flops(256, 224, 224) == b.flops(256, 224, 224)
+    assert a.bucket_plan(32.0) == b.bucket_plan(32.0)

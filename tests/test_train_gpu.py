@@ -34,6 +34,22 @@ def test_train_py_runs_the_smoke_config(dev, tmp_path):
     assert loss2 == loss2 and 0.0 <= m2["Acc@1"].avg <= 100.0
 
 
+def test_train_py_runs_progressive_resize_with_fp8_convs(dev, tmp_path):
+    """BASELINE configs[4] end to end at toy size: two stages with different image sizes (a new native ctx + its own fp8
+    calibration step per shape), `model.dtype: fp8` from the YAML, through train.py / Runner / the stage manager."""
+    sys.path.insert(0, ROOT)
+    import train
+
+    logdir = os.path.relpath(str(tmp_path), ROOT)
+    val_loss, metrics = train.main(["+hydra_exp=progressive_fp8_test", f"log.dir={logdir}", "random_seed=0", "data.pool=2"])
+    assert val_loss == val_loss and 0.0 <= metrics["Acc@1"].avg <= 100.0
+    run = glob.glob(os.path.join(str(tmp_path), "*_progressive_fp8_test", "*"))[0]
+    logs = open(os.path.join(run, "logs.txt")).read()
+    assert logs.count("Train loss:") == 2 and "Model params: 25.56M" in logs
+    losses = [float(x) for x in __import__("re").findall(r"Train loss: ([0-9.]+)", logs)]
+    assert all(abs(l - 6.9) < 1.5 for l in losses), losses
+
+
 def test_legacy_config_and_wd_filter_param_groups(dev, tmp_path):
     """legacy flat schema + `filter_from_wd` (train.py:83-86): BN / bias parameters land in a wd-0 group and the fused
     optimizer must not touch them with weight decay."""
