@@ -451,20 +451,25 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
 void plan_fp8(mi355_ctx* c) {
   const char* only = getenv("MI355_FP8_LAYERS");
   int n = 0;
-  auto legal = [&](ConvBN& l) {
+  // Measured per layer at batch 256 / 224 px (profiles/r03a_conv_per_layer_fp8_vs_bf16.txt): the e4m3 form wins 4-10 us per launch
+  // wherever the reduction spans >= 2 of its 128-channel k-tiles, and loses 15-90 us on the output-heavy launches — the 128 -> 512
+  // 1x1 forward of layer 2 (ONE k-tile under a 512-column epilogue) and every conv1 dgrad (K = 128 ... 512 under the shortcut
+  // addend + BN-backward epilogue: the single workgroup per CU of the 8-wave kernel runs that epilogue with the matrix pipe idle,
+  // the same reason the bf16 rule keeps them on the 4-wave kernel).  Those stay bf16 and get no twins.
+  auto legal = [&](ConvBN& l, bool is_c1) {
     if (only && only[0] && l.conv_name.find(only) == std::string::npos) return;
     IgemmArgs a;
     build_fwd_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
-    l.fp8_fwd = igemm_fp8_legal(a, 1);
+    l.fp8_fwd = igemm_fp8_legal(a, 1) && l.Cin * l.K * l.K >= 256;
     const int nclass = build_dgrad_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
-    l.fp8_dgrad = nclass > 0 && igemm_fp8_legal(a, nclass);
+    l.fp8_dgrad = nclass > 0 && igemm_fp8_legal(a, nclass) && !is_c1;
     if (l.fp8_fwd || l.fp8_dgrad) l.qid_w = n++;
     if (l.fp8_dgrad) l.qid_dy = n++;
   };
   for (size_t i = 0; i < c->blocks.size(); ++i) {
     Block& b = c->blocks[i];
-    legal(b.c1); legal(b.c2); legal(b.c3);
-    if (b.has_ds) legal(b.ds);
+    legal(b.c1, true); legal(b.c2, false); legal(b.c3, false);
+    if (b.has_ds) legal(b.ds, false);
     if (i > 0 && (b.c1.fp8_fwd || (b.has_ds && b.ds.fp8_fwd))) {
       Block& prev = c->blocks[i - 1];
       prev.qid_out = n++;

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const PrepDesc* 
   if (w_q) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(d.q_amax, __float_as_uint(amax));
+    if ((threadIdx.x & 63) == 0 && amax > __uint_as_float(__atomic_load_n(d.q_amax, __ATOMIC_RELAXED))) atomicMax(d.q_amax, __float_as_uint(amax));
   }
 }
 
