@@ -15,6 +15,7 @@
 // second-branch variants are template parameters and last-use streams are loaded non-temporally.
 #include <hip/hip_fp8.h>
 
+#include "bn_fin.h"
 #include "common.h"
 #include "vec.h"
 
@@ -79,6 +80,7 @@ struct ReduceArgs {
   float* pivot;       // [C] (stats): per-channel shift = the channel's value in row 0
   int M, C;
   float slope;        // MASK == 1: gradient factor where the activation was <= 0 (0 ReLU, 0.01 leaky ReLU)
+  BnFinArgs fin;      // fin.mode != 0: the last-arriving workgroup of a channel slice also finalizes it (bn_fin.h)
 };
 
 // MODE 0: s1 = sum x, s2 = sum x^2.   MODE 1: s1 = sum dz, s2 = sum dz*xhat.
@@ -88,7 +90,7 @@ struct ReduceArgs {
 template <typename T, int MODE, int MASK, bool DZ>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
   constexpr int V = Vec16<T>::N;
-  __shared__ float red[2][256 * V];
+  __shared__ __attribute__((aligned(16))) float red[2][256 * V];
   const int tpr_full = p.C / V;
   const int tpr = tpr_full < 256 ? tpr_full : 256;
   const int rpp = 256 / tpr;
@@ -117,7 +119,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
     Vec16<T>::load(x + c0, mu);
     if (blockIdx.x == 0 && r == 0) {
 #pragma unroll
-      for (int e = 0; e < V; ++e) p.pivot[c0 + e] = mu[e];
+      for (int e = 0; e < V; ++e) {
+        if (p.fin.mode != 0) store_wt(p.pivot + c0 + e, mu[e]);  // (read by the finalizing workgroup, possibly behind another L2)
+        else p.pivot[c0 + e] = mu[e];
+      }
     }
   }
   const int step = gridDim.x * rpp;
@@ -191,10 +196,18 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
         b += red[1][(rr * tpr + tid) * V + e];
       }
       const int c = (blockIdx.y * tpr + tid) * V + e;
-      p.partial[((size_t)blockIdx.x * 2 + 0) * p.C + c] = a;
-      p.partial[((size_t)blockIdx.x * 2 + 1) * p.C + c] = b;
+      if (p.fin.mode != 0) {
+        store_wt(p.partial + ((size_t)blockIdx.x * 2 + 0) * p.C + c, a);
+        store_wt(p.partial + ((size_t)blockIdx.x * 2 + 1) * p.C + c, b);
+      } else {
+        p.partial[((size_t)blockIdx.x * 2 + 0) * p.C + c] = a;
+        p.partial[((size_t)blockIdx.x * 2 + 1) * p.C + c] = b;
+      }
     }
   }
+  if (p.fin.mode != 0)
+    bn_fin_last_arriver(p.fin, p.partial, (int)gridDim.x, p.C, (int)blockIdx.y, (int)gridDim.x, (int)blockIdx.y * tpr * V, tpr * V,
+                        reinterpret_cast<char*>(&red[0][0]), tid, 256);
 }
 
 // 16 channels x 16 slices of the block partials per workgroup; fp64 sums in fixed order.
@@ -466,9 +479,10 @@ int check_c(int dtype, int C) {
 int bn_max_blocks() { return 2 * MAXBLK; }  // conv-epilogue statistics use 2 partial rows per workgroup (<= 1024)
 
 int launch_bn_stats(int dtype, const void* x, float* partial, float* pivot, int* nblk_out, int M, int C,
-                    hipStream_t s) {
+                    hipStream_t s, const BnFinArgs* fin) {
   MI355_TRY(check_c(dtype, C));
   ReduceArgs a{};
+  if (fin) a.fin = *fin;
   a.x = x;
   a.partial = partial;
   a.pivot = pivot;
@@ -573,9 +587,10 @@ int launch_bn_apply(int dtype, const void* x, const float* scale, const float* s
 
 int launch_bn_bwd_reduce(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
                          const float* invstd, void* dz_out, float* partial, int* nblk_out, int M, int C,
-                         hipStream_t s, const uint8_t* relu_bits, float slope) {
+                         hipStream_t s, const uint8_t* relu_bits, float slope, const BnFinArgs* fin) {
   MI355_TRY(check_c(dtype, C));
   ReduceArgs a{};
+  if (fin) a.fin = *fin;
   a.slope = slope;
   a.x = x;
   a.g = g;

@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "bn_fin.h"
 #include "lds_dma.h"
 #include "vec.h"
 
@@ -85,6 +86,9 @@ struct IgemmKArgs {
   int sk_mute;              // debug (MI355_SK_DEBUG=mute): contributors never publish, so every owner times out
   int dbg;                  // timing probes (MI355_IGEMM_DBG): 1 = skip the epilogue, 2 = epilogue stores go to the trash page,
                             // 4 = the addend is read from one cached zero page (no HBM latency in the epilogue)
+  int xcd;                  // 1: workgroup b takes the item stream of virtual workgroup (b % 8) * (G / 8) + b / 8, so the workgroups
+                            // resident on ONE XCD (hardware round-robin: b % 8) walk CONSECUTIVE items — with one n-tile per item
+                            // the n-tiles of a row tile run side by side behind one L2 (launch_t says when)
 };
 
 // BM x BN tile, WMW x 2 waves (a wave owns BM/WMW x BN/2 outputs), NSTG-stage LDS ring:
@@ -172,9 +176,10 @@ __global__ __launch_bounds__(128 * WMW, (BM == 256 ? 1 : (BN == 64 && NSTG == 2 
       sk_k11 = __builtin_amdgcn_readfirstlane(sk_k11);
     }
   }
+  const int bx = __builtin_amdgcn_readfirstlane(kp.xcd ? (int)(blockIdx.x & 7u) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x);
   auto unit_at = [&](int seq, int& item, int& k0, int& k1) -> bool {
     if (!SKC || kp.sk_tail == 0) {
-      item = (int)blockIdx.x + seq * G;
+      item = bx + seq * G;
       k0 = 0;
       k1 = -1;
       return item < kp.items;
@@ -651,11 +656,12 @@ __global__ __launch_bounds__(128 * WMW, (BM == 256 ? 1 : (BN == 64 && NSTG == 2 
   if constexpr (STATS != 0) {
     // flush: partial[workgroup / ngroups][0|1][channel], the two wave rows added.  Every item of a workgroup has the
     // same n-tile group because gridDim.x is a multiple of ngroups, so the workgroup owns channels
-    // [grp*chan, (grp+1)*chan) and the ngroups workgroups blockIdx.x/ngroups == r fill row r completely.
+    // [grp*chan, (grp+1)*chan) and the ngroups workgroups bx/ngroups == r fill row r completely (bx: blockIdx.x or its XCD remap).
     MI355_LDS_BARRIER();
     const int chan = kp.ntpg * BN;
-    const int grp = blockIdx.x % kp.ngroups;
-    float* row = p.stat_partial + (size_t)(blockIdx.x / kp.ngroups) * 2 * p.Ncols + grp * chan;
+    const int grp = bx % kp.ngroups;
+    float* row = p.stat_partial + (size_t)(bx / kp.ngroups) * 2 * p.Ncols + grp * chan;
+    const bool fin = p.fin.mode != 0;  // uniform
     for (int c = tid; c < chan; c += NT) {
       float a = 0.f, b = 0.f;
 #pragma unroll
@@ -663,9 +669,16 @@ __global__ __launch_bounds__(128 * WMW, (BM == 256 ? 1 : (BN == 64 && NSTG == 2 
         a += stat_acc[(w * chan + c) * 2];
         b += stat_acc[(w * chan + c) * 2 + 1];
       }
-      row[c] = a;
-      row[p.Ncols + c] = b;
+      if (fin) {
+        store_wt(row + c, a);
+        store_wt(row + p.Ncols + c, b);
+      } else {
+        row[c] = a;
+        row[p.Ncols + c] = b;
+      }
     }
+    // the workgroup of this n-tile group that arrives last turns the group's rows into the BatchNorm coefficients (bn_fin.h)
+    if (fin) bn_fin_last_arriver(p.fin, p.stat_partial, G / kp.ngroups, p.Ncols, grp, G / kp.ngroups, grp * chan, chan, smem, tid, NT);
   }
 }
 
@@ -753,6 +766,20 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
       k.sk_flags = reinterpret_cast<unsigned*>(a.sk_ws);
       k.sk_partial = reinterpret_cast<float*>(reinterpret_cast<char*>(a.sk_ws) + IGEMM_SK_FLAG_BYTES);
     }
+  }
+  // Epilogues that read ReLU bit masks (1 byte per 16-byte vector, [pixel][Ncols / 8]: the shortcut addend's mask and the
+  // BN-backward mask of conv1's dgrad) touch 8 bytes of a 128-byte line per wave tile; with several n-tiles per item the line has
+  // left the L2 again before the next n-tile asks for it, and the other n-tile groups sit behind other XCDs' L2s: PMC shows the
+  // mask bytes fetched up to 16x (profiles/r03_pmc_mask_amplification.txt: 97 MB for a 6.4 MB mask).  One n-tile per item + the XCD
+  // remap puts all n-tiles of a row tile behind ONE L2 at the same time (and its A rows are fetched once instead of ng times):
+  // conv1's dgrad of layers 2-4 612 -> 366 MB and 112 -> 99 us (layer 3), 417 -> 226 MB and 84 -> 67 us (layer 4), 156 -> 146 us
+  // (layer 2); the 256-column launches of layer 1 (2 n-tiles) lose 8 us and keep the plain order.
+  static const int xcd_env = getenv("MI355_IGEMM_XCD") ? atoi(getenv("MI355_IGEMM_XCD")) : -1;  // A/B knob: 0 never, 1 wherever legal
+  k.xcd = 0;
+  if (sizeof(T) == 2 && !sk && BM == 128 && MAX_WG % 8 == 0 && (MAX_WG / 8) % k.ny == 0 && R * k.ny >= MAX_WG && k.ny >= 2 &&
+      (xcd_env < 0 ? (a.addend_bits != nullptr || a.bn_bits != nullptr) && a.Ncols >= 512 : xcd_env == 1)) {
+    ng = k.ny;
+    k.xcd = 1;
   }
   k.ngroups = ng;
   k.ntpg = k.ny / ng;

@@ -36,6 +36,7 @@
 #include <set>
 #include <type_traits>
 
+#include "bn_fin.h"
 #include "common.h"
 #include "lds_dma.h"
 #include "vec.h"
@@ -67,6 +68,8 @@ struct Igemm8KArgs {
   const float* sc_in;    // fp8 operands, executor path: per-tensor scales in device memory (the accumulators are multiplied
   const float* sc_wt;    // by oscale / (*sc_in * *sc_wt)); null: oscale alone
   int korder;            // 0: taps outer, channel chunks inner;  1: channel chunks outer, taps inner (A re-reads stay close)
+  int xcd;               // 1: workgroup b walks the items of virtual workgroup xcd_rank(b): the workgroups resident on one XCD
+                         // (hardware round-robin, b % 8) take CONSECUTIVE items = the n-tiles of the same row tiles
 };
 
 // -DMI355_STAMP8: cycle stamps of waves 0 and 4 of workgroup 0 (one of each wave row), 4 per phase, parked in LDS and
@@ -156,6 +159,9 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wn = wave & 3;
   const int G = gridDim.x;
+  // XCD-aware item order: virtual index = (workgroups on lower-numbered XCDs) + (rank among this XCD's workgroups)
+  const int bx = __builtin_amdgcn_readfirstlane(
+      kp.xcd ? (int)(blockIdx.x & 7u) * (G >> 3) + min((int)(blockIdx.x & 7u), G & 7) + (int)(blockIdx.x >> 3) : (int)blockIdx.x);
   const int Msub = p.N * p.Hsub * p.Wsub;
   const int kcpt = p.Ck / BK;  // k-tiles per tap
 
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
     for (;;) {
       // (the cursor is wave-uniform by construction; the readfirstlanes say so to hipcc, whose divergence analysis
       // otherwise turns the cursor into VGPR values under exec masks)
-      const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x + L_seq * G);
+      const int item = __builtin_amdgcn_readfirstlane(bx + L_seq * G);
       L_valid = item < kp.items;
       if (!L_valid) return;
       const int rowtile = item / kp.ngroups;
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
   bool after_epi = false;  // the epilogue's NST stores are younger than the groups the next k-tile's waits retire
 
   for (int seq = 0;; ++seq) {
-    const int item = (int)blockIdx.x + seq * G;
+    const int item = bx + seq * G;
     if (item >= kp.items) break;
     const int rowtile = item / kp.ngroups;
     const int grp = item - rowtile * kp.ngroups;
@@ -765,14 +771,22 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
   if constexpr (STATS != 0) {
     MI355_LDS_BARRIER();
     const int chan = kp.ntpg * BN;
-    const int grp = blockIdx.x % kp.ngroups;
-    float* row = p.stat_partial + (size_t)(blockIdx.x / kp.ngroups) * 2 * p.Ncols + grp * chan;
+    const int grp = bx % kp.ngroups;
+    float* row = p.stat_partial + (size_t)(bx / kp.ngroups) * 2 * p.Ncols + grp * chan;
+    const bool fin = p.fin.mode != 0;  // uniform
     for (int c = tid; c < chan; c += 512) {
       const float a = stat_acc[c * 2] + stat_acc[(chan + c) * 2];
       const float b = stat_acc[c * 2 + 1] + stat_acc[(chan + c) * 2 + 1];
-      row[c] = a;
-      row[p.Ncols + c] = b;
+      if (fin) {
+        store_wt(row + c, a);
+        store_wt(row + p.Ncols + c, b);
+      } else {
+        row[c] = a;
+        row[p.Ncols + c] = b;
+      }
     }
+    // the workgroup of this n-tile group that arrives last turns the group's rows into the BatchNorm coefficients (bn_fin.h)
+    if (fin) bn_fin_last_arriver(p.fin, p.stat_partial, G / kp.ngroups, p.Ncols, grp, G / kp.ngroups, grp * chan, chan, smem, tid, 512);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef MI355_STAMP8
@@ -801,6 +815,16 @@ int launch8_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
       ng = d;
       break;
     }
+  // MI355_IGEMM8_XCD (A/B knob, read once): 1 = one n-tile per item + XCD-aware item order wherever there are >= 2 n-tiles
+  static const int xcd_env = getenv("MI355_IGEMM8_XCD") ? atoi(getenv("MI355_IGEMM8_XCD")) : -1;
+  k.xcd = 0;
+  // measured per layer (profiles/r03f): neutral or +2...+12 us on the forward launches although their L2-side traffic drops
+  // (layer-3 conv3 270 -> 218 MB), -51 us on the stride-2 downsample dgrad of layer 4 (4 tap classes, 3 of them empty) and
+  // -6 us on layer 3's: on by default for multi-class launches only.
+  if ((xcd_env < 0 ? nclass > 1 : xcd_env == 1) && ny >= 2 && R * ny >= MAX_WG) {
+    ng = ny;
+    k.xcd = 1;
+  }
   k.ngroups = ng;
   k.ntpg = ny / ng;
   k.items = R * ng;

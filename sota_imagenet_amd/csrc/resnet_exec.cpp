@@ -51,6 +51,8 @@ struct ConvBN {
   int bwd_rows = 0;   // partial rows of THIS layer's BN-backward sums left in bn_partial by the dgrad that produced its
                       // activation gradient (0: none, bn_backward runs the standalone reduce kernel)
   bool is_stem = false;
+  bool fin_done = false;      // the launch that summed this layer's forward statistics also finalized them (bn_fin.h)
+  bool bwd_fin_done = false;  // ... and the same for its BN-backward sums
   // fp8 training step (ctx dtype MI355_FP8): forward / dgrad of this layer on e4m3 operands where the geometry allows it
   bool fp8_fwd = false, fp8_dgrad = false;
   void* w_q = nullptr;          // e4m3 [Cout][taps][Cin]
@@ -141,6 +143,9 @@ struct mi355_ctx {
   // weight-gradient side stream (wgrad + split-K reduce run beside the BN-backward / dgrad chain of the main stream)
   bool overlap = false;
   bool fuse_bn_bwd = false;  // BN-backward sums in the dgrad epilogues (MI355_FUSE_BN_BWD=0/1 overrides the default)
+  bool fuse_fin = false;     // BN finalize by the last-arriving workgroup of the summing launch (MI355_BN_FIN=1; measured slower: off)
+  unsigned* fin_counters = nullptr;   // 64 zero words per stream (main / side)
+  unsigned* fin_counters2 = nullptr;
   hipStream_t wstream = nullptr;
   std::vector<hipEvent_t> fork_ev;
   size_t fork_next = 0;
@@ -232,6 +237,29 @@ inline void* sk_ws_of(mi355_ctx* c, hipStream_t s) {
   return c->stream_k ? c->sk_ws[(c->wstream && s == c->wstream) ? 1 : 0] : nullptr;
 }
 inline float* bn_coef_of(mi355_ctx* c, hipStream_t s) { return (c->wstream && s == c->wstream) ? c->bn_coef2 : c->bn_coef; }
+inline unsigned* fin_counters_of(mi355_ctx* c, hipStream_t s) { return (c->wstream && s == c->wstream) ? c->fin_counters2 : c->fin_counters; }
+
+// finalize descriptors of a layer's BatchNorm for the launch that sums its statistics (forward) / its backward sums
+BnFinArgs fin_fwd(mi355_ctx* c, ConvBN& l, float momentum, hipStream_t s) {
+  BnFinArgs f;
+  if (!c->fuse_fin) return f;
+  const int C = l.Cout;
+  f.mode = 1; f.M = c->N * l.Hout * l.Wout; f.eps = BN_EPS; f.momentum = momentum;
+  f.gamma = c->params + l.gamma_off; f.beta = c->params + l.beta_off;
+  f.running_mean = c->buffers + l.rm_off; f.running_var = c->buffers + l.rv_off;
+  f.save_mean = l.stat; f.save_invstd = l.stat + C; f.scale = l.stat + 2 * C; f.shift = l.stat + 3 * C;
+  f.counters = fin_counters_of(c, s);
+  return f;
+}
+BnFinArgs fin_bwd(mi355_ctx* c, ConvBN& l, float beta_acc, hipStream_t s) {
+  BnFinArgs f;
+  if (!c->fuse_fin) return f;
+  f.mode = 2; f.M = c->N * l.Hout * l.Wout; f.beta_acc = beta_acc;
+  f.gamma = c->params + l.gamma_off; f.invstd = l.stat + l.Cout;
+  f.dgamma = c->grads + l.gamma_off; f.dbeta = c->grads + l.beta_off; f.coef = bn_coef_of(c, s);
+  f.counters = fin_counters_of(c, s);
+  return f;
+}
 
 double conv_flops(const mi355_ctx* c, const ConvBN& l) {
   return 2.0 * c->N * l.Hout * l.Wout * (double)l.Cout * l.Cin * l.K * l.K;
@@ -239,11 +267,13 @@ double conv_flops(const mi355_ctx* c, const ConvBN& l) {
 
 // conv forward; in training the epilogue also leaves the BN statistics partials of its output in c->bn_partial
 // (l.stat_rows > 0), unless the shape does not allow it (then bn_prepare runs the standalone statistics kernel)
-int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, hipStream_t s) {
+int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, float momentum, hipStream_t s) {
   IgemmArgs a;
   build_fwd_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
   a.in = in;
   a.stat_partial = training ? bn_partial_of(c, s) : nullptr;
+  if (training) a.fin = fin_fwd(c, l, momentum, s);
+  l.fin_done = false;
   a.sk_ws = sk_ws_of(c, s);
   a.wt = c->dtype == MI355_F32 ? (const void*)(c->params + l.w_off) : (const void*)l.w_cast;
   a.out = l.y;
@@ -254,9 +284,12 @@ int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, hipStrea
   if (q) {
     a.in = l.in_q; a.wt = l.w_q;
     a.q_scale_in = c->q_scale + l.qid_in; a.q_scale_wt = c->q_scale + l.qid_w;
-    return launch_igemm_fp8(a, 1, 1.f, s, &l.stat_rows);
+    MI355_TRY(launch_igemm_fp8(a, 1, 1.f, s, &l.stat_rows));
+  } else {
+    MI355_TRY(launch_igemm(c->dtype, a, 1, s, &l.stat_rows));
   }
-  return launch_igemm(c->dtype, a, 1, s, &l.stat_rows);
+  l.fin_done = a.fin.mode != 0 && l.stat_rows > 0;
+  return 0;
 }
 
 // BN statistics + finalize for one layer (training) or eval coefficients
@@ -269,11 +302,18 @@ int bn_prepare(mi355_ctx* c, ConvBN& l, int training, float momentum, hipStream_
   const float* gamma = c->params + l.gamma_off;
   const float* beta = c->params + l.beta_off;
   if (training) {
+    if (l.fin_done) {  // the conv launch finalized its own statistics
+      l.fin_done = false;
+      return 0;
+    }
     int nblk = l.stat_rows;
     const float* pivot = nullptr;  // conv-epilogue partials are plain sums
     if (nblk == 0) {
       Prof p(c, PC_BN_REDUCE, 0, (double)M * C * c->es, s);
-      MI355_TRY(launch_bn_stats(c->dtype, l.y, bn_partial_of(c, s), bn_coef_of(c, s), &nblk, M, C, s));
+      BnFinArgs f = fin_fwd(c, l, momentum, s);
+      f.pivot = bn_coef_of(c, s);
+      MI355_TRY(launch_bn_stats(c->dtype, l.y, bn_partial_of(c, s), bn_coef_of(c, s), &nblk, M, C, s, &f));
+      if (f.mode != 0) return 0;
       pivot = bn_coef_of(c, s);
     }
     return launch_bn_finalize(bn_partial_of(c, s), pivot, nblk, M, C, gamma, beta, c->buffers + l.rm_off, c->buffers + l.rv_off,
@@ -310,14 +350,19 @@ int bn_backward(mi355_ctx* c, ConvBN& l, const void* g, const uint8_t* bits, voi
   const int M = c->N * l.Hout * l.Wout, C = l.Cout;
   int nblk = l.bwd_rows;
   l.bwd_rows = 0;
+  bool fin_done = l.bwd_fin_done && nblk > 0 && !dz_out;  // the dgrad that summed also finalized (into this stream's coef block)
+  l.bwd_fin_done = false;
   const double mask_bytes = bits ? (double)M * C * c->es / 16 : 0.0;
   if (nblk == 0 || dz_out) {
     Prof p(c, PC_BN_REDUCE, 0, (double)M * C * c->es * (2 + (dz_out ? 1 : 0)) + mask_bytes, s);
+    BnFinArgs f = fin_bwd(c, l, beta_acc, s);
     MI355_TRY(launch_bn_bwd_reduce(c->dtype, g, nullptr, l.y, l.stat, l.stat + C, dz_out, bn_partial_of(c, s), &nblk, M, C, s,
-                                   bits));
+                                   bits, 0.f, &f));
+    fin_done = f.mode != 0;
   }
-  MI355_TRY(launch_bn_bwd_finalize(bn_partial_of(c, s), nblk, M, C, c->params + l.gamma_off, l.stat + C,
-                                   c->grads + l.gamma_off, c->grads + l.beta_off, beta_acc, bn_coef_of(c, s), s));
+  if (!fin_done)
+    MI355_TRY(launch_bn_bwd_finalize(bn_partial_of(c, s), nblk, M, C, c->params + l.gamma_off, l.stat + C,
+                                     c->grads + l.gamma_off, c->grads + l.beta_off, beta_acc, bn_coef_of(c, s), s));
   // after an in-place masked write-back the mask is already applied
   const uint8_t* bits2 = dz_out ? nullptr : bits;
   const void* g2 = dz_out ? dz_out : g;
@@ -346,7 +391,7 @@ int conv_wgrad(mi355_ctx* c, ConvBN& l, const void* dy, const void* x, float bet
 // gradient of — the epilogue then also leaves that layer's BN-backward sums in bn_partial (bn->bwd_rows), which saves
 // the standalone reduce pass over dx and bn->y.
 int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* addend, hipStream_t s,
-               const uint8_t* addend_bits = nullptr, ConvBN* bn = nullptr, const uint8_t* bn_bits = nullptr) {
+               const uint8_t* addend_bits = nullptr, ConvBN* bn = nullptr, const uint8_t* bn_bits = nullptr, float beta_acc = 0.f) {
   IgemmArgs a;
   const int nclass = build_dgrad_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
   if (nclass < 0) return nclass;
@@ -355,6 +400,8 @@ int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* ad
   if (bn && c->fuse_bn_bwd) {
     a.stat_partial = bn_partial_of(c, s);
     a.bn_y = bn->y; a.bn_bits = bn_bits; a.bn_mean = bn->stat; a.bn_invstd = bn->stat + bn->Cout;
+    a.fin = fin_bwd(c, *bn, beta_acc, s);
+    bn->bwd_fin_done = false;
   }
   const double dx_elems = (double)c->N * l.Hin * l.Win * l.Cin;
   void* dyq = c->fp8_bwd_on && l.fp8_dgrad ? grad_twin(c, dy) : nullptr;
@@ -366,9 +413,12 @@ int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* ad
   if (dyq) {
     a.in = dyq; a.wt = l.w_trq;
     a.q_scale_in = c->q_scale + l.qid_dy; a.q_scale_wt = c->q_scale + l.qid_w;
-    return launch_igemm_fp8(a, nclass, 1.f, s, rows);
+    MI355_TRY(launch_igemm_fp8(a, nclass, 1.f, s, rows));
+  } else {
+    MI355_TRY(launch_igemm(c->dtype, a, nclass, s, rows));
   }
-  return launch_igemm(c->dtype, a, nclass, s, rows);
+  if (rows && a.fin.mode != 0 && *rows > 0) bn->bwd_fin_done = true;
+  return 0;
 }
 
 int plan_arena(mi355_ctx* c, Arena& ar) {
@@ -430,6 +480,8 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
   ar.add((void**)&c->bn_partial, (size_t)bn_max_blocks() * 2 * max_c * 4);
   ar.add((void**)&c->bn_coef, (size_t)3 * max_c * 4);
   for (int i = 0; i < 2; ++i) ar.add(&c->sk_ws[i], igemm_sk_ws_bytes());
+  ar.add((void**)&c->fin_counters, 64 * 4);
+  ar.add((void**)&c->fin_counters2, 64 * 4);
   ar.add((void**)&c->bn_partial2, (size_t)bn_max_blocks() * 2 * max_c * 4);
   ar.add((void**)&c->bn_coef2, (size_t)3 * max_c * 4);
   ar.add((void**)&c->wg_partial, max_wg);
@@ -627,22 +679,22 @@ int backward_block(mi355_ctx* c, Block& b, Block* prev, float beta_acc, hipStrea
     if (c->overlap) MI355_HIP(hipEventRecord(c->ds_done, ws));
     MI355_TRY(conv_wgrad(c, b.ds, B2, b.in, beta_acc, ws));
   }
-  MI355_TRY(conv_dgrad(c, b.c3, B1, B3, nullptr, s, nullptr, &b.c2, b.a2_bits));  // B3 = da2 (+ bn2's sums)
+  MI355_TRY(conv_dgrad(c, b.c3, B1, B3, nullptr, s, nullptr, &b.c2, b.a2_bits, beta_acc));  // B3 = da2 (+ bn2's sums)
   MI355_TRY(bn_backward(c, b.c2, B3, b.a2_bits, nullptr, B3, beta_acc, s));  // B3 = dy2
   MI355_TRY(fork(c, s, &ws));
   MI355_TRY(conv_wgrad(c, b.c2, B3, b.a1, beta_acc, ws));
-  MI355_TRY(conv_dgrad(c, b.c2, B3, B4, nullptr, s, nullptr, &b.c1, b.a1_bits));  // B4 = da1 (+ bn1's sums)
+  MI355_TRY(conv_dgrad(c, b.c2, B3, B4, nullptr, s, nullptr, &b.c1, b.a1_bits, beta_acc));  // B4 = da1 (+ bn1's sums)
   MI355_TRY(bn_backward(c, b.c1, B4, b.a1_bits, nullptr, B4, beta_acc, s));  // B4 = dy1
   MI355_TRY(fork(c, s, &ws));
   MI355_TRY(conv_wgrad(c, b.c1, B4, b.in, beta_acc, ws));
   if (b.has_ds) {
     if (c->overlap) MI355_HIP(hipStreamWaitEvent(s, c->ds_done, 0));
     // Gn = dx_in = conv1 dgrad + shortcut gradient (+ the sums of the previous block's bn3)
-    MI355_TRY(conv_dgrad(c, b.c1, B4, Gn, Gn, s, nullptr, prev ? &prev->c3 : nullptr, prev ? prev->out_bits : nullptr));
+    MI355_TRY(conv_dgrad(c, b.c1, B4, Gn, Gn, s, nullptr, prev ? &prev->c3 : nullptr, prev ? prev->out_bits : nullptr, beta_acc));
     c->cur_dout = Gn;
   } else {
     // G = dx_in = conv1 dgrad + masked G (+ the sums of the previous block's bn3)
-    MI355_TRY(conv_dgrad(c, b.c1, B4, G, G, s, b.out_bits, prev ? &prev->c3 : nullptr, prev ? prev->out_bits : nullptr));
+    MI355_TRY(conv_dgrad(c, b.c1, B4, G, G, s, b.out_bits, prev ? &prev->c3 : nullptr, prev ? prev->out_bits : nullptr, beta_acc));
     c->cur_dout = G;
   }
   return release_set(c, par);
@@ -840,6 +892,11 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
   const char* fb = getenv("MI355_FUSE_BN_BWD");
   // measured same-box: -0.6 ms/step in bf16, +0.9 ms in fp32 (the fp32 epilogue is already register-heavy)
   c->fuse_bn_bwd = fb ? fb[0] != '0' : dtype == MI355_BF16;
+  // measured (profiles/README.md, round 3): 20.4 -> 33.3 ms/step with it on.  ONE workgroup reads 0.25-2 MB of partial rows (behind an
+  // L2 invalidate) per BatchNorm while the other 255 CUs have drained — a serial tail of ~100 us x 106 where the separate launch
+  // spreads the same reads over C/4 workgroups in 7 us.  Kept behind MI355_BN_FIN=1 as the record of that experiment.
+  const char* ff = getenv("MI355_BN_FIN");
+  c->fuse_fin = ff && ff[0] == '1';
   const char* ov = getenv("MI355_WGRAD_STREAM");
   c->overlap = !(ov && ov[0] == '0');
   if (c->overlap) {
@@ -944,8 +1001,10 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
     build_stem_fwd_args(a, N, c->H, c->W);
     a.in = c->xpad; a.wt = c->stem_pack; a.out = c->stem.y;
     a.stat_partial = training ? c->bn_partial : nullptr;
+    if (training) a.fin = fin_fwd(c, c->stem, bn_momentum, s);
     Prof p(c, PC_IGEMM64, conv_flops(c, c->stem), 0, s);
     MI355_TRY(launch_igemm(c->dtype, a, 1, s, &c->stem.stat_rows));
+    c->stem.fin_done = a.fin.mode != 0 && c->stem.stat_rows > 0;
   }
   MI355_TRY(bn_prepare(c, c->stem, training, bn_momentum, s));
   {
@@ -959,17 +1018,17 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
     if (b.has_ds) {  // the downsample conv + its statistics run beside conv1..conv3
       hipStream_t ws;
       MI355_TRY(fork(c, s, &ws));
-      MI355_TRY(conv_forward(c, b.ds, b.in, training, ws));
+      MI355_TRY(conv_forward(c, b.ds, b.in, training, bn_momentum, ws));
       MI355_TRY(bn_prepare(c, b.ds, training, bn_momentum, ws));
       if (c->overlap) MI355_HIP(hipEventRecord(c->ds_done, ws));
     }
-    MI355_TRY(conv_forward(c, b.c1, b.in, training, s));
+    MI355_TRY(conv_forward(c, b.c1, b.in, training, bn_momentum, s));
     MI355_TRY(bn_prepare(c, b.c1, training, bn_momentum, s));
     MI355_TRY(bn_apply(c, b.c1, nullptr, nullptr, b.a1, 1, s, training ? b.a1_bits : nullptr, b.a1_q, b.qid_a1));
-    MI355_TRY(conv_forward(c, b.c2, b.a1, training, s));
+    MI355_TRY(conv_forward(c, b.c2, b.a1, training, bn_momentum, s));
     MI355_TRY(bn_prepare(c, b.c2, training, bn_momentum, s));
     MI355_TRY(bn_apply(c, b.c2, nullptr, nullptr, b.a2, 1, s, training ? b.a2_bits : nullptr, b.a2_q, b.qid_a2));
-    MI355_TRY(conv_forward(c, b.c3, b.a2, training, s));
+    MI355_TRY(conv_forward(c, b.c3, b.a2, training, bn_momentum, s));
     MI355_TRY(bn_prepare(c, b.c3, training, bn_momentum, s));
     if (b.has_ds) {
       if (c->overlap) MI355_HIP(hipStreamWaitEvent(s, c->ds_done, 0));
