@@ -1,0 +1,514 @@
+// conv3x3.hip — bf16 3x3 / stride-1 convolution (forward and data gradient) with 64 channels on both sides, as a DIRECT convolution
+// for gfx950 (MI355X): the layer-1 3x3 convs of ResNet-50 (cuDNN conv fwd / dgrad under `model(data)` / `loss.backward()`,
+// sota_imagenet/callbacks.py:316-317).  Same contract as conv_igemm.hip (IgemmArgs: tap table, BN statistics / BN-backward sums in
+// the epilogue, optional addend); launch_igemm() routes the launches that fit here.
+//
+// Why a second kernel: with 64 output columns one wave's tile spans all of N, so an implicit-GEMM kernel re-stages the gathered
+// pixel rows for each of the 9 taps and reads 9 x (A fragment + B fragment) from LDS per k-chunk — the 4-wave igemm runs these
+// layers at 0.45-0.56 PF/s, bound by the staging pieces and the LDS port.  Here
+//   * the image tile (TH output rows + 2 halo rows, every row padded to WP >= W + 2 pixels with zeros) sits in LDS ONCE, all
+//     9 x 64 x 64 weights sit in LDS for the lifetime of the persistent workgroup; nothing is re-staged per tap;
+//   * the tile is addressed as a FLAT pixel list (row pitch WP): tap (dh, dw) of output position q is position q + dh*WP + dw, so
+//     a 16-pixel MFMA operand fragment of tap (dh, -1) / (dh, +1) is the fragment of tap (dh, 0) moved by ONE LANE.  It is fetched
+//     from LDS once per (dh, 32-channel chunk) and the two horizontal neighbours are made in registers by DPP row shifts (lane 15 /
+//     lane 0 patched from the adjacent fragment): 3 instead of 9 operand fetches.  The zero padding columns make every shift
+//     correct without masks; the outputs computed AT padding columns are garbage and are dropped by the epilogue (WP/W - 1 = 3.6 %
+//     of the MFMAs at 56 px);
+//   * 4 waves (one per SIMD), each 8 fragments (128 pixels) x 64 channels = 32 accumulator tiles of v_mfma_f32_16x16x32_bf16
+//     (operands swapped, D^T = W * A^T: a lane ends with 4 consecutive channels of one pixel); per (dh, chunk) a wave reads 9 pixel
+//     fragments + 12 weight fragments for 96 MFMAs — 56 B/clk/CU of LDS reads against 128 available;
+//   * the NEXT tile is prefetched global -> registers (19 x 16 bytes per lane, out-of-image chunks through the buffer range check
+//     = zeros) while the current one is computed, and written to LDS between two barriers: the loads have a whole tile of MFMAs
+//     to land, and the single LDS image is never read and written at the same time;
+//   * persistent workgroups walk tiles in an XCD-aware order (the workgroups behind one L2 take consecutive tiles: the halo rows
+//     two neighbouring tiles share are fetched once).
+// Epilogue from the accumulators: the weight rows sit in LDS in a permuted order that makes a lane's two accumulator tiles 8
+// CONSECUTIVE channels of one pixel (one 16-byte store, no exchange between lanes); BN statistics (STATS 1) / BN-backward sums
+// (STATS 2) by DPP row sums into a per-workgroup LDS accumulator, one partial row per workgroup, no atomics.
+//
+// STATUS (round 3): bit-exact against the implicit-GEMM kernel on integer data for forward, dgrad and dgrad + addend on ten shapes
+// (tools/conv3_check.py exact) — and NOT faster: 111 us against 118 us per layer-1 launch from cold caches (batch 256, 56 x 56).
+// Timing probes (-DMI355_PROBES, MI355_CONV3_DBG): MFMA loop 39 us (5.6 us per tile against 3.8 at the matrix rate), epilogue 17,
+// tile prefetch + LDS write 14, launch + weights + first tile 20 + the rest — and these ADD: with 150 KB of LDS there is one
+// workgroup of one wave per SIMD on a CU, every wave of the chip is in the same phase at the same time, so HBM idles while the
+// matrix pipes run and vice versa, where the 128 x 64 implicit-GEMM tile keeps three independent workgroups per CU out of step.
+// launch_igemm() therefore uses it only under MI355_CONV3=1.  What it would take: two tiles in flight per CU (the LDS for that
+// needs the weights out of LDS: B operand from registers / AGPRs), or the epilogue and the next tile's staging woven into the
+// MFMA gaps by hand.
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+#include <set>
+#include <type_traits>
+
+#include "common.h"
+#include "lds_dma.h"
+#include "vec.h"
+
+namespace mi355 {
+namespace {
+
+constexpr int C3 = 64;             // channels on both sides
+constexpr int MT3 = 8, NT3 = 4;    // 16-pixel fragments per wave, 16-channel tiles per wave
+constexpr int W_BYTES = 9 * C3 * 128;  // weights in LDS: [tap (dh+1)*3 + (dw+1)][cout][128 B, chunks swizzled]
+
+__device__ __attribute__((aligned(256))) unsigned char g3_trash[256 * 16];
+
+struct Conv3KArgs {
+  IgemmArgs a;
+  int TH, WP, F;            // output rows per tile, padded row pitch (pixels), 16-pixel fragments per tile (TH * WP / 16)
+  int tiles_per_img, tiles;
+  int npix;                 // pixels of the LDS image: (TH + 2) * WP + 2
+  int npix_alloc;           // ... allocated: the 4 x 128 positions the waves always compute, + halo (reads behind the tile stay in LDS)
+  unsigned bytes_in, bytes_wt;
+  unsigned magWP;           // floor(2^32 / WP) + 1 (exact quotients for the < 2^16 positions of a tile)
+  int wtap[9];              // weight tap index of (dh + 1) * 3 + (dw + 1)
+  int dbg;                  // MI355_PROBES builds (MI355_CONV3_DBG): 1 skip the MFMA loop, 2 skip the epilogue, 4 no prefetch / commit after the first tile
+};
+#ifdef MI355_PROBES
+#define C3_PROBE(bit) ((kp.dbg & (bit)) != 0)
+#else
+#define C3_PROBE(bit) false
+#endif
+
+void lds_opt_in3(const void* fn) {
+  static std::mutex mu;
+  static std::set<const void*> done;
+  std::lock_guard<std::mutex> g(mu);
+  if (done.count(fn)) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  done.insert(fn);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float row_shr_add3(float x) {
+  const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true);
+  return x + __int_as_float(y);
+}
+__device__ __forceinline__ float row_sum16_3(float x) {  // lane 15 of every 16-lane row ends with the row's sum (fixed order)
+  x = row_shr_add3<0x111>(x);
+  x = row_shr_add3<0x112>(x);
+  x = row_shr_add3<0x114>(x);
+  x = row_shr_add3<0x118>(x);
+  return x;
+}
+
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+
+// fragment moved one lane DOWN the 16-lane rows (lane r takes lane r + 1; lane 15 takes lane 0 of `next`): the operand of tap dw = +1
+__device__ __forceinline__ bf16x8 shift_next(bf16x8 cur, bf16x8 next) {
+  const i32x4v c = __builtin_bit_cast(i32x4v, cur), n = __builtin_bit_cast(i32x4v, next);
+  i32x4v r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = __builtin_amdgcn_update_dpp(0, n[i], 0x11F, 0xf, 0xf, true);      // row_shr:15 — lane 15 <- next lane 0 (others: 0, overwritten)
+    r[i] = __builtin_amdgcn_update_dpp(t, c[i], 0x101, 0xf, 0xf, false);            // row_shl:1  — lanes 0..14 <- cur lane + 1
+  }
+  return __builtin_bit_cast(bf16x8, r);
+}
+// ... one lane UP (lane r takes lane r - 1; lane 0 takes lane 15 of `prev`): the operand of tap dw = -1
+__device__ __forceinline__ bf16x8 shift_prev(bf16x8 cur, bf16x8 prev) {
+  const i32x4v c = __builtin_bit_cast(i32x4v, cur), p = __builtin_bit_cast(i32x4v, prev);
+  i32x4v r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = __builtin_amdgcn_update_dpp(0, p[i], 0x10F, 0xf, 0xf, true);      // row_shl:15 — lane 0 <- prev lane 15 (others: 0, overwritten)
+    r[i] = __builtin_amdgcn_update_dpp(t, c[i], 0x111, 0xf, 0xf, false);            // row_shr:1  — lanes 1..15 <- cur lane - 1
+  }
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int STATS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3_kernel(const Conv3KArgs kp) {
+  const IgemmArgs& p = kp.a;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_w = smem;
+  char* lds_x = smem + W_BYTES;
+  const int x_bytes = kp.npix_alloc * 128;
+  float* stat_acc = reinterpret_cast<float*>(smem + W_BYTES + ((x_bytes + 255) & ~255));  // [4 waves][64 channels][2]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = gridDim.x;
+  const int bx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7u) * (G >> 3) + min((int)(blockIdx.x & 7u), G & 7) + (int)(blockIdx.x >> 3));
+  const int H = p.Hin, W = p.Win, WP = kp.WP;
+  // raw buffer resources: 32-bit byte offsets, out-of-range reads return zeros (the zero padding of the tile comes from there)
+  const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt), 0, (int)kp.bytes_wt, 0x00020000);
+
+  // ---- weights: once per workgroup.  LDS row = tap * 64 + cout (128 bytes = 64 input channels), 16-byte chunk index XORed with
+  //      (row >> 1) & 7 — the 16 rows a fragment read touches then cover all banks once (as in conv_igemm8.hip)
+  {
+    constexpr int NCH = 9 * C3 * 8;  // 16-byte chunks
+    for (int j = tid; j < NCH; j += 256) {
+      const int row = j >> 3, ch = j & 7;
+      // row r of a tap = 16-row tile t = r / 16, row i = r % 16 of it.  A lane of the accumulator tile holds rows 4*(lane / 16) ... + 3:
+      // with output channel 32*(t / 2) + 8*(i / 4) + 4*(t % 2) + i % 4 in row r, the tiles 2n and 2n + 1 of a lane together are the 8
+      // CONSECUTIVE channels 32n + 8*(lane / 16) ... + 7 of its pixel — one 16-byte store, no exchange between lanes
+      const int tap = row >> 6, r = row & 63;
+      const int co = 32 * (r >> 5) + 8 * ((r & 15) >> 2) + 4 * ((r >> 4) & 1) + (r & 3);
+      const unsigned src = (unsigned)((co * p.wtaps + kp.wtap[tap]) * (C3 * 2) + ch * 16);
+      const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srdW, src, 0, 0));
+      *reinterpret_cast<uint4*>(lds_w + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = v;
+    }
+  }
+  if constexpr (STATS != 0) {
+    for (int i = tid; i < 4 * C3 * 2; i += 256) stat_acc[i] = 0.f;
+  }
+
+  // ---- tile prefetch: chunk j = tid + 256 * i of the LDS image (position pp = j / 8, channel chunk j % 8).  Which image pixel a
+  //      chunk holds relative to the tile's first output row is the same for every tile: source offset (relative to the image) and
+  //      LDS address are computed once; rows above / below the image fall out of the per-image buffer range (zeros), padding
+  //      columns get an offset that stays out of range for every tile
+  constexpr int NPF = 19;  // ceil(582 * 8 / 256) for the 56 px tile; the launcher guarantees npix * 8 <= NPF * 256
+  uint4 pf[NPF];
+  const unsigned img_bytes = (unsigned)(H * W * C3 * 2);
+  // chunk i of this thread is position pp0 + 32 * i, channel chunk tid & 7: (pp >> 1) & 7 does not depend on i, so its LDS address
+  // is lds_c0 + 4096 * i
+  const int pp0 = tid >> 3, pch = tid & 7;
+  char* const lds_c0 = lds_x + pp0 * 128 + ((pch ^ ((pp0 >> 1) & 7)) << 4);
+  auto prefetch = [&](int tile) __attribute__((always_inline)) {
+    const int n = tile / kp.tiles_per_img;
+    const int r0 = (tile - n * kp.tiles_per_img) * kp.TH;  // first output row of the tile
+    // per-image resource: offsets of rows -1 and H wrap / exceed num_records and read zeros
+    const __amdgpu_buffer_rsrc_t srdI = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.in) + (size_t)n * img_bytes), 0, (int)img_bytes, 0x00020000);
+    const int base = ((r0 - 1) * W - 1) * (C3 * 2) + pch * 16;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int q = pp0 + 32 * i - 1;  // position pp = 1 + rr * WP + cc: image row r0 - 1 + rr, image column cc - 1
+      const int rr = (int)__umulhi((unsigned)(q < 0 ? 0 : q), kp.magWP);
+      const int cc = q - rr * WP;
+      const bool col_ok = q >= 0 && cc >= 1 && cc <= W;  // (positions >= npix only feed dropped outputs: whatever they load)
+      pf[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srdI, col_ok ? base + (rr * W + cc) * (C3 * 2) : 0x40000000, 0, 0));
+    }
+  };
+  auto commit = [&]() __attribute__((always_inline)) {  // registers -> LDS image
+#pragma unroll
+    for (int i = 0; i < NPF; ++i)
+      if (pp0 + 32 * i < kp.npix) *reinterpret_cast<uint4*>(lds_c0 + 4096 * i) = pf[i];
+  };
+
+  int tile = bx;
+  if (tile < kp.tiles) {
+    prefetch(tile);
+    commit();
+  }
+  __syncthreads();
+
+  const int px = lane & 15, q4 = lane >> 4;
+  // output pixel of this lane's position in fragment mt, relative to the tile's first output row (the same for every tile); -1: a
+  // padding column or a position behind the tile
+  int orel[MT3];
+#pragma unroll
+  for (int mt = 0; mt < MT3; ++mt) {
+    const int q = (wave * MT3 + mt) * 16 + px;
+    const int rr = (int)__umulhi((unsigned)q, kp.magWP);
+    const int cc = q - rr * WP;
+    orel[mt] = (rr < kp.TH && cc >= 1 && cc <= W) ? rr * W + cc - 1 : -1;
+  }
+  bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
+  const bf16_t* addend = reinterpret_cast<const bf16_t*>(p.addend);
+  // every wave always computes MT3 fragments: those behind the tile's last position read whatever the (over-allocated) LDS image
+  // holds there and are dropped by the epilogue — a wave-uniform fragment count would put a branch around every MFMA group
+
+  for (; tile < kp.tiles; tile += G) {
+    const int next = tile + G;
+    if (next < kp.tiles && !C3_PROBE(4)) prefetch(next);  // lands under this tile's MFMAs
+
+    f32x4 acc[MT3][NT3];
+#pragma unroll
+    for (int mt = 0; mt < MT3; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT3; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (!C3_PROBE(1)) {
+      // 6 trips (kc, dh) of 3 taps x 32 MFMAs.  One wave per SIMD has nobody to hide its LDS latency behind, so the reads are
+      // software-pipelined: the pixel fragments + the first tap's weight fragments of trip it + 1 are issued under the last tap's
+      // MFMAs of trip it (two register sets, the loop is unrolled by two), the weight fragments of taps 1 and 2 under the tap
+      // before them.  lgkmcnt is in order and every wait is for the OLDEST outstanding reads.
+      auto load_A = [&](bf16x8(&A)[MT3 + 1], int it) __attribute__((always_inline)) {
+        const int kc = it >= 3 ? 1 : 0, dhi = it - 3 * kc;
+        // this wave's 128 positions of tap row dh: LDS position 1 + WP + wave*128 + (dhi - 1) * WP + mt*16 + px
+        const int pbase = 1 + WP + wave * (MT3 * 16) + (dhi - 1) * WP;
+#pragma unroll
+        for (int mt = 0; mt < MT3; ++mt) {
+          const int pp = pbase + mt * 16 + px;
+          A[mt] = *reinterpret_cast<const bf16x8*>(lds_x + pp * 128 + (((kc * 4 + q4) ^ ((pp >> 1) & 7)) << 4));
+        }
+        // lane 15 of a row: the position just before the wave's range; lane 0: the one just behind it
+        const int pe = px == 15 ? pbase - 1 : pbase + MT3 * 16;
+        A[MT3] = *reinterpret_cast<const bf16x8*>(lds_x + pe * 128 + (((kc * 4 + q4) ^ ((pe >> 1) & 7)) << 4));
+      };
+      auto load_B = [&](bf16x8(&B)[NT3], int it, int dwi) __attribute__((always_inline)) {
+        const int kc = it >= 3 ? 1 : 0, dhi = it - 3 * kc;
+        const int tap = dhi * 3 + dwi;
+#pragma unroll
+        for (int nt = 0; nt < NT3; ++nt) {
+          const int row = tap * C3 + nt * 16 + px;
+          B[nt] = *reinterpret_cast<const bf16x8*>(lds_w + row * 128 + (((kc * 4 + q4) ^ ((row >> 1) & 7)) << 4));
+        }
+      };
+      auto mma_tap = [&](const bf16x8(&A)[MT3 + 1], const bf16x8(&B)[NT3], auto dwc) __attribute__((always_inline)) {
+        constexpr int dwi = decltype(dwc)::value;
+#pragma unroll
+        for (int mt = 0; mt < MT3; ++mt) {
+          bf16x8 av;
+          if constexpr (dwi == 1) {
+            av = A[mt];
+          } else if constexpr (dwi == 2) {
+            av = shift_next(A[mt], A[mt + 1]);  // (A[MT3]: lane 0 holds the position behind the wave's range)
+          } else {
+            av = shift_prev(A[mt], mt > 0 ? A[mt > 0 ? mt - 1 : 0] : A[MT3]);
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT3; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[nt], av, acc[mt][nt], 0, 0, 0);
+        }
+      };
+      auto trip = [&](bf16x8(&A)[MT3 + 1], bf16x8(&B0)[NT3], bf16x8(&An)[MT3 + 1], bf16x8(&B0n)[NT3], int it) __attribute__((always_inline)) {
+        bf16x8 B1[NT3], B2[NT3];
+        load_B(B1, it, 1);
+        mma_tap(A, B0, std::integral_constant<int, 0>{});
+        load_B(B2, it, 2);
+        mma_tap(A, B1, std::integral_constant<int, 1>{});
+        if (it + 1 < 6) {
+          load_A(An, it + 1);
+          load_B(B0n, it + 1, 0);
+        }
+        mma_tap(A, B2, std::integral_constant<int, 2>{});
+      };
+      bf16x8 Aa[MT3 + 1], Ab[MT3 + 1], Ba[NT3], Bb[NT3];
+      load_A(Aa, 0);
+      load_B(Ba, 0, 0);
+#pragma unroll 1
+      for (int it = 0; it < 6; it += 2) {
+        trip(Aa, Ba, Ab, Bb, it);
+        trip(Ab, Bb, Aa, Ba, it + 1);
+      }
+    }
+
+    // The next tile goes into LDS BEFORE this tile's epilogue: its loads landed under the MFMAs, and the epilogue's stores then
+    // retire under the next tile's MFMAs (a commit behind the epilogue would sit in `s_waitcnt vmcnt(0)` until every store has
+    // reached memory: stores count in vmcnt)
+    __syncthreads();  // every wave has finished reading the LDS image of this tile
+    if (next < kp.tiles && !C3_PROBE(4)) commit();
+    __syncthreads();
+
+    // ---- epilogue (registers only; the LDS image is not touched) ---------------------------------------------------------
+    if (!C3_PROBE(2)) {
+      const int n_img = tile / kp.tiles_per_img;
+      const int r0 = (tile - n_img * kp.tiles_per_img) * kp.TH;
+      const int tile_pix0 = (n_img * H + r0) * W;
+      const int cb = q4 * 8;  // this lane's 8 channels inside a pair of 16-row tiles (weight rows are permuted accordingly)
+#pragma unroll
+      for (int ntp = 0; ntp < NT3 / 2; ++ntp) {
+        const int c0 = ntp * 32 + cb;
+        float s1[8], s2[8], bmu[8], bis[8];
+        if constexpr (STATS == 2) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.bn_mean + c0 + 4 * h);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.bn_invstd + c0 + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              bmu[4 * h + e] = a[e];
+              bis[4 * h + e] = b[e];
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+        constexpr int MB = 4;
+#pragma unroll
+        for (int mb = 0; mb < MT3; mb += MB) {
+          int pixs[MB];
+          uint4 araw[MB], yraw[MB];
+          unsigned abits[MB], ybits[MB];
+#pragma unroll
+          for (int u = 0; u < MB; ++u) {
+            const int mt = mb + u;
+            const int pix = orel[mt] < 0 ? -1 : tile_pix0 + orel[mt];
+            pixs[u] = pix;
+            const size_t o = (size_t)(pix < 0 ? 0 : pix) * C3 + c0;
+            if (addend) {
+              araw[u] = *reinterpret_cast<const uint4*>(addend + o);
+              abits[u] = p.addend_bits ? (unsigned)p.addend_bits[o / 8] : 0xffu;
+            }
+            if constexpr (STATS == 2) {
+              yraw[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bn_y) + o);
+              ybits[u] = (unsigned)p.bn_bits[o / 8];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < MB; ++u) {
+            const int mt = mb + u;
+            const f32x4 a = acc[mt][2 * ntp], b = acc[mt][2 * ntp + 1];
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = a[e];
+              v[4 + e] = b[e];
+            }
+            const int pix = pixs[u];
+            if (addend) {
+              float ad[8];
+              Vec16<bf16_t>::unpack(araw[u], ad);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (pix >= 0 && ((abits[u] >> e) & 1u)) ? ad[e] : 0.f;
+            }
+            const size_t o = (size_t)(pix < 0 ? 0 : pix) * C3 + c0;
+            bf16_t* dst = pix < 0 ? reinterpret_cast<bf16_t*>(g3_trash + tid * 16) : out + o;
+            Vec16<bf16_t>::store(dst, v);
+            if constexpr (STATS == 1) {
+              if (pix >= 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const float xr = (float)(bf16_t)v[e];
+                  s1[e] += xr;
+                  s2[e] += xr * xr;
+                }
+              }
+            }
+            if constexpr (STATS == 2) {
+              if (pix >= 0) {
+                float yv[8];
+                Vec16<bf16_t>::unpack(yraw[u], yv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const float dz = (ybits[u] >> e) & 1u ? (float)(bf16_t)v[e] : 0.f;
+                  s1[e] += dz;
+                  s2[e] += dz * ((yv[e] - bmu[e]) * bis[e]);
+                }
+              }
+            }
+          }
+        }
+        if constexpr (STATS != 0) {
+          float* slot = stat_acc + (wave * C3 + c0) * 2;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float a = row_sum16_3(s1[e]);
+            const float b = row_sum16_3(s2[e]);
+            if (px == 15) {
+              slot[2 * e] += a;
+              slot[2 * e + 1] += b;
+            }
+          }
+        }
+      }
+    }
+
+  }
+
+  if constexpr (STATS != 0) {
+    __syncthreads();
+    float* row = p.stat_partial + (size_t)bx * 2 * C3;
+    for (int c = tid; c < C3; c += 256) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {  // the waves, in order
+        a += stat_acc[(w * C3 + c) * 2];
+        b += stat_acc[(w * C3 + c) * 2 + 1];
+      }
+      row[c] = a;
+      row[C3 + c] = b;
+    }
+  }
+}
+
+unsigned magic32_3(unsigned d) { return (unsigned)((1ull << 32) / d + 1); }
+
+// tile geometry: TH | H rows, row pitch WP >= W + 2 with TH * WP a multiple of 16, at most 32 fragments, the LDS image within
+// the prefetch registers (19 x 256 chunks) — the smallest padded area per output pixel wins
+bool plan_conv3(int H, int W, int* TH, int* WP) {
+  double best = 1e30;
+  for (int th = 1; th <= H; ++th) {
+    if (H % th) continue;
+    for (int wp = W + 2; wp < W + 2 + 16; ++wp) {
+      if ((th * wp) % 16) continue;
+      const int F = th * wp / 16;
+      const int npix = (th + 2) * wp + 2;
+      const int alloc = npix > 4 * MT3 * 16 + 2 * wp + 2 ? npix : 4 * MT3 * 16 + 2 * wp + 2;
+      if (F > 4 * MT3 || npix * 8 > 19 * 256 || (size_t)W_BYTES + (size_t)alloc * 128 + 256 + 4 * C3 * 2 * 4 > 160 * 1024) continue;
+      // cost per useful output pixel: the CU is busy for min(8, F) fragment-steps of its 4 waves per tile, plus the staged bytes
+      const double cost = (double)(F > MT3 ? MT3 : F) * 64.0 / (th * W) + 0.15 * (double)npix / (th * W);
+      if (cost < best) {
+        best = cost;
+        *TH = th;
+        *WP = wp;
+      }
+    }
+  }
+  return best < 1e29;
+}
+
+}  // namespace
+
+// true when launch_conv3 can run this launch: bf16 3x3 stride-1 (forward or stride-1 dgrad), 64 channels in and out
+bool conv3_legal(const IgemmArgs& a, int nclass) {
+  if (nclass != 1 || a.Ck != C3 || a.Ncols != C3 || a.pix_stride != C3 || a.pair_delta != 0 || a.IS != 1 || a.OS != 1) return false;
+  if (a.Hsub != a.Hin || a.Wsub != a.Win || a.Hout != a.Hin || a.Wout != a.Win || a.cls[0].ntaps != 9 || a.wtaps != 9) return false;
+  unsigned seen = 0;
+  for (int t = 0; t < 9; ++t) {
+    const Tap& tp = a.cls[0].taps[t];
+    if (tp.dh < -1 || tp.dh > 1 || tp.dw < -1 || tp.dw > 1 || tp.wtap < 0 || tp.wtap >= 9) return false;
+    seen |= 1u << ((tp.dh + 1) * 3 + tp.dw + 1);
+  }
+  if (seen != 0x1ffu) return false;
+  if ((unsigned long long)a.N * a.Hin * a.Win * C3 * 2 >= 0x80000000ull) return false;
+  int th, wp;
+  return plan_conv3(a.Hin, a.Win, &th, &wp);
+}
+
+int launch_conv3(const IgemmArgs& a, hipStream_t stream, int* stat_rows) {
+  MI355_ARG(conv3_legal(a, 1), "conv3: unsupported geometry");
+  Conv3KArgs k;
+  k.a = a;
+  MI355_ARG(plan_conv3(a.Hin, a.Win, &k.TH, &k.WP), "conv3: no tile for %d x %d", a.Hin, a.Win);
+  k.F = k.TH * k.WP / 16;
+  k.tiles_per_img = a.Hin / k.TH;
+  k.tiles = a.N * k.tiles_per_img;
+  k.npix = (k.TH + 2) * k.WP + 2;
+  k.npix_alloc = std::max(k.npix, 4 * MT3 * 16 + 2 * k.WP + 2);
+  k.bytes_in = (unsigned)((size_t)a.N * a.Hin * a.Win * C3 * 2);
+  k.bytes_wt = (unsigned)((size_t)C3 * 9 * C3 * 2);
+  k.magWP = magic32_3((unsigned)k.WP);
+  k.dbg = 0;
+#ifdef MI355_PROBES
+  k.dbg = probe_env("MI355_CONV3_DBG");
+#endif
+  for (int t = 0; t < 9; ++t) {
+    const Tap& tp = a.cls[0].taps[t];
+    k.wtap[(tp.dh + 1) * 3 + tp.dw + 1] = tp.wtap;
+  }
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    static int cached_cus[64] = {0};
+    if (dev >= 0 && dev < 64) {
+      if (!cached_cus[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cached_cus[dev] = v;
+      }
+      if (cached_cus[dev]) cus = cached_cus[dev];
+    }
+  }
+  const int grid = k.tiles < cus ? k.tiles : cus;  // one persistent workgroup per CU (150 KB of LDS)
+  const size_t lds = (size_t)W_BYTES + (((size_t)k.npix_alloc * 128 + 255) & ~(size_t)255) + 4 * C3 * 2 * sizeof(float);
+  MI355_ARG(lds <= 160 * 1024, "conv3: %zu bytes of LDS", lds);
+  const bool stats = a.stat_partial != nullptr;
+  if (stat_rows) *stat_rows = stats ? grid : 0;
+  if (stats && a.bn_y) {
+    lds_opt_in3((const void*)conv3_kernel<2>);
+    hipLaunchKernelGGL(conv3_kernel<2>, dim3(grid), dim3(256), lds, stream, k);
+  } else if (stats) {
+    lds_opt_in3((const void*)conv3_kernel<1>);
+    hipLaunchKernelGGL(conv3_kernel<1>, dim3(grid), dim3(256), lds, stream, k);
+  } else {
+    lds_opt_in3((const void*)conv3_kernel<0>);
+    hipLaunchKernelGGL(conv3_kernel<0>, dim3(grid), dim3(256), lds, stream, k);
+  }
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace mi355

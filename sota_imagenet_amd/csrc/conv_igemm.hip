@@ -817,6 +817,10 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
 
 size_t igemm_sk_ws_bytes() { return IGEMM_SK_FLAG_BYTES + (size_t)512 * 128 * 128 * sizeof(float); }
 
+// conv3x3.hip: direct 3x3 / stride-1 convolution with 64 channels on both sides (layer 1)
+bool conv3_legal(const IgemmArgs& a, int nclass);
+int launch_conv3(const IgemmArgs& a, hipStream_t stream, int* stat_rows);
+
 // conv_igemm8.hip
 bool igemm8_legal(const IgemmArgs& a, int nclass, int bn);
 int launch_igemm8(const IgemmArgs& a, int nclass, int bm, int bn, int korder, int fat, hipStream_t stream, int* stat_rows);
@@ -888,6 +892,12 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
   if (dtype == MI355_F32)
     return wide ? launch_t<float, 128, 128>(a, nclass, stream, stat_rows) : launch_t<float, 128, 64>(a, nclass, stream, stat_rows);
   if (dtype == MI355_BF16) {
+    {
+      // MI355_CONV3=1: the layer-1 3x3 launches on the direct-convolution kernel (conv3x3.hip).  Bit-exact, and measured no faster
+      // than the 3-workgroups-per-CU implicit-GEMM tile (111 vs 118 us per launch from cold caches, profiles/README.md): off by default.
+      const char* c3 = getenv("MI355_CONV3");
+      if (c3 && c3[0] == '1' && conv3_legal(a, nclass)) return launch_conv3(a, stream, stat_rows);
+    }
     {
       int bm8 = 0, bn8 = 0, ko8 = 0, fat8 = 0;
       if (choose_igemm8(a, nclass, &bm8, &bn8, &ko8, &fat8)) return launch_igemm8(a, nclass, bm8, bn8, ko8, fat8, stream, stat_rows);
