@@ -19,6 +19,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 void set_error(const char* fmt, ...);
+int device_cus();  // compute units of the current device (256 when none is visible): persistent grids = device_cus() x workgroups per CU
 // value of a timing-probe environment variable (MI355_*_DBG), 0 when unset; the first non-zero read of each variable prints one
 // line to stderr: with a probe active the kernels skip loads / stores and their RESULTS ARE WRONG (tools/probe8.py only)
 int probe_env(const char* name);

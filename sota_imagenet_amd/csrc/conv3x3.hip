@@ -481,17 +481,7 @@ int launch_conv3(const IgemmArgs& a, hipStream_t stream, int* stat_rows) {
     const Tap& tp = a.cls[0].taps[t];
     k.wtap[(tp.dh + 1) * 3 + tp.dw + 1] = tp.wtap;
   }
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    static int cached_cus[64] = {0};
-    if (dev >= 0 && dev < 64) {
-      if (!cached_cus[dev]) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cached_cus[dev] = v;
-      }
-      if (cached_cus[dev]) cus = cached_cus[dev];
-    }
-  }
+  const int cus = device_cus();
   const int grid = k.tiles < cus ? k.tiles : cus;  // one persistent workgroup per CU (150 KB of LDS)
   const size_t lds = (size_t)W_BYTES + (((size_t)k.npix_alloc * 128 + 255) & ~(size_t)255) + 4 * C3 * 2 * sizeof(float);
   MI355_ARG(lds <= 160 * 1024, "conv3: %zu bytes of LDS", lds);

@@ -35,6 +35,20 @@ int probe_env(const char* name) {
   return x;
 }
 
+// compute units of the current device (hipDeviceProp), the unit every persistent-grid size in this library is a multiple of;
+// 256 (MI355X) while no device is visible — layout-only contexts plan on a GPU-less host
+int device_cus() {
+  static int cached[64] = {0};
+  int n = 0, dev = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 256;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cached[dev]) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cached[dev] = v;
+  }
+  return cached[dev] ? cached[dev] : 256;
+}
+
 static int out_dim(int H, int K, int s, int p) { return (H + 2 * p - K) / s + 1; }
 
 void build_fwd_args(IgemmArgs& a, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {

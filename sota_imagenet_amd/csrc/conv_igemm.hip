@@ -696,7 +696,7 @@ void lds_opt_in(const void* fn, size_t lds) {
 template <typename T, int BM, int BN, int WMW = 2, int NSTG = 2>
 int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
   constexpr int NT = 128 * WMW;
-  constexpr int MAX_WG = BM == 256 ? 256 : (BN == 64 && NSTG == 2 ? 768 : 512);  // persistent workgroups: 1, 3 or 2 per CU
+  const int MAX_WG = device_cus() * (BM == 256 ? 1 : (BN == 64 && NSTG == 2 ? 3 : 2));  // persistent workgroups: 1, 3 or 2 per CU
   IgemmKArgs k;
   k.a = a;
   const int Msub = a.N * a.Hsub * a.Wsub;
@@ -861,14 +861,15 @@ static bool choose_igemm8(const IgemmArgs& a, int nclass, int* bm, int* bn, int*
   const int ko = (max_taps > 1 && a.Ck > 64) ? 1 : 0;
   if (a.Ncols % 256 == 0 && K >= 256 && !heavy_epilogue && igemm8_legal(a, nclass, 256)) {
     const long tiles = ((M + 223) / 224) * nclass * (a.Ncols / 256);
-    if (tiles >= 180 && !(nclass > 1 && tiles > 512 && max_taps > 1)) {
+    const int cus = device_cus();  // thresholds measured on 256 CUs, kept as fractions of the chip (0.7 of a round; two rounds)
+    if (tiles * 10 >= 7L * cus && !(nclass > 1 && tiles > 2L * cus && max_taps > 1)) {
       *bm = 224; *bn = 256; *korder = ko; *fat = 0;
       return true;
     }
   }
   if (a.Ncols % 128 == 0 && K >= 4096 && igemm8_legal(a, nclass, 128)) {
     const long tiles = ((M + 255) / 256) * nclass * (a.Ncols / 128);
-    if (tiles >= 180 && tiles <= 256) {
+    if (tiles * 10 >= 7L * device_cus() && tiles <= device_cus()) {
       *bm = 256; *bn = 128; *korder = ko; *fat = 1;
       return true;
     }
@@ -888,7 +889,7 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
   // the workgroups
   const long tiles128 = (long)cdiv(a.N * a.Hsub * a.Wsub, 128) * nclass * (a.Ncols / 128);
   static const int narrow_env = getenv("MI355_IGEMM_NARROW") ? atoi(getenv("MI355_IGEMM_NARROW")) : 0;  // A/B knob
-  const bool wide = (a.Ncols % 128 == 0) && tiles128 >= 128 && !narrow_env;
+  const bool wide = (a.Ncols % 128 == 0) && tiles128 * 2 >= device_cus() && !narrow_env;
   if (dtype == MI355_F32)
     return wide ? launch_t<float, 128, 128>(a, nclass, stream, stat_rows) : launch_t<float, 128, 64>(a, nclass, stream, stat_rows);
   if (dtype == MI355_BF16) {
@@ -912,14 +913,15 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
     int max_taps = 0;
     for (int ci = 0; ci < nclass; ++ci) max_taps = a.cls[ci].ntaps > max_taps ? a.cls[ci].ntaps : max_taps;
     // (not with the BN-backward sums: that epilogue needs more registers than the 256 x 256 tile leaves)
-    const bool big = a.Ncols % 256 == 0 && (big_mode < 0 ? (items256 >= 192 && max_taps * a.Ck >= 256 && !a.bn_y) : big_mode == 1);
+    const int cus = device_cus();
+    const bool big = a.Ncols % 256 == 0 && (big_mode < 0 ? (items256 * 4 >= 3L * cus && max_taps * a.Ck >= 256 && !a.bn_y) : big_mode == 1);
     if (big) return launch_t<bf16_t, 256, 256>(a, nclass, stream, stat_rows);
     // 256 x 128, 8 waves, 3-stage ring: per CU and k-step 8 % faster than two 128 x 128 workgroups (the slab wait drops
     // from ~700 to ~200 cycles), but a partial round costs it a full one where the 2-workgroup form speeds up when a CU
     // holds a single workgroup — so only where all its tiles fit into one round, and the reduction is long
     const long items3 = (long)cdiv(a.N * a.Hsub * a.Wsub, 256) * nclass * (a.Ncols / 128);
     const bool tall = a.Ncols % 128 == 0 &&
-                      (big_mode < 0 ? ((items3 <= 256 && items3 >= 128 && max_taps * a.Ck >= 512) || (items3 <= 512 && max_taps == 1 && a.Ck >= 1024)) : big_mode == 3);
+                      (big_mode < 0 ? ((items3 <= cus && items3 * 2 >= cus && max_taps * a.Ck >= 512) || (items3 <= 2L * cus && max_taps == 1 && a.Ck >= 1024)) : big_mode == 3);
     if (tall) return launch_t<bf16_t, 256, 128, 4, 3>(a, nclass, stream, stat_rows);
     return wide ? launch_t<bf16_t, 128, 128>(a, nclass, stream, stat_rows) : launch_t<bf16_t, 128, 64>(a, nclass, stream, stat_rows);
   }

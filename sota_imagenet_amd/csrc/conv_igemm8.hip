@@ -802,7 +802,7 @@ template <int BM, int BN, int FAT, int EB = 2>
 int launch8_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows, int korder, float oscale = 1.f) {
   static_assert(EB == 2 || EB == 1, "EB");
   constexpr int NSTG = BN == 256 ? 2 : 3;
-  constexpr int MAX_WG = 256;
+  const int MAX_WG = device_cus();  // one persistent workgroup per CU
   Igemm8KArgs k;
   k.a = a;
   const int Msub = a.N * a.Hsub * a.Wsub;

@@ -27,7 +27,7 @@ namespace mi355 {
 
 namespace {
 
-constexpr int MAX_WG = 512;
+#define MAX_WG (2 * device_cus())  // persistent workgroups: 2 per CU
 
 struct FastDiv {
   uint32_t mul, sh;

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* x, unsigned 
 int pick_tile(const IgemmArgs& a, int nclass, int* bm, int* bn) {
   // the wide tile when it alone fills most of the 256 CUs (same threshold as the bf16 rule, conv_igemm.hip::choose_igemm8)
   const long long M = (long long)a.N * a.Hsub * a.Wsub;
-  if (a.Ncols % 256 == 0 && ((M + 223) / 224) * nclass * (a.Ncols / 256) >= 180) { *bm = 224; *bn = 256; return 0; }
+  if (a.Ncols % 256 == 0 && ((M + 223) / 224) * nclass * (a.Ncols / 256) * 10 >= 7LL * device_cus()) { *bm = 224; *bn = 256; return 0; }
   if (a.Ncols % 128 == 0) { *bm = 256; *bn = 128; return 0; }
   set_error("conv fp8: %d output columns (a multiple of 128 is needed)", a.Ncols);
   return MI355_E_ARG;

@@ -47,7 +47,8 @@ def test_train_py_runs_progressive_resize_with_fp8_convs(dev, tmp_path):
     logs = open(os.path.join(run, "logs.txt")).read()
     assert logs.count("Train loss:") == 2 and "Model params: 25.56M" in logs
     losses = [float(x) for x in __import__("re").findall(r"Train loss: ([0-9.]+)", logs)]
-    assert all(abs(l - 6.9) < 1.5 for l in losses), losses
+    # (data.pool=2: the two synthetic batches repeat, so the fp8 step memorises them — the loss must FALL, from about ln 1000)
+    assert len(losses) == 2 and losses[1] < losses[0] < 7.5 and losses[1] > 0.5, losses
 
 
 def test_legacy_config_and_wd_filter_param_groups(dev, tmp_path):

@@ -12,7 +12,10 @@ from sota_imagenet_amd.optim import SGD  # noqa: E402
 from sota_imagenet_amd.synth import synthetic_batch  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-N, S = 256, 224
+# N S from the environment: at a small batch (HOST_N=16) the GPU outruns the host, the launch queue never fills and the host loop time
+# IS the unblocked enqueue cost of a step; at 256 x 224 some calls block on a full queue
+import os
+N, S = int(os.environ.get("HOST_N", 256)), int(os.environ.get("HOST_S", 224))
 model = resnet50(dtype="bf16").cuda()
 crit = CrossEntropyLoss(smoothing=0.1).cuda()
 opt = SGD([{"params": list(model.parameters())}], lr=0.001, momentum=0.9, weight_decay=3e-5)
