@@ -6,20 +6,21 @@ d = sys.argv[1]
 f = (glob.glob(d + "/*/*_kernel_trace.csv") + glob.glob(d + "/*_kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))  # valid for single-stream runs (MI355_WGRAD_STREAM=0)
-conv = [r for r in rows if "igemm_kernel" in r["Kernel_Name"] or "igemm8_kernel" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"]]
+conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("igemm_kernel", "igemm8_kernel", "wgrad_kernel", "conv3_kernel"))]
 # expected launch sequence of one training step (see csrc/resnet_exec.cpp)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 224  # image size
 seq = []  # (kind, name, flops)
 def fl(Ho, Cin, Cout, K): return 2.0 * N * Ho * Ho * Cout * Cin * K * K
 blocks = []
-h, cin = 56, 64
+h, cin = S // 4, 64
 for st, (nb, p) in enumerate(zip((3, 4, 6, 3), (64, 128, 256, 512))):
     for i in range(nb):
         s = 2 if (i == 0 and st > 0) else 1
         ho = h // s
         blocks.append((f"l{st+1}.{i}", h, ho, cin, p, s, i == 0))
         h, cin = ho, 4 * p
-seq.append(("igemm", "stem", fl(112, 3, 64, 7)))
+seq.append(("igemm", "stem", fl(S // 2, 3, 64, 7)))
 for name, hin, ho, ci, p, s, ds in blocks:
     if ds: seq.append(("igemm", name + ".ds", fl(ho, ci, 4 * p, 1)))
     seq += [("igemm", name + ".c1", fl(hin, ci, p, 1)), ("igemm", name + ".c2", fl(ho, p, p, 3)), ("igemm", name + ".c3", fl(ho, p, 4 * p, 1))]
@@ -31,12 +32,12 @@ for name, hin, ho, ci, p, s, ds in reversed(blocks):
     seq += [("igemm", name + ".c3.d", fl(ho, p, 4 * p, 1)),
             ("wgrad", name + ".c2.w", fl(ho, p, p, 3)), ("igemm", name + ".c2.d", fl(ho, p, p, 3)),
             ("wgrad", name + ".c1.w", fl(hin, ci, p, 1)), ("igemm", name + ".c1.d", fl(hin, ci, p, 1))]
-seq.append(("wgrad", "stem.w", fl(112, 3, 64, 7)))
+seq.append(("wgrad", "stem.w", fl(S // 2, 3, 64, 7)))
 n = len(seq)
 last = conv[-n:]
 tot = 0
 for (kind, name, flops), r in zip(seq, last):
-    assert kind in r["Kernel_Name"], (kind, name, r["Kernel_Name"][:60])
+    assert kind in r["Kernel_Name"] or (kind == "igemm" and "conv3_kernel" in r["Kernel_Name"]), (kind, name, r["Kernel_Name"][:60])
     us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     tot += us
     grid = (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
