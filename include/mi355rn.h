@@ -124,6 +124,11 @@ int mi355_conv2d_fwd_fp8(const void* xq, const void* wq, void* y, float oscale, 
                          int KH, int KW, int stride, int pad, void* stream);
 int mi355_conv2d_dgrad_fp8(const void* dyq, const void* wtq, void* dx, float oscale, int N, int H, int W, int Cin,
                            int Cout, int KH, int KW, int stride, int pad, void* stream);
+/* dw fp32 KRSC = beta * dw + oscale * sum_pixels dyq (x) xq over e4m3 operands (v_mfma_f32_32x32x16_fp8_fp8; both operands are read
+ * TRANSPOSED out of LDS with ds_read_b64_tr_b8 — the reduction index, the pixel, is the slow index of both NHWC tensors).
+ * ws: mi355_conv2d_workspace_bytes(MI355_BF16, ...) + 256 bytes.                                                                   */
+int mi355_conv2d_wgrad_fp8(const void* dyq, const void* xq, float* dw, float beta, float oscale, int N, int H, int W, int Cin,
+                           int Cout, int KH, int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 
 /* the 7x7/2 stem on the loader's NCHW fp32 batch: ingest (NCHW fp32 -> zero-padded NHWC4 `dtype`),
  * forward y[N,H/2,W/2,64], and wgrad dw[64,7,7,3] fp32.  xpad is scratch of

@@ -325,7 +325,7 @@ struct ApplyArgs {
 
 // RES: + residual;  X2: + second normalised tensor (downsample branch);  RELU: 0 none, 1 relu, 2 relu + bit mask out
 // Q (bf16 only): also the e4m3 twin of the output + its amax (fp8 training step)
-template <typename T, bool RES, bool X2, int RELU, bool Q = false>
+template <typename T, bool RES, bool X2, int RELU, bool Q = false, bool QONLY = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
   constexpr int V = Vec16<T>::N;
   static_assert(!Q || V == 8, "the quantised twin exists for bf16 tensors");
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
 #pragma unroll
       for (int e = 0; e < V; ++e) v[e] = v[e] > 0.f ? v[e] : (RELU == 1 ? v[e] * p.slope : 0.f);  // (bit-mask form: ReLU only)
     }
-    Vec16<T>::store(out + i * V, v);
+    if constexpr (!QONLY) Vec16<T>::store(out + i * V, v);
     if constexpr (Q) quant8(v, qs, p.qo.q + i * V, amax);
   }
   if constexpr (Q) amax_flush(amax, p.qo.amax);
@@ -400,7 +400,7 @@ struct BwdApplyArgs {
   QuantOut qo;  // Q: e4m3 twin of dx
 };
 
-template <typename T, int MASK, bool Q = false>
+template <typename T, int MASK, bool Q = false, bool QONLY = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p) {
   constexpr int V = Vec16<T>::N;
   static_assert(!Q || V == 8, "the quantised twin exists for bf16 tensors");
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p)
       const float xh = (xv[e] - mu[e]) * is[e];
       gv[e] = k0[e] * (gv[e] - k1[e] - xh * k2[e]);
     }
-    Vec16<T>::store(dx + i * V, gv);
+    if constexpr (!QONLY) Vec16<T>::store(dx + i * V, gv);
     if constexpr (Q) quant8(gv, qs, p.qo.q + i * V, amax);
   }
   if constexpr (Q) amax_flush(amax, p.qo.amax);
@@ -556,6 +556,7 @@ int launch_bn_apply(int dtype, const void* x, const float* scale, const float* s
     MI355_ARG(dtype == MI355_BF16 && relu == 1 && relu_bits && qo.scale && qo.amax && !(residual && x2), "bn_apply: the e4m3 twin needs bf16 + ReLU bit mask");
     if (residual) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true, false, 2, true>), dim3(blocks), dim3(256), 0, s, a);
     else if (x2) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false, true, 2, true>), dim3(blocks), dim3(256), 0, s, a);
+    else if (qo.only) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false, false, 2, true, true>), dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false, false, 2, true>), dim3(blocks), dim3(256), 0, s, a);
     MI355_LAUNCH_CHECK();
     return 0;
@@ -666,7 +667,9 @@ int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const vo
   a.qo = qo;
   if (qo.q) {
     MI355_ARG(dtype == MI355_BF16 && mask != 1 && qo.scale && qo.amax, "bn_bwd_apply: the e4m3 twin needs bf16 and a bit mask (or none)");
-    if (mask == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 2, true>), dim3(blocks), dim3(256), 0, s, a);
+    if (mask == 2 && qo.only) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 2, true, true>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mask == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 2, true>), dim3(blocks), dim3(256), 0, s, a);
+    else if (qo.only) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0, true, true>), dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0, true>), dim3(blocks), dim3(256), 0, s, a);
     MI355_LAUNCH_CHECK();
     return 0;

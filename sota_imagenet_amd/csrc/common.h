@@ -151,8 +151,9 @@ int launch_igemm_fp8(const IgemmArgs& a, int nclass, float oscale, hipStream_t s
 int plan_wgrad_splits(int dtype, int M, int Cout, int ntaps, int Ck);
 int launch_wgrad(int dtype, const WgradArgs& a, int splits, hipStream_t stream);
 // dst[i] = beta*dst[i] + sum_s partial[s][i], i < n  (n multiple of 4); deterministic order
+// sa / sb (optional device scalars, fp8 wgrad): the sum is multiplied by 1 / (*sa * *sb) before beta * dst is added
 int launch_splitk_reduce(const float* partial, int splits, size_t stride, float* dst, size_t n, float beta,
-                         hipStream_t stream);
+                         hipStream_t stream, const float* sa = nullptr, const float* sb = nullptr);
 // stem unpack: dw[64][7][7][3] = beta*dw + sum_s partial[s][co][kh>>1][(kh&1)*32 + kw*4+c]
 int launch_stem_unpack(float* partial, int splits, float* dw, float beta, hipStream_t stream);  // reduces `partial` in place
 
@@ -209,6 +210,7 @@ struct QuantOut {
   uint8_t* q = nullptr;
   const float* scale = nullptr;
   unsigned* amax = nullptr;
+  bool only = false;  // every consumer of the tensor reads the twin: the bf16 tensor itself is not written
 };
 int launch_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
                     const void* x2, const float* scale2, const float* shift2, void* out, int M, int C, int relu,

@@ -11,6 +11,10 @@
 //   bf16 : ds_read_b64_tr_b16 x2 per v_mfma_f32_32x32x16_bf16 operand; the LDS image stays lane-linear and the four
 //          pixel rows a half-wave touches are spread over all 64 banks by XOR-ing the 16-byte chunk index with
 //          (row&3)<<2 (256-byte rows) / ((row>>1)&1)<<2 (128-byte rows) on the SOURCE address and on the read.
+//   fp8  : (e4m3 twins of dy and x, fp8 training step) ONE ds_read_b64_tr_b8 per v_mfma_f32_32x32x16_fp8_fp8 operand: per
+//          16-lane group the instruction reads a block of 8 rows x 16 byte-columns, lane 2q + p supplies the address of row q,
+//          columns 8p .. 8p+7, lane i receives column i of the 8 rows (tools/micro/tr8_test.hip pins that on the device); the
+//          8 rows x 32 bytes a half-wave touches cover the 64 banks once with the chunk index XORed by ((row>>1)&3)<<1.
 // Tile: BMC (128|64) output channels x BNC (128|64) input channels of TPI taps (1; 3 or 4 for the 64x64 tiles of the
 // small-channel layers, where one staged dy slab then feeds TPI x slabs: the 64x64 single-tap tile is fetch-bound),
 // 4 waves (2x2), swapped MFMA operands
@@ -54,12 +58,16 @@ struct WgradKArgs {
 };
 
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+typedef int v2i32 __attribute__((ext_vector_type(2)));
+typedef v2i32 __attribute__((address_space(3))) * lds_v2i32_ptr;
+typedef unsigned char fp8_t;  // e4m3 operand bytes (ES == 1)
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 // XOR applied to the 16-byte chunk index of a staged row (bf16 only; fp32 reads are conflict-free as they are)
 template <int ES, int ROW_BYTES>
 __device__ __forceinline__ int row_swz(int row) {
   if constexpr (ES == 4) return 0;
+  else if constexpr (ES == 1) return ((row >> 1) & 3) << 1;  // 128-byte rows of bytes, 8-row transposed reads
   else if constexpr (ROW_BYTES == 256) return (row & 3) << 2;
   else return ((row >> 1) & 1) << 2;
 }
@@ -68,7 +76,7 @@ template <typename T, int BMC, int BNC, int TPI>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
   const WgradArgs& p = kp.a;
   constexpr int ES = (int)sizeof(T);
-  constexpr int BKP = 128 / ES;             // pixels per slab: 32 fp32, 64 bf16
+  constexpr int BKP = ES == 1 ? 64 : 128 / ES;  // pixels per slab: 32 fp32, 64 bf16, 64 fp8
   constexpr int RB_A = BMC * ES;            // bytes of one staged dy row
   constexpr int RB_B = BNC * ES;            // bytes of one staged x row
   constexpr int A_BYTES = BKP * RB_A;
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
   constexpr int STAGE = A_BYTES + TPI * B_BYTES;
   constexpr int LPR_A = RB_A / 16, LPR_B = RB_B / 16;  // lanes (16-byte chunks) per row
   constexpr int RPP_A = 64 / LPR_A, RPP_B = 64 / LPR_B;  // rows per 1 KiB piece
-  constexpr int PW_A = BMC / 32, PW_B = BNC / 32;        // pieces per wave per slab
+  constexpr int PW_A = A_BYTES / 4096, PW_B = B_BYTES / 4096;  // 1 KiB pieces per wave per slab
   constexpr int MI = BMC / 64, NI = BNC / 64;            // 32x32 tiles per wave (cout / cin)
   constexpr int NST = TPI * MI * NI * 4;                 // 16-byte stores per thread per item
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -173,6 +181,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
   const int tg = lane >> 4, tw = lane & 15, tq = tw >> 2, tpp = tw & 3;
   const int t_krow = 8 * (tg >> 1) + tq;
   const int t_col = 16 * (tg & 1) + 4 * tpp;  // element column inside the 32-wide tile
+  // fp8 transposed reads: group g reads k rows 8*(g>>1) .. +7 (lane pair q = tw>>1 supplies row q), byte columns 16*(g&1) + 8*(tw&1)
+  const int t8_krow = 8 * (tg >> 1) + (tw >> 1);
+  const int t8_col = 16 * (tg & 1) + 8 * (tw & 1);
 
   L_setup();
   int stage = 0;
@@ -247,6 +258,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
                 acc[jt][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[ni], dv[mi], acc[jt][mi][ni], 0, 0, 0);
           }
         }
+      } else if constexpr (ES == 1) {
+        constexpr int NS = BKP / 16;
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+          const int k0 = ks * 16 + t8_krow;
+          long df[MI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const int byte = cobase + mi * 32 + t8_col;
+            const char* ap = Ad + k0 * RB_A + ((((byte >> 4) ^ row_swz<ES, RB_A>(k0)) << 4) | (byte & 15));
+            df[mi] = __builtin_bit_cast(long, __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i32_ptr)(ap)));
+          }
+          if (lv) {
+#pragma unroll
+            for (int j = ks * NPC / NS; j < (ks + 1) * NPC / NS; ++j) L_piece(j);
+          }
+#pragma unroll
+          for (int jt = 0; jt < TPI; ++jt) {
+            long xf[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              const int byte = cibase + ni * 32 + t8_col;
+              const char* ap = Bx + jt * B_BYTES + k0 * RB_B + ((((byte >> 4) ^ row_swz<ES, RB_B>(k0)) << 4) | (byte & 15));
+              xf[ni] = __builtin_bit_cast(long, __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i32_ptr)(ap)));
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni)
+                acc[jt][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(xf[ni], df[mi], acc[jt][mi][ni], 0, 0, 0);
+          }
+        }
       } else {
         constexpr int NS = BKP / 16;
 #pragma unroll
@@ -319,8 +362,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
 // column would walk hundreds of slabs alone.
 template <int SG>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial, int splits, size_t stride,
-                                                            float* dst, size_t n4, float beta) {
+                                                            float* dst, size_t n4, float beta, const float* sa, const float* sb) {
   constexpr int COLS = 256 / SG;
+  const float oscale = sa ? 1.f / (sa[0] * sb[0]) : 1.f;  // fp8 wgrad: the sums are in units of the two operands' scales
   __shared__ f32x4 red[SG > 1 ? SG : 1][COLS];
   const int col = threadIdx.x % COLS, sg = threadIdx.x / COLS;
   for (size_t i0 = (size_t)blockIdx.x * COLS; i0 < n4; i0 += (size_t)gridDim.x * COLS) {
@@ -350,6 +394,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial
     }
     if (sg == 0 && i < n4) {
       f32x4* d = reinterpret_cast<f32x4*>(dst + i * 4);
+      if (sa) s *= oscale;
       if (beta != 0.f) s += beta * (*d);
       *d = s;
     }
@@ -386,7 +431,7 @@ inline int wg_tpi(int Cout, int Ck, int ntaps) {
 template <typename T, int BMC, int BNC, int TPI>
 int launch_t(const WgradArgs& a, int splits, hipStream_t stream) {
   constexpr int ES = (int)sizeof(T);
-  constexpr int BKP = 128 / ES;
+  constexpr int BKP = ES == 1 ? 64 : 128 / ES;
   WgradKArgs k;
   k.a = a;
   k.M = a.N * a.Ho * a.Wo;
@@ -475,12 +520,16 @@ int launch_wgrad(int dtype, const WgradArgs& a, int splits, hipStream_t stream) 
   MI355_ARG(((size_t)a.pix_stride * dtype_size(dtype)) % 8 == 0, "wgrad: pixel stride not 8-byte aligned");
   if (dtype == MI355_F32) return launch_d<float>(a, splits, stream);
   if (dtype == MI355_BF16) return launch_d<bf16_t>(a, splits, stream);
+  if (dtype == MI355_FP8) {  // e4m3 twins of dy and x: the caller scales the result by 1 / (scale_dy * scale_x) (splitk_reduce)
+    MI355_ARG(a.Cout % 128 == 0 && a.Ck % 128 == 0 && a.pair_delta == 0, "wgrad fp8: Cout=%d Ck=%d must be multiples of 128", a.Cout, a.Ck);
+    return launch_t<fp8_t, 128, 128, 1>(a, splits, stream);
+  }
   set_error("wgrad: bad dtype %d", dtype);
   return MI355_E_ARG;
 }
 
 int launch_splitk_reduce(const float* partial, int splits, size_t stride, float* dst, size_t n, float beta,
-                         hipStream_t stream) {
+                         hipStream_t stream, const float* sa, const float* sb) {
   MI355_ARG(n % 4 == 0 && stride % 4 == 0, "splitk_reduce: n=%zu stride=%zu must be multiples of 4", n, stride);
   const size_t n4 = n / 4;
   // small outputs with many slabs: several threads per column (see the kernel)
@@ -490,11 +539,11 @@ int launch_splitk_reduce(const float* partial, int splits, size_t stride, float*
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   if (sg == 16)
-    hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(blocks), dim3(256), 0, stream, partial, splits, stride, dst, n4, beta);
+    hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(blocks), dim3(256), 0, stream, partial, splits, stride, dst, n4, beta, sa, sb);
   else if (sg == 4)
-    hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, stream, partial, splits, stride, dst, n4, beta);
+    hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, stream, partial, splits, stride, dst, n4, beta, sa, sb);
   else
-    hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, stream, partial, splits, stride, dst, n4, beta);
+    hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, stream, partial, splits, stride, dst, n4, beta, sa, sb);
   MI355_LAUNCH_CHECK();
   return 0;
 }
@@ -502,7 +551,7 @@ int launch_splitk_reduce(const float* partial, int splits, size_t stride, float*
 int launch_stem_unpack(float* partial, int splits, float* dw, float beta, hipStream_t stream) {
   const int n = 64 * 7 * 7 * 3;
   if (splits > 1) {  // slab 0 <- sum of the slabs (a column is read and written by the same threads: in place is safe)
-    MI355_TRY(launch_splitk_reduce(partial, splits, (size_t)64 * 4 * 64, partial, (size_t)64 * 4 * 64, 0.f, stream));
+    MI355_TRY(launch_splitk_reduce(partial, splits, (size_t)64 * 4 * 64, partial, (size_t)64 * 4 * 64, 0.f, stream, nullptr, nullptr));
     splits = 1;
   }
   hipLaunchKernelGGL(stem_unpack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, partial, splits, dw, beta);

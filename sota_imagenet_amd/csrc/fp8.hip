@@ -102,6 +102,25 @@ int mi355_conv2d_fwd_fp8(const void* xq, const void* wq, void* y, float oscale, 
   return launch_igemm_fp8(a, 1, oscale, (hipStream_t)stream);
 }
 
+int mi355_conv2d_wgrad_fp8(const void* dyq, const void* xq, float* dw, float beta, float oscale, int N, int H, int W, int Cin, int Cout,
+                           int KH, int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+  MI355_ARG(dyq && xq && dw && Cin % 128 == 0 && Cout % 128 == 0 && KH * KW <= 9 && (stride == 1 || stride == 2),
+            "conv2d_wgrad_fp8: Cin=%d Cout=%d (multiples of 128)", Cin, Cout);
+  WgradArgs a;
+  build_wgrad_args(a, N, H, W, Cin, Cout, KH, KW, stride, pad);
+  const int splits = plan_wgrad_splits(MI355_BF16, a.N * a.Ho * a.Wo, Cout, KH * KW, Cin);
+  const size_t n = (size_t)Cout * KH * KW * Cin;
+  MI355_ARG(ws && ws_bytes >= (size_t)splits * n * 4 + 256, "wgrad fp8: workspace too small (%zu < %zu)", ws_bytes, (size_t)splits * n * 4 + 256);
+  a.dy = dyq; a.x = xq; a.partial = (float*)ws;
+  hipStream_t s = (hipStream_t)stream;
+  MI355_TRY(launch_wgrad(MI355_FP8, a, splits, s));
+  // the per-op form takes host scales: park 1 / oscale and 1 behind the partial slabs as the two device scalars the reduce reads
+  float* sc = (float*)((char*)ws + (size_t)splits * n * 4);
+  const float host[2] = {1.f / oscale, 1.f};
+  MI355_HIP(hipMemcpyAsync(sc, host, sizeof(host), hipMemcpyHostToDevice, s));
+  return launch_splitk_reduce((const float*)ws, splits, n, dw, n, beta, s, sc, sc + 1);
+}
+
 int mi355_conv2d_dgrad_fp8(const void* dyq, const void* wtq, void* dx, float oscale, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                            int stride, int pad, void* stream) {
   MI355_ARG(dyq && wtq && dx && Cin % 128 == 0 && Cout % 128 == 0 && KH * KW <= 9, "conv2d_dgrad_fp8: Cin=%d Cout=%d (multiples of 128)", Cin, Cout);

@@ -54,7 +54,7 @@ struct ConvBN {
   bool fin_done = false;      // the launch that summed this layer's forward statistics also finalized them (bn_fin.h)
   bool bwd_fin_done = false;  // ... and the same for its BN-backward sums
   // fp8 training step (ctx dtype MI355_FP8): forward / dgrad of this layer on e4m3 operands where the geometry allows it
-  bool fp8_fwd = false, fp8_dgrad = false;
+  bool fp8_fwd = false, fp8_dgrad = false, fp8_wgrad = false;
   void* w_q = nullptr;          // e4m3 [Cout][taps][Cin]
   void* w_trq = nullptr;        // e4m3 [Cin][taps][Cout]
   const void* in_q = nullptr;   // e4m3 twin of the layer's input activation (written by the bn_apply that produced it)
@@ -129,6 +129,10 @@ struct mi355_ctx {
   bool fp8_fwd_cal = false, fp8_bwd_cal = false;  // a training forward / a whole backward has recorded its amaxes
   bool fp8_fwd_on = false, fp8_bwd_on = false;    // this step's convs read the e4m3 twins
   bool fp8_use_fwd = true, fp8_use_bwd = true;    // MI355_FP8_FWD=0 / MI355_FP8_BWD=0 (read at create): keep that direction on bf16 operands (A/B)
+  bool fp8_use_wgrad = true;                      // MI355_FP8_WGRAD=0: weight gradients stay on the bf16 tensors
+  bool fp8_keep_bf16 = false;                     // MI355_FP8_KEEP_BF16=1: write the bf16 tensors even where every consumer reads the twin
+                                                  // (tests compare the twins with them)
+  bool fp8_lean = false;                          // this step: bf16 tensors whose consumers all read twins are not written
   bool grad_sync = true;    // false: backward skips the bucket all-reduces (DDP.no_sync(): non-final accumulation micro-steps)
   bool comm_dirty = false;  // an all-reduce of this backward call is in flight on the communicator's stream
   unsigned* sk_err_host = nullptr;  // pinned copy of the two scratch blocks' error words, refreshed by an async copy at the
@@ -323,14 +327,15 @@ int bn_prepare(mi355_ctx* c, ConvBN& l, int training, float momentum, hipStream_
 }
 
 int bn_apply(mi355_ctx* c, ConvBN& l, const void* residual, ConvBN* l2, void* out, int relu, hipStream_t s,
-             uint8_t* bits, uint8_t* q = nullptr, int qid = -1) {
+             uint8_t* bits, uint8_t* q = nullptr, int qid = -1, bool q_only = false) {
   const int M = c->N * l.Hout * l.Wout, C = l.Cout;
   const int nin = 1 + (residual ? 1 : 0) + (l2 ? 1 : 0);
   QuantOut qo;
   if (q && bits && qid >= 0) {  // training forward of the fp8 step: the e4m3 twin the next conv(s) read + its amax
     qo.q = q; qo.scale = c->q_scale + qid; qo.amax = c->q_amax + qid;
+    qo.only = q_only && !residual && !l2;
   }
-  Prof p(c, PC_BN_APPLY, 0, (double)M * C * (c->es * (nin + 1) + (qo.q ? 1 : 0)), s);
+  Prof p(c, PC_BN_APPLY, 0, (double)M * C * (c->es * (nin + (qo.only ? 0 : 1)) + (qo.q ? 1 : 0)), s);
   return launch_bn_apply(c->dtype, l.y, l.stat + 2 * C, l.stat + 3 * C, residual, l2 ? l2->y : nullptr,
                          l2 ? l2->stat + 2 * C : nullptr, l2 ? l2->stat + 3 * C : nullptr, out, M, C, relu, s, bits, qo);
 }
@@ -367,10 +372,12 @@ int bn_backward(mi355_ctx* c, ConvBN& l, const void* g, const uint8_t* bits, voi
   const uint8_t* bits2 = dz_out ? nullptr : bits;
   const void* g2 = dz_out ? dz_out : g;
   QuantOut qo;
-  if (c->fp8 && l.fp8_dgrad) {  // dx = the gradient wrt this layer's conv output: the operand of its fp8 dgrad
+  if (c->fp8 && l.qid_dy >= 0) {  // dx = the gradient wrt this layer's conv output: the operand of its fp8 dgrad / wgrad
     qo.q = (uint8_t*)grad_twin(c, dx); qo.scale = c->q_scale + l.qid_dy; qo.amax = c->q_amax + l.qid_dy;
+    // both consumers (dgrad, wgrad) read the twin: the bf16 gradient is not written
+    qo.only = c->fp8_lean && c->fp8_bwd_on && l.fp8_dgrad && l.fp8_wgrad && qo.q;
   }
-  Prof p(c, PC_BN_BWD_APPLY, 0, (double)M * C * (c->es * 3 + (qo.q ? 1 : 0)) + (bits2 ? mask_bytes : 0.0), s);
+  Prof p(c, PC_BN_BWD_APPLY, 0, (double)M * C * (c->es * (qo.only ? 2 : 3) + (qo.q ? 1 : 0)) + (bits2 ? mask_bytes : 0.0), s);
   return launch_bn_bwd_apply(c->dtype, g2, nullptr, l.y, l.stat, l.stat + C, bn_coef_of(c, s), dx, M, C, s, bits2, 0.f, qo);
 }
 
@@ -379,7 +386,16 @@ int conv_wgrad(mi355_ctx* c, ConvBN& l, const void* dy, const void* x, float bet
   build_wgrad_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
   a.dy = dy; a.x = x; a.partial = c->wg_partial;
   const size_t n = (size_t)l.Cout * l.K * l.K * l.Cin;
-  const double by = ((double)c->N * l.Hin * l.Win * l.Cin + (double)c->N * l.Hout * l.Wout * l.Cout) * c->es;
+  void* dyq = c->fp8_bwd_on && l.fp8_wgrad ? grad_twin(c, dy) : nullptr;
+  const double by = ((double)c->N * l.Hin * l.Win * l.Cin + (double)c->N * l.Hout * l.Wout * l.Cout) * (dyq ? 1 : c->es);
+  if (dyq) {  // e4m3 twins of both operands; the sums are rescaled by 1 / (scale_dy * scale_x) in the split reduce
+    a.dy = dyq; a.x = l.in_q;
+    {
+      Prof p(c, wgrad_class(l.Cout), conv_flops(c, l), by, s, 2);
+      MI355_TRY(launch_wgrad(MI355_FP8, a, l.splits, s));
+    }
+    return launch_splitk_reduce(c->wg_partial, l.splits, n, c->grads + l.w_off, n, beta_acc, s, c->q_scale + l.qid_dy, c->q_scale + l.qid_in);
+  }
   {
     Prof p(c, wgrad_class(l.Cout), conv_flops(c, l), by, s);
     MI355_TRY(launch_wgrad(c->dtype, a, l.splits, s));
@@ -518,6 +534,10 @@ void plan_fp8(mi355_ctx* c) {
     if (l.fp8_fwd || l.fp8_dgrad) l.qid_w = n++;
     if (l.fp8_dgrad) l.qid_dy = n++;
   };
+  const char* wg = getenv("MI355_FP8_WGRAD");
+  c->fp8_use_wgrad = !(wg && wg[0] == '0');
+  const char* kb = getenv("MI355_FP8_KEEP_BF16");
+  c->fp8_keep_bf16 = kb && kb[0] == '1';
   for (size_t i = 0; i < c->blocks.size(); ++i) {
     Block& b = c->blocks[i];
     legal(b.c1, true); legal(b.c2, false); legal(b.c3, false);
@@ -533,6 +553,14 @@ void plan_fp8(mi355_ctx* c) {
     }
     if (b.c2.fp8_fwd) b.c2.qid_in = b.qid_a1 = n++;
     if (b.c3.fp8_fwd) b.c3.qid_in = b.qid_a2 = n++;
+    // weight gradients on e4m3 operands (transposed byte reads, conv_wgrad.hip ES = 1) wherever the layer's input has a twin anyway
+    // (its forward reads it) and both channel counts are multiples of 128; the gradient twin is then written for conv1 too
+    auto wg_plan = [&](ConvBN& l) {
+      l.fp8_wgrad = c->fp8_use_wgrad && l.fp8_fwd && l.qid_in >= 0 && l.Cin % 128 == 0 && l.Cout % 128 == 0;
+      if (l.fp8_wgrad && l.qid_dy < 0) l.qid_dy = n++;
+    };
+    wg_plan(b.c1); wg_plan(b.c2); wg_plan(b.c3);
+    if (b.has_ds) wg_plan(b.ds);
   }
   c->q_n = (int)align_up((size_t)n, 64);
 }
@@ -988,6 +1016,7 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
     // step of a ctx has none yet and runs its convs on the bf16 tensors (the twins are still written: that records the amaxes)
     c->fp8_fwd_on = c->fp8_fwd_cal && c->fp8_use_fwd;
     c->fp8_bwd_on = c->fp8_fwd_cal && c->fp8_bwd_cal && c->fp8_use_bwd;
+    c->fp8_lean = c->fp8_fwd_on && c->fp8_bwd_on && !c->fp8_keep_bf16;
     if (c->fp8_fwd_cal) MI355_TRY(launch_fp8_scale_update(c->q_scale, c->q_amax, c->q_n, FP8_HEADROOM, s));
   }
   MI355_TRY(weight_prep_all(c, training != 0, s));
@@ -1024,10 +1053,13 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
     }
     MI355_TRY(conv_forward(c, b.c1, b.in, training, bn_momentum, s));
     MI355_TRY(bn_prepare(c, b.c1, training, bn_momentum, s));
-    MI355_TRY(bn_apply(c, b.c1, nullptr, nullptr, b.a1, 1, s, training ? b.a1_bits : nullptr, b.a1_q, b.qid_a1));
+    // (fp8 step, lean: a1 / a2 are read by conv2 / conv3 forward and their weight gradients only — all through the twin)
+    MI355_TRY(bn_apply(c, b.c1, nullptr, nullptr, b.a1, 1, s, training ? b.a1_bits : nullptr, b.a1_q, b.qid_a1,
+                       training && c->fp8_lean && b.c2.fp8_fwd && b.c2.fp8_wgrad));
     MI355_TRY(conv_forward(c, b.c2, b.a1, training, bn_momentum, s));
     MI355_TRY(bn_prepare(c, b.c2, training, bn_momentum, s));
-    MI355_TRY(bn_apply(c, b.c2, nullptr, nullptr, b.a2, 1, s, training ? b.a2_bits : nullptr, b.a2_q, b.qid_a2));
+    MI355_TRY(bn_apply(c, b.c2, nullptr, nullptr, b.a2, 1, s, training ? b.a2_bits : nullptr, b.a2_q, b.qid_a2,
+                       training && c->fp8_lean && b.c3.fp8_fwd && b.c3.fp8_wgrad));
     MI355_TRY(conv_forward(c, b.c3, b.a2, training, bn_momentum, s));
     MI355_TRY(bn_prepare(c, b.c3, training, bn_momentum, s));
     if (b.has_ds) {

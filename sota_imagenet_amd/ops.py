@@ -74,6 +74,18 @@ def conv2d_dgrad_fp8(dyq, wq, x_shape, stride=1, pad=0, oscale=1.0, wt=None):
     return dx
 
 
+def conv2d_wgrad_fp8(dyq, xq, KH, KW, stride=1, pad=0, oscale=1.0):
+    """fp32 dw [Cout,KH,KW,Cin] = oscale * sum_pixels dyq (x) xq from e4m3 dy (NHWC) and x (NHWC) on the fp8 MFMA path."""
+    _need_cuda(dyq, xq)
+    N, H, W, Cin = xq.shape
+    Cout = dyq.shape[-1]
+    ws, n = _conv_ws(native.BF16, N, H, W, Cin, Cout, KH, KW, stride, pad, dyq.device)
+    ws = torch.empty(n + 256, dtype=torch.uint8, device=dyq.device)
+    dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=dyq.device)
+    check(_L().mi355_conv2d_wgrad_fp8(ptr(dyq), ptr(xq), ptr(dw), 0.0, float(oscale), N, H, W, Cin, Cout, KH, KW, stride, pad, ptr(ws), n + 256, cur_stream()))
+    return dw
+
+
 def ingest_u8(packed, table_host, table_dev, S, mean=127.5, std=51.0, aug_host=None, aug_dev=None):
     """decoded u8 RGB crops (packed device bytes + mi355_crop table as a numpy structured array and its device copy) ->
     fp32 NCHW [N,3,S,S]: resize, window, [augment table: blur / colour / grey / erase], mirror, normalise (csrc/ingest.hip)."""

@@ -85,6 +85,27 @@ def test_conv_fp8_scaled_random(dev, case):
     assert (dx - dref).abs().max() <= dref.abs().max() * 2.0 ** -8
 
 
+@pytest.mark.parametrize("case", [(4, 14, 14, 128, 256, 3, 1), (3, 7, 7, 256, 128, 1, 1), (5, 10, 10, 128, 128, 3, 2), (2, 8, 8, 256, 256, 1, 2),
+                                  (64, 14, 14, 256, 256, 3, 1), (33, 7, 7, 512, 128, 1, 1)])
+def test_wgrad_fp8(dev, case):
+    """weight gradient on e4m3 operands (transposed byte reads): on small integers every product and partial sum is exact, so it must
+    equal the bf16 weight gradient of the same data BIT FOR BIT; the output scale is one fp32 multiply."""
+    from sota_imagenet_amd import ops
+
+    N, H, W, Cin, Cout, K, s = case
+    pad = K // 2
+    Ho, Wo = (H + 2 * pad - K) // s + 1, (W + 2 * pad - K) // s + 1
+    g = torch.Generator().manual_seed(13)
+    x = torch.randint(-2, 3, (N, H, W, Cin), generator=g).float().to(dev)
+    dy = torch.randint(-2, 3, (N, Ho, Wo, Cout), generator=g).float().to(dev)
+    dw8 = ops.conv2d_wgrad_fp8(ops.quantize_fp8(dy), ops.quantize_fp8(x), K, K, s, pad)
+    dw16 = ops.conv2d_wgrad(dy.bfloat16(), x.bfloat16(), K, K, s, pad)
+    assert torch.equal(dw8, dw16)
+    _, dwref = R.conv2d_bwd(x.cpu(), torch.zeros(Cout, K, K, Cin), dy.cpu(), s, pad)
+    assert torch.equal(dw8.cpu(), dwref)
+    assert torch.equal(ops.conv2d_wgrad_fp8(ops.quantize_fp8(dy), ops.quantize_fp8(x), K, K, s, pad, oscale=0.25), dw16 * 0.25)
+
+
 def test_conv_fp8_rejects_unsupported_shapes(dev):
     from sota_imagenet_amd import ops
 

@@ -86,10 +86,13 @@ def _check_forward_twins(m, key, img, convs):
         assert (T(bn + ".save_mean").double() - y2.mean(0)).abs().max() <= 1e-4 * y2.mean(0).abs().max() + 1e-6, bn
 
 
-def test_fp8_step_small(dev):
+def test_fp8_step_small(dev, monkeypatch):
     """8 x 64 px, parameters frozen (lr 0) so the bf16 model is a step-by-step yardstick: calibration state machine, twins,
-    teacher-forced fp8 convs of EVERY fp8 layer, losses, gradients."""
+    teacher-forced fp8 convs of EVERY fp8 layer, losses, gradients.  MI355_FP8_KEEP_BF16=1: the bf16 a1 / a2 tensors, which the
+    lean step does not write once every consumer reads the twin, are kept so the twins can be compared with them."""
     from sota_imagenet_amd.losses import CrossEntropyLoss
+
+    monkeypatch.setenv("MI355_FP8_KEEP_BF16", "1")
 
     N, S = 8, 64
     key = (N, S, S)
@@ -129,7 +132,7 @@ def test_fp8_step_small(dev):
 
 def test_fp8_backward_alone_tracks_the_bf16_backward(dev, monkeypatch):
     """MI355_FP8_FWD=0 keeps the forward on bf16 operands, so both models save IDENTICAL activations and the two backwards differ
-    only by the e4m3 rounding of the gradient / weight operands of the 29 fp8 dgrads: every segment's gradient must point where the
+    only by the e4m3 rounding of the operands of the 29 fp8 dgrads and the fp8 weight gradients: every segment's gradient must point where the
     bf16 one does (measured 0.98 at the stem ... 1.000 at fc; an indexing or scaling error in an fp8 dgrad gives ~0)."""
     from sota_imagenet_amd.losses import CrossEntropyLoss
 
@@ -148,9 +151,29 @@ def test_fp8_backward_alone_tracks_the_bf16_backward(dev, monkeypatch):
         assert not torch.equal(m8.flat_grads, m16.flat_grads)
         cs = [torch.nn.functional.cosine_similarity(m8.flat_grads[b:e], m16.flat_grads[b:e], dim=0).item() for b, e in m8.grad_segments]
         print("fp8 backward vs bf16 backward, cosine per segment:", " ".join(f"{c:.3f}" for c in cs))
-        assert cs[0] > 0.9999 and min(cs) > 0.97, cs
+        assert cs[0] > 0.999 and min(cs) > 0.95, cs  # (dgrads AND weight gradients of layers 2-4 on e4m3 operands)
         rel = [((m8.flat_grads[b:e] - m16.flat_grads[b:e]).norm() / m16.flat_grads[b:e].norm()).item() for b, e in m8.grad_segments]
         assert max(rel) < 0.25, rel
+
+
+def test_fp8_lean_step_equals_the_step_that_keeps_the_bf16_tensors(dev, monkeypatch):
+    """once both directions read the twins, the bf16 activations a1 / a2 and the bf16 gradients of conv2 / conv3 / downsample have no
+    reader left and are not written (bn_apply / bn_bwd_apply QONLY): losses and gradients must be BIT-identical to the step that
+    still writes them — anything that still read a stale bf16 tensor would show here."""
+    from sota_imagenet_amd.losses import CrossEntropyLoss
+
+    crit = CrossEntropyLoss(smoothing=0.1).cuda()
+    batches = [synthetic_batch(8, 64, seed=6, index=i, device="cuda") for i in range(3)]
+    runs = []
+    for keep in ("1", "0"):
+        monkeypatch.setenv("MI355_FP8_KEEP_BF16", keep)
+        m = _model("fp8")
+        out = []
+        for d, t in batches:
+            out.append((_step(m, crit, d, t), m.flat_grads.clone()))
+        runs.append(out)
+    for (la, ga), (lb, gb) in zip(*runs):
+        assert la == lb and torch.equal(ga, gb)
 
 
 def test_fp8_step_trains(dev):
@@ -180,12 +203,13 @@ def test_fp8_step_trains(dev):
 
 
 @pytest.mark.parametrize("S", [160, 224, 320])
-def test_config5_fp8_batch_512_progressive_sizes(dev, S):
+def test_config5_fp8_batch_512_progressive_sizes(dev, S, monkeypatch):
     """configs[4] as BASELINE states it: bs 512 at 160 / 224 / 320 px with fp8 convs.  Three steps (calibration, then two on
     the twins); then, on a few images, the teacher-forced check of one fp8 conv per kind and stage (3x3, stride-2 3x3, long and
     short 1x1, downsample), finite loss near ln 1000, step-0 loss within 5 % of a bf16 model's, finite non-zero gradients."""
     from sota_imagenet_amd.losses import CrossEntropyLoss
 
+    monkeypatch.setenv("MI355_FP8_KEEP_BF16", "1")  # (the twins are compared with the bf16 tensors below)
     N = 512
     key = (N, S, S)
     crit = CrossEntropyLoss(smoothing=0.1).cuda()
