@@ -185,7 +185,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(dtype, steps, warmup, want_roof):
+    def run(dtype, steps, warmup, want_roof, N=N, S=S):
         """W untimed + exactly K timed training steps in `dtype`; returns (seconds, final loss, model)."""
         variant = args.model == "bresnet50"
         kw = dict(stem_type="deep", antialias=True, attn_type="eca", norm_layer="inplaceabn", norm_act="leaky_relu", drop_rate=0.2,
@@ -205,7 +205,7 @@ def main():
             from sota_imagenet_amd.parallel import FlatBucketDDP
 
             net = FlatBucketDDP(model, device_ids=[local_rank])
-        pool = [synthetic_batch(N, S, seed=0, stream=rank, index=i, device="cuda") for i in range(8)]  # a pool of 8
+        pool = [synthetic_batch(N, S, seed=0, stream=rank, index=i, device="cuda") for i in range(8 if N <= 256 else 4)]  # a pool of 8
         model.train()
 
         def step(i):
@@ -371,6 +371,26 @@ def main():
                 out["secondary"]["roofline_hbm"] = h2
             else:
                 del m2
+        if world == 1 and not use_ddp and args.dtype == "bf16" and not args.no_secondary:
+            # BASELINE.json configs[4] on one GPU: bs 512, 224 px, fp8 (e4m3) convolutions — the step of §4.6 of DESIGN.md, with the
+            # bf16 step at the SAME shape measured right beside it (same process, same box)
+            model = None
+            torch.cuda.empty_cache()
+            try:
+                k8 = max(8, args.steps // 2)
+                dt8, loss8, m8, _ = run("fp8", k8, 3, False, N=512, S=S)
+                del m8
+                torch.cuda.empty_cache()
+                dt16, loss16, m16, _ = run("bf16", k8, 3, False, N=512, S=S)
+                del m16
+                torch.cuda.empty_cache()
+                out["secondary_fp8"] = {"dtype": "fp8", "workload": f"BASELINE configs[4] on one MI355X: ResNet-50 bs=512 {S}px, fp8 (e4m3) fwd / dgrad / wgrad "
+                                                                    "operands for layers 2-4, delayed per-tensor scaling",
+                                        "value": round(512 * k8 / dt8, 1), "unit": "images/sec", "steps": k8, "ms_per_step": round(dt8 / k8 * 1e3, 3),
+                                        "final_loss": round(loss8, 4),
+                                        "bf16_same_shape": {"value": round(512 * k8 / dt16, 1), "ms_per_step": round(dt16 / k8 * 1e3, 3), "final_loss": round(loss16, 4)}}
+            except Exception as e:  # the headline line must not depend on the extra measurement
+                out["secondary_fp8"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
