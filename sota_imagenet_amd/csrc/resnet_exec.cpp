@@ -920,9 +920,14 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
   const char* fb = getenv("MI355_FUSE_BN_BWD");
   // measured same-box: -0.6 ms/step in bf16, +0.9 ms in fp32 (the fp32 epilogue is already register-heavy)
   c->fuse_bn_bwd = fb ? fb[0] != '0' : dtype == MI355_BF16;
-  // measured (profiles/README.md, round 3): 20.4 -> 33.3 ms/step with it on.  ONE workgroup reads 0.25-2 MB of partial rows (behind an
-  // L2 invalidate) per BatchNorm while the other 255 CUs have drained — a serial tail of ~100 us x 106 where the separate launch
-  // spreads the same reads over C/4 workgroups in 7 us.  Kept behind MI355_BN_FIN=1 as the record of that experiment.
+  // measured (profiles/README.md, round 3): 20.4 -> 33.3 ms/step with it on.  Two further variants were built on top of this one and
+  // measured before being dropped: (1) the last K arrivers finalize 16 channels each in parallel — still 32.9 ms, which showed that
+  // the cost is not the serial reduction but the TICKETS: agent-scope atomics on one address run at ~4 M/s across the 8 XCDs, 512
+  // of them are ~120 us per launch (every conv kernel took 2-3x its time); (2) no atomics at all — every workgroup publishes the
+  // launch's epoch in its own flag word, K designated workgroups poll the flags — 20.8-21.0 ms against 20.0, i.e. still slower than
+  // the 7 us finalize launches it replaces (the tail runs on K CUs while the rest of the chip has drained), and it needed
+  // agent-scope loads for the rows (this XCD's L2 can hold the previous launch's rows of the same scratch buffer) and still lost
+  // one channel at 8-pixel test shapes.  Kept behind MI355_BN_FIN=1 in its first, correct form as the record of the experiment.
   const char* ff = getenv("MI355_BN_FIN");
   c->fuse_fin = ff && ff[0] == '1';
   const char* ov = getenv("MI355_WGRAD_STREAM");
