@@ -185,9 +185,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(dtype, steps, warmup, want_roof, N=N, S=S):
+    def run(dtype, steps, warmup, want_roof, N=N, S=S, variant=None):
         """W untimed + exactly K timed training steps in `dtype`; returns (seconds, final loss, model)."""
-        variant = args.model == "bresnet50"
+        variant = args.model == "bresnet50" if variant is None else variant
         kw = dict(stem_type="deep", antialias=True, attn_type="eca", norm_layer="inplaceabn", norm_act="leaky_relu", drop_rate=0.2,
                   drop_connect_rate=0.2, weight_standardization=True) if variant else {}
         model = resnet50(dtype=dtype, **kw).cuda()
@@ -391,6 +391,21 @@ def main():
                                         "bf16_same_shape": {"value": round(512 * k8 / dt16, 1), "ms_per_step": round(dt16 / k8 * 1e3, 3), "final_loss": round(loss16, 4)}}
             except Exception as e:  # the headline line must not depend on the extra measurement
                 out["secondary_fp8"] = {"error": str(e)[:200]}
+        if world == 1 and not use_ddp and args.dtype == "bf16" and not args.no_secondary:
+            # BASELINE.json configs[3] on one GPU: the BResNet-50 variant graph with CutmixMixup on (bench.py --model bresnet50)
+            model = None
+            torch.cuda.empty_cache()
+            try:
+                kb = max(4, args.steps // 4)
+                dtb, lossb, mb, _ = run("bf16", kb, 2, False, N=256, S=S, variant=True)
+                del mb
+                torch.cuda.empty_cache()
+                out["secondary_bresnet50"] = {"dtype": "bf16", "workload": "BASELINE configs[3] on one MI355X: BResNet-50 (deep stem, anti-alias, ECA, leaky ABN, WS, "
+                                                                           f"drop-connect) bs=256 {S}px, CutmixMixup on, per-op C-ABI graph",
+                                              "value": round(256 * kb / dtb, 1), "unit": "images/sec", "steps": kb, "ms_per_step": round(dtb / kb * 1e3, 3),
+                                              "final_loss": round(lossb, 4)}
+            except Exception as e:
+                out["secondary_bresnet50"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

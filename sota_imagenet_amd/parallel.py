@@ -213,6 +213,8 @@ class FlatBucketDDP(nn.Module):
 
     # ---- C3: called by the model's backward right after a segment's kernels were enqueued ---------------------
     def _on_segment(self, seg, begin, end):
+        if getattr(self, "_skip_sync", False):  # inside no_sync(): gradients stay rank-local
+            return
         rng = self._by_last.get(seg)
         if rng is not None:
             view = self.module.flat_grads[rng[0]: rng[1]]

@@ -63,6 +63,15 @@ def _worker(rank, world, port, q):
             exp[b:e] = sum((r + 1) * (s + 1) for r in range(world)) / world + torch.arange(e - b) * 1e-3
         ok = ok and torch.allclose(m.flat_grads, exp, rtol=0, atol=1e-5)
         nb = len(ddp.buckets)
+        # no_sync() (accumulate_steps > 1): the backward inside issues no collective — gradients stay this rank's own
+        with ddp.no_sync():
+            m.backward()
+        mine = torch.zeros_like(m.flat_grads)
+        for s, (b, e) in enumerate(m.grad_segments):
+            mine[b:e] = (rank + 1) * (s + 1) + torch.arange(e - b) * 1e-3
+        ok = ok and torch.allclose(m.flat_grads, mine, rtol=0, atol=1e-6)
+        m.backward()  # outside again: reduced
+        ok = ok and torch.allclose(m.flat_grads, exp, rtol=0, atol=1e-5)
         # C5: Runner meter reduction
         from sota_imagenet_amd import fit_wrapper as fw
 
