@@ -79,8 +79,8 @@ def conv2d_wgrad_fp8(dyq, xq, KH, KW, stride=1, pad=0, oscale=1.0):
     _need_cuda(dyq, xq)
     N, H, W, Cin = xq.shape
     Cout = dyq.shape[-1]
-    ws, n = _conv_ws(native.BF16, N, H, W, Cin, Cout, KH, KW, stride, pad, dyq.device)
-    ws = torch.empty(n + 256, dtype=torch.uint8, device=dyq.device)
+    n = _L().mi355_conv2d_workspace_bytes(native.BF16, N, H, W, Cin, Cout, KH, KW, stride, pad)
+    ws = torch.empty(n + 256, dtype=torch.uint8, device=dyq.device)  # split-K slabs + the two scale words
     dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=dyq.device)
     check(_L().mi355_conv2d_wgrad_fp8(ptr(dyq), ptr(xq), ptr(dw), 0.0, float(oscale), N, H, W, Cin, Cout, KH, KW, stride, pad, ptr(ws), n + 256, cur_stream()))
     return dw
