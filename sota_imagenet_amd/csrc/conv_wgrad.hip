@@ -32,6 +32,9 @@ namespace mi355 {
 namespace {
 
 #define MAX_WG (2 * device_cus())  // persistent workgroups: 2 per CU
+#ifndef MI355_WGRAD_BKP16
+#define MI355_WGRAD_BKP16 64  // pixels per bf16 slab (A/B builds: -DMI355_WGRAD_BKP16=32 halves the LDS per workgroup)
+#endif
 
 struct FastDiv {
   uint32_t mul, sh;
@@ -76,7 +79,7 @@ template <typename T, int BMC, int BNC, int TPI>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
   const WgradArgs& p = kp.a;
   constexpr int ES = (int)sizeof(T);
-  constexpr int BKP = ES == 1 ? 64 : 128 / ES;  // pixels per slab: 32 fp32, 64 bf16, 64 fp8
+  constexpr int BKP = ES == 1 ? 64 : (ES == 2 ? MI355_WGRAD_BKP16 : 128 / ES);  // pixels per slab: 32 fp32, 64 bf16, 64 fp8
   constexpr int RB_A = BMC * ES;            // bytes of one staged dy row
   constexpr int RB_B = BNC * ES;            // bytes of one staged x row
   constexpr int A_BYTES = BKP * RB_A;
@@ -431,7 +434,7 @@ inline int wg_tpi(int Cout, int Ck, int ntaps) {
 template <typename T, int BMC, int BNC, int TPI>
 int launch_t(const WgradArgs& a, int splits, hipStream_t stream) {
   constexpr int ES = (int)sizeof(T);
-  constexpr int BKP = ES == 1 ? 64 : 128 / ES;
+  constexpr int BKP = ES == 1 ? 64 : (ES == 2 ? MI355_WGRAD_BKP16 : 128 / ES);
   WgradKArgs k;
   k.a = a;
   k.M = a.N * a.Ho * a.Wo;
