@@ -318,7 +318,9 @@ int mi355_resnet50_backward(mi355_ctx* ctx, const float* dlogits, int seg_begin,
  *              the launcher's own channel (the reference has one: init_process_group("nccl", "env://"), train.py:61);
  *              every rank then calls mi355_comm_create(&comm, id, nranks, rank, device) (collective: ncclCommInitRank).
  *   data path  mi355_resnet50_set_comm(ctx, comm, bucket_cap_mb): consecutive backward segments form buckets of at least
- *              bucket_cap_mb MiB of the flat gradient array; mi355_resnet50_backward then launches, when a bucket's last
+ *              bucket_cap_mb MiB of the flat gradient array (the last bucket is cut once more: its trailing segments up to
+ *              bucket_cap_mb / 8 — stem, layer 1, the end of layer 2 — form a small bucket of their own, so that only a few MB
+ *              are reduced after backward has ended); mi355_resnet50_backward then launches, when a bucket's last
  *              segment has been enqueued, ONE mean all-reduce over the bucket's contiguous slice on a HIP stream the
  *              communicator owns, ordered by events behind the kernels that produce it (both executor streams), and makes
  *              `stream` wait for the last one before it returns — so ONE backward call covers all segments, the collective

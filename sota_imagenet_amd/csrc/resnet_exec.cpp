@@ -645,22 +645,49 @@ void seg_range(const mi355_ctx* c, int seg, size_t* b, size_t* e) {
     *b = blk.grad_begin; *e = blk.grad_end;
   }
 }
-// consecutive segments (backward completion order = ascending offsets) form buckets of >= cap_elems gradient elements
+// consecutive segments (backward completion order = ascending offsets) form buckets of >= cap_elems gradient elements.
+// The LAST bucket has nothing left to hide behind (its all-reduce starts when backward ends), so it is cut once more: its trailing
+// segments up to cap_elems / 8 (stem + layer 1 + the end of layer 2: ~4 MB at the default cap) become a bucket of their own and the
+// part before them is reduced while those last, activation-heavy blocks are still computing.
 std::vector<mi355_ctx::Bucket> plan_buckets(const mi355_ctx* c, size_t cap_elems) {
   std::vector<mi355_ctx::Bucket> out;
   const int nseg = (int)c->blocks.size() + 2;
   bool open = false;
   size_t start = 0;
+  int first_seg = 0;
+  std::vector<int> firsts;
   for (int i = 0; i < nseg; ++i) {
     size_t b, e;
     seg_range(c, i, &b, &e);
     if (!open) {
       start = b;
+      first_seg = i;
       open = true;
     }
     if (e - start >= cap_elems || i == nseg - 1) {
       out.push_back({start, e, i});
+      firsts.push_back(first_seg);
       open = false;
+    }
+  }
+  const size_t tail_cap = cap_elems / 8;
+  if (!out.empty() && out.back().end - out.back().begin > tail_cap) {
+    const int f = firsts.back(), l = out.back().last_seg;
+    int cut = l + 1;  // first segment of the tail bucket (l + 1: no tail — the last segment alone exceeds the tail cap)
+    size_t tail = 0;
+    for (int i = l; i > f; --i) {
+      size_t b, e;
+      seg_range(c, i, &b, &e);
+      if (tail + (e - b) > tail_cap) break;
+      tail += e - b;
+      cut = i;
+    }
+    if (cut > f && cut <= l) {
+      size_t b, e;
+      seg_range(c, cut, &b, &e);
+      const mi355_ctx::Bucket last = out.back();
+      out.back() = {last.begin, b, cut - 1};
+      out.push_back({b, last.end, l});
     }
   }
   return out;

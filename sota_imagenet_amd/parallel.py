@@ -28,15 +28,32 @@ import torch.nn as nn
 
 
 def plan_buckets(segments, cap_elems):
-    """[(begin, end)] per backward segment -> [(begin, end, last_segment_index)] buckets of >= cap_elems elements."""
-    buckets = []
+    """[(begin, end)] per backward segment -> [(begin, end, last_segment_index)] buckets of >= cap_elems elements.  The last bucket
+    (nothing left to overlap its all-reduce with) is cut once more: its trailing segments up to cap_elems // 8 form a bucket of their
+    own, the part before them is reduced while those last blocks still compute (same rule as csrc/resnet_exec.cpp plan_buckets)."""
+    buckets, firsts = [], []
     start = None
     for i, (b, e) in enumerate(segments):
         if start is None:
-            start = b
+            start, first = b, i
         if e - start >= cap_elems or i == len(segments) - 1:
             buckets.append((start, e, i))
+            firsts.append(first)
             start = None
+    tail_cap = cap_elems // 8
+    if buckets and buckets[-1][1] - buckets[-1][0] > tail_cap:
+        f, l = firsts[-1], buckets[-1][2]
+        cut, tail = l + 1, 0
+        for i in range(l, f, -1):
+            b, e = segments[i]
+            if tail + (e - b) > tail_cap:
+                break
+            tail += e - b
+            cut = i
+        if f < cut <= l:
+            b0, e0, _ = buckets[-1]
+            buckets[-1] = (b0, segments[cut][0], cut - 1)
+            buckets.append((segments[cut][0], e0, l))
     return buckets
 
 
