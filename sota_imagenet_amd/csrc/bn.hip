@@ -445,6 +445,199 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p)
   if constexpr (Q) amax_flush(amax, p.qo.amax);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Stem backward without the full-resolution gradient of the max pool: g = maxpool3x3/2-backward(dp) is GATHERED on the fly from
+// the pooled gradient dp [N][H/2][W/2][C] and the argmax codes (1 byte per pooled element, position kh * 3 + kw inside the
+// window) by both BN-backward passes, instead of being written by a pool-backward kernel and read back twice (2 x 411 MB at
+// batch 256 / 224 px; maxpool_bwd_kernel in misc.hip is the stand-alone operator, same arithmetic).  One thread per 2 x 2
+// block of full-resolution pixels and channel vector: the windows (a, b) ... (a + 1, b + 1) are the only ones that reach the
+// block, a pixel adds its windows in (oh, ow) order and the sum is rounded to T — the value the unfused path stored.
+template <typename T>
+struct PoolGather {
+  static constexpr int V = Vec16<T>::N;
+  float g[4][V];
+  uint8_t id[4][V];
+  __device__ __forceinline__ void load(const T* __restrict__ dp, const uint8_t* __restrict__ idx, int n, int a, int b, int Ho, int Wo, int C, int c0) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int oh = a + (w >> 1), ow = b + (w & 1);
+      const bool ok = oh < Ho && ow < Wo;
+      const size_t o = (((size_t)n * Ho + (ok ? oh : a)) * Wo + (ok ? ow : b)) * C + c0;
+      Vec16<T>::load(dp + o, g[w]);
+      if constexpr (V == 4) {
+        const uint32_t x = *reinterpret_cast<const uint32_t*>(idx + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) id[w][e] = ok ? (uint8_t)(x >> (8 * e)) : (uint8_t)255;
+      } else {
+        const uint2 x = *reinterpret_cast<const uint2*>(idx + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          id[w][e] = ok ? (uint8_t)(x.x >> (8 * e)) : (uint8_t)255;
+          id[w][4 + e] = ok ? (uint8_t)(x.y >> (8 * e)) : (uint8_t)255;
+        }
+      }
+    }
+  }
+  // gradient of block pixel (r, c), under its ReLU bits
+  template <int r, int c>
+  __device__ __forceinline__ void pixel(unsigned bits, float (&out)[V]) const {
+#pragma unroll
+    for (int e = 0; e < V; ++e) out[e] = 0.f;
+#pragma unroll
+    for (int dr = 0; dr <= r; ++dr)
+#pragma unroll
+      for (int dc = 0; dc <= c; ++dc) {
+        const int pos = (r + 1 - 2 * dr) * 3 + (c + 1 - 2 * dc);
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          if (id[2 * dr + dc][e] == pos) out[e] += g[2 * dr + dc][e];
+      }
+#pragma unroll
+    for (int e = 0; e < V; ++e) out[e] = (bits >> e) & 1u ? (float)(T)out[e] : 0.f;
+  }
+};
+
+struct StemBwdArgs {
+  const void* dp;        // [N][Ho][Wo][C] gradient wrt the pooled activation
+  const uint8_t* idx;    // [N][Ho][Wo][C] argmax codes
+  const uint8_t* bits;   // [N][2Ho][2Wo][C / V] ReLU bits of the full-resolution activation
+  const void* y;         // [N][2Ho][2Wo][C] raw conv output
+  const float* mean;
+  const float* invstd;
+  const float* coef;     // apply: [3][C]
+  float* partial;        // reduce: [gridDim.x][2][C]
+  void* dx;              // apply: gradient wrt y
+  int N, Ho, Wo, C;
+};
+
+// pass 1: s1 = sum dz, s2 = sum dz * xhat.  256 threads = C / V vectors x 256 / (C / V) block slots
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const StemBwdArgs p) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ __attribute__((aligned(16))) float red[2][256 * V];
+  const int tpr = p.C / V, rpp = 256 / tpr;
+  const int tid = threadIdx.x;
+  const int cv = tid % tpr, r = tid / tpr;
+  const int c0 = cv * V;
+  const T* y = reinterpret_cast<const T*>(p.y);
+  const T* dp = reinterpret_cast<const T*>(p.dp);
+  const int H = 2 * p.Ho, W = 2 * p.Wo;
+  float s1[V], s2[V], mu[V], is[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) s1[e] = s2[e] = 0.f;
+  load_consts<V>(p.mean, c0, mu);
+  load_consts<V>(p.invstd, c0, is);
+  const int nb = p.N * p.Ho * p.Wo;
+  const int step = gridDim.x * rpp;
+#pragma unroll 2
+  for (int t = blockIdx.x * rpp + r; t < nb; t += step) {
+    const int b = t % p.Wo, a = (t / p.Wo) % p.Ho, n = t / (p.Wo * p.Ho);
+    PoolGather<T> pg;
+    pg.load(dp, p.idx, n, a, b, p.Ho, p.Wo, p.C, c0);
+    const size_t pix00 = ((size_t)n * H + 2 * a) * W + 2 * b;
+    float yv[4][V];
+    unsigned bt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t pix = pix00 + (size_t)(k >> 1) * W + (k & 1);
+      Vec16<T>::load_nt(y + pix * p.C + c0, yv[k]);
+      bt[k] = p.bits[pix * tpr + cv];
+    }
+    float gv[4][V];
+    pg.template pixel<0, 0>(bt[0], gv[0]);
+    pg.template pixel<0, 1>(bt[1], gv[1]);
+    pg.template pixel<1, 0>(bt[2], gv[2]);
+    pg.template pixel<1, 1>(bt[3], gv[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float xh = (yv[k][e] - mu[e]) * is[e];
+        s1[e] += gv[k][e];
+        s2[e] += gv[k][e] * xh;
+      }
+  }
+  // block slots that share a wavefront: shuffle-reduce, then one LDS row per wave (tpr <= 16 for the 64-channel stem)
+  for (int off = tpr; off < 64; off <<= 1) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      s1[e] += __shfl_xor(s1[e], off);
+      s2[e] += __shfl_xor(s2[e], off);
+    }
+  }
+  if ((tid & 63) < tpr) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      red[0][((tid >> 6) * tpr + cv) * V + e] = s1[e];
+      red[1][((tid >> 6) * tpr + cv) * V + e] = s2[e];
+    }
+  }
+  __syncthreads();
+  if (tid < tpr) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float a = 0.f, b = 0.f;
+      for (int rr = 0; rr < 4; ++rr) {
+        a += red[0][(rr * tpr + tid) * V + e];
+        b += red[1][(rr * tpr + tid) * V + e];
+      }
+      p.partial[((size_t)blockIdx.x * 2 + 0) * p.C + tid * V + e] = a;
+      p.partial[((size_t)blockIdx.x * 2 + 1) * p.C + tid * V + e] = b;
+    }
+  }
+}
+
+// pass 2: dx = k0 * (dz - k1 - xhat * k2)
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bwd_apply_kernel(const StemBwdArgs p) {
+  constexpr int V = Vec16<T>::N;
+  const int tpr = p.C / V;
+  const T* y = reinterpret_cast<const T*>(p.y);
+  const T* dp = reinterpret_cast<const T*>(p.dp);
+  T* dx = reinterpret_cast<T*>(p.dx);
+  const int H = 2 * p.Ho, W = 2 * p.Wo;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;  // a multiple of tpr: a thread keeps its channel vector
+  const int cv = (int)(i % tpr), c0 = cv * V;
+  float mu[V], is[V], k0[V], k1[V], k2[V];
+  load_consts<V>(p.mean, c0, mu);
+  load_consts<V>(p.invstd, c0, is);
+  load_consts<V>(p.coef, c0, k0);
+  load_consts<V>(p.coef + p.C, c0, k1);
+  load_consts<V>(p.coef + 2 * p.C, c0, k2);
+  const size_t total = (size_t)p.N * p.Ho * p.Wo * tpr;
+  for (; i < total; i += stride) {
+    const int t = (int)(i / tpr);
+    const int b = t % p.Wo, a = (t / p.Wo) % p.Ho, n = t / (p.Wo * p.Ho);
+    PoolGather<T> pg;
+    pg.load(dp, p.idx, n, a, b, p.Ho, p.Wo, p.C, c0);
+    const size_t pix00 = ((size_t)n * H + 2 * a) * W + 2 * b;
+    float yv[4][V];
+    unsigned bt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t pix = pix00 + (size_t)(k >> 1) * W + (k & 1);
+      Vec16<T>::load_nt(y + pix * p.C + c0, yv[k]);
+      bt[k] = p.bits[pix * tpr + cv];
+    }
+    float gv[4][V];
+    pg.template pixel<0, 0>(bt[0], gv[0]);
+    pg.template pixel<0, 1>(bt[1], gv[1]);
+    pg.template pixel<1, 0>(bt[2], gv[2]);
+    pg.template pixel<1, 1>(bt[3], gv[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float xh = (yv[k][e] - mu[e]) * is[e];
+        gv[k][e] = k0[e] * (gv[k][e] - k1[e] - xh * k2[e]);
+      }
+      const size_t pix = pix00 + (size_t)(k >> 1) * W + (k & 1);
+      Vec16<T>::store(dx + pix * p.C + c0, gv[k]);
+    }
+  }
+}
+
 int reduce_grid(int dtype, int M, int C, dim3* grid) {
   const int V = 16 / (int)dtype_size(dtype);
   const int tpr_full = C / V;
@@ -686,6 +879,48 @@ int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const vo
     MI355_BN_BWD_APPLY(bf16_t)
   }
 #undef MI355_BN_BWD_APPLY
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+static int stem_bwd_args(StemBwdArgs& a, int dtype, const void* dp, const uint8_t* idx, const uint8_t* bits, const void* y, const float* mean,
+                         const float* invstd, int N, int H, int W, int C) {
+  MI355_TRY(check_c(dtype, C));
+  const int V = 16 / (int)dtype_size(dtype);
+  MI355_ARG(dp && idx && bits && y && H % 2 == 0 && W % 2 == 0 && C / V <= 64, "stem_bwd: N=%d H=%d W=%d C=%d", N, H, W, C);
+  a = StemBwdArgs{};
+  a.dp = dp; a.idx = idx; a.bits = bits; a.y = y; a.mean = mean; a.invstd = invstd;
+  a.N = N; a.Ho = H / 2; a.Wo = W / 2; a.C = C;
+  return 0;
+}
+
+// BN-backward sums of a conv + BN + ReLU + maxpool3x3/2 stage from the POOLED gradient (H, W: the full resolution)
+int launch_stem_bwd_reduce(int dtype, const void* dp, const uint8_t* idx, const uint8_t* bits, const void* y, const float* mean,
+                           const float* invstd, float* partial, int* nblk_out, int N, int H, int W, int C, hipStream_t s) {
+  StemBwdArgs a;
+  MI355_TRY(stem_bwd_args(a, dtype, dp, idx, bits, y, mean, invstd, N, H, W, C));
+  a.partial = partial;
+  const int V = 16 / (int)dtype_size(dtype);
+  const int rpp = 256 / (C / V);
+  int nblk = cdiv(N * a.Ho * a.Wo, rpp * 4);
+  if (nblk > MAXBLK) nblk = MAXBLK;
+  *nblk_out = nblk;
+  if (dtype == MI355_F32) hipLaunchKernelGGL(stem_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(stem_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, a);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+
+// ... and the gradient wrt the raw conv output, dx [N][H][W][C]
+int launch_stem_bwd_apply(int dtype, const void* dp, const uint8_t* idx, const uint8_t* bits, const void* y, const float* mean,
+                          const float* invstd, const float* coef, void* dx, int N, int H, int W, int C, hipStream_t s) {
+  StemBwdArgs a;
+  MI355_TRY(stem_bwd_args(a, dtype, dp, idx, bits, y, mean, invstd, N, H, W, C));
+  a.coef = coef; a.dx = dx;
+  const int V = 16 / (int)dtype_size(dtype);
+  const int blocks = elementwise_blocks((size_t)N * a.Ho * a.Wo * (C / V), C / V);
+  if (dtype == MI355_F32) hipLaunchKernelGGL(stem_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(stem_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, a);
   MI355_LAUNCH_CHECK();
   return 0;
 }

@@ -225,6 +225,12 @@ int launch_bn_bwd_finalize(const float* partial, int nblk, int M, int C, const f
 int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
                         const float* invstd, const float* coef, void* dx, int M, int C, hipStream_t s,
                         const uint8_t* relu_bits = nullptr, float slope = 0.f, QuantOut qo = QuantOut());
+// conv + BN + ReLU + maxpool3x3/2 stage (the stem): both BN-backward passes gather the pool's backward from the pooled gradient
+// dp [N][H/2][W/2][C] and the argmax codes; the full-resolution pool gradient is never stored (H, W: the full resolution)
+int launch_stem_bwd_reduce(int dtype, const void* dp, const uint8_t* idx, const uint8_t* bits, const void* y, const float* mean,
+                           const float* invstd, float* partial, int* nblk_out, int N, int H, int W, int C, hipStream_t s);
+int launch_stem_bwd_apply(int dtype, const void* dp, const uint8_t* idx, const uint8_t* bits, const void* y, const float* mean,
+                          const float* invstd, const float* coef, void* dx, int N, int H, int W, int C, hipStream_t s);
 int bn_max_blocks();
 // fp8 step: scale[i] = amax[i] > 0 ? 448 / (headroom * amax[i]) : scale[i];  amax[i] = 0   (delayed per-tensor scaling)
 int launch_fp8_scale_update(float* scale, unsigned* amax, int n, float headroom, hipStream_t s);

@@ -118,6 +118,118 @@ __device__ __forceinline__ bf16x8 shift_prev(bf16x8 cur, bf16x8 prev) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
+// epilogue of one tile, straight from the accumulators (shared by both kernel forms): output pixel of fragment mt = tile_pix0 + orel[mt]
+// (orel < 0: padding column / behind the tile -> dropped)
+template <int STATS, int MT>
+__device__ __forceinline__ void conv3_epilogue(const Conv3KArgs& kp, f32x4 (&acc)[MT][NT3], const int (&orel)[MT], int tile, float* stat_acc, int wave,
+                                               int px, int q4, int tid) {
+  const IgemmArgs& p = kp.a;
+  const int H = p.Hin, W = p.Win;
+  bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
+  const bf16_t* addend = reinterpret_cast<const bf16_t*>(p.addend);
+  constexpr int MT3 = MT;  // (the body below is written in terms of MT3)
+  const int n_img = tile / kp.tiles_per_img;
+  const int r0 = (tile - n_img * kp.tiles_per_img) * kp.TH;
+  const int tile_pix0 = (n_img * H + r0) * W;
+  const int cb = q4 * 8;  // this lane's 8 channels inside a pair of 16-row tiles (weight rows are permuted accordingly)
+#pragma unroll
+  for (int ntp = 0; ntp < NT3 / 2; ++ntp) {
+    const int c0 = ntp * 32 + cb;
+    float s1[8], s2[8], bmu[8], bis[8];
+    if constexpr (STATS == 2) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.bn_mean + c0 + 4 * h);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bn_invstd + c0 + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bmu[4 * h + e] = a[e];
+          bis[4 * h + e] = b[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    constexpr int MB = 4;
+#pragma unroll
+    for (int mb = 0; mb < MT3; mb += MB) {
+      int pixs[MB];
+      uint4 araw[MB], yraw[MB];
+      unsigned abits[MB], ybits[MB];
+#pragma unroll
+      for (int u = 0; u < MB; ++u) {
+        const int mt = mb + u;
+        const int pix = orel[mt] < 0 ? -1 : tile_pix0 + orel[mt];
+        pixs[u] = pix;
+        const size_t o = (size_t)(pix < 0 ? 0 : pix) * C3 + c0;
+        if (addend) {
+          araw[u] = *reinterpret_cast<const uint4*>(addend + o);
+          abits[u] = p.addend_bits ? (unsigned)p.addend_bits[o / 8] : 0xffu;
+        }
+        if constexpr (STATS == 2) {
+          yraw[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bn_y) + o);
+          ybits[u] = (unsigned)p.bn_bits[o / 8];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < MB; ++u) {
+        const int mt = mb + u;
+        const f32x4 a = acc[mt][2 * ntp], b = acc[mt][2 * ntp + 1];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = a[e];
+          v[4 + e] = b[e];
+        }
+        const int pix = pixs[u];
+        if (addend) {
+          float ad[8];
+          Vec16<bf16_t>::unpack(araw[u], ad);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (pix >= 0 && ((abits[u] >> e) & 1u)) ? ad[e] : 0.f;
+        }
+        const size_t o = (size_t)(pix < 0 ? 0 : pix) * C3 + c0;
+        bf16_t* dst = pix < 0 ? reinterpret_cast<bf16_t*>(g3_trash + tid * 16) : out + o;
+        Vec16<bf16_t>::store(dst, v);
+        if constexpr (STATS == 1) {
+          if (pix >= 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float xr = (float)(bf16_t)v[e];
+              s1[e] += xr;
+              s2[e] += xr * xr;
+            }
+          }
+        }
+        if constexpr (STATS == 2) {
+          if (pix >= 0) {
+            float yv[8];
+            Vec16<bf16_t>::unpack(yraw[u], yv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float dz = (ybits[u] >> e) & 1u ? (float)(bf16_t)v[e] : 0.f;
+              s1[e] += dz;
+              s2[e] += dz * ((yv[e] - bmu[e]) * bis[e]);
+            }
+          }
+        }
+      }
+    }
+    if constexpr (STATS != 0) {
+      float* slot = stat_acc + (wave * C3 + c0) * 2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = row_sum16_3(s1[e]);
+        const float b = row_sum16_3(s2[e]);
+        if (px == 15) {
+          slot[2 * e] += a;
+          slot[2 * e + 1] += b;
+        }
+      }
+    }
+  }
+}
+
 template <int STATS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3_kernel(const Conv3KArgs kp) {
   const IgemmArgs& p = kp.a;
@@ -207,8 +319,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int cc = q - rr * WP;
     orel[mt] = (rr < kp.TH && cc >= 1 && cc <= W) ? rr * W + cc - 1 : -1;
   }
-  bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
-  const bf16_t* addend = reinterpret_cast<const bf16_t*>(p.addend);
   // every wave always computes MT3 fragments: those behind the tile's last position read whatever the (over-allocated) LDS image
   // holds there and are dropped by the epilogue — a wave-uniform fragment count would put a branch around every MFMA group
 
@@ -295,109 +405,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
 
     // ---- epilogue (registers only; the LDS image is not touched) ---------------------------------------------------------
-    if (!C3_PROBE(2)) {
-      const int n_img = tile / kp.tiles_per_img;
-      const int r0 = (tile - n_img * kp.tiles_per_img) * kp.TH;
-      const int tile_pix0 = (n_img * H + r0) * W;
-      const int cb = q4 * 8;  // this lane's 8 channels inside a pair of 16-row tiles (weight rows are permuted accordingly)
-#pragma unroll
-      for (int ntp = 0; ntp < NT3 / 2; ++ntp) {
-        const int c0 = ntp * 32 + cb;
-        float s1[8], s2[8], bmu[8], bis[8];
-        if constexpr (STATS == 2) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(p.bn_mean + c0 + 4 * h);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(p.bn_invstd + c0 + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              bmu[4 * h + e] = a[e];
-              bis[4 * h + e] = b[e];
-            }
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-        constexpr int MB = 4;
-#pragma unroll
-        for (int mb = 0; mb < MT3; mb += MB) {
-          int pixs[MB];
-          uint4 araw[MB], yraw[MB];
-          unsigned abits[MB], ybits[MB];
-#pragma unroll
-          for (int u = 0; u < MB; ++u) {
-            const int mt = mb + u;
-            const int pix = orel[mt] < 0 ? -1 : tile_pix0 + orel[mt];
-            pixs[u] = pix;
-            const size_t o = (size_t)(pix < 0 ? 0 : pix) * C3 + c0;
-            if (addend) {
-              araw[u] = *reinterpret_cast<const uint4*>(addend + o);
-              abits[u] = p.addend_bits ? (unsigned)p.addend_bits[o / 8] : 0xffu;
-            }
-            if constexpr (STATS == 2) {
-              yraw[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bn_y) + o);
-              ybits[u] = (unsigned)p.bn_bits[o / 8];
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < MB; ++u) {
-            const int mt = mb + u;
-            const f32x4 a = acc[mt][2 * ntp], b = acc[mt][2 * ntp + 1];
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[e] = a[e];
-              v[4 + e] = b[e];
-            }
-            const int pix = pixs[u];
-            if (addend) {
-              float ad[8];
-              Vec16<bf16_t>::unpack(araw[u], ad);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += (pix >= 0 && ((abits[u] >> e) & 1u)) ? ad[e] : 0.f;
-            }
-            const size_t o = (size_t)(pix < 0 ? 0 : pix) * C3 + c0;
-            bf16_t* dst = pix < 0 ? reinterpret_cast<bf16_t*>(g3_trash + tid * 16) : out + o;
-            Vec16<bf16_t>::store(dst, v);
-            if constexpr (STATS == 1) {
-              if (pix >= 0) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                  const float xr = (float)(bf16_t)v[e];
-                  s1[e] += xr;
-                  s2[e] += xr * xr;
-                }
-              }
-            }
-            if constexpr (STATS == 2) {
-              if (pix >= 0) {
-                float yv[8];
-                Vec16<bf16_t>::unpack(yraw[u], yv);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                  const float dz = (ybits[u] >> e) & 1u ? (float)(bf16_t)v[e] : 0.f;
-                  s1[e] += dz;
-                  s2[e] += dz * ((yv[e] - bmu[e]) * bis[e]);
-                }
-              }
-            }
-          }
-        }
-        if constexpr (STATS != 0) {
-          float* slot = stat_acc + (wave * C3 + c0) * 2;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float a = row_sum16_3(s1[e]);
-            const float b = row_sum16_3(s2[e]);
-            if (px == 15) {
-              slot[2 * e] += a;
-              slot[2 * e + 1] += b;
-            }
-          }
-        }
-      }
-    }
-
+    if (!C3_PROBE(2)) conv3_epilogue<STATS, MT3>(kp, acc, orel, tile, stat_acc, wave, px, q4, tid);
   }
 
   if constexpr (STATS != 0) {

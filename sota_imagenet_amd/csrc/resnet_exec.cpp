@@ -148,6 +148,7 @@ struct mi355_ctx {
   bool overlap = false;
   bool fuse_bn_bwd = false;  // BN-backward sums in the dgrad epilogues (MI355_FUSE_BN_BWD=0/1 overrides the default)
   bool fuse_fin = false;     // BN finalize by the last-arriving workgroup of the summing launch (MI355_BN_FIN=1; measured slower: off)
+  bool stem_fused_bwd = true;  // stem BN backward gathers the pool gradient on the fly (MI355_STEM_FUSED=0: pool-backward kernel + plain BN backward)
   unsigned* fin_counters = nullptr;   // 64 zero words per stream (main / side)
   unsigned* fin_counters2 = nullptr;
   hipStream_t wstream = nullptr;
@@ -762,11 +763,27 @@ int backward_stem(mi355_ctx* c, float beta_acc, hipStream_t s) {
   void* B1 = c->gset[par][0];
   ConvBN& l = c->stem;
   MI355_TRY(acquire_set(c, par, s));
-  {
-    Prof p(c, PC_OTHER, 0, 0, s);
-    MI355_TRY(launch_maxpool_bwd(c->dtype, G, c->pool_idx, B1, c->N, l.Hout, l.Wout, 64, s));
+  if (c->stem_fused_bwd) {
+    // B1 = dy of the stem conv straight from the pooled gradient: the 4x larger pool gradient is never written / re-read
+    const int M = c->N * l.Hout * l.Wout, C = l.Cout;
+    const double full = (double)M * C * c->es, pooled = full / 4 + (double)M * C / 4, mask = full / 16;
+    int nblk = 0;
+    {
+      Prof p(c, PC_BN_REDUCE, 0, full + pooled + mask, s);
+      MI355_TRY(launch_stem_bwd_reduce(c->dtype, G, c->pool_idx, c->a0_bits, l.y, l.stat, l.stat + C, bn_partial_of(c, s), &nblk, c->N, l.Hout,
+                                       l.Wout, C, s));
+    }
+    MI355_TRY(launch_bn_bwd_finalize(bn_partial_of(c, s), nblk, M, C, c->params + l.gamma_off, l.stat + C, c->grads + l.gamma_off,
+                                     c->grads + l.beta_off, beta_acc, bn_coef_of(c, s), s));
+    Prof p(c, PC_BN_BWD_APPLY, 0, 2 * full + pooled + mask, s);
+    MI355_TRY(launch_stem_bwd_apply(c->dtype, G, c->pool_idx, c->a0_bits, l.y, l.stat, l.stat + C, bn_coef_of(c, s), B1, c->N, l.Hout, l.Wout, C, s));
+  } else {
+    {
+      Prof p(c, PC_OTHER, 0, 0, s);
+      MI355_TRY(launch_maxpool_bwd(c->dtype, G, c->pool_idx, B1, c->N, l.Hout, l.Wout, 64, s));
+    }
+    MI355_TRY(bn_backward(c, l, B1, c->a0_bits, nullptr, B1, beta_acc, s));
   }
-  MI355_TRY(bn_backward(c, l, B1, c->a0_bits, nullptr, B1, beta_acc, s));
   WgradArgs a;
   build_stem_wgrad_args(a, c->N, c->H, c->W);
   a.dy = B1; a.x = c->xpad; a.partial = c->wg_partial;
@@ -957,6 +974,8 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
   // one channel at 8-pixel test shapes.  Kept behind MI355_BN_FIN=1 in its first, correct form as the record of the experiment.
   const char* ff = getenv("MI355_BN_FIN");
   c->fuse_fin = ff && ff[0] == '1';
+  const char* sf = getenv("MI355_STEM_FUSED");
+  c->stem_fused_bwd = !(sf && sf[0] == '0');
   const char* ov = getenv("MI355_WGRAD_STREAM");
   c->overlap = !(ov && ov[0] == '0');
   if (c->overlap) {

@@ -349,6 +349,26 @@ def test_fused_bn_backward_sums_match_standalone_reduce(dev):
     assert max(errs) < 0.3, f"per-segment drift {['%.1e' % x for x in errs]}"
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_stem_backward_from_the_pooled_gradient_matches_pool_backward_kernel(dev, dtype):
+    """The stem's BN backward gathers the max pool's backward on the fly from the pooled gradient (default) vs the stand-alone
+    pool-backward kernel + plain BN backward (MI355_STEM_FUSED=0): the same per-pixel gradient values (the gather rounds the
+    window sum as the kernel stored it), per-channel sums taken in a different order.  Nothing above the stem may change at all;
+    the stem's own gradients (conv1.weight, bn1.weight / bias: the last backward segment) agree to summation-order noise."""
+    from sota_imagenet_amd.models import resnet50
+
+    f = _train_steps(dtype, {"MI355_STEM_FUSED": "1"}, steps=1)
+    u = _train_steps(dtype, {"MI355_STEM_FUSED": "0"}, steps=1)
+    assert torch.equal(f[0][0], u[0][0])
+    segs = resnet50(dtype=dtype).grad_segments
+    for b, e in segs[:-1]:
+        assert torch.equal(f[1][0][b:e], u[1][0][b:e])
+    b, e = segs[-1]
+    assert f[1][0][b:e].abs().max() > 0
+    err = l2err(f[1][0][b:e], u[1][0][b:e])
+    assert err < (1e-5 if dtype == "fp32" else 2e-3), f"stem segment: {err:.3e}"
+
+
 @pytest.mark.parametrize("forced", ["1", "3"])
 @pytest.mark.parametrize("fuse", ["0", "1"])
 def test_256_wide_conv_tiles_in_backward_match_128_wide(dev, fuse, forced, monkeypatch):

@@ -1,8 +1,10 @@
 #!/bin/bash
-# on the GPU box: same build, alternates an environment switch (e.g. MI355_WGRAD_STREAM 0/1); prints ms/step
-VAR=$1; DT=${2:-bf16}; ROUNDS=${3:-3}; LIB=${4:-$PWD/sota_imagenet_amd/lib/libmi355rn.so}
-for r in $(seq $ROUNDS); do for v in 0 1; do
-  export $VAR=$v
-  MI355RN_LIB=$LIB timeout -k 10 300 python bench.py --steps 8 --warmup 3 --dtype $DT \
-    --no-cpu-baseline --no-roofline --no-secondary 2>&1 | grep "^{" | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('$VAR=$v', '$DT', r['ms_per_step'], r['config']['final_loss'])"
-done; done
+# On the GPU box: same-box A/B of one environment switch on the default bench line (interleaved A B A B): tools/ab_env.sh VAR A_VALUE B_VALUE [bench args]
+VAR=${1:?var}; A=${2:?a}; B=${3:?b}; shift 3
+cd "${GRAFT_REPO_ROOT:?not on a gpurun box}"
+mkdir -p gpurun_out
+for rep in 1 2 3; do
+  for v in "$A" "$B"; do
+    env $VAR=$v python3 bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-secondary --no-roofline "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$VAR=$v', d['ms_per_step'])"
+  done
+done
