@@ -15,6 +15,8 @@
 // second-branch variants are template parameters and last-use streams are loaded non-temporally.
 #include <hip/hip_fp8.h>
 
+#include <algorithm>
+
 #include "bn_fin.h"
 #include "common.h"
 #include "vec.h"
@@ -447,34 +449,46 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p)
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Stem backward without the full-resolution gradient of the max pool: g = maxpool3x3/2-backward(dp) is GATHERED on the fly from
-// the pooled gradient dp [N][H/2][W/2][C] and the argmax codes (1 byte per pooled element, position kh * 3 + kw inside the
+// the pooled gradient dp [N][H/2][W/2][64] and the argmax codes (1 byte per pooled element, position kh * 3 + kw inside the
 // window) by both BN-backward passes, instead of being written by a pool-backward kernel and read back twice (2 x 411 MB at
 // batch 256 / 224 px; maxpool_bwd_kernel in misc.hip is the stand-alone operator, same arithmetic).  One thread per 2 x 2
 // block of full-resolution pixels and channel vector: the windows (a, b) ... (a + 1, b + 1) are the only ones that reach the
 // block, a pixel adds its windows in (oh, ow) order and the sum is rounded to T — the value the unfused path stored.
+// Register diet (these loops live on loads in flight; the first version needed 227 VGPRs = two waves per SIMD and ran at
+// half the speed of the apply pass): every stream goes through a raw buffer resource with ONE 32-bit offset register per tensor
+// (row / window steps in the scalar offset and the immediate), gradients and codes stay packed until the pixel that uses them.
+constexpr int SC = 64;  // channels of the stage (the stem)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0xfffffffcull ? 0xfffffffcull : bytes), 0x00020000);
+}
+__device__ __forceinline__ uint4 buf16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, bool nt = false) {
+  return nt ? __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2))   // slc
+            : __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
 template <typename T>
 struct PoolGather {
   static constexpr int V = Vec16<T>::N;
-  float g[4][V];
-  uint8_t id[4][V];
-  __device__ __forceinline__ void load(const T* __restrict__ dp, const uint8_t* __restrict__ idx, int n, int a, int b, int Ho, int Wo, int C, int c0) {
+  uint4 g[4];
+  uint32_t id[4][V / 4];
+  // window w = 2 dr + dc sits (dr * Wo + dc) pooled pixels behind (a, b); a window off the edge is read anyway (the next row /
+  // image: mapped memory; behind the tensor: the buffer range check) and its codes are voided
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rg, __amdgpu_buffer_rsrc_t ri, unsigned t, unsigned cv, int a, int b, int Ho, int Wo) {
+    const unsigned go = (t * SC + cv * V) * (unsigned)sizeof(T), io = t * SC + cv * V;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      const int oh = a + (w >> 1), ow = b + (w & 1);
-      const bool ok = oh < Ho && ow < Wo;
-      const size_t o = (((size_t)n * Ho + (ok ? oh : a)) * Wo + (ok ? ow : b)) * C + c0;
-      Vec16<T>::load(dp + o, g[w]);
+      const bool ok = a + (w >> 1) < Ho && b + (w & 1) < Wo;
+      const unsigned srow = (w >> 1) ? (unsigned)Wo * SC : 0u;
+      g[w] = buf16(rg, go + (w & 1) * SC * (unsigned)sizeof(T), srow * (unsigned)sizeof(T));
       if constexpr (V == 4) {
-        const uint32_t x = *reinterpret_cast<const uint32_t*>(idx + o);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) id[w][e] = ok ? (uint8_t)(x >> (8 * e)) : (uint8_t)255;
+        const unsigned x = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ri, io + (w & 1) * SC, srow, 0);
+        id[w][0] = ok ? x : 0xffffffffu;  // (no position has code 255)
       } else {
-        const uint2 x = *reinterpret_cast<const uint2*>(idx + o);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          id[w][e] = ok ? (uint8_t)(x.x >> (8 * e)) : (uint8_t)255;
-          id[w][4 + e] = ok ? (uint8_t)(x.y >> (8 * e)) : (uint8_t)255;
-        }
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 x = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(ri, io + (w & 1) * SC, srow, 0));
+        id[w][0] = ok ? x[0] : 0xffffffffu;
+        id[w][1] = ok ? x[1] : 0xffffffffu;
       }
     }
   }
@@ -487,10 +501,12 @@ struct PoolGather {
     for (int dr = 0; dr <= r; ++dr)
 #pragma unroll
       for (int dc = 0; dc <= c; ++dc) {
-        const int pos = (r + 1 - 2 * dr) * 3 + (c + 1 - 2 * dc);
+        const unsigned pos = (r + 1 - 2 * dr) * 3 + (c + 1 - 2 * dc);
+        float gw[V];
+        Vec16<T>::unpack(g[2 * dr + dc], gw);
 #pragma unroll
         for (int e = 0; e < V; ++e)
-          if (id[2 * dr + dc][e] == pos) out[e] += g[2 * dr + dc][e];
+          if (((id[2 * dr + dc][e >> 2] >> (8 * (e & 3))) & 0xffu) == pos) out[e] += gw[e];
       }
 #pragma unroll
     for (int e = 0; e < V; ++e) out[e] = (bits >> e) & 1u ? (float)(T)out[e] : 0.f;
@@ -498,66 +514,101 @@ struct PoolGather {
 };
 
 struct StemBwdArgs {
-  const void* dp;        // [N][Ho][Wo][C] gradient wrt the pooled activation
-  const uint8_t* idx;    // [N][Ho][Wo][C] argmax codes
-  const uint8_t* bits;   // [N][2Ho][2Wo][C / V] ReLU bits of the full-resolution activation
-  const void* y;         // [N][2Ho][2Wo][C] raw conv output
+  const void* dp;        // [N][Ho][Wo][64] gradient wrt the pooled activation
+  const uint8_t* idx;    // [N][Ho][Wo][64] argmax codes
+  const uint8_t* bits;   // [N][2Ho][2Wo][64 / V] ReLU bits of the full-resolution activation
+  const void* y;         // [N][2Ho][2Wo][64] raw conv output
   const float* mean;
   const float* invstd;
-  const float* coef;     // apply: [3][C]
-  float* partial;        // reduce: [gridDim.x][2][C]
+  const float* coef;     // apply: [3][64]
+  float* partial;        // reduce: [gridDim.x][2][64]
   void* dx;              // apply: gradient wrt y
-  int N, Ho, Wo, C;
+  int N, Ho, Wo;
 };
 
-// pass 1: s1 = sum dz, s2 = sum dz * xhat.  256 threads = C / V vectors x 256 / (C / V) block slots
+// the four pixels of block t = (n, a, b): y vectors (last use in the apply pass: streamed) and ReLU bits
 template <typename T>
-__global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const StemBwdArgs p) {
-  constexpr int V = Vec16<T>::N;
-  __shared__ __attribute__((aligned(16))) float red[2][256 * V];
-  const int tpr = p.C / V, rpp = 256 / tpr;
+struct BlockIn {
+  uint4 y[4];
+  unsigned bt[4];
+  unsigned pix00;
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t ry, __amdgpu_buffer_rsrc_t rb, int n, int a, int b, int Ho, int Wo, unsigned cv, bool nt) {
+    constexpr int V = Vec16<T>::N;
+    const unsigned W = 2 * Wo;
+    pix00 = ((unsigned)n * 2 * Ho + 2 * a) * W + 2 * b;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned srow = (k >> 1) ? W : 0u;
+      y[k] = buf16(ry, (pix00 * SC + cv * V) * (unsigned)sizeof(T) + (k & 1) * SC * (unsigned)sizeof(T), srow * SC * (unsigned)sizeof(T), nt);
+      bt[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rb, pix00 * (SC / V) + cv + (k & 1) * (SC / V), srow * (SC / V), 0);
+    }
+  }
+};
+
+// pass 1: s1 = sum dz, s2 = sum dz * xhat.  256 threads = 64 / V vectors x 256 / (64 / V) block slots
+template <typename T>
+__global__ __launch_bounds__(256, 2) void stem_bwd_reduce_kernel(const StemBwdArgs p) {
+  constexpr int V = Vec16<T>::N, tpr = SC / V, rpp = 256 / tpr;
+  __shared__ __attribute__((aligned(16))) float red[2][4 * SC];
   const int tid = threadIdx.x;
-  const int cv = tid % tpr, r = tid / tpr;
-  const int c0 = cv * V;
-  const T* y = reinterpret_cast<const T*>(p.y);
-  const T* dp = reinterpret_cast<const T*>(p.dp);
-  const int H = 2 * p.Ho, W = 2 * p.Wo;
+  const unsigned cv = tid % tpr;
+  const int r = tid / tpr;
+  const size_t full = (size_t)p.N * p.Ho * p.Wo * 4 * SC;
+  const __amdgpu_buffer_rsrc_t ry = rsrc_of(p.y, full * sizeof(T)), rb = rsrc_of(p.bits, full / V);
+  const __amdgpu_buffer_rsrc_t rg = rsrc_of(p.dp, full / 4 * sizeof(T)), ri = rsrc_of(p.idx, full / 4);
   float s1[V], s2[V], mu[V], is[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) s1[e] = s2[e] = 0.f;
-  load_consts<V>(p.mean, c0, mu);
-  load_consts<V>(p.invstd, c0, is);
+  load_consts<V>(p.mean, cv * V, mu);
+  load_consts<V>(p.invstd, cv * V, is);
   const int nb = p.N * p.Ho * p.Wo;
   const int step = gridDim.x * rpp;
-#pragma unroll 2
-  for (int t = blockIdx.x * rpp + r; t < nb; t += step) {
+  // the NEXT block's 16 loads are issued before this block's ~600 instructions of arithmetic: a wave then always has a batch in
+  // flight (three waves per SIMD alone leave HBM idle while they compute)
+  auto fetch = [&](PoolGather<T>& pg, BlockIn<T>& in, int t) __attribute__((always_inline)) {
     const int b = t % p.Wo, a = (t / p.Wo) % p.Ho, n = t / (p.Wo * p.Ho);
-    PoolGather<T> pg;
-    pg.load(dp, p.idx, n, a, b, p.Ho, p.Wo, p.C, c0);
-    const size_t pix00 = ((size_t)n * H + 2 * a) * W + 2 * b;
-    float yv[4][V];
-    unsigned bt[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const size_t pix = pix00 + (size_t)(k >> 1) * W + (k & 1);
-      Vec16<T>::load_nt(y + pix * p.C + c0, yv[k]);
-      bt[k] = p.bits[pix * tpr + cv];
-    }
-    float gv[4][V];
-    pg.template pixel<0, 0>(bt[0], gv[0]);
-    pg.template pixel<0, 1>(bt[1], gv[1]);
-    pg.template pixel<1, 0>(bt[2], gv[2]);
-    pg.template pixel<1, 1>(bt[3], gv[3]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
+    pg.load(rg, ri, (unsigned)t, cv, a, b, p.Ho, p.Wo);
+    in.load(ry, rb, n, a, b, p.Ho, p.Wo, cv, false);
+  };
+  auto consume = [&](const PoolGather<T>& pg, const BlockIn<T>& in) __attribute__((always_inline)) {
+    auto add = [&](const float (&gv)[V], const uint4& yraw) __attribute__((always_inline)) {
+      float yv[V];
+      Vec16<T>::unpack(yraw, yv);
 #pragma unroll
       for (int e = 0; e < V; ++e) {
-        const float xh = (yv[k][e] - mu[e]) * is[e];
-        s1[e] += gv[k][e];
-        s2[e] += gv[k][e] * xh;
+        const float xh = (yv[e] - mu[e]) * is[e];
+        s1[e] += gv[e];
+        s2[e] += gv[e] * xh;
       }
+    };
+    float gv[V];
+    pg.template pixel<0, 0>(in.bt[0], gv);
+    add(gv, in.y[0]);
+    pg.template pixel<0, 1>(in.bt[1], gv);
+    add(gv, in.y[1]);
+    pg.template pixel<1, 0>(in.bt[2], gv);
+    add(gv, in.y[2]);
+    pg.template pixel<1, 1>(in.bt[3], gv);
+    add(gv, in.y[3]);
+  };
+  int t = blockIdx.x * rpp + r;
+  if (t < nb) {
+    PoolGather<T> pga, pgb;
+    BlockIn<T> ina, inb;
+    fetch(pga, ina, t);
+#pragma unroll 1
+    for (;;) {
+      int tn = t + step;
+      if (tn < nb) fetch(pgb, inb, tn);
+      consume(pga, ina);
+      if (tn >= nb) break;
+      t = tn + step;
+      if (t < nb) fetch(pga, ina, t);
+      consume(pgb, inb);
+      if (t >= nb) break;
+    }
   }
-  // block slots that share a wavefront: shuffle-reduce, then one LDS row per wave (tpr <= 16 for the 64-channel stem)
+  // block slots that share a wavefront: shuffle-reduce, then one LDS row per wave
   for (int off = tpr; off < 64; off <<= 1) {
 #pragma unroll
     for (int e = 0; e < V; ++e) {
@@ -568,73 +619,68 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const StemBwdArgs 
   if ((tid & 63) < tpr) {
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      red[0][((tid >> 6) * tpr + cv) * V + e] = s1[e];
-      red[1][((tid >> 6) * tpr + cv) * V + e] = s2[e];
+      red[0][(tid >> 6) * SC + cv * V + e] = s1[e];
+      red[1][(tid >> 6) * SC + cv * V + e] = s2[e];
     }
   }
   __syncthreads();
-  if (tid < tpr) {
-#pragma unroll
-    for (int e = 0; e < V; ++e) {
-      float a = 0.f, b = 0.f;
-      for (int rr = 0; rr < 4; ++rr) {
-        a += red[0][(rr * tpr + tid) * V + e];
-        b += red[1][(rr * tpr + tid) * V + e];
-      }
-      p.partial[((size_t)blockIdx.x * 2 + 0) * p.C + tid * V + e] = a;
-      p.partial[((size_t)blockIdx.x * 2 + 1) * p.C + tid * V + e] = b;
+  if (tid < SC) {
+    float a = 0.f, b = 0.f;
+    for (int rr = 0; rr < 4; ++rr) {  // the waves, in order
+      a += red[0][rr * SC + tid];
+      b += red[1][rr * SC + tid];
     }
+    p.partial[((size_t)blockIdx.x * 2 + 0) * SC + tid] = a;
+    p.partial[((size_t)blockIdx.x * 2 + 1) * SC + tid] = b;
   }
 }
 
 // pass 2: dx = k0 * (dz - k1 - xhat * k2)
 template <typename T>
-__global__ __launch_bounds__(256) void stem_bwd_apply_kernel(const StemBwdArgs p) {
-  constexpr int V = Vec16<T>::N;
-  const int tpr = p.C / V;
-  const T* y = reinterpret_cast<const T*>(p.y);
-  const T* dp = reinterpret_cast<const T*>(p.dp);
+__global__ __launch_bounds__(256, 4) void stem_bwd_apply_kernel(const StemBwdArgs p) {
+  constexpr int V = Vec16<T>::N, tpr = SC / V;
   T* dx = reinterpret_cast<T*>(p.dx);
-  const int H = 2 * p.Ho, W = 2 * p.Wo;
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * 256;  // a multiple of tpr: a thread keeps its channel vector
-  const int cv = (int)(i % tpr), c0 = cv * V;
+  const size_t full = (size_t)p.N * p.Ho * p.Wo * 4 * SC;
+  const __amdgpu_buffer_rsrc_t ry = rsrc_of(p.y, full * sizeof(T)), rb = rsrc_of(p.bits, full / V);
+  const __amdgpu_buffer_rsrc_t rg = rsrc_of(p.dp, full / 4 * sizeof(T)), ri = rsrc_of(p.idx, full / 4);
+  unsigned i = blockIdx.x * 256 + threadIdx.x;
+  const unsigned stride = gridDim.x * 256;  // a multiple of tpr: a thread keeps its channel vector
+  const unsigned cv = i % tpr, c0 = cv * V;
   float mu[V], is[V], k0[V], k1[V], k2[V];
   load_consts<V>(p.mean, c0, mu);
   load_consts<V>(p.invstd, c0, is);
   load_consts<V>(p.coef, c0, k0);
-  load_consts<V>(p.coef + p.C, c0, k1);
-  load_consts<V>(p.coef + 2 * p.C, c0, k2);
-  const size_t total = (size_t)p.N * p.Ho * p.Wo * tpr;
+  load_consts<V>(p.coef + SC, c0, k1);
+  load_consts<V>(p.coef + 2 * SC, c0, k2);
+  const unsigned total = (unsigned)p.N * p.Ho * p.Wo * tpr;
+  const unsigned W = 2 * p.Wo;
+#pragma unroll 1
   for (; i < total; i += stride) {
     const int t = (int)(i / tpr);
     const int b = t % p.Wo, a = (t / p.Wo) % p.Ho, n = t / (p.Wo * p.Ho);
     PoolGather<T> pg;
-    pg.load(dp, p.idx, n, a, b, p.Ho, p.Wo, p.C, c0);
-    const size_t pix00 = ((size_t)n * H + 2 * a) * W + 2 * b;
-    float yv[4][V];
-    unsigned bt[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const size_t pix = pix00 + (size_t)(k >> 1) * W + (k & 1);
-      Vec16<T>::load_nt(y + pix * p.C + c0, yv[k]);
-      bt[k] = p.bits[pix * tpr + cv];
-    }
-    float gv[4][V];
-    pg.template pixel<0, 0>(bt[0], gv[0]);
-    pg.template pixel<0, 1>(bt[1], gv[1]);
-    pg.template pixel<1, 0>(bt[2], gv[2]);
-    pg.template pixel<1, 1>(bt[3], gv[3]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    pg.load(rg, ri, (unsigned)t, cv, a, b, p.Ho, p.Wo);
+    BlockIn<T> in;
+    in.load(ry, rb, n, a, b, p.Ho, p.Wo, cv, true);
+    auto put = [&](float (&gv)[V], const uint4& yraw, int k) __attribute__((always_inline)) {
+      float yv[V];
+      Vec16<T>::unpack(yraw, yv);
 #pragma unroll
       for (int e = 0; e < V; ++e) {
-        const float xh = (yv[k][e] - mu[e]) * is[e];
-        gv[k][e] = k0[e] * (gv[k][e] - k1[e] - xh * k2[e]);
+        const float xh = (yv[e] - mu[e]) * is[e];
+        gv[e] = k0[e] * (gv[e] - k1[e] - xh * k2[e]);
       }
-      const size_t pix = pix00 + (size_t)(k >> 1) * W + (k & 1);
-      Vec16<T>::store(dx + pix * p.C + c0, gv[k]);
-    }
+      Vec16<T>::store(dx + ((size_t)in.pix00 + (k >> 1) * W + (k & 1)) * SC + c0, gv);
+    };
+    float gv[V];
+    pg.template pixel<0, 0>(in.bt[0], gv);
+    put(gv, in.y[0], 0);
+    pg.template pixel<0, 1>(in.bt[1], gv);
+    put(gv, in.y[1], 1);
+    pg.template pixel<1, 0>(in.bt[2], gv);
+    put(gv, in.y[2], 2);
+    pg.template pixel<1, 1>(in.bt[3], gv);
+    put(gv, in.y[3], 3);
   }
 }
 
@@ -887,10 +933,12 @@ static int stem_bwd_args(StemBwdArgs& a, int dtype, const void* dp, const uint8_
                          const float* invstd, int N, int H, int W, int C) {
   MI355_TRY(check_c(dtype, C));
   const int V = 16 / (int)dtype_size(dtype);
-  MI355_ARG(dp && idx && bits && y && H % 2 == 0 && W % 2 == 0 && C / V <= 64, "stem_bwd: N=%d H=%d W=%d C=%d", N, H, W, C);
+  (void)V;
+  MI355_ARG(dp && idx && bits && y && H % 2 == 0 && W % 2 == 0 && C == SC, "stem_bwd: N=%d H=%d W=%d C=%d (64 channels)", N, H, W, C);
+  MI355_ARG((unsigned long long)N * H * W * C * dtype_size(dtype) < 0xfffffff0ull, "stem_bwd: tensor beyond 32-bit offsets");
   a = StemBwdArgs{};
   a.dp = dp; a.idx = idx; a.bits = bits; a.y = y; a.mean = mean; a.invstd = invstd;
-  a.N = N; a.Ho = H / 2; a.Wo = W / 2; a.C = C;
+  a.N = N; a.Ho = H / 2; a.Wo = W / 2;
   return 0;
 }
 
@@ -903,7 +951,8 @@ int launch_stem_bwd_reduce(int dtype, const void* dp, const uint8_t* idx, const 
   const int V = 16 / (int)dtype_size(dtype);
   const int rpp = 256 / (C / V);
   int nblk = cdiv(N * a.Ho * a.Wo, rpp * 4);
-  if (nblk > MAXBLK) nblk = MAXBLK;
+  const int cap = std::min(2 * MAXBLK, 2 * device_cus());  // one resident round of 2 workgroups per CU (<= bn_max_blocks() partial rows)
+  if (nblk > cap) nblk = cap;
   *nblk_out = nblk;
   if (dtype == MI355_F32) hipLaunchKernelGGL(stem_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(stem_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, a);

@@ -820,6 +820,8 @@ size_t igemm_sk_ws_bytes() { return IGEMM_SK_FLAG_BYTES + (size_t)512 * 128 * 12
 // conv3x3.hip: direct 3x3 / stride-1 convolution with 64 channels on both sides (layer 1)
 bool conv3_legal(const IgemmArgs& a, int nclass);
 int launch_conv3(const IgemmArgs& a, hipStream_t stream, int* stat_rows);
+bool stem_direct_legal(const IgemmArgs& a, int nclass);
+int launch_stem_direct(const IgemmArgs& a, hipStream_t stream, int* stat_rows);
 
 // conv_igemm8.hip
 bool igemm8_legal(const IgemmArgs& a, int nclass, int bn);
@@ -898,6 +900,9 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
       // than the 3-workgroups-per-CU implicit-GEMM tile (111 vs 118 us per launch from cold caches, profiles/README.md): off by default.
       const char* c3 = getenv("MI355_CONV3");
       if (c3 && c3[0] == '1' && conv3_legal(a, nclass)) return launch_conv3(a, stream, stat_rows);
+      // the stem as a direct convolution out of raw input rows (conv3x3.hip; MI355_STEM_DIRECT=0: the row-pair implicit GEMM)
+      const char* sd = getenv("MI355_STEM_DIRECT");
+      if (!(sd && sd[0] == '0') && stem_direct_legal(a, nclass)) return launch_stem_direct(a, stream, stat_rows);
     }
     {
       int bm8 = 0, bn8 = 0, ko8 = 0, fat8 = 0;

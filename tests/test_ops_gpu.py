@@ -116,6 +116,25 @@ def test_stem(dev, dtype, shape):
     assert nerr(dw, dw_ref) < TOL[dtype], "stem wgrad"
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 64), (2, 96, 128), (1, 160, 160), (1, 224, 224), (1, 320, 320)])
+def test_stem_direct_kernel_is_exact_on_integer_data(dev, shape, monkeypatch):
+    """bf16 stem forward: the direct convolution out of raw input rows (csrc/conv3x3.hip stem_direct_kernel, the default) and the
+    row-pair implicit GEMM (MI355_STEM_DIRECT=0) on small-integer data, where every fp32 partial sum is exact whatever the
+    summation order: both must equal the oracle's result rounded to bf16 BIT for bit (tile shapes: 1 ... 10 fragments per row)."""
+    from sota_imagenet_amd import ops
+
+    N, H, W = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-3, 4, (N, 3, H, W), generator=g).float()
+    w = torch.randint(-2, 3, (64, 7, 7, 3), generator=g).float()
+    y_ref = R.conv2d_fwd(R.nchw_to_nhwc(x), w, 2, 3).to(torch.bfloat16).float()
+    xpad = ops.stem_ingest(x.to(dev), torch.bfloat16)
+    for direct in ("1", "0"):
+        monkeypatch.setenv("MI355_STEM_DIRECT", direct)
+        y = ops.stem_fwd(xpad, w.to(dev), N, H, W, torch.bfloat16)
+        assert torch.equal(y.float().cpu(), y_ref), f"MI355_STEM_DIRECT={direct}"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 7, 7, 64), (4, 14, 14, 256), (2, 5, 5, 2048), (3, 9, 11, 1024), (1, 28, 28, 128)])
 @pytest.mark.parametrize("residual", [False, True])
