@@ -271,6 +271,12 @@ def main():
                     "alg_gflop_per_launch": round(flops / launches / 1e9, 3),
                     "alg_bytes_per_launch": int(nbytes / launches),
                     "event_steps": min(4, args.steps),
+                    # the roofline MODEL's ceiling for this class: min(MFMA peak, arithmetic intensity x HBM peak).  `frac` stays
+                    # achieved / MFMA peak (the number earlier rounds tracked); below the ridge the class is HBM-bound by the model
+                    "intensity_flop_per_byte": round(flops / max(nbytes, 1), 1),
+                    "ridge_flop_per_byte": round(peak * 1e12 / (PEAK_HBM_GBS * 1e9), 1),
+                    "attainable": round(min(peak, flops / max(nbytes, 1) * PEAK_HBM_GBS * 1e9 / 1e12), 1),
+                    "frac_of_attainable": round(ach / min(peak, flops / max(nbytes, 1) * PEAK_HBM_GBS * 1e9 / 1e12), 4),
                     "note": "timed with the weight-gradient side stream active: kernels of the two streams share the CUs, "
                             "so a launch takes longer than it does alone (serial_frac: same kernels, side stream off)"}
         t_ms, n_l, _, nbytes = model.profile_read(shape, HBM_CLASS)

@@ -310,6 +310,36 @@ int mi355_resnet50_segment_range(const mi355_ctx* ctx, int seg, size_t* grad_beg
 int mi355_resnet50_backward(mi355_ctx* ctx, const float* dlogits, int seg_begin, int seg_end,
                             int accumulate, void* stream);
 
+/* ---- BResNet-50 (BASELINE configs[3]) as a static executor — csrc/bresnet_exec.cpp -------------------------------------
+ * The model the reference builds with `_target_: pytorch_tools.models.resnet50` and the model_params of
+ * configs/_old_configs/_first_attempts/BResNet50_encoder.yaml:41-51 (deep stem, anti-aliasing, ECA, leaky-ReLU ABN, drop-connect,
+ * dropout) + weight standardisation of every conv (train.py:66-67): one call per forward (train.py:64 `model(data)` under
+ * callbacks.py:316) and one per backward (callbacks.py:317).  Same protocol as mi355_resnet50_*: create (device < 0: layout-only,
+ * works without a GPU), tensor table (pytorch_tools names; kind 0 parameter / 1 buffer; conv weights logical [Cout,Cin,KH,KW] over
+ * [Cout][KH][KW][Cin] memory; FC rows padded to a multiple of 128 inside the flat array), bind the three flat fp32 arrays, run.
+ *   forward   training != 0: batch statistics, running stats updated with `bn_momentum`, everything backward needs is kept.
+ *             Drop-connect / dropout (training only, rates from mi355_bresnet50_set_drop): block i > 0 scales its branch by
+ *             keep_scale(N, rate * i / 16, seed, step * 64 + i), the pooled features by keep_scale(N * 2048, drop_rate, seed,
+ *             step * 64 + 63) (mi355_keep_scale).  keep_override != NULL replaces the generator: 16 pointers, entry i = the [N]
+ *             sample scales of block i or NULL (none); dropout_override = [N][2048] scales or NULL (none) — the test hook.
+ *   backward  of the last training forward; accumulate != 0 adds to the flat gradient array.                                   */
+typedef struct mi355_bctx mi355_bctx;
+int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H, int W, int num_classes, int weight_std);
+int mi355_bresnet50_destroy(mi355_bctx* ctx);
+int mi355_bresnet50_num_tensors(const mi355_bctx* ctx);
+int mi355_bresnet50_tensor_info(const mi355_bctx* ctx, int idx, char* name, int name_cap, int* kind, size_t* offset, int* ndim,
+                                int* shape);
+size_t mi355_bresnet50_flat_param_elems(const mi355_bctx* ctx);
+size_t mi355_bresnet50_flat_buffer_elems(const mi355_bctx* ctx);
+size_t mi355_bresnet50_workspace_bytes(const mi355_bctx* ctx);
+int mi355_bresnet50_bind(mi355_bctx* ctx, float* params, float* grads, float* buffers);
+int mi355_bresnet50_set_drop(mi355_bctx* ctx, float drop_rate, float drop_connect_rate, unsigned long long seed);
+int mi355_bresnet50_forward(mi355_bctx* ctx, const float* x_nchw, float* logits, int training, float bn_momentum,
+                            unsigned long long step, const float* const* keep_override, const float* dropout_override,
+                            void* stream);
+int mi355_bresnet50_backward(mi355_bctx* ctx, const float* dlogits, int accumulate, void* stream);
+int mi355_bresnet50_flops(const mi355_bctx* ctx, double* fwd_flops, double* train_flops);
+
 /* ---- gradient collective inside the boundary: RCCL over xGMI, one process per GPU ---------------------------------
  * replaces torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) — train.py:113-114, process group
  * train.py:58-61 — i.e. the one-time rank-0 broadcast of parameters / buffers and the bucketed gradient MEAN all-reduce

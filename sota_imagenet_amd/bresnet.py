@@ -17,10 +17,14 @@ with the names / shapes pytorch_tools gives them (conv1.0.weight, layer1.0.se_mo
 Channel counts below 64 (the 3 / 32-channel stem) run zero-padded to 64, the granule of the conv kernels.  There is no CPU
 path: a CPU tensor raises.
 """
+import ctypes
+from collections import OrderedDict
+
 import torch
 import torch.nn as nn
 
 from . import ops
+from .models import _BNLeaf, _FlatModel, _ResNetFn
 
 LEAKY_ACT = 2  # activation code of the C-ABI: 0 identity, 1 ReLU, 2 leaky ReLU (0.01)
 
@@ -251,7 +255,10 @@ class _Bottleneck(nn.Module):
         return _ResidualActFn.apply(out, sc, keep, LEAKY_ACT)
 
 
-class BResNet50(nn.Module):
+class BResNet50Graph(nn.Module):
+    """the round-2 form: this graph driven from Python, one C-ABI call per op through torch.autograd nodes.  Kept as the
+    cross-check of the static executor (tests/test_variant_gpu.py: same kernels in the same order => same bits up to the FC)."""
+
     def __init__(self, num_classes=1000, dtype="bf16", drop_rate=0.0, drop_connect_rate=0.0, weight_standardization=False, seed=0, **kw):
         super().__init__()
         unknown = set(kw) - {"pretrained", "stem_type", "antialias", "attn_type", "norm_layer", "norm_act"}
@@ -329,6 +336,187 @@ class BResNet50(nn.Module):
         if train:
             self._step += 1
         return torch.nn.functional.linear(p, self.fc.weight, self.fc.bias)
+
+
+_DT = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
+
+
+def _layout(dtype_code, num_classes, wstd):
+    """tensor table of the native BResNet-50 executor: [(name, kind, offset, shape)] + flat sizes (layout-only ctx: no GPU needed)"""
+    from . import native
+
+    L = native.lib()
+    ctx = ctypes.c_void_p()
+    native.check(L.mi355_bresnet50_create(ctypes.byref(ctx), -1, dtype_code, 1, 32, 32, num_classes, int(wstd)))
+    try:
+        table = []
+        for i in range(L.mi355_bresnet50_num_tensors(ctx)):
+            name = ctypes.create_string_buffer(128)
+            kind, off, nd, sh = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_int(), (ctypes.c_int * 4)()
+            native.check(L.mi355_bresnet50_tensor_info(ctx, i, name, 128, ctypes.byref(kind), ctypes.byref(off), ctypes.byref(nd), sh))
+            table.append((name.value.decode(), kind.value, off.value, tuple(sh[j] for j in range(nd.value))))
+        return table, L.mi355_bresnet50_flat_param_elems(ctx), L.mi355_bresnet50_flat_buffer_elems(ctx)
+    finally:
+        L.mi355_bresnet50_destroy(ctx)
+
+
+class BResNet50(_FlatModel):
+    """BResNet-50 on the static executor (csrc/bresnet_exec.cpp): forward and backward are ONE C-ABI call each; every parameter
+    (pytorch_tools names / shapes, see the module docstring) is a view into one flat fp32 array, so the native SGD and the flat
+    gradient all-reduce apply as they do to models.ResNet50.  No CPU path: a CPU tensor raises."""
+
+    def __init__(self, num_classes=1000, dtype="bf16", drop_rate=0.0, drop_connect_rate=0.0, weight_standardization=False, seed=0, **kw):
+        super().__init__()
+        unknown = set(kw) - {"pretrained", "stem_type", "antialias", "attn_type", "norm_layer", "norm_act"}
+        if unknown:
+            raise TypeError(f"bresnet50: unsupported arguments {sorted(unknown)}")
+        from . import native
+
+        self.compute_dtype = _DT[str(dtype)]
+        self._dt = native.dtype_code(self.compute_dtype)
+        self.num_classes, self.drop_rate, self.drop_connect_rate, self.seed = int(num_classes), float(drop_rate), float(drop_connect_rate), int(seed)
+        self.weight_standardization = bool(weight_standardization)
+        self._table, self._nparam, self._nbuf = _layout(self._dt, self.num_classes, self.weight_standardization)
+        self._segments = [(0, self._nparam)]  # one backward call completes every gradient
+        self._flat_params = torch.zeros(self._nparam, dtype=torch.float32)
+        self._flat_grads = torch.zeros(self._nparam, dtype=torch.float32)
+        self._flat_buffers = torch.zeros(self._nbuf, dtype=torch.float32)
+        self._hook = torch.zeros(1, requires_grad=True)
+        self._ctxs = OrderedDict()
+        self._grads_dirty = False
+        self._grad_sync = None  # parallel.FlatBucketDDP: callable(segment, begin, end), run after the backward call
+        self._grad_sync_points = None
+        self._sync_grads = True
+        self._bn_leaves = []
+        self._step = 0
+        self.masks = None  # test hook: {"dc": [per block [N] fp32 or None], "do": [N, 2048] fp32 or None} overrides the sampler
+        self._build_modules()
+        self._rebind_views()
+        self.reset_parameters()
+
+    def _canonical_order(self):
+        return list(self._table)  # the executor registers in pytorch_tools' module order
+
+    def reset_parameters(self, seed=None, gamma=1.41421356):
+        """train.py:69-71 `pt.utils.misc.initialize(model, cfg.init_gamma)`: kaiming-style conv init with gain `gamma` (fan-out),
+        BN weight 1 / bias 0; the exact law of the un-vendored helper is unknown — initial weights are an
+        input of the parity tests, not a parity claim.  Same draws, in the same order, as BResNet50Graph.reset_parameters."""
+        g = torch.Generator().manual_seed(self.seed if seed is None else int(seed))
+        with torch.no_grad():
+            for leaf, attr, kind, off, shape in self._entries:
+                name = attr
+                if kind != 0:
+                    tgt = leaf._buffers[attr]
+                    tgt.fill_(1.0 if name == "running_var" else 0.0)
+                    continue
+                p = leaf._parameters[attr]
+                if len(shape) == 4:
+                    p.copy_((torch.randn(shape, generator=g) * float(gamma) / (shape[0] * shape[2] * shape[3]) ** 0.5).to(p.device))
+                elif len(shape) == 3:
+                    p.copy_(((torch.rand(shape, generator=g) * 2 - 1) * (1.0 / 3.0) ** 0.5).to(p.device))
+                elif len(shape) == 2:
+                    p.copy_(((torch.rand(shape, generator=g) * 2 - 1) / 2048 ** 0.5).to(p.device))
+                else:
+                    p.fill_(1.0 if (attr == "weight" and isinstance(leaf, _BNLeaf)) else 0.0)
+
+    # ---- native contexts ---------------------------------------------------------------------------------------------
+    def _destroy_ctxs(self):
+        if self._ctxs:
+            from . import native
+
+            L = native.lib()
+            for c in self._ctxs.values():
+                L.mi355_bresnet50_destroy(c)
+            self._ctxs.clear()
+
+    def _ctx(self, N, H, W):
+        from . import native
+
+        key = (N, H, W)
+        c = self._ctxs.get(key)
+        if c is None:
+            if not self._flat_params.is_cuda:
+                raise RuntimeError("bresnet50: the MI355X hot path has no CPU fallback — call .cuda() first")
+            if len(self._ctxs) >= 2:  # train + val batch shapes (each holds every activation AND every gradient: ~46 GB at 256 x 224 px)
+                _, old = self._ctxs.popitem(last=False)
+                native.lib().mi355_bresnet50_destroy(old)
+            L = native.lib()
+            c = ctypes.c_void_p()
+            dev = self._flat_params.device.index or 0
+            native.check(L.mi355_bresnet50_create(ctypes.byref(c), dev, self._dt, N, H, W, self.num_classes, int(self.weight_standardization)))
+            native.check(L.mi355_bresnet50_bind(c, native.ptr(self._flat_params), native.ptr(self._flat_grads), native.ptr(self._flat_buffers)))
+            self._ctxs[key] = c
+        else:
+            self._ctxs.move_to_end(key)
+        return c
+
+    def _native_forward(self, x, training):
+        from . import native
+
+        if not x.is_cuda:
+            raise RuntimeError("bresnet50: the MI355X hot path has no CPU fallback — move the model and the batch to CUDA")
+        if not (x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3):
+            raise ValueError("bresnet50 expects a CUDA float32 NCHW batch [N,3,H,W] (dali_dataloader.py:113-122 contract)")
+        x = x.contiguous()
+        N, _, H, W = x.shape
+        c = self._ctx(N, H, W)
+        L = native.lib()
+        sample = bool(self.training and torch.is_grad_enabled() and self.masks is None)  # draw drop-connect / dropout on the device
+        native.check(L.mi355_bresnet50_set_drop(c, self.drop_rate, self.drop_connect_rate, self.seed))
+        keep_arr, do_ptr, alive = None, None, []
+        if not sample:  # given masks (test hook), or none at all (eval / no_grad): the generator stays off
+            keep_arr = (ctypes.c_void_p * 16)()
+            if self.masks is not None:
+                for i, k in enumerate(self.masks["dc"]):
+                    if k is not None:
+                        k = k.to(device=x.device, dtype=torch.float32).contiguous()
+                        alive.append(k)
+                        keep_arr[i] = k.data_ptr()
+                d = self.masks.get("do")
+                if d is not None:
+                    d = d.to(device=x.device, dtype=torch.float32).contiguous()
+                    alive.append(d)
+                    do_ptr = d.data_ptr()
+        logits = torch.empty((N, self.num_classes), dtype=torch.float32, device=x.device)
+        native.check(L.mi355_bresnet50_forward(c, native.ptr(x), native.ptr(logits), int(bool(self.training)), self.bn_momentum(), self._step, keep_arr,
+                                               do_ptr, native.cur_stream()))
+        self._last = (c, x, alive)  # keep the input (and the mask tensors: copied on the stream) alive until backward
+        if self.training:
+            self._nbt += 1
+            if torch.is_grad_enabled():
+                self._step += 1
+        return logits
+
+    def _native_backward(self, dlogits):
+        from . import native
+
+        c = self._last[0]
+        self._attach_grads()
+        native.check(native.lib().mi355_bresnet50_backward(c, native.ptr(dlogits.contiguous()), int(self._grads_dirty), native.cur_stream()))
+        if self._grad_sync is not None and self._sync_grads:
+            self._grad_sync(0, 0, self._nparam)
+        self._grads_dirty = True
+
+    def set_grad_sync(self, on):
+        """DDP.no_sync(): off -> backward leaves the gradients rank-local"""
+        self._sync_grads = bool(on)
+
+    def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            return _ResNetFn.apply(x, self._hook, self)
+        return self._native_forward(x, training=self.training)
+
+    def flops(self, N, H, W):
+        """(forward, training) algorithmic FLOPs of one step at this shape (2 FLOP/MAC, conv + FC)"""
+        from . import native
+
+        L = native.lib()
+        ctx = ctypes.c_void_p()
+        native.check(L.mi355_bresnet50_create(ctypes.byref(ctx), -1, self._dt, N, H, W, self.num_classes, int(self.weight_standardization)))
+        f, t = ctypes.c_double(), ctypes.c_double()
+        native.check(L.mi355_bresnet50_flops(ctx, ctypes.byref(f), ctypes.byref(t)))
+        L.mi355_bresnet50_destroy(ctx)
+        return f.value, t.value
 
 
 def bresnet50(**kwargs):

@@ -232,6 +232,11 @@ int launch_stem_bwd_reduce(int dtype, const void* dp, const uint8_t* idx, const 
 int launch_stem_bwd_apply(int dtype, const void* dp, const uint8_t* idx, const uint8_t* bits, const void* y, const float* mean,
                           const float* invstd, const float* coef, void* dx, int N, int H, int W, int C, hipStream_t s);
 int bn_max_blocks();
+// variant.hip: glue kernels of the static BResNet-50 executor
+int launch_nchw_pad64(int dtype, const float* x_nchw, void* h_nhwc64, int N, int HW, hipStream_t s);
+int launch_weight_pad_cast(int dtype, const float* w, void* wp, int Cout, int taps, int Cin, int Coutp, int Cinp, hipStream_t s);
+int launch_weight_unpad(const float* dwp, float* dw, float beta, int Cout, int taps, int Cin, int Cinp, hipStream_t s);
+int launch_axpby(const float* src, float* dst, float beta, size_t n, hipStream_t s);
 // fp8 step: scale[i] = amax[i] > 0 ? 448 / (headroom * amax[i]) : scale[i];  amax[i] = 0   (delayed per-tensor scaling)
 int launch_fp8_scale_update(float* scale, unsigned* amax, int n, float headroom, hipStream_t s);
 

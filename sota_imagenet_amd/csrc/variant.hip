@@ -419,7 +419,82 @@ __global__ void mul_kernel(const float* a, const float* b, float* out, size_t n)
   GRID_STRIDE(i, n) out[i] = a[i] * b[i];
 }
 
+// ---- glue of the static BResNet-50 executor (bresnet_exec.cpp): what the per-op graph did with torch cat / permute / .to() --------
+// NCHW fp32 batch -> NHWC with 64 channels (3 real, 61 zero: the granule of the conv kernels): one thread per pixel and 16-byte vector
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_pad64_kernel(const float* __restrict__ x, T* __restrict__ h, int N, int HW) {
+  constexpr int V = Vec16<T>::N, CV = 64 / V;
+  const size_t total = (size_t)N * HW * CV;
+  GRID_STRIDE(i, total) {
+    const int cv = (int)(i % CV);
+    const size_t pix = i / CV;
+    float v[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = 0.f;
+    if (cv == 0) {
+      const size_t n = pix / HW, q = pix - n * HW;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = x[(n * 3 + c) * HW + q];
+    }
+    Vec16<T>::store(h + pix * 64 + cv * V, v);
+  }
+}
+
+// conv weights fp32 [Cout][taps][Cin] -> T [Coutp][taps][Cinp], zero padded
+template <typename T>
+__global__ __launch_bounds__(256) void weight_pad_cast_kernel(const float* __restrict__ w, T* __restrict__ wp, int Cout, int taps, int Cin, int Coutp, int Cinp) {
+  const size_t total = (size_t)Coutp * taps * Cinp;
+  GRID_STRIDE(i, total) {
+    const int ci = (int)(i % Cinp);
+    const size_t r = i / Cinp;
+    const int t = (int)(r % taps), co = (int)(r / taps);
+    wp[i] = (T)((co < Cout && ci < Cin) ? w[((size_t)co * taps + t) * Cin + ci] : 0.f);
+  }
+}
+
+// ... and the way back for the gradient: dw[Cout][taps][Cin] = beta * dw + dwp[Coutp][taps][Cinp] restricted
+__global__ __launch_bounds__(256) void weight_unpad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, float beta, int Cout, int taps, int Cin, int Cinp) {
+  const size_t total = (size_t)Cout * taps * Cin;
+  GRID_STRIDE(i, total) {
+    const int ci = (int)(i % Cin);
+    const size_t r = i / Cin;  // co * taps + t
+    const float g = dwp[r * Cinp + ci];
+    dw[i] = beta != 0.f ? beta * dw[i] + g : g;
+  }
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ src, float* __restrict__ dst, float beta, size_t n) {
+  GRID_STRIDE(i, n) dst[i] = beta != 0.f ? beta * dst[i] + src[i] : src[i];
+}
+
 }  // namespace
+}  // namespace mi355
+
+namespace mi355 {
+int launch_nchw_pad64(int dtype, const float* x, void* h, int N, int HW, hipStream_t s) {
+  const size_t total = (size_t)N * HW * 64;
+  if (dtype == MI355_F32) hipLaunchKernelGGL(nchw_pad64_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, x, (float*)h, N, HW);
+  else hipLaunchKernelGGL(nchw_pad64_kernel<bf16_t>, dim3(grid_for(total / 8)), dim3(256), 0, s, x, (bf16_t*)h, N, HW);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+int launch_weight_pad_cast(int dtype, const float* w, void* wp, int Cout, int taps, int Cin, int Coutp, int Cinp, hipStream_t s) {
+  const size_t total = (size_t)Coutp * taps * Cinp;
+  if (dtype == MI355_F32) hipLaunchKernelGGL(weight_pad_cast_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w, (float*)wp, Cout, taps, Cin, Coutp, Cinp);
+  else hipLaunchKernelGGL(weight_pad_cast_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, w, (bf16_t*)wp, Cout, taps, Cin, Coutp, Cinp);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+int launch_weight_unpad(const float* dwp, float* dw, float beta, int Cout, int taps, int Cin, int Cinp, hipStream_t s) {
+  hipLaunchKernelGGL(weight_unpad_kernel, dim3(grid_for((size_t)Cout * taps * Cin)), dim3(256), 0, s, dwp, dw, beta, Cout, taps, Cin, Cinp);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+int launch_axpby(const float* src, float* dst, float beta, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dst, beta, n);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
 }  // namespace mi355
 
 using namespace mi355;

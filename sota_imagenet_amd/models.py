@@ -79,60 +79,10 @@ class _ResNetFn(torch.autograd.Function):
         return None, None, None
 
 
-class ResNet50(nn.Module):
-    def __init__(self, num_classes=1000, dtype=None, pretrained=None, **unsupported):
-        super().__init__()
-        if pretrained:
-            raise ValueError("pretrained weights are not available offline")
-        # architecture kwargs of pytorch_tools.models.resnet50 that would change the graph are rejected loudly
-        for k, v in unsupported.items():
-            if v not in (None, False, "", 0, 0.0, "relu", "abn"):
-                raise NotImplementedError(f"resnet50({k}={v!r}) is outside the MI355X hot path (SURVEY.md §8f)")
-        self.num_classes = int(num_classes)
-        self.compute_dtype = _DTYPES[dtype]
-        self.fp8 = isinstance(dtype, str) and dtype in _FP8_NAMES
-        self._dt = native.FP8 if self.fp8 else native.dtype_code(self.compute_dtype)
-        table, self._nparam, self._nbuf, self._segments = _layout(self._dt, 1, 32, 32, self.num_classes)
-        self._table = table
-        self._flat_params = torch.zeros(self._nparam, dtype=torch.float32)
-        self._flat_grads = torch.zeros(self._nparam, dtype=torch.float32)
-        self._flat_buffers = torch.zeros(self._nbuf, dtype=torch.float32)
-        self._hook = torch.zeros(1, requires_grad=True)  # gives autograd an edge into _ResNetFn
-        self._ctxs = OrderedDict()  # (N,H,W) -> native ctx
-        self._grads_dirty = False
-        self._grad_sync = None  # set by parallel.FlatBucketDDP: callable(segment, begin, end)
-        self._grad_sync_points = None  # optional set of segments the hook acts on (None: after every segment)
-        self._comm = None  # (mi355_comm*, bucket cap in MiB) once a native communicator is attached
-        self._sync_grads = True  # False inside FlatBucketDDP.no_sync(): backward keeps the gradients rank-local
-        self._bn_leaves = []
-        self._build_modules()
-        self._rebind_views()
-        self.reset_parameters()
-
-    # ---- module tree with torchvision names --------------------------------------------------------------
-    def _canonical_order(self):
-        """torchvision registration order: conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var."""
-        by_name = {t[0]: t for t in self._table}
-        convs = [n[: -len(".weight")] for n, k, _, sh in self._table if k == 0 and len(sh) == 4]
-        order = []
-
-        def convbn(conv, bn):
-            order.append(by_name[conv + ".weight"])
-            for suffix in ("weight", "bias", "running_mean", "running_var"):
-                order.append(by_name[f"{bn}.{suffix}"])
-
-        convbn("conv1", "bn1")
-        blocks = sorted({c.rsplit(".", 1)[0] for c in convs if c.startswith("layer") and "downsample" not in c},
-                        key=lambda s: (int(s[5]), int(s.split(".")[1])))
-        for b in blocks:
-            for i in (1, 2, 3):
-                convbn(f"{b}.conv{i}", f"{b}.bn{i}")
-            if f"{b}.downsample.0.weight" in by_name:
-                convbn(f"{b}.downsample.0", f"{b}.downsample.1")
-        order.append(by_name["fc.weight"])
-        order.append(by_name["fc.bias"])
-        assert len(order) == len(self._table)
-        return order
+class _FlatModel(nn.Module):
+    """What the facades over the two static executors (ResNet-50 here, BResNet-50 in bresnet.py) share: every parameter / buffer is
+    a view into ONE flat fp32 array (gradients likewise) laid out by the native library; subclasses provide `_table`
+    [(name, kind, offset, shape)], `_canonical_order()`, the flat arrays, `_segments`, and `_destroy_ctxs()`."""
 
     def _leaf(self, dotted, bn=False):
         node = self
@@ -220,16 +170,6 @@ class ResNet50(nn.Module):
         self._rebind_views()
         return self
 
-    def reset_parameters(self, seed=0, gamma=1.72):
-        from .synth import init_state_dict
-
-        shapes = [(f"{self._name_of(leaf)}.{attr}", shape) for leaf, attr, kind, off, shape in self._entries]
-        sd = init_state_dict(shapes, seed=seed, gamma=gamma)
-        with torch.no_grad():
-            for (leaf, attr, kind, off, shape), (name, _) in zip(self._entries, shapes):
-                tgt = leaf._parameters[attr] if kind == 0 else leaf._buffers[attr]
-                tgt.copy_(sd[name].to(tgt.device))
-
     def _name_of(self, leaf):
         for n, m in self.named_modules():
             if m is leaf:
@@ -249,6 +189,85 @@ class ResNet50(nn.Module):
     def grad_segments(self):
         """[(begin, end)] element ranges of the flat gradient array, in backward completion order."""
         return list(self._segments)
+
+    def mark_grads_clean(self):
+        """the next backward overwrites the flat gradients instead of accumulating (optimizer.zero_grad())."""
+        self._grads_dirty = False
+
+    def __del__(self):
+        try:
+            self._destroy_ctxs()
+        except Exception:
+            pass
+
+    def bn_momentum(self):
+        return float(self._bn_leaves[0].momentum) if self._bn_leaves else 0.1
+
+
+class ResNet50(_FlatModel):
+    def __init__(self, num_classes=1000, dtype=None, pretrained=None, **unsupported):
+        super().__init__()
+        if pretrained:
+            raise ValueError("pretrained weights are not available offline")
+        # architecture kwargs of pytorch_tools.models.resnet50 that would change the graph are rejected loudly
+        for k, v in unsupported.items():
+            if v not in (None, False, "", 0, 0.0, "relu", "abn"):
+                raise NotImplementedError(f"resnet50({k}={v!r}) is outside the MI355X hot path (SURVEY.md §8f)")
+        self.num_classes = int(num_classes)
+        self.compute_dtype = _DTYPES[dtype]
+        self.fp8 = isinstance(dtype, str) and dtype in _FP8_NAMES
+        self._dt = native.FP8 if self.fp8 else native.dtype_code(self.compute_dtype)
+        table, self._nparam, self._nbuf, self._segments = _layout(self._dt, 1, 32, 32, self.num_classes)
+        self._table = table
+        self._flat_params = torch.zeros(self._nparam, dtype=torch.float32)
+        self._flat_grads = torch.zeros(self._nparam, dtype=torch.float32)
+        self._flat_buffers = torch.zeros(self._nbuf, dtype=torch.float32)
+        self._hook = torch.zeros(1, requires_grad=True)  # gives autograd an edge into _ResNetFn
+        self._ctxs = OrderedDict()  # (N,H,W) -> native ctx
+        self._grads_dirty = False
+        self._grad_sync = None  # set by parallel.FlatBucketDDP: callable(segment, begin, end)
+        self._grad_sync_points = None  # optional set of segments the hook acts on (None: after every segment)
+        self._comm = None  # (mi355_comm*, bucket cap in MiB) once a native communicator is attached
+        self._sync_grads = True  # False inside FlatBucketDDP.no_sync(): backward keeps the gradients rank-local
+        self._bn_leaves = []
+        self._build_modules()
+        self._rebind_views()
+        self.reset_parameters()
+
+    # ---- module tree with torchvision names --------------------------------------------------------------
+    def _canonical_order(self):
+        """torchvision registration order: conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var."""
+        by_name = {t[0]: t for t in self._table}
+        convs = [n[: -len(".weight")] for n, k, _, sh in self._table if k == 0 and len(sh) == 4]
+        order = []
+
+        def convbn(conv, bn):
+            order.append(by_name[conv + ".weight"])
+            for suffix in ("weight", "bias", "running_mean", "running_var"):
+                order.append(by_name[f"{bn}.{suffix}"])
+
+        convbn("conv1", "bn1")
+        blocks = sorted({c.rsplit(".", 1)[0] for c in convs if c.startswith("layer") and "downsample" not in c},
+                        key=lambda s: (int(s[5]), int(s.split(".")[1])))
+        for b in blocks:
+            for i in (1, 2, 3):
+                convbn(f"{b}.conv{i}", f"{b}.bn{i}")
+            if f"{b}.downsample.0.weight" in by_name:
+                convbn(f"{b}.downsample.0", f"{b}.downsample.1")
+        order.append(by_name["fc.weight"])
+        order.append(by_name["fc.bias"])
+        assert len(order) == len(self._table)
+        return order
+
+    def reset_parameters(self, seed=0, gamma=1.72):
+        from .synth import init_state_dict
+
+        shapes = [(f"{self._name_of(leaf)}.{attr}", shape) for leaf, attr, kind, off, shape in self._entries]
+        sd = init_state_dict(shapes, seed=seed, gamma=gamma)
+        with torch.no_grad():
+            for (leaf, attr, kind, off, shape), (name, _) in zip(self._entries, shapes):
+                tgt = leaf._parameters[attr] if kind == 0 else leaf._buffers[attr]
+                tgt.copy_(sd[name].to(tgt.device))
 
     def set_comm(self, comm, bucket_cap_mb=32.0):
         """attaches a native RCCL communicator (mi355_comm*, parallel.FlatBucketDDP owns it): every backward then reduces
@@ -279,10 +298,6 @@ class ResNet50(nn.Module):
         finally:
             L.mi355_resnet50_destroy(ctx)
 
-    def mark_grads_clean(self):
-        """the next backward overwrites the flat gradients instead of accumulating (optimizer.zero_grad())."""
-        self._grads_dirty = False
-
     # ---- native contexts -------------------------------------------------------------------------------------
     def _destroy_ctxs(self):
         if self._ctxs:
@@ -290,12 +305,6 @@ class ResNet50(nn.Module):
             for c in self._ctxs.values():
                 L.mi355_resnet50_destroy(c)
             self._ctxs.clear()
-
-    def __del__(self):
-        try:
-            self._destroy_ctxs()
-        except Exception:
-            pass
 
     def _ctx(self, N, H, W):
         key = (N, H, W)
@@ -319,9 +328,6 @@ class ResNet50(nn.Module):
         else:
             self._ctxs.move_to_end(key)
         return c
-
-    def bn_momentum(self):
-        return float(self._bn_leaves[0].momentum) if self._bn_leaves else 0.1
 
     def _native_forward(self, x, training):
         if not x.is_cuda:

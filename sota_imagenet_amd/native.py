@@ -42,7 +42,7 @@ def _ctype(decl):
     nptr += d.count("*")
     d = d.replace("*", " ").split()
     base = " ".join(d) if d[0] == "unsigned" else d[0]
-    if base in ("mi355_ctx", "mi355_comm", "mi355_crop", "mi355_augment"):
+    if base in ("mi355_ctx", "mi355_bctx", "mi355_comm", "mi355_crop", "mi355_augment"):
         return ctypes.c_void_p  # opaque handles / descriptor tables (any pointer depth)
     if base == "void" and nptr:
         return ctypes.c_void_p

@@ -196,6 +196,47 @@ def test_bresnet50_bf16_trains(dev):
     assert e.shape == (4, 1000) and torch.isfinite(e).all()
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("wstd", [True, False])
+def test_static_executor_matches_the_per_op_graph(dev, dtype, wstd, monkeypatch):
+    """csrc/bresnet_exec.cpp runs the operator sequence of bresnet.BResNet50Graph (one C-ABI call per op from Python) — same kernels,
+    same order — from C++.  With the shortcut-gradient add as its own launch (MI355_BRESNET_FUSED_ADD=0; default: in conv1's dgrad
+    epilogue) everything up to the pooled features is the same arithmetic: running statistics must be BIT-identical.  The FC is
+    fc_kernel here and torch's GEMM there, so logits and gradients agree to fp32 GEMM rounding / its bf16 amplification."""
+    from sota_imagenet_amd.bresnet import BResNet50, BResNet50Graph
+    from sota_imagenet_amd.synth import synthetic_batch
+
+    monkeypatch.setenv("MI355_BRESNET_FUSED_ADD", "0")
+    N, S = 4, 64
+    kw = dict(dtype=dtype, drop_rate=0.2, drop_connect_rate=0.2, weight_standardization=wstd)
+    m, g = BResNet50(**kw), BResNet50Graph(**kw)
+    g.load_state_dict({k: v.detach().clone().contiguous() for k, v in m.state_dict().items()})
+    m, g = m.cuda(), g.cuda()
+    data, target = synthetic_batch(N, S, seed=0, index=2, device="cuda")
+    masks = _masks(N, 3)
+    mk = {"dc": [None if k is None else k.to(dev) for k in masks["dc"]], "do": masks["do"].to(dev)}
+    m.masks, g.masks = mk, mk
+    m.train(), g.train()
+    om, og = m(data), g(data)
+    assert nerr(om, og) < 1e-5 if dtype == "fp32" else nerr(om, og) < 1e-4, f"logits {nerr(om, og):.2e}"
+    for name in ("conv1.1.running_mean", "bn1.running_var", "layer2.0.downsample.1.running_var", "layer4.2.bn3.running_mean"):
+        assert torch.equal(m.state_dict()[name], g.state_dict()[name]), name
+    R.smooth_ce(om, target, 0.1).backward()
+    R.smooth_ce(og, target, 0.1).backward()
+    gm, gg = dict(m.named_parameters()), dict(g.named_parameters())
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item()
+    tot = rel(torch.cat([p.grad.flatten() for p in gm.values()]), torch.cat([gg[k].grad.flatten() for k in gm]))
+    assert tot < (1e-4 if dtype == "fp32" else 3e-2), f"all gradients: rel L2 {tot:.2e}"
+    for name in ("fc.weight", "fc.bias", "layer4.2.se_module.conv.weight", "layer4.2.conv3.weight", "layer2.0.downsample.0.weight", "layer1.0.bn1.weight",
+                 "conv1.0.weight", "conv1.1.weight", "conv1.2.weight", "bn1.bias"):
+        r = rel(gm[name].grad, gg[name].grad)
+        assert r < (1e-3 if dtype == "fp32" else 0.1), f"{name}: {r:.2e}"
+    # a second backward into the same flat array accumulates (accumulate_steps > 1)
+    g1 = m.flat_grads.clone()
+    R.smooth_ce(m(data), target, 0.1).backward()
+    assert rel(m.flat_grads, 2 * g1) < (1e-5 if dtype == "fp32" else 2e-2)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_epilogue_statistics_feed_the_next_batchnorm(dev, dtype):
     """ops.conv2d_fwd(stats=True) returns (y, partial rows); ops.bn_fwd_train(y, ..., stats=partial) takes the sums the conv
