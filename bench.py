@@ -192,14 +192,13 @@ def main():
                   drop_connect_rate=0.2, weight_standardization=True) if variant else {}
         model = resnet50(dtype=dtype, **kw).cuda()
         criterion = CrossEntropyLoss(smoothing=0.1).cuda()
-        if variant:  # separate parameter tensors: torch's foreach SGD (one fused launch per group) instead of 177 native launches
-            opt = torch.optim.SGD(model.parameters(), lr=0.0, momentum=0.9, weight_decay=3e-5)
+        # both executors keep their parameters in one flat array: the native SGD updates it in a handful of launches
+        opt = SGD([{"params": list(model.parameters())}], lr=0.0, momentum=0.9, weight_decay=3e-5)
+        opt.attach_model(model)
+        mixer = None
+        if variant:
             from sota_imagenet_amd.callbacks import CutmixMixup
             mixer = CutmixMixup(1.0, 0.2, prob=0.5)
-        else:
-            opt = SGD([{"params": list(model.parameters())}], lr=0.0, momentum=0.9, weight_decay=3e-5)
-            opt.attach_model(model)
-            mixer = None
         net = model
         if use_ddp:
             from sota_imagenet_amd.parallel import FlatBucketDDP
@@ -324,8 +323,14 @@ def main():
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                               "config": {"workload": "BASELINE configs[3]: BResNet-50 (deep stem, anti-alias, ECA, leaky ABN, WS, drop-connect) train step "
-                                                     "with CutmixMixup on, per-op C-ABI graph", "global_batch": world * N, "image_size": S,
-                                         "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)}, "roofline": None, "cpu_baseline": None}), flush=True)
+                                                     "with CutmixMixup on, static executor (csrc/bresnet_exec.cpp)", "global_batch": world * N, "image_size": S,
+                                         "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
+                              # whole step (every kernel, not one class): algorithmic conv + FC FLOPs of a training step / step time
+                              "roofline": {"bound": "mfma", "scope": "whole step", "achieved": round(model.flops(N, S, S)[1] / (ms * 1e-3) / 1e12, 2),
+                                           "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                                           "frac": round(model.flops(N, S, S)[1] / (ms * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                                           "alg_gflop_per_step": round(model.flops(N, S, S)[1] / 1e9, 1)},
+                              "cpu_baseline": None}), flush=True)
             if use_ddp:
                 import torch.distributed as dist
 
@@ -404,12 +409,13 @@ def main():
             try:
                 kb = max(4, args.steps // 4)
                 dtb, lossb, mb, _ = run("bf16", kb, 2, False, N=256, S=S, variant=True)
+                flb = mb.flops(256, S, S)[1]
                 del mb
                 torch.cuda.empty_cache()
                 out["secondary_bresnet50"] = {"dtype": "bf16", "workload": "BASELINE configs[3] on one MI355X: BResNet-50 (deep stem, anti-alias, ECA, leaky ABN, WS, "
-                                                                           f"drop-connect) bs=256 {S}px, CutmixMixup on, per-op C-ABI graph",
+                                                                           f"drop-connect) bs=256 {S}px, CutmixMixup on, static executor (csrc/bresnet_exec.cpp)",
                                               "value": round(256 * kb / dtb, 1), "unit": "images/sec", "steps": kb, "ms_per_step": round(dtb / kb * 1e3, 3),
-                                              "final_loss": round(lossb, 4)}
+                                              "final_loss": round(lossb, 4), "step_tflops": round(flb / (dtb / kb) / 1e12, 1)}
             except Exception as e:
                 out["secondary_bresnet50"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:

@@ -80,6 +80,9 @@ class FlatBucketDDP(nn.Module):
         if self._cuda and hasattr(module, "set_comm"):
             self._native_init(flat.device, bucket_cap_mb, broadcast)
             return
+        if self._cuda:  # a flat model whose executor has no collective inside (bresnet.BResNet50: one backward call, one segment)
+            self._native_flat_init(flat.device, broadcast)
+            return
         if self._cuda:
             self._side = torch.cuda.Stream(device=flat.device)
         if broadcast:
@@ -111,6 +114,36 @@ class FlatBucketDDP(nn.Module):
         self.module.set_comm(comm, bucket_cap_mb)
         native_plan = self.module.bucket_plan(bucket_cap_mb)
         assert native_plan == self._buckets, (native_plan, self._buckets)  # one plan, stated twice (C++ / plan_buckets)
+
+    # ---- flat model, collective outside the executor: ONE native mean all-reduce over the whole flat gradient array, enqueued on
+    # the caller's stream right behind the single backward call (the optimizer step that follows on that stream sees the mean)
+    def _native_flat_init(self, device, broadcast):
+        from . import native
+
+        L = native.lib()
+        if not L.mi355_comm_available():
+            raise RuntimeError("FlatBucketDDP: librccl.so.1 not found (the MI355X data-parallel path has no fallback)")
+        rank = dist.get_rank(self.group)
+        uid = (ctypes.c_char * 128)()
+        if rank == 0:
+            native.check(L.mi355_comm_unique_id(uid))
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0, group=self.group)
+        comm = ctypes.c_void_p()
+        native.check(L.mi355_comm_create(ctypes.byref(comm), box[0], self.world, rank, device.index or 0))
+        self._comm = comm
+        m = self.module
+        if broadcast:
+            st = native.cur_stream()
+            native.check(L.mi355_comm_broadcast(comm, native.ptr(m.flat_params), m.flat_params.numel(), 0, st))
+            native.check(L.mi355_comm_broadcast(comm, native.ptr(m._flat_buffers), m._flat_buffers.numel(), 0, st))
+
+        def on_backward(seg, begin, end):
+            if seg == self._nseg - 1 and not getattr(self, "_skip_sync", False):
+                native.check(L.mi355_comm_allreduce_mean(comm, native.ptr(m.flat_grads), m.flat_grads.numel(), native.cur_stream()))
+
+        m._grad_sync = on_backward
+        m._grad_sync_points = None
 
     # ---- models without a flat gradient array (the per-op BResNet-50 graph): gradients are coalesced into one fp32 buffer
     # when backward has finished, reduced with ONE native mean all-reduce (RCCL through the C-ABI), and copied back.

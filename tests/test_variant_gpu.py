@@ -237,6 +237,40 @@ def test_static_executor_matches_the_per_op_graph(dev, dtype, wstd, monkeypatch)
     assert rel(m.flat_grads, 2 * g1) < (1e-5 if dtype == "fp32" else 2e-2)
 
 
+def test_static_executor_at_the_baseline_batch(dev):
+    """BASELINE configs[3] at its own size — bs 256, 224 px, bf16: the launch rules pick other tiles / kernels there than at the toy sizes
+    of the oracle tests (8-wave tiles, split-K plans, the 112 x 112 stem tensors).  The static executor and the per-op graph must still
+    run the same arithmetic: BIT-identical running statistics after a training forward at every depth of the net (the statistics of
+    layer 4 have seen every kernel before them), logits equal up to the FC GEMM, a loss near ln 1000, finite gradients that agree."""
+    from sota_imagenet_amd.bresnet import BResNet50, BResNet50Graph
+    from sota_imagenet_amd.synth import synthetic_batch
+
+    N, S = 256, 224
+    kw = dict(dtype="bf16", drop_rate=0.0, drop_connect_rate=0.0, weight_standardization=True)
+    m, g = BResNet50(**kw), BResNet50Graph(**kw)
+    g.load_state_dict({k: v.detach().clone().contiguous() for k, v in m.state_dict().items()})
+    m, g = m.cuda(), g.cuda()
+    data, target = synthetic_batch(N, S, seed=0, index=0, device="cuda")
+    m.train(), g.train()
+    om = m(data)
+    lm = R.smooth_ce(om, target, 0.1)
+    lm.backward()
+    og = g(data)
+    lg = R.smooth_ce(og, target, 0.1)
+    lg.backward()
+    for name in ("conv1.1.running_var", "conv1.3.running_mean", "bn1.running_var", "layer1.0.bn2.running_var", "layer2.0.downsample.1.running_mean",
+                 "layer3.5.bn3.running_var", "layer4.0.bn2.running_var", "layer4.2.bn3.running_mean"):
+        assert torch.equal(m.state_dict()[name], g.state_dict()[name]), name
+    assert nerr(om, og) < 1e-4 and abs(lm.item() - 6.9078) < 0.2 and abs(lm.item() - lg.item()) < 1e-4
+    gm, gg = dict(m.named_parameters()), dict(g.named_parameters())
+    assert torch.isfinite(m.flat_grads).all()
+    for name in ("fc.weight", "layer4.2.conv3.weight", "layer3.0.conv2.weight", "layer1.0.conv1.weight", "conv1.0.weight"):
+        a, b = gm[name].grad.float(), gg[name].grad.float()
+        assert ((a - b).norm() / b.norm()).item() < 0.1, name  # (fused shortcut add + the FC kernels: bf16 roundings, amplified backwards)
+    del g
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_epilogue_statistics_feed_the_next_batchnorm(dev, dtype):
     """ops.conv2d_fwd(stats=True) returns (y, partial rows); ops.bn_fwd_train(y, ..., stats=partial) takes the sums the conv
