@@ -137,7 +137,9 @@ struct mi355_bctx {
   hipStream_t wstream = nullptr;
   std::vector<hipEvent_t> ev;
   size_t ev_next = 0;
-  bool overlap = true, w_dirty = false, fused_add = true;
+  bool overlap = true, w_dirty = false;
+  bool fused_add = true;   // shortcut gradient added in conv1's dgrad epilogue (MI355_BRESNET_FUSED_ADD=0: its own launch, as the per-op graph)
+  bool fused_eca = true;   // ECA gate x drop-connect x shortcut add x activation in one pass each way (MI355_BRESNET_FUSED_ECA=0: op by op)
   bool have_fwd = false, dropped = false;  // state of the last forward: training pass / dropout mask in use
   double fwd_flops = 0;
 };
@@ -476,6 +478,8 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
   c->overlap = !(ov && ov[0] == '0');
   const char* fa = getenv("MI355_BRESNET_FUSED_ADD");
   c->fused_add = !(fa && fa[0] == '0');
+  const char* fe = getenv("MI355_BRESNET_FUSED_ECA");
+  c->fused_eca = !(fe && fe[0] == '0');
   bool ok = true;
   if (c->overlap) {
     ok = hipStreamCreateWithFlags(&c->wstream, hipStreamNonBlocking) == hipSuccess;
@@ -579,7 +583,7 @@ int mi355_bresnet50_forward(mi355_bctx* c, const float* x_nchw, float* logits, i
     }
     MI355_TRY(conv_bn(c, b.c3, b.b3, a2, tr, bn_momentum, s));
     const int C4 = 4 * b.planes;
-    MI355_TRY(mi355_eca_fwd(dt, b.b3.out, c->params + b.eca_off, 3, b.e, b.pooled, b.gate, N, b.Ho * b.Wo, C4, s));
+    if (!c->fused_eca) MI355_TRY(mi355_eca_fwd(dt, b.b3.out, c->params + b.eca_off, 3, b.e, b.pooled, b.gate, N, b.Ho * b.Wo, C4, s));
     const void* sc = x;
     if (b.has_ds) {
       const void* scin = x;
@@ -601,7 +605,11 @@ int mi355_bresnet50_forward(mi355_bctx* c, const float* x_nchw, float* logits, i
       MI355_TRY(mi355_keep_scale(b.keep, (size_t)N, c->drop_connect * (float)i / (float)nblocks, c->seed, step * 64 + (unsigned long long)i, s));
       b.scaled = true;
     }
-    MI355_TRY(mi355_residual_act_fwd(dt, b.e, b.scaled ? b.keep : nullptr, sc, b.out, N, (size_t)b.Ho * b.Wo * C4, ACT_LEAKY, s));
+    if (c->fused_eca)  // gate, drop-connect scale, shortcut add and activation in one pass: the gated tensor is never stored
+      MI355_TRY(launch_eca_residual_fwd(dt, b.b3.out, c->params + b.eca_off, 3, b.scaled ? b.keep : nullptr, sc, b.out, b.pooled, b.gate, N, b.Ho * b.Wo, C4,
+                                        ACT_LEAKY, s));
+    else
+      MI355_TRY(mi355_residual_act_fwd(dt, b.e, b.scaled ? b.keep : nullptr, sc, b.out, N, (size_t)b.Ho * b.Wo * C4, ACT_LEAKY, s));
     x = b.out;
   }
   // ---- head --------------------------------------------------------------------------------------------------------------------
@@ -657,9 +665,14 @@ int mi355_bresnet50_backward(mi355_bctx* c, const float* dlogits, int accumulate
     VBlock& b = c->blocks[i];
     const void* xin = i > 0 ? c->blocks[i - 1].out : c->p;
     const int C4 = 4 * b.planes;
-    MI355_TRY(mi355_residual_act_bwd(dt, g, b.out, b.scaled ? b.keep : nullptr, b.de, b.dsc, N, (size_t)b.Ho * b.Wo * C4, ACT_LEAKY, s));
-    MI355_TRY(mi355_eca_bwd(dt, b.de, b.b3.out, c->params + b.eca_off, 3, b.pooled, b.gate, b.b3.dout, c->grads + b.eca_off, beta, c->eca_ws, N,
-                            b.Ho * b.Wo, C4, s));
+    if (c->fused_eca) {
+      MI355_TRY(launch_eca_residual_bwd(dt, g, b.out, b.b3.out, b.scaled ? b.keep : nullptr, c->params + b.eca_off, 3, b.pooled, b.gate, b.dsc, b.b3.dout,
+                                        c->grads + b.eca_off, beta, c->eca_ws, N, b.Ho * b.Wo, C4, ACT_LEAKY, s));
+    } else {
+      MI355_TRY(mi355_residual_act_bwd(dt, g, b.out, b.scaled ? b.keep : nullptr, b.de, b.dsc, N, (size_t)b.Ho * b.Wo * C4, ACT_LEAKY, s));
+      MI355_TRY(mi355_eca_bwd(dt, b.de, b.b3.out, c->params + b.eca_off, 3, b.pooled, b.gate, b.b3.dout, c->grads + b.eca_off, beta, c->eca_ws, N,
+                              b.Ho * b.Wo, C4, s));
+    }
     MI355_TRY(bn_back(c, b.c3, b.b3, b.b3.dout, beta, s));
     const void* a2 = b.stride == 2 ? b.a2b : b.b2.out;
     MI355_TRY(conv_wgrad(c, b.c3, a2, beta, s));

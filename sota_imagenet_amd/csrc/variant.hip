@@ -328,6 +328,91 @@ __global__ void eca_dw_finish_kernel(const float* dwpart, float* dw, int k, floa
   dw[j] = (beta != 0.f ? beta * dw[j] : 0.f) + a;
 }
 
+// ---- ECA + drop-connect + shortcut + activation in one pass each way (the static executor, bresnet_exec.cpp) ------------------------
+// Forward: out = act(x * gate[n][c] * keep[n] + shortcut) — the gated tensor (eca_scale) is never stored.
+template <typename T>
+__global__ __launch_bounds__(256) void eca_residual_fwd_kernel(const T* x, const float* gate, const float* keep, const T* shortcut, T* out, int N, int HW,
+                                                               int C, int act) {
+  constexpr int V = Vec16<T>::N;
+  const int CV = C / V;
+  const size_t total = (size_t)N * HW * CV;
+  GRID_STRIDE(i, total) {
+    const int cv = (int)(i % CV);
+    const int n = (int)(i / ((size_t)HW * CV));
+    const float kn = keep ? keep[n] : 1.f;
+    float v[V], s[V];
+    Vec16<T>::load(x + i * V, v);
+    Vec16<T>::load(shortcut + i * V, s);
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = act_fwd(v[e] * gate[(size_t)n * C + cv * V + e] * kn + s[e], act);
+    Vec16<T>::store(out + i * V, v);
+  }
+}
+// Backward, pass 1: dz = dout * act'(out) is the shortcut gradient (stored) and, times keep[n], the gradient of the gated tensor, whose
+// product with x summed over the pixels is what the gate's backward needs: s[n][c] = sum_hw dz * keep[n] * x.  Work layout and summation
+// order of eca_prod_reduce_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void eca_residual_bwd_reduce_kernel(const T* dout, const T* out, const T* x, const float* keep, T* dshortcut, float* s, int N,
+                                                                      int HW, int C, int act) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[32][8 * V + 1];
+  const int slabs = C / (8 * V);
+  const int n = blockIdx.x / slabs, c0 = (blockIdx.x % slabs) * 8 * V;
+  const int cv = threadIdx.x & 7, r = threadIdx.x >> 3;
+  const float kn = keep ? keep[n] : 1.f;
+  float acc[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) acc[e] = 0.f;
+  for (int p = r; p < HW; p += 32) {
+    const size_t o = ((size_t)n * HW + p) * C + c0 + cv * V;
+    float g[V], ov[V], xv[V];
+    Vec16<T>::load(dout + o, g);
+    Vec16<T>::load(out + o, ov);
+    Vec16<T>::load(x + o, xv);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      g[e] *= act_slope(ov[e], act);
+      acc[e] += g[e] * kn * xv[e];
+    }
+    Vec16<T>::store(dshortcut + o, g);
+  }
+#pragma unroll
+  for (int e = 0; e < V; ++e) red[r][cv * V + e] = acc[e];
+  __syncthreads();
+  for (int st = 16; st > 0; st >>= 1) {
+    if (r < st) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) red[r][cv * V + e] += red[r + st][cv * V + e];
+    }
+    __syncthreads();
+  }
+  if (r == 0) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) s[(size_t)n * C + c0 + cv * V + e] = red[0][cv * V + e];
+  }
+}
+// pass 2: dx = dz * keep[n] * gate[n][c] + dpool[n][c]
+template <typename T>
+__global__ __launch_bounds__(256) void eca_residual_bwd_apply_kernel(const T* dz, const float* gate, const float* dpool, const float* keep, T* dx, int N, int HW,
+                                                                     int C) {
+  constexpr int V = Vec16<T>::N;
+  const int CV = C / V;
+  const size_t total = (size_t)N * HW * CV;
+  GRID_STRIDE(i, total) {
+    const int cv = (int)(i % CV);
+    const int n = (int)(i / ((size_t)HW * CV));
+    const float kn = keep ? keep[n] : 1.f;
+    float v[V];
+    Vec16<T>::load(dz + i * V, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const size_t g = (size_t)n * C + cv * V + e;
+      v[e] = v[e] * kn * gate[g] + dpool[g];
+    }
+    Vec16<T>::store(dx + i * V, v);
+  }
+}
+
 // ---- weight standardisation: one workgroup per output channel ---------------------------------------------------------
 __global__ __launch_bounds__(256) void weight_std_fwd_kernel(const float* w, float* w_hat, float* mean, float* invstd, int K, float eps) {
   __shared__ double r1[256], r2[256];
@@ -487,6 +572,39 @@ int launch_weight_pad_cast(int dtype, const float* w, void* wp, int Cout, int ta
 }
 int launch_weight_unpad(const float* dwp, float* dw, float beta, int Cout, int taps, int Cin, int Cinp, hipStream_t s) {
   hipLaunchKernelGGL(weight_unpad_kernel, dim3(grid_for((size_t)Cout * taps * Cin)), dim3(256), 0, s, dwp, dw, beta, Cout, taps, Cin, Cinp);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+// out = act(eca(x) * keep[n] + shortcut); pooled / gate [N][C] are kept for backward (k = 3 ... 9 odd)
+int launch_eca_residual_fwd(int dtype, const void* x, const float* w, int k, const float* keep, const void* shortcut, void* out, float* pooled, float* gate,
+                            int N, int HW, int C, int act, hipStream_t s) {
+  MI355_TRY(mi355_gap_fwd(dtype, x, pooled, N, HW, C, s));
+  hipLaunchKernelGGL(eca_gate_kernel, dim3(grid_for((size_t)N * C)), dim3(256), 0, s, pooled, w, k, gate, N, C);
+  const size_t total = (size_t)N * HW * C;
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL(eca_residual_fwd_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)x, gate, keep, (const float*)shortcut, (float*)out, N, HW, C, act);
+  else
+    hipLaunchKernelGGL(eca_residual_fwd_kernel<bf16_t>, dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)x, gate, keep, (const bf16_t*)shortcut, (bf16_t*)out, N, HW, C, act);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
+// its backward from dout: dshortcut (the shortcut operand's gradient), dx (the ECA input's), dw[k] (beta 0 / 1); ws: 2*N*C + 1152 floats
+int launch_eca_residual_bwd(int dtype, const void* dout, const void* out, const void* x, const float* keep, const float* w, int k, const float* pooled,
+                            const float* gate, void* dshortcut, void* dx, float* dw, float beta, float* ws, int N, int HW, int C, int act, hipStream_t s) {
+  float *sprod = ws, *dpool = ws + (size_t)N * C, *dwpart = ws + (size_t)2 * N * C;
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL(eca_residual_bwd_reduce_kernel<float>, dim3(N * (C / 32)), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)x, keep,
+                       (float*)dshortcut, sprod, N, HW, C, act);
+  else
+    hipLaunchKernelGGL(eca_residual_bwd_reduce_kernel<bf16_t>, dim3(N * (C / 64)), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x,
+                       keep, (bf16_t*)dshortcut, sprod, N, HW, C, act);
+  hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3(ECA_GB), dim3(256), 0, s, sprod, gate, pooled, w, k, dpool, dwpart, N, C, 1.f / (float)HW);
+  hipLaunchKernelGGL(eca_dw_finish_kernel, dim3(1), dim3(64), 0, s, dwpart, dw, k, beta);
+  const size_t total = (size_t)N * HW * C;
+  if (dtype == MI355_F32)
+    hipLaunchKernelGGL(eca_residual_bwd_apply_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)dshortcut, gate, dpool, keep, (float*)dx, N, HW, C);
+  else
+    hipLaunchKernelGGL(eca_residual_bwd_apply_kernel<bf16_t>, dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)dshortcut, gate, dpool, keep, (bf16_t*)dx, N, HW, C);
   MI355_LAUNCH_CHECK();
   return 0;
 }

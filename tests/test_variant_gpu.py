@@ -201,12 +201,14 @@ def test_bresnet50_bf16_trains(dev):
 def test_static_executor_matches_the_per_op_graph(dev, dtype, wstd, monkeypatch):
     """csrc/bresnet_exec.cpp runs the operator sequence of bresnet.BResNet50Graph (one C-ABI call per op from Python) — same kernels,
     same order — from C++.  With the shortcut-gradient add as its own launch (MI355_BRESNET_FUSED_ADD=0; default: in conv1's dgrad
-    epilogue) everything up to the pooled features is the same arithmetic: running statistics must be BIT-identical.  The FC is
+    epilogue) and the ECA / residual tail op by op (MI355_BRESNET_FUSED_ECA=0; default: one fused pass each way) everything up to the
+    pooled features is the same arithmetic: running statistics must be BIT-identical.  The FC is
     fc_kernel here and torch's GEMM there, so logits and gradients agree to fp32 GEMM rounding / its bf16 amplification."""
     from sota_imagenet_amd.bresnet import BResNet50, BResNet50Graph
     from sota_imagenet_amd.synth import synthetic_batch
 
     monkeypatch.setenv("MI355_BRESNET_FUSED_ADD", "0")
+    monkeypatch.setenv("MI355_BRESNET_FUSED_ECA", "0")
     N, S = 4, 64
     kw = dict(dtype=dtype, drop_rate=0.2, drop_connect_rate=0.2, weight_standardization=wstd)
     m, g = BResNet50(**kw), BResNet50Graph(**kw)
@@ -237,7 +239,7 @@ def test_static_executor_matches_the_per_op_graph(dev, dtype, wstd, monkeypatch)
     assert rel(m.flat_grads, 2 * g1) < (1e-5 if dtype == "fp32" else 2e-2)
 
 
-def test_static_executor_at_the_baseline_batch(dev):
+def test_static_executor_at_the_baseline_batch(dev, monkeypatch):
     """BASELINE configs[3] at its own size — bs 256, 224 px, bf16: the launch rules pick other tiles / kernels there than at the toy sizes
     of the oracle tests (8-wave tiles, split-K plans, the 112 x 112 stem tensors).  The static executor and the per-op graph must still
     run the same arithmetic: BIT-identical running statistics after a training forward at every depth of the net (the statistics of
@@ -245,6 +247,7 @@ def test_static_executor_at_the_baseline_batch(dev):
     from sota_imagenet_amd.bresnet import BResNet50, BResNet50Graph
     from sota_imagenet_amd.synth import synthetic_batch
 
+    monkeypatch.setenv("MI355_BRESNET_FUSED_ECA", "0")  # (the fused tail skips one bf16 rounding of the gated tensor: not the graph's bits)
     N, S = 256, 224
     kw = dict(dtype="bf16", drop_rate=0.0, drop_connect_rate=0.0, weight_standardization=True)
     m, g = BResNet50(**kw), BResNet50Graph(**kw)
