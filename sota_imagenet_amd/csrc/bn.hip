@@ -86,7 +86,7 @@ struct ReduceArgs {
 };
 
 // MODE 0: s1 = sum x, s2 = sum x^2.   MODE 1: s1 = sum dz, s2 = sum dz*xhat.
-// MASK (MODE 1): 0 none, 1 post-activation tensor, 2 bit mask;  DZ: also store the masked gradient.
+// MASK (MODE 1): 0 none, 1 post-activation tensor (slope), 2 bit mask (ReLU), 3 bit mask + slope (leaky ReLU);  DZ: also store the masked gradient.
 // The variants are template parameters, not runtime branches: a branch in the loop body keeps the compiler from
 // hoisting the loads of the unrolled iterations above the arithmetic, and these kernels live on loads in flight.
 template <typename T, int MODE, int MASK, bool DZ>
@@ -147,6 +147,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
         const unsigned b = p.bits[off / V];
 #pragma unroll
         for (int e = 0; e < V; ++e) gv[e] = (b >> e) & 1u ? gv[e] : 0.f;
+      } else if constexpr (MASK == 3) {  // bit mask of a leaky ReLU
+        const unsigned b = p.bits[off / V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) gv[e] = (b >> e) & 1u ? gv[e] : gv[e] * p.slope;
       } else if constexpr (MASK == 1) {
         float mv[V];
         Vec16<T>::load(mk + off, mv);
@@ -325,7 +329,8 @@ struct ApplyArgs {
   QuantOut qo;    // Q: e4m3 twin of `out`
 };
 
-// RES: + residual;  X2: + second normalised tensor (downsample branch);  RELU: 0 none, 1 relu, 2 relu + bit mask out
+// RES: + residual;  X2: + second normalised tensor (downsample branch);  RELU: 0 none, 1 (leaky) relu with p.slope, 2 relu + bit mask out,
+// 3 leaky relu with p.slope + bit mask out (the BResNet-50 executor)
 // Q (bf16 only): also the e4m3 twin of the output + its amax (fp8 training step)
 template <typename T, bool RES, bool X2, int RELU, bool Q = false, bool QONLY = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
@@ -372,14 +377,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
       for (int e = 0; e < V; ++e) v[e] += fmaf(rv[e], sc2[e], sh2[e]);
     }
     if constexpr (RELU != 0) {
-      if constexpr (RELU == 2) {
+      if constexpr (RELU == 2 || RELU == 3) {
         unsigned b = 0;
 #pragma unroll
         for (int e = 0; e < V; ++e) b |= (v[e] > 0.f ? 1u : 0u) << e;
         __builtin_nontemporal_store((uint8_t)b, p.bits + i);  // read in backward only
       }
 #pragma unroll
-      for (int e = 0; e < V; ++e) v[e] = v[e] > 0.f ? v[e] : (RELU == 1 ? v[e] * p.slope : 0.f);  // (bit-mask form: ReLU only)
+      for (int e = 0; e < V; ++e) v[e] = v[e] > 0.f ? v[e] : (RELU == 2 ? 0.f : v[e] * p.slope);
     }
     if constexpr (!QONLY) Vec16<T>::store(out + i * V, v);
     if constexpr (Q) quant8(v, qs, p.qo.q + i * V, amax);
@@ -430,6 +435,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p)
       const unsigned b = p.bits[i];
 #pragma unroll
       for (int e = 0; e < V; ++e) gv[e] = (b >> e) & 1u ? gv[e] : 0.f;
+    } else if constexpr (MASK == 3) {
+      const unsigned b = p.bits[i];
+#pragma unroll
+      for (int e = 0; e < V; ++e) gv[e] = (b >> e) & 1u ? gv[e] : gv[e] * p.slope;
     } else if constexpr (MASK == 1) {
       float mv[V];
       Vec16<T>::load(mk + i * V, mv);
@@ -803,6 +812,13 @@ int launch_bn_apply(int dtype, const void* x, const float* scale, const float* s
   const int rl = relu ? (relu_bits ? 2 : 1) : 0;
   const int variant = (residual ? 6 : 0) + (x2 ? 3 : 0) + rl;
   MI355_ARG(!(residual && x2), "bn_apply: residual and second branch together are not supported");
+  if (relu == 2 && relu_bits) {  // leaky ReLU + bit mask
+    MI355_ARG(!residual && !x2, "bn_apply: the leaky bit-mask form has no residual / second-branch variant");
+    if (dtype == MI355_F32) hipLaunchKernelGGL((bn_apply_kernel<float, false, false, 3>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false, false, 3>), dim3(blocks), dim3(256), 0, s, a);
+    MI355_LAUNCH_CHECK();
+    return 0;
+  }
 #define MI355_BN_APPLY(TT)                                                                                      \
   switch (variant) {                                                                                            \
     case 0: hipLaunchKernelGGL((bn_apply_kernel<TT, false, false, 0>), dim3(blocks), dim3(256), 0, s, a); break; \
@@ -844,7 +860,7 @@ int launch_bn_bwd_reduce(int dtype, const void* g, const void* mask_src, const v
   a.C = C;
   dim3 grid;
   *nblk_out = reduce_grid(dtype, M, C, &grid);
-  const int mask = relu_bits ? 2 : mask_src ? 1 : 0;
+  const int mask = relu_bits ? (slope != 0.f ? 3 : 2) : mask_src ? 1 : 0;
   const int variant = mask * 2 + (dz_out ? 1 : 0);
 #define MI355_BN_REDUCE(TT)                                                                                     \
   switch (variant) {                                                                                            \
@@ -853,7 +869,9 @@ int launch_bn_bwd_reduce(int dtype, const void* g, const void* mask_src, const v
     case 2: hipLaunchKernelGGL((bn_reduce_kernel<TT, 1, 1, false>), grid, dim3(256), 0, s, a); break;           \
     case 3: hipLaunchKernelGGL((bn_reduce_kernel<TT, 1, 1, true>), grid, dim3(256), 0, s, a); break;            \
     case 4: hipLaunchKernelGGL((bn_reduce_kernel<TT, 1, 2, false>), grid, dim3(256), 0, s, a); break;           \
-    default: hipLaunchKernelGGL((bn_reduce_kernel<TT, 1, 2, true>), grid, dim3(256), 0, s, a); break;           \
+    case 5: hipLaunchKernelGGL((bn_reduce_kernel<TT, 1, 2, true>), grid, dim3(256), 0, s, a); break;            \
+    case 6: hipLaunchKernelGGL((bn_reduce_kernel<TT, 1, 3, false>), grid, dim3(256), 0, s, a); break;           \
+    default: hipLaunchKernelGGL((bn_reduce_kernel<TT, 1, 3, true>), grid, dim3(256), 0, s, a); break;           \
   }
   if (dtype == MI355_F32) {
     MI355_BN_REDUCE(float)
@@ -902,10 +920,10 @@ int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const vo
   a.cvecs = C / V;
   a.C = C;
   const int blocks = elementwise_blocks(a.nvec, a.cvecs);
-  const int mask = relu_bits ? 2 : mask_src ? 1 : 0;
+  const int mask = relu_bits ? (slope != 0.f ? 3 : 2) : mask_src ? 1 : 0;
   a.qo = qo;
   if (qo.q) {
-    MI355_ARG(dtype == MI355_BF16 && mask != 1 && qo.scale && qo.amax, "bn_bwd_apply: the e4m3 twin needs bf16 and a bit mask (or none)");
+    MI355_ARG(dtype == MI355_BF16 && mask != 1 && mask != 3 && qo.scale && qo.amax, "bn_bwd_apply: the e4m3 twin needs bf16 and a ReLU bit mask (or none)");
     if (mask == 2 && qo.only) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 2, true, true>), dim3(blocks), dim3(256), 0, s, a);
     else if (mask == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 2, true>), dim3(blocks), dim3(256), 0, s, a);
     else if (qo.only) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0, true, true>), dim3(blocks), dim3(256), 0, s, a);
@@ -917,7 +935,8 @@ int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const vo
   switch (mask) {                                                                                               \
     case 0: hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, 0>), dim3(blocks), dim3(256), 0, s, a); break;          \
     case 1: hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, 1>), dim3(blocks), dim3(256), 0, s, a); break;          \
-    default: hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, 2>), dim3(blocks), dim3(256), 0, s, a); break;         \
+    case 2: hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, 2>), dim3(blocks), dim3(256), 0, s, a); break;          \
+    default: hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, 3>), dim3(blocks), dim3(256), 0, s, a); break;         \
   }
   if (dtype == MI355_F32) {
     MI355_BN_BWD_APPLY(float)

@@ -69,6 +69,8 @@ struct VBN {
   float *mean = nullptr, *invstd = nullptr;  // [Cp] batch statistics kept for backward
   void* out = nullptr;      // activation
   void* dout = nullptr;     // gradient wrt the activation
+  uint8_t* bits = nullptr;  // leaky-ReLU mask of `out` (bit e of byte i = element e of 16-byte vector i was > 0), written by the training forward
+  bool has_bits = false;    // ... by the last one
 };
 
 struct VBlock {
@@ -139,6 +141,7 @@ struct mi355_bctx {
   size_t ev_next = 0;
   bool overlap = true, w_dirty = false;
   bool fused_add = true;   // shortcut gradient added in conv1's dgrad epilogue (MI355_BRESNET_FUSED_ADD=0: its own launch, as the per-op graph)
+  bool use_bits = true;    // leaky-ReLU masks travel as one bit per element (MI355_BRESNET_BITS=0: backward reads the activation itself)
   bool fused_eca = true;   // ECA gate x drop-connect x shortcut add x activation in one pass each way (MI355_BRESNET_FUSED_ECA=0: op by op)
   bool have_fwd = false, dropped = false;  // state of the last forward: training pass / dropout mask in use
   double fwd_flops = 0;
@@ -204,6 +207,7 @@ void plan_bn(mi355_bctx* c, Arena& ar, VBN& b, int H, int W, bool want_dout = tr
   const size_t o = (size_t)c->N * H * W * b.Cp * c->es;
   ar.add(&b.out, o);
   if (want_dout) ar.add(&b.dout, o);
+  if (b.act != ACT_NONE) ar.add(&b.bits, o / 16);
 }
 
 int fork(mi355_bctx* c, hipStream_t s, hipStream_t* w) {
@@ -269,12 +273,19 @@ int conv_bn(mi355_bctx* c, VConv& v, VBN& b, const void* in, bool training, floa
   int nblk = 0;
   MI355_TRY(mi355_conv2d_fwd_stats(c->dtype, in, v.wp, v.y, c->partial, c->partial_bytes, &nblk, c->N, v.Hin, v.Win, v.Cinp, v.Coutp, v.K, v.K,
                                    v.stride, v.pad, s));
-  if (nblk > 0)
-    MI355_TRY(mi355_bn_fwd_train_partial(c->dtype, v.y, nullptr, b.out, q.g, q.b, q.rm, q.rv, b.mean, b.invstd, M, b.Cp, BN_EPS, momentum, b.act,
-                                         c->partial, nblk, c->bn_ws, c->bn_ws_bytes, s));
-  else
+  b.has_bits = false;
+  if (nblk > 0) {
+    // finalize from the conv epilogue's partial rows, then normalise + activate; the activation's sign goes out as one bit per element
+    // (backward then reads 1/16 of a tensor instead of `out` itself, in both of its passes)
+    float *scale = (float*)c->bn_ws, *shift = scale + b.Cp;
+    MI355_TRY(launch_bn_finalize(c->partial, nullptr, nblk, M, b.Cp, q.g, q.b, q.rm, q.rv, b.mean, b.invstd, scale, shift, BN_EPS, momentum, s));
+    uint8_t* bits = (c->use_bits && b.act != ACT_NONE) ? b.bits : nullptr;
+    MI355_TRY(launch_bn_apply(c->dtype, v.y, scale, shift, nullptr, nullptr, nullptr, nullptr, b.out, M, b.Cp, b.act, s, bits));
+    b.has_bits = bits != nullptr;
+  } else {
     MI355_TRY(mi355_bn_fwd_train(c->dtype, v.y, nullptr, b.out, q.g, q.b, q.rm, q.rv, b.mean, b.invstd, M, b.Cp, BN_EPS, momentum, b.act, c->bn_ws,
                                  c->bn_ws_bytes, s));
+  }
   if (b.Cp != b.C) {  // running statistics back into the flat buffer array
     MI355_HIP(hipMemcpyAsync(c->buffers + b.rm_off, q.rm, (size_t)b.C * 4, hipMemcpyDeviceToDevice, s));
     MI355_HIP(hipMemcpyAsync(c->buffers + b.rv_off, q.rv, (size_t)b.C * 4, hipMemcpyDeviceToDevice, s));
@@ -288,8 +299,17 @@ int bn_back(mi355_bctx* c, VConv& v, VBN& b, const void* dout, float beta, hipSt
   BNP q;
   MI355_TRY(bn_params(c, b, q, false, s));  // (the staged gamma of this step's forward is still there)
   const bool staged = b.Cp != b.C;
-  MI355_TRY(mi355_bn_bwd(c->dtype, dout, b.out, v.y, q.g, b.mean, b.invstd, v.dy, nullptr, q.dg, q.db, staged ? 0.f : beta, M, b.Cp, b.act, c->bn_ws,
-                         c->bn_ws_bytes, s));
+  {
+    float* partial = (float*)c->bn_ws;
+    float* coef = partial + (size_t)bn_max_blocks() * 2 * b.Cp;
+    const uint8_t* bits = b.has_bits ? b.bits : nullptr;
+    const void* mask = (b.act != ACT_NONE && !bits) ? b.out : nullptr;
+    const float slope = b.act == ACT_LEAKY ? 0.01f : 0.f;
+    int nblk = 0;
+    MI355_TRY(launch_bn_bwd_reduce(c->dtype, dout, mask, v.y, b.mean, b.invstd, nullptr, partial, &nblk, M, b.Cp, s, bits, slope));
+    MI355_TRY(launch_bn_bwd_finalize(partial, nblk, M, b.Cp, q.g, b.invstd, q.dg, q.db, staged ? 0.f : beta, coef, s));
+    MI355_TRY(launch_bn_bwd_apply(c->dtype, dout, mask, v.y, b.mean, b.invstd, coef, v.dy, M, b.Cp, s, bits, slope));
+  }
   if (staged) {
     MI355_TRY(launch_axpby(q.dg, c->grads + b.g_off, beta, (size_t)b.C, s));
     MI355_TRY(launch_axpby(q.db, c->grads + b.b_off, beta, (size_t)b.C, s));
@@ -478,6 +498,8 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
   c->overlap = !(ov && ov[0] == '0');
   const char* fa = getenv("MI355_BRESNET_FUSED_ADD");
   c->fused_add = !(fa && fa[0] == '0');
+  const char* ub = getenv("MI355_BRESNET_BITS");
+  c->use_bits = !(ub && ub[0] == '0');
   const char* fe = getenv("MI355_BRESNET_FUSED_ECA");
   c->fused_eca = !(fe && fe[0] == '0');
   bool ok = true;
