@@ -180,8 +180,17 @@ __global__ __launch_bounds__(256) void maxpool3s1_fwd_kernel(const T* x, T* y, u
       }
     }
     Vec16<T>::store(y + i * V, best);
+    // the V argmax codes of a thread are V consecutive bytes: one 4- / 8-byte store instead of V byte stores
+    uint32_t w0 = 0, w1 = 0;
 #pragma unroll
-    for (int e = 0; e < V; ++e) idx[i * V + e] = (uint8_t)bi[e];
+    for (int e = 0; e < 4; ++e) w0 |= (uint32_t)bi[e] << (8 * e);
+    if constexpr (V == 8) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w1 |= (uint32_t)bi[4 + e] << (8 * e);
+      *reinterpret_cast<uint2*>(idx + i * V) = make_uint2(w0, w1);
+    } else {
+      *reinterpret_cast<uint32_t*>(idx + i * V) = w0;
+    }
   }
 }
 template <typename T>
@@ -209,8 +218,16 @@ __global__ __launch_bounds__(256) void maxpool3s1_bwd_kernel(const T* dy, const 
         const size_t o = (((size_t)n * H + oh) * W + ow) * C + cv * V;
         float v[V];
         Vec16<T>::load(dy + o, v);
+        uint32_t w[V / 4];
+        if constexpr (V == 8) {
+          const uint2 t2 = *reinterpret_cast<const uint2*>(idx + o);
+          w[0] = t2.x;
+          w[1] = t2.y;
+        } else {
+          w[0] = *reinterpret_cast<const uint32_t*>(idx + o);
+        }
 #pragma unroll
-        for (int e = 0; e < V; ++e) acc[e] += idx[o + e] == a * 3 + b ? v[e] : 0.f;
+        for (int e = 0; e < V; ++e) acc[e] += ((w[e >> 2] >> (8 * (e & 3))) & 0xffu) == (unsigned)(a * 3 + b) ? v[e] : 0.f;
       }
     }
     Vec16<T>::store(dx + i * V, acc);
