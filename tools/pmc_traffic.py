@@ -20,7 +20,8 @@ import sys
 
 def short(n):
     m = re.search(r"(igemm8_kernel|igemm_kernel|wgrad_kernel|bn_reduce_kernel|bn_apply_kernel|bn_bwd_apply_kernel|bn_finalize_kernel|"
-                  r"splitk_reduce_kernel|sgd_kernel|fc_kernel|dbias_kernel|ce_row_kernel|bn_relu_maxpool_kernel|maxpool_\w+_kernel|gap_\w+_kernel|stem_ingest_kernel|weight_prep_batch_kernel|weight_prep_kernel)", n)
+                  r"splitk_reduce_kernel|sgd_kernel|fc_kernel|dbias_kernel|ce_row_kernel|bn_relu_maxpool\d?_kernel|maxpool_\w+_kernel|gap_\w+_kernel|stem_ingest_kernel|"
+                  r"stem_direct_kernel|stem_bwd_reduce_kernel|stem_bwd_apply_kernel|weight_prep_batch_kernel|weight_prep_kernel)", n)
     if not m:
         return None
     base = m.group(1)
