@@ -54,6 +54,7 @@ struct VConv {
   float* ws_mean = nullptr; // [Cout]
   float* ws_invstd = nullptr;
   void* wp = nullptr;       // [Coutp][K][K][Cinp] in the compute dtype: what the kernels read
+  void* wtr = nullptr;      // [Cinp][K][K][Coutp]: the same weights transposed, what the data-gradient convolution reads
   void* y = nullptr;        // conv output [N][Hout][Wout][Coutp]
   void* dy = nullptr;       // its gradient
   bool padded() const { return Cin != Cinp || Cout != Coutp; }
@@ -196,6 +197,7 @@ void plan_conv(mi355_bctx* c, Arena& ar, VConv& v) {
     ar.add(&v.ws_invstd, (size_t)v.Cout * 4);
   }
   ar.add(&v.wp, v.wpelems() * c->es);
+  ar.add(&v.wtr, v.wpelems() * c->es);
   const size_t o = (size_t)c->N * v.Hout * v.Wout * v.Coutp * c->es;
   ar.add(&v.y, o);
   ar.add(&v.dy, o);
@@ -337,8 +339,14 @@ int conv_wgrad(mi355_bctx* c, VConv& v, const void* in, float beta, hipStream_t 
   return 0;
 }
 
+// dx = conv_transpose(v.dy) (+ addend), from the transposed weights the forward's weight preparation left in v.wtr (mi355_conv2d_dgrad
+// would transpose them again in front of every launch: 54 small kernels on backward's critical path)
 int conv_dgrad(mi355_bctx* c, VConv& v, void* dx, const void* addend, hipStream_t s) {
-  return mi355_conv2d_dgrad(c->dtype, v.dy, v.wp, dx, addend, c->N, v.Hin, v.Win, v.Cinp, v.Coutp, v.K, v.K, v.stride, v.pad, c->dg_ws, c->dg_ws_bytes, s);
+  IgemmArgs a;
+  const int nclass = build_dgrad_args(a, c->N, v.Hin, v.Win, v.Cinp, v.Coutp, v.K, v.K, v.stride, v.pad);
+  if (nclass < 0) return nclass;
+  a.in = v.dy; a.wt = v.wtr; a.out = dx; a.addend = addend;
+  return launch_igemm(c->dtype, a, nclass, s);
 }
 
 size_t conv_ws_bytes(const mi355_bctx* c, const VConv& v) {
@@ -578,15 +586,22 @@ int mi355_bresnet50_forward(mi355_bctx* c, const float* x_nchw, float* logits, i
   const bool tr = training != 0;
   MI355_TRY(join(c, s));  // (a previous backward's side-stream work reads the tensors this pass overwrites)
   // ---- weight preparation: [standardise] -> pad -> cast; FC weights transposed for the input gradient ------------------------------
+  // The first conv's weights on the caller's stream; everything else (106 + 54 small launches) on the side stream, beside the input
+  // conversion and the first conv, which only have to wait for their own.
+  MI355_TRY(prep_weight(c, c->s0, s));
+  hipStream_t ps;
+  MI355_TRY(fork(c, s, &ps));
   int rc = 0;
   for_each_conv(c, [&](VConv& v) {
-    if (rc == 0) rc = prep_weight(c, v, s);
+    if (rc == 0 && &v != &c->s0) rc = prep_weight(c, v, ps);
+    if (rc == 0 && tr && &v != &c->s0) rc = launch_transpose_any(dt, v.wp, v.wtr, v.Coutp, v.K * v.K, v.Cinp, ps);
   });
   if (rc) return rc;
-  if (tr) MI355_TRY(launch_weight_prep(MI355_F32, c->params + c->fc_w_off, nullptr, c->fc_wtr, c->fc_pad, 1, 2048, s));
+  if (tr) MI355_TRY(launch_weight_prep(MI355_F32, c->params + c->fc_w_off, nullptr, c->fc_wtr, c->fc_pad, 1, 2048, ps));
   // ---- stem --------------------------------------------------------------------------------------------------------------------
   MI355_TRY(launch_nchw_pad64(dt, x_nchw, c->h0, N, c->H * c->W, s));
   MI355_TRY(conv_bn(c, c->s0, c->sb0, c->h0, tr, bn_momentum, s));
+  MI355_TRY(join(c, s));  // the prepared weights of every later layer
   MI355_TRY(conv_bn(c, c->s1, c->sb1, c->sb0.out, tr, bn_momentum, s));
   MI355_TRY(conv_bn(c, c->s2, c->sb2, c->sb1.out, tr, bn_momentum, s));
   MI355_TRY(mi355_maxpool3s1_fwd(dt, c->sb2.out, c->m, c->pool_idx, N, c->H / 2, c->W / 2, 64, s));
