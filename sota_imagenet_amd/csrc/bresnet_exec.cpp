@@ -70,6 +70,8 @@ struct VBN {
   float *mean = nullptr, *invstd = nullptr;  // [Cp] batch statistics kept for backward
   void* out = nullptr;      // activation
   void* dout = nullptr;     // gradient wrt the activation
+  float *scale = nullptr, *shift = nullptr;  // [Cp] the normalisation as y * scale + shift (kept when the consumer applies it on the fly)
+  bool lazy = false;        // last forward: `out` was NOT written, the consumer reads (conv output, scale, shift)
   uint8_t* bits = nullptr;  // leaky-ReLU mask of `out` (bit e of byte i = element e of 16-byte vector i was > 0), written by the training forward
   bool has_bits = false;    // ... by the last one
 };
@@ -143,6 +145,7 @@ struct mi355_bctx {
   bool overlap = true, w_dirty = false;
   bool fused_add = true;   // shortcut gradient added in conv1's dgrad epilogue (MI355_BRESNET_FUSED_ADD=0: its own launch, as the per-op graph)
   bool use_bits = true;    // leaky-ReLU masks travel as one bit per element (MI355_BRESNET_BITS=0: backward reads the activation itself)
+  bool lazy_bn = true;     // bn3 / downsample BN normalised inside the fused ECA pass, their outputs never stored (MI355_BRESNET_LAZY_BN=0: stored)
   bool fused_eca = true;   // ECA gate x drop-connect x shortcut add x activation in one pass each way (MI355_BRESNET_FUSED_ECA=0: op by op)
   bool have_fwd = false, dropped = false;  // state of the last forward: training pass / dropout mask in use
   double fwd_flops = 0;
@@ -206,6 +209,8 @@ void plan_bn(mi355_bctx* c, Arena& ar, VBN& b, int H, int W, bool want_dout = tr
   if (b.Cp != b.C) ar.add(&b.stage, (size_t)6 * b.Cp * 4);
   ar.add(&b.mean, (size_t)b.Cp * 4);
   ar.add(&b.invstd, (size_t)b.Cp * 4);
+  ar.add(&b.scale, (size_t)b.Cp * 4);
+  ar.add(&b.shift, (size_t)b.Cp * 4);
   const size_t o = (size_t)c->N * H * W * b.Cp * c->es;
   ar.add(&b.out, o);
   if (want_dout) ar.add(&b.dout, o);
@@ -264,12 +269,19 @@ int prep_weight(mi355_bctx* c, VConv& v, hipStream_t s) {
 }
 
 // y = conv(in), out = act(bn(y)): the conv epilogue sums y for the batch statistics wherever its launch shape can
-int conv_bn(mi355_bctx* c, VConv& v, VBN& b, const void* in, bool training, float momentum, hipStream_t s) {
+// lazy_ok (identity-activation BNs whose only consumer is the fused ECA / residual pass): leave the normalisation to that pass — b.scale /
+// b.shift are written, b.out is not (b.lazy says which happened: a conv launch that could not carry the statistics takes the plain route)
+int conv_bn(mi355_bctx* c, VConv& v, VBN& b, const void* in, bool training, float momentum, hipStream_t s, bool lazy_ok = false) {
   const int M = c->N * v.Hout * v.Wout;
   BNP q;
   MI355_TRY(bn_params(c, b, q, true, s));
+  b.lazy = false;
   if (!training) {
     MI355_TRY(mi355_conv2d_fwd(c->dtype, in, v.wp, v.y, c->N, v.Hin, v.Win, v.Cinp, v.Coutp, v.K, v.K, v.stride, v.pad, s));
+    if (lazy_ok) {
+      b.lazy = true;
+      return launch_bn_eval_coeffs(q.g, q.b, q.rm, q.rv, b.scale, b.shift, b.Cp, BN_EPS, s);
+    }
     return mi355_bn_fwd_eval(c->dtype, v.y, nullptr, b.out, q.g, q.b, q.rm, q.rv, M, b.Cp, BN_EPS, b.act, c->bn_ws, c->bn_ws_bytes, s);
   }
   int nblk = 0;
@@ -279,11 +291,14 @@ int conv_bn(mi355_bctx* c, VConv& v, VBN& b, const void* in, bool training, floa
   if (nblk > 0) {
     // finalize from the conv epilogue's partial rows, then normalise + activate; the activation's sign goes out as one bit per element
     // (backward then reads 1/16 of a tensor instead of `out` itself, in both of its passes)
-    float *scale = (float*)c->bn_ws, *shift = scale + b.Cp;
-    MI355_TRY(launch_bn_finalize(c->partial, nullptr, nblk, M, b.Cp, q.g, q.b, q.rm, q.rv, b.mean, b.invstd, scale, shift, BN_EPS, momentum, s));
-    uint8_t* bits = (c->use_bits && b.act != ACT_NONE) ? b.bits : nullptr;
-    MI355_TRY(launch_bn_apply(c->dtype, v.y, scale, shift, nullptr, nullptr, nullptr, nullptr, b.out, M, b.Cp, b.act, s, bits));
-    b.has_bits = bits != nullptr;
+    MI355_TRY(launch_bn_finalize(c->partial, nullptr, nblk, M, b.Cp, q.g, q.b, q.rm, q.rv, b.mean, b.invstd, b.scale, b.shift, BN_EPS, momentum, s));
+    if (lazy_ok) {
+      b.lazy = true;
+    } else {
+      uint8_t* bits = (c->use_bits && b.act != ACT_NONE) ? b.bits : nullptr;
+      MI355_TRY(launch_bn_apply(c->dtype, v.y, b.scale, b.shift, nullptr, nullptr, nullptr, nullptr, b.out, M, b.Cp, b.act, s, bits));
+      b.has_bits = bits != nullptr;
+    }
   } else {
     MI355_TRY(mi355_bn_fwd_train(c->dtype, v.y, nullptr, b.out, q.g, q.b, q.rm, q.rv, b.mean, b.invstd, M, b.Cp, BN_EPS, momentum, b.act, c->bn_ws,
                                  c->bn_ws_bytes, s));
@@ -508,6 +523,8 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
   c->fused_add = !(fa && fa[0] == '0');
   const char* ub = getenv("MI355_BRESNET_BITS");
   c->use_bits = !(ub && ub[0] == '0');
+  const char* lb = getenv("MI355_BRESNET_LAZY_BN");
+  c->lazy_bn = !(lb && lb[0] == '0');
   const char* fe = getenv("MI355_BRESNET_FUSED_ECA");
   c->fused_eca = !(fe && fe[0] == '0');
   bool ok = true;
@@ -618,7 +635,8 @@ int mi355_bresnet50_forward(mi355_bctx* c, const float* x_nchw, float* logits, i
       MI355_TRY(mi355_blurpool_fwd(dt, a2, b.a2b, N, b.H, b.W, b.planes, s));
       a2 = b.a2b;
     }
-    MI355_TRY(conv_bn(c, b.c3, b.b3, a2, tr, bn_momentum, s));
+    const bool lazy_ok = c->fused_eca && c->lazy_bn;  // bn3 / the downsample BN are applied inside the fused ECA + residual pass
+    MI355_TRY(conv_bn(c, b.c3, b.b3, a2, tr, bn_momentum, s, lazy_ok));
     const int C4 = 4 * b.planes;
     if (!c->fused_eca) MI355_TRY(mi355_eca_fwd(dt, b.b3.out, c->params + b.eca_off, 3, b.e, b.pooled, b.gate, N, b.Ho * b.Wo, C4, s));
     const void* sc = x;
@@ -628,8 +646,8 @@ int mi355_bresnet50_forward(mi355_bctx* c, const float* x_nchw, float* logits, i
         MI355_TRY(mi355_avgpool2_fwd(dt, x, b.scin, N, b.H, b.W, b.cin, s));
         scin = b.scin;
       }
-      MI355_TRY(conv_bn(c, b.ds, b.bd, scin, tr, bn_momentum, s));
-      sc = b.bd.out;
+      MI355_TRY(conv_bn(c, b.ds, b.bd, scin, tr, bn_momentum, s, lazy_ok));
+      sc = b.bd.lazy ? b.ds.y : b.bd.out;
     }
     // drop-connect: sample scales from the caller (tests) or from the counter-based generator, kept in b.keep for backward
     b.scaled = false;
@@ -643,8 +661,9 @@ int mi355_bresnet50_forward(mi355_bctx* c, const float* x_nchw, float* logits, i
       b.scaled = true;
     }
     if (c->fused_eca)  // gate, drop-connect scale, shortcut add and activation in one pass: the gated tensor is never stored
-      MI355_TRY(launch_eca_residual_fwd(dt, b.b3.out, c->params + b.eca_off, 3, b.scaled ? b.keep : nullptr, sc, b.out, b.pooled, b.gate, N, b.Ho * b.Wo, C4,
-                                        ACT_LEAKY, s));
+      MI355_TRY(launch_eca_residual_fwd(dt, b.b3.lazy ? b.c3.y : b.b3.out, c->params + b.eca_off, 3, b.scaled ? b.keep : nullptr, sc, b.out, b.pooled, b.gate, N,
+                                        b.Ho * b.Wo, C4, ACT_LEAKY, s, b.b3.lazy ? b.b3.scale : nullptr, b.b3.shift,
+                                        (b.has_ds && b.bd.lazy) ? b.bd.scale : nullptr, b.bd.shift));
     else
       MI355_TRY(mi355_residual_act_fwd(dt, b.e, b.scaled ? b.keep : nullptr, sc, b.out, N, (size_t)b.Ho * b.Wo * C4, ACT_LEAKY, s));
     x = b.out;
@@ -703,8 +722,9 @@ int mi355_bresnet50_backward(mi355_bctx* c, const float* dlogits, int accumulate
     const void* xin = i > 0 ? c->blocks[i - 1].out : c->p;
     const int C4 = 4 * b.planes;
     if (c->fused_eca) {
-      MI355_TRY(launch_eca_residual_bwd(dt, g, b.out, b.b3.out, b.scaled ? b.keep : nullptr, c->params + b.eca_off, 3, b.pooled, b.gate, b.dsc, b.b3.dout,
-                                        c->grads + b.eca_off, beta, c->eca_ws, N, b.Ho * b.Wo, C4, ACT_LEAKY, s));
+      MI355_TRY(launch_eca_residual_bwd(dt, g, b.out, b.b3.lazy ? b.c3.y : b.b3.out, b.scaled ? b.keep : nullptr, c->params + b.eca_off, 3, b.pooled, b.gate,
+                                        b.dsc, b.b3.dout, c->grads + b.eca_off, beta, c->eca_ws, N, b.Ho * b.Wo, C4, ACT_LEAKY, s,
+                                        b.b3.lazy ? b.b3.scale : nullptr, b.b3.shift));
     } else {
       MI355_TRY(mi355_residual_act_bwd(dt, g, b.out, b.scaled ? b.keep : nullptr, b.de, b.dsc, N, (size_t)b.Ho * b.Wo * C4, ACT_LEAKY, s));
       MI355_TRY(mi355_eca_bwd(dt, b.de, b.b3.out, c->params + b.eca_off, 3, b.pooled, b.gate, b.b3.dout, c->grads + b.eca_off, beta, c->eca_ws, N,

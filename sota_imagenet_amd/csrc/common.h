@@ -237,10 +237,13 @@ int launch_nchw_pad64(int dtype, const float* x_nchw, void* h_nhwc64, int N, int
 int launch_weight_pad_cast(int dtype, const float* w, void* wp, int Cout, int taps, int Cin, int Coutp, int Cinp, hipStream_t s);
 int launch_weight_unpad(const float* dwp, float* dw, float beta, int Cout, int taps, int Cin, int Cinp, hipStream_t s);
 int launch_axpby(const float* src, float* dst, float beta, size_t n, hipStream_t s);
+// xs / xh (optional): x stands for x * xs[c] + xh[c] (a BatchNorm with identity activation applied on the fly); ss / sh2: the same for the shortcut
 int launch_eca_residual_fwd(int dtype, const void* x, const float* w, int k, const float* keep, const void* shortcut, void* out, float* pooled, float* gate,
-                            int N, int HW, int C, int act, hipStream_t s);
+                            int N, int HW, int C, int act, hipStream_t s, const float* xs = nullptr, const float* xh = nullptr, const float* ss = nullptr,
+                            const float* sh2 = nullptr);
 int launch_eca_residual_bwd(int dtype, const void* dout, const void* out, const void* x, const float* keep, const float* w, int k, const float* pooled,
-                            const float* gate, void* dshortcut, void* dx, float* dw, float beta, float* ws, int N, int HW, int C, int act, hipStream_t s);
+                            const float* gate, void* dshortcut, void* dx, float* dw, float beta, float* ws, int N, int HW, int C, int act, hipStream_t s,
+                            const float* xs = nullptr, const float* xh = nullptr);
 // fp8 step: scale[i] = amax[i] > 0 ? 448 / (headroom * amax[i]) : scale[i];  amax[i] = 0   (delayed per-tensor scaling)
 int launch_fp8_scale_update(float* scale, unsigned* amax, int n, float headroom, hipStream_t s);
 

@@ -347,9 +347,17 @@ __global__ void eca_dw_finish_kernel(const float* dwpart, float* dw, int k, floa
 
 // ---- ECA + drop-connect + shortcut + activation in one pass each way (the static executor, bresnet_exec.cpp) ------------------------
 // Forward: out = act(x * gate[n][c] * keep[n] + shortcut) — the gated tensor (eca_scale) is never stored.
+// xs / xh (optional): x stands for x * xs[c] + xh[c], i.e. the raw conv output under its BatchNorm (identity activation) applied on the fly —
+// the normalised tensor is never stored either; ss / sh2 the same for the shortcut (the downsample branch's BatchNorm).
+struct Affine {
+  const float* xs;
+  const float* xh;
+  const float* ss;
+  const float* sh2;
+};
 template <typename T>
 __global__ __launch_bounds__(256) void eca_residual_fwd_kernel(const T* x, const float* gate, const float* keep, const T* shortcut, T* out, int N, int HW,
-                                                               int C, int act) {
+                                                               int C, int act, Affine af) {
   constexpr int V = Vec16<T>::N;
   const int CV = C / V;
   const size_t total = (size_t)N * HW * CV;
@@ -360,6 +368,14 @@ __global__ __launch_bounds__(256) void eca_residual_fwd_kernel(const T* x, const
     float v[V], s[V];
     Vec16<T>::load(x + i * V, v);
     Vec16<T>::load(shortcut + i * V, s);
+    if (af.xs) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] = fmaf(v[e], af.xs[cv * V + e], af.xh[cv * V + e]);
+    }
+    if (af.ss) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) s[e] = fmaf(s[e], af.ss[cv * V + e], af.sh2[cv * V + e]);
+    }
 #pragma unroll
     for (int e = 0; e < V; ++e) v[e] = act_fwd(v[e] * gate[(size_t)n * C + cv * V + e] * kn + s[e], act);
     Vec16<T>::store(out + i * V, v);
@@ -370,16 +386,20 @@ __global__ __launch_bounds__(256) void eca_residual_fwd_kernel(const T* x, const
 // order of eca_prod_reduce_kernel.
 template <typename T>
 __global__ __launch_bounds__(256) void eca_residual_bwd_reduce_kernel(const T* dout, const T* out, const T* x, const float* keep, T* dshortcut, float* s, int N,
-                                                                      int HW, int C, int act) {
+                                                                      int HW, int C, int act, const float* xs, const float* xh) {
   constexpr int V = Vec16<T>::N;
   __shared__ float red[32][8 * V + 1];
   const int slabs = C / (8 * V);
   const int n = blockIdx.x / slabs, c0 = (blockIdx.x % slabs) * 8 * V;
   const int cv = threadIdx.x & 7, r = threadIdx.x >> 3;
   const float kn = keep ? keep[n] : 1.f;
-  float acc[V];
+  float acc[V], sc[V], sh[V];
 #pragma unroll
-  for (int e = 0; e < V; ++e) acc[e] = 0.f;
+  for (int e = 0; e < V; ++e) {
+    acc[e] = 0.f;
+    sc[e] = xs ? xs[c0 + cv * V + e] : 1.f;
+    sh[e] = xs ? xh[c0 + cv * V + e] : 0.f;
+  }
   for (int p = r; p < HW; p += 32) {
     const size_t o = ((size_t)n * HW + p) * C + c0 + cv * V;
     float g[V], ov[V], xv[V];
@@ -389,7 +409,7 @@ __global__ __launch_bounds__(256) void eca_residual_bwd_reduce_kernel(const T* d
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       g[e] *= act_slope(ov[e], act);
-      acc[e] += g[e] * kn * xv[e];
+      acc[e] += g[e] * kn * fmaf(xv[e], sc[e], sh[e]);
     }
     Vec16<T>::store(dshortcut + o, g);
   }
@@ -427,6 +447,14 @@ __global__ __launch_bounds__(256) void eca_residual_bwd_apply_kernel(const T* dz
       v[e] = v[e] * kn * gate[g] + dpool[g];
     }
     Vec16<T>::store(dx + i * V, v);
+  }
+}
+
+// pooled[n][c] = pooled[n][c] * xs[c] + xh[c]: the pooled features of a tensor that only exists as (raw conv output, BN scale / shift)
+__global__ void pooled_affine_kernel(float* pooled, const float* xs, const float* xh, int N, int C) {
+  GRID_STRIDE(i, (size_t)N * C) {
+    const int c = (int)(i % C);
+    pooled[i] = fmaf(pooled[i], xs[c], xh[c]);
   }
 }
 
@@ -594,27 +622,30 @@ int launch_weight_unpad(const float* dwp, float* dw, float beta, int Cout, int t
 }
 // out = act(eca(x) * keep[n] + shortcut); pooled / gate [N][C] are kept for backward (k = 3 ... 9 odd)
 int launch_eca_residual_fwd(int dtype, const void* x, const float* w, int k, const float* keep, const void* shortcut, void* out, float* pooled, float* gate,
-                            int N, int HW, int C, int act, hipStream_t s) {
+                            int N, int HW, int C, int act, hipStream_t s, const float* xs, const float* xh, const float* ss, const float* sh2) {
   MI355_TRY(mi355_gap_fwd(dtype, x, pooled, N, HW, C, s));
+  if (xs) hipLaunchKernelGGL(pooled_affine_kernel, dim3(grid_for((size_t)N * C)), dim3(256), 0, s, pooled, xs, xh, N, C);
   hipLaunchKernelGGL(eca_gate_kernel, dim3(grid_for((size_t)N * C)), dim3(256), 0, s, pooled, w, k, gate, N, C);
+  const Affine af{xs, xh, ss, sh2};
   const size_t total = (size_t)N * HW * C;
   if (dtype == MI355_F32)
-    hipLaunchKernelGGL(eca_residual_fwd_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)x, gate, keep, (const float*)shortcut, (float*)out, N, HW, C, act);
+    hipLaunchKernelGGL(eca_residual_fwd_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)x, gate, keep, (const float*)shortcut, (float*)out, N, HW, C, act, af);
   else
-    hipLaunchKernelGGL(eca_residual_fwd_kernel<bf16_t>, dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)x, gate, keep, (const bf16_t*)shortcut, (bf16_t*)out, N, HW, C, act);
+    hipLaunchKernelGGL(eca_residual_fwd_kernel<bf16_t>, dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)x, gate, keep, (const bf16_t*)shortcut, (bf16_t*)out, N, HW, C, act, af);
   MI355_LAUNCH_CHECK();
   return 0;
 }
 // its backward from dout: dshortcut (the shortcut operand's gradient), dx (the ECA input's), dw[k] (beta 0 / 1); ws: 2*N*C + 1152 floats
 int launch_eca_residual_bwd(int dtype, const void* dout, const void* out, const void* x, const float* keep, const float* w, int k, const float* pooled,
-                            const float* gate, void* dshortcut, void* dx, float* dw, float beta, float* ws, int N, int HW, int C, int act, hipStream_t s) {
+                            const float* gate, void* dshortcut, void* dx, float* dw, float beta, float* ws, int N, int HW, int C, int act, hipStream_t s,
+                            const float* xs, const float* xh) {
   float *sprod = ws, *dpool = ws + (size_t)N * C, *dwpart = ws + (size_t)2 * N * C;
   if (dtype == MI355_F32)
     hipLaunchKernelGGL(eca_residual_bwd_reduce_kernel<float>, dim3(N * (C / 32)), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)x, keep,
-                       (float*)dshortcut, sprod, N, HW, C, act);
+                       (float*)dshortcut, sprod, N, HW, C, act, xs, xh);
   else
     hipLaunchKernelGGL(eca_residual_bwd_reduce_kernel<bf16_t>, dim3(N * (C / 64)), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x,
-                       keep, (bf16_t*)dshortcut, sprod, N, HW, C, act);
+                       keep, (bf16_t*)dshortcut, sprod, N, HW, C, act, xs, xh);
   hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3(ECA_GB), dim3(256), 0, s, sprod, gate, pooled, w, k, dpool, dwpart, N, C, 1.f / (float)HW);
   hipLaunchKernelGGL(eca_dw_finish_kernel, dim3(1), dim3(64), 0, s, dwpart, dw, k, beta);
   const size_t total = (size_t)N * HW * C;
