@@ -70,6 +70,16 @@ __device__ __forceinline__ void load_consts(const float* __restrict__ p, int c0,
   }
 }
 
+// gradient wrt an ECA module's input from the gradient wrt the gated, drop-connect-scaled tensor: g * keep[n] * gate[n][c] + dpool[n][c],
+// rounded to T as the stand-alone pass (variant.hip eca_residual_bwd_apply) stored it
+template <typename T, int V>
+__device__ __forceinline__ void eca_grad(const EcaGrad& eg, int n, int C, int c0, float (&gv)[V]) {
+  const float kn = eg.keep ? eg.keep[n] : 1.f;
+  const size_t o = (size_t)n * C + c0;
+#pragma unroll
+  for (int e = 0; e < V; ++e) gv[e] = (float)(T)(gv[e] * kn * eg.gate[o + e] + eg.dpool[o + e]);
+}
+
 struct ReduceArgs {
   const void* x;      // pre-BN tensor [M][C]
   const void* g;      // upstream gradient (bwd) or null
@@ -82,6 +92,7 @@ struct ReduceArgs {
   float* pivot;       // [C] (stats): per-channel shift = the channel's value in row 0
   int M, C;
   float slope;        // MASK == 1: gradient factor where the activation was <= 0 (0 ReLU, 0.01 leaky ReLU)
+  EcaGrad eg;         // MASK == 4: g stands for g * keep[n] * gate[n][c] + dpool[n][c] (the ECA backward applied on the fly)
   BnFinArgs fin;      // fin.mode != 0: the last-arriving workgroup of a channel slice also finalizes it (bn_fin.h)
 };
 
@@ -156,6 +167,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
         Vec16<T>::load(mk + off, mv);
 #pragma unroll
         for (int e = 0; e < V; ++e) gv[e] = mv[e] > 0.f ? gv[e] : gv[e] * p.slope;  // slope 0: ReLU, 0.01: leaky ReLU
+      } else if constexpr (MASK == 4) {
+        eca_grad<T, V>(p.eg, m / p.eg.hw, p.C, c0, gv);
       }
       if constexpr (DZ) Vec16<T>::store(dz_out + off, gv);
 #pragma unroll
@@ -404,6 +417,7 @@ struct BwdApplyArgs {
   size_t nvec;
   int cvecs, C;
   float slope;  // MASK == 1: gradient factor where the activation was <= 0
+  EcaGrad eg;   // MASK == 4 (see ReduceArgs)
   QuantOut qo;  // Q: e4m3 twin of dx
 };
 
@@ -439,6 +453,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p)
       const unsigned b = p.bits[i];
 #pragma unroll
       for (int e = 0; e < V; ++e) gv[e] = (b >> e) & 1u ? gv[e] : gv[e] * p.slope;
+    } else if constexpr (MASK == 4) {
+      eca_grad<T, V>(p.eg, (int)((i / p.cvecs) / (size_t)p.eg.hw), p.C, c0, gv);
     } else if constexpr (MASK == 1) {
       float mv[V];
       Vec16<T>::load(mk + i * V, mv);
@@ -843,10 +859,11 @@ int launch_bn_apply(int dtype, const void* x, const float* scale, const float* s
 
 int launch_bn_bwd_reduce(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
                          const float* invstd, void* dz_out, float* partial, int* nblk_out, int M, int C,
-                         hipStream_t s, const uint8_t* relu_bits, float slope, const BnFinArgs* fin) {
+                         hipStream_t s, const uint8_t* relu_bits, float slope, const BnFinArgs* fin, const EcaGrad* eg) {
   MI355_TRY(check_c(dtype, C));
   ReduceArgs a{};
   if (fin) a.fin = *fin;
+  if (eg) a.eg = *eg;
   a.slope = slope;
   a.x = x;
   a.g = g;
@@ -861,6 +878,13 @@ int launch_bn_bwd_reduce(int dtype, const void* g, const void* mask_src, const v
   dim3 grid;
   *nblk_out = reduce_grid(dtype, M, C, &grid);
   const int mask = relu_bits ? (slope != 0.f ? 3 : 2) : mask_src ? 1 : 0;
+  if (eg) {  // the gradient comes out of an ECA backward on the fly: identity activation, nothing else stored
+    MI355_ARG(mask == 0 && !dz_out && eg->gate && eg->dpool && eg->hw > 0, "bn_bwd_reduce: the ECA gradient source takes no mask / dz output");
+    if (dtype == MI355_F32) hipLaunchKernelGGL((bn_reduce_kernel<float, 1, 4, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1, 4, false>), grid, dim3(256), 0, s, a);
+    MI355_LAUNCH_CHECK();
+    return 0;
+  }
   const int variant = mask * 2 + (dz_out ? 1 : 0);
 #define MI355_BN_REDUCE(TT)                                                                                     \
   switch (variant) {                                                                                            \
@@ -903,10 +927,11 @@ int launch_bn_bwd_finalize(const float* partial, int nblk, int M, int C, const f
 
 int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
                         const float* invstd, const float* coef, void* dx, int M, int C, hipStream_t s,
-                        const uint8_t* relu_bits, float slope, QuantOut qo) {
+                        const uint8_t* relu_bits, float slope, QuantOut qo, const EcaGrad* eg) {
   MI355_TRY(check_c(dtype, C));
   const int V = 16 / (int)dtype_size(dtype);
   BwdApplyArgs a{};
+  if (eg) a.eg = *eg;
   a.slope = slope;
   a.g = g;
   a.mask = mask_src;
@@ -922,6 +947,13 @@ int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const vo
   const int blocks = elementwise_blocks(a.nvec, a.cvecs);
   const int mask = relu_bits ? (slope != 0.f ? 3 : 2) : mask_src ? 1 : 0;
   a.qo = qo;
+  if (eg) {
+    MI355_ARG(mask == 0 && !qo.q && eg->gate && eg->dpool && eg->hw > 0, "bn_bwd_apply: the ECA gradient source takes no mask / twin");
+    if (dtype == MI355_F32) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 4>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 4>), dim3(blocks), dim3(256), 0, s, a);
+    MI355_LAUNCH_CHECK();
+    return 0;
+  }
   if (qo.q) {
     MI355_ARG(dtype == MI355_BF16 && mask != 1 && mask != 3 && qo.scale && qo.amax, "bn_bwd_apply: the e4m3 twin needs bf16 and a ReLU bit mask (or none)");
     if (mask == 2 && qo.only) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 2, true, true>), dim3(blocks), dim3(256), 0, s, a);

@@ -145,6 +145,7 @@ struct mi355_bctx {
   bool overlap = true, w_dirty = false;
   bool fused_add = true;   // shortcut gradient added in conv1's dgrad epilogue (MI355_BRESNET_FUSED_ADD=0: its own launch, as the per-op graph)
   bool use_bits = true;    // leaky-ReLU masks travel as one bit per element (MI355_BRESNET_BITS=0: backward reads the activation itself)
+  bool lazy_dz3 = true;    // bn3's backward forms its input gradient from the ECA backward on the fly (MI355_BRESNET_LAZY_DZ3=0: stored)
   bool lazy_bn = true;     // bn3 / downsample BN normalised inside the fused ECA pass, their outputs never stored (MI355_BRESNET_LAZY_BN=0: stored)
   bool fused_eca = true;   // ECA gate x drop-connect x shortcut add x activation in one pass each way (MI355_BRESNET_FUSED_ECA=0: op by op)
   bool have_fwd = false, dropped = false;  // state of the last forward: training pass / dropout mask in use
@@ -311,7 +312,8 @@ int conv_bn(mi355_bctx* c, VConv& v, VBN& b, const void* in, bool training, floa
 }
 
 // v.dy = gradient wrt the conv output, from the gradient wrt the activation b.dout (dout may be another buffer)
-int bn_back(mi355_bctx* c, VConv& v, VBN& b, const void* dout, float beta, hipStream_t s) {
+// eg (optional): `dout` is the gradient wrt an ECA module's OUTPUT side (see EcaGrad): both passes form the module's input gradient on the fly
+int bn_back(mi355_bctx* c, VConv& v, VBN& b, const void* dout, float beta, hipStream_t s, const EcaGrad* eg = nullptr) {
   const int M = c->N * v.Hout * v.Wout;
   BNP q;
   MI355_TRY(bn_params(c, b, q, false, s));  // (the staged gamma of this step's forward is still there)
@@ -323,9 +325,9 @@ int bn_back(mi355_bctx* c, VConv& v, VBN& b, const void* dout, float beta, hipSt
     const void* mask = (b.act != ACT_NONE && !bits) ? b.out : nullptr;
     const float slope = b.act == ACT_LEAKY ? 0.01f : 0.f;
     int nblk = 0;
-    MI355_TRY(launch_bn_bwd_reduce(c->dtype, dout, mask, v.y, b.mean, b.invstd, nullptr, partial, &nblk, M, b.Cp, s, bits, slope));
+    MI355_TRY(launch_bn_bwd_reduce(c->dtype, dout, mask, v.y, b.mean, b.invstd, nullptr, partial, &nblk, M, b.Cp, s, bits, slope, nullptr, eg));
     MI355_TRY(launch_bn_bwd_finalize(partial, nblk, M, b.Cp, q.g, b.invstd, q.dg, q.db, staged ? 0.f : beta, coef, s));
-    MI355_TRY(launch_bn_bwd_apply(c->dtype, dout, mask, v.y, b.mean, b.invstd, coef, v.dy, M, b.Cp, s, bits, slope));
+    MI355_TRY(launch_bn_bwd_apply(c->dtype, dout, mask, v.y, b.mean, b.invstd, coef, v.dy, M, b.Cp, s, bits, slope, QuantOut(), eg));
   }
   if (staged) {
     MI355_TRY(launch_axpby(q.dg, c->grads + b.g_off, beta, (size_t)b.C, s));
@@ -523,6 +525,8 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
   c->fused_add = !(fa && fa[0] == '0');
   const char* ub = getenv("MI355_BRESNET_BITS");
   c->use_bits = !(ub && ub[0] == '0');
+  const char* lz = getenv("MI355_BRESNET_LAZY_DZ3");
+  c->lazy_dz3 = !(lz && lz[0] == '0');
   const char* lb = getenv("MI355_BRESNET_LAZY_BN");
   c->lazy_bn = !(lb && lb[0] == '0');
   const char* fe = getenv("MI355_BRESNET_FUSED_ECA");
@@ -721,16 +725,26 @@ int mi355_bresnet50_backward(mi355_bctx* c, const float* dlogits, int accumulate
     VBlock& b = c->blocks[i];
     const void* xin = i > 0 ? c->blocks[i - 1].out : c->p;
     const int C4 = 4 * b.planes;
+    bool lazy_dz = false;
     if (c->fused_eca) {
+      // pass 2 of the ECA backward (dz3 = dsc * keep * gate + dpool) is left to bn3's backward, which forms it on the fly from dsc in
+      // both of its passes: the gradient wrt bn3's output is never stored
+      lazy_dz = c->lazy_dz3;
       MI355_TRY(launch_eca_residual_bwd(dt, g, b.out, b.b3.lazy ? b.c3.y : b.b3.out, b.scaled ? b.keep : nullptr, c->params + b.eca_off, 3, b.pooled, b.gate,
-                                        b.dsc, b.b3.dout, c->grads + b.eca_off, beta, c->eca_ws, N, b.Ho * b.Wo, C4, ACT_LEAKY, s,
+                                        b.dsc, lazy_dz ? nullptr : b.b3.dout, c->grads + b.eca_off, beta, c->eca_ws, N, b.Ho * b.Wo, C4, ACT_LEAKY, s,
                                         b.b3.lazy ? b.b3.scale : nullptr, b.b3.shift));
     } else {
       MI355_TRY(mi355_residual_act_bwd(dt, g, b.out, b.scaled ? b.keep : nullptr, b.de, b.dsc, N, (size_t)b.Ho * b.Wo * C4, ACT_LEAKY, s));
       MI355_TRY(mi355_eca_bwd(dt, b.de, b.b3.out, c->params + b.eca_off, 3, b.pooled, b.gate, b.b3.dout, c->grads + b.eca_off, beta, c->eca_ws, N,
                               b.Ho * b.Wo, C4, s));
     }
-    MI355_TRY(bn_back(c, b.c3, b.b3, b.b3.dout, beta, s));
+    if (lazy_dz) {
+      EcaGrad eg;
+      eg.keep = b.scaled ? b.keep : nullptr; eg.gate = b.gate; eg.dpool = c->eca_ws + (size_t)N * C4; eg.hw = b.Ho * b.Wo;
+      MI355_TRY(bn_back(c, b.c3, b.b3, b.dsc, beta, s, &eg));
+    } else {
+      MI355_TRY(bn_back(c, b.c3, b.b3, b.b3.dout, beta, s));
+    }
     const void* a2 = b.stride == 2 ? b.a2b : b.b2.out;
     MI355_TRY(conv_wgrad(c, b.c3, a2, beta, s));
     if (b.stride == 2) {

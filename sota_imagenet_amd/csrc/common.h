@@ -217,14 +217,23 @@ int launch_bn_apply(int dtype, const void* x, const float* scale, const float* s
                     hipStream_t s, uint8_t* relu_bits = nullptr, QuantOut qo = QuantOut());
 // relu_bits: the ReLU mask as one byte per 16-byte vector of the tensor (bit e = element e of the vector was > 0);
 // written by launch_bn_apply, read by the two backward kernels in place of the post-activation tensor
+// optional gradient source of the BN-backward passes: g stands for g * keep[n] * gate[n][c] + dpool[n][c], n = pixel / hw — the backward of an
+// ECA module (channel gate + drop-connect scale) applied on the fly (the BResNet-50 executor: the module's input gradient is never stored)
+struct EcaGrad {
+  const float* keep = nullptr;   // [N] or null
+  const float* gate = nullptr;   // [N][C]
+  const float* dpool = nullptr;  // [N][C]
+  int hw = 0;
+};
 int launch_bn_bwd_reduce(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
                          const float* invstd, void* dz_out, float* partial, int* nblk_out, int M, int C,
-                         hipStream_t s, const uint8_t* relu_bits = nullptr, float slope = 0.f, const BnFinArgs* fin = nullptr);
+                         hipStream_t s, const uint8_t* relu_bits = nullptr, float slope = 0.f, const BnFinArgs* fin = nullptr,
+                         const EcaGrad* eg = nullptr);
 int launch_bn_bwd_finalize(const float* partial, int nblk, int M, int C, const float* gamma, const float* invstd,
                            float* dgamma, float* dbeta, float beta_acc, float* coef /*[3][C]*/, hipStream_t s);
 int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
                         const float* invstd, const float* coef, void* dx, int M, int C, hipStream_t s,
-                        const uint8_t* relu_bits = nullptr, float slope = 0.f, QuantOut qo = QuantOut());
+                        const uint8_t* relu_bits = nullptr, float slope = 0.f, QuantOut qo = QuantOut(), const EcaGrad* eg = nullptr);
 // conv + BN + ReLU + maxpool3x3/2 stage (the stem): both BN-backward passes gather the pool's backward from the pooled gradient
 // dp [N][H/2][W/2][C] and the argmax codes; the full-resolution pool gradient is never stored (H, W: the full resolution)
 int launch_stem_bwd_reduce(int dtype, const void* dp, const uint8_t* idx, const uint8_t* bits, const void* y, const float* mean,

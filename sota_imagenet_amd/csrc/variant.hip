@@ -639,6 +639,7 @@ int launch_eca_residual_fwd(int dtype, const void* x, const float* w, int k, con
 int launch_eca_residual_bwd(int dtype, const void* dout, const void* out, const void* x, const float* keep, const float* w, int k, const float* pooled,
                             const float* gate, void* dshortcut, void* dx, float* dw, float beta, float* ws, int N, int HW, int C, int act, hipStream_t s,
                             const float* xs, const float* xh) {
+  // dx == nullptr: pass 2 is left to the consumer — dx = dshortcut * keep[n] * gate[n][c] + dpool[n][c] with dpool = ws + N * C (EcaGrad)
   float *sprod = ws, *dpool = ws + (size_t)N * C, *dwpart = ws + (size_t)2 * N * C;
   if (dtype == MI355_F32)
     hipLaunchKernelGGL(eca_residual_bwd_reduce_kernel<float>, dim3(N * (C / 32)), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)x, keep,
@@ -648,6 +649,10 @@ int launch_eca_residual_bwd(int dtype, const void* dout, const void* out, const 
                        keep, (bf16_t*)dshortcut, sprod, N, HW, C, act, xs, xh);
   hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3(ECA_GB), dim3(256), 0, s, sprod, gate, pooled, w, k, dpool, dwpart, N, C, 1.f / (float)HW);
   hipLaunchKernelGGL(eca_dw_finish_kernel, dim3(1), dim3(64), 0, s, dwpart, dw, k, beta);
+  if (!dx) {
+    MI355_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t total = (size_t)N * HW * C;
   if (dtype == MI355_F32)
     hipLaunchKernelGGL(eca_residual_bwd_apply_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)dshortcut, gate, dpool, keep, (float*)dx, N, HW, C);
