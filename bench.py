@@ -28,6 +28,8 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2516.6, "fp8": 5033.2}  # MI355X_MICROARCH.md: dense MFMA peaks (no sparsity)
 FP8_KIND = 9  # profile_read kind: the conv launches that ran on e4m3 operands
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+EVENT_STEPS = 2  # timed steps whose conv / BN launches carry HIP-event pairs for `roofline` (each pair is a barrier on its stream: such a
+                 # step is ~1.2 ms slower, and that is part of `value` — 2 steps = ~200 timed launches of the dominant class are enough)
 HBM_CLASS = 7  # executor profile class of bn_bwd_apply_kernel, the largest HBM-bound kernel of the step
 # profile class -> kernel symbols (template instances of one source; names as tools/pmc_traffic.py writes them)
 KERNEL_NAMES = {0: ["igemm_kernel<{T},128,128>", "igemm_kernel<{T},256,256>", "igemm_kernel<{T},256,128>", "igemm8_kernel<224,256>", "igemm8_kernel<256,128>"],
@@ -229,7 +231,7 @@ def main():
             tot = [model.profile_read((N, S, S), k)[0] for k in range(4)]
             dom = max(range(4), key=lambda k: tot[k])
             model.profile((N, S, S), 0)
-        nprof = min(4, steps)  # a timed event pair drains the queue around its kernel: sample the last few timed steps only
+        nprof = min(EVENT_STEPS, steps)  # a timed event pair drains the queue around its kernel: sample the last few timed steps only
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
@@ -269,7 +271,7 @@ def main():
                     "launches": launches, "avg_launch_ms": round(tot_ms / launches, 4),
                     "alg_gflop_per_launch": round(flops / launches / 1e9, 3),
                     "alg_bytes_per_launch": int(nbytes / launches),
-                    "event_steps": min(4, args.steps),
+                    "event_steps": min(EVENT_STEPS, args.steps),
                     # the roofline MODEL's ceiling for this class: min(MFMA peak, arithmetic intensity x HBM peak).  `frac` stays
                     # achieved / MFMA peak (the number earlier rounds tracked); below the ridge the class is HBM-bound by the model
                     "intensity_flop_per_byte": round(flops / max(nbytes, 1), 1),
