@@ -131,8 +131,6 @@ struct mi355_bctx {
   size_t partial_bytes = 0;
   void* bn_ws = nullptr;
   size_t bn_ws_bytes = 0;
-  void* dg_ws = nullptr;   // transposed weights of the running dgrad (main stream)
-  size_t dg_ws_bytes = 0;
   void* wg_ws = nullptr;   // split-K slabs of the running wgrad (side stream)
   size_t wg_ws_bytes = 0;
   float* dw_tmp = nullptr; // padded / pre-standardisation weight gradient (side stream)
@@ -492,9 +490,7 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
     dw_max = std::max(dw_max, v.wpelems() + v.welems());
   });
   const size_t fc_wg = (size_t)plan_wgrad_splits(MI355_F32, N, c->fc_pad, 1, 2048) * c->fc_pad * 2048 * 4;
-  c->dg_ws_bytes = ws_max;
   c->wg_ws_bytes = std::max(ws_max, fc_wg);
-  ar.add(&c->dg_ws, c->dg_ws_bytes);
   ar.add(&c->wg_ws, c->wg_ws_bytes);
   ar.add(&c->dw_tmp, dw_max * 4);
   ar.add(&c->eca_ws, ((size_t)2 * N * 2048 + 1152) * 4);

@@ -100,6 +100,20 @@ def test_bench_launches_its_own_ranks(dev):
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["parallelism"] == "dp1"
 
 
+def test_bench_bresnet50_line_with_rccl_single_rank(dev):
+    """`bench.py --model bresnet50` (BASELINE configs[3] on its static executor) as a 1-rank process group: the flat gradient array goes
+    through ONE native mean all-reduce behind the backward call; the line carries the whole-step roofline object."""
+    env = dict(os.environ, BENCH_FORCE_DDP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29519")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                          "127.0.0.1", "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
+                          "--warmup", "1", "--batch", "8", "--size", "64", "--model", "bresnet50", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and "static executor" in rec["config"]["workload"]
+    assert rec["roofline"]["scope"] == "whole step" and 0 < rec["roofline"]["frac"] < 1 and abs(rec["config"]["final_loss"] - 6.9) < 0.6
+
+
 _DDP_CHECK = r"""
 import os, sys, torch, torch.distributed as dist
 from sota_imagenet_amd.losses import CrossEntropyLoss
