@@ -338,7 +338,8 @@ class BResNet50Graph(nn.Module):
         return torch.nn.functional.linear(p, self.fc.weight, self.fc.bias)
 
 
-_DT = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
+_DT = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "torch.bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32,
+       "torch.float32": torch.float32, "None": torch.float32}  # (keys are str(dtype): None = fp32, as models.resnet50)
 
 
 def _layout(dtype_code, num_classes, wstd):
@@ -372,6 +373,8 @@ class BResNet50(_FlatModel):
             raise TypeError(f"bresnet50: unsupported arguments {sorted(unknown)}")
         from . import native
 
+        if str(dtype) not in _DT:
+            raise ValueError(f"bresnet50: dtype {dtype!r} (bf16 | fp32; the fp8 step exists for the torchvision-layout resnet50 only)")
         self.compute_dtype = _DT[str(dtype)]
         self._dt = native.dtype_code(self.compute_dtype)
         self.num_classes, self.drop_rate, self.drop_connect_rate, self.seed = int(num_classes), float(drop_rate), float(drop_connect_rate), int(seed)

@@ -601,6 +601,7 @@ int mi355_bresnet50_forward(mi355_bctx* c, const float* x_nchw, float* logits, i
   hipStream_t s = (hipStream_t)stream;
   const int N = c->N, dt = c->dtype;
   const bool tr = training != 0;
+  c->have_fwd = false;  // (until this pass has completed: a failed forward must not be differentiated)
   MI355_TRY(join(c, s));  // (a previous backward's side-stream work reads the tensors this pass overwrites)
   // ---- weight preparation: [standardise] -> pad -> cast; FC weights transposed for the input gradient ------------------------------
   // The first conv's weights on the caller's stream; everything else (106 + 54 small launches) on the side stream, beside the input

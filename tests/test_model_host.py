@@ -76,3 +76,27 @@ def test_fp8_model_keeps_the_bf16_parameter_table():
     assert [(n, tuple(p.shape)) for n, p in a.named_parameters()] == [(n, tuple(p.shape)) for n, p in b.named_parameters()]
     assert a.grad_segments == b.grad_segments and a.flops(256, 224, 224) == b.flops(256, 224, 224)
     assert a.bucket_plan(32.0) == b.bucket_plan(32.0)
+
+
+def test_bresnet50_executor_facade_layout_matches_the_per_op_graph():
+    """bresnet.BResNet50 (views into the static executor's flat arrays, layout-only context: no GPU) and bresnet.BResNet50Graph (separate
+    nn.Parameters) expose the same pytorch_tools names, shapes, registration order and initial values; no CPU compute path exists."""
+    import pytest
+
+    from sota_imagenet_amd.bresnet import BResNet50, BResNet50Graph
+
+    m, g = BResNet50(weight_standardization=True), BResNet50Graph(weight_standardization=True)
+    a, b = m.state_dict(), g.state_dict()
+    assert list(a) == list(b) and len(a) == 348
+    for k in a:
+        assert a[k].shape == b[k].shape and torch.equal(a[k].float(), b[k].float()), k
+    assert [(n, tuple(p.shape)) for n, p in m.named_parameters()] == [(n, tuple(p.shape)) for n, p in g.named_parameters()]
+    assert sum(p.numel() for p in m.parameters()) == 25576312
+    w = dict(m.named_parameters())["layer3.0.conv2.weight"]
+    assert w.shape == (256, 256, 3, 3) and w.stride() == (2304, 1, 768, 256)  # OIHW logical over [Cout][KH][KW][Cin] memory
+    assert w.untyped_storage().data_ptr() == m.flat_params.untyped_storage().data_ptr() and w.grad.shape == w.shape
+    assert m.grad_segments == [(0, m.flat_params.numel())]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(2, 3, 64, 64))
+    with pytest.raises(ValueError):
+        BResNet50(dtype="fp8")
