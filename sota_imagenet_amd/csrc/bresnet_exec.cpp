@@ -123,7 +123,7 @@ struct mi355_bctx {
   // workspace
   char* arena = nullptr;
   size_t arena_bytes = 0;
-  void *h0 = nullptr, *m = nullptr, *dm = nullptr, *p = nullptr, *dp = nullptr;
+  void *h0 = nullptr, *m = nullptr, *dm = nullptr, *p = nullptr;
   uint8_t* pool_idx = nullptr;
   float *pooled = nullptr, *pooled_d = nullptr, *do_mask = nullptr, *fc_tmp = nullptr, *dlogits_pad = nullptr, *dpooled = nullptr, *fc_wtr = nullptr;
   void* dlast = nullptr;  // gradient wrt the last block's output
@@ -135,7 +135,6 @@ struct mi355_bctx {
   size_t wg_ws_bytes = 0;
   float* dw_tmp = nullptr; // padded / pre-standardisation weight gradient (side stream)
   float* eca_ws = nullptr;
-  float* eca_dw = nullptr;
   // streams
   hipStream_t wstream = nullptr;
   std::vector<hipEvent_t> ev;
@@ -445,7 +444,6 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
   ar.add(&c->dm, act_bytes(H / 2, W / 2, 64));
   ar.add(&c->pool_idx, (size_t)N * (H / 2) * (W / 2) * 64);
   ar.add(&c->p, act_bytes(H / 4, W / 4, 64));
-  ar.add(&c->dp, act_bytes(H / 4, W / 4, 64));
   for (VBlock& b : c->blocks) {
     plan_conv(c, ar, b.c1); plan_bn(c, ar, b.b1, b.H, b.W);
     plan_conv(c, ar, b.c2); plan_bn(c, ar, b.b2, b.H, b.W);
@@ -494,7 +492,6 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
   ar.add(&c->wg_ws, c->wg_ws_bytes);
   ar.add(&c->dw_tmp, dw_max * 4);
   ar.add(&c->eca_ws, ((size_t)2 * N * 2048 + 1152) * 4);
-  ar.add(&c->eca_dw, 64);
   c->arena_bytes = ar.size;
   if (hipMalloc((void**)&c->arena, c->arena_bytes) != hipSuccess) {
     set_error("bresnet50_create: hipMalloc(%zu bytes) failed: %s", c->arena_bytes, hipGetErrorString(hipGetLastError()));
