@@ -440,7 +440,7 @@ class BResNet50(_FlatModel):
         if c is None:
             if not self._flat_params.is_cuda:
                 raise RuntimeError("bresnet50: the MI355X hot path has no CPU fallback — call .cuda() first")
-            if len(self._ctxs) >= 2:  # train + val batch shapes (each holds every activation AND every gradient: ~46 GB at 256 x 224 px)
+            if len(self._ctxs) >= 2:  # train + val batch shapes (each holds every activation AND every gradient: 50 GB at 256 x 224 px)
                 _, old = self._ctxs.popitem(last=False)
                 native.lib().mi355_bresnet50_destroy(old)
             L = native.lib()

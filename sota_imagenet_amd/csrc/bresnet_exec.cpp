@@ -16,7 +16,7 @@
 // the two agree bit for bit up to the FC GEMM — runs from C++ over
 //   * ONE flat fp32 parameter array / gradient array / buffer array (what the native SGD and the bucketed all-reduce take), conv
 //     weights in [Cout][KH][KW][Cin] order = torch OIHW in channels_last memory;
-//   * a workspace laid out once per (N, H, W): every activation and every gradient has its own slot (23 + 23 GB at batch 256 /
+//   * a workspace laid out once per (N, H, W): every activation and every gradient has its own slot (50 GB in all at batch 256 /
 //     224 px in bf16, of 288), so no launch waits for a buffer;
 //   * weight standardisation + channel padding (the 3- and 32-channel stem tensors run zero-padded to 64) + cast in the weight
 //     preparation at the head of each forward, the inverse (un-pad, standardisation backward) behind each weight gradient;
