@@ -1,0 +1,855 @@
+#!/usr/bin/env python3
+"""dconv_gen.py — generator of the hand-scheduled gfx950 (MI355X) direct 3x3 / stride-1 convolution kernels.
+
+What the kernels replace: the cuDNN conv forward / data-gradient under `model(data)` / `loss.backward()` of the reference
+(call form /root/reference/sota_imagenet/callbacks.py:316-317) for the 3x3 convolutions of ResNet-50's layers 3 and 4 —
+the same IgemmArgs contract as conv_igemm8.hip (BN statistics / BN-backward sums in the epilogue), selected in launch_igemm().
+
+Why a generator that prints assembly: the structure below needs ONE wave per SIMD with 224 accumulator registers, fragment
+reads of the next k-step and LDS-DMA issue placed BETWEEN the MFMAs of the current one, and counted waits across one
+barrier per 112 MFMAs.  hipcc does not keep such a schedule; the text printed here is the schedule.
+
+Structure (one workgroup = 4 waves = one wave per SIMD, one tile per workgroup):
+  tile        RO output rows x P positions per row (P = padded row pitch, a multiple of 8, >= W + 1) of IPT whole images
+              x BN = 256 output channels; waves 2 (M) x 2 (N); a wave owns MFR x 8 accumulator tiles of 16 x 16
+              (v_mfma_f32_16x16x32_bf16, operands swapped: D^T = W * A^T, a lane ends with 4 channels of one pixel).
+  A operand   the zero-haloed input tile of ONE 64-channel chunk is staged ONCE ([position][128 B] rows, LDS-DMA) and
+              all 9 taps read it at shifted addresses: output position p, tap (ky, kx) reads position p + ky*P + kx, so
+              a fragment (16 consecutive positions) of any tap is again 16 consecutive rows.  The 16-byte chunk index is
+              rotated by (position & ~1) on the DMA source and on the read: conflict-free for ds_read_b128 at EVERY shift
+              (the XOR swizzle of the other kernels is conflict-free only at even shifts), and because P % 8 == 0 the
+              ky shift and the fragment index are immediates of the read: 6 address registers serve every A read.
+              Staging bytes per 64-channel chunk: 1 A tile + 9 weight slabs instead of 9 + 9.
+  B operand   weight rows [256][128 B] per (chunk, tap) stage, 2-stage ring, rows permuted so that a lane's accumulators
+              of a tile pair are 8 consecutive channels (16-byte stores, no lane exchange).
+  schedule    per stage 2 substeps of 56 MFMAs; substep s computes on fragment set s & 1 while the 15 ds_read_b128 of
+              substep s + 1 and the LDS-DMA pieces of stage + 2 are issued between its MFMAs; ONE s_barrier per stage
+              (at the start of its second substep) behind counted vmcnt / lgkmcnt(0).
+  epilogue    accumulators -> bf16 -> 16-byte stores; BN statistics (sum, sum of squares of the rounded values) or the
+              BN-backward sums of the layer whose activation gradient the output is, reduced by DPP row sums, one partial
+              row per workgroup.
+"""
+import argparse
+import os
+import sys
+from dataclasses import dataclass
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@dataclass
+class Cfg:
+    name: str
+    H: int
+    W: int
+    P: int            # LDS row pitch in positions
+    IPT: int          # images per tile
+    Cin: int          # channels of the input tensor (= pixel stride = reduction per tap)
+    NCOLS: int        # columns of the output tensor (multiple of 256; blockIdx.y picks the 256-column tile)
+    stats: int        # 0 none, 1 BN statistics of the output, 2 BN-backward sums
+    skew: int = 0     # s_nop-based wave stagger after each barrier (experiment knob)
+    WM: int = 2
+    WN: int = 2
+    NT: int = 8       # 16-column tiles per wave
+    BN: int = 256
+
+    @property
+    def SR(self):     # LDS rows per image slot (the halo row between two images is shared)
+        return self.H + 1 if self.IPT > 1 else self.H + 2
+
+    @property
+    def RO(self):     # output rows enumerated per tile (IPT > 1: includes one garbage row per image)
+        return self.IPT * self.SR if self.IPT > 1 else self.H
+
+    @property
+    def NFRAG(self):
+        assert (self.RO * self.P) % 16 == 0
+        return self.RO * self.P // 16
+
+    @property
+    def MFR(self):
+        assert self.NFRAG % self.WM == 0
+        return self.NFRAG // self.WM
+
+    @property
+    def LROWS(self):  # LDS rows of the A tile
+        return self.RO + 2
+
+    @property
+    def ABUF(self):   # bytes of one A buffer: the tile + the 2 positions the last garbage columns read past it, padded to a block
+        pos = self.LROWS * self.P + 8
+        return pos * 128
+
+    @property
+    def ASTRIDE(self):  # distance of the two A buffers: each is followed by its 1 KiB sink
+        return self.ABUF + 1024
+
+    @property
+    def BSTAGE(self):
+        return self.BN * 128
+
+    @property
+    def w_row(self):  # bytes of one weight row [taps][Cin]
+        return 9 * self.Cin * 2
+
+
+ABASE = 2 * 32768  # LDS: [B ring 2 x 32 KiB][A buffer 0][A buffer 1][stats scratch reuses the B ring]
+
+
+def valid_rows(c):
+    """LDS A rows that hold image data: list of (g, image, y)"""
+    out = []
+    for g in range(c.LROWS):
+        if c.IPT == 1:
+            if 1 <= g <= c.H:
+                out.append((g, 0, g - 1))
+        else:
+            i, y = divmod(g - 1, c.SR) if g >= 1 else (0, -1)
+            if g >= 1 and y < c.H and i < c.IPT:
+                out.append((g, i, y))
+    return out
+
+
+def a_pieces(c):
+    """all A pieces of a chunk: (lds offset inside the buffer, source row constant in bytes, variant = block index in row)"""
+    bpr = c.P // 8
+    pcs = []
+    for g, i, y in valid_rows(c):
+        for xb in range(bpr):
+            # blocks entirely in the right padding of the row need no data (they stay zero from the initial fill)
+            if xb * 8 > c.W:
+                continue
+            pcs.append(((g * bpr + xb) * 1024, ((i * c.H + y) * c.W) * c.Cin * 2, xb))
+    return pcs
+
+
+def sink_off(c):
+    """offset, relative to an A buffer's base, of the 1 KiB LDS sink that follows each A buffer (padding pieces land there)"""
+    return c.ABUF
+
+
+def a_schedule(c):
+    """pieces per wave, padded by repetition so that every wave issues the same number; piece i has ONE variant for all waves"""
+    pcs = a_pieces(c)
+    byvar = {}
+    for p in pcs:
+        byvar.setdefault(p[2], []).append(p)
+    slots = []  # list of (variant, [piece for wave 0..3])
+    for var, lst in sorted(byvar.items()):
+        for k in range(0, len(lst), 4):
+            grp = lst[k:k + 4]
+            while len(grp) < 4:
+                grp.append((sink_off(c), grp[-1][1], var))  # padding piece: real source rows, lands in the sink (never read)
+            slots.append((var, grp))
+    return slots
+
+
+def b_piece_const(c, w, i):
+    """source constant (bytes) of B piece i of wave w: the first channel of its 8 rows"""
+    R0 = 64 * w + 8 * i
+    wn, rem = divmod(R0, c.NT * 16)
+    n = rem // 16
+    p, odd = n >> 1, n & 1
+    cout_base = wn * (c.NT * 16) + p * 32 + 4 * odd
+    return cout_base * c.w_row
+
+
+def tables(c):
+    """per-wave table (uint32 words): [A lds offsets][A source consts][B source consts], padded to 32 words"""
+    sl = a_schedule(c)
+    rows = []
+    for w in range(4):
+        words = [g[w][0] for _, g in sl] + [g[w][1] for _, g in sl] + [b_piece_const(c, w, i) for i in range(8)]
+        assert len(words) <= 32
+        rows.append(words + [0] * (32 - len(words)))
+    return rows
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class Alloc:
+    def __init__(self, prefix, first, limit):
+        self.p, self.n, self.limit = prefix, first, limit
+
+    def get(self, n=1, align=1):
+        self.n = (self.n + align - 1) // align * align
+        r = self.n
+        self.n += n
+        assert self.n <= self.limit, "out of %s registers" % self.p
+        return r
+
+
+def R(p, i, n=1):
+    return "%s%d" % (p, i) if n == 1 else "%s[%d:%d]" % (p, i, i + n - 1)
+
+
+class Gen:
+    def __init__(self, c: Cfg):
+        self.c = c
+        self.out = []
+        self.nlabel = 0
+        self.S = Alloc("s", 4, 100)
+        self.V = Alloc("v", 1, 256)
+
+    def e(self, s, comment=None):
+        self.out.append("\t" + s + ("\t; " + comment if comment else ""))
+
+    def label(self, name):
+        self.out.append(name + ":")
+
+    def newlabel(self, stem):
+        self.nlabel += 1
+        return "L_%s_%d" % (stem, self.nlabel)
+
+    def comment(self, s):
+        self.out.append("\t; " + s)
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def gen(self):
+        c = self.c
+        S, V, e = self.S, self.V, self.e
+        sl = a_schedule(c)
+        NPA = len(sl)
+        assert NPA <= 8, "A pieces per wave per chunk must fit the 8 kk=0 substeps that issue them (got %d)" % NPA
+        self.NPA = NPA
+
+        # ---- registers ----------------------------------------------------------------------------------------------
+        # s[0:1] kernarg, s2 = workgroup id x (tile), s3 = workgroup id y (256-column tile)
+        self.s_tile, self.s_nt = 2, 3
+        self.srdA = S.get(4, 4)
+        self.srdB = S.get(4, 4)
+        self.srdO = S.get(4, 4)
+        self.srdX = S.get(4, 4)   # statistics rows / bn_y
+        self.srdM = S.get(4, 4)   # bn_bits
+        self.s_wt = S.get(9, 4)
+        self.s_cnt = S.get()
+        self.s_cC = S.get()
+        self.s_cN = S.get()
+        self.s_t0 = S.get()
+        self.s_t1 = S.get()
+        self.s_w = S.get()
+        self.s_wm = S.get()
+        self.s_wn = S.get()
+        self.s_nch = S.get()
+        self.s_ldsBw = S.get()
+        self.s_stg = S.get()
+        self.s_tbl = S.get(32, 4)        # per-wave table: [NPA lds][NPA src][8 B consts]
+        self.s_ka = self.s_tbl           # kernarg scratch: the 8 pointers are consumed before the table is loaded over them
+        self.s_kb = S.get(4, 4)
+        self.s_tA_lds = self.s_tbl
+        self.s_tA_src = self.s_tbl + NPA
+        self.s_tB = self.s_tbl + 2 * NPA
+
+        self.v_tid = 0
+        self.vA_rd = [[V.get() for kk in range(2)] for kx in range(3)]
+        self.vB_rd = [V.get() for kk in range(2)]
+        nvar = c.P // 8
+        self.vA_dma = [V.get() for _ in range(nvar)]
+        self.vB_dma = [V.get() for _ in range(2)]
+        self.v_out = V.get()
+        self.v_t = [V.get() for _ in range(12)]
+        self.F = []
+        for s in range(2):
+            fa = V.get(4 * c.MFR, 4)
+            fb = V.get(4 * c.NT, 4)
+            self.F.append((fa, fb))
+        self.nvgpr = V.n
+        self.accum_offset = (self.nvgpr + 7) // 8 * 8
+        self.nagpr = c.MFR * c.NT * 4
+        assert self.nagpr <= 256
+
+        self.prologue()
+        self.mainloop()
+        self.epilogue()
+        return self.finish()
+
+    # -----------------------------------------------------------------------------------------------------------------
+    KA = dict(in_=0, wt=8, out=16, stat=24, bn_y=32, bn_bits=40, bn_mean=48, bn_invstd=56, table=64, wtap=72, nchunks=108,
+              size=112)
+
+    def prologue(self):
+        c, e = self.c, self.e
+        ka, kb = self.s_ka, self.s_kb
+        self.comment("---- prologue: kernel arguments, lane constants, descriptors, first loads")
+        e("s_load_dwordx16 %s, s[0:1], 0x0" % R("s", ka, 16))       # in, wt, out, stat, bn_y, bn_bits, bn_mean, bn_invstd
+        e("s_load_dwordx2 %s, s[0:1], 0x40" % R("s", kb, 2))        # table
+        e("s_load_dwordx8 %s, s[0:1], 0x48" % R("s", self.s_wt, 8))  # wtap[0..7]
+        e("s_load_dwordx2 %s, s[0:1], 0x68" % R("s", kb + 2, 2))    # wtap[8], nchunks
+        # lane constants while the loads fly
+        v = self.v_t
+        lane, r, kg = v[0], v[1], v[2]
+        e("v_and_b32 %s, 63, v0" % R("v", lane))
+        e("v_and_b32 %s, 15, v0" % R("v", r))
+        e("v_bfe_u32 %s, v0, 4, 2" % R("v", kg))
+        e("v_lshrrev_b32 %s, 6, v0" % R("v", v[3]))
+        e("s_nop 0")
+        e("v_readfirstlane_b32 %s, %s" % (R("s", self.s_w), R("v", v[3])))
+        e("s_nop 3")
+        e("s_lshr_b32 %s, %s, 1" % (R("s", self.s_wm), R("s", self.s_w)))
+        e("s_and_b32 %s, %s, 1" % (R("s", self.s_wn), R("s", self.s_w)))
+        # ---- A read bases: pos0 = wm*MFR*16 + r + kx ; chunk = (kg + 4kk + (pos0 & 6)) & 7
+        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wm), c.MFR * 16 * 128))
+        for kx in range(3):
+            t, ee, cc = v[3], v[4], v[5]
+            e("v_add_u32 %s, %d, %s" % (R("v", t), kx, R("v", r)))
+            e("v_and_b32 %s, 6, %s" % (R("v", ee), R("v", t)))
+            e("v_add_u32 %s, %s, %s" % (R("v", cc), R("v", ee), R("v", kg)))
+            e("v_and_b32 %s, 7, %s" % (R("v", cc), R("v", cc)))
+            e("v_lshlrev_b32 %s, 4, %s" % (R("v", cc), R("v", cc)))
+            e("v_lshl_add_u32 %s, %s, 7, %s" % (R("v", cc), R("v", t), R("v", cc)))
+            e("v_add_u32 %s, %s, %s" % (R("v", cc), R("s", self.s_t0), R("v", cc)))
+            e("v_add_u32 %s, %d, %s" % (R("v", self.vA_rd[kx][0]), ABASE, R("v", cc)))
+            e("v_xor_b32 %s, 64, %s" % (R("v", self.vA_rd[kx][1]), R("v", self.vA_rd[kx][0])))
+        # ---- B read bases: row = wn*NT*16 + r ; chunk = (kg + 4kk) ^ ((r >> 1) & 7)
+        sw, cc = v[3], v[4]
+        e("v_bfe_u32 %s, %s, 1, 3" % (R("v", sw), R("v", r)))
+        e("v_xor_b32 %s, %s, %s" % (R("v", cc), R("v", kg), R("v", sw)))
+        e("v_lshlrev_b32 %s, 4, %s" % (R("v", cc), R("v", cc)))
+        e("v_lshl_add_u32 %s, %s, 7, %s" % (R("v", cc), R("v", r), R("v", cc)))
+        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wn), c.NT * 16 * 128))
+        e("v_add_u32 %s, %s, %s" % (R("v", self.vB_rd[0]), R("s", self.s_t0), R("v", cc)))
+        e("v_xor_b32 %s, 64, %s" % (R("v", self.vB_rd[1]), R("v", self.vB_rd[0])))
+        # ---- A DMA lane parts: x'' = xb*8 + (lane >> 3); j = ((lane & 7) - ((lane >> 3) & 6)) & 7
+        l3, l7, j, x, off = v[3], v[4], v[5], v[6], v[7]
+        e("v_lshrrev_b32 %s, 3, %s" % (R("v", l3), R("v", lane)))
+        e("v_and_b32 %s, 7, %s" % (R("v", l7), R("v", lane)))
+        e("v_and_b32 %s, 6, %s" % (R("v", j), R("v", l3)))
+        e("v_sub_u32 %s, %s, %s" % (R("v", j), R("v", l7), R("v", j)))
+        e("v_and_b32 %s, 7, %s" % (R("v", j), R("v", j)))
+        e("v_lshlrev_b32 %s, 4, %s" % (R("v", j), R("v", j)))
+        for xb in range(c.P // 8):
+            e("v_add_u32 %s, %d, %s" % (R("v", x), xb * 8 - 1, R("v", l3)), "input x of this lane's position")
+            e("v_mov_b32 %s, %d" % (R("v", off), c.Cin * 2))
+            e("v_mad_u32_u24 %s, %s, %s, %s" % (R("v", off), R("v", x), R("v", off), R("v", j)))
+            e("v_cmp_gt_u32 vcc, %d, %s" % (c.W, R("v", x)), "0 <= x < W (x = -1 wraps to 2^32 - 1)")
+            e("v_mov_b32 %s, 0x80000000" % R("v", x))
+            e("v_cndmask_b32 %s, %s, %s, vcc" % (R("v", self.vA_dma[xb]), R("v", x), R("v", off)))
+        # ---- B DMA lane parts (variant ib = piece & 1): rr = 8*ib + (lane>>3)
+        #      channel = (2*ib + (lane>>5))*8 + ((lane>>3)&3) ; chunk = (lane&7) ^ (4*ib + ((lane>>4)&3))
+        l5, l43, ch, x = v[5], v[8], v[7], v[9]
+        e("v_lshrrev_b32 %s, 5, %s" % (R("v", l5), R("v", lane)))
+        e("v_bfe_u32 %s, %s, 4, 2" % (R("v", l43), R("v", lane)))
+        for ib in range(2):
+            e("v_lshl_add_u32 %s, %s, 3, %d" % (R("v", ch), R("v", l5), 16 * ib))
+            e("v_and_b32 %s, 3, %s" % (R("v", x), R("v", l3)))
+            e("v_add_u32 %s, %s, %s" % (R("v", ch), R("v", ch), R("v", x)))
+            e("v_mov_b32 %s, %d" % (R("v", x), c.w_row))
+            e("v_mul_lo_u32 %s, %s, %s" % (R("v", ch), R("v", ch), R("v", x)))
+            e("v_or_b32 %s, %d, %s" % (R("v", x), 4 * ib, R("v", l43)))
+            e("v_xor_b32 %s, %s, %s" % (R("v", x), R("v", l7), R("v", x)))
+            e("v_lshl_add_u32 %s, %s, 4, %s" % (R("v", self.vB_dma[ib]), R("v", x), R("v", ch)))
+        # ---- output lane offset: pixel part * NCOLS*2 + (wn*NT*16 + kg*8)*2
+        x, off = v[6], v[7]
+        if c.P >= 16:
+            e("v_mov_b32 %s, %s" % (R("v", x), R("v", r)))
+        else:  # P == 8: two image rows per fragment
+            e("v_lshrrev_b32 %s, 3, %s" % (R("v", x), R("v", r)))
+            e("v_mul_u32_u24 %s, %d, %s" % (R("v", x), c.W, R("v", x)))
+            e("v_and_b32 %s, 7, %s" % (R("v", off), R("v", r)))
+            e("v_add_u32 %s, %s, %s" % (R("v", x), R("v", x), R("v", off)))
+        e("v_mov_b32 %s, %d" % (R("v", off), c.NCOLS * 2))
+        e("v_mul_lo_u32 %s, %s, %s" % (R("v", x), R("v", x), R("v", off)))
+        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wn), c.NT * 16 * 2))
+        e("v_lshl_add_u32 %s, %s, 4, %s" % (R("v", x), R("v", kg), R("v", x)))
+        e("v_add_u32 %s, %s, %s" % (R("v", self.v_out), R("s", self.s_t0), R("v", x)))
+        # keep r and kg for the epilogue
+        self.v_r, self.v_kg = v[1], v[2]
+
+        # ---- zero the A buffers' halo rows / padding (every byte of both buffers; cheap, once)
+        self.comment("zero both A buffers (halo rows, padding columns are never written by the DMA)")
+        z = self.F[0][0]
+        for i in range(4):
+            e("v_mov_b32 %s, 0" % R("v", z + i))
+        e("v_lshlrev_b32 %s, 4, v0" % R("v", v[3]), "tid*16")
+        e("v_add_u32 %s, %d, %s" % (R("v", v[3]), ABASE, R("v", v[3])))
+        tot = 2 * c.ASTRIDE
+        assert tot % 16 == 0
+        n16 = tot // 16
+        full = n16 // 256
+        for k in range(full):
+            if k and k % 16 == 0:
+                e("v_add_u32 %s, 0x10000, %s" % (R("v", v[3]), R("v", v[3])))
+            e("ds_write_b128 %s, %s offset:%d" % (R("v", v[3]), R("v", z, 4), (k % 16) * 4096))
+        rem = n16 - full * 256
+        if rem:
+            if full % 16 == 0:
+                e("v_add_u32 %s, 0x10000, %s" % (R("v", v[3]), R("v", v[3])))
+            e("v_cmp_gt_u32 vcc, %d, v0" % rem)
+            e("s_nop 4")
+            e("s_and_b64 exec, exec, vcc")
+            e("ds_write_b128 %s, %s offset:%d" % (R("v", v[3]), R("v", z, 4), (full % 16) * 4096))
+            e("s_mov_b64 exec, -1")
+
+        # ---- descriptors ------------------------------------------------------------------------------------------
+        e("s_waitcnt lgkmcnt(0)")
+        self.comment("descriptors: A = this tile's images, B = this column tile's weight rows, O = this tile's output pixels")
+        tile_in = c.IPT * c.H * c.W * c.Cin * 2
+        tile_out = c.IPT * c.H * c.W * c.NCOLS * 2
+        t0, t1 = self.s_t0, self.s_t1
+        # A
+        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_tile), tile_in))
+        e("s_mul_hi_u32 %s, %s, %d" % (R("s", t1), R("s", self.s_tile), tile_in))
+        e("s_add_u32 %s, %s, %s" % (R("s", self.srdA), R("s", ka + 0), R("s", t0)))
+        e("s_addc_u32 %s, %s, %s" % (R("s", self.srdA + 1), R("s", ka + 1), R("s", t1)))
+        e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdA + 1), R("s", self.srdA + 1)))
+        e("s_mov_b32 %s, %d" % (R("s", self.srdA + 2), tile_in))
+        e("s_mov_b32 %s, 0x00020000" % R("s", self.srdA + 3))
+        # B: rows nt*256 .. +256
+        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_nt), c.BN * c.w_row))
+        e("s_add_u32 %s, %s, %s" % (R("s", self.srdB), R("s", ka + 2), R("s", t0)))
+        e("s_addc_u32 %s, %s, 0" % (R("s", self.srdB + 1), R("s", ka + 3)))
+        e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdB + 1), R("s", self.srdB + 1)))
+        e("s_mov_b32 %s, %d" % (R("s", self.srdB + 2), c.BN * c.w_row))
+        e("s_mov_b32 %s, 0x00020000" % R("s", self.srdB + 3))
+        # O: + tile*tile_out + nt*512 bytes
+        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_tile), tile_out))
+        e("s_mul_hi_u32 %s, %s, %d" % (R("s", t1), R("s", self.s_tile), tile_out))
+        e("s_lshl_b32 %s, %s, 9" % (R("s", self.s_stg), R("s", self.s_nt)))
+        e("s_add_u32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", self.s_stg)))
+        e("s_addc_u32 %s, %s, 0" % (R("s", t1), R("s", t1)))
+        e("s_add_u32 %s, %s, %s" % (R("s", self.srdO), R("s", ka + 4), R("s", t0)))
+        e("s_addc_u32 %s, %s, %s" % (R("s", self.srdO + 1), R("s", ka + 5), R("s", t1)))
+        e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdO + 1), R("s", self.srdO + 1)))
+        e("s_mov_b32 %s, %d" % (R("s", self.srdO + 2), tile_out - 0))
+        e("s_mov_b32 %s, 0x00020000" % R("s", self.srdO + 3))
+        # (the O window starts at this tile's column offset, so its last bytes end nt*512 short of the window: harmless,
+        #  num_records only has to cover what is stored: subtract the column offset)
+        e("s_sub_u32 %s, %s, %s" % (R("s", self.srdO + 2), R("s", self.srdO + 2), R("s", self.s_stg)))
+        e("s_mov_b32 %s, %s" % (R("s", self.srdX), R("s", ka + 6)), "statistics rows")
+        e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdX + 1), R("s", ka + 7)))
+        e("s_mov_b32 %s, 0x7fffffff" % R("s", self.srdX + 2))
+        e("s_mov_b32 %s, 0x00020000" % R("s", self.srdX + 3))
+        e("s_mov_b32 %s, %s" % (R("s", self.s_nch), R("s", kb + 3)))
+        e("s_mov_b32 %s, %s" % (R("s", self.s_wt + 8), R("s", kb + 2)))
+        # per-wave table
+        e("s_lshl_b32 %s, %s, 7" % (R("s", t0), R("s", self.s_w)))
+        e("s_add_u32 %s, %s, %s" % (R("s", kb), R("s", kb), R("s", t0)))
+        e("s_addc_u32 %s, %s, 0" % (R("s", kb + 1), R("s", kb + 1)))
+        e("s_load_dwordx16 %s, %s, 0x0" % (R("s", self.s_tbl, 16), R("s", kb, 2)))
+        e("s_load_dwordx16 %s, %s, 0x40" % (R("s", self.s_tbl + 16, 16), R("s", kb, 2)))
+        e("s_lshl_b32 %s, %s, 13" % (R("s", self.s_ldsBw), R("s", self.s_w)), "this wave's 8 KiB of a weight stage")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier", "every wave's zero fill is done before any LDS-DMA lands in the A buffers")
+
+        # ---- first loads: A(0), B stage 0, B stage 1 ----------------------------------------------------------------
+        self.comment("first loads: A tile of chunk 0, weight stages 0 and 1")
+        e("s_mov_b32 %s, 0" % R("s", self.s_cC))
+        for i in range(self.NPA):
+            self.a_piece(i, 0, soff_chunk=self.s_cC)
+        self.b_stage_issue_all(0, 0, self.s_cC)
+        self.b_stage_issue_all(1, 1, self.s_cC)
+        e("s_waitcnt vmcnt(8)")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier")
+        # accumulators = 0
+        for i in range(self.nagpr):
+            e("v_accvgpr_write_b32 a%d, 0" % i)
+        # fragments of (stage 0, kk 0)
+        for ins in self.frag_reads(0, 0, 0, 0):
+            e(ins)
+        e("s_mov_b32 %s, %s" % (R("s", self.s_cnt), R("s", self.s_nch)))
+
+    # one A piece (slot i of the schedule) of the NEXT chunk (or chunk 0 in the prologue) into A buffer `buf`
+    def a_piece(self, i, buf, soff_chunk):
+        c, e = self.c, self.e
+        var = a_schedule(c)[i][0]
+        e("s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", soff_chunk), R("s", self.s_tA_src + i)))
+        e("s_add_u32 m0, %s, %d" % (R("s", self.s_tA_lds + i), ABASE + buf * c.ASTRIDE))
+        e("buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vA_dma[var]), R("s", self.srdA, 4), R("s", self.s_t0)))
+
+    def b_piece_insts(self, i, bp, s_stage):
+        """the three instructions of weight piece i into ring stage bp; s_stage holds (wtap*Cin + chunk*64)*2"""
+        c = self.c
+        return ["s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", s_stage), R("s", self.s_tB + i)),
+                "s_add_u32 m0, %s, %d" % (R("s", self.s_ldsBw), bp * c.BSTAGE + i * 1024),
+                "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vB_dma[i & 1]), R("s", self.srdB, 4), R("s", self.s_t0))]
+
+    def b_stage_issue_all(self, tap, bp, s_chunk):
+        e = self.e
+        e("s_add_u32 %s, %s, %s" % (R("s", self.s_stg), R("s", self.s_wt + tap), R("s", s_chunk)))
+        for i in range(8):
+            for ins in self.b_piece_insts(i, bp, self.s_stg):
+                e(ins)
+
+    def frag_reads(self, fset, tap, kk, bp):
+        """ds_read_b128 list of the fragments of (tap, kk) from the CURRENT A bases and weight stage bp into fragment set fset"""
+        c = self.c
+        ky, kx = divmod(tap, 3)
+        fa, fb = self.F[fset]
+        out = []
+        # weights first: the first MFMAs of a substep need B0 and A0
+        order = []
+        for n in range(c.NT):
+            order.append(("b", n))
+            if n < c.MFR:
+                order.append(("a", n))
+        for m in range(c.NT, c.MFR):
+            order.append(("a", m))
+        for kind, i in order:
+            if kind == "a":
+                off = i * 2048 + ky * c.P * 128  # fragment i starts at position 16*i, the tap's row shift is ky*P positions
+                out.append("ds_read_b128 %s, %s offset:%d" % (R("v", fa + 4 * i, 4), R("v", self.vA_rd[kx][kk]), off))
+            else:
+                off = bp * c.BSTAGE + i * 2048
+                out.append("ds_read_b128 %s, %s offset:%d" % (R("v", fb + 4 * i, 4), R("v", self.vB_rd[kk]), off))
+        return out
+
+    def mfmas(self, fset):
+        c = self.c
+        fa, fb = self.F[fset]
+        out = []
+        for n in range(c.NT):
+            for m in range(c.MFR):
+                acc = (m * c.NT + n) * 4
+                out.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (R("a", acc, 4), R("v", fb + 4 * n, 4), R("v", fa + 4 * m, 4), R("a", acc, 4)))
+        return out
+
+    def interleave(self, mf, others, first=1):
+        """place the instruction groups `others` (lists) between the MFMAs, evenly, starting after MFMA `first`"""
+        n, k = len(mf), len(others)
+        slots = {}
+        if k:
+            span = n - first - 1
+            for j, grp in enumerate(others):
+                pos = first + (j * span) // k
+                slots.setdefault(pos, []).extend(grp)
+        for i, m in enumerate(mf):
+            self.e(m)
+            for ins in slots.get(i, []):
+                self.e(ins)
+
+    def skew(self):
+        c, e = self.c, self.e
+        if not c.skew:
+            return
+        lab = self.newlabel("skew")
+        for k in range(1, 4):
+            e("s_cmp_lt_u32 %s, %d" % (R("s", self.s_w), k))
+            e("s_cbranch_scc1 %s" % lab)
+            e("s_nop %d" % (c.skew - 1))
+        self.label(lab)
+
+    def mainloop(self):
+        c, e = self.c, self.e
+        self.comment("---- main loop: chunks (2 per trip: the A buffer and the weight-stage parity alternate) x 9 taps x 2 substeps")
+        top, done = self.newlabel("loop"), self.newlabel("done")
+        self.label(top)
+        for cp in range(2):
+            # chunk offsets: current and next (the last chunk re-loads chunk 0: valid memory, never used)
+            e("s_add_u32 %s, %s, 128" % (R("s", self.s_cN), R("s", self.s_cC)))
+            e("s_cmp_eq_u32 %s, 1" % R("s", self.s_cnt))
+            e("s_cbranch_scc0 %s" % (lab := self.newlabel("notlast")))
+            e("s_mov_b32 %s, 0" % R("s", self.s_cN))
+            self.label(lab)
+            for t in range(9):
+                bp = (cp + t) & 1
+                # ---- substep kk = 0: compute on set 0, read (t, kk 1) into set 1, one A piece of the next chunk
+                self.comment("chunk parity %d tap %d substep 0" % (cp, t))
+                e("s_waitcnt lgkmcnt(0)")
+                groups = [[r] for r in self.frag_reads(1, t, 1, bp)]
+                mf = self.mfmas(0)
+                pieces = []
+                if t < self.NPA:
+                    var = a_schedule(c)[t][0]
+                    pieces.append(["s_add_u32 %s, %s, %s" % (R("s", self.s_t1), R("s", self.s_cN), R("s", self.s_tA_src + t)),
+                                   "s_add_u32 m0, %s, %d" % (R("s", self.s_tA_lds + t), ABASE + (cp ^ 1) * c.ASTRIDE),
+                                   "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vA_dma[var]), R("s", self.srdA, 4), R("s", self.s_t1))])
+                self.interleave(mf, self.merge(groups, pieces))
+                # ---- the stage barrier: stage t+1's weights (and after tap 8 the next A tile) have landed for every wave
+                self.comment("chunk parity %d tap %d substep 1" % (cp, t))
+                e("s_waitcnt vmcnt(%d)" % (1 if t < self.NPA else 0))
+                e("s_waitcnt lgkmcnt(0)")
+                e("s_barrier")
+                self.skew()
+                t2 = (t + 1) % 9
+                if t == 8:  # next chunk: the A bases move to the other buffer
+                    d = c.ASTRIDE if cp == 0 else -c.ASTRIDE
+                    for kx in range(3):
+                        for kk in range(2):
+                            rr = R("v", self.vA_rd[kx][kk])
+                            e("v_add_u32 %s, %d, %s" % (rr, d, rr) if d > 0 else "v_subrev_u32 %s, %d, %s" % (rr, -d, rr))
+                groups = [[r] for r in self.frag_reads(0, t2, 0, bp ^ 1)]
+                # weight stage t+2 into ring stage bp
+                t3 = (t + 2) % 9
+                s_ch = self.s_cC if t + 2 < 9 else self.s_cN
+                pieces = []
+                for i in range(8):
+                    g = self.b_piece_insts(i, bp, self.s_stg)
+                    if i == 0:
+                        g = ["s_add_u32 %s, %s, %s" % (R("s", self.s_stg), R("s", self.s_wt + t3), R("s", s_ch))] + g
+                    pieces.append(g)
+                mf = self.mfmas(1)
+                self.interleave(mf, self.merge(groups, pieces))
+            # next chunk
+            e("s_mov_b32 %s, %s" % (R("s", self.s_cC), R("s", self.s_cN)))
+            e("s_sub_u32 %s, %s, 1" % (R("s", self.s_cnt), R("s", self.s_cnt)))
+            e("s_cmp_eq_u32 %s, 0" % R("s", self.s_cnt))
+            if cp == 0:
+                e("s_cbranch_scc1 %s" % done)
+            else:
+                e("s_cbranch_scc0 %s" % top)
+        self.label(done)
+
+    @staticmethod
+    def merge(a, b):
+        """merge two group lists evenly (b spread through a)"""
+        if not b:
+            return a
+        out = []
+        na, nb = len(a), len(b)
+        ib = 0
+        for i, g in enumerate(a):
+            out.append(g)
+            while ib < nb and (ib + 1) * na <= (i + 1) * nb:
+                out.append(b[ib])
+                ib += 1
+        out.extend(b[ib:])
+        return out
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def frag_out(self, f):
+        """(exec mask, output byte offset constant) of global fragment f (0 .. NFRAG-1)"""
+        c = self.c
+        mask = 0
+        for r in range(16):
+            po = 16 * f + r
+            go, xo = divmod(po, c.P)
+            if c.IPT > 1:
+                i, y = divmod(go, c.SR)
+            else:
+                i, y = 0, go
+            ok = xo < c.W and y < c.H and i < c.IPT
+            if ok:
+                for q in range(4):
+                    mask |= 1 << (16 * q + r)
+        # constant: pixel index of lane r = 0 of the fragment minus the lane part at r = 0 (which is 0)
+        po = 16 * f
+        go, xo = divmod(po, c.P)
+        if c.IPT > 1:
+            i, y = divmod(go, c.SR)
+        else:
+            i, y = 0, go
+        pix = (i * c.H + y) * c.W + xo
+        return mask, pix * c.NCOLS * 2
+
+    def epilogue(self):
+        c, e = self.c, self.e
+        self.comment("---- epilogue")
+        e("s_waitcnt vmcnt(0)")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier", "every LDS-DMA of the (unused) lookahead has landed: the ring is free for the statistics scratch")
+        e("s_nop 15")
+        e("s_nop 15")
+        V = self.V
+        base = self.F[0][0]           # fragment registers are free now
+        tv = [base + i for i in range(8)]            # accumulator values
+        dsets = [base + 8 + 4 * i for i in range(4)]  # packed bf16 data, rotating
+        xr = [base + 24 + i for i in range(8)]
+        s1 = [base + 32 + i for i in range(8)]
+        s2 = [base + 40 + i for i in range(8)]
+        vst = base + 48               # LDS address of this lane's statistics slot
+        assert base + 49 <= self.F[1][1] + 4 * c.NT
+        if c.stats:
+            # STAT scratch: [wm][256 channels][2] floats at LDS 0 ; this lane (r == 15) owns channels wn*128 + p*32 + kg*8 + e
+            e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wm), c.BN * 8))
+            e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t1), R("s", self.s_wn), c.NT * 16 * 8))
+            e("s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", self.s_t0), R("s", self.s_t1)))
+            e("v_lshl_add_u32 %s, %s, 6, %s" % (R("v", vst), R("v", self.v_kg), R("s", self.s_t0)))
+        if c.stats == 2:
+            raise NotImplementedError
+        for p in range(c.NT // 2):
+            if c.stats:
+                for i in range(8):
+                    e("v_mov_b32 %s, 0" % R("v", s1[i]))
+                    e("v_mov_b32 %s, 0" % R("v", s2[i]))
+            for m in range(c.MFR):
+                # the exec mask and output offset depend on the GLOBAL fragment wm*MFR + m: both wave rows take the same code
+                # when the masks agree; otherwise select by s_wm
+                f0, f1 = self.frag_out(m), self.frag_out(c.MFR + m)
+                e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wm), f1[1] - f0[1]))
+                e("s_add_u32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_t0), f0[1]))
+                if f0[0] == f1[0]:
+                    self.set_exec(f0[0])
+                else:
+                    lab, lab2 = self.newlabel("m1"), self.newlabel("m2")
+                    e("s_cmp_eq_u32 %s, 0" % R("s", self.s_wm))
+                    e("s_cbranch_scc0 %s" % lab)
+                    self.set_exec(f0[0])
+                    e("s_branch %s" % lab2)
+                    self.label(lab)
+                    self.set_exec(f1[0])
+                    self.label(lab2)
+                d = dsets[m % 4]
+                for i in range(4):
+                    e("v_accvgpr_read_b32 %s, a%d" % (R("v", tv[i]), (m * c.NT + 2 * p) * 4 + i))
+                    e("v_accvgpr_read_b32 %s, a%d" % (R("v", tv[4 + i]), (m * c.NT + 2 * p + 1) * 4 + i))
+                for i in range(4):
+                    e("v_cvt_pk_bf16_f32 %s, %s, %s" % (R("v", d + i), R("v", tv[2 * i]), R("v", tv[2 * i + 1])))
+                e("buffer_store_dwordx4 %s, %s, %s, %s offen offset:%d" % (R("v", d, 4), R("v", self.v_out), R("s", self.srdO, 4), R("s", self.s_t0), p * 64))
+                if c.stats == 1:
+                    for i in range(4):
+                        e("v_lshlrev_b32 %s, 16, %s" % (R("v", xr[2 * i]), R("v", d + i)))
+                        e("v_and_b32 %s, 0xffff0000, %s" % (R("v", xr[2 * i + 1]), R("v", d + i)))
+                    for i in range(8):
+                        e("v_add_f32 %s, %s, %s" % (R("v", s1[i]), R("v", s1[i]), R("v", xr[i])))
+                        e("v_fma_f32 %s, %s, %s, %s" % (R("v", s2[i]), R("v", xr[i]), R("v", xr[i]), R("v", s2[i])))
+            if c.stats:
+                e("s_mov_b64 exec, -1")
+                e("s_nop 1")
+                for sh in (1, 2, 4, 8):
+                    for arr in (s1, s2):
+                        for i in range(8):
+                            rr = R("v", arr[i])
+                            e("v_add_f32_dpp %s, %s, %s row_shr:%d row_mask:0xf bank_mask:0xf bound_ctrl:1" % (rr, rr, rr, sh))
+                # lanes 15 of every row write their 8 channel slots: [channel][2]
+                self.set_exec(0x8000800080008000)
+                for i in range(8):
+                    e("ds_write_b32 %s, %s offset:%d" % (R("v", vst), R("v", s1[i]), p * 32 * 8 + i * 8))
+                    e("ds_write_b32 %s, %s offset:%d" % (R("v", vst), R("v", s2[i]), p * 32 * 8 + i * 8 + 4))
+                e("s_mov_b64 exec, -1")
+        if c.stats:
+            # partial row of this workgroup: row[c] = sum, row[NCOLS + c] = sum of squares, c = nt*256 + tid
+            e("s_waitcnt lgkmcnt(0)")
+            e("s_barrier")
+            a0, a1, b0, b1, ad, go = tv[0], tv[1], tv[2], tv[3], tv[4], tv[5]
+            e("v_lshlrev_b32 %s, 3, v0" % R("v", ad))
+            e("ds_read_b64 %s, %s" % (R("v", a0, 2), R("v", ad)))
+            e("ds_read_b64 %s, %s offset:%d" % (R("v", b0, 2), R("v", ad), c.BN * 8))
+            # global offset: (tile*2*NCOLS + nt*256 + tid)*4
+            e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_tile), 2 * c.NCOLS * 4))
+            e("s_lshl_b32 %s, %s, 10" % (R("s", self.s_t1), R("s", self.s_nt)))
+            e("s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", self.s_t0), R("s", self.s_t1)))
+            e("v_lshlrev_b32 %s, 2, v0" % R("v", go))
+            e("s_waitcnt lgkmcnt(0)")
+            # a0/a1 = (sum, sq) of wave row 0, b0/b1 of wave row 1 — (a0, a1) must be an aligned pair: tv[0] is 4-aligned
+            e("v_add_f32 %s, %s, %s" % (R("v", a0), R("v", a0), R("v", b0)))
+            e("v_add_f32 %s, %s, %s" % (R("v", a1), R("v", a1), R("v", b1)))
+            e("buffer_store_dword %s, %s, %s, %s offen" % (R("v", a0), R("v", go), R("s", self.srdX, 4), R("s", self.s_t0)))
+            e("s_add_u32 %s, %s, %d" % (R("s", self.s_t1), R("s", self.s_t0), c.NCOLS * 4))
+            e("buffer_store_dword %s, %s, %s, %s offen" % (R("v", a1), R("v", go), R("s", self.srdX, 4), R("s", self.s_t1)))
+        e("s_waitcnt vmcnt(0)")
+        e("s_endpgm")
+
+    def set_exec(self, mask):
+        e = self.e
+        lo, hi = mask & 0xFFFFFFFF, mask >> 32
+        e("s_mov_b32 exec_lo, 0x%x" % lo)
+        e("s_mov_b32 exec_hi, 0x%x" % hi)
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def finish(self):
+        c = self.c
+        name = c.name
+        lds = ABASE + 2 * c.ASTRIDE  # B ring, two A buffers each followed by the sink of its padding pieces
+        assert lds <= 160 * 1024
+        total_v = self.accum_offset + self.nagpr
+        hdr = []
+        hdr.append('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
+        hdr.append("\t.amdhsa_code_object_version 6")
+        hdr.append("\t.text")
+        hdr.append("\t.protected\t%s" % name)
+        hdr.append("\t.globl\t%s" % name)
+        hdr.append("\t.p2align\t8")
+        hdr.append("\t.type\t%s,@function" % name)
+        hdr.append("%s:" % name)
+        tail = []
+        tail.append("\t.section\t.rodata,\"a\",@progbits")
+        tail.append("\t.p2align\t6, 0x0")
+        tail.append("\t.amdhsa_kernel %s" % name)
+        kd = dict(group_segment_fixed_size=lds, private_segment_fixed_size=0, kernarg_size=self.KA["size"],
+                  user_sgpr_count=2, user_sgpr_dispatch_ptr=0, user_sgpr_queue_ptr=0, user_sgpr_kernarg_segment_ptr=1,
+                  user_sgpr_dispatch_id=0, user_sgpr_kernarg_preload_length=0, user_sgpr_kernarg_preload_offset=0,
+                  user_sgpr_private_segment_size=0, uses_dynamic_stack=0, enable_private_segment=0,
+                  system_sgpr_workgroup_id_x=1, system_sgpr_workgroup_id_y=1, system_sgpr_workgroup_id_z=0,
+                  system_sgpr_workgroup_info=0, system_vgpr_workitem_id=0, next_free_vgpr=total_v,
+                  next_free_sgpr=self.S.n, accum_offset=self.accum_offset, reserve_vcc=1, float_round_mode_32=0,
+                  float_round_mode_16_64=0, float_denorm_mode_32=3, float_denorm_mode_16_64=3, dx10_clamp=1, ieee_mode=1,
+                  fp16_overflow=0, tg_split=0)
+        for k, v in kd.items():
+            tail.append("\t\t.amdhsa_%s %d" % (k, v))
+        tail.append("\t.end_amdhsa_kernel")
+        tail.append("\t.text")
+        tail.append("\t.amdgpu_metadata")
+        tail.append("---")
+        tail.append("amdhsa.kernels:")
+        tail.append("  - .agpr_count:     %d" % self.nagpr)
+        tail.append("    .args:")
+        off = 0
+        for i in range(9):
+            tail.append("      - .address_space:  global\n        .offset:         %d\n        .size:           8\n        .value_kind:     global_buffer" % off)
+            off += 8
+        for i in range(10):
+            tail.append("      - .offset:         %d\n        .size:           4\n        .value_kind:     by_value" % off)
+            off += 4
+        assert off == self.KA["size"]
+        tail.append("    .group_segment_fixed_size: %d" % lds)
+        tail.append("    .kernarg_segment_align: 8")
+        tail.append("    .kernarg_segment_size: %d" % self.KA["size"])
+        tail.append("    .max_flat_workgroup_size: 256")
+        tail.append("    .name:           %s" % name)
+        tail.append("    .private_segment_fixed_size: 0")
+        tail.append("    .sgpr_count:     %d" % (self.S.n + 6))
+        tail.append("    .sgpr_spill_count: 0")
+        tail.append("    .symbol:         %s.kd" % name)
+        tail.append("    .uniform_work_group_size: 1")
+        tail.append("    .uses_dynamic_stack: false")
+        tail.append("    .vgpr_count:     %d" % total_v)
+        tail.append("    .vgpr_spill_count: 0")
+        tail.append("    .wavefront_size: 64")
+        tail.append("amdhsa.target:   amdgcn-amd-amdhsa--gfx950")
+        tail.append("amdhsa.version:\n  - 1\n  - 2")
+        tail.append("...")
+        tail.append("\t.end_amdgpu_metadata")
+        body = self.out + ["\t.p2align 8", ".Lend_%s:" % name, "\t.size\t%s, .Lend_%s-%s" % (name, name, name)]
+        self.lds_bytes = lds
+        return "\n".join(hdr + body + tail) + "\n"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+VARIANTS = {
+    # name: geometry of the launches it serves (ResNet-50 at 224 px: layer 3 = 14 x 14 x 256, layer 4 = 7 x 7 x 512)
+    "dconv_l3_s1": Cfg("dconv_l3_s1", H=14, W=14, P=16, IPT=1, Cin=256, NCOLS=256, stats=1),
+    "dconv_l3_s0": Cfg("dconv_l3_s0", H=14, W=14, P=16, IPT=1, Cin=256, NCOLS=256, stats=0),
+}
+
+
+def generate(name, **over):
+    c = VARIANTS[name]
+    if over:
+        c = Cfg(**{**c.__dict__, **over})
+    g = Gen(c)
+    text = g.gen()
+    return c, g, text
+
+
+def write_meta(out_dir, hsaco):
+    """dconv_blob.inc: the linked code object as a byte array; dconv_meta.inc: one DconvVariant initialiser per kernel"""
+    blob = open(hsaco, "rb").read()
+    with open(os.path.join(out_dir, "dconv_blob.inc"), "w") as f:
+        for i in range(0, len(blob), 32):
+            f.write(",".join(str(b) for b in blob[i:i + 32]) + ",\n")
+    with open(os.path.join(out_dir, "dconv_meta.inc"), "w") as f:
+        for name in VARIANTS:
+            c, g, _ = generate(name)
+            tab = tables(c)
+            words = ",".join("%du" % w for row in tab for w in row)
+            f.write('{"%s", %d, %d, %d, %d, %d, %d, %d, %d, {%s}},\n' % (name, c.H, c.W, c.IPT, c.Cin, c.NCOLS, c.stats, g.lds_bytes, Gen.KA["size"], words))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="build")
+    ap.add_argument("--embed", default=None, help="linked .hsaco: write dconv_blob.inc / dconv_meta.inc instead of the .s files")
+    ap.add_argument("names", nargs="*")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    if a.embed:
+        write_meta(a.out, a.embed)
+        return
+    for name in (a.names or VARIANTS):
+        c, g, text = generate(name)
+        with open(os.path.join(a.out, name + ".s"), "w") as f:
+            f.write(text)
+        print("%s: %d lines, %d VGPR + %d AGPR, %d SGPR, LDS %d" % (name, text.count("\n"), g.accum_offset, g.nagpr, g.S.n, g.lds_bytes))
+
+
+if __name__ == "__main__":
+    main()

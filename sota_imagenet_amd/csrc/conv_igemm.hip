@@ -823,6 +823,10 @@ int launch_conv3(const IgemmArgs& a, hipStream_t stream, int* stat_rows);
 bool stem_direct_legal(const IgemmArgs& a, int nclass);
 int launch_stem_direct(const IgemmArgs& a, hipStream_t stream, int* stat_rows);
 
+// dconv.cpp: the generated one-wave-per-SIMD direct 3x3 / stride-1 kernels (asm/dconv_gen.py) for the layer-3 / layer-4 shapes
+bool dconv_legal(const IgemmArgs& a, int nclass);
+int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows);
+
 // conv_igemm8.hip
 bool igemm8_legal(const IgemmArgs& a, int nclass, int bn);
 int launch_igemm8(const IgemmArgs& a, int nclass, int bm, int bn, int korder, int fat, hipStream_t stream, int* stat_rows);
@@ -895,6 +899,7 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
   if (dtype == MI355_F32)
     return wide ? launch_t<float, 128, 128>(a, nclass, stream, stat_rows) : launch_t<float, 128, 64>(a, nclass, stream, stat_rows);
   if (dtype == MI355_BF16) {
+    if (dconv_legal(a, nclass)) return launch_dconv(a, nclass, stream, stat_rows);
     {
       // MI355_CONV3=1: the layer-1 3x3 launches on the direct-convolution kernel (conv3x3.hip).  Bit-exact, and measured no faster
       // than the 3-workgroups-per-CU implicit-GEMM tile (111 vs 118 us per launch from cold caches, profiles/README.md): off by default.

@@ -1,0 +1,177 @@
+// dconv.cpp — host side of the generated direct 3x3 / stride-1 convolution kernels (asm/dconv_gen.py): the code object is
+// embedded in this library, loaded per device with hipModuleLoadData, and launched with the IgemmArgs contract of
+// launch_igemm() (conv forward / data gradient under `model(data)` / `loss.backward()`,
+// /root/reference/sota_imagenet/callbacks.py:316-317).
+#include <cstdlib>
+#include <mutex>
+
+#include "common.h"
+
+namespace mi355 {
+
+namespace {
+
+struct DconvVariant {
+  const char* name;
+  int H, W, IPT, Cin, NCOLS, stats, lds, kernarg;
+  unsigned table[4 * 32];  // per-wave LDS-DMA piece table (asm/dconv_gen.py tables())
+};
+
+const DconvVariant g_variants[] = {
+#include "build/asm/dconv_meta.inc"
+};
+constexpr int NVAR = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
+
+alignas(4096) const unsigned char g_blob[] = {
+#include "build/asm/dconv_blob.inc"
+};
+
+struct DevState {
+  bool tried = false, ok = false;
+  hipModule_t mod = nullptr;
+  hipFunction_t fn[NVAR] = {};
+  unsigned* tables = nullptr;  // NVAR x 128 words in device memory
+};
+DevState g_dev[64];
+std::mutex g_mu;
+
+// loads the module on the current device (once); false with the error set when the runtime refuses it
+bool dev_state(DevState** out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    set_error("dconv: no current device");
+    return false;
+  }
+  std::lock_guard<std::mutex> lock(g_mu);
+  DevState& d = g_dev[dev];
+  if (!d.tried) {
+    d.tried = true;
+    hipError_t e = hipModuleLoadData(&d.mod, g_blob);
+    if (e != hipSuccess) {
+      set_error("dconv: hipModuleLoadData -> %s", hipGetErrorString(e));
+      return false;
+    }
+    for (int i = 0; i < NVAR; ++i) {
+      e = hipModuleGetFunction(&d.fn[i], d.mod, g_variants[i].name);
+      if (e != hipSuccess) {
+        set_error("dconv: hipModuleGetFunction(%s) -> %s", g_variants[i].name, hipGetErrorString(e));
+        return false;
+      }
+    }
+    e = hipMalloc((void**)&d.tables, sizeof(unsigned) * 128 * NVAR);
+    if (e != hipSuccess) {
+      set_error("dconv: hipMalloc -> %s", hipGetErrorString(e));
+      return false;
+    }
+    for (int i = 0; i < NVAR; ++i) {
+      e = hipMemcpy(d.tables + 128 * i, g_variants[i].table, sizeof(unsigned) * 128, hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+        set_error("dconv: hipMemcpy -> %s", hipGetErrorString(e));
+        return false;
+      }
+    }
+    d.ok = true;
+  }
+  if (!d.ok) {
+    set_error("dconv: module load failed earlier on this device");
+    return false;
+  }
+  *out = &d;
+  return true;
+}
+
+// the 9 taps of a stride-1 3x3 class as wtap[(dh + 1)*3 + (dw + 1)], false when the class is not that pattern
+bool tap_table(const TapClass& c, int wtap[9]) {
+  if (c.ntaps != 9 || c.ph != 0 || c.pw != 0) return false;
+  bool seen[9] = {};
+  for (int t = 0; t < 9; ++t) {
+    const Tap& tp = c.taps[t];
+    if (tp.dh < -1 || tp.dh > 1 || tp.dw < -1 || tp.dw > 1 || tp.wtap < 0 || tp.wtap >= 9) return false;
+    const int k = (tp.dh + 1) * 3 + (tp.dw + 1);
+    if (seen[k]) return false;
+    seen[k] = true;
+    wtap[k] = tp.wtap;
+  }
+  return true;
+}
+
+int find_variant(const IgemmArgs& a, int nclass, int stats) {
+  if (nclass != 1 || a.IS != 1 || a.OS != 1 || a.pair_delta != 0 || a.wtaps != 9) return -1;
+  if (a.Hsub != a.Hin || a.Wsub != a.Win || a.Hout != a.Hin || a.Wout != a.Win) return -1;
+  if (a.pix_stride != a.Ck || a.addend != nullptr || a.sk_ws != nullptr || a.fin.mode != 0) return -1;
+  if (a.q_scale_in != nullptr || a.q_scale_wt != nullptr) return -1;
+  int wtap[9];
+  if (!tap_table(a.cls[0], wtap)) return -1;
+  for (int i = 0; i < NVAR; ++i) {
+    const DconvVariant& v = g_variants[i];
+    if (v.H == a.Hin && v.W == a.Win && v.Cin == a.Ck && v.NCOLS == a.Ncols && v.stats == stats && a.N % v.IPT == 0) return i;
+  }
+  return -1;
+}
+
+int wanted_stats(const IgemmArgs& a) { return a.stat_partial == nullptr ? 0 : (a.bn_y != nullptr ? 2 : 1); }
+
+}  // namespace
+
+// MI355_DCONV=0 keeps every launch on the implicit-GEMM kernels (A/B, tests); read once
+static bool dconv_enabled() {
+  static const bool on = !(getenv("MI355_DCONV") && getenv("MI355_DCONV")[0] == '0');
+  return on;
+}
+
+bool dconv_legal(const IgemmArgs& a, int nclass) {
+  if (!dconv_enabled()) return false;
+  const int v = find_variant(a, nclass, wanted_stats(a));
+  if (v < 0) return false;
+  // one partial statistics row per tile: bn_finalize adds at most bn_max_blocks() rows
+  if (a.stat_partial != nullptr && a.N / g_variants[v].IPT > (bn_max_blocks() < 768 ? bn_max_blocks() : 768)) return false;  // (768: the per-op API's buffer)
+  return true;
+}
+
+int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
+  const int vi = find_variant(a, nclass, wanted_stats(a));
+  MI355_ARG(vi >= 0, "dconv: no kernel variant for this launch");
+  const DconvVariant& v = g_variants[vi];
+  DevState* d = nullptr;
+  if (!dev_state(&d)) return MI355_E_HIP;
+  int wtap[9];
+  tap_table(a.cls[0], wtap);
+  struct __attribute__((packed)) KArgs {
+    const void* in;
+    const void* wt;
+    void* out;
+    float* stat;
+    const void* bn_y;
+    const void* bn_bits;
+    const float* bn_mean;
+    const float* bn_invstd;
+    const unsigned* table;
+    unsigned wtap_off[9];
+    unsigned nchunks;
+  } k;
+  static_assert(sizeof(KArgs) == 112, "kernarg layout of asm/dconv_gen.py (Gen.KA)");
+  MI355_ARG((int)sizeof(KArgs) == v.kernarg, "dconv: kernarg size mismatch");
+  k.in = a.in;
+  k.wt = a.wt;
+  k.out = a.out;
+  k.stat = a.stat_partial;
+  k.bn_y = a.bn_y;
+  k.bn_bits = a.bn_bits;
+  k.bn_mean = a.bn_mean;
+  k.bn_invstd = a.bn_invstd;
+  k.table = d->tables + 128 * vi;
+  for (int t = 0; t < 9; ++t) k.wtap_off[t] = (unsigned)(wtap[t] * a.Ck * 2);
+  k.nchunks = (unsigned)(a.Ck / 64);
+  size_t ksize = sizeof(k);
+  void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
+  const int tiles = a.N / v.IPT;
+  const hipError_t e = hipModuleLaunchKernel(d->fn[vi], (unsigned)tiles, (unsigned)(a.Ncols / 256), 1, 256, 1, 1, 0, stream, nullptr, extra);
+  if (e != hipSuccess) {
+    set_error("dconv: hipModuleLaunchKernel(%s) -> %s", v.name, hipGetErrorString(e));
+    return MI355_E_HIP;
+  }
+  if (stat_rows) *stat_rows = a.stat_partial ? tiles : 0;
+  return 0;
+}
+
+}  // namespace mi355

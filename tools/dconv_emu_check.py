@@ -1,0 +1,99 @@
+"""dconv_emu_check.py — run a generated direct-conv kernel (csrc/asm/dconv_gen.py) in the CPU emulator (tools/gcn_emu.py)
+against a numpy convolution on exact small-integer data.  Test infrastructure; used by tests/test_dconv_emu.py."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "sota_imagenet_amd", "csrc", "asm"))
+
+import dconv_gen  # noqa: E402
+import gcn_emu  # noqa: E402
+
+
+def to_bf16_bits(x):
+    u = np.asarray(x, dtype=np.float32).view(np.uint32)
+    assert ((u & 0xFFFF) == 0).all(), "test data must be exactly representable in bf16"
+    return (u >> 16).astype(np.uint16)
+
+
+def from_bf16_bits(b):
+    return (np.asarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def bf16_round(x):
+    return from_bf16_bits(gcn_emu.bf16_round_rne(np.asarray(x, dtype=np.float32)).astype(np.uint16))
+
+
+def conv_ref(x, w, taps):
+    """x [N][H][W][C], w [Co][9][C] (float64); taps: list of 9 (dh, dw, wtap) -> out [N][H][W][Co]"""
+    N, H, W, C = x.shape
+    Co = w.shape[0]
+    xp = np.zeros((N, H + 2, W + 2, C))
+    xp[:, 1:H + 1, 1:W + 1] = x
+    out = np.zeros((N, H, W, Co))
+    for dh, dw, wt in taps:
+        out += np.einsum("nhwc,oc->nhwo", xp[:, 1 + dh:1 + dh + H, 1 + dw:1 + dw + W], w[:, wt])
+    return out
+
+
+def run(name, tiles=(0,), ntile=0, seed=0, dgrad_taps=False, check=True, **over):
+    c, g, text = dconv_gen.generate(name, **over)
+    rng = np.random.default_rng(seed)
+    ntiles = max(tiles) + 1
+    N = ntiles * c.IPT
+    x = rng.integers(-2, 3, size=(N, c.H, c.W, c.Cin)).astype(np.float32)
+    w = rng.integers(-2, 3, size=(c.NCOLS, 9, c.Cin)).astype(np.float32)
+    if dgrad_taps:
+        taps = [(1 - kh, 1 - kw, kh * 3 + kw) for kh in range(3) for kw in range(3)]
+    else:
+        taps = [(kh - 1, kw - 1, kh * 3 + kw) for kh in range(3) for kw in range(3)]
+    # the kernel's tap t = (dh + 1)*3 + (dw + 1) reads weight tap wtap
+    wtap_of = [0] * 9
+    for dh, dw, wt in taps:
+        wtap_of[(dh + 1) * 3 + (dw + 1)] = wt
+    mem = gcn_emu.Memory()
+    a_in = mem.alloc(to_bf16_bits(x))
+    a_wt = mem.alloc(to_bf16_bits(w))
+    out0 = np.full((N, c.H, c.W, c.NCOLS), 0x7FC0, dtype=np.uint16)  # NaN: unwritten outputs show
+    a_out = mem.alloc(out0)
+    a_stat = mem.alloc(np.full((ntiles, 2, c.NCOLS), np.nan, dtype=np.float32))
+    a_tab = mem.alloc(np.array(dconv_gen.tables(c), dtype=np.uint32))
+    dummy = mem.alloc(np.zeros(64, dtype=np.uint8))
+    fields = [("q", a_in), ("q", a_wt), ("q", a_out), ("q", a_stat), ("q", dummy), ("q", dummy), ("q", dummy), ("q", dummy),
+              ("q", a_tab)] + [("I", wtap_of[t] * c.Cin * 2) for t in range(9)] + [("I", c.Cin // 64)]
+    ka = gcn_emu.pack_kernarg(fields)
+    assert len(ka) == dconv_gen.Gen.KA["size"], len(ka)
+    a_ka = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
+    total = 0
+    for t in tiles:
+        emu = gcn_emu.Emulator(text, mem, lds_bytes=g.lds_bytes, check=check, sinks=[(dconv_gen.ABASE + b * c.ASTRIDE + c.ABUF, dconv_gen.ABASE + (b + 1) * c.ASTRIDE) for b in range(2)])
+        total += emu.run_workgroup(4, a_ka, wg_id=(t, ntile, 0))
+    got = from_bf16_bits(mem.array(a_out, np.uint16, out0.shape)).astype(np.float64)
+    ref = conv_ref(x.astype(np.float64), w.astype(np.float64), taps)
+    cols = slice(ntile * 256, ntile * 256 + 256)
+    res = {"insts": total, "cfg": c}
+    refr = bf16_round(ref.astype(np.float32)).astype(np.float64)
+    sel = [i for t in tiles for i in range(t * c.IPT, (t + 1) * c.IPT)]
+    res["max_err"] = float(np.abs(got[sel][..., cols] - refr[sel][..., cols]).max())
+    res["untouched_ok"] = True
+    if c.NCOLS > 256:
+        other = np.ones(c.NCOLS, dtype=bool)
+        other[cols] = False
+        res["untouched_ok"] = bool(np.isnan(got[..., other]).all())
+    if c.stats == 1:
+        st = mem.array(a_stat, np.float32, (ntiles, 2, c.NCOLS))
+        s1 = np.stack([refr[t * c.IPT:(t + 1) * c.IPT].sum(axis=(0, 1, 2)) for t in range(ntiles)])
+        s2 = np.stack([(refr[t * c.IPT:(t + 1) * c.IPT] ** 2).sum(axis=(0, 1, 2)) for t in range(ntiles)])
+        tl = list(tiles)
+        res["stat_err"] = float(max(np.abs(st[tl, 0][:, cols] - s1[tl][:, cols]).max(), np.abs(st[tl, 1][:, cols] - s2[tl][:, cols]).max()))
+    return res
+
+
+if __name__ == "__main__":
+    import time
+    t0 = time.time()
+    r = run("dconv_l3_s1", tiles=(0, 1), Cin=128)
+    print({k: v for k, v in r.items() if k != "cfg"}, "%.1f s" % (time.time() - t0))
