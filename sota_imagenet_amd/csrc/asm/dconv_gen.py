@@ -47,6 +47,7 @@ class Cfg:
     NCOLS: int        # columns of the output tensor (multiple of 256; blockIdx.y picks the 256-column tile)
     stats: int        # 0 none, 1 BN statistics of the output, 2 BN-backward sums
     skew: int = 0     # s_nop-based wave stagger after each barrier (experiment knob)
+    probe: int = 0    # timing probes (WRONG results): 1 no LDS-DMA in the main loop, 2 no fragment reads, 4 no barriers
     WM: int = 2
     WN: int = 2
     NT: int = 8       # 16-column tiles per wave
@@ -159,7 +160,7 @@ def tables(c):
     rows = []
     for w in range(4):
         words = [g[w][0] for _, g in sl] + [g[w][1] for _, g in sl] + [b_piece_const(c, w, i) for i in range(8)]
-        assert len(words) <= 32
+        assert len(words) <= 24
         rows.append(words + [0] * (32 - len(words)))
     return rows
 
@@ -219,6 +220,9 @@ class Gen:
         self.srdO = S.get(4, 4)
         self.srdX = S.get(4, 4)   # statistics rows / bn_y
         self.srdM = S.get(4, 4)   # bn_bits
+        self.srdY = S.get(4, 4)   # bn_y
+        self.srdMu = S.get(4, 4)  # bn_mean
+        self.srdIs = S.get(4, 4)  # bn_invstd
         self.s_wt = S.get(9, 4)
         self.s_cnt = S.get()
         self.s_cC = S.get()
@@ -231,8 +235,9 @@ class Gen:
         self.s_nch = S.get()
         self.s_ldsBw = S.get()
         self.s_stg = S.get()
-        self.s_tbl = S.get(32, 4)        # per-wave table: [NPA lds][NPA src][8 B consts]
-        self.s_ka = self.s_tbl           # kernarg scratch: the 8 pointers are consumed before the table is loaded over them
+        self.s_tbl = S.get(24, 4)        # per-wave table: [NPA lds][NPA src][8 B consts]
+        self.s_tbl2 = self.s_tbl
+        self.s_ka = S.get(16, 4)         # the 8 pointers
         self.s_kb = S.get(4, 4)
         self.s_tA_lds = self.s_tbl
         self.s_tA_src = self.s_tbl + NPA
@@ -251,7 +256,7 @@ class Gen:
             fa = V.get(4 * c.MFR, 4)
             fb = V.get(4 * c.NT, 4)
             self.F.append((fa, fb))
-        self.nvgpr = V.n
+        self.nvgpr = V.n + (2 * (5 * c.MFR + 16) + 2 if c.stats == 2 else 0)   # + the BN-backward epilogue's load registers
         self.accum_offset = (self.nvgpr + 7) // 8 * 8
         self.nagpr = c.MFR * c.NT * 4
         assert self.nagpr <= 256
@@ -262,52 +267,44 @@ class Gen:
         return self.finish()
 
     # -----------------------------------------------------------------------------------------------------------------
-    KA = dict(in_=0, wt=8, out=16, stat=24, bn_y=32, bn_bits=40, bn_mean=48, bn_invstd=56, table=64, wtap=72, nchunks=108,
-              size=112)
+    # kernel arguments: 9 pointers (the 9th unused: reserved), 9 weight-tap byte offsets, the chunk count, padding to 128 bytes,
+    # then the per-wave piece tables (4 x 32 words)
+    KA = dict(in_=0, wt=8, out=16, stat=24, bn_y=32, bn_bits=40, bn_mean=48, bn_invstd=56, rsvd=64, wtap=72, nchunks=108,
+              table=128, size=640)
+
+    def never_written_blocks(self):
+        """1 KiB blocks (relative to an A buffer's base) that no LDS-DMA piece ever writes: halo rows, right padding, the tail"""
+        c = self.c
+        written = {p[0] for p in a_pieces(c)}
+        return [b * 1024 for b in range(c.ABUF // 1024) if b * 1024 not in written]
 
     def prologue(self):
         c, e = self.c, self.e
         ka, kb = self.s_ka, self.s_kb
+        v = self.v_t
+        t0, t1 = self.s_t0, self.s_t1
         self.comment("---- prologue: kernel arguments, lane constants, descriptors, first loads")
         e("s_load_dwordx16 %s, s[0:1], 0x0" % R("s", ka, 16))       # in, wt, out, stat, bn_y, bn_bits, bn_mean, bn_invstd
-        e("s_load_dwordx2 %s, s[0:1], 0x40" % R("s", kb, 2))        # table
         e("s_load_dwordx8 %s, s[0:1], 0x48" % R("s", self.s_wt, 8))  # wtap[0..7]
         e("s_load_dwordx2 %s, s[0:1], 0x68" % R("s", kb + 2, 2))    # wtap[8], nchunks
-        # lane constants while the loads fly
-        v = self.v_t
         lane, r, kg = v[0], v[1], v[2]
+        e("v_lshrrev_b32 %s, 6, v0" % R("v", v[3]))
         e("v_and_b32 %s, 63, v0" % R("v", lane))
+        e("v_readfirstlane_b32 %s, %s" % (R("s", self.s_w), R("v", v[3])))
         e("v_and_b32 %s, 15, v0" % R("v", r))
         e("v_bfe_u32 %s, v0, 4, 2" % R("v", kg))
-        e("v_lshrrev_b32 %s, 6, v0" % R("v", v[3]))
-        e("s_nop 0")
-        e("v_readfirstlane_b32 %s, %s" % (R("s", self.s_w), R("v", v[3])))
         e("s_nop 3")
+        # this wave's table: kernarg + 128 + w*128  (the kernarg loads above do not touch s[0:1])
+        e("s_lshl_b32 %s, %s, 7" % (R("s", t0), R("s", self.s_w)))
+        e("s_add_u32 %s, s0, %s" % (R("s", kb), R("s", t0)))
+        e("s_addc_u32 %s, s1, 0" % R("s", kb + 1))
+        e("s_load_dwordx16 %s, %s, 0x80" % (R("s", self.s_tbl2, 16), R("s", kb, 2)))
+        e("s_load_dwordx8 %s, %s, 0xc0" % (R("s", self.s_tbl2 + 16, 8), R("s", kb, 2)))
         e("s_lshr_b32 %s, %s, 1" % (R("s", self.s_wm), R("s", self.s_w)))
         e("s_and_b32 %s, %s, 1" % (R("s", self.s_wn), R("s", self.s_w)))
-        # ---- A read bases: pos0 = wm*MFR*16 + r + kx ; chunk = (kg + 4kk + (pos0 & 6)) & 7
-        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wm), c.MFR * 16 * 128))
-        for kx in range(3):
-            t, ee, cc = v[3], v[4], v[5]
-            e("v_add_u32 %s, %d, %s" % (R("v", t), kx, R("v", r)))
-            e("v_and_b32 %s, 6, %s" % (R("v", ee), R("v", t)))
-            e("v_add_u32 %s, %s, %s" % (R("v", cc), R("v", ee), R("v", kg)))
-            e("v_and_b32 %s, 7, %s" % (R("v", cc), R("v", cc)))
-            e("v_lshlrev_b32 %s, 4, %s" % (R("v", cc), R("v", cc)))
-            e("v_lshl_add_u32 %s, %s, 7, %s" % (R("v", cc), R("v", t), R("v", cc)))
-            e("v_add_u32 %s, %s, %s" % (R("v", cc), R("s", self.s_t0), R("v", cc)))
-            e("v_add_u32 %s, %d, %s" % (R("v", self.vA_rd[kx][0]), ABASE, R("v", cc)))
-            e("v_xor_b32 %s, 64, %s" % (R("v", self.vA_rd[kx][1]), R("v", self.vA_rd[kx][0])))
-        # ---- B read bases: row = wn*NT*16 + r ; chunk = (kg + 4kk) ^ ((r >> 1) & 7)
-        sw, cc = v[3], v[4]
-        e("v_bfe_u32 %s, %s, 1, 3" % (R("v", sw), R("v", r)))
-        e("v_xor_b32 %s, %s, %s" % (R("v", cc), R("v", kg), R("v", sw)))
-        e("v_lshlrev_b32 %s, 4, %s" % (R("v", cc), R("v", cc)))
-        e("v_lshl_add_u32 %s, %s, 7, %s" % (R("v", cc), R("v", r), R("v", cc)))
-        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wn), c.NT * 16 * 128))
-        e("v_add_u32 %s, %s, %s" % (R("v", self.vB_rd[0]), R("s", self.s_t0), R("v", cc)))
-        e("v_xor_b32 %s, 64, %s" % (R("v", self.vB_rd[1]), R("v", self.vB_rd[0])))
-        # ---- A DMA lane parts: x'' = xb*8 + (lane >> 3); j = ((lane & 7) - ((lane >> 3) & 6)) & 7
+        e("s_lshl_b32 %s, %s, 13" % (R("s", self.s_ldsBw), R("s", self.s_w)), "this wave's 8 KiB of a weight stage")
+        # ---- DMA lane parts first: the first loads wait for nothing else
+        # A: x'' = xb*8 + (lane >> 3); j = ((lane & 7) - ((lane >> 3) & 6)) & 7
         l3, l7, j, x, off = v[3], v[4], v[5], v[6], v[7]
         e("v_lshrrev_b32 %s, 3, %s" % (R("v", l3), R("v", lane)))
         e("v_and_b32 %s, 7, %s" % (R("v", l7), R("v", lane)))
@@ -322,8 +319,8 @@ class Gen:
             e("v_cmp_gt_u32 vcc, %d, %s" % (c.W, R("v", x)), "0 <= x < W (x = -1 wraps to 2^32 - 1)")
             e("v_mov_b32 %s, 0x80000000" % R("v", x))
             e("v_cndmask_b32 %s, %s, %s, vcc" % (R("v", self.vA_dma[xb]), R("v", x), R("v", off)))
-        # ---- B DMA lane parts (variant ib = piece & 1): rr = 8*ib + (lane>>3)
-        #      channel = (2*ib + (lane>>5))*8 + ((lane>>3)&3) ; chunk = (lane&7) ^ (4*ib + ((lane>>4)&3))
+        # B (variant ib = piece & 1): rr = 8*ib + (lane>>3); channel = (2*ib + (lane>>5))*8 + ((lane>>3)&3);
+        #   chunk = (lane&7) ^ (4*ib + ((lane>>4)&3))
         l5, l43, ch, x = v[5], v[8], v[7], v[9]
         e("v_lshrrev_b32 %s, 5, %s" % (R("v", l5), R("v", lane)))
         e("v_bfe_u32 %s, %s, 4, 2" % (R("v", l43), R("v", lane)))
@@ -336,54 +333,12 @@ class Gen:
             e("v_or_b32 %s, %d, %s" % (R("v", x), 4 * ib, R("v", l43)))
             e("v_xor_b32 %s, %s, %s" % (R("v", x), R("v", l7), R("v", x)))
             e("v_lshl_add_u32 %s, %s, 4, %s" % (R("v", self.vB_dma[ib]), R("v", x), R("v", ch)))
-        # ---- output lane offset: pixel part * NCOLS*2 + (wn*NT*16 + kg*8)*2
-        x, off = v[6], v[7]
-        if c.P >= 16:
-            e("v_mov_b32 %s, %s" % (R("v", x), R("v", r)))
-        else:  # P == 8: two image rows per fragment
-            e("v_lshrrev_b32 %s, 3, %s" % (R("v", x), R("v", r)))
-            e("v_mul_u32_u24 %s, %d, %s" % (R("v", x), c.W, R("v", x)))
-            e("v_and_b32 %s, 7, %s" % (R("v", off), R("v", r)))
-            e("v_add_u32 %s, %s, %s" % (R("v", x), R("v", x), R("v", off)))
-        e("v_mov_b32 %s, %d" % (R("v", off), c.NCOLS * 2))
-        e("v_mul_lo_u32 %s, %s, %s" % (R("v", x), R("v", x), R("v", off)))
-        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wn), c.NT * 16 * 2))
-        e("v_lshl_add_u32 %s, %s, 4, %s" % (R("v", x), R("v", kg), R("v", x)))
-        e("v_add_u32 %s, %s, %s" % (R("v", self.v_out), R("s", self.s_t0), R("v", x)))
-        # keep r and kg for the epilogue
-        self.v_r, self.v_kg = v[1], v[2]
-
-        # ---- zero the A buffers' halo rows / padding (every byte of both buffers; cheap, once)
-        self.comment("zero both A buffers (halo rows, padding columns are never written by the DMA)")
-        z = self.F[0][0]
-        for i in range(4):
-            e("v_mov_b32 %s, 0" % R("v", z + i))
-        e("v_lshlrev_b32 %s, 4, v0" % R("v", v[3]), "tid*16")
-        e("v_add_u32 %s, %d, %s" % (R("v", v[3]), ABASE, R("v", v[3])))
-        tot = 2 * c.ASTRIDE
-        assert tot % 16 == 0
-        n16 = tot // 16
-        full = n16 // 256
-        for k in range(full):
-            if k and k % 16 == 0:
-                e("v_add_u32 %s, 0x10000, %s" % (R("v", v[3]), R("v", v[3])))
-            e("ds_write_b128 %s, %s offset:%d" % (R("v", v[3]), R("v", z, 4), (k % 16) * 4096))
-        rem = n16 - full * 256
-        if rem:
-            if full % 16 == 0:
-                e("v_add_u32 %s, 0x10000, %s" % (R("v", v[3]), R("v", v[3])))
-            e("v_cmp_gt_u32 vcc, %d, v0" % rem)
-            e("s_nop 4")
-            e("s_and_b64 exec, exec, vcc")
-            e("ds_write_b128 %s, %s offset:%d" % (R("v", v[3]), R("v", z, 4), (full % 16) * 4096))
-            e("s_mov_b64 exec, -1")
 
         # ---- descriptors ------------------------------------------------------------------------------------------
         e("s_waitcnt lgkmcnt(0)")
         self.comment("descriptors: A = this tile's images, B = this column tile's weight rows, O = this tile's output pixels")
         tile_in = c.IPT * c.H * c.W * c.Cin * 2
         tile_out = c.IPT * c.H * c.W * c.NCOLS * 2
-        t0, t1 = self.s_t0, self.s_t1
         # A
         e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_tile), tile_in))
         e("s_mul_hi_u32 %s, %s, %d" % (R("s", t1), R("s", self.s_tile), tile_in))
@@ -399,6 +354,18 @@ class Gen:
         e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdB + 1), R("s", self.srdB + 1)))
         e("s_mov_b32 %s, %d" % (R("s", self.srdB + 2), c.BN * c.w_row))
         e("s_mov_b32 %s, 0x00020000" % R("s", self.srdB + 3))
+        e("s_mov_b32 %s, %s" % (R("s", self.s_nch), R("s", kb + 3)))
+        e("s_mov_b32 %s, %s" % (R("s", self.s_wt + 8), R("s", kb + 2)))
+        # the table (24 words) to its place: [NPA lds][NPA src][8 B consts]
+        # ---- first loads: weight stages 0 and 1, the A tile of chunk 0 (its pieces never overlap the zero fill below)
+        self.comment("first loads: weight stages 0 and 1, A tile of chunk 0")
+        e("s_mov_b32 %s, 0" % R("s", self.s_cC))
+        self.b_stage_issue_all(0, 0, self.s_cC)
+        for i in range(self.NPA):
+            self.a_piece(i, 0, soff_chunk=self.s_cC)
+        self.b_stage_issue_all(1, 1, self.s_cC)
+
+        # ---- the rest of the set-up runs under the latency of those loads
         # O: + tile*tile_out + nt*512 bytes
         e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_tile), tile_out))
         e("s_mul_hi_u32 %s, %s, %d" % (R("s", t1), R("s", self.s_tile), tile_out))
@@ -408,40 +375,102 @@ class Gen:
         e("s_add_u32 %s, %s, %s" % (R("s", self.srdO), R("s", ka + 4), R("s", t0)))
         e("s_addc_u32 %s, %s, %s" % (R("s", self.srdO + 1), R("s", ka + 5), R("s", t1)))
         e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdO + 1), R("s", self.srdO + 1)))
-        e("s_mov_b32 %s, %d" % (R("s", self.srdO + 2), tile_out - 0))
+        e("s_mov_b32 %s, %d" % (R("s", self.srdO + 2), tile_out))
         e("s_mov_b32 %s, 0x00020000" % R("s", self.srdO + 3))
-        # (the O window starts at this tile's column offset, so its last bytes end nt*512 short of the window: harmless,
-        #  num_records only has to cover what is stored: subtract the column offset)
+        # (the O window starts at this tile's column offset: num_records covers exactly what may be stored)
         e("s_sub_u32 %s, %s, %s" % (R("s", self.srdO + 2), R("s", self.srdO + 2), R("s", self.s_stg)))
         e("s_mov_b32 %s, %s" % (R("s", self.srdX), R("s", ka + 6)), "statistics rows")
         e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdX + 1), R("s", ka + 7)))
         e("s_mov_b32 %s, 0x7fffffff" % R("s", self.srdX + 2))
         e("s_mov_b32 %s, 0x00020000" % R("s", self.srdX + 3))
-        e("s_mov_b32 %s, %s" % (R("s", self.s_nch), R("s", kb + 3)))
-        e("s_mov_b32 %s, %s" % (R("s", self.s_wt + 8), R("s", kb + 2)))
-        # per-wave table
-        e("s_lshl_b32 %s, %s, 7" % (R("s", t0), R("s", self.s_w)))
-        e("s_add_u32 %s, %s, %s" % (R("s", kb), R("s", kb), R("s", t0)))
-        e("s_addc_u32 %s, %s, 0" % (R("s", kb + 1), R("s", kb + 1)))
-        e("s_load_dwordx16 %s, %s, 0x0" % (R("s", self.s_tbl, 16), R("s", kb, 2)))
-        e("s_load_dwordx16 %s, %s, 0x40" % (R("s", self.s_tbl + 16, 16), R("s", kb, 2)))
-        e("s_lshl_b32 %s, %s, 13" % (R("s", self.s_ldsBw), R("s", self.s_w)), "this wave's 8 KiB of a weight stage")
-        e("s_waitcnt lgkmcnt(0)")
-        e("s_barrier", "every wave's zero fill is done before any LDS-DMA lands in the A buffers")
+        if c.stats == 2:
+            # y: laid out like the output (same window); mask bytes: 1/16 of it; mean / invstd: this column tile's 256 floats
+            e("s_add_u32 %s, %s, %s" % (R("s", self.srdY), R("s", ka + 8), R("s", t0)))
+            e("s_addc_u32 %s, %s, %s" % (R("s", self.srdY + 1), R("s", ka + 9), R("s", t1)))
+            e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdY + 1), R("s", self.srdY + 1)))
+            e("s_mov_b32 %s, %s" % (R("s", self.srdY + 2), R("s", self.srdO + 2)))
+            e("s_mov_b32 %s, 0x00020000" % R("s", self.srdY + 3))
+            e("s_lshr_b32 %s, %s, 4" % (R("s", t0), R("s", t0)))
+            e("s_lshl_b32 %s, %s, 28" % (R("s", self.s_stg), R("s", t1)))
+            e("s_or_b32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", self.s_stg)))
+            e("s_lshr_b32 %s, %s, 4" % (R("s", t1), R("s", t1)))
+            e("s_add_u32 %s, %s, %s" % (R("s", self.srdM), R("s", ka + 10), R("s", t0)))
+            e("s_addc_u32 %s, %s, %s" % (R("s", self.srdM + 1), R("s", ka + 11), R("s", t1)))
+            e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdM + 1), R("s", self.srdM + 1)))
+            e("s_lshr_b32 %s, %s, 4" % (R("s", self.srdM + 2), R("s", self.srdO + 2)))
+            e("s_mov_b32 %s, 0x00020000" % R("s", self.srdM + 3))
+            e("s_lshl_b32 %s, %s, 10" % (R("s", t0), R("s", self.s_nt)))
+            for srd, k0 in ((self.srdMu, 12), (self.srdIs, 14)):
+                e("s_add_u32 %s, %s, %s" % (R("s", srd), R("s", ka + k0), R("s", t0)))
+                e("s_addc_u32 %s, %s, 0" % (R("s", srd + 1), R("s", ka + k0 + 1)))
+                e("s_and_b32 %s, %s, 0xffff" % (R("s", srd + 1), R("s", srd + 1)))
+                e("s_mov_b32 %s, 1024" % R("s", srd + 2))
+                e("s_mov_b32 %s, 0x00020000" % R("s", srd + 3))
+        # ---- A read bases: pos0 = wm*MFR*16 + r + kx ; chunk = (kg + 4kk + (pos0 & 6)) & 7
+        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_wm), c.MFR * 16 * 128))
+        for kx in range(3):
+            t, ee, cc = v[3], v[4], v[5]
+            e("v_add_u32 %s, %d, %s" % (R("v", t), kx, R("v", r)))
+            e("v_and_b32 %s, 6, %s" % (R("v", ee), R("v", t)))
+            e("v_add_u32 %s, %s, %s" % (R("v", cc), R("v", ee), R("v", kg)))
+            e("v_and_b32 %s, 7, %s" % (R("v", cc), R("v", cc)))
+            e("v_lshlrev_b32 %s, 4, %s" % (R("v", cc), R("v", cc)))
+            e("v_lshl_add_u32 %s, %s, 7, %s" % (R("v", cc), R("v", t), R("v", cc)))
+            e("v_add_u32 %s, %s, %s" % (R("v", cc), R("s", t0), R("v", cc)))
+            e("v_add_u32 %s, %d, %s" % (R("v", self.vA_rd[kx][0]), ABASE, R("v", cc)))
+            e("v_xor_b32 %s, 64, %s" % (R("v", self.vA_rd[kx][1]), R("v", self.vA_rd[kx][0])))
+        # ---- B read bases: row = wn*NT*16 + r ; chunk = (kg + 4kk) ^ ((r >> 1) & 7)
+        sw, cc = v[3], v[4]
+        e("v_bfe_u32 %s, %s, 1, 3" % (R("v", sw), R("v", r)))
+        e("v_xor_b32 %s, %s, %s" % (R("v", cc), R("v", kg), R("v", sw)))
+        e("v_lshlrev_b32 %s, 4, %s" % (R("v", cc), R("v", cc)))
+        e("v_lshl_add_u32 %s, %s, 7, %s" % (R("v", cc), R("v", r), R("v", cc)))
+        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_wn), c.NT * 16 * 128))
+        e("v_add_u32 %s, %s, %s" % (R("v", self.vB_rd[0]), R("s", t0), R("v", cc)))
+        e("v_xor_b32 %s, 64, %s" % (R("v", self.vB_rd[1]), R("v", self.vB_rd[0])))
+        # ---- output lane offset: pixel part * NCOLS*2 + (wn*NT*16 + kg*8)*2
+        x, off = v[6], v[7]
+        if c.P >= 16:
+            e("v_mov_b32 %s, %s" % (R("v", x), R("v", r)))
+        else:  # P == 8: two image rows per fragment
+            e("v_lshrrev_b32 %s, 3, %s" % (R("v", x), R("v", r)))
+            e("v_mul_u32_u24 %s, %d, %s" % (R("v", x), c.W, R("v", x)))
+            e("v_and_b32 %s, 7, %s" % (R("v", off), R("v", r)))
+            e("v_add_u32 %s, %s, %s" % (R("v", x), R("v", x), R("v", off)))
+        e("v_mov_b32 %s, %d" % (R("v", off), c.NCOLS * 2))
+        e("v_mul_lo_u32 %s, %s, %s" % (R("v", x), R("v", x), R("v", off)))
+        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_wn), c.NT * 16 * 2))
+        e("v_lshl_add_u32 %s, %s, 4, %s" % (R("v", x), R("v", kg), R("v", x)))
+        e("v_add_u32 %s, %s, %s" % (R("v", self.v_out), R("s", t0), R("v", x)))
+        self.v_r, self.v_kg = v[1], v[2]
 
-        # ---- first loads: A(0), B stage 0, B stage 1 ----------------------------------------------------------------
-        self.comment("first loads: A tile of chunk 0, weight stages 0 and 1")
-        e("s_mov_b32 %s, 0" % R("s", self.s_cC))
-        for i in range(self.NPA):
-            self.a_piece(i, 0, soff_chunk=self.s_cC)
-        self.b_stage_issue_all(0, 0, self.s_cC)
-        self.b_stage_issue_all(1, 1, self.s_cC)
-        e("s_waitcnt vmcnt(8)")
-        e("s_waitcnt lgkmcnt(0)")
-        e("s_barrier")
+        # ---- zero the LDS blocks of both A buffers that no DMA piece writes (halo rows, padding): wave w takes blocks w, w+4, ...
+        self.comment("zero the never-written blocks of both A buffers")
+        z = self.F[0][0]
+        for i in range(4):
+            e("v_mov_b32 %s, 0" % R("v", z + i))
+        blocks = [ABASE + b * c.ASTRIDE + o for b in range(2) for o in self.never_written_blocks()]
+        e("v_lshlrev_b32 %s, 4, %s" % (R("v", v[3]), R("v", lane)), "lane*16")
+        n = len(blocks)
+        for k in range((n + 3) // 4):
+            grp = blocks[4 * k:4 * k + 4]
+            # the four waves take grp[w]; a short last group repeats its last block (same zeros)
+            while len(grp) < 4:
+                grp.append(grp[-1])
+            # address = lane*16 + grp[w]: select by wave with scalar compares
+            e("s_mov_b32 %s, %d" % (R("s", t0), grp[0]))
+            for w in range(1, 4):
+                if grp[w] != grp[0]:
+                    e("s_cmp_eq_u32 %s, %d" % (R("s", self.s_w), w))
+                    e("s_cselect_b32 %s, %d, %s" % (R("s", t0), grp[w], R("s", t0)))
+            e("v_add_u32 %s, %s, %s" % (R("v", v[4]), R("s", t0), R("v", v[3])))
+            e("ds_write_b128 %s, %s" % (R("v", v[4]), R("v", z, 4)))
         # accumulators = 0
         for i in range(self.nagpr):
             e("v_accvgpr_write_b32 a%d, 0" % i)
+        e("s_waitcnt vmcnt(8)")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier")
         # fragments of (stage 0, kk 0)
         for ins in self.frag_reads(0, 0, 0, 0):
             e(ins)
@@ -552,12 +581,17 @@ class Gen:
                     pieces.append(["s_add_u32 %s, %s, %s" % (R("s", self.s_t1), R("s", self.s_cN), R("s", self.s_tA_src + t)),
                                    "s_add_u32 m0, %s, %d" % (R("s", self.s_tA_lds + t), ABASE + (cp ^ 1) * c.ASTRIDE),
                                    "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vA_dma[var]), R("s", self.srdA, 4), R("s", self.s_t1))])
+                if c.probe & 1:
+                    pieces = []
+                if c.probe & 2:
+                    groups = []
                 self.interleave(mf, self.merge(groups, pieces))
                 # ---- the stage barrier: stage t+1's weights (and after tap 8 the next A tile) have landed for every wave
                 self.comment("chunk parity %d tap %d substep 1" % (cp, t))
                 e("s_waitcnt vmcnt(%d)" % (1 if t < self.NPA else 0))
                 e("s_waitcnt lgkmcnt(0)")
-                e("s_barrier")
+                if not c.probe & 4:
+                    e("s_barrier")
                 self.skew()
                 t2 = (t + 1) % 9
                 if t == 8:  # next chunk: the A bases move to the other buffer
@@ -577,6 +611,10 @@ class Gen:
                         g = ["s_add_u32 %s, %s, %s" % (R("s", self.s_stg), R("s", self.s_wt + t3), R("s", s_ch))] + g
                     pieces.append(g)
                 mf = self.mfmas(1)
+                if c.probe & 1:
+                    pieces = []
+                if c.probe & 2:
+                    groups = []
                 self.interleave(mf, self.merge(groups, pieces))
             # next chunk
             e("s_mov_b32 %s, %s" % (R("s", self.s_cC), R("s", self.s_cN)))
@@ -633,11 +671,6 @@ class Gen:
     def epilogue(self):
         c, e = self.c, self.e
         self.comment("---- epilogue")
-        e("s_waitcnt vmcnt(0)")
-        e("s_waitcnt lgkmcnt(0)")
-        e("s_barrier", "every LDS-DMA of the (unused) lookahead has landed: the ring is free for the statistics scratch")
-        e("s_nop 15")
-        e("s_nop 15")
         V = self.V
         base = self.F[0][0]           # fragment registers are free now
         tv = [base + i for i in range(8)]            # accumulator values
@@ -646,20 +679,60 @@ class Gen:
         s1 = [base + 32 + i for i in range(8)]
         s2 = [base + 40 + i for i in range(8)]
         vst = base + 48               # LDS address of this lane's statistics slot
-        assert base + 49 <= self.F[1][1] + 4 * c.NT
+        yv = [base + 49 + i for i in range(2)]
+        assert base + 51 <= self.F[1][1] + 4 * c.NT
+        npair = c.NT // 2
+        if c.stats == 2:
+            # BN-backward sums: y / mask of the same (pixel, 8 channels) vectors as the output, two register sets (pair p + 1 loads
+            # under pair p's arithmetic); mean / invstd of this lane's 8 channels per pair
+            ysets = [[V.get(4, 4) for m in range(c.MFR)] for _ in range(2)]
+            bsets = [[V.get() for m in range(c.MFR)] for _ in range(2)]
+            msets = [V.get(16, 4) for _ in range(2)]   # mean[8], invstd[8]
+            v_bits, v_chan = V.get(), V.get()
+            self.nvgpr_epi = V.n
+            e("v_lshrrev_b32 %s, 4, %s" % (R("v", v_bits), R("v", self.v_out)), "mask bytes: one per 16-byte output vector")
+            # channel byte offset of this lane's 8 floats in mean / invstd: (wn*128 + kg*8)*4
+            e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wn), c.NT * 16 * 4))
+            e("v_lshl_add_u32 %s, %s, 5, %s" % (R("v", v_chan), R("v", self.v_kg), R("s", self.s_t0)))
+
+            def issue_loads(p):
+                k = p & 1
+                for m in range(c.MFR):
+                    f0, f1 = self.frag_out(m), self.frag_out(c.MFR + m)
+                    assert f0[1] % 16 == 0 and (f1[1] - f0[1]) % 16 == 0
+                    e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wm), f1[1] - f0[1]))
+                    e("s_add_u32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_t0), f0[1]))
+                    e("s_lshr_b32 %s, %s, 4" % (R("s", self.s_t1), R("s", self.s_t0)))
+                    e("buffer_load_dwordx4 %s, %s, %s, %s offen offset:%d" % (R("v", ysets[k][m], 4), R("v", self.v_out), R("s", self.srdY, 4), R("s", self.s_t0), p * 64))
+                    e("buffer_load_ubyte %s, %s, %s, %s offen offset:%d" % (R("v", bsets[k][m]), R("v", v_bits), R("s", self.srdM, 4), R("s", self.s_t1), p * 4))
+                for h in range(2):
+                    e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", msets[k] + 4 * h, 4), R("v", v_chan), R("s", self.srdMu, 4), p * 128 + 16 * h))
+                    e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", msets[k] + 8 + 4 * h, 4), R("v", v_chan), R("s", self.srdIs, 4), p * 128 + 16 * h))
+            GL = 2 * c.MFR + 4
+        e("s_waitcnt vmcnt(0)")
+        e("s_waitcnt lgkmcnt(0)")
+        if c.stats == 2:
+            issue_loads(0)
+        e("s_barrier", "every LDS-DMA of the (unused) lookahead has landed: the ring is free for the statistics scratch")
+        e("s_nop 15")
+        e("s_nop 15")
         if c.stats:
             # STAT scratch: [wm][256 channels][2] floats at LDS 0 ; this lane (r == 15) owns channels wn*128 + p*32 + kg*8 + e
             e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wm), c.BN * 8))
             e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t1), R("s", self.s_wn), c.NT * 16 * 8))
             e("s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", self.s_t0), R("s", self.s_t1)))
             e("v_lshl_add_u32 %s, %s, 6, %s" % (R("v", vst), R("v", self.v_kg), R("s", self.s_t0)))
-        if c.stats == 2:
-            raise NotImplementedError
-        for p in range(c.NT // 2):
+        for p in range(npair):
             if c.stats:
                 for i in range(8):
                     e("v_mov_b32 %s, 0" % R("v", s1[i]))
                     e("v_mov_b32 %s, 0" % R("v", s2[i]))
+            if c.stats == 2:
+                if p + 1 < npair:
+                    issue_loads(p + 1)
+                    e("s_waitcnt vmcnt(%d)" % (GL + (c.MFR if p > 0 else 0)))
+                else:
+                    e("s_waitcnt vmcnt(%d)" % c.MFR)
             for m in range(c.MFR):
                 # the exec mask and output offset depend on the GLOBAL fragment wm*MFR + m: both wave rows take the same code
                 # when the masks agree; otherwise select by s_wm
@@ -684,13 +757,26 @@ class Gen:
                 for i in range(4):
                     e("v_cvt_pk_bf16_f32 %s, %s, %s" % (R("v", d + i), R("v", tv[2 * i]), R("v", tv[2 * i + 1])))
                 e("buffer_store_dwordx4 %s, %s, %s, %s offen offset:%d" % (R("v", d, 4), R("v", self.v_out), R("s", self.srdO, 4), R("s", self.s_t0), p * 64))
-                if c.stats == 1:
+                if c.stats:
                     for i in range(4):
                         e("v_lshlrev_b32 %s, 16, %s" % (R("v", xr[2 * i]), R("v", d + i)))
                         e("v_and_b32 %s, 0xffff0000, %s" % (R("v", xr[2 * i + 1]), R("v", d + i)))
+                if c.stats == 1:
                     for i in range(8):
                         e("v_add_f32 %s, %s, %s" % (R("v", s1[i]), R("v", s1[i]), R("v", xr[i])))
                         e("v_fma_f32 %s, %s, %s, %s" % (R("v", s2[i]), R("v", xr[i]), R("v", xr[i]), R("v", s2[i])))
+                if c.stats == 2:
+                    yr, br = ysets[p & 1][m], bsets[p & 1][m]
+                    for i in range(8):
+                        t = tv[i]  # (the accumulator copies are dead after the conversion)
+                        e("v_bfe_i32 %s, %s, %d, 1" % (R("v", t), R("v", br), i), "0 / -1: ReLU mask bit of element %d" % i)
+                        e("v_and_b32 %s, %s, %s" % (R("v", xr[i]), R("v", xr[i]), R("v", t)), "dz")
+                        if i & 1:
+                            e("v_and_b32 %s, 0xffff0000, %s" % (R("v", yv[1]), R("v", yr + i // 2)))
+                        else:
+                            e("v_lshlrev_b32 %s, 16, %s" % (R("v", yv[0]), R("v", yr + i // 2)))
+                        e("v_add_f32 %s, %s, %s" % (R("v", s1[i]), R("v", s1[i]), R("v", xr[i])))
+                        e("v_fma_f32 %s, %s, %s, %s" % (R("v", s2[i]), R("v", xr[i]), R("v", yv[i & 1]), R("v", s2[i])), "sum dz*y")
             if c.stats:
                 e("s_mov_b64 exec, -1")
                 e("s_nop 1")
@@ -699,6 +785,15 @@ class Gen:
                         for i in range(8):
                             rr = R("v", arr[i])
                             e("v_add_f32_dpp %s, %s, %s row_shr:%d row_mask:0xf bank_mask:0xf bound_ctrl:1" % (rr, rr, rr, sh))
+                if c.stats == 2:
+                    # sum dz*xhat = invstd * (sum dz*y - mean * sum dz)
+                    mu, isd = msets[p & 1], msets[p & 1] + 8
+                    for i in range(8):
+                        e("v_mul_f32 %s, %s, %s" % (R("v", tv[i]), R("v", mu + i), R("v", s1[i])))
+                    for i in range(8):
+                        e("v_sub_f32 %s, %s, %s" % (R("v", s2[i]), R("v", s2[i]), R("v", tv[i])))
+                    for i in range(8):
+                        e("v_mul_f32 %s, %s, %s" % (R("v", s2[i]), R("v", isd + i), R("v", s2[i])))
                 # lanes 15 of every row write their 8 channel slots: [channel][2]
                 self.set_exec(0x8000800080008000)
                 for i in range(8):
@@ -779,6 +874,8 @@ class Gen:
         for i in range(10):
             tail.append("      - .offset:         %d\n        .size:           4\n        .value_kind:     by_value" % off)
             off += 4
+        tail.append("      - .offset:         %d\n        .size:           %d\n        .value_kind:     by_value" % (off, self.KA["size"] - off))
+        off = self.KA["size"]
         assert off == self.KA["size"]
         tail.append("    .group_segment_fixed_size: %d" % lds)
         tail.append("    .kernarg_segment_align: 8")
@@ -808,11 +905,15 @@ VARIANTS = {
     # name: geometry of the launches it serves (ResNet-50 at 224 px: layer 3 = 14 x 14 x 256, layer 4 = 7 x 7 x 512)
     "dconv_l3_s1": Cfg("dconv_l3_s1", H=14, W=14, P=16, IPT=1, Cin=256, NCOLS=256, stats=1),
     "dconv_l3_s0": Cfg("dconv_l3_s0", H=14, W=14, P=16, IPT=1, Cin=256, NCOLS=256, stats=0),
+    "dconv_l3_s2": Cfg("dconv_l3_s2", H=14, W=14, P=16, IPT=1, Cin=256, NCOLS=256, stats=2),
+    "dconv_l4_s0": Cfg("dconv_l4_s0", H=7, W=7, P=8, IPT=2, Cin=512, NCOLS=512, stats=0),
+    "dconv_l4_s1": Cfg("dconv_l4_s1", H=7, W=7, P=8, IPT=2, Cin=512, NCOLS=512, stats=1),
+    "dconv_l4_s2": Cfg("dconv_l4_s2", H=7, W=7, P=8, IPT=2, Cin=512, NCOLS=512, stats=2),
 }
 
 
-def generate(name, **over):
-    c = VARIANTS[name]
+def generate(base, **over):
+    c = VARIANTS[base]
     if over:
         c = Cfg(**{**c.__dict__, **over})
     g = Gen(c)
@@ -838,14 +939,24 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="build")
     ap.add_argument("--embed", default=None, help="linked .hsaco: write dconv_blob.inc / dconv_meta.inc instead of the .s files")
+    ap.add_argument("--set", action="append", default=[], help="tuning: override a Cfg field (key=int), with --suffix names the kernel")
+    ap.add_argument("--suffix", default="")
     ap.add_argument("names", nargs="*")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     if a.embed:
         write_meta(a.out, a.embed)
         return
+    over = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.set}
     for name in (a.names or VARIANTS):
-        c, g, text = generate(name)
+        if a.suffix:
+            over["name"] = name + a.suffix
+        c, g, text = generate(name, **over)
+        name = c.name
+        if a.suffix:  # tuning builds: the per-wave table as a raw file for tools/micro/dconv_bench.cpp
+            import struct
+            with open(os.path.join(a.out, name + ".tbl"), "wb") as f:
+                f.write(struct.pack("<128I", *[w for row in tables(c) for w in row]))
         with open(os.path.join(a.out, name + ".s"), "w") as f:
             f.write(text)
         print("%s: %d lines, %d VGPR + %d AGPR, %d SGPR, LDS %d" % (name, text.count("\n"), g.accum_offset, g.nagpr, g.S.n, g.lds_bytes))

@@ -30,7 +30,6 @@ struct DevState {
   bool tried = false, ok = false;
   hipModule_t mod = nullptr;
   hipFunction_t fn[NVAR] = {};
-  unsigned* tables = nullptr;  // NVAR x 128 words in device memory
 };
 DevState g_dev[64];
 std::mutex g_mu;
@@ -55,18 +54,6 @@ bool dev_state(DevState** out) {
       e = hipModuleGetFunction(&d.fn[i], d.mod, g_variants[i].name);
       if (e != hipSuccess) {
         set_error("dconv: hipModuleGetFunction(%s) -> %s", g_variants[i].name, hipGetErrorString(e));
-        return false;
-      }
-    }
-    e = hipMalloc((void**)&d.tables, sizeof(unsigned) * 128 * NVAR);
-    if (e != hipSuccess) {
-      set_error("dconv: hipMalloc -> %s", hipGetErrorString(e));
-      return false;
-    }
-    for (int i = 0; i < NVAR; ++i) {
-      e = hipMemcpy(d.tables + 128 * i, g_variants[i].table, sizeof(unsigned) * 128, hipMemcpyHostToDevice);
-      if (e != hipSuccess) {
-        set_error("dconv: hipMemcpy -> %s", hipGetErrorString(e));
         return false;
       }
     }
@@ -145,11 +132,13 @@ int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_r
     const void* bn_bits;
     const float* bn_mean;
     const float* bn_invstd;
-    const unsigned* table;
+    const void* rsvd;
     unsigned wtap_off[9];
     unsigned nchunks;
+    unsigned pad[4];
+    unsigned table[128];  // per-wave LDS-DMA piece tables, read with scalar loads
   } k;
-  static_assert(sizeof(KArgs) == 112, "kernarg layout of asm/dconv_gen.py (Gen.KA)");
+  static_assert(sizeof(KArgs) == 640, "kernarg layout of asm/dconv_gen.py (Gen.KA)");
   MI355_ARG((int)sizeof(KArgs) == v.kernarg, "dconv: kernarg size mismatch");
   k.in = a.in;
   k.wt = a.wt;
@@ -159,7 +148,9 @@ int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_r
   k.bn_bits = a.bn_bits;
   k.bn_mean = a.bn_mean;
   k.bn_invstd = a.bn_invstd;
-  k.table = d->tables + 128 * vi;
+  k.rsvd = nullptr;
+  memset(k.pad, 0, sizeof(k.pad));
+  memcpy(k.table, v.table, sizeof(k.table));
   for (int t = 0; t < 9; ++t) k.wtap_off[t] = (unsigned)(wtap[t] * a.Ck * 2);
   k.nchunks = (unsigned)(a.Ck / 64);
   size_t ksize = sizeof(k);

@@ -60,10 +60,15 @@ def run(name, tiles=(0,), ntile=0, seed=0, dgrad_taps=False, check=True, **over)
     out0 = np.full((N, c.H, c.W, c.NCOLS), 0x7FC0, dtype=np.uint16)  # NaN: unwritten outputs show
     a_out = mem.alloc(out0)
     a_stat = mem.alloc(np.full((ntiles, 2, c.NCOLS), np.nan, dtype=np.float32))
-    a_tab = mem.alloc(np.array(dconv_gen.tables(c), dtype=np.uint32))
-    dummy = mem.alloc(np.zeros(64, dtype=np.uint8))
-    fields = [("q", a_in), ("q", a_wt), ("q", a_out), ("q", a_stat), ("q", dummy), ("q", dummy), ("q", dummy), ("q", dummy),
-              ("q", a_tab)] + [("I", wtap_of[t] * c.Cin * 2) for t in range(9)] + [("I", c.Cin // 64)]
+    # BN-backward inputs (stats == 2): y laid out like the output, one mask byte per 8 channels, per-channel mean / invstd
+    yb = rng.integers(-3, 4, size=(N, c.H, c.W, c.NCOLS)).astype(np.float32)
+    bits = rng.integers(0, 256, size=(N, c.H, c.W, c.NCOLS // 8)).astype(np.uint8)
+    mean = (rng.integers(-4, 5, size=c.NCOLS) * 0.25).astype(np.float32)
+    invstd = (rng.integers(1, 5, size=c.NCOLS) * 0.5).astype(np.float32)
+    a_y, a_bits, a_mu, a_is = mem.alloc(to_bf16_bits(yb)), mem.alloc(bits), mem.alloc(mean), mem.alloc(invstd)
+    fields = [("q", a_in), ("q", a_wt), ("q", a_out), ("q", a_stat), ("q", a_y), ("q", a_bits), ("q", a_mu), ("q", a_is),
+              ("q", 0)] + [("I", wtap_of[t] * c.Cin * 2) for t in range(9)] + [("I", c.Cin // 64)] + [("I", 0)] * 4
+    fields += [("I", w) for row in dconv_gen.tables(c) for w in row]
     ka = gcn_emu.pack_kernarg(fields)
     assert len(ka) == dconv_gen.Gen.KA["size"], len(ka)
     a_ka = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
@@ -89,6 +94,16 @@ def run(name, tiles=(0,), ntile=0, seed=0, dgrad_taps=False, check=True, **over)
         s2 = np.stack([(refr[t * c.IPT:(t + 1) * c.IPT] ** 2).sum(axis=(0, 1, 2)) for t in range(ntiles)])
         tl = list(tiles)
         res["stat_err"] = float(max(np.abs(st[tl, 0][:, cols] - s1[tl][:, cols]).max(), np.abs(st[tl, 1][:, cols] - s2[tl][:, cols]).max()))
+    if c.stats == 2:
+        st = mem.array(a_stat, np.float32, (ntiles, 2, c.NCOLS))
+        mask = ((bits[..., None] >> np.arange(8)) & 1).reshape(N, c.H, c.W, c.NCOLS).astype(np.float64)
+        dz = refr * mask
+        xhat = (yb.astype(np.float64) - mean) * invstd
+        tl = list(tiles)
+        s1 = np.stack([dz[t * c.IPT:(t + 1) * c.IPT].sum(axis=(0, 1, 2)) for t in range(ntiles)])
+        s2 = np.stack([(dz * xhat)[t * c.IPT:(t + 1) * c.IPT].sum(axis=(0, 1, 2)) for t in range(ntiles)])
+        scale = max(np.abs(s1).max(), np.abs(s2).max(), 1.0)
+        res["stat_err"] = float(max(np.abs(st[tl, 0][:, cols] - s1[tl][:, cols]).max(), np.abs(st[tl, 1][:, cols] - s2[tl][:, cols]).max()) / scale)
     return res
 
 

@@ -519,6 +519,10 @@ class Emulator:
         wv.scc = 1 if r else 0
         self.swrite64(wv, ins.ops[0], r, ins)
 
+    def i_s_cselect_b32(self, wv, ins):
+        a, b = self._s2(wv, ins)
+        self.swrite(wv, ins.ops[0], a if wv.scc else b, ins)
+
     def i_s_bfe_u32(self, wv, ins):
         a, b = self._s2(wv, ins)
         off, width = b & 31, (b >> 16) & 0x7F
@@ -689,6 +693,13 @@ class Emulator:
     def i_v_bfe_u32(self, wv, ins):
         a, b, c = self._v3(wv, ins)
         self._vw(wv, ins, (a >> (b & 31)) & ((1 << (c & 31)) - 1))
+
+    def i_v_bfe_i32(self, wv, ins):
+        a, b, c = self._v3(wv, ins)
+        a, b, w = a.astype(np.int64), b.astype(np.int64), (c & 31).astype(np.int64)
+        f = (a >> (b & 31)) & ((np.int64(1) << w) - 1)
+        sign = (f >> (w - 1)) & 1
+        self._vw(wv, ins, np.where(sign == 1, f - (np.int64(1) << w) + (np.int64(1) << 32), f).astype(np.uint64))
 
     def i_v_perm_b32(self, wv, ins):
         a, b, c = self._v3(wv, ins)
