@@ -52,6 +52,11 @@ class Cfg:
     WN: int = 2
     NT: int = 8       # 16-column tiles per wave
     BN: int = 256
+    NB: int = 2       # stages of the weight ring (3 where LDS allows: the pieces of stage s + 3 then have two stages to land)
+
+    @property
+    def ABASE(self):
+        return self.NB * self.BSTAGE
 
     @property
     def SR(self):     # LDS rows per image slot (the halo row between two images is shared)
@@ -93,7 +98,7 @@ class Cfg:
         return 9 * self.Cin * 2
 
 
-ABASE = 2 * 32768  # LDS: [B ring 2 x 32 KiB][A buffer 0][A buffer 1][stats scratch reuses the B ring]
+# LDS: [weight ring NB x 32 KiB][A buffer 0][sink][A buffer 1][sink]; the statistics scratch reuses the ring
 
 
 def valid_rows(c):
@@ -245,7 +250,7 @@ class Gen:
 
         self.v_tid = 0
         self.vA_rd = [[V.get() for kk in range(2)] for kx in range(3)]
-        self.vB_rd = [V.get() for kk in range(2)]
+        self.vB_rd = [[V.get() for kk in range(2)] for st in range(c.NB)]
         nvar = c.P // 8
         self.vA_dma = [V.get() for _ in range(nvar)]
         self.vB_dma = [V.get() for _ in range(2)]
@@ -363,7 +368,8 @@ class Gen:
         self.b_stage_issue_all(0, 0, self.s_cC)
         for i in range(self.NPA):
             self.a_piece(i, 0, soff_chunk=self.s_cC)
-        self.b_stage_issue_all(1, 1, self.s_cC)
+        for st in range(1, c.NB):
+            self.b_stage_issue_all(st, st, self.s_cC)
 
         # ---- the rest of the set-up runs under the latency of those loads
         # O: + tile*tile_out + nt*512 bytes
@@ -417,7 +423,7 @@ class Gen:
             e("v_lshlrev_b32 %s, 4, %s" % (R("v", cc), R("v", cc)))
             e("v_lshl_add_u32 %s, %s, 7, %s" % (R("v", cc), R("v", t), R("v", cc)))
             e("v_add_u32 %s, %s, %s" % (R("v", cc), R("s", t0), R("v", cc)))
-            e("v_add_u32 %s, %d, %s" % (R("v", self.vA_rd[kx][0]), ABASE, R("v", cc)))
+            e("v_add_u32 %s, %d, %s" % (R("v", self.vA_rd[kx][0]), c.ABASE, R("v", cc)))
             e("v_xor_b32 %s, 64, %s" % (R("v", self.vA_rd[kx][1]), R("v", self.vA_rd[kx][0])))
         # ---- B read bases: row = wn*NT*16 + r ; chunk = (kg + 4kk) ^ ((r >> 1) & 7)
         sw, cc = v[3], v[4]
@@ -426,8 +432,11 @@ class Gen:
         e("v_lshlrev_b32 %s, 4, %s" % (R("v", cc), R("v", cc)))
         e("v_lshl_add_u32 %s, %s, 7, %s" % (R("v", cc), R("v", r), R("v", cc)))
         e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_wn), c.NT * 16 * 128))
-        e("v_add_u32 %s, %s, %s" % (R("v", self.vB_rd[0]), R("s", t0), R("v", cc)))
-        e("v_xor_b32 %s, 64, %s" % (R("v", self.vB_rd[1]), R("v", self.vB_rd[0])))
+        e("v_add_u32 %s, %s, %s" % (R("v", self.vB_rd[0][0]), R("s", t0), R("v", cc)))
+        e("v_xor_b32 %s, 64, %s" % (R("v", self.vB_rd[0][1]), R("v", self.vB_rd[0][0])))
+        for st in range(1, c.NB):
+            for kk in range(2):
+                e("v_add_u32 %s, %d, %s" % (R("v", self.vB_rd[st][kk]), st * c.BSTAGE, R("v", self.vB_rd[0][kk])))
         # ---- output lane offset: pixel part * NCOLS*2 + (wn*NT*16 + kg*8)*2
         x, off = v[6], v[7]
         if c.P >= 16:
@@ -449,7 +458,7 @@ class Gen:
         z = self.F[0][0]
         for i in range(4):
             e("v_mov_b32 %s, 0" % R("v", z + i))
-        blocks = [ABASE + b * c.ASTRIDE + o for b in range(2) for o in self.never_written_blocks()]
+        blocks = [c.ABASE + b * c.ASTRIDE + o for b in range(2) for o in self.never_written_blocks()]
         e("v_lshlrev_b32 %s, 4, %s" % (R("v", v[3]), R("v", lane)), "lane*16")
         n = len(blocks)
         for k in range((n + 3) // 4):
@@ -468,7 +477,7 @@ class Gen:
         # accumulators = 0
         for i in range(self.nagpr):
             e("v_accvgpr_write_b32 a%d, 0" % i)
-        e("s_waitcnt vmcnt(8)")
+        e("s_waitcnt vmcnt(%d)" % (8 * (c.NB - 1)))
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier")
         # fragments of (stage 0, kk 0)
@@ -481,7 +490,7 @@ class Gen:
         c, e = self.c, self.e
         var = a_schedule(c)[i][0]
         e("s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", soff_chunk), R("s", self.s_tA_src + i)))
-        e("s_add_u32 m0, %s, %d" % (R("s", self.s_tA_lds + i), ABASE + buf * c.ASTRIDE))
+        e("s_add_u32 m0, %s, %d" % (R("s", self.s_tA_lds + i), c.ABASE + buf * c.ASTRIDE))
         e("buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vA_dma[var]), R("s", self.srdA, 4), R("s", self.s_t0)))
 
     def b_piece_insts(self, i, bp, s_stage):
@@ -517,8 +526,7 @@ class Gen:
                 off = i * 2048 + ky * c.P * 128  # fragment i starts at position 16*i, the tap's row shift is ky*P positions
                 out.append("ds_read_b128 %s, %s offset:%d" % (R("v", fa + 4 * i, 4), R("v", self.vA_rd[kx][kk]), off))
             else:
-                off = bp * c.BSTAGE + i * 2048
-                out.append("ds_read_b128 %s, %s offset:%d" % (R("v", fb + 4 * i, 4), R("v", self.vB_rd[kk]), off))
+                out.append("ds_read_b128 %s, %s offset:%d" % (R("v", fb + 4 * i, 4), R("v", self.vB_rd[bp][kk]), i * 2048))
         return out
 
     def mfmas(self, fset):
@@ -569,7 +577,8 @@ class Gen:
             e("s_mov_b32 %s, 0" % R("s", self.s_cN))
             self.label(lab)
             for t in range(9):
-                bp = (cp + t) & 1
+                bp = (cp * 9 + t) % c.NB          # ring stage of (chunk parity, tap): 9 % 3 == 0, so NB = 3 does not depend on cp
+                bp1 = (cp * 9 + t + 1) % c.NB     # ... of the next stage
                 # ---- substep kk = 0: compute on set 0, read (t, kk 1) into set 1, one A piece of the next chunk
                 self.comment("chunk parity %d tap %d substep 0" % (cp, t))
                 e("s_waitcnt lgkmcnt(0)")
@@ -579,7 +588,7 @@ class Gen:
                 if t < self.NPA:
                     var = a_schedule(c)[t][0]
                     pieces.append(["s_add_u32 %s, %s, %s" % (R("s", self.s_t1), R("s", self.s_cN), R("s", self.s_tA_src + t)),
-                                   "s_add_u32 m0, %s, %d" % (R("s", self.s_tA_lds + t), ABASE + (cp ^ 1) * c.ASTRIDE),
+                                   "s_add_u32 m0, %s, %d" % (R("s", self.s_tA_lds + t), c.ABASE + (cp ^ 1) * c.ASTRIDE),
                                    "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vA_dma[var]), R("s", self.srdA, 4), R("s", self.s_t1))])
                 if c.probe & 1:
                     pieces = []
@@ -588,7 +597,10 @@ class Gen:
                 self.interleave(mf, self.merge(groups, pieces))
                 # ---- the stage barrier: stage t+1's weights (and after tap 8 the next A tile) have landed for every wave
                 self.comment("chunk parity %d tap %d substep 1" % (cp, t))
-                e("s_waitcnt vmcnt(%d)" % (1 if t < self.NPA else 0))
+                # younger than stage t+1's pieces: the weight groups of stages t+2 .. t+NB-1 and the A pieces issued since; at tap 8
+                # the A pieces must have landed too (they are older than those groups: NPA <= 8)
+                ayoung = sum(1 for j in range(t + 2 - c.NB, t + 1) if 0 <= j < self.NPA)
+                e("s_waitcnt vmcnt(%d)" % (8 * (c.NB - 2) + (ayoung if t < 8 else 0)))
                 e("s_waitcnt lgkmcnt(0)")
                 if not c.probe & 4:
                     e("s_barrier")
@@ -600,10 +612,10 @@ class Gen:
                         for kk in range(2):
                             rr = R("v", self.vA_rd[kx][kk])
                             e("v_add_u32 %s, %d, %s" % (rr, d, rr) if d > 0 else "v_subrev_u32 %s, %d, %s" % (rr, -d, rr))
-                groups = [[r] for r in self.frag_reads(0, t2, 0, bp ^ 1)]
-                # weight stage t+2 into ring stage bp
-                t3 = (t + 2) % 9
-                s_ch = self.s_cC if t + 2 < 9 else self.s_cN
+                groups = [[r] for r in self.frag_reads(0, t2, 0, bp1)]
+                # weight stage t+NB into ring stage bp (just released by the barrier)
+                t3 = (t + c.NB) % 9
+                s_ch = self.s_cC if t + c.NB < 9 else self.s_cN
                 pieces = []
                 for i in range(8):
                     g = self.b_piece_insts(i, bp, self.s_stg)
@@ -833,7 +845,7 @@ class Gen:
     def finish(self):
         c = self.c
         name = c.name
-        lds = ABASE + 2 * c.ASTRIDE  # B ring, two A buffers each followed by the sink of its padding pieces
+        lds = c.ABASE + 2 * c.ASTRIDE  # B ring, two A buffers each followed by the sink of its padding pieces
         assert lds <= 160 * 1024
         total_v = self.accum_offset + self.nagpr
         hdr = []
@@ -906,9 +918,9 @@ VARIANTS = {
     "dconv_l3_s1": Cfg("dconv_l3_s1", H=14, W=14, P=16, IPT=1, Cin=256, NCOLS=256, stats=1),
     "dconv_l3_s0": Cfg("dconv_l3_s0", H=14, W=14, P=16, IPT=1, Cin=256, NCOLS=256, stats=0),
     "dconv_l3_s2": Cfg("dconv_l3_s2", H=14, W=14, P=16, IPT=1, Cin=256, NCOLS=256, stats=2),
-    "dconv_l4_s0": Cfg("dconv_l4_s0", H=7, W=7, P=8, IPT=2, Cin=512, NCOLS=512, stats=0),
-    "dconv_l4_s1": Cfg("dconv_l4_s1", H=7, W=7, P=8, IPT=2, Cin=512, NCOLS=512, stats=1),
-    "dconv_l4_s2": Cfg("dconv_l4_s2", H=7, W=7, P=8, IPT=2, Cin=512, NCOLS=512, stats=2),
+    "dconv_l4_s0": Cfg("dconv_l4_s0", H=7, W=7, P=8, IPT=2, Cin=512, NCOLS=512, stats=0, NB=3),
+    "dconv_l4_s1": Cfg("dconv_l4_s1", H=7, W=7, P=8, IPT=2, Cin=512, NCOLS=512, stats=1, NB=3),
+    "dconv_l4_s2": Cfg("dconv_l4_s2", H=7, W=7, P=8, IPT=2, Cin=512, NCOLS=512, stats=2, NB=3),
 }
 
 

@@ -85,7 +85,7 @@ bool tap_table(const TapClass& c, int wtap[9]) {
 int find_variant(const IgemmArgs& a, int nclass, int stats) {
   if (nclass != 1 || a.IS != 1 || a.OS != 1 || a.pair_delta != 0 || a.wtaps != 9) return -1;
   if (a.Hsub != a.Hin || a.Wsub != a.Win || a.Hout != a.Hin || a.Wout != a.Win) return -1;
-  if (a.pix_stride != a.Ck || a.addend != nullptr || a.sk_ws != nullptr || a.fin.mode != 0) return -1;
+  if (a.pix_stride != a.Ck || a.addend != nullptr || a.fin.mode != 0) return -1;  // (sk_ws is optional scratch: not needed here)
   if (a.q_scale_in != nullptr || a.q_scale_wt != nullptr) return -1;
   int wtap[9];
   if (!tap_table(a.cls[0], wtap)) return -1;

@@ -74,7 +74,7 @@ def run(name, tiles=(0,), ntile=0, seed=0, dgrad_taps=False, check=True, **over)
     a_ka = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     total = 0
     for t in tiles:
-        emu = gcn_emu.Emulator(text, mem, lds_bytes=g.lds_bytes, check=check, sinks=[(dconv_gen.ABASE + b * c.ASTRIDE + c.ABUF, dconv_gen.ABASE + (b + 1) * c.ASTRIDE) for b in range(2)])
+        emu = gcn_emu.Emulator(text, mem, lds_bytes=g.lds_bytes, check=check, sinks=[(c.ABASE + b * c.ASTRIDE + c.ABUF, c.ABASE + (b + 1) * c.ASTRIDE) for b in range(2)])
         total += emu.run_workgroup(4, a_ka, wg_id=(t, ntile, 0))
     got = from_bf16_bits(mem.array(a_out, np.uint16, out0.shape)).astype(np.float64)
     ref = conv_ref(x.astype(np.float64), w.astype(np.float64), taps)
