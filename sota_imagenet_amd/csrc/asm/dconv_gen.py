@@ -489,15 +489,15 @@ class Gen:
     def a_piece(self, i, buf, soff_chunk):
         c, e = self.c, self.e
         var = a_schedule(c)[i][0]
-        e("s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", soff_chunk), R("s", self.s_tA_src + i)))
         e("s_add_u32 m0, %s, %d" % (R("s", self.s_tA_lds + i), c.ABASE + buf * c.ASTRIDE))
+        e("s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", soff_chunk), R("s", self.s_tA_src + i)), "(also the wait state between the M0 write and the DMA)")
         e("buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vA_dma[var]), R("s", self.srdA, 4), R("s", self.s_t0)))
 
     def b_piece_insts(self, i, bp, s_stage):
         """the three instructions of weight piece i into ring stage bp; s_stage holds (wtap*Cin + chunk*64)*2"""
         c = self.c
-        return ["s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", s_stage), R("s", self.s_tB + i)),
-                "s_add_u32 m0, %s, %d" % (R("s", self.s_ldsBw), bp * c.BSTAGE + i * 1024),
+        return ["s_add_u32 m0, %s, %d" % (R("s", self.s_ldsBw), bp * c.BSTAGE + i * 1024),
+                "s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", s_stage), R("s", self.s_tB + i)),
                 "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vB_dma[i & 1]), R("s", self.srdB, 4), R("s", self.s_t0))]
 
     def b_stage_issue_all(self, tap, bp, s_chunk):
@@ -587,8 +587,8 @@ class Gen:
                 pieces = []
                 if t < self.NPA:
                     var = a_schedule(c)[t][0]
-                    pieces.append(["s_add_u32 %s, %s, %s" % (R("s", self.s_t1), R("s", self.s_cN), R("s", self.s_tA_src + t)),
-                                   "s_add_u32 m0, %s, %d" % (R("s", self.s_tA_lds + t), c.ABASE + (cp ^ 1) * c.ASTRIDE),
+                    pieces.append(["s_add_u32 m0, %s, %d" % (R("s", self.s_tA_lds + t), c.ABASE + (cp ^ 1) * c.ASTRIDE),
+                                   "s_add_u32 %s, %s, %s" % (R("s", self.s_t1), R("s", self.s_cN), R("s", self.s_tA_src + t)),
                                    "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vA_dma[var]), R("s", self.srdA, 4), R("s", self.s_t1))])
                 if c.probe & 1:
                     pieces = []
@@ -933,32 +933,14 @@ def generate(base, **over):
     return c, g, text
 
 
-def write_meta(out_dir, hsaco):
-    """dconv_blob.inc: the linked code object as a byte array; dconv_meta.inc: one DconvVariant initialiser per kernel"""
-    blob = open(hsaco, "rb").read()
-    with open(os.path.join(out_dir, "dconv_blob.inc"), "w") as f:
-        for i in range(0, len(blob), 32):
-            f.write(",".join(str(b) for b in blob[i:i + 32]) + ",\n")
-    with open(os.path.join(out_dir, "dconv_meta.inc"), "w") as f:
-        for name in VARIANTS:
-            c, g, _ = generate(name)
-            tab = tables(c)
-            words = ",".join("%du" % w for row in tab for w in row)
-            f.write('{"%s", %d, %d, %d, %d, %d, %d, %d, %d, {%s}},\n' % (name, c.H, c.W, c.IPT, c.Cin, c.NCOLS, c.stats, g.lds_bytes, Gen.KA["size"], words))
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="build")
-    ap.add_argument("--embed", default=None, help="linked .hsaco: write dconv_blob.inc / dconv_meta.inc instead of the .s files")
     ap.add_argument("--set", action="append", default=[], help="tuning: override a Cfg field (key=int), with --suffix names the kernel")
     ap.add_argument("--suffix", default="")
     ap.add_argument("names", nargs="*")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
-    if a.embed:
-        write_meta(a.out, a.embed)
-        return
     over = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.set}
     for name in (a.names or VARIANTS):
         if a.suffix:

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""embed.py <out dir> <linked .hsaco> — writes the include files dconv.cpp embeds: the code object as a byte array
+(dconv_blob.inc) and one initialiser per generated kernel (dconv_meta.inc: direct 3x3 kernels, pw_meta.inc: pointwise)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import dconv_gen  # noqa: E402
+import pw_gen  # noqa: E402
+
+
+def main():
+    out_dir, hsaco = sys.argv[1], sys.argv[2]
+    blob = open(hsaco, "rb").read()
+    with open(os.path.join(out_dir, "dconv_blob.inc"), "w") as f:
+        for i in range(0, len(blob), 32):
+            f.write(",".join(str(b) for b in blob[i:i + 32]) + ",\n")
+    with open(os.path.join(out_dir, "dconv_meta.inc"), "w") as f:
+        for name in dconv_gen.VARIANTS:
+            c, g, _ = dconv_gen.generate(name)
+            words = ",".join("%du" % w for row in dconv_gen.tables(c) for w in row)
+            f.write('{"%s", %d, %d, %d, %d, %d, %d, %d, %d, {%s}},\n' % (name, c.H, c.W, c.IPT, c.Cin, c.NCOLS, c.stats, g.lds_bytes, dconv_gen.Gen.KA["size"], words))
+    with open(os.path.join(out_dir, "pw_meta.inc"), "w") as f:
+        for name in pw_gen.VARIANTS:
+            c, g, _ = pw_gen.generate(name)
+            words = ",".join("%du" % w for row in pw_gen.tables(c) for w in row)
+            f.write('{"%s", %d, %d, %d, %d, %d, %d, {%s}},\n' % (name, c.K, c.N, c.stats, c.ROWS, c.LDS, pw_gen.Gen.KA["size"], words))
+
+
+if __name__ == "__main__":
+    main()

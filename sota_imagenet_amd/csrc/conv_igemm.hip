@@ -826,6 +826,8 @@ int launch_stem_direct(const IgemmArgs& a, hipStream_t stream, int* stat_rows);
 // dconv.cpp: the generated one-wave-per-SIMD direct 3x3 / stride-1 kernels (asm/dconv_gen.py) for the layer-3 / layer-4 shapes
 bool dconv_legal(const IgemmArgs& a, int nclass);
 int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows);
+bool pw_legal(const IgemmArgs& a, int nclass);  // the persistent pointwise kernels (asm/pw_gen.py): output-heavy 1x1 forward
+int launch_pw(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows);
 
 // conv_igemm8.hip
 bool igemm8_legal(const IgemmArgs& a, int nclass, int bn);
@@ -900,6 +902,7 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
     return wide ? launch_t<float, 128, 128>(a, nclass, stream, stat_rows) : launch_t<float, 128, 64>(a, nclass, stream, stat_rows);
   if (dtype == MI355_BF16) {
     if (dconv_legal(a, nclass)) return launch_dconv(a, nclass, stream, stat_rows);
+    if (pw_legal(a, nclass)) return launch_pw(a, nclass, stream, stat_rows);
     {
       // MI355_CONV3=1: the layer-1 3x3 launches on the direct-convolution kernel (conv3x3.hip).  Bit-exact, and measured no faster
       // than the 3-workgroups-per-CU implicit-GEMM tile (111 vs 118 us per launch from cold caches, profiles/README.md): off by default.

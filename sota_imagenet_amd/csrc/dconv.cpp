@@ -22,6 +22,17 @@ const DconvVariant g_variants[] = {
 };
 constexpr int NVAR = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
 
+// persistent pointwise kernels (asm/pw_gen.py)
+struct PwVariant {
+  const char* name;
+  int K, N, stats, rows, lds, kernarg;
+  unsigned table[4 * 32];
+};
+const PwVariant g_pw[] = {
+#include "build/asm/pw_meta.inc"
+};
+constexpr int NPW = (int)(sizeof(g_pw) / sizeof(g_pw[0]));
+
 alignas(4096) const unsigned char g_blob[] = {
 #include "build/asm/dconv_blob.inc"
 };
@@ -30,6 +41,7 @@ struct DevState {
   bool tried = false, ok = false;
   hipModule_t mod = nullptr;
   hipFunction_t fn[NVAR] = {};
+  hipFunction_t pw[NPW] = {};
 };
 DevState g_dev[64];
 std::mutex g_mu;
@@ -54,6 +66,13 @@ bool dev_state(DevState** out) {
       e = hipModuleGetFunction(&d.fn[i], d.mod, g_variants[i].name);
       if (e != hipSuccess) {
         set_error("dconv: hipModuleGetFunction(%s) -> %s", g_variants[i].name, hipGetErrorString(e));
+        return false;
+      }
+    }
+    for (int i = 0; i < NPW; ++i) {
+      e = hipModuleGetFunction(&d.pw[i], d.mod, g_pw[i].name);
+      if (e != hipSuccess) {
+        set_error("dconv: hipModuleGetFunction(%s) -> %s", g_pw[i].name, hipGetErrorString(e));
         return false;
       }
     }
@@ -96,6 +115,21 @@ int find_variant(const IgemmArgs& a, int nclass, int stats) {
   return -1;
 }
 
+// the persistent pointwise kernel that can run this launch (1x1, stride 1, no addend, statistics 0 / 1), or -1
+int find_pw(const IgemmArgs& a, int nclass, int stats) {
+  if (nclass != 1 || a.IS != 1 || a.OS != 1 || a.pair_delta != 0 || a.wtaps != 1 || a.cls[0].ntaps != 1) return -1;
+  if (a.cls[0].taps[0].dh != 0 || a.cls[0].taps[0].dw != 0 || a.cls[0].taps[0].wtap != 0 || a.cls[0].ph != 0 || a.cls[0].pw != 0) return -1;
+  if (a.Hsub != a.Hin || a.Wsub != a.Win || a.Hout != a.Hin || a.Wout != a.Win) return -1;
+  if (a.pix_stride != a.Ck || a.addend != nullptr || a.fin.mode != 0 || a.q_scale_in != nullptr || a.q_scale_wt != nullptr) return -1;
+  if (stats == 2) return -1;
+  const long M = (long)a.N * a.Hin * a.Win;
+  for (int i = 0; i < NPW; ++i) {
+    const PwVariant& v = g_pw[i];
+    if (v.K == a.Ck && v.N == a.Ncols && v.stats == stats && M % v.rows == 0 && M / v.rows < (1 << 20)) return i;
+  }
+  return -1;
+}
+
 int wanted_stats(const IgemmArgs& a) { return a.stat_partial == nullptr ? 0 : (a.bn_y != nullptr ? 2 : 1); }
 
 }  // namespace
@@ -104,6 +138,52 @@ int wanted_stats(const IgemmArgs& a) { return a.stat_partial == nullptr ? 0 : (a
 static bool dconv_enabled() {
   static const bool on = !(getenv("MI355_DCONV") && getenv("MI355_DCONV")[0] == '0');
   return on;
+}
+
+bool pw_legal(const IgemmArgs& a, int nclass) {
+  if (!dconv_enabled()) return false;
+  return find_pw(a, nclass, wanted_stats(a)) >= 0;
+}
+
+int launch_pw(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
+  const int vi = find_pw(a, nclass, wanted_stats(a));
+  MI355_ARG(vi >= 0, "pw: no kernel variant for this launch");
+  const PwVariant& v = g_pw[vi];
+  DevState* d = nullptr;
+  if (!dev_state(&d)) return MI355_E_HIP;
+  struct __attribute__((packed)) KArgs {
+    const void* in;
+    const void* wt;
+    void* out;
+    float* stat;
+    const void* rsvd[6];
+    unsigned units, upw, mtiles, pad0;
+    unsigned pad[8];
+    unsigned table[128];
+  } k;
+  static_assert(sizeof(KArgs) == 640, "kernarg layout of asm/pw_gen.py (Gen.KA)");
+  MI355_ARG((int)sizeof(KArgs) == v.kernarg, "pw: kernarg size mismatch");
+  memset(&k, 0, sizeof(k));
+  k.in = a.in;
+  k.wt = a.wt;
+  k.out = a.out;
+  k.stat = a.stat_partial;
+  const long M = (long)a.N * a.Hin * a.Win;
+  k.mtiles = (unsigned)(M / v.rows);
+  k.units = k.mtiles * (unsigned)(v.N / 256);
+  const unsigned cus = (unsigned)device_cus();
+  k.upw = (k.units + cus - 1) / cus;
+  const unsigned grid = (k.units + k.upw - 1) / k.upw;  // every workgroup has at least one unit (it writes its statistics row)
+  memcpy(k.table, v.table, sizeof(k.table));
+  size_t ksize = sizeof(k);
+  void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
+  const hipError_t e = hipModuleLaunchKernel(d->pw[vi], grid, 1, 1, 256, 1, 1, 0, stream, nullptr, extra);
+  if (e != hipSuccess) {
+    set_error("pw: hipModuleLaunchKernel(%s) -> %s", v.name, hipGetErrorString(e));
+    return MI355_E_HIP;
+  }
+  if (stat_rows) *stat_rows = a.stat_partial ? (int)grid : 0;
+  return 0;
 }
 
 bool dconv_legal(const IgemmArgs& a, int nclass) {

@@ -519,6 +519,11 @@ class Emulator:
         wv.scc = 1 if r else 0
         self.swrite64(wv, ins.ops[0], r, ins)
 
+    def i_s_min_u32(self, wv, ins):
+        a, b = self._s2(wv, ins)
+        wv.scc = 1 if a <= b else 0
+        self.swrite(wv, ins.ops[0], min(a, b), ins)
+
     def i_s_cselect_b32(self, wv, ins):
         a, b = self._s2(wv, ins)
         self.swrite(wv, ins.ops[0], a if wv.scc else b, ins)
@@ -904,6 +909,18 @@ class Emulator:
             self.lds[a:a + nbytes] = np.array([vals[i][l] for i in range(nd)], dtype=np.uint32).view(np.uint8)
         wv.lgkm_ops.append({"kind": "ldsw"})
 
+    def i_ds_add_f32(self, wv, ins):
+        addr_o, data = ins.ops[0], ins.ops[1]
+        addrs = self._ds_addr(wv, ins, addr_o)
+        mask = self.lanes(wv)
+        if (addrs[mask] + 4 > self.lds.size).any() or ((addrs[mask] % 4) != 0).any():
+            self.err(ins, "ds_add_f32 beyond the LDS allocation / misaligned")
+        vals = _f32(self.vval(wv, data, ins))
+        lds32 = self.lds.view(np.float32)
+        for l in np.nonzero(mask)[0]:
+            lds32[int(addrs[l]) // 4] = np.float32(lds32[int(addrs[l]) // 4] + vals[l])
+        wv.lgkm_ops.append({"kind": "ldsw"})
+
     def i_ds_write_b128(self, wv, ins):
         self._ds_write(wv, ins, 16)
 
@@ -942,7 +959,10 @@ class Emulator:
             if dst0 + 64 * nbytes > self.lds.size:
                 self.err(ins, "LDS-DMA beyond the LDS allocation")
             slots = np.arange(dst0 // 16, dst0 // 16 + 64 * nbytes // 16)
-            self.lds_write_check(wv, slots, ins)
+            dup = self.check and (self.slot_state[slots] == 1).all() and (self.slot_owner[slots] == wv.wid).all()
+            old = self.lds[dst0: dst0 + 64 * nbytes].copy() if dup else None
+            if not dup:
+                self.lds_write_check(wv, slots, ins)
             if self.slot_seq is None:
                 self.slot_seq = np.zeros(self.slot_state.size, dtype=np.int64)
             self.dma_seq = getattr(self, "dma_seq", 0) + 1
@@ -957,6 +977,8 @@ class Emulator:
                         self.err(ins, "in-range offset pushed past num_records by soffset (lane %d): the hardware range check is not relied on for this" % l)
                     data = self.mem.read(base + o + soff, nbytes)
                 self.lds[dst0 + l * nbytes: dst0 + (l + 1) * nbytes] = data
+            if dup and not (old == self.lds[dst0: dst0 + 64 * nbytes]).all():
+                self.err(ins, "LDS bytes rewritten with DIFFERENT data while this wave's earlier LDS-DMA into them is in flight")
             self.slot_state[slots] = 1
             self.slot_owner[slots] = wv.wid
             self.slot_seq[slots] = self.dma_seq
