@@ -42,7 +42,7 @@ class PwCfg:
     stats: int        # 0 / 1 (BN statistics of the output)
     MT: int = 7       # pixel fragments per unit
     NB: int = 3
-    probe: int = 0    # timing probes (WRONG results): 1 no epilogue work in the loop
+    probe: int = 0    # timing probes (WRONG results): 1 no epilogue work in the loop, 2 no stores, 4 no weight DMA in the loop, 8 no barriers, 16 epilogue = accumulator reads only, 32 epilogue without accumulator reads
 
     @property
     def NCH(self):
@@ -180,6 +180,7 @@ class Gen:
     def gen(self):
         c, S, V = self.c, self.S, self.V
         assert c.NTN & (c.NTN - 1) == 0 and c.LDS <= 160 * 1024, c.LDS
+        assert c.NCH >= 2, "a plane is refilled one stage before its next read: needs at least two planes"
         self.s_wg = 2
         self.srdA = S.get(4, 4)     # the pixel tile whose planes are being (re)filled
         self.srdB = S.get(4, 4)
@@ -189,8 +190,9 @@ class Gen:
         self.s_ka = S.get(16, 4)
         self.s_kb = S.get(4, 4)
         (self.s_u, self.s_uend, self.s_mt, self.s_nt, self.s_ntn, self.s_last, self.s_pnt, self.s_w, self.s_t0, self.s_t1,
-         self.s_bcur, self.s_bnext, self.s_fillw, self.s_ldsBw, self.s_bsrc_cur, self.s_bsrc_nxt, self.s_stg, self.s_mtiles,
+         self.s_bcur, self.s_bnext, self.s_fillw, self.s_ldsBw, self.s_bsrc0, self.s_bsrc1, self.s_stg, self.s_mtiles,
          self.s_outlo, self.s_outhi, self.s_alo, self.s_ahi, self.s_t2) = [S.get() for _ in range(23)]
+        self.s_bsrc = [self.s_bsrc0, self.s_bsrc1, S.get(), S.get()]   # weight row offset of the column tile of unit u + k
         self.s_tA_lds, self.s_tA_src, self.s_tB = self.s_tbl, self.s_tbl + 4, self.s_tbl + 8
 
         self.vA_rd = [V.get() for _ in range(2)]
@@ -218,6 +220,9 @@ class Gen:
         self.nacc = c.MT * 4 * 4          # one accumulator set
         self.nagpr = 2 * self.nacc
 
+        self.UB = 2
+        while self.UB * c.NCH < c.NB + 1:
+            self.UB += 2
         self.prologue()
         self.loop()
         text = self.finish()
@@ -258,8 +263,10 @@ class Gen:
         c, e = self.c, self.e
         e("s_add_u32 %s, %s, 1" % (R("s", self.s_ntn), R("s", self.s_nt)))
         e("s_and_b32 %s, %s, %d" % (R("s", self.s_ntn), R("s", self.s_ntn), c.NTN - 1))
-        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_bsrc_cur), R("s", self.s_nt), 256 * c.w_row))
-        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_bsrc_nxt), R("s", self.s_ntn), 256 * c.w_row))
+        for k in range(4):
+            e("s_add_u32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_nt), k))
+            e("s_and_b32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_t0), c.NTN - 1))
+            e("s_mul_i32 %s, %s, %d" % (R("s", self.s_bsrc[k]), R("s", self.s_t0), 256 * c.w_row))
         # refill tile = min(mt + 1, mtiles - 1): its planes are loaded during this unit when it is the last column tile
         e("s_add_u32 %s, %s, 1" % (R("s", self.s_t2), R("s", self.s_mt)))
         e("s_sub_u32 %s, %s, 1" % (R("s", self.s_t0), R("s", self.s_mtiles)))
@@ -373,10 +380,13 @@ class Gen:
         # first loads: the planes of this unit's pixel tile, weight stages 0 .. NB-1 of this unit
         self.set_srdA(self.s_mt)
         e("s_mov_b32 %s, 0" % R("s", self.s_bcur))
-        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_bsrc_cur), R("s", self.s_nt), 256 * c.w_row))
+        for k in range(4):
+            e("s_add_u32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_nt), k))
+            e("s_and_b32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_t0), c.NTN - 1))
+            e("s_mul_i32 %s, %s, %d" % (R("s", self.s_bsrc[k]), R("s", self.s_t0), 256 * c.w_row))
         for st in range(c.NB):
             e("s_add_u32 %s, %s, %d" % (R("s", self.s_fillw), R("s", self.s_ldsBw), st * 32768))
-            e("s_add_u32 %s, %s, %d" % (R("s", self.s_stg), R("s", self.s_bsrc_cur), st * 128))
+            e("s_add_u32 %s, %s, %d" % (R("s", self.s_stg), R("s", self.s_bsrc[st // c.NCH]), (st % c.NCH) * 128))
             for i in range(8):
                 for ins in self.b_piece_insts(i, self.s_fillw, self.s_stg):
                     e(ins)
@@ -440,12 +450,17 @@ class Gen:
         d = self.dsets[k % 4]
         g = []
         for i in range(4):
+            if c.probe & 32:
+                break
             g.append("v_accvgpr_read_b32 %s, a%d" % (R("v", tv[i]), ap * self.nacc + (m * 4 + 2 * p) * 4 + i))
             g.append("v_accvgpr_read_b32 %s, a%d" % (R("v", tv[4 + i]), ap * self.nacc + (m * 4 + 2 * p + 1) * 4 + i))
+        if c.probe & 16:
+            return g
         for i in range(4):
             g.append("v_cvt_pk_bf16_f32 %s, %s, %s" % (R("v", d + i), R("v", tv[2 * i]), R("v", tv[2 * i + 1])))
         g.append("s_mov_b32 %s, %d" % (R("s", self.s_t1), m * 16 * c.N * 2))
-        g.append(("vm", "store", "buffer_store_dwordx4 %s, %s, %s, %s offen offset:%d" % (R("v", d, 4), R("v", self.v_out), R("s", self.srdOp, 4), R("s", self.s_t1), p * 64)))
+        if not (c.probe & 2):
+            g.append(("vm", "store", "buffer_store_dwordx4 %s, %s, %s, %s offen offset:%d" % (R("v", d, 4), R("v", self.v_out), R("s", self.srdOp, 4), R("s", self.s_t1), p * 64)))
         if c.stats:
             for i in range(4):
                 g.append("v_lshlrev_b32 %s, 16, %s" % (R("v", xr[2 * i]), R("v", d + i)))
@@ -518,10 +533,11 @@ class Gen:
         self.e("s_waitcnt vmcnt(@VM%d@)" % slot)
 
     # -----------------------------------------------------------------------------------------------------------------
-    def unit_body(self, ap):
-        """one unit accumulating into set ap, with the epilogue of set ap ^ 1 (the previous unit) between its MFMAs"""
+    def unit_body(self, ub):
+        """unit `ub` of the loop body accumulating into set ub & 1, with the epilogue of the other set (the previous unit) between its MFMAs"""
+        ap = ub & 1
         c, e = self.c, self.e
-        nsub = 2 * c.NCH
+        nsub = self.UB * c.NCH
         # distribute the previous unit's epilogue over the substeps: flat stream of entries, blocks stay whole
         epi = self.epi_groups(ap ^ 1) if not (c.probe & 1) else []
         flat = []   # list of groups (each a list of instructions kept together)
@@ -540,13 +556,14 @@ class Gen:
             self.interleave(self.mfmas(0, ap, zero_c=(ch == 0)), self.merge(per[2 * ch], groups))
             # ---- the stage barrier: the next stage's weights have landed for every wave (and, at the last stage, plane 0)
             self.comment("acc set %d stage %d substep 1" % (ap, ch))
-            g = (ap * c.NCH + ch)
-            need = [("B", (g + 1) % (2 * c.NCH))]
+            g = (ub * c.NCH + ch)
+            need = [("B", (g + 1) % (self.UB * c.NCH))]
             nplane = (ch + 1) % c.NCH
-            need.append(("A", nplane, (g + 1) % (2 * c.NCH) // c.NCH))
+            need.append(("A", nplane, (g + 1) % (self.UB * c.NCH) // c.NCH))
             self.wait_vm(need)
             e("s_waitcnt lgkmcnt(0)")
-            e("s_barrier")
+            if not (c.probe & 8):
+                e("s_barrier")
             # ring: next stage's offset; this stage's slot is refilled below
             e("s_add_u32 %s, %s, 32768" % (R("s", self.s_bnext), R("s", self.s_bcur)))
             e("s_cmp_eq_u32 %s, %d" % (R("s", self.s_bnext), c.NB * 32768))
@@ -555,14 +572,16 @@ class Gen:
             e("s_add_u32 %s, %s, %s" % (R("s", self.s_fillw), R("s", self.s_ldsBw), R("s", self.s_bcur)))
             # weight stage + NB: chunk (ch + NB) % NCH of this unit or the next
             cf = (ch + c.NB) % c.NCH
-            src = self.s_bsrc_cur if ch + c.NB < c.NCH else self.s_bsrc_nxt
+            src = self.s_bsrc[(ch + c.NB) // c.NCH]
             e("s_add_u32 %s, %s, %d" % (R("s", self.s_stg), R("s", src), cf * 128))
             groups = [[r] for r in self.frag_reads(0, nplane, 0)]
             dma = []
-            gt = (g + c.NB) % (2 * c.NCH)
+            gt = (g + c.NB) % (self.UB * c.NCH)
             for i in range(8):
                 ins = self.b_piece_insts(i, self.s_fillw, self.s_stg)
                 dma.append(ins[:2] + [("vm", ("B", gt), ins[2])])
+            if c.probe & 4:
+                dma = [[("vm", ("B", gt), "s_nop 0")] for i in range(8)]
             mf = self.mfmas(1, ap, zero_c=False)
             # A refill of plane ch with the NEXT pixel tile — only during the last column tile of this pixel tile: two copies of
             # the substep, selected by a scalar branch (same MFMAs / reads / weight pieces in both)
@@ -572,7 +591,7 @@ class Gen:
             adma = []
             for k in range(len(a_slots(c))):
                 ins = self.a_slot_insts(k, ch)
-                adma.append(ins[:2] + [("vm", ("A", ch, 1 - ap), ins[2], True)])
+                adma.append(ins[:2] + [("vm", ("A", ch, (ub + 1) % self.UB), ins[2], True)])
             saved = list(self.tr.events)
             allg = self.merge(self.merge(per[2 * ch + 1], groups), self.merge(dma, adma))
             self.interleave(mf, allg)
@@ -649,9 +668,9 @@ class Gen:
         exits = [self.newlabel("exit0"), self.newlabel("exit1")]
         done = self.newlabel("done")
         self.label(top)
-        for ap in range(2):
-            self.unit_body(ap)
-            self.unit_switch(ap, exits[ap])
+        for ub in range(self.UB):
+            self.unit_body(ub)
+            self.unit_switch(ub & 1, exits[ub & 1])
         e("s_branch %s" % top)
         # ---- the last unit's epilogue, not interleaved
         for ap in range(2):
@@ -725,6 +744,8 @@ class Gen:
 VARIANTS = {
     "pw_k256_n1024_s1": PwCfg("pw_k256_n1024_s1", K=256, N=1024, stats=1),
     "pw_k256_n1024_s0": PwCfg("pw_k256_n1024_s0", K=256, N=1024, stats=0),
+    # (K = 128 -> 512, layer 2's conv3, is generated correctly too — tests/test_dconv_emu.py — and measured no faster than the
+    # 2-workgroups-per-CU kernel, 80 vs 81 us: store-bound, and one wave per SIMD keeps too few stores in flight; not shipped)
 }
 
 

@@ -11,7 +11,8 @@ i=0
 for sets in "$@"; do
   args=""; for kv in $sets; do args="$args --set $kv"; done
   sfx="_t$i"
-  python3 sota_imagenet_amd/csrc/asm/dconv_gen.py --out $out $args --suffix $sfx $base > /dev/null
+  gen=dconv_gen.py; case $base in pw_*) gen=pw_gen.py;; esac
+  python3 sota_imagenet_amd/csrc/asm/$gen --out $out $args --suffix $sfx $base > /dev/null
   $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $out/$base$sfx.s -o $out/$base$sfx.o
   $LLVM/ld.lld -shared $out/$base$sfx.o -o $out/$base$sfx.hsaco
   echo "== $base [$sets]"

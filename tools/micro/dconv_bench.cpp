@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
   }
   fclose(f);
   const int POOL = 12;
-  const size_t in_elems = (size_t)N * H * W * Cin, wt_elems = (size_t)NCOLS * 9 * Cin, out_elems = (size_t)N * H * W * NCOLS;
+  const size_t in_elems = (size_t)N * H * W * Cin, wt_elems = (size_t)NCOLS * 9 * Cin + 4096, out_elems = (size_t)N * H * W * NCOLS;
   std::vector<unsigned short> h(std::max(in_elems, wt_elems));
   unsigned short* d_in[POOL];
   srand(1);
@@ -83,16 +83,41 @@ int main(int argc, char** argv) {
   memcpy(k.table, tbl, sizeof(k.table));
   for (int t = 0; t < 9; ++t) k.wtap_off[t] = (unsigned)(t * Cin * 2);
   k.nchunks = (unsigned)nchunks;
-  size_t ksize = sizeof(k);
+  // pointwise kernels (asm/pw_gen.py): kernel name "pw_*", IPT = rows per unit; H*W*N = pixels
+  const bool pw = strncmp(kname, "pw_", 3) == 0;
+  struct __attribute__((packed)) PwArgs {
+    const void* in;
+    const void* wt;
+    void* out;
+    float* stat;
+    const void* rsvd[6];
+    unsigned units, upw, mtiles, pad0;
+    unsigned pad[8];
+    unsigned table[128];
+  } pk;
+  unsigned pw_grid = 0;
+  if (pw) {
+    memset(&pk, 0, sizeof(pk));
+    pk.wt = d_wt; pk.out = d_out; pk.stat = d_stat;
+    const long M = (long)N * H * W;
+    pk.mtiles = (unsigned)(M / IPT);
+    pk.units = pk.mtiles * (unsigned)(NCOLS / 256);
+    pk.upw = (pk.units + 255) / 256;
+    pw_grid = (pk.units + pk.upw - 1) / pk.upw;
+    memcpy(pk.table, tbl, sizeof(pk.table));
+  }
+  size_t ksize = pw ? sizeof(pk) : sizeof(k);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   std::vector<float> ts;
   for (int it = 0; it < iters + 5; ++it) {
     k.in = d_in[it % POOL];
-    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
+    pk.in = d_in[it % POOL];
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, pw ? (void*)&pk : (void*)&k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
     CK(hipEventRecord(e0, 0));
-    CK(hipModuleLaunchKernel(fn, (unsigned)(N / IPT), (unsigned)(NCOLS / 256), 1, 256, 1, 1, 0, 0, nullptr, extra));
+    if (pw) CK(hipModuleLaunchKernel(fn, pw_grid, 1, 1, 256, 1, 1, 0, 0, nullptr, extra));
+    else CK(hipModuleLaunchKernel(fn, (unsigned)(N / IPT), (unsigned)(NCOLS / 256), 1, 256, 1, 1, 0, 0, nullptr, extra));
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -100,7 +125,7 @@ int main(int argc, char** argv) {
     if (it >= 5) ts.push_back(ms * 1000.f);
   }
   std::sort(ts.begin(), ts.end());
-  const double fl = 2.0 * N * H * W * (double)NCOLS * 64.0 * nchunks * 9;
+  const double fl = 2.0 * N * H * W * (double)NCOLS * 64.0 * nchunks * (strncmp(kname, "pw_", 3) == 0 ? 1 : 9);
   printf("%-28s nchunks %d: median %7.1f us  min %7.1f us  %7.1f TF/s (median)\n", kname, nchunks, ts[ts.size() / 2], ts[0], fl / ts[ts.size() / 2] * 1e-6);
   return 0;
 }

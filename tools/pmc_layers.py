@@ -7,7 +7,7 @@ def load(c):
     f = glob.glob(f"{root}/pmc_{c}/*/*_counter_collection.csv")[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    return [r for r in rows if any(k in r["Kernel_Name"] for k in ("igemm_kernel", "igemm8_kernel", "wgrad_kernel", "stem_direct_kernel"))]
+    return [r for r in rows if any(k in r["Kernel_Name"] for k in ("igemm_kernel", "igemm8_kernel", "wgrad_kernel", "stem_direct_kernel", "dconv_", "pw_k"))]
 fe, wr = load("FETCH_SIZE"), load("WRITE_SIZE")
 seq = []
 def el(h, c): return N * h * h * c

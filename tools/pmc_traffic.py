@@ -19,6 +19,9 @@ import sys
 
 
 def short(n):
+    m0 = re.match(r"(dconv_l\d|pw_k\d+_n\d+)", n)  # generated assembly kernels (asm/dconv_gen.py, asm/pw_gen.py): one symbol per layer shape
+    if m0:
+        return m0.group(1)
     m = re.search(r"(igemm8_kernel|igemm_kernel|wgrad_kernel|bn_reduce_kernel|bn_apply_kernel|bn_bwd_apply_kernel|bn_finalize_kernel|"
                   r"splitk_reduce_kernel|sgd_kernel|fc_kernel|dbias_kernel|ce_row_kernel|bn_relu_maxpool\d?_kernel|maxpool_\w+_kernel|gap_\w+_kernel|stem_ingest_kernel|"
                   r"stem_direct_kernel|stem_bwd_reduce_kernel|stem_bwd_apply_kernel|weight_prep_batch_kernel|weight_prep_kernel)", n)
