@@ -1,0 +1,105 @@
+"""CPU tests of the generated gfx950 assembly kernels (sota_imagenet_amd/csrc/asm/dconv_gen.py, pw_gen.py): the text the
+generators print is executed by the functional emulator tools/gcn_emu.py — one workgroup at a time, exact small-integer
+data — and compared with a numpy convolution (the same quantity oracle/ops_ref.conv2d_fwd restates; integer data makes
+every summation order exact).  The emulator also enforces the LDS-DMA protocol the kernels rely on (counted vmcnt before
+the issuing wave reads, + a barrier before any other wave reads, no rewrite of bytes another wave read in the same barrier
+epoch), so a wrong wait count fails here and not as a rare wrong tile on the GPU.  No GPU needed."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import dconv_emu_check as D  # noqa: E402
+import gcn_emu  # noqa: E402
+import pw_emu_check as P  # noqa: E402
+
+CLANG = "/opt/rocm/lib/llvm/bin/clang"
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("dconv_l3_s1", dict(Cin=128, tiles=(0, 1))),                                      # forward + BN statistics, 2 chunks
+    ("dconv_l3_s2", dict(Cin=64, NCOLS=512, ntile=1, tiles=(1,), dgrad_taps=True)),    # dgrad taps, BN-backward sums, 2nd column tile
+    ("dconv_l3_s0", dict(Cin=192)),                                                    # odd chunk count (loop exit in the middle)
+    ("dconv_l4_s1", dict(Cin=64, ntile=1)),                                            # 2 images per tile, 3-stage weight ring
+    ("dconv_l4_s2", dict(Cin=128, tiles=(1,))),
+])
+def test_direct_conv_kernels_are_exact_in_the_emulator(name, kw):
+    r = D.run(name, **kw)
+    assert r["max_err"] == 0.0 and r["untouched_ok"], r
+    if "stat_err" in r:
+        assert r["stat_err"] < 1e-6, r
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("pw_k256_n1024_s1", dict(mtiles=2, grid=2, N=512)),   # pixel-tile change inside a workgroup's range, statistics rows
+    ("pw_k256_n1024_s1", dict(mtiles=3, grid=2)),          # 6 units per workgroup: both accumulator sets, refill path and not
+    ("pw_k256_n1024_s0", dict(mtiles=2, grid=3, N=256)),   # one column tile: every unit refills
+    ("pw_k256_n1024_s1", dict(mtiles=2, grid=2, K=128, N=512)),  # 2 planes: a weight stage two units ahead
+])
+def test_pointwise_kernels_are_exact_in_the_emulator(name, kw):
+    r = P.run(name, **kw)
+    assert r["max_err"] == 0.0, r
+    if "stat_err" in r:
+        assert r["stat_err"] == 0.0, r
+
+
+def _tiny(body):
+    return "\n".join(["t:"] + ["\t" + l for l in body] + ["\ts_endpgm"])
+
+
+def test_the_emulator_rejects_an_lds_read_before_the_dma_wait():
+    import numpy as np
+
+    mem = gcn_emu.Memory()
+    src = mem.alloc(np.arange(1024, dtype=np.uint8))
+    ka = mem.alloc(np.frombuffer(gcn_emu.pack_kernarg([("q", src)]), dtype=np.uint8))
+    head = ["s_load_dwordx2 s[4:5], s[0:1], 0x0", "s_waitcnt lgkmcnt(0)", "s_and_b32 s5, s5, 0xffff", "s_mov_b32 s6, 1024",
+            "s_mov_b32 s7, 0x00020000", "v_lshlrev_b32 v1, 4, v0", "s_mov_b32 m0, 0", "s_nop 0",
+            "buffer_load_dwordx4 v1, s[4:7], 0 offen lds"]
+    bad = _tiny(head + ["ds_read_b128 v[4:7], v1", "s_waitcnt lgkmcnt(0)"])
+    with pytest.raises(gcn_emu.EmuError, match="not been waited for"):
+        gcn_emu.Emulator(bad, mem, lds_bytes=4096).run_workgroup(1, ka)
+    good = _tiny(head + ["s_waitcnt vmcnt(0)", "ds_read_b128 v[4:7], v1", "s_waitcnt lgkmcnt(0)"])
+    gcn_emu.Emulator(good, mem, lds_bytes=4096).run_workgroup(1, ka)
+
+
+def test_the_emulator_rejects_a_read_of_another_waves_dma_without_a_barrier():
+    import numpy as np
+
+    mem = gcn_emu.Memory()
+    src = mem.alloc(np.arange(2048, dtype=np.uint8))
+    ka = mem.alloc(np.frombuffer(gcn_emu.pack_kernarg([("q", src)]), dtype=np.uint8))
+    head = ["s_load_dwordx2 s[4:5], s[0:1], 0x0", "s_waitcnt lgkmcnt(0)", "s_and_b32 s5, s5, 0xffff", "s_mov_b32 s6, 2048",
+            "s_mov_b32 s7, 0x00020000", "v_lshlrev_b32 v1, 4, v0",                      # tid*16: wave w fills bytes 1024w ..
+            "v_and_b32 v2, 63, v0", "v_lshlrev_b32 v2, 4, v2",
+            "v_lshrrev_b32 v3, 6, v0", "s_nop 0", "v_readfirstlane_b32 s8, v3", "s_nop 3", "s_lshl_b32 s8, s8, 10", "s_mov_b32 m0, s8", "s_nop 0",
+            "buffer_load_dwordx4 v1, s[4:7], 0 offen lds", "s_waitcnt vmcnt(0)",
+            "v_mov_b32 v4, v2"]                                                          # wave 0's bytes, read by both waves
+    bad = _tiny(head + ["ds_read_b128 v[8:11], v4", "s_waitcnt lgkmcnt(0)"])
+    with pytest.raises(gcn_emu.EmuError, match="not yet published by a barrier"):
+        gcn_emu.Emulator(bad, mem, lds_bytes=4096).run_workgroup(2, ka)
+    good = _tiny(head + ["s_barrier", "ds_read_b128 v[8:11], v4", "s_waitcnt lgkmcnt(0)"])
+    gcn_emu.Emulator(good, mem, lds_bytes=4096).run_workgroup(2, ka)
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm clang not installed")
+def test_every_shipped_variant_assembles_for_gfx950_within_the_register_and_lds_budget(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "sota_imagenet_amd", "csrc", "asm"))
+    import dconv_gen
+    import pw_gen
+
+    for mod in (dconv_gen, pw_gen):
+        for name in mod.VARIANTS:
+            c, g, text = mod.generate(name)
+            assert g.accum_offset + g.nagpr <= 512
+            lds = g.lds_bytes if hasattr(g, "lds_bytes") else c.LDS
+            assert lds <= 160 * 1024
+            f = tmp_path / (name + ".s")
+            f.write_text(text)
+            subprocess.run([CLANG, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(f), "-o", str(tmp_path / (name + ".o"))],
+                           check=True, capture_output=True, timeout=120)

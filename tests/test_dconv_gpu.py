@@ -1,0 +1,63 @@
+"""GPU parity of the generated assembly kernels (csrc/asm/dconv_gen.py, pw_gen.py) through the per-op C-ABI, at the batch the
+BASELINE configs name (256 images): exact on small-integer data against torch's fp32 convolution of the same operands (any
+summation order is exact there), forward with its BN-statistics rows and the data gradient; and on random data within one
+bf16 rounding of the fp32 convolution.  The BN-backward-sums epilogue of the dgrad variants is exercised through the
+executor (tests/test_resnet_gpu.py: test_teacher_forced_layers, test_baseline_batch_rule_selected_variants)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(256, 14, 256, 256, 3), (256, 7, 512, 512, 3), (256, 14, 256, 1024, 1)]
+
+
+def _ref(x, w, K):
+    return torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=K // 2).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout,K", SHAPES)
+def test_forward_statistics_and_dgrad_are_exact_on_integer_data(dev, N, H, Cin, Cout, K):
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(0)
+    x = torch.randint(-2, 3, (N, H, H, Cin), device=dev).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (Cout, K, K, Cin), device=dev).to(torch.bfloat16)
+    y, part = ops.conv2d_fwd(x, w, 1, K // 2, stats=True)
+    ref = _ref(x, w, K).to(torch.bfloat16)
+    assert torch.equal(y, ref)
+    assert part is not None and part.shape[1:] == (2, Cout)
+    s1, s2 = ref.float().sum(dim=(0, 1, 2)).double(), (ref.float() ** 2).sum(dim=(0, 1, 2)).double()
+    assert (part[:, 0].double().sum(0) - s1).abs().max() <= 1e-6 * s1.abs().max()
+    assert (part[:, 1].double().sum(0) - s2).abs().max() <= 1e-6 * s2.abs().max()
+    y0 = ops.conv2d_fwd(x, w, 1, K // 2)  # the variant without the statistics epilogue
+    assert torch.equal(y0, ref)
+    dy = torch.randint(-2, 3, (N, H, H, Cout), device=dev).to(torch.bfloat16)
+    dx = ops.conv2d_dgrad(dy, w, (N, H, H, Cin), 1, K // 2)
+    refd = torch.nn.functional.conv_transpose2d(dy.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=K // 2).permute(0, 2, 3, 1)
+    assert torch.equal(dx, refd.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout,K", SHAPES)
+def test_forward_on_random_data_is_within_one_bf16_rounding(dev, N, H, Cin, Cout, K):
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(1)
+    x = torch.randn(N, H, H, Cin, device=dev).to(torch.bfloat16)
+    w = (torch.randn(Cout, K, K, Cin, device=dev) * 0.05).to(torch.bfloat16)
+    y = ops.conv2d_fwd(x, w, 1, K // 2).float()
+    ref = _ref(x, w, K)
+    # tolerance: bf16 has 8 significant bits -> 2^-8 relative per element, plus fp32 summation-order noise on the largest values
+    tol = 2.0 ** -8 * ref.abs() + 2.0 ** -9 * ref.abs().max() * 1e-2
+    assert ((y - ref).abs() <= tol + 1e-6).all()
+
+
+def test_other_batch_sizes_take_the_same_kernels(dev):
+    """8 images: 8 tiles (layer 3) / 4 tiles (layer 4, two images each) / 14 pixel tiles of 112 (pointwise)"""
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(2)
+    for (_, H, Cin, Cout, K) in SHAPES:
+        x = torch.randint(-2, 3, (8, H, H, Cin), device=dev).to(torch.bfloat16)
+        w = torch.randint(-2, 3, (Cout, K, K, Cin), device=dev).to(torch.bfloat16)
+        y, part = ops.conv2d_fwd(x, w, 1, K // 2, stats=True)
+        assert torch.equal(y, _ref(x, w, K).to(torch.bfloat16))

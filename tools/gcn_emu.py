@@ -959,7 +959,8 @@ class Emulator:
             if dst0 + 64 * nbytes > self.lds.size:
                 self.err(ins, "LDS-DMA beyond the LDS allocation")
             slots = np.arange(dst0 // 16, dst0 // 16 + 64 * nbytes // 16)
-            dup = self.check and (self.slot_state[slots] == 1).all() and (self.slot_owner[slots] == wv.wid).all()
+            in_sink = any(lo <= dst0 and dst0 + 64 * nbytes <= hi for lo, hi in self.sinks)
+            dup = self.check and not in_sink and (self.slot_state[slots] == 1).all() and (self.slot_owner[slots] == wv.wid).all()
             old = self.lds[dst0: dst0 + 64 * nbytes].copy() if dup else None
             if not dup:
                 self.lds_write_check(wv, slots, ins)
