@@ -48,15 +48,27 @@ class Cfg:
     stats: int        # 0 none, 1 BN statistics of the output, 2 BN-backward sums
     skew: int = 0     # s_nop-based wave stagger after each barrier (experiment knob)
     probe: int = 0    # timing probes (WRONG results): 1 no LDS-DMA in the main loop, 2 no fragment reads, 4 no barriers
-    WM: int = 2
-    WN: int = 2
+    WM: int = 2       # waves along the pixel dimension
+    WN: int = 2       # waves along the output channels (WM * WN = 4: one wave per SIMD)
     NT: int = 8       # 16-column tiles per wave
-    BN: int = 256
     NB: int = 2       # stages of the weight ring (3 where LDS allows: the pieces of stage s + 3 then have two stages to land)
+    ROWS_T: int = 0   # 0: a tile is IPT whole images; else a tile is ROWS_T consecutive output rows of ONE image (H % ROWS_T == 0)
+
+    @property
+    def BN(self):     # output columns per workgroup
+        return self.WN * self.NT * 16
+
+    @property
+    def TPI(self):    # tiles per image
+        return self.H // self.ROWS_T if self.ROWS_T else 1
 
     @property
     def ABASE(self):
-        return self.NB * self.BSTAGE
+        return 0
+
+    @property
+    def BBASE(self):
+        return 2 * self.ABUF
 
     @property
     def SR(self):     # LDS rows per image slot (the halo row between two images is shared)
@@ -64,6 +76,8 @@ class Cfg:
 
     @property
     def RO(self):     # output rows enumerated per tile (IPT > 1: includes one garbage row per image)
+        if self.ROWS_T:
+            return self.ROWS_T
         return self.IPT * self.SR if self.IPT > 1 else self.H
 
     @property
@@ -81,77 +95,75 @@ class Cfg:
         return self.RO + 2
 
     @property
-    def ABUF(self):   # bytes of one A buffer: the tile + the 2 positions the last garbage columns read past it, padded to a block
-        pos = self.LROWS * self.P + 8
-        return pos * 128
+    def ABUF(self):   # bytes of one A buffer (the 2 positions the last garbage columns read past it fall into what follows it in LDS)
+        return self.LROWS * self.P * 128
 
     @property
-    def ASTRIDE(self):  # distance of the two A buffers: each is followed by its 1 KiB sink
-        return self.ABUF + 1024
+    def ASTRIDE(self):
+        return self.ABUF
 
     @property
     def BSTAGE(self):
         return self.BN * 128
 
     @property
+    def NPB(self):    # weight pieces per wave and stage
+        return self.BSTAGE // 1024 // 4
+
+    @property
     def w_row(self):  # bytes of one weight row [taps][Cin]
         return 9 * self.Cin * 2
 
+    @property
+    def tile_rows(self):
+        return self.ROWS_T if self.ROWS_T else self.IPT * self.H
 
-# LDS: [weight ring NB x 32 KiB][A buffer 0][sink][A buffer 1][sink]; the statistics scratch reuses the ring
+
+# LDS: [A buffer 0][A buffer 1][weight ring NB stages]; the statistics scratch reuses the ring
 
 
-def valid_rows(c):
-    """LDS A rows that hold image data: list of (g, image, y)"""
-    out = []
+def a_rows(c, par):
+    """LDS rows of the A tile of a tile of parity `par`: list of (g, source row constant in bytes | None = stays zero)"""
+    rows = []
     for g in range(c.LROWS):
-        if c.IPT == 1:
-            if 1 <= g <= c.H:
-                out.append((g, 0, g - 1))
+        if c.ROWS_T:
+            y = par * c.ROWS_T - 1 + g
+            rows.append((g, y * c.W * c.Cin * 2 if 0 <= y < c.H else None))
+        elif c.IPT == 1:
+            rows.append((g, (g - 1) * c.W * c.Cin * 2 if 1 <= g <= c.H else None))
         else:
             i, y = divmod(g - 1, c.SR) if g >= 1 else (0, -1)
-            if g >= 1 and y < c.H and i < c.IPT:
-                out.append((g, i, y))
-    return out
+            ok = g >= 1 and y < c.H and i < c.IPT
+            rows.append((g, ((i * c.H + y) * c.W) * c.Cin * 2 if ok else None))
+    return rows
 
 
-def a_pieces(c):
-    """all A pieces of a chunk: (lds offset inside the buffer, source row constant in bytes, variant = block index in row)"""
-    bpr = c.P // 8
-    pcs = []
-    for g, i, y in valid_rows(c):
-        for xb in range(bpr):
-            # blocks entirely in the right padding of the row need no data (they stay zero from the initial fill)
-            if xb * 8 > c.W:
-                continue
-            pcs.append(((g * bpr + xb) * 1024, ((i * c.H + y) * c.W) * c.Cin * 2, xb))
-    return pcs
+def live_rows(c):
+    """rows that hold image data in SOME tile parity"""
+    return sorted({g for par in range(c.TPI) for g, src in a_rows(c, par) if src is not None})
 
 
-def sink_off(c):
-    """offset, relative to an A buffer's base, of the 1 KiB LDS sink that follows each A buffer (padding pieces land there)"""
-    return c.ABUF
-
-
-def a_schedule(c):
-    """pieces per wave, padded by repetition so that every wave issues the same number; piece i has ONE variant for all waves"""
-    pcs = a_pieces(c)
-    byvar = {}
-    for p in pcs:
-        byvar.setdefault(p[2], []).append(p)
-    slots = []  # list of (variant, [piece for wave 0..3])
-    for var, lst in sorted(byvar.items()):
-        for k in range(0, len(lst), 4):
-            grp = lst[k:k + 4]
-            while len(grp) < 4:
-                grp.append((sink_off(c), grp[-1][1], var))  # padding piece: real source rows, lands in the sink (never read)
-            slots.append((var, grp))
+def a_slots(c):
+    """the A pieces of a chunk as slots: (variant = 8-position block index in the row, [LDS row for wave 0..3 | None])"""
+    live = live_rows(c)
+    slots = []
+    for xb in range(c.P // 8):
+        if xb * 8 > c.W:   # blocks entirely in the right padding of the row stay zero
+            continue
+        for k in range(0, len(live), 4):
+            grp = live[k:k + 4]
+            slots.append((xb, grp + [None] * (4 - len(grp))))
     return slots
+
+
+def written_blocks(c):
+    bpr = c.P // 8
+    return {(g * bpr + xb) * 1024 for xb, grp in a_slots(c) for g in grp if g is not None}
 
 
 def b_piece_const(c, w, i):
     """source constant (bytes) of B piece i of wave w: the first channel of its 8 rows"""
-    R0 = 64 * w + 8 * i
+    R0 = (c.BN // 4) * w + 8 * i
     wn, rem = divmod(R0, c.NT * 16)
     n = rem // 16
     p, odd = n >> 1, n & 1
@@ -160,14 +172,29 @@ def b_piece_const(c, w, i):
 
 
 def tables(c):
-    """per-wave table (uint32 words): [A lds offsets][A source consts][B source consts], padded to 32 words"""
-    sl = a_schedule(c)
-    rows = []
-    for w in range(4):
-        words = [g[w][0] for _, g in sl] + [g[w][1] for _, g in sl] + [b_piece_const(c, w, i) for i in range(8)]
-        assert len(words) <= 24
-        rows.append(words + [0] * (32 - len(words)))
-    return rows
+    """[tile parity 0 / 1][wave] -> 64 words: [A LDS offsets][A source constants][B source constants].  A slot whose row holds no
+    data for this wave / parity repeats one of the wave's own pieces of the same variant (same bytes to the same place)."""
+    sl = a_slots(c)
+    bpr = c.P // 8
+    out = []
+    for par in range(2):
+        src = dict(a_rows(c, par % c.TPI))
+        rows = []
+        for w in range(4):
+            lds, srcs = [], []
+            for xb, grp in sl:
+                g = grp[w]
+                if g is None or src[g] is None:
+                    cands = [gg[w] for x2, gg in sl if x2 == xb and gg[w] is not None and src[gg[w]] is not None]
+                    assert cands, "a wave without any piece of variant %d" % xb
+                    g = cands[0]
+                lds.append((g * bpr + xb) * 1024)
+                srcs.append(src[g])
+            words = lds + srcs + [b_piece_const(c, w, i) for i in range(c.NPB)]
+            assert len(words) <= 64
+            rows.append(words + [0] * (64 - len(words)))
+        out.append(rows)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -212,41 +239,38 @@ class Gen:
     def gen(self):
         c = self.c
         S, V, e = self.S, self.V, self.e
-        sl = a_schedule(c)
+        sl = a_slots(c)
         NPA = len(sl)
-        assert NPA <= 8, "A pieces per wave per chunk must fit the 8 kk=0 substeps that issue them (got %d)" % NPA
         self.NPA = NPA
+        self.APS = (NPA + 7) // 8                    # A pieces issued per first substep of a tap
+        self.ATAPS = (NPA + self.APS - 1) // self.APS  # taps whose first substep carries A pieces (<= 8)
+        assert self.ATAPS <= 8 and c.WM * c.WN == 4 and c.TPI in (1, 2)
 
         # ---- registers ----------------------------------------------------------------------------------------------
-        # s[0:1] kernarg, s2 = workgroup id x (tile), s3 = workgroup id y (256-column tile)
+        # s[0:1] kernarg, s2 = workgroup id x (tile), s3 = workgroup id y (column tile)
         self.s_tile, self.s_nt = 2, 3
         self.srdA = S.get(4, 4)
         self.srdB = S.get(4, 4)
         self.srdO = S.get(4, 4)
-        self.srdX = S.get(4, 4)   # statistics rows / bn_y
-        self.srdM = S.get(4, 4)   # bn_bits
-        self.srdY = S.get(4, 4)   # bn_y
-        self.srdMu = S.get(4, 4)  # bn_mean
-        self.srdIs = S.get(4, 4)  # bn_invstd
+        self.srdX = S.get(4, 4)   # statistics rows
+        # the piece table of this wave: in SGPRs (scalar loads, as many as 24 words) or, when larger, in a VGPR read with v_readlane
+        self.tab_sgpr = (2 * NPA + c.NPB <= 24) and c.TPI == 1
+        if not self.tab_sgpr:
+            self.srdK = S.get(4, 4)   # the piece tables in the kernarg segment
+        if c.stats == 2:
+            self.srdM = S.get(4, 4)   # bn_bits
+            self.srdY = S.get(4, 4)   # bn_y
+            self.srdMu = S.get(4, 4)  # bn_mean
+            self.srdIs = S.get(4, 4)  # bn_invstd
         self.s_wt = S.get(9, 4)
-        self.s_cnt = S.get()
-        self.s_cC = S.get()
-        self.s_cN = S.get()
-        self.s_t0 = S.get()
-        self.s_t1 = S.get()
-        self.s_w = S.get()
-        self.s_wm = S.get()
-        self.s_wn = S.get()
-        self.s_nch = S.get()
-        self.s_ldsBw = S.get()
-        self.s_stg = S.get()
-        self.s_tbl = S.get(24, 4)        # per-wave table: [NPA lds][NPA src][8 B consts]
-        self.s_tbl2 = self.s_tbl
+        (self.s_cnt, self.s_cC, self.s_cN, self.s_t0, self.s_t1, self.s_w, self.s_wm, self.s_wn, self.s_nch, self.s_ldsBw,
+         self.s_stg) = [S.get() for _ in range(11)]
+        if self.tab_sgpr:
+            self.s_tbl = S.get(24, 4)
+        else:
+            self.s_a, self.s_b, self.s_par = S.get(), S.get(), S.get()
         self.s_ka = S.get(16, 4)         # the 8 pointers
         self.s_kb = S.get(4, 4)
-        self.s_tA_lds = self.s_tbl
-        self.s_tA_src = self.s_tbl + NPA
-        self.s_tB = self.s_tbl + 2 * NPA
 
         self.v_tid = 0
         self.vA_rd = [[V.get() for kk in range(2)] for kx in range(3)]
@@ -255,13 +279,25 @@ class Gen:
         self.vA_dma = [V.get() for _ in range(nvar)]
         self.vB_dma = [V.get() for _ in range(2)]
         self.v_out = V.get()
-        self.v_t = [V.get() for _ in range(12)]
+        self.v_tab = V.get()             # this wave's piece table: word i in lane i (read with v_readlane)
+        self.v_kg = V.get()              # lane >> 4 (kept for the epilogue)
         self.F = []
         for s in range(2):
             fa = V.get(4 * c.MFR, 4)
             fb = V.get(4 * c.NT, 4)
             self.F.append((fa, fb))
-        self.nvgpr = V.n + (2 * (5 * c.MFR + 16) + 2 if c.stats == 2 else 0)   # + the BN-backward epilogue's load registers
+        # prologue temporaries live in fragment set 1, which is first written by the main loop (v_t[2] = the kept lane >> 4)
+        self.v_t = [self.F[1][0] + i for i in range(10)]
+        self.v_t[2] = self.v_kg
+        if c.stats == 2:
+            # BN-backward sums: y / mask of the same (pixel, 8 channels) vectors as the output in two register sets, mean / invstd of
+            # this lane's 8 channels per tile pair.  The sets of pairs 0 and 1 are loaded in the PROLOGUE (the main loop does not
+            # touch these registers), pairs 2 and 3 under the arithmetic of pairs 0 and 1.
+            self.ysets = [[V.get(4, 4) for m in range(c.MFR)] for _ in range(2)]
+            self.bsets = [[V.get() for m in range(c.MFR)] for _ in range(2)]
+            self.msets = [V.get(16, 4) for _ in range(2)]   # mean[8], invstd[8]
+            self.v_bits, self.v_chan = V.get(), V.get()
+        self.nvgpr = V.n
         self.accum_offset = (self.nvgpr + 7) // 8 * 8
         self.nagpr = c.MFR * c.NT * 4
         assert self.nagpr <= 256
@@ -273,15 +309,22 @@ class Gen:
 
     # -----------------------------------------------------------------------------------------------------------------
     # kernel arguments: 9 pointers (the 9th unused: reserved), 9 weight-tap byte offsets, the chunk count, padding to 128 bytes,
-    # then the per-wave piece tables (4 x 32 words)
+    # then the per-wave piece tables (2 tile parities x 4 waves x 64 words)
     KA = dict(in_=0, wt=8, out=16, stat=24, bn_y=32, bn_bits=40, bn_mean=48, bn_invstd=56, rsvd=64, wtap=72, nchunks=108,
-              table=128, size=640)
+              table=128, size=128 + 2 * 4 * 256)
 
     def never_written_blocks(self):
         """1 KiB blocks (relative to an A buffer's base) that no LDS-DMA piece ever writes: halo rows, right padding, the tail"""
         c = self.c
-        written = {p[0] for p in a_pieces(c)}
+        written = written_blocks(c)
         return [b * 1024 for b in range(c.ABUF // 1024) if b * 1024 not in written]
+
+    def dynamic_halo_blocks(self):
+        """blocks of rows that hold data in one tile parity and must be zero in the other (row tiles of an image)"""
+        c = self.c
+        bpr = c.P // 8
+        dyn = [g for g in live_rows(c) if any(dict(a_rows(c, par))[g] is None for par in range(c.TPI))]
+        return [(g * bpr + xb) * 1024 for g in dyn for xb in range(bpr) if (g * bpr + xb) * 1024 in written_blocks(c)]
 
     def prologue(self):
         c, e = self.c, self.e
@@ -299,15 +342,31 @@ class Gen:
         e("v_and_b32 %s, 15, v0" % R("v", r))
         e("v_bfe_u32 %s, v0, 4, 2" % R("v", kg))
         e("s_nop 3")
-        # this wave's table: kernarg + 128 + w*128  (the kernarg loads above do not touch s[0:1])
-        e("s_lshl_b32 %s, %s, 7" % (R("s", t0), R("s", self.s_w)))
-        e("s_add_u32 %s, s0, %s" % (R("s", kb), R("s", t0)))
-        e("s_addc_u32 %s, s1, 0" % R("s", kb + 1))
-        e("s_load_dwordx16 %s, %s, 0x80" % (R("s", self.s_tbl2, 16), R("s", kb, 2)))
-        e("s_load_dwordx8 %s, %s, 0xc0" % (R("s", self.s_tbl2 + 16, 8), R("s", kb, 2)))
-        e("s_lshr_b32 %s, %s, 1" % (R("s", self.s_wm), R("s", self.s_w)))
-        e("s_and_b32 %s, %s, 1" % (R("s", self.s_wn), R("s", self.s_w)))
-        e("s_lshl_b32 %s, %s, 13" % (R("s", self.s_ldsBw), R("s", self.s_w)), "this wave's 8 KiB of a weight stage")
+        if self.tab_sgpr:
+            # this wave's piece table: kernarg + 128 + w*256, 24 words by scalar loads (they do not wait for the loads above)
+            e("s_lshl_b32 %s, %s, 8" % (R("s", t0), R("s", self.s_w)))
+            e("s_add_u32 %s, s0, %s" % (R("s", kb), R("s", t0)))
+            e("s_addc_u32 %s, s1, 0" % R("s", kb + 1))
+            e("s_load_dwordx16 %s, %s, 0x80" % (R("s", self.s_tbl, 16), R("s", kb, 2)))
+            e("s_load_dwordx8 %s, %s, 0xc0" % (R("s", self.s_tbl + 16, 8), R("s", kb, 2)))
+        else:
+            # this wave's piece table: 64 words at kernarg + 128 + (parity*4 + w)*256, word i into lane i (one vector load; the
+            # kernarg pointer is in s[0:1] from the start, so this does not wait for the scalar loads above)
+            e("s_add_u32 %s, s0, 128" % R("s", self.srdK))
+            e("s_addc_u32 %s, s1, 0" % R("s", self.srdK + 1))
+            e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdK + 1), R("s", self.srdK + 1)))
+            e("s_mov_b32 %s, 2048" % R("s", self.srdK + 2))
+            e("s_mov_b32 %s, 0x00020000" % R("s", self.srdK + 3))
+            e("s_and_b32 %s, %s, %d" % (R("s", self.s_par), R("s", self.s_tile), c.TPI - 1))
+            e("s_lshl_b32 %s, %s, 2" % (R("s", t0), R("s", self.s_par)))
+            e("s_add_u32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", self.s_w)))
+            e("s_lshl_b32 %s, %s, 8" % (R("s", t0), R("s", t0)))
+            e("v_lshl_add_u32 %s, %s, 2, %s" % (R("v", v[3]), R("v", lane), R("s", t0)))
+            e("buffer_load_dword %s, %s, %s, 0 offen" % (R("v", self.v_tab), R("v", v[3]), R("s", self.srdK, 4)))
+        lgn = c.WN.bit_length() - 1
+        e("s_lshr_b32 %s, %s, %d" % (R("s", self.s_wm), R("s", self.s_w), lgn))
+        e("s_and_b32 %s, %s, %d" % (R("s", self.s_wn), R("s", self.s_w), c.WN - 1))
+        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_ldsBw), R("s", self.s_w), c.BSTAGE // 4), "this wave's quarter of a weight stage")
         # ---- DMA lane parts first: the first loads wait for nothing else
         # A: x'' = xb*8 + (lane >> 3); j = ((lane & 7) - ((lane >> 3) & 6)) & 7
         l3, l7, j, x, off = v[3], v[4], v[5], v[6], v[7]
@@ -318,6 +377,8 @@ class Gen:
         e("v_and_b32 %s, 7, %s" % (R("v", j), R("v", j)))
         e("v_lshlrev_b32 %s, 4, %s" % (R("v", j), R("v", j)))
         for xb in range(c.P // 8):
+            if xb * 8 > c.W:
+                continue
             e("v_add_u32 %s, %d, %s" % (R("v", x), xb * 8 - 1, R("v", l3)), "input x of this lane's position")
             e("v_mov_b32 %s, %d" % (R("v", off), c.Cin * 2))
             e("v_mad_u32_u24 %s, %s, %s, %s" % (R("v", off), R("v", x), R("v", off), R("v", j)))
@@ -342,17 +403,21 @@ class Gen:
         # ---- descriptors ------------------------------------------------------------------------------------------
         e("s_waitcnt lgkmcnt(0)")
         self.comment("descriptors: A = this tile's images, B = this column tile's weight rows, O = this tile's output pixels")
-        tile_in = c.IPT * c.H * c.W * c.Cin * 2
-        tile_out = c.IPT * c.H * c.W * c.NCOLS * 2
+        tile_in = (1 if c.ROWS_T else c.IPT) * c.H * c.W * c.Cin * 2   # the window the A pieces address: the tile's image(s)
+        tile_out = c.tile_rows * c.W * c.NCOLS * 2
         # A
-        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_tile), tile_in))
-        e("s_mul_hi_u32 %s, %s, %d" % (R("s", t1), R("s", self.s_tile), tile_in))
+        s_img = self.s_tile
+        if c.TPI > 1:
+            e("s_lshr_b32 %s, %s, %d" % (R("s", self.s_stg), R("s", self.s_tile), c.TPI.bit_length() - 1))
+            s_img = self.s_stg
+        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", s_img), tile_in))
+        e("s_mul_hi_u32 %s, %s, %d" % (R("s", t1), R("s", s_img), tile_in))
         e("s_add_u32 %s, %s, %s" % (R("s", self.srdA), R("s", ka + 0), R("s", t0)))
         e("s_addc_u32 %s, %s, %s" % (R("s", self.srdA + 1), R("s", ka + 1), R("s", t1)))
         e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdA + 1), R("s", self.srdA + 1)))
         e("s_mov_b32 %s, %d" % (R("s", self.srdA + 2), tile_in))
         e("s_mov_b32 %s, 0x00020000" % R("s", self.srdA + 3))
-        # B: rows nt*256 .. +256
+        # B: rows nt*BN .. + BN
         e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_nt), c.BN * c.w_row))
         e("s_add_u32 %s, %s, %s" % (R("s", self.srdB), R("s", ka + 2), R("s", t0)))
         e("s_addc_u32 %s, %s, 0" % (R("s", self.srdB + 1), R("s", ka + 3)))
@@ -362,56 +427,100 @@ class Gen:
         e("s_mov_b32 %s, %s" % (R("s", self.s_nch), R("s", kb + 3)))
         e("s_mov_b32 %s, %s" % (R("s", self.s_wt + 8), R("s", kb + 2)))
         # the table (24 words) to its place: [NPA lds][NPA src][8 B consts]
-        # ---- first loads: weight stages 0 and 1, the A tile of chunk 0 (its pieces never overlap the zero fill below)
-        self.comment("first loads: weight stages 0 and 1, A tile of chunk 0")
-        e("s_mov_b32 %s, 0" % R("s", self.s_cC))
-        self.b_stage_issue_all(0, 0, self.s_cC)
-        for i in range(self.NPA):
-            self.a_piece(i, 0, soff_chunk=self.s_cC)
-        for st in range(1, c.NB):
-            self.b_stage_issue_all(st, st, self.s_cC)
+        def first_loads():
+            # ---- first loads: weight stages 0 .. NB-1, the A tile of chunk 0 (its pieces never overlap the static zero fill below)
+            self.comment("first loads: weight stages, A tile of chunk 0")
+            if not self.tab_sgpr:
+                e("s_waitcnt vmcnt(0)", "the piece table")
+            e("s_mov_b32 %s, 0" % R("s", self.s_cC))
+            self.b_stage_issue_all(0, 0, self.s_cC)
+            if self.dynamic_halo_blocks():
+                # rows that are data in one tile parity and zero halo in the other: zeroed by every tile BEFORE its pieces land
+                self.zero_blocks([c.ABASE + b * c.ASTRIDE + o for b in range(2) for o in self.dynamic_halo_blocks()])
+                e("s_waitcnt lgkmcnt(0)")
+                e("s_barrier")
+            for i in range(self.NPA):
+                for ins in self.a_piece_insts(i, 0, self.s_cC):
+                    e(ins)
+            for st in range(1, c.NB):
+                self.b_stage_issue_all(st, st, self.s_cC)
 
-        # ---- the rest of the set-up runs under the latency of those loads
-        # O: + tile*tile_out + nt*512 bytes
-        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_tile), tile_out))
-        e("s_mul_hi_u32 %s, %s, %d" % (R("s", t1), R("s", self.s_tile), tile_out))
-        e("s_lshl_b32 %s, %s, 9" % (R("s", self.s_stg), R("s", self.s_nt)))
-        e("s_add_u32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", self.s_stg)))
-        e("s_addc_u32 %s, %s, 0" % (R("s", t1), R("s", t1)))
-        e("s_add_u32 %s, %s, %s" % (R("s", self.srdO), R("s", ka + 4), R("s", t0)))
-        e("s_addc_u32 %s, %s, %s" % (R("s", self.srdO + 1), R("s", ka + 5), R("s", t1)))
-        e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdO + 1), R("s", self.srdO + 1)))
-        e("s_mov_b32 %s, %d" % (R("s", self.srdO + 2), tile_out))
-        e("s_mov_b32 %s, 0x00020000" % R("s", self.srdO + 3))
-        # (the O window starts at this tile's column offset: num_records covers exactly what may be stored)
-        e("s_sub_u32 %s, %s, %s" % (R("s", self.srdO + 2), R("s", self.srdO + 2), R("s", self.s_stg)))
-        e("s_mov_b32 %s, %s" % (R("s", self.srdX), R("s", ka + 6)), "statistics rows")
-        e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdX + 1), R("s", ka + 7)))
-        e("s_mov_b32 %s, 0x7fffffff" % R("s", self.srdX + 2))
-        e("s_mov_b32 %s, 0x00020000" % R("s", self.srdX + 3))
+
+        def descriptors_out():
+            # ---- the rest of the set-up runs under the latency of those loads
+            # O: + tile*tile_out + nt*512 bytes
+            e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_tile), tile_out))
+            e("s_mul_hi_u32 %s, %s, %d" % (R("s", t1), R("s", self.s_tile), tile_out))
+            e("s_mul_i32 %s, %s, %d" % (R("s", self.s_stg), R("s", self.s_nt), c.BN * 2))
+            e("s_add_u32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", self.s_stg)))
+            e("s_addc_u32 %s, %s, 0" % (R("s", t1), R("s", t1)))
+            e("s_add_u32 %s, %s, %s" % (R("s", self.srdO), R("s", ka + 4), R("s", t0)))
+            e("s_addc_u32 %s, %s, %s" % (R("s", self.srdO + 1), R("s", ka + 5), R("s", t1)))
+            e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdO + 1), R("s", self.srdO + 1)))
+            e("s_mov_b32 %s, %d" % (R("s", self.srdO + 2), tile_out))
+            e("s_mov_b32 %s, 0x00020000" % R("s", self.srdO + 3))
+            # (the O window starts at this tile's column offset: num_records covers exactly what may be stored)
+            e("s_sub_u32 %s, %s, %s" % (R("s", self.srdO + 2), R("s", self.srdO + 2), R("s", self.s_stg)))
+            e("s_mov_b32 %s, %s" % (R("s", self.srdX), R("s", ka + 6)), "statistics rows")
+            e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdX + 1), R("s", ka + 7)))
+            e("s_mov_b32 %s, 0x7fffffff" % R("s", self.srdX + 2))
+            e("s_mov_b32 %s, 0x00020000" % R("s", self.srdX + 3))
+            if c.stats == 2:
+                # y: laid out like the output (same window); mask bytes: 1/16 of it; mean / invstd: this column tile's 256 floats
+                e("s_add_u32 %s, %s, %s" % (R("s", self.srdY), R("s", ka + 8), R("s", t0)))
+                e("s_addc_u32 %s, %s, %s" % (R("s", self.srdY + 1), R("s", ka + 9), R("s", t1)))
+                e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdY + 1), R("s", self.srdY + 1)))
+                e("s_mov_b32 %s, %s" % (R("s", self.srdY + 2), R("s", self.srdO + 2)))
+                e("s_mov_b32 %s, 0x00020000" % R("s", self.srdY + 3))
+                e("s_lshr_b32 %s, %s, 4" % (R("s", t0), R("s", t0)))
+                e("s_lshl_b32 %s, %s, 28" % (R("s", self.s_stg), R("s", t1)))
+                e("s_or_b32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", self.s_stg)))
+                e("s_lshr_b32 %s, %s, 4" % (R("s", t1), R("s", t1)))
+                e("s_add_u32 %s, %s, %s" % (R("s", self.srdM), R("s", ka + 10), R("s", t0)))
+                e("s_addc_u32 %s, %s, %s" % (R("s", self.srdM + 1), R("s", ka + 11), R("s", t1)))
+                e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdM + 1), R("s", self.srdM + 1)))
+                e("s_lshr_b32 %s, %s, 4" % (R("s", self.srdM + 2), R("s", self.srdO + 2)))
+                e("s_mov_b32 %s, 0x00020000" % R("s", self.srdM + 3))
+                e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_nt), c.BN * 4))
+                for srd, k0 in ((self.srdMu, 12), (self.srdIs, 14)):
+                    e("s_add_u32 %s, %s, %s" % (R("s", srd), R("s", ka + k0), R("s", t0)))
+                    e("s_addc_u32 %s, %s, 0" % (R("s", srd + 1), R("s", ka + k0 + 1)))
+                    e("s_and_b32 %s, %s, 0xffff" % (R("s", srd + 1), R("s", srd + 1)))
+                    e("s_mov_b32 %s, %d" % (R("s", srd + 2), c.BN * 4))
+                    e("s_mov_b32 %s, 0x00020000" % R("s", srd + 3))
+
+        def lane_out():
+            # ---- output lane offset: pixel part * NCOLS*2 + (wn*NT*16 + kg*8)*2
+            x, off = v[6], v[7]
+            if c.P >= 16:
+                e("v_mov_b32 %s, %s" % (R("v", x), R("v", r)))
+            else:  # P == 8: two image rows per fragment
+                e("v_lshrrev_b32 %s, 3, %s" % (R("v", x), R("v", r)))
+                e("v_mul_u32_u24 %s, %d, %s" % (R("v", x), c.W, R("v", x)))
+                e("v_and_b32 %s, 7, %s" % (R("v", off), R("v", r)))
+                e("v_add_u32 %s, %s, %s" % (R("v", x), R("v", x), R("v", off)))
+            e("v_mov_b32 %s, %d" % (R("v", off), c.NCOLS * 2))
+            e("v_mul_lo_u32 %s, %s, %s" % (R("v", x), R("v", x), R("v", off)))
+            e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_wn), c.NT * 16 * 2))
+            e("v_lshl_add_u32 %s, %s, 4, %s" % (R("v", x), R("v", kg), R("v", x)))
+            e("v_add_u32 %s, %s, %s" % (R("v", self.v_out), R("s", t0), R("v", x)))
+
+
         if c.stats == 2:
-            # y: laid out like the output (same window); mask bytes: 1/16 of it; mean / invstd: this column tile's 256 floats
-            e("s_add_u32 %s, %s, %s" % (R("s", self.srdY), R("s", ka + 8), R("s", t0)))
-            e("s_addc_u32 %s, %s, %s" % (R("s", self.srdY + 1), R("s", ka + 9), R("s", t1)))
-            e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdY + 1), R("s", self.srdY + 1)))
-            e("s_mov_b32 %s, %s" % (R("s", self.srdY + 2), R("s", self.srdO + 2)))
-            e("s_mov_b32 %s, 0x00020000" % R("s", self.srdY + 3))
-            e("s_lshr_b32 %s, %s, 4" % (R("s", t0), R("s", t0)))
-            e("s_lshl_b32 %s, %s, 28" % (R("s", self.s_stg), R("s", t1)))
-            e("s_or_b32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", self.s_stg)))
-            e("s_lshr_b32 %s, %s, 4" % (R("s", t1), R("s", t1)))
-            e("s_add_u32 %s, %s, %s" % (R("s", self.srdM), R("s", ka + 10), R("s", t0)))
-            e("s_addc_u32 %s, %s, %s" % (R("s", self.srdM + 1), R("s", ka + 11), R("s", t1)))
-            e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdM + 1), R("s", self.srdM + 1)))
-            e("s_lshr_b32 %s, %s, 4" % (R("s", self.srdM + 2), R("s", self.srdO + 2)))
-            e("s_mov_b32 %s, 0x00020000" % R("s", self.srdM + 3))
-            e("s_lshl_b32 %s, %s, 10" % (R("s", t0), R("s", self.s_nt)))
-            for srd, k0 in ((self.srdMu, 12), (self.srdIs, 14)):
-                e("s_add_u32 %s, %s, %s" % (R("s", srd), R("s", ka + k0), R("s", t0)))
-                e("s_addc_u32 %s, %s, 0" % (R("s", srd + 1), R("s", ka + k0 + 1)))
-                e("s_and_b32 %s, %s, 0xffff" % (R("s", srd + 1), R("s", srd + 1)))
-                e("s_mov_b32 %s, 1024" % R("s", srd + 2))
-                e("s_mov_b32 %s, 0x00020000" % R("s", srd + 3))
+            # the BN-backward inputs of tile pairs 0 and 1 are requested FIRST (oldest vector-memory operations: every counted wait
+            # of the main loop is unaffected), so the epilogue finds them in registers
+            descriptors_out()
+            lane_out()
+            e("v_lshrrev_b32 %s, 4, %s" % (R("v", self.v_bits), R("v", self.v_out)), "mask bytes: one per 16-byte output vector")
+            e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_wn), c.NT * 16 * 4))
+            e("v_lshl_add_u32 %s, %s, 5, %s" % (R("v", self.v_chan), R("v", self.v_kg), R("s", t0)), "this lane's 8 floats of mean / invstd")
+            self.epi_issue_loads(0)
+            self.epi_issue_loads(1)
+            first_loads()
+        else:
+            first_loads()
+            descriptors_out()
+            lane_out()
         # ---- A read bases: pos0 = wm*MFR*16 + r + kx ; chunk = (kg + 4kk + (pos0 & 6)) & 7
         e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_wm), c.MFR * 16 * 128))
         for kx in range(3):
@@ -432,52 +541,19 @@ class Gen:
         e("v_lshlrev_b32 %s, 4, %s" % (R("v", cc), R("v", cc)))
         e("v_lshl_add_u32 %s, %s, 7, %s" % (R("v", cc), R("v", r), R("v", cc)))
         e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_wn), c.NT * 16 * 128))
+        e("s_add_u32 %s, %s, %d" % (R("s", t0), R("s", t0), c.BBASE))
         e("v_add_u32 %s, %s, %s" % (R("v", self.vB_rd[0][0]), R("s", t0), R("v", cc)))
         e("v_xor_b32 %s, 64, %s" % (R("v", self.vB_rd[0][1]), R("v", self.vB_rd[0][0])))
         for st in range(1, c.NB):
             for kk in range(2):
                 e("v_add_u32 %s, %d, %s" % (R("v", self.vB_rd[st][kk]), st * c.BSTAGE, R("v", self.vB_rd[0][kk])))
-        # ---- output lane offset: pixel part * NCOLS*2 + (wn*NT*16 + kg*8)*2
-        x, off = v[6], v[7]
-        if c.P >= 16:
-            e("v_mov_b32 %s, %s" % (R("v", x), R("v", r)))
-        else:  # P == 8: two image rows per fragment
-            e("v_lshrrev_b32 %s, 3, %s" % (R("v", x), R("v", r)))
-            e("v_mul_u32_u24 %s, %d, %s" % (R("v", x), c.W, R("v", x)))
-            e("v_and_b32 %s, 7, %s" % (R("v", off), R("v", r)))
-            e("v_add_u32 %s, %s, %s" % (R("v", x), R("v", x), R("v", off)))
-        e("v_mov_b32 %s, %d" % (R("v", off), c.NCOLS * 2))
-        e("v_mul_lo_u32 %s, %s, %s" % (R("v", x), R("v", x), R("v", off)))
-        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_wn), c.NT * 16 * 2))
-        e("v_lshl_add_u32 %s, %s, 4, %s" % (R("v", x), R("v", kg), R("v", x)))
-        e("v_add_u32 %s, %s, %s" % (R("v", self.v_out), R("s", t0), R("v", x)))
-        self.v_r, self.v_kg = v[1], v[2]
-
         # ---- zero the LDS blocks of both A buffers that no DMA piece writes (halo rows, padding): wave w takes blocks w, w+4, ...
         self.comment("zero the never-written blocks of both A buffers")
-        z = self.F[0][0]
-        for i in range(4):
-            e("v_mov_b32 %s, 0" % R("v", z + i))
-        blocks = [c.ABASE + b * c.ASTRIDE + o for b in range(2) for o in self.never_written_blocks()]
-        e("v_lshlrev_b32 %s, 4, %s" % (R("v", v[3]), R("v", lane)), "lane*16")
-        n = len(blocks)
-        for k in range((n + 3) // 4):
-            grp = blocks[4 * k:4 * k + 4]
-            # the four waves take grp[w]; a short last group repeats its last block (same zeros)
-            while len(grp) < 4:
-                grp.append(grp[-1])
-            # address = lane*16 + grp[w]: select by wave with scalar compares
-            e("s_mov_b32 %s, %d" % (R("s", t0), grp[0]))
-            for w in range(1, 4):
-                if grp[w] != grp[0]:
-                    e("s_cmp_eq_u32 %s, %d" % (R("s", self.s_w), w))
-                    e("s_cselect_b32 %s, %d, %s" % (R("s", t0), grp[w], R("s", t0)))
-            e("v_add_u32 %s, %s, %s" % (R("v", v[4]), R("s", t0), R("v", v[3])))
-            e("ds_write_b128 %s, %s" % (R("v", v[4]), R("v", z, 4)))
+        self.zero_blocks([c.ABASE + b * c.ASTRIDE + o for b in range(2) for o in self.never_written_blocks()])
         # accumulators = 0
         for i in range(self.nagpr):
             e("v_accvgpr_write_b32 a%d, 0" % i)
-        e("s_waitcnt vmcnt(%d)" % (8 * (c.NB - 1)))
+        e("s_waitcnt vmcnt(%d)" % (c.NPB * (c.NB - 1)))
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier")
         # fragments of (stage 0, kk 0)
@@ -485,25 +561,59 @@ class Gen:
             e(ins)
         e("s_mov_b32 %s, %s" % (R("s", self.s_cnt), R("s", self.s_nch)))
 
-    # one A piece (slot i of the schedule) of the NEXT chunk (or chunk 0 in the prologue) into A buffer `buf`
-    def a_piece(self, i, buf, soff_chunk):
+    def zero_blocks(self, blocks):
+        """ds_write zeros over the listed 1 KiB LDS blocks: the four waves take blocks[4k + w]"""
         c, e = self.c, self.e
-        var = a_schedule(c)[i][0]
-        e("s_add_u32 m0, %s, %d" % (R("s", self.s_tA_lds + i), c.ABASE + buf * c.ASTRIDE))
-        e("s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", soff_chunk), R("s", self.s_tA_src + i)), "(also the wait state between the M0 write and the DMA)")
-        e("buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vA_dma[var]), R("s", self.srdA, 4), R("s", self.s_t0)))
+        if not blocks:
+            return
+        v, t0 = self.v_t, self.s_t0
+        z = self.F[0][0]
+        for i in range(4):
+            e("v_mov_b32 %s, 0" % R("v", z + i))
+        e("v_and_b32 %s, 63, v0" % R("v", v[8]))
+        e("v_lshlrev_b32 %s, 4, %s" % (R("v", v[8]), R("v", v[8])), "lane*16")
+        for k in range((len(blocks) + 3) // 4):
+            grp = blocks[4 * k:4 * k + 4]
+            while len(grp) < 4:      # a short last group repeats its last block (same zeros)
+                grp.append(grp[-1])
+            e("s_mov_b32 %s, %d" % (R("s", t0), grp[0]))
+            for w in range(1, 4):
+                if grp[w] != grp[0]:
+                    e("s_cmp_eq_u32 %s, %d" % (R("s", self.s_w), w))
+                    e("s_cselect_b32 %s, %d, %s" % (R("s", t0), grp[w], R("s", t0)))
+            e("v_add_u32 %s, %s, %s" % (R("v", v[9]), R("s", t0), R("v", v[8])))
+            e("ds_write_b128 %s, %s" % (R("v", v[9]), R("v", z, 4)))
+
+    def a_piece_insts(self, k, buf, s_chunk):
+        """A piece slot k (table entries k and NPA + k of this wave) of the chunk at byte offset s_chunk into A buffer `buf`"""
+        c = self.c
+        var = a_slots(c)[k][0]
+        if self.tab_sgpr:
+            return ["s_add_u32 m0, %s, %d" % (R("s", self.s_tbl + k), c.ABASE + buf * c.ASTRIDE),
+                    "s_add_u32 %s, %s, %s" % (R("s", self.s_t1), R("s", s_chunk), R("s", self.s_tbl + self.NPA + k)),
+                    "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vA_dma[var]), R("s", self.srdA, 4), R("s", self.s_t1))]
+        return ["v_readlane_b32 %s, %s, %d" % (R("s", self.s_a), R("v", self.v_tab), k),
+                "v_readlane_b32 %s, %s, %d" % (R("s", self.s_b), R("v", self.v_tab), self.NPA + k),
+                "s_add_u32 m0, %s, %d" % (R("s", self.s_a), c.ABASE + buf * c.ASTRIDE),
+                "s_add_u32 %s, %s, %s" % (R("s", self.s_t1), R("s", s_chunk), R("s", self.s_b)),
+                "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vA_dma[var]), R("s", self.srdA, 4), R("s", self.s_t1))]
 
     def b_piece_insts(self, i, bp, s_stage):
-        """the three instructions of weight piece i into ring stage bp; s_stage holds (wtap*Cin + chunk*64)*2"""
+        """weight piece i into ring stage bp; s_stage holds (wtap*Cin + chunk*64)*2"""
         c = self.c
-        return ["s_add_u32 m0, %s, %d" % (R("s", self.s_ldsBw), bp * c.BSTAGE + i * 1024),
-                "s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", s_stage), R("s", self.s_tB + i)),
+        if self.tab_sgpr:
+            return ["s_add_u32 m0, %s, %d" % (R("s", self.s_ldsBw), c.BBASE + bp * c.BSTAGE + i * 1024),
+                    "s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", s_stage), R("s", self.s_tbl + 2 * self.NPA + i)),
+                    "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vB_dma[i & 1]), R("s", self.srdB, 4), R("s", self.s_t0))]
+        return ["v_readlane_b32 %s, %s, %d" % (R("s", self.s_b), R("v", self.v_tab), 2 * self.NPA + i),
+                "s_add_u32 m0, %s, %d" % (R("s", self.s_ldsBw), c.BBASE + bp * c.BSTAGE + i * 1024),
+                "s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", s_stage), R("s", self.s_b)),
                 "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vB_dma[i & 1]), R("s", self.srdB, 4), R("s", self.s_t0))]
 
     def b_stage_issue_all(self, tap, bp, s_chunk):
         e = self.e
         e("s_add_u32 %s, %s, %s" % (R("s", self.s_stg), R("s", self.s_wt + tap), R("s", s_chunk)))
-        for i in range(8):
+        for i in range(self.c.NPB):
             for ins in self.b_piece_insts(i, bp, self.s_stg):
                 e(ins)
 
@@ -584,12 +694,7 @@ class Gen:
                 e("s_waitcnt lgkmcnt(0)")
                 groups = [[r] for r in self.frag_reads(1, t, 1, bp)]
                 mf = self.mfmas(0)
-                pieces = []
-                if t < self.NPA:
-                    var = a_schedule(c)[t][0]
-                    pieces.append(["s_add_u32 m0, %s, %d" % (R("s", self.s_tA_lds + t), c.ABASE + (cp ^ 1) * c.ASTRIDE),
-                                   "s_add_u32 %s, %s, %s" % (R("s", self.s_t1), R("s", self.s_cN), R("s", self.s_tA_src + t)),
-                                   "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vA_dma[var]), R("s", self.srdA, 4), R("s", self.s_t1))])
+                pieces = [self.a_piece_insts(k, cp ^ 1, self.s_cN) for k in range(t * self.APS, min((t + 1) * self.APS, self.NPA))]
                 if c.probe & 1:
                     pieces = []
                 if c.probe & 2:
@@ -599,8 +704,9 @@ class Gen:
                 self.comment("chunk parity %d tap %d substep 1" % (cp, t))
                 # younger than stage t+1's pieces: the weight groups of stages t+2 .. t+NB-1 and the A pieces issued since; at tap 8
                 # the A pieces must have landed too (they are older than those groups: NPA <= 8)
-                ayoung = sum(1 for j in range(t + 2 - c.NB, t + 1) if 0 <= j < self.NPA)
-                e("s_waitcnt vmcnt(%d)" % (8 * (c.NB - 2) + (ayoung if t < 8 else 0)))
+                npc = lambda j: max(0, min((j + 1) * self.APS, self.NPA) - j * self.APS) if j >= 0 else 0
+                ayoung = sum(npc(j) for j in range(t + 2 - c.NB, t + 1))
+                e("s_waitcnt vmcnt(%d)" % (c.NPB * (c.NB - 2) + (ayoung if t < 8 else 0)))
                 e("s_waitcnt lgkmcnt(0)")
                 if not c.probe & 4:
                     e("s_barrier")
@@ -617,7 +723,7 @@ class Gen:
                 t3 = (t + c.NB) % 9
                 s_ch = self.s_cC if t + c.NB < 9 else self.s_cN
                 pieces = []
-                for i in range(8):
+                for i in range(c.NPB):
                     g = self.b_piece_insts(i, bp, self.s_stg)
                     if i == 0:
                         g = ["s_add_u32 %s, %s, %s" % (R("s", self.s_stg), R("s", self.s_wt + t3), R("s", s_ch))] + g
@@ -666,7 +772,7 @@ class Gen:
                 i, y = divmod(go, c.SR)
             else:
                 i, y = 0, go
-            ok = xo < c.W and y < c.H and i < c.IPT
+            ok = xo < c.W and y < (c.ROWS_T if c.ROWS_T else c.H) and i < c.IPT
             if ok:
                 for q in range(4):
                     mask |= 1 << (16 * q + r)
@@ -679,6 +785,48 @@ class Gen:
             i, y = 0, go
         pix = (i * c.H + y) * c.W + xo
         return mask, pix * c.NCOLS * 2
+
+    def emit_frag(self, m, set_mask=True):
+        """s_t0 = output byte offset of THIS wave row's fragment m; with set_mask, EXEC = its valid lanes.  Affine in the wave row
+        where the geometry allows, else a compare / select chain over the wave rows."""
+        c, e = self.c, self.e
+        metas = [self.frag_out(wm * c.MFR + m) for wm in range(c.WM)]
+        offs = [x[1] for x in metas]
+        masks = [x[0] for x in metas]
+        d = offs[1] - offs[0] if c.WM > 1 else 0
+        if all(offs[i] - offs[0] == i * d for i in range(c.WM)):
+            e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wm), d))
+            e("s_add_u32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_t0), offs[0]))
+        else:
+            e("s_mov_b32 %s, %d" % (R("s", self.s_t0), offs[0]))
+            for wm in range(1, c.WM):
+                e("s_cmp_eq_u32 %s, %d" % (R("s", self.s_wm), wm))
+                e("s_cselect_b32 %s, %d, %s" % (R("s", self.s_t0), offs[wm], R("s", self.s_t0)))
+        if not set_mask:
+            return
+        if len(set(masks)) == 1:
+            self.set_exec(masks[0])
+        else:
+            e("s_mov_b32 exec_lo, 0x%x" % (masks[0] & 0xFFFFFFFF))
+            e("s_mov_b32 exec_hi, 0x%x" % (masks[0] >> 32))
+            for wm in range(1, c.WM):
+                if masks[wm] != masks[0]:
+                    e("s_cmp_eq_u32 %s, %d" % (R("s", self.s_wm), wm))
+                    e("s_cselect_b32 exec_lo, 0x%x, exec_lo" % (masks[wm] & 0xFFFFFFFF))
+                    e("s_cselect_b32 exec_hi, 0x%x, exec_hi" % (masks[wm] >> 32))
+
+    def epi_issue_loads(self, p):
+        """BN-backward inputs of tile pair p into register set p & 1"""
+        c, e = self.c, self.e
+        k = p & 1
+        for m in range(c.MFR):
+            self.emit_frag(m, set_mask=False)
+            e("s_lshr_b32 %s, %s, 4" % (R("s", self.s_t1), R("s", self.s_t0)))
+            e("buffer_load_dwordx4 %s, %s, %s, %s offen offset:%d" % (R("v", self.ysets[k][m], 4), R("v", self.v_out), R("s", self.srdY, 4), R("s", self.s_t0), p * 64))
+            e("buffer_load_ubyte %s, %s, %s, %s offen offset:%d" % (R("v", self.bsets[k][m]), R("v", self.v_bits), R("s", self.srdM, 4), R("s", self.s_t1), p * 4))
+        for h in range(2):
+            e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", self.msets[k] + 4 * h, 4), R("v", self.v_chan), R("s", self.srdMu, 4), p * 128 + 16 * h))
+            e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", self.msets[k] + 8 + 4 * h, 4), R("v", self.v_chan), R("s", self.srdIs, 4), p * 128 + 16 * h))
 
     def epilogue(self):
         c, e = self.c, self.e
@@ -695,36 +843,11 @@ class Gen:
         assert base + 51 <= self.F[1][1] + 4 * c.NT
         npair = c.NT // 2
         if c.stats == 2:
-            # BN-backward sums: y / mask of the same (pixel, 8 channels) vectors as the output, two register sets (pair p + 1 loads
-            # under pair p's arithmetic); mean / invstd of this lane's 8 channels per pair
-            ysets = [[V.get(4, 4) for m in range(c.MFR)] for _ in range(2)]
-            bsets = [[V.get() for m in range(c.MFR)] for _ in range(2)]
-            msets = [V.get(16, 4) for _ in range(2)]   # mean[8], invstd[8]
-            v_bits, v_chan = V.get(), V.get()
-            self.nvgpr_epi = V.n
-            e("v_lshrrev_b32 %s, 4, %s" % (R("v", v_bits), R("v", self.v_out)), "mask bytes: one per 16-byte output vector")
-            # channel byte offset of this lane's 8 floats in mean / invstd: (wn*128 + kg*8)*4
-            e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wn), c.NT * 16 * 4))
-            e("v_lshl_add_u32 %s, %s, 5, %s" % (R("v", v_chan), R("v", self.v_kg), R("s", self.s_t0)))
-
-            def issue_loads(p):
-                k = p & 1
-                for m in range(c.MFR):
-                    f0, f1 = self.frag_out(m), self.frag_out(c.MFR + m)
-                    assert f0[1] % 16 == 0 and (f1[1] - f0[1]) % 16 == 0
-                    e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wm), f1[1] - f0[1]))
-                    e("s_add_u32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_t0), f0[1]))
-                    e("s_lshr_b32 %s, %s, 4" % (R("s", self.s_t1), R("s", self.s_t0)))
-                    e("buffer_load_dwordx4 %s, %s, %s, %s offen offset:%d" % (R("v", ysets[k][m], 4), R("v", self.v_out), R("s", self.srdY, 4), R("s", self.s_t0), p * 64))
-                    e("buffer_load_ubyte %s, %s, %s, %s offen offset:%d" % (R("v", bsets[k][m]), R("v", v_bits), R("s", self.srdM, 4), R("s", self.s_t1), p * 4))
-                for h in range(2):
-                    e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", msets[k] + 4 * h, 4), R("v", v_chan), R("s", self.srdMu, 4), p * 128 + 16 * h))
-                    e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", msets[k] + 8 + 4 * h, 4), R("v", v_chan), R("s", self.srdIs, 4), p * 128 + 16 * h))
+            ysets, bsets, msets = self.ysets, self.bsets, self.msets
+            issue_loads = self.epi_issue_loads
             GL = 2 * c.MFR + 4
         e("s_waitcnt vmcnt(0)")
         e("s_waitcnt lgkmcnt(0)")
-        if c.stats == 2:
-            issue_loads(0)
         e("s_barrier", "every LDS-DMA of the (unused) lookahead has landed: the ring is free for the statistics scratch")
         e("s_nop 15")
         e("s_nop 15")
@@ -733,35 +856,18 @@ class Gen:
             e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wm), c.BN * 8))
             e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t1), R("s", self.s_wn), c.NT * 16 * 8))
             e("s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", self.s_t0), R("s", self.s_t1)))
+            e("s_add_u32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_t0), c.BBASE), "the statistics scratch reuses the weight ring")
             e("v_lshl_add_u32 %s, %s, 6, %s" % (R("v", vst), R("v", self.v_kg), R("s", self.s_t0)))
         for p in range(npair):
             if c.stats:
                 for i in range(8):
                     e("v_mov_b32 %s, 0" % R("v", s1[i]))
                     e("v_mov_b32 %s, 0" % R("v", s2[i]))
-            if c.stats == 2:
-                if p + 1 < npair:
-                    issue_loads(p + 1)
-                    e("s_waitcnt vmcnt(%d)" % (GL + (c.MFR if p > 0 else 0)))
-                else:
-                    e("s_waitcnt vmcnt(%d)" % c.MFR)
+            if c.stats == 2 and p >= 2:
+                # pair p's loads were issued behind pair p - 2; younger: pair p - 1's stores (+ pair p + 1's loads)
+                e("s_waitcnt vmcnt(%d)" % (c.MFR + (GL if p + 1 < npair else 0)))
             for m in range(c.MFR):
-                # the exec mask and output offset depend on the GLOBAL fragment wm*MFR + m: both wave rows take the same code
-                # when the masks agree; otherwise select by s_wm
-                f0, f1 = self.frag_out(m), self.frag_out(c.MFR + m)
-                e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wm), f1[1] - f0[1]))
-                e("s_add_u32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_t0), f0[1]))
-                if f0[0] == f1[0]:
-                    self.set_exec(f0[0])
-                else:
-                    lab, lab2 = self.newlabel("m1"), self.newlabel("m2")
-                    e("s_cmp_eq_u32 %s, 0" % R("s", self.s_wm))
-                    e("s_cbranch_scc0 %s" % lab)
-                    self.set_exec(f0[0])
-                    e("s_branch %s" % lab2)
-                    self.label(lab)
-                    self.set_exec(f1[0])
-                    self.label(lab2)
+                self.emit_frag(m)
                 d = dsets[m % 4]
                 for i in range(4):
                     e("v_accvgpr_read_b32 %s, a%d" % (R("v", tv[i]), (m * c.NT + 2 * p) * 4 + i))
@@ -812,23 +918,31 @@ class Gen:
                     e("ds_write_b32 %s, %s offset:%d" % (R("v", vst), R("v", s1[i]), p * 32 * 8 + i * 8))
                     e("ds_write_b32 %s, %s offset:%d" % (R("v", vst), R("v", s2[i]), p * 32 * 8 + i * 8 + 4))
                 e("s_mov_b64 exec, -1")
+                if c.stats == 2 and p + 2 < npair:
+                    issue_loads(p + 2)
         if c.stats:
             # partial row of this workgroup: row[c] = sum, row[NCOLS + c] = sum of squares, c = nt*256 + tid
             e("s_waitcnt lgkmcnt(0)")
             e("s_barrier")
             a0, a1, b0, b1, ad, go = tv[0], tv[1], tv[2], tv[3], tv[4], tv[5]
+            if c.BN < 256:
+                e("v_cmp_gt_u32 vcc, %d, v0" % c.BN)
+                e("s_nop 4")
+                e("s_and_b64 exec, exec, vcc", "one thread per channel of the column tile")
             e("v_lshlrev_b32 %s, 3, v0" % R("v", ad))
+            e("v_add_u32 %s, %d, %s" % (R("v", ad), c.BBASE, R("v", ad)))
             e("ds_read_b64 %s, %s" % (R("v", a0, 2), R("v", ad)))
-            e("ds_read_b64 %s, %s offset:%d" % (R("v", b0, 2), R("v", ad), c.BN * 8))
-            # global offset: (tile*2*NCOLS + nt*256 + tid)*4
+            # global offset: (tile*2*NCOLS + nt*BN + tid)*4
             e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_tile), 2 * c.NCOLS * 4))
-            e("s_lshl_b32 %s, %s, 10" % (R("s", self.s_t1), R("s", self.s_nt)))
+            e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t1), R("s", self.s_nt), c.BN * 4))
             e("s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", self.s_t0), R("s", self.s_t1)))
             e("v_lshlrev_b32 %s, 2, v0" % R("v", go))
+            for wmi in range(1, c.WM):   # + the other wave rows, in order
+                e("ds_read_b64 %s, %s offset:%d" % (R("v", b0, 2), R("v", ad), wmi * c.BN * 8))
+                e("s_waitcnt lgkmcnt(0)")
+                e("v_add_f32 %s, %s, %s" % (R("v", a0), R("v", a0), R("v", b0)))
+                e("v_add_f32 %s, %s, %s" % (R("v", a1), R("v", a1), R("v", b1)))
             e("s_waitcnt lgkmcnt(0)")
-            # a0/a1 = (sum, sq) of wave row 0, b0/b1 of wave row 1 — (a0, a1) must be an aligned pair: tv[0] is 4-aligned
-            e("v_add_f32 %s, %s, %s" % (R("v", a0), R("v", a0), R("v", b0)))
-            e("v_add_f32 %s, %s, %s" % (R("v", a1), R("v", a1), R("v", b1)))
             e("buffer_store_dword %s, %s, %s, %s offen" % (R("v", a0), R("v", go), R("s", self.srdX, 4), R("s", self.s_t0)))
             e("s_add_u32 %s, %s, %d" % (R("s", self.s_t1), R("s", self.s_t0), c.NCOLS * 4))
             e("buffer_store_dword %s, %s, %s, %s offen" % (R("v", a1), R("v", go), R("s", self.srdX, 4), R("s", self.s_t1)))
@@ -845,7 +959,7 @@ class Gen:
     def finish(self):
         c = self.c
         name = c.name
-        lds = c.ABASE + 2 * c.ASTRIDE  # B ring, two A buffers each followed by the sink of its padding pieces
+        lds = 2 * c.ABUF + c.NB * c.BSTAGE  # two A buffers, the weight ring
         assert lds <= 160 * 1024
         total_v = self.accum_offset + self.nagpr
         hdr = []
@@ -921,6 +1035,10 @@ VARIANTS = {
     "dconv_l4_s0": Cfg("dconv_l4_s0", H=7, W=7, P=8, IPT=2, Cin=512, NCOLS=512, stats=0, NB=3),
     "dconv_l4_s1": Cfg("dconv_l4_s1", H=7, W=7, P=8, IPT=2, Cin=512, NCOLS=512, stats=1, NB=3),
     "dconv_l4_s2": Cfg("dconv_l4_s2", H=7, W=7, P=8, IPT=2, Cin=512, NCOLS=512, stats=2, NB=3),
+    # layer 2 (28 x 28 x 128 -> 128): a tile = 14 output rows of one image (2 tiles per image), waves 4 (pixels) x 1, 128 columns
+    "dconv_l2_s0": Cfg("dconv_l2_s0", H=28, W=28, P=32, IPT=1, Cin=128, NCOLS=128, stats=0, WM=4, WN=1, ROWS_T=14),
+    "dconv_l2_s1": Cfg("dconv_l2_s1", H=28, W=28, P=32, IPT=1, Cin=128, NCOLS=128, stats=1, WM=4, WN=1, ROWS_T=14),
+    "dconv_l2_s2": Cfg("dconv_l2_s2", H=28, W=28, P=32, IPT=1, Cin=128, NCOLS=128, stats=2, WM=4, WN=1, ROWS_T=14),
 }
 
 
@@ -950,7 +1068,7 @@ def main():
         if a.suffix:  # tuning builds: the per-wave table as a raw file for tools/micro/dconv_bench.cpp
             import struct
             with open(os.path.join(a.out, name + ".tbl"), "wb") as f:
-                f.write(struct.pack("<128I", *[w for row in tables(c) for w in row]))
+                f.write(struct.pack("<512I", *[w for par in tables(c) for row in par for w in row]))
         with open(os.path.join(a.out, name + ".s"), "w") as f:
             f.write(text)
         print("%s: %d lines, %d VGPR + %d AGPR, %d SGPR, LDS %d" % (name, text.count("\n"), g.accum_offset, g.nagpr, g.S.n, g.lds_bytes))

@@ -13,8 +13,8 @@ namespace {
 
 struct DconvVariant {
   const char* name;
-  int H, W, IPT, Cin, NCOLS, stats, lds, kernarg;
-  unsigned table[4 * 32];  // per-wave LDS-DMA piece table (asm/dconv_gen.py tables())
+  int H, W, IPT, TPI, BN, Cin, NCOLS, stats, lds, kernarg;  // IPT images per tile, or TPI tiles per image; BN columns per workgroup
+  unsigned table[2 * 4 * 64];  // [tile parity][wave] LDS-DMA piece tables (asm/dconv_gen.py tables())
 };
 
 const DconvVariant g_variants[] = {
@@ -191,7 +191,7 @@ bool dconv_legal(const IgemmArgs& a, int nclass) {
   const int v = find_variant(a, nclass, wanted_stats(a));
   if (v < 0) return false;
   // one partial statistics row per tile: bn_finalize adds at most bn_max_blocks() rows
-  if (a.stat_partial != nullptr && a.N / g_variants[v].IPT > (bn_max_blocks() < 768 ? bn_max_blocks() : 768)) return false;  // (768: the per-op API's buffer)
+  if (a.stat_partial != nullptr && a.N * g_variants[v].TPI / g_variants[v].IPT > (bn_max_blocks() < 768 ? bn_max_blocks() : 768)) return false;  // (768: the per-op API's buffer)
   return true;
 }
 
@@ -216,9 +216,9 @@ int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_r
     unsigned wtap_off[9];
     unsigned nchunks;
     unsigned pad[4];
-    unsigned table[128];  // per-wave LDS-DMA piece tables, read with scalar loads
+    unsigned table[512];  // [tile parity][wave][64] LDS-DMA piece tables
   } k;
-  static_assert(sizeof(KArgs) == 640, "kernarg layout of asm/dconv_gen.py (Gen.KA)");
+  static_assert(sizeof(KArgs) == 128 + 2048, "kernarg layout of asm/dconv_gen.py (Gen.KA)");
   MI355_ARG((int)sizeof(KArgs) == v.kernarg, "dconv: kernarg size mismatch");
   k.in = a.in;
   k.wt = a.wt;
@@ -235,8 +235,8 @@ int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_r
   k.nchunks = (unsigned)(a.Ck / 64);
   size_t ksize = sizeof(k);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
-  const int tiles = a.N / v.IPT;
-  const hipError_t e = hipModuleLaunchKernel(d->fn[vi], (unsigned)tiles, (unsigned)(a.Ncols / 256), 1, 256, 1, 1, 0, stream, nullptr, extra);
+  const int tiles = a.N * v.TPI / v.IPT;
+  const hipError_t e = hipModuleLaunchKernel(d->fn[vi], (unsigned)tiles, (unsigned)(a.Ncols / v.BN), 1, 256, 1, 1, 0, stream, nullptr, extra);
   if (e != hipSuccess) {
     set_error("dconv: hipModuleLaunchKernel(%s) -> %s", v.name, hipGetErrorString(e));
     return MI355_E_HIP;

@@ -27,6 +27,8 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang"
     ("dconv_l3_s0", dict(Cin=192)),                                                    # odd chunk count (loop exit in the middle)
     ("dconv_l4_s1", dict(Cin=64, ntile=1)),                                            # 2 images per tile, 3-stage weight ring
     ("dconv_l4_s2", dict(Cin=128, tiles=(1,))),
+    ("dconv_l2_s1", dict(Cin=128, tiles=(0, 1))),                                      # half-image tiles: both parities, 4 x 1 waves
+    ("dconv_l2_s2", dict(Cin=64, tiles=(3,), dgrad_taps=True)),
 ])
 def test_direct_conv_kernels_are_exact_in_the_emulator(name, kw):
     r = D.run(name, **kw)

@@ -43,7 +43,7 @@ def run(name, tiles=(0,), ntile=0, seed=0, dgrad_taps=False, check=True, **over)
     c, g, text = dconv_gen.generate(name, **over)
     rng = np.random.default_rng(seed)
     ntiles = max(tiles) + 1
-    N = ntiles * c.IPT
+    N = -(-ntiles // c.TPI) if c.ROWS_T else ntiles * c.IPT
     x = rng.integers(-2, 3, size=(N, c.H, c.W, c.Cin)).astype(np.float32)
     w = rng.integers(-2, 3, size=(c.NCOLS, 9, c.Cin)).astype(np.float32)
     if dgrad_taps:
@@ -59,7 +59,8 @@ def run(name, tiles=(0,), ntile=0, seed=0, dgrad_taps=False, check=True, **over)
     a_wt = mem.alloc(to_bf16_bits(w))
     out0 = np.full((N, c.H, c.W, c.NCOLS), 0x7FC0, dtype=np.uint16)  # NaN: unwritten outputs show
     a_out = mem.alloc(out0)
-    a_stat = mem.alloc(np.full((ntiles, 2, c.NCOLS), np.nan, dtype=np.float32))
+    ntiles_all = N * c.TPI if c.ROWS_T else ntiles
+    a_stat = mem.alloc(np.full((ntiles_all, 2, c.NCOLS), np.nan, dtype=np.float32))
     # BN-backward inputs (stats == 2): y laid out like the output, one mask byte per 8 channels, per-channel mean / invstd
     yb = rng.integers(-3, 4, size=(N, c.H, c.W, c.NCOLS)).astype(np.float32)
     bits = rng.integers(0, 256, size=(N, c.H, c.W, c.NCOLS // 8)).astype(np.uint8)
@@ -68,40 +69,43 @@ def run(name, tiles=(0,), ntile=0, seed=0, dgrad_taps=False, check=True, **over)
     a_y, a_bits, a_mu, a_is = mem.alloc(to_bf16_bits(yb)), mem.alloc(bits), mem.alloc(mean), mem.alloc(invstd)
     fields = [("q", a_in), ("q", a_wt), ("q", a_out), ("q", a_stat), ("q", a_y), ("q", a_bits), ("q", a_mu), ("q", a_is),
               ("q", 0)] + [("I", wtap_of[t] * c.Cin * 2) for t in range(9)] + [("I", c.Cin // 64)] + [("I", 0)] * 4
-    fields += [("I", w) for row in dconv_gen.tables(c) for w in row]
+    fields += [("I", w) for par in dconv_gen.tables(c) for row in par for w in row]
     ka = gcn_emu.pack_kernarg(fields)
     assert len(ka) == dconv_gen.Gen.KA["size"], len(ka)
     a_ka = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     total = 0
     for t in tiles:
-        emu = gcn_emu.Emulator(text, mem, lds_bytes=g.lds_bytes, check=check, sinks=[(c.ABASE + b * c.ASTRIDE + c.ABUF, c.ABASE + (b + 1) * c.ASTRIDE) for b in range(2)])
+        emu = gcn_emu.Emulator(text, mem, lds_bytes=g.lds_bytes, check=check, dontcare=[(c.ABASE + (b + 1) * c.ABUF, c.ABASE + (b + 1) * c.ABUF + 256) for b in range(2)])
         total += emu.run_workgroup(4, a_ka, wg_id=(t, ntile, 0))
     got = from_bf16_bits(mem.array(a_out, np.uint16, out0.shape)).astype(np.float64)
     ref = conv_ref(x.astype(np.float64), w.astype(np.float64), taps)
-    cols = slice(ntile * 256, ntile * 256 + 256)
+    cols = slice(ntile * c.BN, ntile * c.BN + c.BN)
     res = {"insts": total, "cfg": c}
     refr = bf16_round(ref.astype(np.float32)).astype(np.float64)
-    sel = [i for t in tiles for i in range(t * c.IPT, (t + 1) * c.IPT)]
-    res["max_err"] = float(np.abs(got[sel][..., cols] - refr[sel][..., cols]).max())
+    # tiles as flat pixel-row ranges: tile t covers rows [t*tile_rows, (t+1)*tile_rows) of the [N*H][W] pixel grid
+    got = got.reshape(N * c.H, c.W, c.NCOLS)
+    refr = refr.reshape(N * c.H, c.W, c.NCOLS)
+    rows_of = lambda t: slice(t * c.tile_rows, (t + 1) * c.tile_rows)
+    res["max_err"] = float(max(np.abs(got[rows_of(t)][..., cols] - refr[rows_of(t)][..., cols]).max() for t in tiles))
     res["untouched_ok"] = True
-    if c.NCOLS > 256:
+    if c.NCOLS > c.BN:
         other = np.ones(c.NCOLS, dtype=bool)
         other[cols] = False
         res["untouched_ok"] = bool(np.isnan(got[..., other]).all())
     if c.stats == 1:
-        st = mem.array(a_stat, np.float32, (ntiles, 2, c.NCOLS))
-        s1 = np.stack([refr[t * c.IPT:(t + 1) * c.IPT].sum(axis=(0, 1, 2)) for t in range(ntiles)])
-        s2 = np.stack([(refr[t * c.IPT:(t + 1) * c.IPT] ** 2).sum(axis=(0, 1, 2)) for t in range(ntiles)])
+        st = mem.array(a_stat, np.float32, (ntiles_all, 2, c.NCOLS))
+        s1 = np.stack([refr[rows_of(t)].sum(axis=(0, 1)) for t in range(ntiles_all)])
+        s2 = np.stack([(refr[rows_of(t)] ** 2).sum(axis=(0, 1)) for t in range(ntiles_all)])
         tl = list(tiles)
         res["stat_err"] = float(max(np.abs(st[tl, 0][:, cols] - s1[tl][:, cols]).max(), np.abs(st[tl, 1][:, cols] - s2[tl][:, cols]).max()))
     if c.stats == 2:
-        st = mem.array(a_stat, np.float32, (ntiles, 2, c.NCOLS))
-        mask = ((bits[..., None] >> np.arange(8)) & 1).reshape(N, c.H, c.W, c.NCOLS).astype(np.float64)
+        st = mem.array(a_stat, np.float32, (ntiles_all, 2, c.NCOLS))
+        mask = ((bits[..., None] >> np.arange(8)) & 1).reshape(N * c.H, c.W, c.NCOLS).astype(np.float64)
         dz = refr * mask
-        xhat = (yb.astype(np.float64) - mean) * invstd
+        xhat = (yb.astype(np.float64).reshape(N * c.H, c.W, c.NCOLS) - mean) * invstd
         tl = list(tiles)
-        s1 = np.stack([dz[t * c.IPT:(t + 1) * c.IPT].sum(axis=(0, 1, 2)) for t in range(ntiles)])
-        s2 = np.stack([(dz * xhat)[t * c.IPT:(t + 1) * c.IPT].sum(axis=(0, 1, 2)) for t in range(ntiles)])
+        s1 = np.stack([dz[rows_of(t)].sum(axis=(0, 1)) for t in range(ntiles_all)])
+        s2 = np.stack([(dz * xhat)[rows_of(t)].sum(axis=(0, 1)) for t in range(ntiles_all)])
         scale = max(np.abs(s1).max(), np.abs(s2).max(), 1.0)
         res["stat_err"] = float(max(np.abs(st[tl, 0][:, cols] - s1[tl][:, cols]).max(), np.abs(st[tl, 1][:, cols] - s2[tl][:, cols]).max()) / scale)
     return res

@@ -175,7 +175,10 @@ class Wave:
 class Emulator:
     LDS_BYTES = 160 * 1024
 
-    def __init__(self, text, mem, lds_bytes=None, check=True, sinks=None):
+    def __init__(self, text, mem, lds_bytes=None, check=True, sinks=None, dontcare=None):
+        # dontcare: (first byte, end byte) LDS ranges whose READS are exempt from the DMA-protocol checks: the generator declares
+        # them for fragment reads that run a few positions past a tile into whatever follows it and only feed discarded lanes
+        self.dontcare = dontcare or []
         self.sinks = sinks or []  # (first byte, end byte) LDS regions written by padding DMAs and never read: exempt from the write checks
         self.insts, self.labels = parse_program(text)
         self.mem = mem
@@ -371,6 +374,10 @@ class Emulator:
         if not self.check:
             return
         sl = (addrs[mask] // 16).astype(np.int64)  # accesses are naturally aligned and <= 16 bytes: one slot per lane
+        for lo, hi in self.dontcare:
+            sl = sl[(sl < lo // 16) | (sl >= hi // 16)]
+        if sl.size == 0:
+            return
         st = self.slot_state[sl]
         if (st == 1).any():
             i = int(np.nonzero(st == 1)[0][0])

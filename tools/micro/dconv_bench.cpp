@@ -31,13 +31,15 @@ int main(int argc, char** argv) {
   const int H = atoi(argv[4]), W = atoi(argv[5]), IPT = atoi(argv[6]), Cin = atoi(argv[7]), NCOLS = atoi(argv[8]), N = atoi(argv[9]);
   const int nchunks = argc > 10 ? atoi(argv[10]) : Cin / 64;
   const int iters = argc > 11 ? atoi(argv[11]) : 40;
+  const int BNC = argc > 12 ? atoi(argv[12]) : 256;  // columns per workgroup
   hipModule_t mod;
   hipFunction_t fn;
   CK(hipModuleLoad(&mod, hsaco));
   CK(hipModuleGetFunction(&fn, mod, kname));
-  unsigned tbl[128];
+  unsigned tbl[512];
+  memset(tbl, 0, sizeof(tbl));
   FILE* f = fopen(tblf, "rb");
-  if (!f || fread(tbl, 4, 128, f) != 128) {
+  if (!f || fread(tbl, 4, 512, f) < 128) {
     fprintf(stderr, "cannot read %s\n", tblf);
     return 1;
   }
@@ -59,7 +61,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc((void**)&d_wt, wt_elems * 2));
   CK(hipMemcpy(d_wt, h.data(), wt_elems * 2, hipMemcpyHostToDevice));
   CK(hipMalloc((void**)&d_out, out_elems * 2));
-  CK(hipMalloc((void**)&d_stat, (size_t)(N / IPT) * 2 * NCOLS * 4));
+  CK(hipMalloc((void**)&d_stat, (size_t)(IPT < 0 ? N * -IPT : N / IPT) * 2 * NCOLS * 4 + 4096));
   CK(hipMalloc((void**)&d_tbl, 512));
   CK(hipMemcpy(d_tbl, tbl, 512, hipMemcpyHostToDevice));
   struct __attribute__((packed)) KArgs {
@@ -72,7 +74,7 @@ int main(int argc, char** argv) {
     unsigned wtap_off[9];
     unsigned nchunks;
     unsigned pad[4];
-    unsigned table[128];
+    unsigned table[512];
   } k;
   memset(&k, 0, sizeof(k));
   k.wt = d_wt;
@@ -117,7 +119,7 @@ int main(int argc, char** argv) {
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, pw ? (void*)&pk : (void*)&k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
     CK(hipEventRecord(e0, 0));
     if (pw) CK(hipModuleLaunchKernel(fn, pw_grid, 1, 1, 256, 1, 1, 0, 0, nullptr, extra));
-    else CK(hipModuleLaunchKernel(fn, (unsigned)(N / IPT), (unsigned)(NCOLS / 256), 1, 256, 1, 1, 0, 0, nullptr, extra));
+    else CK(hipModuleLaunchKernel(fn, (unsigned)(IPT < 0 ? N * -IPT : N / IPT), (unsigned)(NCOLS / BNC), 1, 256, 1, 1, 0, 0, nullptr, extra));  // IPT < 0: -IPT tiles per image
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms;
