@@ -47,7 +47,8 @@ class Cfg:
     NCOLS: int        # columns of the output tensor (multiple of 256; blockIdx.y picks the 256-column tile)
     stats: int        # 0 none, 1 BN statistics of the output, 2 BN-backward sums
     skew: int = 0     # s_nop-based wave stagger after each barrier (experiment knob)
-    probe: int = 0    # timing probes (WRONG results): 1 no LDS-DMA in the main loop, 2 no fragment reads, 4 no barriers
+    probe: int = 0    # timing probes (WRONG results): 1 no LDS-DMA in the main loop, 2 no fragment reads, 4 no barriers,
+                      # 8 no BN-backward input loads, 16 no statistics arithmetic, 32 no output stores
     WM: int = 2       # waves along the pixel dimension
     WN: int = 2       # waves along the output channels (WM * WN = 4: one wave per SIMD)
     NT: int = 8       # 16-column tiles per wave
@@ -819,6 +820,10 @@ class Gen:
         """BN-backward inputs of tile pair p into register set p & 1"""
         c, e = self.c, self.e
         k = p & 1
+        if c.probe & 8:
+            for i in range(2 * c.MFR + 4):
+                e("s_nop 0")
+            return
         for m in range(c.MFR):
             self.emit_frag(m, set_mask=False)
             e("s_lshr_b32 %s, %s, 4" % (R("s", self.s_t1), R("s", self.s_t0)))
@@ -865,7 +870,7 @@ class Gen:
                     e("v_mov_b32 %s, 0" % R("v", s2[i]))
             if c.stats == 2 and p >= 2:
                 # pair p's loads were issued behind pair p - 2; younger: pair p - 1's stores (+ pair p + 1's loads)
-                e("s_waitcnt vmcnt(%d)" % (c.MFR + (GL if p + 1 < npair else 0)))
+                e("s_waitcnt vmcnt(%d)" % (0 if c.probe & 40 else c.MFR + (GL if p + 1 < npair else 0)))
             for m in range(c.MFR):
                 self.emit_frag(m)
                 d = dsets[m % 4]
@@ -874,16 +879,19 @@ class Gen:
                     e("v_accvgpr_read_b32 %s, a%d" % (R("v", tv[4 + i]), (m * c.NT + 2 * p + 1) * 4 + i))
                 for i in range(4):
                     e("v_cvt_pk_bf16_f32 %s, %s, %s" % (R("v", d + i), R("v", tv[2 * i]), R("v", tv[2 * i + 1])))
-                e("buffer_store_dwordx4 %s, %s, %s, %s offen offset:%d" % (R("v", d, 4), R("v", self.v_out), R("s", self.srdO, 4), R("s", self.s_t0), p * 64))
-                if c.stats:
+                if not (c.probe & 32):
+                    e("buffer_store_dwordx4 %s, %s, %s, %s offen offset:%d" % (R("v", d, 4), R("v", self.v_out), R("s", self.srdO, 4), R("s", self.s_t0), p * 64))
+                else:
+                    e("s_nop 0")
+                if c.stats and not (c.probe & 16):
                     for i in range(4):
                         e("v_lshlrev_b32 %s, 16, %s" % (R("v", xr[2 * i]), R("v", d + i)))
                         e("v_and_b32 %s, 0xffff0000, %s" % (R("v", xr[2 * i + 1]), R("v", d + i)))
-                if c.stats == 1:
+                if c.stats == 1 and not (c.probe & 16):
                     for i in range(8):
                         e("v_add_f32 %s, %s, %s" % (R("v", s1[i]), R("v", s1[i]), R("v", xr[i])))
                         e("v_fma_f32 %s, %s, %s, %s" % (R("v", s2[i]), R("v", xr[i]), R("v", xr[i]), R("v", s2[i])))
-                if c.stats == 2:
+                if c.stats == 2 and not (c.probe & 16):
                     yr, br = ysets[p & 1][m], bsets[p & 1][m]
                     for i in range(8):
                         t = tv[i]  # (the accumulator copies are dead after the conversion)

@@ -89,6 +89,8 @@ struct Arena {
 
 using namespace mi355;
 
+constexpr int MAX_GSETS = 4;
+
 struct mi355_ctx {
   int device = 0, dtype = 0, N = 0, H = 0, W = 0, num_classes = 0, fc_pad = 0;
   size_t es = 4;
@@ -125,7 +127,7 @@ struct mi355_ctx {
   int q_n = 0;
   float* q_scale = nullptr;
   unsigned* q_amax = nullptr;
-  void* gq[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // e4m3 twins of gset
+  void* gq[MAX_GSETS][4] = {};  // e4m3 twins of gset
   bool fp8_fwd_cal = false, fp8_bwd_cal = false;  // a training forward / a whole backward has recorded its amaxes
   bool fp8_fwd_on = false, fp8_bwd_on = false;    // this step's convs read the e4m3 twins
   bool fp8_use_fwd = true, fp8_use_bwd = true;    // MI355_FP8_FWD=0 / MI355_FP8_BWD=0 (read at create): keep that direction on bf16 operands (A/B)
@@ -143,7 +145,9 @@ struct mi355_ctx {
   // gradients (dy3, dy_ds, dy2, dy1) of the blocks of parity p — two sets so that the weight-gradient stream may
   // still be reading block k's gradients while block k+1 is written
   void* gG[2] = {nullptr, nullptr};
-  void* gset[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+  void* gset[MAX_GSETS][4] = {};
+  int nsets = 2;  // gradient buffer sets in rotation (MI355_GSETS, read at ctx creation): the main stream waits for the weight gradients of
+                  // the block that used a set nsets blocks ago
   // weight-gradient side stream (wgrad + split-K reduce run beside the BN-backward / dgrad chain of the main stream)
   bool overlap = false;
   bool fuse_bn_bwd = false;  // BN-backward sums in the dgrad epilogues (MI355_FUSE_BN_BWD=0/1 overrides the default)
@@ -154,9 +158,9 @@ struct mi355_ctx {
   hipStream_t wstream = nullptr;
   std::vector<hipEvent_t> fork_ev;
   size_t fork_next = 0;
-  hipEvent_t w_done[2] = {nullptr, nullptr};
+  hipEvent_t w_done[MAX_GSETS] = {};
   hipEvent_t ds_done = nullptr;  // the downsample branch issued to the side stream has finished
-  bool w_pending[2] = {false, false};
+  bool w_pending[MAX_GSETS] = {};
   bool w_dirty = false;
   int bwd_parity = 0;
   bool fwd_training_done = false;
@@ -343,7 +347,7 @@ int bn_apply(mi355_ctx* c, ConvBN& l, const void* residual, ConvBN* l2, void* ou
 
 // e4m3 twin of one of the per-layer gradient buffers (gset[p][i] -> gq[p][i]); null for any other pointer
 void* grad_twin(const mi355_ctx* c, const void* g) {
-  for (int p = 0; p < 2; ++p)
+  for (int p = 0; p < c->nsets; ++p)
     for (int i = 0; i < 4; ++i)
       if (c->gset[p][i] == g) return c->gq[p][i];
   return nullptr;
@@ -503,10 +507,10 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
   ar.add((void**)&c->bn_coef2, (size_t)3 * max_c * 4);
   ar.add((void**)&c->wg_partial, max_wg);
   for (int i = 0; i < 2; ++i) ar.add(&c->gG[i], max_act);
-  for (int p = 0; p < 2; ++p)
+  for (int p = 0; p < c->nsets; ++p)
     for (int i = 0; i < 4; ++i) ar.add(&c->gset[p][i], max_act);
   if (c->fp8) {
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < c->nsets; ++p)
       for (int i = 0; i < 4; ++i) ar.add(&c->gq[p][i], max_act / c->es);
     ar.add((void**)&c->q_scale, (size_t)c->q_n * 4);
     ar.add((void**)&c->q_amax, (size_t)c->q_n * 4);
@@ -612,7 +616,7 @@ int join(mi355_ctx* c, hipStream_t s) {
   MI355_HIP(hipEventRecord(e, c->wstream));
   MI355_HIP(hipStreamWaitEvent(s, e, 0));
   c->w_dirty = false;
-  c->w_pending[0] = c->w_pending[1] = false;
+  for (int p = 0; p < MAX_GSETS; ++p) c->w_pending[p] = false;
   return 0;
 }
 
@@ -720,7 +724,7 @@ int backward_block(mi355_ctx* c, Block& b, Block* prev, float beta_acc, hipStrea
                           // fly by the three consumers (bn3 / downsample-bn backward, the shortcut add of conv1's dgrad)
   void* Gn = G == c->gG[0] ? c->gG[1] : c->gG[0];
   const int par = c->bwd_parity;
-  c->bwd_parity ^= 1;
+  c->bwd_parity = (par + 1) % c->nsets;
   void** S = c->gset[par];
   void *B1 = S[0], *B2 = S[1], *B3 = S[2], *B4 = S[3];
   hipStream_t ws;
@@ -759,7 +763,7 @@ int backward_block(mi355_ctx* c, Block& b, Block* prev, float beta_acc, hipStrea
 int backward_stem(mi355_ctx* c, float beta_acc, hipStream_t s) {
   void* G = c->cur_dout;  // gradient wrt maxpool output
   const int par = c->bwd_parity;
-  c->bwd_parity ^= 1;
+  c->bwd_parity = (par + 1) % c->nsets;
   void* B1 = c->gset[par][0];
   ConvBN& l = c->stem;
   MI355_TRY(acquire_set(c, par, s));
@@ -881,6 +885,10 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
     c->fp8_use_fwd = !(e && e[0] == '0');
     e = getenv("MI355_FP8_BWD");
     c->fp8_use_bwd = !(e && e[0] == '0');
+  }
+  if (const char* gs = getenv("MI355_GSETS")) {  // A/B knob, read once per ctx (before the workspace is planned)
+    const int v = atoi(gs);
+    if (v >= 2 && v <= MAX_GSETS) c->nsets = v;
   }
   Arena ar;
   plan_arena(c, ar);

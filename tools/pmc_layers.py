@@ -30,7 +30,7 @@ for name, hin, ho, ci, p, ds in reversed(blocks):
 seq.append(("wgrad", "stem.w", None))
 n = len(seq)
 for (kind, name, alg), f, w in zip(seq, fe[-n:], wr[-n:]):
-    assert kind in f["Kernel_Name"] or (kind == "igemm" and "stem_direct_kernel" in f["Kernel_Name"]), (kind, name, f["Kernel_Name"][:50])
+    assert kind in f["Kernel_Name"] or (kind == "igemm" and any(k in f["Kernel_Name"] for k in ("stem_direct_kernel", "dconv_", "pw_k"))), (kind, name, f["Kernel_Name"][:50])
     hbm = (2 * float(f["Counter_Value"]) + float(w["Counter_Value"])) * 1024
     a = f"{alg*ES/1e6:8.1f}" if alg else "       -"
     r = f"{hbm/(alg*ES):5.2f}x" if alg else ""
