@@ -817,9 +817,7 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
 
 size_t igemm_sk_ws_bytes() { return IGEMM_SK_FLAG_BYTES + (size_t)512 * 128 * 128 * sizeof(float); }
 
-// conv3x3.hip: direct 3x3 / stride-1 convolution with 64 channels on both sides (layer 1)
-bool conv3_legal(const IgemmArgs& a, int nclass);
-int launch_conv3(const IgemmArgs& a, hipStream_t stream, int* stat_rows);
+// stem_direct.hip: the stem as a direct convolution
 bool stem_direct_legal(const IgemmArgs& a, int nclass);
 int launch_stem_direct(const IgemmArgs& a, hipStream_t stream, int* stat_rows);
 
@@ -904,11 +902,7 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
     if (dconv_legal(a, nclass)) return launch_dconv(a, nclass, stream, stat_rows);
     if (pw_legal(a, nclass)) return launch_pw(a, nclass, stream, stat_rows);
     {
-      // MI355_CONV3=1: the layer-1 3x3 launches on the direct-convolution kernel (conv3x3.hip).  Bit-exact, and measured no faster
-      // than the 3-workgroups-per-CU implicit-GEMM tile (111 vs 118 us per launch from cold caches, profiles/README.md): off by default.
-      const char* c3 = getenv("MI355_CONV3");
-      if (c3 && c3[0] == '1' && conv3_legal(a, nclass)) return launch_conv3(a, stream, stat_rows);
-      // the stem as a direct convolution out of raw input rows (conv3x3.hip; MI355_STEM_DIRECT=0: the row-pair implicit GEMM)
+      // the stem as a direct convolution out of raw input rows (stem_direct.hip; MI355_STEM_DIRECT=0: the row-pair implicit GEMM)
       const char* sd = getenv("MI355_STEM_DIRECT");
       if (!(sd && sd[0] == '0') && stem_direct_legal(a, nclass)) return launch_stem_direct(a, stream, stat_rows);
     }

@@ -134,10 +134,11 @@ int wanted_stats(const IgemmArgs& a) { return a.stat_partial == nullptr ? 0 : (a
 
 }  // namespace
 
-// MI355_DCONV=0 keeps every launch on the implicit-GEMM kernels (A/B, tests); read once
+// MI355_DCONV=0 keeps every launch on the implicit-GEMM kernels (A/B; read once).  A launch that FORCES an implicit-GEMM tile
+// (MI355_IGEMM8 / MI355_IGEMM_BIG, the per-launch knobs of the tile tests) is left to those kernels too.
 static bool dconv_enabled() {
   static const bool on = !(getenv("MI355_DCONV") && getenv("MI355_DCONV")[0] == '0');
-  return on;
+  return on && getenv("MI355_IGEMM8") == nullptr && getenv("MI355_IGEMM_BIG") == nullptr;
 }
 
 bool pw_legal(const IgemmArgs& a, int nclass) {

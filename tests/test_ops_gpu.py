@@ -118,7 +118,7 @@ def test_stem(dev, dtype, shape):
 
 @pytest.mark.parametrize("shape", [(2, 64, 64), (2, 96, 128), (1, 160, 160), (1, 224, 224), (1, 320, 320)])
 def test_stem_direct_kernel_is_exact_on_integer_data(dev, shape, monkeypatch):
-    """bf16 stem forward: the direct convolution out of raw input rows (csrc/conv3x3.hip stem_direct_kernel, the default) and the
+    """bf16 stem forward: the direct convolution out of raw input rows (csrc/stem_direct.hip stem_direct_kernel, the default) and the
     row-pair implicit GEMM (MI355_STEM_DIRECT=0) on small-integer data, where every fp32 partial sum is exact whatever the
     summation order: both must equal the oracle's result rounded to bf16 BIT for bit (tile shapes: 1 ... 10 fragments per row)."""
     from sota_imagenet_amd import ops
