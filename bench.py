@@ -38,6 +38,37 @@ KERNEL_NAMES = {0: ["igemm_kernel<{T},128,128>", "igemm_kernel<{T},256,256>", "i
                 2: ["wgrad_kernel<{T},128,128>", "wgrad_kernel<{T},128,64>"], 3: ["wgrad_kernel<{T},64,128>", "wgrad_kernel<{T},64,64>"]}
 
 
+def runner_rate(N, S, steps):
+    """img/s of fit_wrapper.Runner.fit (BatchMetrics with Acc@1 / Acc@5, PhasesScheduler) at batch N: the Runner path of train.py"""
+    import time
+
+    import torch
+
+    from sota_imagenet_amd import fit_wrapper as fw
+    from sota_imagenet_amd.data import SyntheticLoader
+    from sota_imagenet_amd.losses import CrossEntropyLoss
+    from sota_imagenet_amd.models import resnet50
+    from sota_imagenet_amd.optim import SGD
+
+    model = resnet50(dtype="bf16").cuda()
+    crit = CrossEntropyLoss(smoothing=0.1).cuda()
+    opt = SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=3e-5)
+    loader = SyntheticLoader(dict(batch_size=N, image_size=S, num_classes=1000), size=N * steps, seed=0, device="cuda", pool=8)
+    cbs = [fw.BatchMetrics([fw.Accuracy(), fw.Accuracy(5)]),
+           fw.PhasesScheduler([{"ep": [0, 1], "lr": [0.001, 0.1], "mode": "linear"}, {"ep": [1, 4], "lr": [0.1, 0.0], "mode": "cos"}])]
+    runner = fw.Runner(model, opt, crit, callbacks=cbs, use_fp16=False)
+    runner.fit(loader, steps_per_epoch=8, epochs=1)  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    runner.fit(loader, steps_per_epoch=steps, epochs=2, start_epoch=1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del runner, model
+    torch.cuda.empty_cache()
+    return {"workload": "fit_wrapper.Runner.fit: the same bf16 step behind the Runner loop (BatchMetrics Acc@1/Acc@5 + PhasesScheduler)",
+            "value": round(N * steps / dt, 1), "unit": "images/sec", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3)}
+
+
 def pmc_traffic(kernels, dtype, batch, size):
     """HBM bytes per launch (launch-weighted over the symbols `kernels`) from the committed rocprofv3 --pmc passes of this
     same command (profiles/*_pmc_traffic_<dtype>.json, made by tools/pmc_traffic.py; PMC cannot be collected from inside
@@ -188,7 +219,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(dtype, steps, warmup, want_roof, N=N, S=S, variant=None):
+    def run(dtype, steps, warmup, want_roof, N=N, S=S, variant=None, extra_mask=0):
         """W untimed + exactly K timed training steps in `dtype`; returns (seconds, final loss, model)."""
         variant = args.model == "bresnet50" if variant is None else variant
         kw = dict(stem_type="deep", antialias=True, attn_type="eca", norm_layer="inplaceabn", norm_act="leaky_relu", drop_rate=0.2,
@@ -238,7 +269,7 @@ def main():
         for i in range(steps):
             if want_roof and i == steps - nprof:
                 # HIP events around the dominant conv class and the largest HBM-bound kernel, inside the timed region
-                model.profile((N, S, S), (1 << dom) | 0b11 | (1 << HBM_CLASS))  # 0b11: both igemm classes (the 3x3 convs)
+                model.profile((N, S, S), (1 << dom) | 0b11 | (1 << HBM_CLASS) | extra_mask)  # 0b11: both igemm classes (the 3x3 convs)
             loss = step(warmup + i)
         fence()
         dt = time.perf_counter() - t0
@@ -300,9 +331,19 @@ def main():
         """the same kernel class with every kernel on one stream (MI355_WGRAD_STREAM=0), untimed extra steps"""
         os.environ["MI355_WGRAD_STREAM"] = "0"
         try:
-            _, _, ms_, dom_s = run(dtype, steps, 2, True)
+            _, _, ms_, dom_s = run(dtype, steps, 2, True, extra_mask=0b1100)  # + the weight-gradient classes (untimed steps: their events cost nothing that is reported)
             t_ms, n_l, fl, _ = ms_.profile_read(shape, FP8_KIND if dtype == "fp8" else dom_s)
             t3, n3, fl3, _ = ms_.profile_read(shape, 8)
+            tw = nw = fw_ = 0.0
+            for cls in (2, 3):
+                t_w, n_w, fl_w, _ = ms_.profile_read(shape, cls)
+                tw, nw, fw_ = tw + t_w, nw + n_w, fw_ + fl_w
+            if tw and dtype != "fp8":
+                # the weight-gradient kernels (the largest symbol of the step): every kernel on one stream, like serial_frac
+                tdt = "float" if dtype == "fp32" else "__bf16"
+                roof["wgrad"] = {"serial_achieved": round(fw_ / (tw * 1e-3) / 1e12, 2), "serial_frac": round(fw_ / (tw * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 4),
+                                 "launches": int(nw), "serial_avg_launch_ms": round(tw / nw, 4),
+                                 "kernel": " + ".join(n.format(T=tdt) for c2 in (2, 3) for n in KERNEL_NAMES[c2])}
             ms_.profile(shape, 0)
             if n_l and (dom_s == roof_class or dtype == "fp8"):
                 roof["serial_frac"] = round(fl / (t_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 4)
@@ -421,6 +462,16 @@ def main():
                                               "final_loss": round(lossb, 4), "step_tflops": round(flb / (dtb / kb) / 1e12, 1)}
             except Exception as e:
                 out["secondary_bresnet50"] = {"error": str(e)[:200]}
+        if world == 1 and not use_ddp and args.dtype == "bf16" and not args.no_secondary and args.model != "bresnet50":
+            # the reference's entry point is pytorch_tools' Runner (/root/reference/train.py:145-173): the same step driven by
+            # fit_wrapper.Runner with BatchMetrics + PhasesScheduler, on the same batch pool — what the loop around the step costs
+            model = None
+            torch.cuda.empty_cache()
+            try:
+                out["secondary_runner"] = runner_rate(N, S, max(10, args.steps))
+                out["secondary_runner"]["vs_value"] = round(out["secondary_runner"]["value"] / out["value"], 4)
+            except Exception as e:
+                out["secondary_runner"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
