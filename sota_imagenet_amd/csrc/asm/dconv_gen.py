@@ -68,8 +68,12 @@ class Cfg:
         return 0
 
     @property
+    def NA(self):     # A buffers: the tile of chunk c + 1 lands while chunk c is computed; one chunk (Cin = 64) needs one buffer
+        return 1 if self.Cin == 64 else 2
+
+    @property
     def BBASE(self):
-        return 2 * self.ABUF
+        return self.NA * self.ABUF
 
     @property
     def SR(self):     # LDS rows per image slot (the halo row between two images is shared)
@@ -123,13 +127,17 @@ class Cfg:
 # LDS: [A buffer 0][A buffer 1][weight ring NB stages]; the statistics scratch reuses the ring
 
 
-def a_rows(c, par):
-    """LDS rows of the A tile of a tile of parity `par`: list of (g, source row constant in bytes | None = stays zero)"""
+NCLS = 3  # tile classes of a row tile: 0 first of its image (the row above is zero halo), 1 middle, 2 last (the row below is)
+
+
+def a_rows(c, cls):
+    """LDS rows of the A tile of a tile of class `cls`: list of (g, source row constant in bytes | None = stays zero).  Row tiles
+    address a window that starts one image row above the tile (srdA), so the constant does not depend on the tile."""
     rows = []
     for g in range(c.LROWS):
         if c.ROWS_T:
-            y = par * c.ROWS_T - 1 + g
-            rows.append((g, y * c.W * c.Cin * 2 if 0 <= y < c.H else None))
+            dead = (cls == 0 and g == 0) or (cls == 2 and g == c.LROWS - 1) or (c.TPI == 1 and g in (0, c.LROWS - 1))
+            rows.append((g, None if dead else g * c.W * c.Cin * 2))
         elif c.IPT == 1:
             rows.append((g, (g - 1) * c.W * c.Cin * 2 if 1 <= g <= c.H else None))
         else:
@@ -139,9 +147,15 @@ def a_rows(c, par):
     return rows
 
 
+def tile_classes(c):
+    if not c.ROWS_T or c.TPI == 1:
+        return [0]
+    return [0, 2] if c.TPI == 2 else [0, 1, 2]
+
+
 def live_rows(c):
     """rows that hold image data in SOME tile parity"""
-    return sorted({g for par in range(c.TPI) for g, src in a_rows(c, par) if src is not None})
+    return sorted({g for cls in tile_classes(c) for g, src in a_rows(c, cls) if src is not None})
 
 
 def a_slots(c):
@@ -173,13 +187,13 @@ def b_piece_const(c, w, i):
 
 
 def tables(c):
-    """[tile parity 0 / 1][wave] -> 64 words: [A LDS offsets][A source constants][B source constants].  A slot whose row holds no
-    data for this wave / parity repeats one of the wave's own pieces of the same variant (same bytes to the same place)."""
+    """[tile class 0 / 1 / 2][wave] -> 64 words: [A LDS offsets][A source constants][B source constants].  A slot whose row holds no
+    data for this wave / class repeats one of the wave's own pieces of the same variant (same bytes to the same place)."""
     sl = a_slots(c)
     bpr = c.P // 8
     out = []
-    for par in range(2):
-        src = dict(a_rows(c, par % c.TPI))
+    for cls in range(NCLS):
+        src = dict(a_rows(c, cls if cls in tile_classes(c) else tile_classes(c)[0]))
         rows = []
         for w in range(4):
             lds, srcs = [], []
@@ -245,7 +259,7 @@ class Gen:
         self.NPA = NPA
         self.APS = (NPA + 7) // 8                    # A pieces issued per first substep of a tap
         self.ATAPS = (NPA + self.APS - 1) // self.APS  # taps whose first substep carries A pieces (<= 8)
-        assert self.ATAPS <= 8 and c.WM * c.WN == 4 and c.TPI in (1, 2)
+        assert (self.ATAPS <= 8 or c.NA == 1) and c.WM * c.WN == 4
 
         # ---- registers ----------------------------------------------------------------------------------------------
         # s[0:1] kernarg, s2 = workgroup id x (tile), s3 = workgroup id y (column tile)
@@ -269,7 +283,7 @@ class Gen:
         if self.tab_sgpr:
             self.s_tbl = S.get(24, 4)
         else:
-            self.s_a, self.s_b, self.s_par = S.get(), S.get(), S.get()
+            self.s_a, self.s_b, self.s_par, self.s_img = S.get(), S.get(), S.get(), S.get()
         self.s_ka = S.get(16, 4)         # the 8 pointers
         self.s_kb = S.get(4, 4)
 
@@ -310,9 +324,9 @@ class Gen:
 
     # -----------------------------------------------------------------------------------------------------------------
     # kernel arguments: 9 pointers (the 9th unused: reserved), 9 weight-tap byte offsets, the chunk count, padding to 128 bytes,
-    # then the per-wave piece tables (2 tile parities x 4 waves x 64 words)
+    # then the per-wave piece tables (3 tile classes x 4 waves x 64 words)
     KA = dict(in_=0, wt=8, out=16, stat=24, bn_y=32, bn_bits=40, bn_mean=48, bn_invstd=56, rsvd=64, wtap=72, nchunks=108,
-              table=128, size=128 + 2 * 4 * 256)
+              table=128, size=128 + NCLS * 4 * 256)
 
     def never_written_blocks(self):
         """1 KiB blocks (relative to an A buffer's base) that no LDS-DMA piece ever writes: halo rows, right padding, the tail"""
@@ -324,7 +338,7 @@ class Gen:
         """blocks of rows that hold data in one tile parity and must be zero in the other (row tiles of an image)"""
         c = self.c
         bpr = c.P // 8
-        dyn = [g for g in live_rows(c) if any(dict(a_rows(c, par))[g] is None for par in range(c.TPI))]
+        dyn = [g for g in live_rows(c) if any(dict(a_rows(c, cls))[g] is None for cls in tile_classes(c))]
         return [(g * bpr + xb) * 1024 for g in dyn for xb in range(bpr) if (g * bpr + xb) * 1024 in written_blocks(c)]
 
     def prologue(self):
@@ -356,10 +370,18 @@ class Gen:
             e("s_add_u32 %s, s0, 128" % R("s", self.srdK))
             e("s_addc_u32 %s, s1, 0" % R("s", self.srdK + 1))
             e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdK + 1), R("s", self.srdK + 1)))
-            e("s_mov_b32 %s, 2048" % R("s", self.srdK + 2))
+            e("s_mov_b32 %s, %d" % (R("s", self.srdK + 2), NCLS * 1024))
             e("s_mov_b32 %s, 0x00020000" % R("s", self.srdK + 3))
-            e("s_and_b32 %s, %s, %d" % (R("s", self.s_par), R("s", self.s_tile), c.TPI - 1))
-            e("s_lshl_b32 %s, %s, 2" % (R("s", t0), R("s", self.s_par)))
+            # tile -> image (s_img), row tile t inside it (s_par), class (first 0 / middle 1 / last 2)
+            magic = ((1 << 32) + c.TPI - 1) // c.TPI
+            e("s_mul_hi_u32 %s, %s, 0x%x" % (R("s", self.s_img), R("s", self.s_tile), magic), "tile / TPI (exact for tiles < 2^32 / TPI)")
+            e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_img), c.TPI))
+            e("s_sub_u32 %s, %s, %s" % (R("s", self.s_par), R("s", self.s_tile), R("s", t0)))
+            e("s_cmp_eq_u32 %s, %d" % (R("s", self.s_par), c.TPI - 1))
+            e("s_cselect_b32 %s, 2, 1" % R("s", t1))
+            e("s_cmp_eq_u32 %s, 0" % R("s", self.s_par))
+            e("s_cselect_b32 %s, 0, %s" % (R("s", t1), R("s", t1)))
+            e("s_lshl_b32 %s, %s, 2" % (R("s", t0), R("s", t1)))
             e("s_add_u32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", self.s_w)))
             e("s_lshl_b32 %s, %s, 8" % (R("s", t0), R("s", t0)))
             e("v_lshl_add_u32 %s, %s, 2, %s" % (R("v", v[3]), R("v", lane), R("s", t0)))
@@ -404,15 +426,20 @@ class Gen:
         # ---- descriptors ------------------------------------------------------------------------------------------
         e("s_waitcnt lgkmcnt(0)")
         self.comment("descriptors: A = this tile's images, B = this column tile's weight rows, O = this tile's output pixels")
-        tile_in = (1 if c.ROWS_T else c.IPT) * c.H * c.W * c.Cin * 2   # the window the A pieces address: the tile's image(s)
         tile_out = c.tile_rows * c.W * c.NCOLS * 2
-        # A
-        s_img = self.s_tile
-        if c.TPI > 1:
-            e("s_lshr_b32 %s, %s, %d" % (R("s", self.s_stg), R("s", self.s_tile), c.TPI.bit_length() - 1))
-            s_img = self.s_stg
-        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", s_img), tile_in))
-        e("s_mul_hi_u32 %s, %s, %d" % (R("s", t1), R("s", s_img), tile_in))
+        rowb = c.W * c.Cin * 2
+        if c.ROWS_T:
+            # A window of a row tile: LROWS image rows starting ONE ROW ABOVE the tile (the first tile of an image never touches
+            # that row, the last never the row below: those table slots repeat another piece).  tile*ROWS_T rows - 1 row, 64-bit
+            tile_in = c.LROWS * rowb
+            e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_tile), c.ROWS_T * rowb))
+            e("s_mul_hi_u32 %s, %s, %d" % (R("s", t1), R("s", self.s_tile), c.ROWS_T * rowb))
+            e("s_sub_u32 %s, %s, %d" % (R("s", t0), R("s", t0), rowb))
+            e("s_subb_u32 %s, %s, 0" % (R("s", t1), R("s", t1)))
+        else:
+            tile_in = c.IPT * c.H * rowb
+            e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_tile), tile_in))
+            e("s_mul_hi_u32 %s, %s, %d" % (R("s", t1), R("s", self.s_tile), tile_in))
         e("s_add_u32 %s, %s, %s" % (R("s", self.srdA), R("s", ka + 0), R("s", t0)))
         e("s_addc_u32 %s, %s, %s" % (R("s", self.srdA + 1), R("s", ka + 1), R("s", t1)))
         e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdA + 1), R("s", self.srdA + 1)))
@@ -437,7 +464,7 @@ class Gen:
             self.b_stage_issue_all(0, 0, self.s_cC)
             if self.dynamic_halo_blocks():
                 # rows that are data in one tile parity and zero halo in the other: zeroed by every tile BEFORE its pieces land
-                self.zero_blocks([c.ABASE + b * c.ASTRIDE + o for b in range(2) for o in self.dynamic_halo_blocks()])
+                self.zero_blocks([c.ABASE + b * c.ASTRIDE + o for b in range(c.NA) for o in self.dynamic_halo_blocks()])
                 e("s_waitcnt lgkmcnt(0)")
                 e("s_barrier")
             for i in range(self.NPA):
@@ -550,7 +577,7 @@ class Gen:
                 e("v_add_u32 %s, %d, %s" % (R("v", self.vB_rd[st][kk]), st * c.BSTAGE, R("v", self.vB_rd[0][kk])))
         # ---- zero the LDS blocks of both A buffers that no DMA piece writes (halo rows, padding): wave w takes blocks w, w+4, ...
         self.comment("zero the never-written blocks of both A buffers")
-        self.zero_blocks([c.ABASE + b * c.ASTRIDE + o for b in range(2) for o in self.never_written_blocks()])
+        self.zero_blocks([c.ABASE + b * c.ASTRIDE + o for b in range(c.NA) for o in self.never_written_blocks()])
         # accumulators = 0
         for i in range(self.nagpr):
             e("v_accvgpr_write_b32 a%d, 0" % i)
@@ -680,13 +707,16 @@ class Gen:
         self.comment("---- main loop: chunks (2 per trip: the A buffer and the weight-stage parity alternate) x 9 taps x 2 substeps")
         top, done = self.newlabel("loop"), self.newlabel("done")
         self.label(top)
-        for cp in range(2):
-            # chunk offsets: current and next (the last chunk re-loads chunk 0: valid memory, never used)
-            e("s_add_u32 %s, %s, 128" % (R("s", self.s_cN), R("s", self.s_cC)))
-            e("s_cmp_eq_u32 %s, 1" % R("s", self.s_cnt))
-            e("s_cbranch_scc0 %s" % (lab := self.newlabel("notlast")))
-            e("s_mov_b32 %s, 0" % R("s", self.s_cN))
-            self.label(lab)
+        for cp in range(c.NA):
+            if c.NA == 1:
+                e("s_mov_b32 %s, 0" % R("s", self.s_cN), "one chunk: the weight stages past the last tap re-load chunk 0 (never used)")
+            else:
+                # chunk offsets: current and next (the last chunk re-loads chunk 0: valid memory, never used)
+                e("s_add_u32 %s, %s, 128" % (R("s", self.s_cN), R("s", self.s_cC)))
+                e("s_cmp_eq_u32 %s, 1" % R("s", self.s_cnt))
+                e("s_cbranch_scc0 %s" % (lab := self.newlabel("notlast")))
+                e("s_mov_b32 %s, 0" % R("s", self.s_cN))
+                self.label(lab)
             for t in range(9):
                 bp = (cp * 9 + t) % c.NB          # ring stage of (chunk parity, tap): 9 % 3 == 0, so NB = 3 does not depend on cp
                 bp1 = (cp * 9 + t + 1) % c.NB     # ... of the next stage
@@ -695,7 +725,7 @@ class Gen:
                 e("s_waitcnt lgkmcnt(0)")
                 groups = [[r] for r in self.frag_reads(1, t, 1, bp)]
                 mf = self.mfmas(0)
-                pieces = [self.a_piece_insts(k, cp ^ 1, self.s_cN) for k in range(t * self.APS, min((t + 1) * self.APS, self.NPA))]
+                pieces = [self.a_piece_insts(k, cp ^ 1, self.s_cN) for k in range(t * self.APS, min((t + 1) * self.APS, self.NPA))] if c.NA == 2 else []
                 if c.probe & 1:
                     pieces = []
                 if c.probe & 2:
@@ -705,7 +735,7 @@ class Gen:
                 self.comment("chunk parity %d tap %d substep 1" % (cp, t))
                 # younger than stage t+1's pieces: the weight groups of stages t+2 .. t+NB-1 and the A pieces issued since; at tap 8
                 # the A pieces must have landed too (they are older than those groups: NPA <= 8)
-                npc = lambda j: max(0, min((j + 1) * self.APS, self.NPA) - j * self.APS) if j >= 0 else 0
+                npc = lambda j: max(0, min((j + 1) * self.APS, self.NPA) - j * self.APS) if (j >= 0 and c.NA == 2) else 0
                 ayoung = sum(npc(j) for j in range(t + 2 - c.NB, t + 1))
                 e("s_waitcnt vmcnt(%d)" % (c.NPB * (c.NB - 2) + (ayoung if t < 8 else 0)))
                 e("s_waitcnt lgkmcnt(0)")
@@ -713,7 +743,7 @@ class Gen:
                     e("s_barrier")
                 self.skew()
                 t2 = (t + 1) % 9
-                if t == 8:  # next chunk: the A bases move to the other buffer
+                if t == 8 and c.NA == 2:  # next chunk: the A bases move to the other buffer
                     d = c.ASTRIDE if cp == 0 else -c.ASTRIDE
                     for kx in range(3):
                         for kk in range(2):
@@ -735,6 +765,8 @@ class Gen:
                 if c.probe & 2:
                     groups = []
                 self.interleave(mf, self.merge(groups, pieces))
+            if c.NA == 1:
+                break
             # next chunk
             e("s_mov_b32 %s, %s" % (R("s", self.s_cC), R("s", self.s_cN)))
             e("s_sub_u32 %s, %s, 1" % (R("s", self.s_cnt), R("s", self.s_cnt)))
@@ -967,7 +999,7 @@ class Gen:
     def finish(self):
         c = self.c
         name = c.name
-        lds = 2 * c.ABUF + c.NB * c.BSTAGE  # two A buffers, the weight ring
+        lds = c.NA * c.ABUF + c.NB * c.BSTAGE  # the A buffer(s), the weight ring
         assert lds <= 160 * 1024
         total_v = self.accum_offset + self.nagpr
         hdr = []
@@ -1047,6 +1079,11 @@ VARIANTS = {
     "dconv_l2_s0": Cfg("dconv_l2_s0", H=28, W=28, P=32, IPT=1, Cin=128, NCOLS=128, stats=0, WM=4, WN=1, ROWS_T=14),
     "dconv_l2_s1": Cfg("dconv_l2_s1", H=28, W=28, P=32, IPT=1, Cin=128, NCOLS=128, stats=1, WM=4, WN=1, ROWS_T=14),
     "dconv_l2_s2": Cfg("dconv_l2_s2", H=28, W=28, P=32, IPT=1, Cin=128, NCOLS=128, stats=2, WM=4, WN=1, ROWS_T=14),
+    # layer 1 (56 x 56 x 64 -> 64): a tile = 4 output rows (14 per image), one 64-channel chunk, 64 columns: 64 KiB of LDS and
+    # <= 256 registers, so TWO workgroups share a CU and cover each other's prologue / epilogue
+    "dconv_l1_s0": Cfg("dconv_l1_s0", H=56, W=56, P=64, IPT=1, Cin=64, NCOLS=64, stats=0, WM=4, WN=1, NT=4, ROWS_T=4),
+    "dconv_l1_s1": Cfg("dconv_l1_s1", H=56, W=56, P=64, IPT=1, Cin=64, NCOLS=64, stats=1, WM=4, WN=1, NT=4, ROWS_T=4),
+    "dconv_l1_s2": Cfg("dconv_l1_s2", H=56, W=56, P=64, IPT=1, Cin=64, NCOLS=64, stats=2, WM=4, WN=1, NT=4, ROWS_T=4),
 }
 
 
@@ -1076,7 +1113,7 @@ def main():
         if a.suffix:  # tuning builds: the per-wave table as a raw file for tools/micro/dconv_bench.cpp
             import struct
             with open(os.path.join(a.out, name + ".tbl"), "wb") as f:
-                f.write(struct.pack("<512I", *[w for par in tables(c) for row in par for w in row]))
+                f.write(struct.pack("<768I", *[w for par in tables(c) for row in par for w in row]))
         with open(os.path.join(a.out, name + ".s"), "w") as f:
             f.write(text)
         print("%s: %d lines, %d VGPR + %d AGPR, %d SGPR, LDS %d" % (name, text.count("\n"), g.accum_offset, g.nagpr, g.S.n, g.lds_bytes))

@@ -102,6 +102,7 @@ struct IgemmArgs {
   void* out;           // [N][Hout][Wout][Ncols]
   const void* addend;  // optional, laid out like out
   const uint8_t* addend_bits = nullptr;  // optional ReLU mask of the addend (1 byte per 16-byte vector): masked before the add
+  int stat_rows_cap = 0;  // rows `stat_partial` can hold (0: the per-op API's 768); a launch never writes more partial rows than this
   float* stat_partial; // optional [stat_rows][2][Ncols]: per-workgroup-row sums of out and out^2 (BN statistics), or,
                        // when bn_y is set, of dz and dz*xhat (BN backward of the layer whose activation gradient `out`
                        // is): dz = out under the ReLU mask bn_bits, xhat = (bn_y - bn_mean) * bn_invstd

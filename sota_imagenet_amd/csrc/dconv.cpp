@@ -14,7 +14,7 @@ namespace {
 struct DconvVariant {
   const char* name;
   int H, W, IPT, TPI, BN, Cin, NCOLS, stats, lds, kernarg;  // IPT images per tile, or TPI tiles per image; BN columns per workgroup
-  unsigned table[2 * 4 * 64];  // [tile parity][wave] LDS-DMA piece tables (asm/dconv_gen.py tables())
+  unsigned table[3 * 4 * 64];  // [tile class][wave] LDS-DMA piece tables (asm/dconv_gen.py tables())
 };
 
 const DconvVariant g_variants[] = {
@@ -191,8 +191,8 @@ bool dconv_legal(const IgemmArgs& a, int nclass) {
   if (!dconv_enabled()) return false;
   const int v = find_variant(a, nclass, wanted_stats(a));
   if (v < 0) return false;
-  // one partial statistics row per tile: bn_finalize adds at most bn_max_blocks() rows
-  if (a.stat_partial != nullptr && a.N * g_variants[v].TPI / g_variants[v].IPT > (bn_max_blocks() < 768 ? bn_max_blocks() : 768)) return false;  // (768: the per-op API's buffer)
+  // one partial statistics row per tile: the caller's buffer must hold them (bn_finalize adds any number of rows, 512 per pass)
+  if (a.stat_partial != nullptr && a.N * g_variants[v].TPI / g_variants[v].IPT > (a.stat_rows_cap > 0 ? a.stat_rows_cap : 768)) return false;
   return true;
 }
 
@@ -217,9 +217,9 @@ int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_r
     unsigned wtap_off[9];
     unsigned nchunks;
     unsigned pad[4];
-    unsigned table[512];  // [tile parity][wave][64] LDS-DMA piece tables
+    unsigned table[768];  // [tile class][wave][64] LDS-DMA piece tables
   } k;
-  static_assert(sizeof(KArgs) == 128 + 2048, "kernarg layout of asm/dconv_gen.py (Gen.KA)");
+  static_assert(sizeof(KArgs) == 128 + 3072, "kernarg layout of asm/dconv_gen.py (Gen.KA)");
   MI355_ARG((int)sizeof(KArgs) == v.kernarg, "dconv: kernarg size mismatch");
   k.in = a.in;
   k.wt = a.wt;

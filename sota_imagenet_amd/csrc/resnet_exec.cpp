@@ -146,6 +146,7 @@ struct mi355_ctx {
   // still be reading block k's gradients while block k+1 is written
   void* gG[2] = {nullptr, nullptr};
   void* gset[MAX_GSETS][4] = {};
+  size_t max_c = 64;  // widest BatchNorm of the network (sizes bn_partial)
   int nsets = 2;  // gradient buffer sets in rotation (MI355_GSETS, read at ctx creation): the main stream waits for the weight gradients of
                   // the block that used a set nsets blocks ago
   // weight-gradient side stream (wgrad + split-K reduce run beside the BN-backward / dgrad chain of the main stream)
@@ -281,6 +282,7 @@ int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, float mo
   build_fwd_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
   a.in = in;
   a.stat_partial = training ? bn_partial_of(c, s) : nullptr;
+  a.stat_rows_cap = (int)((size_t)bn_max_blocks() * c->max_c / l.Cout);  // the scratch holds bn_max_blocks() rows of the widest layer
   if (training) a.fin = fin_fwd(c, l, momentum, s);
   l.fin_done = false;
   a.sk_ws = sk_ws_of(c, s);
@@ -420,6 +422,7 @@ int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* ad
   a.sk_ws = sk_ws_of(c, s);
   if (bn && c->fuse_bn_bwd) {
     a.stat_partial = bn_partial_of(c, s);
+    a.stat_rows_cap = (int)((size_t)bn_max_blocks() * c->max_c / bn->Cout);
     a.bn_y = bn->y; a.bn_bits = bn_bits; a.bn_mean = bn->stat; a.bn_invstd = bn->stat + bn->Cout;
     a.fin = fin_bwd(c, *bn, beta_acc, s);
     bn->bwd_fin_done = false;
@@ -444,7 +447,7 @@ int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* ad
 
 int plan_arena(mi355_ctx* c, Arena& ar) {
   const int N = c->N;
-  size_t max_act = 0, max_wg = 0, max_c = 64;
+  size_t max_act = 0, max_wg = 0, max_c = 64;  // (max_c is kept in the ctx: conv launches derive their partial-row capacity from it)
   auto conv_ws = [&](ConvBN& l) {
     ar.add(&l.y, act_bytes(c, l.Hout, l.Wout, l.Cout));
     ar.add((void**)&l.stat, (size_t)4 * l.Cout * 4);
@@ -498,6 +501,7 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
     max_wg = std::max(max_wg, (size_t)fsplits * fcp * 2048 * 4);
   }
   for (int i = 0; i < 2; ++i) ar.add((void**)&c->prep_table[i], (size_t)64 * sizeof(PrepDesc));
+  c->max_c = max_c;
   ar.add((void**)&c->bn_partial, (size_t)bn_max_blocks() * 2 * max_c * 4);
   ar.add((void**)&c->bn_coef, (size_t)3 * max_c * 4);
   for (int i = 0; i < 2; ++i) ar.add(&c->sk_ws[i], igemm_sk_ws_bytes());

@@ -29,6 +29,8 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang"
     ("dconv_l4_s2", dict(Cin=128, tiles=(1,))),
     ("dconv_l2_s1", dict(Cin=128, tiles=(0, 1))),                                      # half-image tiles: both parities, 4 x 1 waves
     ("dconv_l2_s2", dict(Cin=64, tiles=(3,), dgrad_taps=True)),
+    ("dconv_l1_s1", dict(tiles=(0, 1, 13))),                                           # 14 row tiles per image: first / middle / last, one chunk
+    ("dconv_l1_s2", dict(tiles=(14, 27), dgrad_taps=True)),
 ])
 def test_direct_conv_kernels_are_exact_in_the_emulator(name, kw):
     r = D.run(name, **kw)

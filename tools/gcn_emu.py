@@ -483,6 +483,12 @@ class Emulator:
 
     i_s_sub_i32 = i_s_sub_u32
 
+    def i_s_subb_u32(self, wv, ins):
+        a, b = self._s2(wv, ins)
+        r = a - b - wv.scc
+        wv.scc = 1 if r < 0 else 0
+        self.swrite(wv, ins.ops[0], r, ins)
+
     def i_s_mul_i32(self, wv, ins):
         a, b = self._s2(wv, ins)
         self.swrite(wv, ins.ops[0], a * b, ins)

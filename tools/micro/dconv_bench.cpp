@@ -36,10 +36,10 @@ int main(int argc, char** argv) {
   hipFunction_t fn;
   CK(hipModuleLoad(&mod, hsaco));
   CK(hipModuleGetFunction(&fn, mod, kname));
-  unsigned tbl[512];
+  unsigned tbl[768];
   memset(tbl, 0, sizeof(tbl));
   FILE* f = fopen(tblf, "rb");
-  if (!f || fread(tbl, 4, 512, f) < 128) {
+  if (!f || fread(tbl, 4, 768, f) < 128) {
     fprintf(stderr, "cannot read %s\n", tblf);
     return 1;
   }
@@ -74,7 +74,7 @@ int main(int argc, char** argv) {
     unsigned wtap_off[9];
     unsigned nchunks;
     unsigned pad[4];
-    unsigned table[512];
+    unsigned table[768];
   } k;
   memset(&k, 0, sizeof(k));
   k.wt = d_wt;
