@@ -991,7 +991,17 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
   const char* ov = getenv("MI355_WGRAD_STREAM");
   c->overlap = !(ov && ov[0] == '0');
   if (c->overlap) {
-    bool ok = hipStreamCreateWithFlags(&c->wstream, hipStreamNonBlocking) == hipSuccess;
+    // the weight-gradient stream runs at the highest priority: it is the busier of the two during backward and the main stream ends
+    // up waiting for it (profiles/r04_ab_side_stream_priority.txt: -0.07..-0.13 ms per step on three boxes); MI355_SIDE_PRIO=0 restores
+    // the default priority, 1 selects the lowest
+    bool ok;
+    {
+      const char* sp = getenv("MI355_SIDE_PRIO");
+      int want = sp ? atoi(sp) : -1, lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      ok = want == 0 ? hipStreamCreateWithFlags(&c->wstream, hipStreamNonBlocking) == hipSuccess
+                     : hipStreamCreateWithPriority(&c->wstream, hipStreamNonBlocking, want < 0 ? hi : lo) == hipSuccess;
+    }
     c->fork_ev.resize(16);
     for (auto& ev : c->fork_ev) ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
     for (auto& ev : c->w_done) ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
