@@ -255,18 +255,33 @@ class _Bottleneck(nn.Module):
         return _ResidualActFn.apply(out, sc, keep, LEAKY_ACT)
 
 
-class BResNet50Graph(nn.Module):
+class _DropStream:
+    """position of the drop-connect / dropout generator, shared by the two BResNet-50 forms: the stream is keyed by (seed, step).
+    `reseed` gives every (run seed, rank) its own stream (the reference draws from per-process torch generators, so ranks must not
+    share keep vectors); `set_drop_position` makes the counter a function of (epoch, step) so a resumed run continues the sequence
+    instead of replaying it.  The Runner calls both (fit_wrapper.Runner.fit / _run_loader); a `seed=` given to the constructor stays."""
+
+    def reseed(self, random_seed, rank):
+        if not self._seed_given:
+            self.seed = (int(random_seed or 0) * 1000003 + int(rank) * 7919 + 54321) & 0x7FFFFFFF
+
+    def set_drop_position(self, epoch, step=0):
+        self._step = (int(epoch) << 32) | int(step)
+
+
+class BResNet50Graph(_DropStream, nn.Module):
     """the round-2 form: this graph driven from Python, one C-ABI call per op through torch.autograd nodes.  Kept as the
     cross-check of the static executor (tests/test_variant_gpu.py: same kernels in the same order => same bits up to the FC)."""
 
-    def __init__(self, num_classes=1000, dtype="bf16", drop_rate=0.0, drop_connect_rate=0.0, weight_standardization=False, seed=0, **kw):
+    def __init__(self, num_classes=1000, dtype="bf16", drop_rate=0.0, drop_connect_rate=0.0, weight_standardization=False, seed=None, **kw):
         super().__init__()
         unknown = set(kw) - {"pretrained", "stem_type", "antialias", "attn_type", "norm_layer", "norm_act"}
         if unknown:
             raise TypeError(f"bresnet50: unsupported arguments {sorted(unknown)}")
         self._dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}[str(dtype)]
         S = weight_standardization
-        self.num_classes, self.drop_rate, self.drop_connect_rate, self.seed = num_classes, float(drop_rate), float(drop_connect_rate), int(seed)
+        self.num_classes, self.drop_rate, self.drop_connect_rate, self.seed = num_classes, float(drop_rate), float(drop_connect_rate), int(seed or 0)
+        self._seed_given = seed is not None
         self.conv1 = nn.Sequential(_Conv(3, 32, 3, 2, S), _ABN(32, LEAKY_ACT), _Conv(32, 32, 3, 1, S), _ABN(32, LEAKY_ACT), _Conv(32, 64, 3, 1, S))
         self.bn1 = _ABN(64, LEAKY_ACT)
         cin = 64
@@ -361,12 +376,12 @@ def _layout(dtype_code, num_classes, wstd):
         L.mi355_bresnet50_destroy(ctx)
 
 
-class BResNet50(_FlatModel):
+class BResNet50(_DropStream, _FlatModel):
     """BResNet-50 on the static executor (csrc/bresnet_exec.cpp): forward and backward are ONE C-ABI call each; every parameter
     (pytorch_tools names / shapes, see the module docstring) is a view into one flat fp32 array, so the native SGD and the flat
     gradient all-reduce apply as they do to models.ResNet50.  No CPU path: a CPU tensor raises."""
 
-    def __init__(self, num_classes=1000, dtype="bf16", drop_rate=0.0, drop_connect_rate=0.0, weight_standardization=False, seed=0, **kw):
+    def __init__(self, num_classes=1000, dtype="bf16", drop_rate=0.0, drop_connect_rate=0.0, weight_standardization=False, seed=None, **kw):
         super().__init__()
         unknown = set(kw) - {"pretrained", "stem_type", "antialias", "attn_type", "norm_layer", "norm_act"}
         if unknown:
@@ -377,7 +392,8 @@ class BResNet50(_FlatModel):
             raise ValueError(f"bresnet50: dtype {dtype!r} (bf16 | fp32; the fp8 step exists for the torchvision-layout resnet50 only)")
         self.compute_dtype = _DT[str(dtype)]
         self._dt = native.dtype_code(self.compute_dtype)
-        self.num_classes, self.drop_rate, self.drop_connect_rate, self.seed = int(num_classes), float(drop_rate), float(drop_connect_rate), int(seed)
+        self.num_classes, self.drop_rate, self.drop_connect_rate, self.seed = int(num_classes), float(drop_rate), float(drop_connect_rate), int(seed or 0)
+        self._seed_given = seed is not None
         self.weight_standardization = bool(weight_standardization)
         self._table, self._nparam, self._nbuf = _layout(self._dt, self.num_classes, self.weight_standardization)
         self._segments = [(0, self._nparam)]  # one backward call completes every gradient
@@ -441,8 +457,11 @@ class BResNet50(_FlatModel):
             if not self._flat_params.is_cuda:
                 raise RuntimeError("bresnet50: the MI355X hot path has no CPU fallback — call .cuda() first")
             if len(self._ctxs) >= 2:  # train + val batch shapes (each holds every activation AND every gradient: 50 GB at 256 x 224 px)
-                _, old = self._ctxs.popitem(last=False)
-                native.lib().mi355_bresnet50_destroy(old)
+                pending = getattr(self, "_last", None)
+                for k in list(self._ctxs):  # oldest first; the context a pending backward will use is never the one to go
+                    if pending is None or self._ctxs[k] is not pending[0]:
+                        native.lib().mi355_bresnet50_destroy(self._ctxs.pop(k))
+                        break
             L = native.lib()
             c = ctypes.c_void_p()
             dev = self._flat_params.device.index or 0
@@ -464,7 +483,9 @@ class BResNet50(_FlatModel):
         N, _, H, W = x.shape
         c = self._ctx(N, H, W)
         L = native.lib()
-        sample = bool(self.training and torch.is_grad_enabled() and self.masks is None)  # draw drop-connect / dropout on the device
+        # draw drop-connect / dropout on the device: decided by `training` (True only on the autograd training path — grad mode itself
+        # reads False inside autograd.Function.forward, so it cannot be asked here)
+        sample = bool(training and self.training and self.masks is None)
         native.check(L.mi355_bresnet50_set_drop(c, self.drop_rate, self.drop_connect_rate, self.seed))
         keep_arr, do_ptr, alive = None, None, []
         if not sample:  # given masks (test hook), or none at all (eval / no_grad): the generator stays off
@@ -483,19 +504,25 @@ class BResNet50(_FlatModel):
         logits = torch.empty((N, self.num_classes), dtype=torch.float32, device=x.device)
         native.check(L.mi355_bresnet50_forward(c, native.ptr(x), native.ptr(logits), int(bool(self.training)), self.bn_momentum(), self._step, keep_arr,
                                                do_ptr, native.cur_stream()))
-        self._last = (c, x, alive)  # keep the input (and the mask tensors: copied on the stream) alive until backward
+        if training:
+            self._last = (c, x, alive)  # keep the input (and the mask tensors: copied on the stream) alive until backward
+        else:
+            self._eval_alive = (x, alive)  # (an eval forward between a training forward and its backward leaves that pair alone)
         if self.training:
             self._nbt += 1
-            if torch.is_grad_enabled():
+            if training:
                 self._step += 1
         return logits
 
     def _native_backward(self, dlogits):
         from . import native
 
+        if getattr(self, "_last", None) is None:
+            raise RuntimeError("bresnet50: backward without a pending training forward")
         c = self._last[0]
         self._attach_grads()
         native.check(native.lib().mi355_bresnet50_backward(c, native.ptr(dlogits.contiguous()), int(self._grads_dirty), native.cur_stream()))
+        self._last = None  # the context may be evicted again
         if self._grad_sync is not None and self._sync_grads:
             self._grad_sync(0, 0, self._nparam)
         self._grads_dirty = True
@@ -507,7 +534,7 @@ class BResNet50(_FlatModel):
     def forward(self, x):
         if self.training and torch.is_grad_enabled():
             return _ResNetFn.apply(x, self._hook, self)
-        return self._native_forward(x, training=self.training)
+        return self._native_forward(x, training=False)  # eval, or train mode under no_grad: batch statistics as the mode says, no drops
 
     def flops(self, N, H, W):
         """(forward, training) algorithmic FLOPs of one step at this shape (2 FLOP/MAC, conv + FC)"""

@@ -76,7 +76,7 @@ class Mixup(Callback):
     def on_loader_begin(self):
         # the sampler's position is a function of (epoch, step): a resumed run continues the sequence instead of replaying it
         if self.state.is_train and self.state.epoch_size:
-            self._dev.counter = int(self.state.epoch) * int(self.state.epoch_size)
+            self._dev.counter = int(self.state.epoch) << 32  # (epoch, step) kept apart: epoch_size changes between progressive-resize stages
 
     def _onehot(self, target):
         if target.dim() == 1:

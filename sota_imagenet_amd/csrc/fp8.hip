@@ -93,6 +93,14 @@ int mi355_quantize_fp8(int src_dtype, const void* x, void* q, float scale, size_
   return 0;
 }
 
+}  // extern "C"
+
+__global__ void set_two_scalars(float* p, float a, float b) {
+  if (threadIdx.x == 0) { p[0] = a; p[1] = b; }
+}
+
+extern "C" {
+
 int mi355_conv2d_fwd_fp8(const void* xq, const void* wq, void* y, float oscale, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                          int pad, void* stream) {
   MI355_ARG(xq && wq && y && Cin % 128 == 0 && Cout % 128 == 0 && KH * KW <= 9 && (stride == 1 || stride == 2), "conv2d_fwd_fp8: Cin=%d Cout=%d (multiples of 128)", Cin, Cout);
@@ -116,8 +124,8 @@ int mi355_conv2d_wgrad_fp8(const void* dyq, const void* xq, float* dw, float bet
   MI355_TRY(launch_wgrad(MI355_FP8, a, splits, s));
   // the per-op form takes host scales: park 1 / oscale and 1 behind the partial slabs as the two device scalars the reduce reads
   float* sc = (float*)((char*)ws + (size_t)splits * n * 4);
-  const float host[2] = {1.f / oscale, 1.f};
-  MI355_HIP(hipMemcpyAsync(sc, host, sizeof(host), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(set_two_scalars, dim3(1), dim3(64), 0, s, sc, 1.f / oscale, 1.f);  // (values travel as kernel arguments: no host buffer outlives the call)
+  MI355_HIP(hipGetLastError());
   return launch_splitk_reduce((const float*)ws, splits, n, dw, n, beta, s, sc, sc + 1);
 }
 

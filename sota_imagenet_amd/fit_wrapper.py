@@ -435,6 +435,9 @@ class Runner:
     def fit(self, train_loader, steps_per_epoch=None, val_loader=None, val_steps=None, epochs=1, start_epoch=0):
         self.state.num_epochs = epochs
         self.state.batch_size = getattr(train_loader, "batch_size", 1)
+        m = _unwrap(self.state.model)
+        if hasattr(m, "reseed"):  # device-side drop-connect / dropout: one stream per (run seed, rank), like CutmixMixup
+            m.reseed(self.state.random_seed, self.state.rank)
         self.callbacks.on_begin()
         for epoch in range(start_epoch, epochs):
             self.state.is_train = True
@@ -485,6 +488,9 @@ class Runner:
         for m in self.state.metric_meters.values():
             m.reset()
         self.state.epoch_size = steps or len(loader)
+        m = _unwrap(self.state.model)
+        if self.state.is_train and hasattr(m, "set_drop_position"):  # (epoch, step) -> generator position: a resumed run does not replay masks
+            m.set_drop_position(self.state.epoch, 0)
         self.callbacks.on_loader_begin()
         with torch.set_grad_enabled(self.state.is_train):
             for i, batch in enumerate(loader):

@@ -74,13 +74,19 @@ def conv2d_dgrad_fp8(dyq, wq, x_shape, stride=1, pad=0, oscale=1.0, wt=None):
     return dx
 
 
+_WGRAD_WS = {}
+
+
 def conv2d_wgrad_fp8(dyq, xq, KH, KW, stride=1, pad=0, oscale=1.0):
     """fp32 dw [Cout,KH,KW,Cin] = oscale * sum_pixels dyq (x) xq from e4m3 dy (NHWC) and x (NHWC) on the fp8 MFMA path."""
     _need_cuda(dyq, xq)
     N, H, W, Cin = xq.shape
     Cout = dyq.shape[-1]
     n = _L().mi355_conv2d_workspace_bytes(native.BF16, N, H, W, Cin, Cout, KH, KW, stride, pad)
-    ws = torch.empty(n + 256, dtype=torch.uint8, device=dyq.device)  # split-K slabs + the two scale words
+    key = (dyq.device, n)
+    ws = _WGRAD_WS.get(key)  # split-K slabs + the two scale words: one workspace per (device, size), reused on the caller's stream
+    if ws is None:
+        ws = _WGRAD_WS[key] = torch.empty(n + 256, dtype=torch.uint8, device=dyq.device)
     dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=dyq.device)
     check(_L().mi355_conv2d_wgrad_fp8(ptr(dyq), ptr(xq), ptr(dw), 0.0, float(oscale), N, H, W, Cin, Cout, KH, KW, stride, pad, ptr(ws), n + 256, cur_stream()))
     return dw

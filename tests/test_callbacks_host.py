@@ -84,7 +84,7 @@ def test_device_sampler_stream_is_per_seed_rank_and_epoch():
     assert a._dev.seed == b._dev.seed
     sa.epoch, sa.epoch_size = 3, 100
     a.on_loader_begin()
-    assert a._dev.counter == 300  # a resumed run continues the sequence
+    assert a._dev.counter == 3 << 32  # a resumed run continues the sequence; epochs of different lengths cannot overlap
     sa.is_train = False
     a._dev.counter = 7
     a.on_loader_begin()

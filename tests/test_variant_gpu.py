@@ -196,6 +196,67 @@ def test_bresnet50_bf16_trains(dev):
     assert e.shape == (4, 1000) and torch.isfinite(e).all()
 
 
+def test_static_executor_samples_drop_connect_and_dropout(dev):
+    """training through autograd (the Runner's path): the executor draws drop-connect / dropout itself.  Two training forwards of one
+    batch differ (the generator position advances), the position is reproducible (set_drop_position), (run seed, rank) selects the
+    stream (reseed), rates of 0 give bit-equal logits, and the per-op graph — which draws the same keep_scale vectors from Python —
+    lands on the same logits."""
+    from sota_imagenet_amd.bresnet import BResNet50, BResNet50Graph
+    from sota_imagenet_amd.synth import synthetic_batch
+
+    N, S = 8, 64
+    kw = dict(dtype="fp32", drop_rate=0.2, drop_connect_rate=0.2, weight_standardization=False)
+    m, g = BResNet50(**kw), BResNet50Graph(**kw)
+    g.load_state_dict({k: v.detach().clone().contiguous() for k, v in m.state_dict().items()})
+    m, g = m.cuda().train(), g.cuda().train()
+    data, _ = synthetic_batch(N, S, seed=0, index=1, device="cuda")
+    for mod in (m, g):
+        mod.reseed(7, 0)
+        mod.set_drop_position(3, 0)
+    a0 = m(data).detach().clone()
+    assert m._step == (3 << 32) + 1
+    a1 = m(data).detach().clone()
+    assert m._step == (3 << 32) + 2
+    assert not torch.equal(a0, a1), "drop-connect / dropout were not sampled"
+    assert ((a0 - a1).norm() / a0.norm()).item() > 1e-2
+    g0 = g(data).detach()
+    assert nerr(a0, g0) < 1e-4, f"executor vs per-op graph under the same generator position: {nerr(a0, g0):.2e}"
+    m.set_drop_position(3, 0)  # same position, same masks (batch statistics do not depend on the running buffers)
+    assert torch.equal(m(data).detach(), a0)
+    m.reseed(7, 1)  # another rank: another stream
+    m.set_drop_position(3, 0)
+    assert not torch.equal(m(data).detach(), a0)
+    with torch.no_grad():  # train mode without autograd: batch statistics, no drops, the position stays
+        before = m._step
+        n0, n1 = m(data).clone(), m(data).clone()
+    assert torch.equal(n0, n1) and m._step == before
+    z = BResNet50(dtype="fp32").cuda().train()
+    z0, z1 = z(data).detach().clone(), z(data).detach().clone()
+    assert torch.equal(z0, z1)
+    s = BResNet50(dtype="fp32", drop_rate=0.2, seed=5)  # an explicit seed stays
+    s.reseed(7, 1)
+    assert s.seed == 5
+
+
+def test_runner_positions_the_drop_generator(dev):
+    """fit_wrapper.Runner gives the model its (run seed, rank) stream and the (epoch, step) position: epoch 1 of a resumed run does not
+    replay the masks of epoch 0"""
+    from sota_imagenet_amd.bresnet import BResNet50
+    from sota_imagenet_amd.fit_wrapper import Runner
+    from sota_imagenet_amd.losses import CrossEntropyLoss
+    from sota_imagenet_amd.optim import SGD
+    from sota_imagenet_amd.data import SyntheticLoader
+
+    m = BResNet50(dtype="bf16", drop_rate=0.2, drop_connect_rate=0.2).cuda()
+    opt = SGD([{"params": list(m.parameters())}], lr=0.0, momentum=0.0, weight_decay=0.0)
+    r = Runner(m, opt, CrossEntropyLoss(smoothing=0.1))
+    r.state.random_seed = 11
+    loader = SyntheticLoader(dict(batch_size=4, image_size=64, num_classes=1000), size=8, seed=0, device="cuda", pool=2)
+    r.fit(loader, steps_per_epoch=2, epochs=2, start_epoch=1)
+    assert m.seed == (11 * 1000003 + 54321) & 0x7FFFFFFF
+    assert m._step == (1 << 32) + 2
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("wstd", [True, False])
 def test_static_executor_matches_the_per_op_graph(dev, dtype, wstd, monkeypatch):
