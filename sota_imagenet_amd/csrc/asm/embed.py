@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """embed.py <out dir> <linked .hsaco> — writes the include files dconv.cpp embeds: the code object as a byte array
-(dconv_blob.inc) and one initialiser per generated kernel (dconv_meta.inc: direct 3x3 kernels, pw_meta.inc: pointwise)."""
+(dconv_blob.inc) and one initialiser per generated kernel (dconv_meta.inc: direct 3x3 kernels, pw_meta.inc: pointwise, wg_meta.inc: 3x3 weight gradient)."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import dconv_gen  # noqa: E402
 import pw_gen  # noqa: E402
+import wg_gen  # noqa: E402
 
 
 def main():
@@ -25,6 +26,11 @@ def main():
             c, g, _ = pw_gen.generate(name)
             words = ",".join("%du" % w for row in pw_gen.tables(c) for w in row)
             f.write('{"%s", %d, %d, %d, %d, %d, %d, {%s}},\n' % (name, c.K, c.N, c.stats, c.ROWS, c.LDS, pw_gen.Gen.KA["size"], words))
+    with open(os.path.join(out_dir, "wg_meta.inc"), "w") as f:
+        for name in wg_gen.VARIANTS:
+            c, g, _ = wg_gen.generate(name)
+            tn, ti = c.TPI_NUM
+            f.write('{"%s", %d, %d, %d, %d, %d, %d, %d, %d},\n' % (name, c.H, c.W, c.C, c.CO, tn, ti, g.lds_bytes, wg_gen.Gen.KA["size"]))
 
 
 if __name__ == "__main__":

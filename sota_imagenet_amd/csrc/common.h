@@ -150,6 +150,11 @@ bool igemm_fp8_legal(const IgemmArgs& a, int nclass);
 int launch_igemm_fp8(const IgemmArgs& a, int nclass, float oscale, hipStream_t stream, int* stat_rows = nullptr);
 // splits chosen by plan_wgrad_splits(); partial must hold splits*Cout*wtaps*Ck floats
 int plan_wgrad_splits(int dtype, int M, int Cout, int ntaps, int Ck);
+// plan_wgrad: the split count for THIS launch — the generated 3x3 kernels (asm/wg_gen.py, dconv.cpp) have their own, every other
+// launch plan_wgrad_splits' — and what launch_wgrad must be given for the launch to take the kernel the plan was made for
+int plan_wgrad(int dtype, const WgradArgs& a);
+int wg3_plan(int dtype, const WgradArgs& a);  // 0: the launch is not served by a generated kernel
+int launch_wg3(const WgradArgs& a, int splits, hipStream_t stream);
 int launch_wgrad(int dtype, const WgradArgs& a, int splits, hipStream_t stream);
 // dst[i] = beta*dst[i] + sum_s partial[s][i], i < n  (n multiple of 4); deterministic order
 // sa / sb (optional device scalars, fp8 wgrad): the sum is multiplied by 1 / (*sa * *sb) before beta * dst is added

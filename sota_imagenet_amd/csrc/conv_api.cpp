@@ -197,7 +197,9 @@ size_t mi355_conv2d_workspace_bytes(int dtype, int N, int H, int W, int Cin, int
   const size_t es = dtype_size(dtype);
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   const size_t wbytes = align_up((size_t)Cin * KH * KW * Cout * es, 256);
-  const int splits = plan_wgrad_splits(dtype, N * Ho * Wo, Cout, KH * KW, Cin);
+  WgradArgs wa;
+  build_wgrad_args(wa, N, H, W, Cin, Cout, KH, KW, stride, pad);
+  const int splits = std::max(plan_wgrad(dtype, wa), plan_wgrad_splits(dtype, N * Ho * Wo, Cout, KH * KW, Cin));  // (fp8 twins use the latter)
   const size_t pbytes = align_up((size_t)splits * Cout * KH * KW * Cin * 4, 256);
   return wbytes + pbytes + wbytes;  // transposed + partials + cast copy
 }
@@ -244,7 +246,7 @@ int mi355_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw, floa
   MI355_TRY(check_conv(dtype, Cin, Cout, KH, KW, stride));
   WgradArgs a;
   build_wgrad_args(a, N, H, W, Cin, Cout, KH, KW, stride, pad);
-  const int splits = plan_wgrad_splits(dtype, a.N * a.Ho * a.Wo, Cout, KH * KW, Cin);
+  const int splits = plan_wgrad(dtype, a);
   const size_t n = (size_t)Cout * KH * KW * Cin;
   MI355_ARG(ws && ws_bytes >= (size_t)splits * n * 4, "wgrad: workspace too small (%zu < %zu)", ws_bytes,
             (size_t)splits * n * 4);

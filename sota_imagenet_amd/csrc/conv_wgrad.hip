@@ -516,8 +516,14 @@ int plan_wgrad_splits(int dtype, int M, int Cout, int ntaps, int Ck) {
   return cdiv(chunks, cps);
 }
 
+int plan_wgrad(int dtype, const WgradArgs& a) {
+  const int g = wg3_plan(dtype, a);
+  return g > 0 ? g : plan_wgrad_splits(dtype, a.N * a.Ho * a.Wo, a.Cout, a.ntaps, a.Ck);
+}
+
 int launch_wgrad(int dtype, const WgradArgs& a, int splits, hipStream_t stream) {
   MI355_ARG(a.dy && a.x && a.partial, "wgrad: null pointer");
+  if (splits > 0 && wg3_plan(dtype, a) == splits) return launch_wg3(a, splits, stream);
   MI355_ARG(a.Cout % 64 == 0 && a.Ck % 64 == 0, "wgrad: Cout=%d Ck=%d must be multiples of 64", a.Cout, a.Ck);
   MI355_ARG(splits >= 1, "wgrad: splits=%d", splits);
   MI355_ARG(((size_t)a.pix_stride * dtype_size(dtype)) % 8 == 0, "wgrad: pixel stride not 8-byte aligned");

@@ -33,6 +33,16 @@ const PwVariant g_pw[] = {
 };
 constexpr int NPW = (int)(sizeof(g_pw) / sizeof(g_pw[0]));
 
+// 3x3 weight-gradient kernels (asm/wg_gen.py)
+struct WgVariant {
+  const char* name;
+  int H, W, C, CO, tn, ti, lds, kernarg;  // tn / ti: tiles per image as a fraction
+};
+const WgVariant g_wg[] = {
+#include "build/asm/wg_meta.inc"
+};
+constexpr int NWG = (int)(sizeof(g_wg) / sizeof(g_wg[0]));
+
 alignas(4096) const unsigned char g_blob[] = {
 #include "build/asm/dconv_blob.inc"
 };
@@ -42,6 +52,7 @@ struct DevState {
   hipModule_t mod = nullptr;
   hipFunction_t fn[NVAR] = {};
   hipFunction_t pw[NPW] = {};
+  hipFunction_t wg[NWG] = {};
 };
 DevState g_dev[64];
 std::mutex g_mu;
@@ -73,6 +84,13 @@ bool dev_state(DevState** out) {
       e = hipModuleGetFunction(&d.pw[i], d.mod, g_pw[i].name);
       if (e != hipSuccess) {
         set_error("dconv: hipModuleGetFunction(%s) -> %s", g_pw[i].name, hipGetErrorString(e));
+        return false;
+      }
+    }
+    for (int i = 0; i < NWG; ++i) {
+      e = hipModuleGetFunction(&d.wg[i], d.mod, g_wg[i].name);
+      if (e != hipSuccess) {
+        set_error("dconv: hipModuleGetFunction(%s) -> %s", g_wg[i].name, hipGetErrorString(e));
         return false;
       }
     }
@@ -130,6 +148,19 @@ int find_pw(const IgemmArgs& a, int nclass, int stats) {
   return -1;
 }
 
+// the generated 3x3 / stride-1 weight-gradient kernel of this launch, or -1
+int find_wg(int dtype, const WgradArgs& a) {
+  if (dtype != MI355_BF16 || a.ntaps != 9 || a.wtaps != 9 || a.IS != 1 || a.pair_delta != 0) return -1;
+  if (a.Ho != a.Hin || a.Wo != a.Win || a.pix_stride != a.Ck) return -1;
+  for (int t = 0; t < 9; ++t)
+    if (a.taps[t].dh != t / 3 - 1 || a.taps[t].dw != t % 3 - 1 || a.taps[t].wtap != t) return -1;
+  for (int i = 0; i < NWG; ++i) {
+    const WgVariant& v = g_wg[i];
+    if (v.H == a.Hin && v.W == a.Win && v.C == a.Ck && v.CO == a.Cout && (a.N * v.tn) % v.ti == 0) return i;
+  }
+  return -1;
+}
+
 int wanted_stats(const IgemmArgs& a) { return a.stat_partial == nullptr ? 0 : (a.bn_y != nullptr ? 2 : 1); }
 
 }  // namespace
@@ -139,6 +170,53 @@ int wanted_stats(const IgemmArgs& a) { return a.stat_partial == nullptr ? 0 : (a
 static bool dconv_enabled() {
   static const bool on = !(getenv("MI355_DCONV") && getenv("MI355_DCONV")[0] == '0');
   return on && getenv("MI355_IGEMM8") == nullptr && getenv("MI355_IGEMM_BIG") == nullptr;
+}
+
+// split count of the generated weight-gradient kernel for this launch (0: not served).  One workgroup per CU: the (ci tile, co tile)
+// pairs times the splits fill the device once; a split is a run of whole tiles.
+int wg3_plan(int dtype, const WgradArgs& a) {
+  static const bool on = !(getenv("MI355_WG3") && getenv("MI355_WG3")[0] == '0');
+  if (!on || !dconv_enabled()) return 0;
+  const int vi = find_wg(dtype, a);
+  if (vi < 0) return 0;
+  const WgVariant& v = g_wg[vi];
+  const int pairs = (v.C / 64) * (v.CO / 64), ntiles = a.N * v.tn / v.ti;
+  const int cus = device_cus();
+  const int max_splits = cus / pairs > 0 ? cus / pairs : 1;
+  const int tps = (ntiles + max_splits - 1) / max_splits;
+  return (ntiles + tps - 1) / tps;
+}
+
+int launch_wg3(const WgradArgs& a, int splits, hipStream_t stream) {
+  const int vi = find_wg(MI355_BF16, a);
+  MI355_ARG(vi >= 0 && splits >= 1, "wg3: no kernel variant for this launch");
+  const WgVariant& v = g_wg[vi];
+  DevState* d = nullptr;
+  if (!dev_state(&d)) return MI355_E_HIP;
+  struct __attribute__((packed)) KArgs {
+    const void* dy;
+    const void* x;
+    float* partial;
+    unsigned tps, ntiles;
+    unsigned pad[8];
+  } k;
+  static_assert(sizeof(KArgs) == 64, "kernarg layout of asm/wg_gen.py (Gen.KA)");
+  MI355_ARG((int)sizeof(KArgs) == v.kernarg, "wg3: kernarg size mismatch");
+  memset(&k, 0, sizeof(k));
+  k.dy = a.dy;
+  k.x = a.x;
+  k.partial = a.partial;
+  k.ntiles = (unsigned)(a.N * v.tn / v.ti);
+  k.tps = (k.ntiles + (unsigned)splits - 1) / (unsigned)splits;
+  MI355_ARG((k.ntiles + k.tps - 1) / k.tps == (unsigned)splits, "wg3: %d splits leave an empty split (%u tiles)", splits, k.ntiles);
+  size_t ksize = sizeof(k);
+  void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
+  const hipError_t e = hipModuleLaunchKernel(d->wg[vi], (unsigned)((v.C / 64) * (v.CO / 64)), (unsigned)splits, 1, 256, 1, 1, 0, stream, nullptr, extra);
+  if (e != hipSuccess) {
+    set_error("wg3: hipModuleLaunchKernel(%s) -> %s", v.name, hipGetErrorString(e));
+    return MI355_E_HIP;
+  }
+  return 0;
 }
 
 bool pw_legal(const IgemmArgs& a, int nclass) {

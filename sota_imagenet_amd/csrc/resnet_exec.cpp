@@ -462,7 +462,10 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
         ar.add(&l.w_q, wn);
         ar.add(&l.w_trq, wn);
       }
-      l.splits = plan_wgrad_splits(c->dtype, N * l.Hout * l.Wout, l.Cout, l.K * l.K, l.Cin);
+      WgradArgs wa;
+      build_wgrad_args(wa, N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
+      // (the fp8 step launches e4m3 twins with the same split count: it keeps the implicit-GEMM plan)
+      l.splits = c->fp8 ? plan_wgrad_splits(c->dtype, N * l.Hout * l.Wout, l.Cout, l.K * l.K, l.Cin) : plan_wgrad(c->dtype, wa);
       max_wg = std::max(max_wg, (size_t)l.splits * wn * 4);
     } else {
       l.splits = plan_wgrad_splits(c->dtype, N * l.Hout * l.Wout, 64, 4, STEM_CK);

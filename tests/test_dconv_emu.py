@@ -72,6 +72,48 @@ def test_the_emulator_rejects_an_lds_read_before_the_dma_wait():
     gcn_emu.Emulator(good, mem, lds_bytes=4096).run_workgroup(1, ka)
 
 
+@pytest.mark.parametrize("name,kw", [("wg3_l3", dict(splits=2, tps=3, pairs=((3, 2),))), ("wg3_l3", dict(splits=3, tps=1, pairs=((0, 1),))),
+                                     ("wg3_l2", dict(splits=3, tps=2, pairs=((1, 0),))), ("wg3_l4", dict(splits=2, tps=2, pairs=((5, 7),)))])
+def test_weight_gradient_kernels_are_exact_in_the_emulator(name, kw):
+    """csrc/asm/wg_gen.py: odd and single tile counts per split, splits that end inside an image (row tiles), last channel tiles;
+    every slab element of the run workgroups exact, nothing else written, no LDS-DMA protocol violation"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import wg_emu_check
+
+    r = wg_emu_check.run(name, **kw)
+    assert r["max_err"] == 0.0 and r["untouched_ok"]
+
+
+def test_the_transposed_lds_read_of_the_emulator_follows_the_documented_lane_map():
+    """ds_read_b64_tr_b16 (guide T10): per 16 lanes a 4 x 16 block; lane 4q + p addresses row q, columns 4p .. 4p + 3; lane i receives
+    column i, row q in element q"""
+    import numpy as np
+
+    mem = gcn_emu.Memory()
+    ka = mem.alloc(np.zeros(8, dtype=np.uint8))
+    # LDS image: 16 rows of 128 bytes, element (row, col) = row * 64 + col as u16; every group reads rows 4G .. 4G + 3, columns 16 .. 31
+    prog = ["v_and_b32 v1, 63, v0", "v_lshlrev_b32 v2, 1, v1", "v_lshlrev_b32 v3, 2, v1"]
+    prog += ["v_mov_b32 v4, %d" % 0]
+    # fill: lane l writes dwords: element pairs (2k, 2k + 1) of row r: use ds_write_b32 in a loop over 16 rows x 32 dwords = 512 dwords / 64 lanes
+    for k in range(8):
+        prog += ["v_add_u32 v5, %d, v1" % (64 * k),            # dword index d = 64k + lane -> row = d >> 5, col pair = d & 31
+                 "v_lshrrev_b32 v6, 5, v5", "v_and_b32 v7, 31, v5", "v_lshlrev_b32 v8, 6, v6", "v_lshl_add_u32 v8, v7, 1, v8",   # first element value
+                 "v_add_u32 v9, 1, v8", "v_lshl_add_u32 v9, v9, 16, v8", "v_lshlrev_b32 v10, 2, v5", "ds_write_b32 v10, v9"]
+    prog += ["s_waitcnt lgkmcnt(0)",
+             "v_lshrrev_b32 v11, 4, v1", "v_and_b32 v12, 15, v1", "v_lshrrev_b32 v13, 2, v12", "v_and_b32 v14, 3, v12",
+             "v_lshl_add_u32 v13, v11, 2, v13",                  # row = 4G + q
+             "v_lshlrev_b32 v15, 7, v13", "v_lshl_add_u32 v15, v14, 3, v15", "v_add_u32 v15, 32, v15",   # + column 16 (32 bytes) + 8p
+             "ds_read_b64_tr_b16 v[16:17], v15", "s_waitcnt lgkmcnt(0)"]
+    emu = gcn_emu.Emulator(_tiny(prog), mem, lds_bytes=4096)
+    emu.run_workgroup(1, ka)
+    wv = emu.waves[0]
+    for lane in range(64):
+        G, i = lane >> 4, lane & 15
+        want = [(4 * G + q) * 64 + 16 + i for q in range(4)]
+        got = [int(wv.v[16][lane]) & 0xFFFF, int(wv.v[16][lane]) >> 16, int(wv.v[17][lane]) & 0xFFFF, int(wv.v[17][lane]) >> 16]
+        assert got == want, (lane, got, want)
+
+
 def test_the_emulator_rejects_a_read_of_another_waves_dma_without_a_barrier():
     import numpy as np
 
@@ -96,8 +138,9 @@ def test_every_shipped_variant_assembles_for_gfx950_within_the_register_and_lds_
     sys.path.insert(0, os.path.join(ROOT, "sota_imagenet_amd", "csrc", "asm"))
     import dconv_gen
     import pw_gen
+    import wg_gen
 
-    for mod in (dconv_gen, pw_gen):
+    for mod in (dconv_gen, pw_gen, wg_gen):
         for name in mod.VARIANTS:
             c, g, text = mod.generate(name)
             assert g.accum_offset + g.nagpr <= 512

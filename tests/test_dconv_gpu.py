@@ -61,3 +61,47 @@ def test_other_batch_sizes_take_the_same_kernels(dev):
         w = torch.randint(-2, 3, (Cout, K, K, Cin), device=dev).to(torch.bfloat16)
         y, part = ops.conv2d_fwd(x, w, 1, K // 2, stats=True)
         assert torch.equal(y, _ref(x, w, K).to(torch.bfloat16))
+
+
+WG_SHAPES = [(256, 14, 256, 256), (256, 28, 128, 128), (256, 7, 512, 512), (8, 14, 256, 256), (12, 28, 128, 128), (20, 7, 512, 512)]
+
+
+def _wgrad_ref(dy, x):
+    """fp32 weight gradient of a 3x3 / pad 1 convolution, [Cout][3][3][Cin] (exact on small-integer data in any order)"""
+    xp = torch.nn.functional.pad(x.float(), (0, 0, 1, 1, 1, 1))
+    H, W = x.shape[1], x.shape[2]
+    d2 = dy.float().reshape(-1, dy.shape[-1])
+    out = torch.empty(dy.shape[-1], 3, 3, x.shape[-1], device=x.device)
+    for ky in range(3):
+        for kx in range(3):
+            out[:, ky, kx] = d2.t() @ xp[:, ky:ky + H, kx:kx + W].reshape(-1, x.shape[-1])
+    return out
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout", WG_SHAPES)
+def test_weight_gradient_is_exact_on_integer_data(dev, N, H, Cin, Cout, monkeypatch):
+    """the generated 3x3 weight-gradient kernels (csrc/asm/wg_gen.py) at the baseline batch and at batches that leave short last
+    splits; the implicit-GEMM kernel (MI355_WG3=0 is read once per process, so it is compared through its own exactness test in
+    test_ops_gpu.py) and this one must both equal the fp32 reference bit for bit on integer data"""
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(3)
+    x = torch.randint(-2, 3, (N, H, H, Cin), device=dev).to(torch.bfloat16)
+    dy = torch.randint(-2, 3, (N, H, H, Cout), device=dev).to(torch.bfloat16)
+    ref = _wgrad_ref(dy, x)
+    dw = ops.conv2d_wgrad(dy, x, 3, 3, 1, 1)
+    assert torch.equal(dw, ref)
+    dw2 = ops.conv2d_wgrad(dy, x, 3, 3, 1, 1, dw=dw.clone(), beta=1.0)
+    assert torch.equal(dw2, 2 * ref)
+
+
+def test_weight_gradient_on_random_data(dev):
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(4)
+    for (N, H, Cin, Cout) in WG_SHAPES[:3]:
+        x = torch.randn(N, H, H, Cin, device=dev).to(torch.bfloat16)
+        dy = (torch.randn(N, H, H, Cout, device=dev) * 0.1).to(torch.bfloat16)
+        ref = _wgrad_ref(dy, x)
+        dw = ops.conv2d_wgrad(dy, x, 3, 3, 1, 1)
+        assert ((dw - ref).norm() / ref.norm()).item() < 1e-5  # fp32 accumulation of exact bf16 products: summation order only

@@ -541,6 +541,10 @@ class Emulator:
         a, b = self._s2(wv, ins)
         self.swrite(wv, ins.ops[0], a if wv.scc else b, ins)
 
+    def i_s_cselect_b64(self, wv, ins):
+        a, b = self.sval64(wv, ins.ops[1], ins), self.sval64(wv, ins.ops[2], ins)
+        self.swrite64(wv, ins.ops[0], a if wv.scc else b, ins)
+
     def i_s_bfe_u32(self, wv, ins):
         a, b = self._s2(wv, ins)
         off, width = b & 31, (b >> 16) & 0x7F
@@ -896,6 +900,34 @@ class Emulator:
 
     def i_ds_read_b128(self, wv, ins):
         self._ds_read(wv, ins, 16)
+
+    def i_ds_read_b64_tr_b16(self, wv, ins):
+        """hardware transpose read (guide T10): per group of 16 lanes a block of 4 rows x 16 columns of 16-bit elements; lane 4q + p of
+        the group supplies the address of row q, columns 4p .. 4p + 3; lane i receives column i of the 4 rows, row q in element q"""
+        dst, addr_o = ins.ops[0], ins.ops[1]
+        addrs = self._ds_addr(wv, ins, addr_o)
+        if wv.exec != (1 << 64) - 1:
+            self.err(ins, "ds_read_b64_tr_b16 with partial EXEC")
+        if (addrs + 8 > self.lds.size).any():
+            self.err(ins, "ds_read beyond the LDS allocation")
+        if ((addrs % 8) != 0).any():
+            self.err(ins, "misaligned ds_read_b64_tr_b16")
+        self.lds_read_check(wv, addrs, 8, self.lanes(wv), ins)
+        lds16 = self.lds.view(np.uint16)
+        lane = np.arange(64)
+        grp, i = lane & ~15, lane & 15
+        out = []
+        for q in range(4):
+            src_lane = grp + 4 * q + (i >> 2)
+            out.append(lds16[(addrs[src_lane] + 2 * (i & 3)) // 2].astype(np.uint32))
+        wv.v[dst.idx] = out[0] | (out[1] << 16)
+        wv.v[dst.idx + 1] = out[2] | (out[3] << 16)
+        rec = {"kind": "lds", "vgprs": [dst.idx, dst.idx + 1]}
+        for r in rec["vgprs"]:
+            if self.check and r in wv.pending_v:
+                self.err(ins, "v%d is the destination of two loads in flight" % r)
+            wv.pending_v[r] = rec
+        wv.lgkm_ops.append(rec)
 
     def i_ds_read_b64(self, wv, ins):
         self._ds_read(wv, ins, 8)
