@@ -127,8 +127,10 @@ def pieces(c, kind):
     rowb = c.W * ch * 2
     base = 0 if kind == "d" else c.DYB
     bpr = c.P // 8
-    nblk = (c.W + (0 if kind == "d" else 1)) // 8 + 1      # blocks of a row that hold data
-    nblk = min(nblk, bpr)
+    nblk = -(-(c.W + (0 if kind == "d" else 1)) // 8)      # blocks of a row that hold data (dy: columns 0 .. W-1, in: 0 .. W)
+    nrows = len(rows_of(c, kind))
+    while (nrows * nblk) % 4 and nblk < bpr:               # a block of padding only is written with zeros (all lanes out of range)
+        nblk += 1
     allp = []
     for lrow, src in rows_of(c, kind):
         for xb in range(nblk):
@@ -138,25 +140,22 @@ def pieces(c, kind):
 
 
 def piece_plan(c, kind):
-    """affine form of the pieces: lds[w][j] = LW[w] + LJ[j], src[w][j] = SW[w] + SJ[j]; xb[w]; variants: dead-wave set per j"""
+    """affine form of the pieces: lds[w][j] = LW[w] + LJ[j], src[w][j] = SW[w] + SJ[j]; per j a VARIANT = (block of the row per wave,
+    waves whose piece must write zeros): one lane-offset register per variant"""
     pw = pieces(c, kind)
     n = len(pw[0])
     LJ = [pw[0][j][0] - pw[0][0][0] for j in range(n)]
     SJ = [pw[0][j][1] - pw[0][0][1] for j in range(n)]
     LW = [pw[w][0][0] for w in range(4)]
     SW = [pw[w][0][1] for w in range(4)]
-    XB = [pw[w][0][2] for w in range(4)]
-    dead = []
+    keys = []
     for j in range(n):
         for w in range(4):
-            assert pw[w][j][2] == XB[w]
-            if not pw[w][j][3]:
-                assert pw[w][j][0] == LW[w] + LJ[j] and pw[w][j][1] == SW[w] + SJ[j], (kind, w, j)
-            else:
-                assert pw[w][j][0] == LW[w] + LJ[j]
-        dead.append(frozenset(w for w in range(4) if pw[w][j][3]))
-    variants = sorted(set(dead), key=lambda s: sorted(s))
-    return dict(n=n, LJ=LJ, SJ=SJ, LW=LW, SW=SW, XB=XB, var=[variants.index(d) for d in dead], variants=variants)
+            assert pw[w][j][0] == LW[w] + LJ[j], (kind, w, j)
+            assert pw[w][j][3] or pw[w][j][1] == SW[w] + SJ[j], (kind, w, j)
+        keys.append((tuple(pw[w][j][2] for w in range(4)), frozenset(w for w in range(4) if pw[w][j][3])))
+    variants = sorted(set(keys), key=lambda k: (k[0], sorted(k[1])))
+    return dict(n=n, LJ=LJ, SJ=SJ, LW=LW, SW=SW, var=[variants.index(k) for k in keys], variants=variants)
 
 
 class Gen:
@@ -231,10 +230,14 @@ class Gen:
         out = []
         a = out.append
         tpw = c.TPW
-        if tpw > 1:
-            assert tpw & (tpw - 1) == 0, "tiles per image must be a power of two"
+        if tpw > 1 and tpw & (tpw - 1) == 0:
             a("s_lshr_b32 %s, %s, %d" % (R("s", t2), R("s", self.s_tile), tpw.bit_length() - 1))
             a("s_and_b32 %s, %s, %d" % (R("s", self.s_t3), R("s", self.s_tile), tpw - 1))
+        elif tpw > 1:
+            magic = ((1 << 32) + tpw - 1) // tpw
+            a("s_mul_hi_u32 %s, %s, 0x%x" % (R("s", t2), R("s", self.s_tile), magic))  # tile / TPW (exact far beyond any tile count here)
+            a("s_mul_i32 %s, %s, %d" % (R("s", self.s_t3), R("s", t2), tpw))
+            a("s_sub_u32 %s, %s, %s" % (R("s", self.s_t3), R("s", self.s_tile), R("s", self.s_t3)))
         else:
             a("s_mov_b32 %s, %s" % (R("s", t2), R("s", self.s_tile)))
         for k, ch, ptr, tile_ch in (("d", c.CO, 0, self.s_co), ("x", c.C, 2, self.s_ci)):
@@ -354,22 +357,20 @@ class Gen:
         e("v_lshlrev_b32 %s, 4, %s" % (R("v", ch16), R("v", ch16)))
         for k, chn in (("d", c.CO), ("x", c.C)):
             pl = self.plan[k]
-            self.sel_w(t0, [xb * 8 - (1 if k == "x" else 0) for xb in pl["XB"]])
-            e("v_add_u32 %s, %s, %s" % (R("v", x), R("s", t0), R("v", l3)), "pixel column of this lane's position")
-            e("v_mov_b32 %s, %d" % (R("v", off), chn * 2))
-            e("v_mad_u32_u24 %s, %s, %s, %s" % (R("v", off), R("v", x), R("v", off), R("v", ch16)))
-            e("v_cmp_gt_u32 vcc, %d, %s" % (c.W, R("v", x)), "0 <= column < W")
-            e("v_mov_b32 %s, 0x80000000" % R("v", x))
-            e("v_cndmask_b32 %s, %s, %s, vcc" % (R("v", off), R("v", x), R("v", off)))
-            for vi, deadset in enumerate(pl["variants"]):
+            for vi, (xbs, deadset) in enumerate(pl["variants"]):
                 dst = self.v_dma[k][vi]
-                if not deadset:
-                    e("v_mov_b32 %s, %s" % (R("v", dst), R("v", off)))
-                else:
+                self.sel_w(t0, [xb * 8 - (1 if k == "x" else 0) for xb in xbs])
+                e("v_add_u32 %s, %s, %s" % (R("v", x), R("s", t0), R("v", l3)), "pixel column of this lane's position")
+                e("v_mov_b32 %s, %d" % (R("v", off), chn * 2))
+                e("v_mad_u32_u24 %s, %s, %s, %s" % (R("v", off), R("v", x), R("v", off), R("v", ch16)))
+                e("v_cmp_gt_u32 vcc, %d, %s" % (c.W, R("v", x)), "0 <= column < W")
+                e("v_mov_b32 %s, 0x80000000" % R("v", x))
+                e("v_cndmask_b32 %s, %s, %s, vcc" % (R("v", dst), R("v", x), R("v", off)))
+                if deadset:
                     self.sel_w(t1, [1 if w in deadset else 0 for w in range(4)])
                     e("s_cmp_eq_u32 %s, 1" % R("s", t1))
                     e("s_cselect_b64 vcc, -1, 0")
-                    e("v_cndmask_b32 %s, %s, %s, vcc" % (R("v", dst), R("v", off), R("v", x)))
+                    e("v_cndmask_b32 %s, %s, %s, vcc" % (R("v", dst), R("v", dst), R("v", x)))
             self.sel_w(self.s_lds[k], pl["LW"])
             self.sel_w(self.s_srcw[k], pl["SW"])
         e("s_waitcnt lgkmcnt(0)")
@@ -397,7 +398,7 @@ class Gen:
         e("s_lshl_b32 %s, %s, 7" % (R("s", self.s_co), R("s", self.s_co)))
         for k, chn in (("d", c.CO), ("x", c.C)):
             srd = self.srd[k]
-            e("s_mov_b32 %s, %d" % (R("s", srd + 2), c.WIN_PIX * chn * 2 - 127), "window bytes (less than a row of slack for the channel tile offset)")
+            e("s_sub_u32 %s, %d, %s" % (R("s", srd + 2), c.WIN_PIX * chn * 2, R("s", self.s_co if k == "d" else self.s_ci)), "window bytes behind the channel tile offset")
             e("s_mov_b32 %s, 0x00020000" % R("s", srd + 3))
         # first tile of this split, last tile
         e("s_mul_i32 %s, %s, %s" % (R("s", self.s_tile), R("s", self.s_split), R("s", ka + 6)))
@@ -571,10 +572,12 @@ class Gen:
 
 # ---------------------------------------------------------------------------------------------------------------------
 VARIANTS = {
-    # ResNet-50 at 224 px: conv2 of the bottlenecks of layer 3 (14 x 14, 256 -> 256), layer 2 (28 x 28, 128 -> 128), layer 4 (7 x 7, 512 -> 512)
+    # ResNet-50 at 224 px: conv2 of the bottlenecks of layer 3 (14 x 14, 256 -> 256), layer 2 (28 x 28, 128 -> 128), layer 4 (7 x 7, 512 -> 512),
+    # layer 1 (56 x 56, 64 -> 64: two-row tiles, 28 per image)
     "wg3_l3": WCfg("wg3_l3", H=14, W=14, P=16, C=256, CO=256, geom="img", DR=14),
     "wg3_l2": WCfg("wg3_l2", H=28, W=28, P=32, C=128, CO=128, geom="rows", DR=7),
     "wg3_l4": WCfg("wg3_l4", H=7, W=7, P=8, C=512, CO=512, geom="pack", DR=32, IPT=4),
+    "wg3_l1": WCfg("wg3_l1", H=56, W=56, P=64, C=64, CO=64, geom="rows", DR=2),
 }
 
 

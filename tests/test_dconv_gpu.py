@@ -63,7 +63,8 @@ def test_other_batch_sizes_take_the_same_kernels(dev):
         assert torch.equal(y, _ref(x, w, K).to(torch.bfloat16))
 
 
-WG_SHAPES = [(256, 14, 256, 256), (256, 28, 128, 128), (256, 7, 512, 512), (8, 14, 256, 256), (12, 28, 128, 128), (20, 7, 512, 512)]
+WG_SHAPES = [(256, 14, 256, 256), (256, 28, 128, 128), (256, 7, 512, 512), (256, 56, 64, 64), (8, 14, 256, 256), (12, 28, 128, 128), (20, 7, 512, 512),
+             (5, 56, 64, 64)]
 
 
 def _wgrad_ref(dy, x):
@@ -99,7 +100,7 @@ def test_weight_gradient_on_random_data(dev):
     from sota_imagenet_amd import ops
 
     torch.manual_seed(4)
-    for (N, H, Cin, Cout) in WG_SHAPES[:3]:
+    for (N, H, Cin, Cout) in WG_SHAPES[:4]:
         x = torch.randn(N, H, H, Cin, device=dev).to(torch.bfloat16)
         dy = (torch.randn(N, H, H, Cout, device=dev) * 0.1).to(torch.bfloat16)
         ref = _wgrad_ref(dy, x)
