@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """embed.py <out dir> <linked .hsaco> — writes the include files dconv.cpp embeds: the code object as a byte array
-(dconv_blob.inc) and one initialiser per generated kernel (dconv_meta.inc: direct 3x3 kernels, pw_meta.inc: pointwise, wg_meta.inc: 3x3 weight gradient)."""
+(dconv_blob.inc) and one initialiser per generated kernel (dconv_meta.inc: direct 3x3 kernels, pw_meta.inc: pointwise, wg_meta.inc / wg1_meta.inc: 3x3 / 1x1 weight gradient)."""
 import os
 import sys
 
@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import dconv_gen  # noqa: E402
 import pw_gen  # noqa: E402
 import wg_gen  # noqa: E402
+import wg1_gen  # noqa: E402
 
 
 def main():
@@ -31,6 +32,10 @@ def main():
             c, g, _ = wg_gen.generate(name)
             tn, ti = c.TPI_NUM
             f.write('{"%s", %d, %d, %d, %d, %d, %d, %d, %d},\n' % (name, c.H, c.W, c.C, c.CO, tn, ti, g.lds_bytes, wg_gen.Gen.KA["size"]))
+    with open(os.path.join(out_dir, "wg1_meta.inc"), "w") as f:
+        for name in wg1_gen.VARIANTS:
+            c, g, _ = wg1_gen.generate(name)
+            f.write('{"%s", %d, %d, %d, %d},\n' % (name, c.C, c.CO, g.lds_bytes, wg1_gen.Gen.KA["size"]))
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ conv_wgrad.hip (fp32 partial slabs [split][Cout][9][Cin], summed in a fixed orde
 
     dW[co][ky][kx][ci] = sum over (n, y, x) of dy[n][y][x][co] * in[n][y + ky - 1][x + kx - 1][ci]
 
-Structure (one workgroup = 4 waves = one wave per SIMD; grid = (ci tiles x co tiles) x splits):
+Structure (one workgroup = 4 waves = one wave per SIMD; grid = splits x (ci tiles x co tiles): the workgroups of a split share an XCD):
   tile        64 input channels x 64 output channels x ALL 9 taps: 144 accumulator tiles of 16 x 16; wave w owns input channels
               16w .. 16w + 15 (36 tiles, 144 AGPRs).  v_mfma_f32_16x16x32_bf16 with the in fragment as src0 and the dy fragment as
               src1: a lane ends with 4 consecutive ci of one co (16-byte stores into the slab).
@@ -194,7 +194,8 @@ class Gen:
     def gen(self):
         c, S, V = self.c, self.S, self.V
         self.plan = {k: piece_plan(c, k) for k in ("d", "x")}
-        self.s_pair, self.s_split = 2, 3
+        self.s_split, self.s_pair = 2, 3   # grid = (splits, channel-tile pairs): the workgroups of one split share their pixels' bytes and
+        # land on the same XCD (workgroup id % 8), so the sharing happens in that XCD's L2
         self.srd = {"d": S.get(4, 4), "x": S.get(4, 4)}
         self.srdP = S.get(4, 4)
         self.s_ka = S.get(8, 4)

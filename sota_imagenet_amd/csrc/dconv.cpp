@@ -43,6 +43,16 @@ const WgVariant g_wg[] = {
 };
 constexpr int NWG = (int)(sizeof(g_wg) / sizeof(g_wg[0]));
 
+// 1x1 weight-gradient kernels (asm/wg1_gen.py): 128 ci x 256 co per workgroup, tiles of 64 pixels
+struct Wg1Variant {
+  const char* name;
+  int C, CO, lds, kernarg;
+};
+const Wg1Variant g_wg1[] = {
+#include "build/asm/wg1_meta.inc"
+};
+constexpr int NWG1 = (int)(sizeof(g_wg1) / sizeof(g_wg1[0]));
+
 alignas(4096) const unsigned char g_blob[] = {
 #include "build/asm/dconv_blob.inc"
 };
@@ -53,6 +63,7 @@ struct DevState {
   hipFunction_t fn[NVAR] = {};
   hipFunction_t pw[NPW] = {};
   hipFunction_t wg[NWG] = {};
+  hipFunction_t wg1[NWG1] = {};
 };
 DevState g_dev[64];
 std::mutex g_mu;
@@ -91,6 +102,13 @@ bool dev_state(DevState** out) {
       e = hipModuleGetFunction(&d.wg[i], d.mod, g_wg[i].name);
       if (e != hipSuccess) {
         set_error("dconv: hipModuleGetFunction(%s) -> %s", g_wg[i].name, hipGetErrorString(e));
+        return false;
+      }
+    }
+    for (int i = 0; i < NWG1; ++i) {
+      e = hipModuleGetFunction(&d.wg1[i], d.mod, g_wg1[i].name);
+      if (e != hipSuccess) {
+        set_error("dconv: hipModuleGetFunction(%s) -> %s", g_wg1[i].name, hipGetErrorString(e));
         return false;
       }
     }
@@ -161,6 +179,16 @@ int find_wg(int dtype, const WgradArgs& a) {
   return -1;
 }
 
+// the generated 1x1 / stride-1 weight-gradient kernel of this launch, or -1
+int find_wg1(int dtype, const WgradArgs& a) {
+  if (dtype != MI355_BF16 || a.ntaps != 1 || a.wtaps != 1 || a.IS != 1 || a.pair_delta != 0) return -1;
+  if (a.Ho != a.Hin || a.Wo != a.Win || a.pix_stride != a.Ck || a.taps[0].dh != 0 || a.taps[0].dw != 0 || a.taps[0].wtap != 0) return -1;
+  if ((long)a.N * a.Ho * a.Wo * (long)(a.Ck > a.Cout ? a.Ck : a.Cout) * 2 >= (1L << 32)) return -1;  // 32-bit offsets into the tensors
+  for (int i = 0; i < NWG1; ++i)
+    if (g_wg1[i].C == a.Ck && g_wg1[i].CO == a.Cout) return i;
+  return -1;
+}
+
 int wanted_stats(const IgemmArgs& a) { return a.stat_partial == nullptr ? 0 : (a.bn_y != nullptr ? 2 : 1); }
 
 }  // namespace
@@ -178,9 +206,17 @@ int wg3_plan(int dtype, const WgradArgs& a) {
   static const bool on = !(getenv("MI355_WG3") && getenv("MI355_WG3")[0] == '0');
   if (!on || !dconv_enabled()) return 0;
   const int vi = find_wg(dtype, a);
-  if (vi < 0) return 0;
-  const WgVariant& v = g_wg[vi];
-  const int pairs = (v.C / 64) * (v.CO / 64), ntiles = a.N * v.tn / v.ti;
+  const int v1 = vi < 0 ? find_wg1(dtype, a) : -1;
+  if (vi < 0 && v1 < 0) return 0;
+  int pairs, ntiles;
+  if (vi >= 0) {
+    const WgVariant& v = g_wg[vi];
+    pairs = (v.C / 64) * (v.CO / 64);
+    ntiles = a.N * v.tn / v.ti;
+  } else {
+    pairs = (g_wg1[v1].C / 128) * (g_wg1[v1].CO / 256);
+    ntiles = (a.N * a.Ho * a.Wo + 63) / 64;
+  }
   const int cus = device_cus();
   const int max_splits = cus / pairs > 0 ? cus / pairs : 1;
   const int tps = (ntiles + max_splits - 1) / max_splits;
@@ -189,17 +225,38 @@ int wg3_plan(int dtype, const WgradArgs& a) {
 
 int launch_wg3(const WgradArgs& a, int splits, hipStream_t stream) {
   const int vi = find_wg(MI355_BF16, a);
-  MI355_ARG(vi >= 0 && splits >= 1, "wg3: no kernel variant for this launch");
-  const WgVariant& v = g_wg[vi];
+  const int v1 = vi < 0 ? find_wg1(MI355_BF16, a) : -1;
+  MI355_ARG((vi >= 0 || v1 >= 0) && splits >= 1, "wg3: no kernel variant for this launch");
   DevState* d = nullptr;
   if (!dev_state(&d)) return MI355_E_HIP;
   struct __attribute__((packed)) KArgs {
     const void* dy;
     const void* x;
     float* partial;
-    unsigned tps, ntiles;
-    unsigned pad[8];
+    unsigned tps, ntiles, npix;
+    unsigned pad[7];
   } k;
+  if (v1 >= 0) {  // 1x1: flat pixel tiles
+    const Wg1Variant& v = g_wg1[v1];
+    MI355_ARG((int)sizeof(KArgs) == v.kernarg, "wg1: kernarg size mismatch");
+    memset(&k, 0, sizeof(k));
+    k.dy = a.dy;
+    k.x = a.x;
+    k.partial = a.partial;
+    k.npix = (unsigned)(a.N * a.Ho * a.Wo);
+    k.ntiles = (k.npix + 63) / 64;
+    k.tps = (k.ntiles + (unsigned)splits - 1) / (unsigned)splits;
+    MI355_ARG((k.ntiles + k.tps - 1) / k.tps == (unsigned)splits, "wg1: %d splits leave an empty split (%u tiles)", splits, k.ntiles);
+    size_t ksize = sizeof(k);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
+    const hipError_t e = hipModuleLaunchKernel(d->wg1[v1], (unsigned)splits, (unsigned)((v.C / 128) * (v.CO / 256)), 1, 256, 1, 1, 0, stream, nullptr, extra);
+    if (e != hipSuccess) {
+      set_error("wg1: hipModuleLaunchKernel(%s) -> %s", v.name, hipGetErrorString(e));
+      return MI355_E_HIP;
+    }
+    return 0;
+  }
+  const WgVariant& v = g_wg[vi];
   static_assert(sizeof(KArgs) == 64, "kernarg layout of asm/wg_gen.py (Gen.KA)");
   MI355_ARG((int)sizeof(KArgs) == v.kernarg, "wg3: kernarg size mismatch");
   memset(&k, 0, sizeof(k));
@@ -211,7 +268,7 @@ int launch_wg3(const WgradArgs& a, int splits, hipStream_t stream) {
   MI355_ARG((k.ntiles + k.tps - 1) / k.tps == (unsigned)splits, "wg3: %d splits leave an empty split (%u tiles)", splits, k.ntiles);
   size_t ksize = sizeof(k);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
-  const hipError_t e = hipModuleLaunchKernel(d->wg[vi], (unsigned)((v.C / 64) * (v.CO / 64)), (unsigned)splits, 1, 256, 1, 1, 0, stream, nullptr, extra);
+  const hipError_t e = hipModuleLaunchKernel(d->wg[vi], (unsigned)splits, (unsigned)((v.C / 64) * (v.CO / 64)), 1, 256, 1, 1, 0, stream, nullptr, extra);
   if (e != hipSuccess) {
     set_error("wg3: hipModuleLaunchKernel(%s) -> %s", v.name, hipGetErrorString(e));
     return MI355_E_HIP;

@@ -85,6 +85,18 @@ def test_weight_gradient_kernels_are_exact_in_the_emulator(name, kw):
     assert r["max_err"] == 0.0 and r["untouched_ok"]
 
 
+@pytest.mark.parametrize("name,kw", [("wg1_c256_o1024", dict(splits=2, tps=4, pairs=((1, 3),))), ("wg1_c1024_o256", dict(splits=1, tps=5, npix=300, pairs=((7, 0),))),
+                                     ("wg1_c512_o2048", dict(splits=2, tps=1, pairs=((3, 7),))), ("wg1_c2048_o512", dict(splits=1, tps=7, npix=400, pairs=((15, 1),)))])
+def test_pointwise_weight_gradient_kernels_are_exact_in_the_emulator(name, kw):
+    """csrc/asm/wg1_gen.py: tile counts of 1, 4, 5 and 7 per split (every exit of the three-buffer loop), a ragged last tile (300 and
+    400 pixels), first and last channel tiles"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import wg1_emu_check
+
+    r = wg1_emu_check.run(name, **kw)
+    assert r["max_err"] == 0.0 and r["untouched_ok"]
+
+
 def test_the_transposed_lds_read_of_the_emulator_follows_the_documented_lane_map():
     """ds_read_b64_tr_b16 (guide T10): per 16 lanes a 4 x 16 block; lane 4q + p addresses row q, columns 4p .. 4p + 3; lane i receives
     column i, row q in element q"""
@@ -139,9 +151,10 @@ def test_every_shipped_variant_assembles_for_gfx950_within_the_register_and_lds_
     sys.path.insert(0, os.path.join(ROOT, "sota_imagenet_amd", "csrc", "asm"))
     import dconv_gen
     import pw_gen
+    import wg1_gen
     import wg_gen
 
-    for mod in (dconv_gen, pw_gen, wg_gen):
+    for mod in (dconv_gen, pw_gen, wg_gen, wg1_gen):
         for name in mod.VARIANTS:
             c, g, text = mod.generate(name)
             assert g.accum_offset + g.nagpr <= 512

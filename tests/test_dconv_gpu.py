@@ -106,3 +106,18 @@ def test_weight_gradient_on_random_data(dev):
         ref = _wgrad_ref(dy, x)
         dw = ops.conv2d_wgrad(dy, x, 3, 3, 1, 1)
         assert ((dw - ref).norm() / ref.norm()).item() < 1e-5  # fp32 accumulation of exact bf16 products: summation order only
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout", [(256, 14, 1024, 256), (256, 14, 256, 1024), (256, 7, 2048, 512), (256, 7, 512, 2048), (3, 14, 256, 1024), (5, 7, 2048, 512)])
+def test_pointwise_weight_gradient_is_exact_on_integer_data(dev, N, H, Cin, Cout):
+    """the generated 1x1 weight-gradient kernels (csrc/asm/wg1_gen.py): flat 64-pixel tiles, ragged last tile (3 x 196 = 588 and
+    5 x 49 = 245 pixels are not multiples of 64), accumulation into an existing gradient"""
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(5)
+    x = torch.randint(-2, 3, (N, H, H, Cin), device=dev).to(torch.bfloat16)
+    dy = torch.randint(-2, 3, (N, H, H, Cout), device=dev).to(torch.bfloat16)
+    ref = (dy.float().reshape(-1, Cout).t() @ x.float().reshape(-1, Cin)).reshape(Cout, 1, 1, Cin)
+    dw = ops.conv2d_wgrad(dy, x, 1, 1, 1, 0)
+    assert torch.equal(dw, ref)
+    assert torch.equal(ops.conv2d_wgrad(dy, x, 1, 1, 1, 0, dw=dw.clone(), beta=1.0), 2 * ref)

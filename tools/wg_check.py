@@ -10,6 +10,25 @@ sys.path.insert(0, "tests")
 from test_dconv_gpu import WG_SHAPES, _wgrad_ref  # noqa: E402
 
 dev = "cuda"
+K1 = [(256, 14, 1024, 256), (256, 14, 256, 1024), (256, 7, 2048, 512), (256, 7, 512, 2048), (3, 14, 256, 1024), (5, 7, 2048, 512)]
+for (N, H, Cin, Cout) in K1:
+    torch.manual_seed(0)
+    x = torch.randint(-2, 3, (N, H, H, Cin), device=dev).to(torch.bfloat16)
+    dy = torch.randint(-2, 3, (N, H, H, Cout), device=dev).to(torch.bfloat16)
+    ref = (dy.float().reshape(-1, Cout).t() @ x.float().reshape(-1, Cin)).reshape(Cout, 1, 1, Cin)
+    dw = ops.conv2d_wgrad(dy, x, 1, 1, 1, 0)
+    torch.cuda.synchronize()
+    ok = torch.equal(dw, ref)
+    for _ in range(3):
+        ops.conv2d_wgrad(dy, x, 1, 1, 1, 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        ops.conv2d_wgrad(dy, x, 1, 1, 1, 0)
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / 20 * 1e6
+    fl = 2.0 * N * H * H * Cin * Cout
+    print(f"1x1 N={N} H={H} {Cin}->{Cout}: exact={ok} maxerr={(dw - ref).abs().max().item():.3g}  {us:.1f} us (wgrad + reduce)  {fl / us / 1e6:.0f} TF/s", flush=True)
 for (N, H, Cin, Cout) in WG_SHAPES:
     torch.manual_seed(0)
     x = torch.randint(-2, 3, (N, H, H, Cin), device=dev).to(torch.bfloat16)

@@ -47,7 +47,7 @@ def run(name, pairs=((0, 0),), splits=2, tps=2, seed=0, check=True, **over):
     for ci_t, co_t in pairs:
         for sp in range(splits):
             emu = gcn_emu.Emulator(text, mem, lds_bytes=g.lds_bytes, check=check, dontcare=[((b + 1) * c.BUF, (b + 1) * c.BUF + 256) for b in range(2)])  # the two spill positions meet dy's zero columns
-            total += emu.run_workgroup(4, a_ka, wg_id=(ci_t + c.NCI * co_t, sp, 0))
+            total += emu.run_workgroup(4, a_ka, wg_id=(sp, ci_t + c.NCI * co_t, 0))
     got = mem.array(a_p, np.float32, p0.shape).astype(np.float64)
     # tiles of split s = images [s*tps*ti/tn, ...) (whole images only when tn == 1; row tiles: the split must cover whole images or the
     # reference is computed per row range)
