@@ -35,7 +35,7 @@ def main():
     with open(os.path.join(out_dir, "wg1_meta.inc"), "w") as f:
         for name in wg1_gen.VARIANTS:
             c, g, _ = wg1_gen.generate(name)
-            f.write('{"%s", %d, %d, %d, %d},\n' % (name, c.C, c.CO, g.lds_bytes, wg1_gen.Gen.KA["size"]))
+            f.write('{"%s", %d, %d, %d, %d, %d, %d},\n' % (name, c.C, c.CO, c.XP, c.DP, g.lds_bytes, wg1_gen.Gen.KA["size"]))
 
 
 if __name__ == "__main__":

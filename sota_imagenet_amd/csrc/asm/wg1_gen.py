@@ -35,11 +35,11 @@ class W1Cfg:
     name: str
     C: int        # channels of the input tensor
     CO: int       # channels of dy
+    XP: int = 2   # in planes of 64 channels per workgroup
+    DP: int = 4   # dy planes of 64 channels per workgroup; a wave owns DP of the 4 * DP dy fragments (16 * DP output channels)
     NBUF: int = 3
 
     TP = 64       # positions per tile
-    XP = 2        # in planes per workgroup (128 ci)
-    DP = 4        # dy planes per workgroup (256 co)
 
     @property
     def BUF(self):
@@ -51,11 +51,11 @@ class W1Cfg:
 
     @property
     def NCI(self):
-        return self.C // 128
+        return self.C // (64 * self.XP)
 
     @property
     def NCO(self):
-        return self.CO // 256
+        return self.CO // (64 * self.DP)
 
 
 class Gen(wg_gen.Gen):
@@ -68,10 +68,11 @@ class Gen(wg_gen.Gen):
         self.S = Alloc("s", 4, 100)
         self.V = Alloc("v", 1, 256)
 
-    NPC = 12  # pieces per wave and tile: 6 planes x 2 blocks
 
     def gen(self):
         c, S, V = self.c, self.S, self.V
+        self.NPC = 2 * (c.XP + c.DP)   # pieces per wave and tile: every plane's two 8-position blocks w and w + 4
+        self.NF, self.NX = c.DP, 4 * c.XP  # dy / in fragments of a wave
         self.s_split, self.s_pair = 2, 3   # grid = (splits, channel-tile pairs): the workgroups of one split share their pixels' bytes and
         # land on the same XCD (workgroup id % 8), so the sharing happens in that XCD's L2
         self.srd = {"d": S.get(4, 4), "x": S.get(4, 4)}
@@ -82,20 +83,20 @@ class Gen(wg_gen.Gen):
         self.s_srcw = {"d": S.get(), "x": S.get()}
         self.s_tsrc = {"d": S.get(), "x": S.get()}
         # read bases per buffer: dy fragment n of this wave's plane, in fragment n of plane 0 (plane 1: + 8192 as an immediate)
-        self.vD_rd = [[V.get() for n in range(4)] for b in range(c.NBUF)]
+        self.vD_rd = [[V.get() for n in range(self.NF)] for b in range(c.NBUF)]
         self.vX_rd = [[V.get() for n in range(4)] for b in range(c.NBUF)]
         self.v_dma = {"d": V.get(), "x": V.get()}
         self.v_tmp = [V.get(), V.get()]
         self.v_out = V.get()
         self.F = []
         for s in range(2):
-            fd = V.get(16, 4)
-            fx = V.get(32, 4)
+            fd = V.get(4 * self.NF, 4)
+            fx = V.get(4 * self.NX, 4)
             self.F.append((fd, fx))
         self.v_t = [self.F[1][1] + i for i in range(12)]
         self.nvgpr = V.n
         self.accum_offset = (self.nvgpr + 7) // 8 * 8
-        self.nagpr = 128
+        self.nagpr = 4 * self.NF * self.NX
         self.tmp_i = 0
         self.prologue()
         self.mainloop()
@@ -133,10 +134,10 @@ class Gen(wg_gen.Gen):
         c = self.c
         fd, fx = self.F[fset]
         out = []
-        for n in range(4):
+        for n in range(self.NF):
             for h in range(2):
                 out.append("ds_read_b64_tr_b16 %s, %s offset:%d" % (R("v", fd + 4 * n + 2 * h, 2), R("v", self.vD_rd[buf][n]), step * 4096 + h * 2048))
-        for j in range(8):
+        for j in range(self.NX):
             q, n = divmod(j, 4)
             for h in range(2):
                 out.append("ds_read_b64_tr_b16 %s, %s offset:%d" % (R("v", fx + 4 * j + 2 * h, 2), R("v", self.vX_rd[buf][n]), q * 8192 + step * 4096 + h * 2048))
@@ -145,9 +146,9 @@ class Gen(wg_gen.Gen):
     def mfmas(self, fset):
         fd, fx = self.F[fset]
         out = []
-        for j in range(8):
-            for n in range(4):
-                acc = (j * 4 + n) * 4
+        for j in range(self.NX):
+            for n in range(self.NF):
+                acc = (j * self.NF + n) * 4
                 out.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (R("a", acc, 4), R("v", fx + 4 * j, 4), R("v", fd + 4 * n, 4), R("a", acc, 4)))
         return out
 
@@ -185,20 +186,20 @@ class Gen(wg_gen.Gen):
         nslab = c.CO * c.C * 4
         e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_split), nslab))
         e("s_mul_hi_u32 %s, %s, %d" % (R("s", t1), R("s", self.s_split), nslab))
-        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t2), R("s", self.s_co), 256 * c.C * 4))
-        e("s_lshl_b32 %s, %s, 9" % (R("s", self.s_t3), R("s", self.s_ci)))
+        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t2), R("s", self.s_co), c.DP * 64 * c.C * 4))
+        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t3), R("s", self.s_ci), c.XP * 64 * 4))
         e("s_add_u32 %s, %s, %s" % (R("s", self.s_t2), R("s", self.s_t2), R("s", self.s_t3)))
         e("s_add_u32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", self.s_t2)))
         e("s_addc_u32 %s, %s, 0" % (R("s", t1), R("s", t1)))
         e("s_add_u32 %s, %s, %s" % (R("s", self.srdP), R("s", ka + 4), R("s", t0)))
         e("s_addc_u32 %s, %s, %s" % (R("s", self.srdP + 1), R("s", ka + 5), R("s", t1)))
         e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdP + 1), R("s", self.srdP + 1)))
-        e("s_mov_b32 %s, %d" % (R("s", self.srdP + 2), 256 * c.C * 4))
+        e("s_mov_b32 %s, %d" % (R("s", self.srdP + 2), c.DP * 64 * c.C * 4))
         e("s_mov_b32 %s, 0x00020000" % R("s", self.srdP + 3))
-        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_outw), R("s", self.s_w), 64 * c.C * 4), "this wave's 64 output channels in the slab")
-        # channel tile byte offsets into the pixel rows: 128 ci = 256 B, 256 co = 512 B
-        e("s_lshl_b32 %s, %s, 8" % (R("s", self.s_ci), R("s", self.s_ci)))
-        e("s_lshl_b32 %s, %s, 9" % (R("s", self.s_co), R("s", self.s_co)))
+        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_outw), R("s", self.s_w), 16 * c.DP * c.C * 4), "this wave's output channels in the slab")
+        # channel tile byte offsets into the pixel rows
+        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_ci), R("s", self.s_ci), c.XP * 128))
+        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_co), R("s", self.s_co), c.DP * 128))
         for k, chn, ptr, tile_ch in (("d", c.CO, 0, self.s_co), ("x", c.C, 2, self.s_ci)):
             srd = self.srd[k]
             e("s_add_u32 %s, %s, %s" % (R("s", srd), R("s", ka + ptr), R("s", tile_ch)))
@@ -236,15 +237,24 @@ class Gen(wg_gen.Gen):
         e("v_lshlrev_b32 %s, 3, %s" % (R("v", p8), R("v", p8)))
         e("v_lshl_add_u32 %s, %s, 7, %s" % (R("v", p8), R("v", row), R("v", p8)))
         e("v_and_b32 %s, 6, %s" % (R("v", cc), R("v", row)))
-        e("s_lshl_b32 %s, %s, 13" % (R("s", t0), R("s", self.s_w)), "this wave's dy plane")
         for n in range(4):
             e("v_xor_b32 %s, %d, %s" % (R("v", rk), 2 * n, R("v", cc)))
             e("v_lshl_add_u32 %s, %s, 4, %s" % (R("v", rk), R("v", rk), R("v", p8)))
             for b in range(c.NBUF):
                 e("v_add_u32 %s, %d, %s" % (R("v", self.vX_rd[b][n]), b * c.BUF + c.DP * c.TP * 128, R("v", rk)))
+        # dy fragment f of this wave = fragment (w * DP + f) of the workgroup's 4 * DP: plane (.. >> 2), fragment-in-plane (.. & 3)
+        for f in range(self.NF):
+            e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_w), c.DP))
+            e("s_add_u32 %s, %s, %d" % (R("s", t0), R("s", t0), f))
+            e("s_and_b32 %s, %s, 3" % (R("s", t1), R("s", t0)))
+            e("s_lshl_b32 %s, %s, 1" % (R("s", t1), R("s", t1)))
+            e("s_lshr_b32 %s, %s, 2" % (R("s", t0), R("s", t0)))
+            e("s_lshl_b32 %s, %s, 13" % (R("s", t0), R("s", t0)))
+            e("v_xor_b32 %s, %s, %s" % (R("v", rk), R("s", t1), R("v", cc)))
+            e("v_lshl_add_u32 %s, %s, 4, %s" % (R("v", rk), R("v", rk), R("v", p8)))
             e("v_add_u32 %s, %s, %s" % (R("v", rk), R("s", t0), R("v", rk)))
             for b in range(c.NBUF):
-                e("v_add_u32 %s, %d, %s" % (R("v", self.vD_rd[b][n]), b * c.BUF, R("v", rk)))
+                e("v_add_u32 %s, %d, %s" % (R("v", self.vD_rd[b][f]), b * c.BUF, R("v", rk)))
         for i in range(self.nagpr):
             e("v_accvgpr_write_b32 a%d, 0" % i)
         e("s_waitcnt vmcnt(%d)" % (self.NPC + self.NPC // 2), "tile 0 has landed")
@@ -254,7 +264,7 @@ class Gen(wg_gen.Gen):
 
     def mainloop(self):
         c, e = self.c, self.e
-        self.comment("---- main loop: %d tiles per trip (the LDS buffers rotate), 2 k-steps of 32 MFMAs per tile" % c.NBUF)
+        self.comment("---- main loop: %d tiles per trip (the LDS buffers rotate), 2 k-steps of %d MFMAs per tile" % (c.NBUF, self.NF * self.NX))
         top, done = self.newlabel("loop"), self.newlabel("done")
         self.label(top)
         for b in range(c.NBUF):
@@ -289,14 +299,14 @@ class Gen(wg_gen.Gen):
 
     def epilogue(self):
         c, e = self.c, self.e
-        self.comment("---- epilogue: 32 accumulator tiles -> this split's slab")
+        self.comment("---- epilogue: the accumulator tiles -> this split's slab")
         e("s_waitcnt vmcnt(0)", "the look-ahead pieces (never used) have landed: no LDS-DMA is in flight when the wave ends")
         e("s_waitcnt lgkmcnt(0)")
         e("s_nop 15")
         e("s_nop 15")
-        for j in range(8):
-            for n in range(4):
-                acc = (j * 4 + n) * 4
+        for j in range(self.NX):
+            for n in range(self.NF):
+                acc = (j * self.NF + n) * 4
                 e("s_add_u32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_outw), (n * 16 * c.C + j * 16) * 4))
                 e("buffer_store_dwordx4 %s, %s, %s, %s offen" % (R("a", acc, 4), R("v", self.v_out), R("s", self.srdP, 4), R("s", self.s_t0)))
         e("s_waitcnt vmcnt(0)")
@@ -310,7 +320,14 @@ VARIANTS = {
     "wg1_c256_o1024": W1Cfg("wg1_c256_o1024", C=256, CO=1024),
     "wg1_c2048_o512": W1Cfg("wg1_c2048_o512", C=2048, CO=512),
     "wg1_c512_o2048": W1Cfg("wg1_c512_o2048", C=512, CO=2048),
-    "wg1_c1024_o2048": W1Cfg("wg1_c1024_o2048", C=1024, CO=2048),   # layer 4's downsample (stride 2: the caller's pixel gather excludes it today)
+    # first blocks of layers 3 and 4 (conv1 runs before the stride), layer 2 (512 <-> 128, 256 -> 128), layer 1 (256 <-> 64)
+    "wg1_c512_o256": W1Cfg("wg1_c512_o256", C=512, CO=256),
+    "wg1_c1024_o512": W1Cfg("wg1_c1024_o512", C=1024, CO=512),
+    "wg1_c128_o512": W1Cfg("wg1_c128_o512", C=128, CO=512),
+    "wg1_c512_o128": W1Cfg("wg1_c512_o128", C=512, CO=128, XP=4, DP=2),
+    "wg1_c256_o128": W1Cfg("wg1_c256_o128", C=256, CO=128, XP=4, DP=2),
+    "wg1_c64_o256": W1Cfg("wg1_c64_o256", C=64, CO=256, XP=1, DP=4),
+    "wg1_c256_o64": W1Cfg("wg1_c256_o64", C=256, CO=64, XP=4, DP=1),
 }
 
 

@@ -43,10 +43,10 @@ const WgVariant g_wg[] = {
 };
 constexpr int NWG = (int)(sizeof(g_wg) / sizeof(g_wg[0]));
 
-// 1x1 weight-gradient kernels (asm/wg1_gen.py): 128 ci x 256 co per workgroup, tiles of 64 pixels
+// 1x1 weight-gradient kernels (asm/wg1_gen.py): 64 XP ci x 64 DP co per workgroup, tiles of 64 pixels
 struct Wg1Variant {
   const char* name;
-  int C, CO, lds, kernarg;
+  int C, CO, XP, DP, lds, kernarg;
 };
 const Wg1Variant g_wg1[] = {
 #include "build/asm/wg1_meta.inc"
@@ -214,7 +214,7 @@ int wg3_plan(int dtype, const WgradArgs& a) {
     pairs = (v.C / 64) * (v.CO / 64);
     ntiles = a.N * v.tn / v.ti;
   } else {
-    pairs = (g_wg1[v1].C / 128) * (g_wg1[v1].CO / 256);
+    pairs = (g_wg1[v1].C / (64 * g_wg1[v1].XP)) * (g_wg1[v1].CO / (64 * g_wg1[v1].DP));
     ntiles = (a.N * a.Ho * a.Wo + 63) / 64;
   }
   const int cus = device_cus();
@@ -249,7 +249,7 @@ int launch_wg3(const WgradArgs& a, int splits, hipStream_t stream) {
     MI355_ARG((k.ntiles + k.tps - 1) / k.tps == (unsigned)splits, "wg1: %d splits leave an empty split (%u tiles)", splits, k.ntiles);
     size_t ksize = sizeof(k);
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
-    const hipError_t e = hipModuleLaunchKernel(d->wg1[v1], (unsigned)splits, (unsigned)((v.C / 128) * (v.CO / 256)), 1, 256, 1, 1, 0, stream, nullptr, extra);
+    const hipError_t e = hipModuleLaunchKernel(d->wg1[v1], (unsigned)splits, (unsigned)((v.C / (64 * v.XP)) * (v.CO / (64 * v.DP))), 1, 256, 1, 1, 0, stream, nullptr, extra);
     if (e != hipSuccess) {
       set_error("wg1: hipModuleLaunchKernel(%s) -> %s", v.name, hipGetErrorString(e));
       return MI355_E_HIP;

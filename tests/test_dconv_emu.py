@@ -86,7 +86,9 @@ def test_weight_gradient_kernels_are_exact_in_the_emulator(name, kw):
 
 
 @pytest.mark.parametrize("name,kw", [("wg1_c256_o1024", dict(splits=2, tps=4, pairs=((1, 3),))), ("wg1_c1024_o256", dict(splits=1, tps=5, npix=300, pairs=((7, 0),))),
-                                     ("wg1_c512_o2048", dict(splits=2, tps=1, pairs=((3, 7),))), ("wg1_c2048_o512", dict(splits=1, tps=7, npix=400, pairs=((15, 1),)))])
+                                     ("wg1_c512_o2048", dict(splits=2, tps=1, pairs=((3, 7),))), ("wg1_c2048_o512", dict(splits=1, tps=7, npix=400, pairs=((15, 1),))),
+                                     ("wg1_c512_o128", dict(splits=1, tps=3, npix=150, pairs=((1, 0),))), ("wg1_c64_o256", dict(splits=2, tps=2, pairs=((0, 0),))),
+                                     ("wg1_c256_o64", dict(splits=1, tps=4, pairs=((0, 0),)))])
 def test_pointwise_weight_gradient_kernels_are_exact_in_the_emulator(name, kw):
     """csrc/asm/wg1_gen.py: tile counts of 1, 4, 5 and 7 per split (every exit of the three-buffer loop), a ragged last tile (300 and
     400 pixels), first and last channel tiles"""

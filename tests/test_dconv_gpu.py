@@ -108,10 +108,12 @@ def test_weight_gradient_on_random_data(dev):
         assert ((dw - ref).norm() / ref.norm()).item() < 1e-5  # fp32 accumulation of exact bf16 products: summation order only
 
 
-@pytest.mark.parametrize("N,H,Cin,Cout", [(256, 14, 1024, 256), (256, 14, 256, 1024), (256, 7, 2048, 512), (256, 7, 512, 2048), (3, 14, 256, 1024), (5, 7, 2048, 512)])
+@pytest.mark.parametrize("N,H,Cin,Cout", [(256, 14, 1024, 256), (256, 14, 256, 1024), (256, 7, 2048, 512), (256, 7, 512, 2048), (256, 28, 512, 128), (256, 28, 128, 512),
+                                          (256, 56, 256, 64), (256, 56, 64, 256), (256, 56, 256, 128), (256, 28, 512, 256), (256, 14, 1024, 512),
+                                          (3, 14, 256, 1024), (5, 7, 2048, 512), (3, 56, 64, 256), (3, 56, 256, 64), (3, 28, 512, 128)])
 def test_pointwise_weight_gradient_is_exact_on_integer_data(dev, N, H, Cin, Cout):
-    """the generated 1x1 weight-gradient kernels (csrc/asm/wg1_gen.py): flat 64-pixel tiles, ragged last tile (3 x 196 = 588 and
-    5 x 49 = 245 pixels are not multiples of 64), accumulation into an existing gradient"""
+    """the generated 1x1 weight-gradient kernels (csrc/asm/wg1_gen.py): every (channels, tile shape) variant at the baseline batch; flat
+    64-pixel tiles with a ragged last tile (3 x 196 = 588 and 5 x 49 = 245 pixels are not multiples of 64); accumulation into an existing gradient"""
     from sota_imagenet_amd import ops
 
     torch.manual_seed(5)

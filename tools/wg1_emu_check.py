@@ -43,7 +43,7 @@ def run(name, pairs=((0, 0),), splits=2, tps=2, npix=None, seed=0, check=True, *
         p_lo, p_hi = sp * tps * c.TP, min((sp + 1) * tps * c.TP, npix)
         ref = dy[p_lo:p_hi].astype(np.float64).T @ x[p_lo:p_hi].astype(np.float64)
         for ci_t, co_t in pairs:
-            sl = (sp, slice(co_t * 256, co_t * 256 + 256), slice(ci_t * 128, ci_t * 128 + 128))
+            sl = (sp, slice(co_t * 64 * c.DP, (co_t + 1) * 64 * c.DP), slice(ci_t * 64 * c.XP, (ci_t + 1) * 64 * c.XP))
             a = got[sl]
             res["max_err"] = max(res["max_err"], float(np.abs(a - ref[sl[1], sl[2]]).max()) if not np.isnan(a).any() else float("inf"))
             touched[sl] = True

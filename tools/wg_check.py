@@ -10,7 +10,8 @@ sys.path.insert(0, "tests")
 from test_dconv_gpu import WG_SHAPES, _wgrad_ref  # noqa: E402
 
 dev = "cuda"
-K1 = [(256, 14, 1024, 256), (256, 14, 256, 1024), (256, 7, 2048, 512), (256, 7, 512, 2048), (3, 14, 256, 1024), (5, 7, 2048, 512)]
+K1 = [(256, 14, 1024, 256), (256, 14, 256, 1024), (256, 7, 2048, 512), (256, 7, 512, 2048), (256, 28, 512, 128), (256, 28, 128, 512), (256, 56, 256, 64),
+      (256, 56, 64, 256), (256, 56, 256, 128), (256, 28, 512, 256), (256, 14, 1024, 512), (3, 14, 256, 1024), (5, 7, 2048, 512), (3, 56, 64, 256)]
 for (N, H, Cin, Cout) in K1:
     torch.manual_seed(0)
     x = torch.randint(-2, 3, (N, H, H, Cin), device=dev).to(torch.bfloat16)
