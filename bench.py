@@ -33,10 +33,12 @@ EVENT_STEPS = 2  # timed steps whose conv / BN launches carry HIP-event pairs fo
 HBM_CLASS = 7  # executor profile class of bn_bwd_apply_kernel, the largest HBM-bound kernel of the step
 # profile class -> kernel symbols (template instances of one source; names as tools/pmc_traffic.py writes them)
 KERNEL_NAMES = {0: ["igemm_kernel<{T},128,128>", "igemm_kernel<{T},256,256>", "igemm_kernel<{T},256,128>", "igemm8_kernel<224,256>", "igemm8_kernel<256,128>",
-                    "dconv_l3", "dconv_l4", "pw_k256_n1024"],  # (bf16 only: the generated assembly kernels of asm/dconv_gen.py, asm/pw_gen.py)
+                    "dconv_l3", "dconv_l4", "pw_k256_n1024", "pk_k1024_w196", "pk_k1024_w98", "pk_k2048_w98"],  # (bf16 only: the generated assembly kernels of asm/dconv_gen.py, asm/pw_gen.py)
                 1: ["igemm_kernel<{T},128,64>"],
-                2: ["wgrad_kernel<{T},128,128>", "wgrad_kernel<{T},128,64>", "wg3_l2", "wg3_l3", "wg3_l4"],  # (wg3_*: asm/wg_gen.py, bf16 only)
-                3: ["wgrad_kernel<{T},64,128>", "wgrad_kernel<{T},64,64>", "wg3_l1"]}
+                # (wg3_* / wg1_*: the generated kernels of asm/wg_gen.py / asm/wg1_gen.py, bf16 only; class by Cout % 128 as the executor files them)
+                2: ["wgrad_kernel<{T},128,128>", "wgrad_kernel<{T},128,64>", "wg3_l2", "wg3_l3", "wg3_l4", "wg1_c1024_o256", "wg1_c256_o1024", "wg1_c2048_o512",
+                    "wg1_c512_o2048", "wg1_c512_o256", "wg1_c1024_o512", "wg1_c128_o512", "wg1_c512_o128", "wg1_c256_o128", "wg1_c64_o256"],
+                3: ["wgrad_kernel<{T},64,128>", "wgrad_kernel<{T},64,64>", "wg3_l1", "wg1_c256_o64"]}
 
 
 def runner_rate(N, S, steps):
@@ -298,7 +300,7 @@ def main():
             ach = flops / (tot_ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[dtype]
             knames = ["igemm8_kernel<224,256,EB=1>", "igemm8_kernel<256,128,EB=1>"] if dtype == "fp8" else \
-                [n.format(T=tdt) for n in KERNEL_NAMES[dom] if not (dtype == "fp32" and n.startswith(("igemm8", "dconv_", "pw_", "wg3_")))]
+                [n.format(T=tdt) for n in KERNEL_NAMES[dom] if not (dtype == "fp32" and n.startswith(("igemm8", "dconv_", "pw_", "pk_", "wg3_", "wg1_")))]
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": pmc_traffic(knames, dtype, N, S), "kernel": " + ".join(knames),
                     "launches": launches, "avg_launch_ms": round(tot_ms / launches, 4),

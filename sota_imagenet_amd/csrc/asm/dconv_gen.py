@@ -888,6 +888,9 @@ class Gen:
         e("s_barrier", "every LDS-DMA of the (unused) lookahead has landed: the ring is free for the statistics scratch")
         e("s_nop 15")
         e("s_nop 15")
+        late1 = c.stats == 2 and getattr(self, "late_pair1", False)  # (pk_gen.py: the second register set lives in the fragment registers)
+        if late1:
+            issue_loads(1)
         if c.stats:
             # STAT scratch: [wm][256 channels][2] floats at LDS 0 ; this lane (r == 15) owns channels wn*128 + p*32 + kg*8 + e
             e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_wm), c.BN * 8))
@@ -900,7 +903,7 @@ class Gen:
                 for i in range(8):
                     e("v_mov_b32 %s, 0" % R("v", s1[i]))
                     e("v_mov_b32 %s, 0" % R("v", s2[i]))
-            if c.stats == 2 and p >= 2:
+            if c.stats == 2 and (p >= 2 or (late1 and p == 1)):
                 # pair p's loads were issued behind pair p - 2; younger: pair p - 1's stores (+ pair p + 1's loads)
                 e("s_waitcnt vmcnt(%d)" % (0 if c.probe & 40 else c.MFR + (GL if p + 1 < npair else 0)))
             for m in range(c.MFR):

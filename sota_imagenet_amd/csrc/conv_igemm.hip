@@ -826,6 +826,8 @@ bool dconv_legal(const IgemmArgs& a, int nclass);
 int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows);
 bool pw_legal(const IgemmArgs& a, int nclass);  // the persistent pointwise kernels (asm/pw_gen.py): output-heavy 1x1 forward
 int launch_pw(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows);
+bool pk_legal(const IgemmArgs& a, int nclass);  // the long-reduction pointwise kernels (asm/pk_gen.py): K = 1024 / 2048 -> 256-column tiles
+int launch_pk(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows);
 
 // conv_igemm8.hip
 bool igemm8_legal(const IgemmArgs& a, int nclass, int bn);
@@ -901,6 +903,7 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
   if (dtype == MI355_BF16) {
     if (dconv_legal(a, nclass)) return launch_dconv(a, nclass, stream, stat_rows);
     if (pw_legal(a, nclass)) return launch_pw(a, nclass, stream, stat_rows);
+    if (pk_legal(a, nclass)) return launch_pk(a, nclass, stream, stat_rows);
     {
       // the stem as a direct convolution out of raw input rows (stem_direct.hip; MI355_STEM_DIRECT=0: the row-pair implicit GEMM)
       const char* sd = getenv("MI355_STEM_DIRECT");

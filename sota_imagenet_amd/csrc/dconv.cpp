@@ -33,6 +33,16 @@ const PwVariant g_pw[] = {
 };
 constexpr int NPW = (int)(sizeof(g_pw) / sizeof(g_pw[0]));
 
+// long-reduction pointwise kernels (asm/pk_gen.py): tiles of W pixels x 256 columns
+struct PkVariant {
+  const char* name;
+  int W, K, N, stats, lds, kernarg;
+};
+const PkVariant g_pk[] = {
+#include "build/asm/pk_meta.inc"
+};
+constexpr int NPK = (int)(sizeof(g_pk) / sizeof(g_pk[0]));
+
 // 3x3 weight-gradient kernels (asm/wg_gen.py)
 struct WgVariant {
   const char* name;
@@ -63,6 +73,7 @@ struct DevState {
   hipFunction_t fn[NVAR] = {};
   hipFunction_t pw[NPW] = {};
   hipFunction_t wg[NWG] = {};
+  hipFunction_t pk[NPK] = {};
   hipFunction_t wg1[NWG1] = {};
 };
 DevState g_dev[64];
@@ -102,6 +113,13 @@ bool dev_state(DevState** out) {
       e = hipModuleGetFunction(&d.wg[i], d.mod, g_wg[i].name);
       if (e != hipSuccess) {
         set_error("dconv: hipModuleGetFunction(%s) -> %s", g_wg[i].name, hipGetErrorString(e));
+        return false;
+      }
+    }
+    for (int i = 0; i < NPK; ++i) {
+      e = hipModuleGetFunction(&d.pk[i], d.mod, g_pk[i].name);
+      if (e != hipSuccess) {
+        set_error("dconv: hipModuleGetFunction(%s) -> %s", g_pk[i].name, hipGetErrorString(e));
         return false;
       }
     }
@@ -190,6 +208,20 @@ int find_wg1(int dtype, const WgradArgs& a) {
 }
 
 int wanted_stats(const IgemmArgs& a) { return a.stat_partial == nullptr ? 0 : (a.bn_y != nullptr ? 2 : 1); }
+
+// the long-reduction pointwise kernel that can run this launch (1x1, stride 1, no addend), or -1
+int find_pk(const IgemmArgs& a, int nclass, int stats) {
+  if (nclass != 1 || a.IS != 1 || a.OS != 1 || a.pair_delta != 0 || a.wtaps != 1 || a.cls[0].ntaps != 1) return -1;
+  if (a.cls[0].taps[0].dh != 0 || a.cls[0].taps[0].dw != 0 || a.cls[0].taps[0].wtap != 0 || a.cls[0].ph != 0 || a.cls[0].pw != 0) return -1;
+  if (a.Hsub != a.Hin || a.Wsub != a.Win || a.Hout != a.Hin || a.Wout != a.Win) return -1;
+  if (a.pix_stride != a.Ck || a.addend != nullptr || a.fin.mode != 0 || a.q_scale_in != nullptr || a.q_scale_wt != nullptr) return -1;
+  const long M = (long)a.N * a.Hin * a.Win;
+  for (int i = 0; i < NPK; ++i) {
+    const PkVariant& v = g_pk[i];
+    if (v.K == a.Ck && v.N == a.Ncols && v.stats == stats && M % v.W == 0 && M / v.W < (1 << 20)) return i;
+  }
+  return -1;
+}
 
 }  // namespace
 
@@ -319,6 +351,58 @@ int launch_pw(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
     return MI355_E_HIP;
   }
   if (stat_rows) *stat_rows = a.stat_partial ? (int)grid : 0;
+  return 0;
+}
+
+bool pk_legal(const IgemmArgs& a, int nclass) {
+  static const bool on = !(getenv("MI355_PK") && getenv("MI355_PK")[0] == '0');
+  if (!on || !dconv_enabled()) return false;
+  const int v = find_pk(a, nclass, wanted_stats(a));
+  if (v < 0) return false;
+  const long tiles = (long)a.N * a.Hin * a.Win / g_pk[v].W;   // one partial statistics row per pixel tile
+  return a.stat_partial == nullptr || tiles <= (a.stat_rows_cap > 0 ? a.stat_rows_cap : 768);
+}
+
+int launch_pk(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
+  const int vi = find_pk(a, nclass, wanted_stats(a));
+  MI355_ARG(vi >= 0, "pk: no kernel variant for this launch");
+  const PkVariant& v = g_pk[vi];
+  DevState* d = nullptr;
+  if (!dev_state(&d)) return MI355_E_HIP;
+  struct __attribute__((packed)) KArgs {
+    const void* in;
+    const void* wt;
+    void* out;
+    float* stat;
+    const void* bn_y;
+    const void* bn_bits;
+    const float* bn_mean;
+    const float* bn_invstd;
+    const void* rsvd;
+    unsigned nchunks;
+    unsigned pad[13];
+  } k;
+  static_assert(sizeof(KArgs) == 128, "kernarg layout of asm/pk_gen.py (Gen.KA)");
+  MI355_ARG((int)sizeof(KArgs) == v.kernarg, "pk: kernarg size mismatch");
+  memset(&k, 0, sizeof(k));
+  k.in = a.in;
+  k.wt = a.wt;
+  k.out = a.out;
+  k.stat = a.stat_partial;
+  k.bn_y = a.bn_y;
+  k.bn_bits = a.bn_bits;
+  k.bn_mean = a.bn_mean;
+  k.bn_invstd = a.bn_invstd;
+  k.nchunks = (unsigned)(a.Ck / 64);
+  const unsigned tiles = (unsigned)((long)a.N * a.Hin * a.Win / v.W);
+  size_t ksize = sizeof(k);
+  void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
+  const hipError_t e = hipModuleLaunchKernel(d->pk[vi], tiles, (unsigned)(v.N / 256), 1, 256, 1, 1, 0, stream, nullptr, extra);
+  if (e != hipSuccess) {
+    set_error("pk: hipModuleLaunchKernel(%s) -> %s", v.name, hipGetErrorString(e));
+    return MI355_E_HIP;
+  }
+  if (stat_rows) *stat_rows = a.stat_partial ? (int)tiles : 0;
   return 0;
 }
 

@@ -99,6 +99,19 @@ def test_pointwise_weight_gradient_kernels_are_exact_in_the_emulator(name, kw):
     assert r["max_err"] == 0.0 and r["untouched_ok"]
 
 
+@pytest.mark.parametrize("name,kw", [("pk_k1024_w196_s1", dict(tiles=(1,), Cin=256)), ("pk_k1024_w196_s2", dict(tiles=(0, 2), Cin=448)),
+                                     ("pk_k2048_w98_s1", dict(tiles=(1,), ntile=1, Cin=320)), ("pk_k2048_w98_s2", dict(tiles=(0,), ntile=1, Cin=192)),
+                                     ("pk_k1024_w196_s0", dict(tiles=(0,), Cin=64)), ("pk_k2048_w98_s0", dict(tiles=(2,), Cin=384))])
+def test_long_reduction_pointwise_kernels_are_exact_in_the_emulator(name, kw):
+    """csrc/asm/pk_gen.py with 1 .. 7 chunks of 64 channels (every exit of the unrolled buffer rotation), both column tiles, the three
+    epilogues (none / BN statistics / BN-backward sums, the latter with the late second register set at 13 fragments)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pk_emu_check
+
+    r = pk_emu_check.run(name, **kw)
+    assert r["max_err"] == 0.0 and r["untouched_ok"] and r.get("stat_err", 0.0) <= 1e-6
+
+
 def test_the_transposed_lds_read_of_the_emulator_follows_the_documented_lane_map():
     """ds_read_b64_tr_b16 (guide T10): per 16 lanes a 4 x 16 block; lane 4q + p addresses row q, columns 4p .. 4p + 3; lane i receives
     column i, row q in element q"""
@@ -153,10 +166,11 @@ def test_every_shipped_variant_assembles_for_gfx950_within_the_register_and_lds_
     sys.path.insert(0, os.path.join(ROOT, "sota_imagenet_amd", "csrc", "asm"))
     import dconv_gen
     import pw_gen
+    import pk_gen
     import wg1_gen
     import wg_gen
 
-    for mod in (dconv_gen, pw_gen, wg_gen, wg1_gen):
+    for mod in (dconv_gen, pw_gen, pk_gen, wg_gen, wg1_gen):
         for name in mod.VARIANTS:
             c, g, text = mod.generate(name)
             assert g.accum_offset + g.nagpr <= 512
