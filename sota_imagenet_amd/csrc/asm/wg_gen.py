@@ -579,6 +579,8 @@ VARIANTS = {
     "wg3_l2": WCfg("wg3_l2", H=28, W=28, P=32, C=128, CO=128, geom="rows", DR=7),
     "wg3_l4": WCfg("wg3_l4", H=7, W=7, P=8, C=512, CO=512, geom="pack", DR=32, IPT=4),
     "wg3_l1": WCfg("wg3_l1", H=56, W=56, P=64, C=64, CO=64, geom="rows", DR=2),
+    # BResNet-50's deep stem (configs[3]): the 3x3 convolutions at 112 x 112 with channels padded to 64 (one-row tiles, 112 per image)
+    "wg3_s112": WCfg("wg3_s112", H=112, W=112, P=128, C=64, CO=64, geom="rows", DR=1),
 }
 
 

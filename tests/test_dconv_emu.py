@@ -74,7 +74,7 @@ def test_the_emulator_rejects_an_lds_read_before_the_dma_wait():
 
 @pytest.mark.parametrize("name,kw", [("wg3_l3", dict(splits=2, tps=3, pairs=((3, 2),))), ("wg3_l3", dict(splits=3, tps=1, pairs=((0, 1),))),
                                      ("wg3_l2", dict(splits=3, tps=2, pairs=((1, 0),))), ("wg3_l4", dict(splits=2, tps=2, pairs=((5, 7),))),
-                                     ("wg3_l1", dict(splits=1, tps=29))])
+                                     ("wg3_l1", dict(splits=1, tps=29)), ("wg3_s112", dict(splits=2, tps=3))])
 def test_weight_gradient_kernels_are_exact_in_the_emulator(name, kw):
     """csrc/asm/wg_gen.py: odd and single tile counts per split, splits that end inside an image (row tiles), last channel tiles;
     every slab element of the run workgroups exact, nothing else written, no LDS-DMA protocol violation"""

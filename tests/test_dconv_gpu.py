@@ -65,7 +65,7 @@ def test_other_batch_sizes_take_the_same_kernels(dev):
 
 
 WG_SHAPES = [(256, 14, 256, 256), (256, 28, 128, 128), (256, 7, 512, 512), (256, 56, 64, 64), (8, 14, 256, 256), (12, 28, 128, 128), (20, 7, 512, 512),
-             (5, 56, 64, 64)]
+             (5, 56, 64, 64), (64, 112, 64, 64)]
 
 
 def _wgrad_ref(dy, x):

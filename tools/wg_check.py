@@ -30,7 +30,7 @@ for (N, H, Cin, Cout) in K1:
     us = (time.perf_counter() - t0) / 20 * 1e6
     fl = 2.0 * N * H * H * Cin * Cout
     print(f"1x1 N={N} H={H} {Cin}->{Cout}: exact={ok} maxerr={(dw - ref).abs().max().item():.3g}  {us:.1f} us (wgrad + reduce)  {fl / us / 1e6:.0f} TF/s", flush=True)
-for (N, H, Cin, Cout) in WG_SHAPES:
+for (N, H, Cin, Cout) in WG_SHAPES + [(256, 112, 64, 64)]:
     torch.manual_seed(0)
     x = torch.randint(-2, 3, (N, H, H, Cin), device=dev).to(torch.bfloat16)
     dy = torch.randint(-2, 3, (N, H, H, Cout), device=dev).to(torch.bfloat16)
