@@ -17,7 +17,6 @@
 
 #include <algorithm>
 
-#include "bn_fin.h"
 #include "common.h"
 #include "vec.h"
 
@@ -93,7 +92,6 @@ struct ReduceArgs {
   int M, C;
   float slope;        // MASK == 1: gradient factor where the activation was <= 0 (0 ReLU, 0.01 leaky ReLU)
   EcaGrad eg;         // MASK == 4: g stands for g * keep[n] * gate[n][c] + dpool[n][c] (the ECA backward applied on the fly)
-  BnFinArgs fin;      // fin.mode != 0: the last-arriving workgroup of a channel slice also finalizes it (bn_fin.h)
 };
 
 // MODE 0: s1 = sum x, s2 = sum x^2.   MODE 1: s1 = sum dz, s2 = sum dz*xhat.
@@ -133,8 +131,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
     if (blockIdx.x == 0 && r == 0) {
 #pragma unroll
       for (int e = 0; e < V; ++e) {
-        if (p.fin.mode != 0) store_wt(p.pivot + c0 + e, mu[e]);  // (read by the finalizing workgroup, possibly behind another L2)
-        else p.pivot[c0 + e] = mu[e];
+        p.pivot[c0 + e] = mu[e];
       }
     }
   }
@@ -215,18 +212,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const ReduceArgs p) {
         b += red[1][(rr * tpr + tid) * V + e];
       }
       const int c = (blockIdx.y * tpr + tid) * V + e;
-      if (p.fin.mode != 0) {
-        store_wt(p.partial + ((size_t)blockIdx.x * 2 + 0) * p.C + c, a);
-        store_wt(p.partial + ((size_t)blockIdx.x * 2 + 1) * p.C + c, b);
-      } else {
-        p.partial[((size_t)blockIdx.x * 2 + 0) * p.C + c] = a;
-        p.partial[((size_t)blockIdx.x * 2 + 1) * p.C + c] = b;
-      }
+      p.partial[((size_t)blockIdx.x * 2 + 0) * p.C + c] = a;
+      p.partial[((size_t)blockIdx.x * 2 + 1) * p.C + c] = b;
     }
   }
-  if (p.fin.mode != 0)
-    bn_fin_last_arriver(p.fin, p.partial, (int)gridDim.x, p.C, (int)blockIdx.y, (int)gridDim.x, (int)blockIdx.y * tpr * V, tpr * V,
-                        reinterpret_cast<char*>(&red[0][0]), tid, 256);
 }
 
 // 16 channels x 16 slices of the block partials per workgroup; fp64 sums in fixed order.
@@ -743,10 +732,9 @@ int check_c(int dtype, int C) {
 int bn_max_blocks() { return 2 * MAXBLK; }  // conv-epilogue statistics use 2 partial rows per workgroup (<= 1024)
 
 int launch_bn_stats(int dtype, const void* x, float* partial, float* pivot, int* nblk_out, int M, int C,
-                    hipStream_t s, const BnFinArgs* fin) {
+                    hipStream_t s) {
   MI355_TRY(check_c(dtype, C));
   ReduceArgs a{};
-  if (fin) a.fin = *fin;
   a.x = x;
   a.partial = partial;
   a.pivot = pivot;
@@ -859,10 +847,9 @@ int launch_bn_apply(int dtype, const void* x, const float* scale, const float* s
 
 int launch_bn_bwd_reduce(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
                          const float* invstd, void* dz_out, float* partial, int* nblk_out, int M, int C,
-                         hipStream_t s, const uint8_t* relu_bits, float slope, const BnFinArgs* fin, const EcaGrad* eg) {
+                         hipStream_t s, const uint8_t* relu_bits, float slope, const EcaGrad* eg) {
   MI355_TRY(check_c(dtype, C));
   ReduceArgs a{};
-  if (fin) a.fin = *fin;
   if (eg) a.eg = *eg;
   a.slope = slope;
   a.x = x;

@@ -322,7 +322,7 @@ int bn_back(mi355_bctx* c, VConv& v, VBN& b, const void* dout, float beta, hipSt
     const void* mask = (b.act != ACT_NONE && !bits) ? b.out : nullptr;
     const float slope = b.act == ACT_LEAKY ? 0.01f : 0.f;
     int nblk = 0;
-    MI355_TRY(launch_bn_bwd_reduce(c->dtype, dout, mask, v.y, b.mean, b.invstd, nullptr, partial, &nblk, M, b.Cp, s, bits, slope, nullptr, eg));
+    MI355_TRY(launch_bn_bwd_reduce(c->dtype, dout, mask, v.y, b.mean, b.invstd, nullptr, partial, &nblk, M, b.Cp, s, bits, slope, eg));
     MI355_TRY(launch_bn_bwd_finalize(partial, nblk, M, b.Cp, q.g, b.invstd, q.dg, q.db, staged ? 0.f : beta, coef, s));
     MI355_TRY(launch_bn_bwd_apply(c->dtype, dout, mask, v.y, b.mean, b.invstd, coef, v.dy, M, b.Cp, s, bits, slope, QuantOut(), eg));
   }

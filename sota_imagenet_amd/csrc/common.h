@@ -73,29 +73,6 @@ struct TapClass {
   int ph, pw, ntaps;
   Tap taps[9];
 };
-// BatchNorm finalize done by the last-arriving workgroup of the launch that produces the partial rows (bn_fin.h).
-// mode 0: off (a separate bn_finalize launch follows); 1: forward statistics -> mean / invstd / scale / shift (+ running stats);
-// 2: backward sums -> dgamma / dbeta / coef[3][C].  counters: >= 64 zero-initialised words owned by ONE stream.
-struct BnFinArgs {
-  int mode = 0;
-  int M = 0;
-  float eps = 0.f, momentum = 0.f, beta_acc = 0.f;
-  const float* pivot = nullptr;
-  const float* gamma = nullptr;
-  const float* beta = nullptr;
-  float* running_mean = nullptr;
-  float* running_var = nullptr;
-  float* save_mean = nullptr;
-  float* save_invstd = nullptr;
-  float* scale = nullptr;
-  float* shift = nullptr;
-  const float* invstd = nullptr;
-  float* dgamma = nullptr;
-  float* dbeta = nullptr;
-  float* coef = nullptr;
-  unsigned* counters = nullptr;
-};
-
 struct IgemmArgs {
   const void* in;      // [N][Hin][Win] pixels of pix_stride elements
   const void* wt;      // [Ncols][wtaps][Ck], K-contiguous
@@ -112,7 +89,6 @@ struct IgemmArgs {
   const uint8_t* bn_bits = nullptr;    // 1 byte per 16-byte vector of out
   const float* bn_mean = nullptr;      // [Ncols]
   const float* bn_invstd = nullptr;    // [Ncols]
-  BnFinArgs fin;                       // fin.mode != 0 (with stat_partial): the launch also finalizes the statistics it sums
   const float* q_scale_in = nullptr;   // fp8 operand launches (launch_igemm_fp8): the per-tensor quantisation scales of `in` and
   const float* q_scale_wt = nullptr;   // `wt` in device memory — out = acc / (*q_scale_in * *q_scale_wt); null: plain oscale
   int N, Hin, Win, pix_stride;
@@ -201,9 +177,7 @@ static inline int stem_hp(int H) { return H + 2 * STEM_PAD; }
 static inline int stem_wp(int W) { return W + STEM_RPAD; }  // 2*(W/2-1)+16 = W+14 <= Wp, Wp even
 
 // BN (bn.hip)
-// fin (optional, mode 1 / 2): the reduce launch also finalizes (bn_fin.h) — no launch_bn_finalize / launch_bn_bwd_finalize after it
-int launch_bn_stats(int dtype, const void* x, float* partial, float* pivot, int* nblk_out, int M, int C, hipStream_t s,
-                    const BnFinArgs* fin = nullptr);
+int launch_bn_stats(int dtype, const void* x, float* partial, float* pivot, int* nblk_out, int M, int C, hipStream_t s);
 int launch_bn_finalize(const float* partial, const float* pivot, int nblk, int M, int C, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                        float* scale, float* shift, float eps, float momentum, hipStream_t s);
@@ -233,8 +207,7 @@ struct EcaGrad {
 };
 int launch_bn_bwd_reduce(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,
                          const float* invstd, void* dz_out, float* partial, int* nblk_out, int M, int C,
-                         hipStream_t s, const uint8_t* relu_bits = nullptr, float slope = 0.f, const BnFinArgs* fin = nullptr,
-                         const EcaGrad* eg = nullptr);
+                         hipStream_t s, const uint8_t* relu_bits = nullptr, float slope = 0.f, const EcaGrad* eg = nullptr);
 int launch_bn_bwd_finalize(const float* partial, int nblk, int M, int C, const float* gamma, const float* invstd,
                            float* dgamma, float* dbeta, float beta_acc, float* coef /*[3][C]*/, hipStream_t s);
 int launch_bn_bwd_apply(int dtype, const void* g, const void* mask_src, const void* x, const float* mean,

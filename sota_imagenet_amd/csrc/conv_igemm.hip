@@ -37,7 +37,6 @@
 #include <type_traits>
 
 #include "common.h"
-#include "bn_fin.h"
 #include "lds_dma.h"
 #include "vec.h"
 
@@ -661,7 +660,6 @@ __global__ __launch_bounds__(128 * WMW, (BM == 256 ? 1 : (BN == 64 && NSTG == 2 
     const int chan = kp.ntpg * BN;
     const int grp = bx % kp.ngroups;
     float* row = p.stat_partial + (size_t)(bx / kp.ngroups) * 2 * p.Ncols + grp * chan;
-    const bool fin = p.fin.mode != 0;  // uniform
     for (int c = tid; c < chan; c += NT) {
       float a = 0.f, b = 0.f;
 #pragma unroll
@@ -669,16 +667,9 @@ __global__ __launch_bounds__(128 * WMW, (BM == 256 ? 1 : (BN == 64 && NSTG == 2 
         a += stat_acc[(w * chan + c) * 2];
         b += stat_acc[(w * chan + c) * 2 + 1];
       }
-      if (fin) {
-        store_wt(row + c, a);
-        store_wt(row + p.Ncols + c, b);
-      } else {
-        row[c] = a;
-        row[p.Ncols + c] = b;
-      }
+      row[c] = a;
+      row[p.Ncols + c] = b;
     }
-    // the workgroup of this n-tile group that arrives last turns the group's rows into the BatchNorm coefficients (bn_fin.h)
-    if (fin) bn_fin_last_arriver(p.fin, p.stat_partial, G / kp.ngroups, p.Ncols, grp, G / kp.ngroups, grp * chan, chan, smem, tid, NT);
   }
 }
 

@@ -36,7 +36,6 @@
 #include <set>
 #include <type_traits>
 
-#include "bn_fin.h"
 #include "common.h"
 #include "lds_dma.h"
 #include "vec.h"
@@ -773,20 +772,12 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
     const int chan = kp.ntpg * BN;
     const int grp = bx % kp.ngroups;
     float* row = p.stat_partial + (size_t)(bx / kp.ngroups) * 2 * p.Ncols + grp * chan;
-    const bool fin = p.fin.mode != 0;  // uniform
     for (int c = tid; c < chan; c += 512) {
       const float a = stat_acc[c * 2] + stat_acc[(chan + c) * 2];
       const float b = stat_acc[c * 2 + 1] + stat_acc[(chan + c) * 2 + 1];
-      if (fin) {
-        store_wt(row + c, a);
-        store_wt(row + p.Ncols + c, b);
-      } else {
-        row[c] = a;
-        row[p.Ncols + c] = b;
-      }
+      row[c] = a;
+      row[p.Ncols + c] = b;
     }
-    // the workgroup of this n-tile group that arrives last turns the group's rows into the BatchNorm coefficients (bn_fin.h)
-    if (fin) bn_fin_last_arriver(p.fin, p.stat_partial, G / kp.ngroups, p.Ncols, grp, G / kp.ngroups, grp * chan, chan, smem, tid, 512);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef MI355_STAMP8

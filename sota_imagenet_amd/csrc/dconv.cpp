@@ -158,7 +158,7 @@ bool tap_table(const TapClass& c, int wtap[9]) {
 int find_variant(const IgemmArgs& a, int nclass, int stats) {
   if (nclass != 1 || a.IS != 1 || a.OS != 1 || a.pair_delta != 0 || a.wtaps != 9) return -1;
   if (a.Hsub != a.Hin || a.Wsub != a.Win || a.Hout != a.Hin || a.Wout != a.Win) return -1;
-  if (a.pix_stride != a.Ck || a.addend != nullptr || a.fin.mode != 0) return -1;  // (sk_ws is optional scratch: not needed here)
+  if (a.pix_stride != a.Ck || a.addend != nullptr) return -1;  // (sk_ws is optional scratch: not needed here)
   if (a.q_scale_in != nullptr || a.q_scale_wt != nullptr) return -1;
   int wtap[9];
   if (!tap_table(a.cls[0], wtap)) return -1;
@@ -174,7 +174,7 @@ int find_pw(const IgemmArgs& a, int nclass, int stats) {
   if (nclass != 1 || a.IS != 1 || a.OS != 1 || a.pair_delta != 0 || a.wtaps != 1 || a.cls[0].ntaps != 1) return -1;
   if (a.cls[0].taps[0].dh != 0 || a.cls[0].taps[0].dw != 0 || a.cls[0].taps[0].wtap != 0 || a.cls[0].ph != 0 || a.cls[0].pw != 0) return -1;
   if (a.Hsub != a.Hin || a.Wsub != a.Win || a.Hout != a.Hin || a.Wout != a.Win) return -1;
-  if (a.pix_stride != a.Ck || a.addend != nullptr || a.fin.mode != 0 || a.q_scale_in != nullptr || a.q_scale_wt != nullptr) return -1;
+  if (a.pix_stride != a.Ck || a.addend != nullptr || a.q_scale_in != nullptr || a.q_scale_wt != nullptr) return -1;
   if (stats == 2) return -1;
   const long M = (long)a.N * a.Hin * a.Win;
   for (int i = 0; i < NPW; ++i) {
@@ -214,7 +214,7 @@ int find_pk(const IgemmArgs& a, int nclass, int stats) {
   if (nclass != 1 || a.IS != 1 || a.OS != 1 || a.pair_delta != 0 || a.wtaps != 1 || a.cls[0].ntaps != 1) return -1;
   if (a.cls[0].taps[0].dh != 0 || a.cls[0].taps[0].dw != 0 || a.cls[0].taps[0].wtap != 0 || a.cls[0].ph != 0 || a.cls[0].pw != 0) return -1;
   if (a.Hsub != a.Hin || a.Wsub != a.Win || a.Hout != a.Hin || a.Wout != a.Win) return -1;
-  if (a.pix_stride != a.Ck || a.addend != nullptr || a.fin.mode != 0 || a.q_scale_in != nullptr || a.q_scale_wt != nullptr) return -1;
+  if (a.pix_stride != a.Ck || a.addend != nullptr || a.q_scale_in != nullptr || a.q_scale_wt != nullptr) return -1;
   const long M = (long)a.N * a.Hin * a.Win;
   for (int i = 0; i < NPK; ++i) {
     const PkVariant& v = g_pk[i];

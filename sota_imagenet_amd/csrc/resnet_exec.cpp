@@ -51,8 +51,6 @@ struct ConvBN {
   int bwd_rows = 0;   // partial rows of THIS layer's BN-backward sums left in bn_partial by the dgrad that produced its
                       // activation gradient (0: none, bn_backward runs the standalone reduce kernel)
   bool is_stem = false;
-  bool fin_done = false;      // the launch that summed this layer's forward statistics also finalized them (bn_fin.h)
-  bool bwd_fin_done = false;  // ... and the same for its BN-backward sums
   // fp8 training step (ctx dtype MI355_FP8): forward / dgrad of this layer on e4m3 operands where the geometry allows it
   bool fp8_fwd = false, fp8_dgrad = false, fp8_wgrad = false;
   void* w_q = nullptr;          // e4m3 [Cout][taps][Cin]
@@ -152,10 +150,7 @@ struct mi355_ctx {
   // weight-gradient side stream (wgrad + split-K reduce run beside the BN-backward / dgrad chain of the main stream)
   bool overlap = false;
   bool fuse_bn_bwd = false;  // BN-backward sums in the dgrad epilogues (MI355_FUSE_BN_BWD=0/1 overrides the default)
-  bool fuse_fin = false;     // BN finalize by the last-arriving workgroup of the summing launch (MI355_BN_FIN=1; measured slower: off)
   bool stem_fused_bwd = true;  // stem BN backward gathers the pool gradient on the fly (MI355_STEM_FUSED=0: pool-backward kernel + plain BN backward)
-  unsigned* fin_counters = nullptr;   // 64 zero words per stream (main / side)
-  unsigned* fin_counters2 = nullptr;
   hipStream_t wstream = nullptr;
   std::vector<hipEvent_t> fork_ev;
   size_t fork_next = 0;
@@ -247,30 +242,6 @@ inline void* sk_ws_of(mi355_ctx* c, hipStream_t s) {
   return c->stream_k ? c->sk_ws[(c->wstream && s == c->wstream) ? 1 : 0] : nullptr;
 }
 inline float* bn_coef_of(mi355_ctx* c, hipStream_t s) { return (c->wstream && s == c->wstream) ? c->bn_coef2 : c->bn_coef; }
-inline unsigned* fin_counters_of(mi355_ctx* c, hipStream_t s) { return (c->wstream && s == c->wstream) ? c->fin_counters2 : c->fin_counters; }
-
-// finalize descriptors of a layer's BatchNorm for the launch that sums its statistics (forward) / its backward sums
-BnFinArgs fin_fwd(mi355_ctx* c, ConvBN& l, float momentum, hipStream_t s) {
-  BnFinArgs f;
-  if (!c->fuse_fin) return f;
-  const int C = l.Cout;
-  f.mode = 1; f.M = c->N * l.Hout * l.Wout; f.eps = BN_EPS; f.momentum = momentum;
-  f.gamma = c->params + l.gamma_off; f.beta = c->params + l.beta_off;
-  f.running_mean = c->buffers + l.rm_off; f.running_var = c->buffers + l.rv_off;
-  f.save_mean = l.stat; f.save_invstd = l.stat + C; f.scale = l.stat + 2 * C; f.shift = l.stat + 3 * C;
-  f.counters = fin_counters_of(c, s);
-  return f;
-}
-BnFinArgs fin_bwd(mi355_ctx* c, ConvBN& l, float beta_acc, hipStream_t s) {
-  BnFinArgs f;
-  if (!c->fuse_fin) return f;
-  f.mode = 2; f.M = c->N * l.Hout * l.Wout; f.beta_acc = beta_acc;
-  f.gamma = c->params + l.gamma_off; f.invstd = l.stat + l.Cout;
-  f.dgamma = c->grads + l.gamma_off; f.dbeta = c->grads + l.beta_off; f.coef = bn_coef_of(c, s);
-  f.counters = fin_counters_of(c, s);
-  return f;
-}
-
 double conv_flops(const mi355_ctx* c, const ConvBN& l) {
   return 2.0 * c->N * l.Hout * l.Wout * (double)l.Cout * l.Cin * l.K * l.K;
 }
@@ -283,8 +254,6 @@ int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, float mo
   a.in = in;
   a.stat_partial = training ? bn_partial_of(c, s) : nullptr;
   a.stat_rows_cap = (int)((size_t)bn_max_blocks() * c->max_c / l.Cout);  // the scratch holds bn_max_blocks() rows of the widest layer
-  if (training) a.fin = fin_fwd(c, l, momentum, s);
-  l.fin_done = false;
   a.sk_ws = sk_ws_of(c, s);
   a.wt = c->dtype == MI355_F32 ? (const void*)(c->params + l.w_off) : (const void*)l.w_cast;
   a.out = l.y;
@@ -299,7 +268,6 @@ int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, float mo
   } else {
     MI355_TRY(launch_igemm(c->dtype, a, 1, s, &l.stat_rows));
   }
-  l.fin_done = a.fin.mode != 0 && l.stat_rows > 0;
   return 0;
 }
 
@@ -313,18 +281,11 @@ int bn_prepare(mi355_ctx* c, ConvBN& l, int training, float momentum, hipStream_
   const float* gamma = c->params + l.gamma_off;
   const float* beta = c->params + l.beta_off;
   if (training) {
-    if (l.fin_done) {  // the conv launch finalized its own statistics
-      l.fin_done = false;
-      return 0;
-    }
     int nblk = l.stat_rows;
     const float* pivot = nullptr;  // conv-epilogue partials are plain sums
     if (nblk == 0) {
       Prof p(c, PC_BN_REDUCE, 0, (double)M * C * c->es, s);
-      BnFinArgs f = fin_fwd(c, l, momentum, s);
-      f.pivot = bn_coef_of(c, s);
-      MI355_TRY(launch_bn_stats(c->dtype, l.y, bn_partial_of(c, s), bn_coef_of(c, s), &nblk, M, C, s, &f));
-      if (f.mode != 0) return 0;
+      MI355_TRY(launch_bn_stats(c->dtype, l.y, bn_partial_of(c, s), bn_coef_of(c, s), &nblk, M, C, s));
       pivot = bn_coef_of(c, s);
     }
     return launch_bn_finalize(bn_partial_of(c, s), pivot, nblk, M, C, gamma, beta, c->buffers + l.rm_off, c->buffers + l.rv_off,
@@ -362,18 +323,13 @@ int bn_backward(mi355_ctx* c, ConvBN& l, const void* g, const uint8_t* bits, voi
   const int M = c->N * l.Hout * l.Wout, C = l.Cout;
   int nblk = l.bwd_rows;
   l.bwd_rows = 0;
-  bool fin_done = l.bwd_fin_done && nblk > 0 && !dz_out;  // the dgrad that summed also finalized (into this stream's coef block)
-  l.bwd_fin_done = false;
   const double mask_bytes = bits ? (double)M * C * c->es / 16 : 0.0;
   if (nblk == 0 || dz_out) {
     Prof p(c, PC_BN_REDUCE, 0, (double)M * C * c->es * (2 + (dz_out ? 1 : 0)) + mask_bytes, s);
-    BnFinArgs f = fin_bwd(c, l, beta_acc, s);
     MI355_TRY(launch_bn_bwd_reduce(c->dtype, g, nullptr, l.y, l.stat, l.stat + C, dz_out, bn_partial_of(c, s), &nblk, M, C, s,
-                                   bits, 0.f, &f));
-    fin_done = f.mode != 0;
+                                   bits, 0.f));
   }
-  if (!fin_done)
-    MI355_TRY(launch_bn_bwd_finalize(bn_partial_of(c, s), nblk, M, C, c->params + l.gamma_off, l.stat + C,
+  MI355_TRY(launch_bn_bwd_finalize(bn_partial_of(c, s), nblk, M, C, c->params + l.gamma_off, l.stat + C,
                                      c->grads + l.gamma_off, c->grads + l.beta_off, beta_acc, bn_coef_of(c, s), s));
   // after an in-place masked write-back the mask is already applied
   const uint8_t* bits2 = dz_out ? nullptr : bits;
@@ -424,8 +380,6 @@ int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* ad
     a.stat_partial = bn_partial_of(c, s);
     a.stat_rows_cap = (int)((size_t)bn_max_blocks() * c->max_c / bn->Cout);
     a.bn_y = bn->y; a.bn_bits = bn_bits; a.bn_mean = bn->stat; a.bn_invstd = bn->stat + bn->Cout;
-    a.fin = fin_bwd(c, *bn, beta_acc, s);
-    bn->bwd_fin_done = false;
   }
   const double dx_elems = (double)c->N * l.Hin * l.Win * l.Cin;
   void* dyq = c->fp8_bwd_on && l.fp8_dgrad ? grad_twin(c, dy) : nullptr;
@@ -441,7 +395,6 @@ int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* ad
   } else {
     MI355_TRY(launch_igemm(c->dtype, a, nclass, s, rows));
   }
-  if (rows && a.fin.mode != 0 && *rows > 0) bn->bwd_fin_done = true;
   return 0;
 }
 
@@ -508,8 +461,6 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
   ar.add((void**)&c->bn_partial, (size_t)bn_max_blocks() * 2 * max_c * 4);
   ar.add((void**)&c->bn_coef, (size_t)3 * max_c * 4);
   for (int i = 0; i < 2; ++i) ar.add(&c->sk_ws[i], igemm_sk_ws_bytes());
-  ar.add((void**)&c->fin_counters, 64 * 4);
-  ar.add((void**)&c->fin_counters2, 64 * 4);
   ar.add((void**)&c->bn_partial2, (size_t)bn_max_blocks() * 2 * max_c * 4);
   ar.add((void**)&c->bn_coef2, (size_t)3 * max_c * 4);
   ar.add((void**)&c->wg_partial, max_wg);
@@ -979,16 +930,6 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
   const char* fb = getenv("MI355_FUSE_BN_BWD");
   // measured same-box: -0.6 ms/step in bf16, +0.9 ms in fp32 (the fp32 epilogue is already register-heavy)
   c->fuse_bn_bwd = fb ? fb[0] != '0' : dtype == MI355_BF16;
-  // measured (profiles/README.md, round 3): 20.4 -> 33.3 ms/step with it on.  Two further variants were built on top of this one and
-  // measured before being dropped: (1) the last K arrivers finalize 16 channels each in parallel — still 32.9 ms, which showed that
-  // the cost is not the serial reduction but the TICKETS: agent-scope atomics on one address run at ~4 M/s across the 8 XCDs, 512
-  // of them are ~120 us per launch (every conv kernel took 2-3x its time); (2) no atomics at all — every workgroup publishes the
-  // launch's epoch in its own flag word, K designated workgroups poll the flags — 20.8-21.0 ms against 20.0, i.e. still slower than
-  // the 7 us finalize launches it replaces (the tail runs on K CUs while the rest of the chip has drained), and it needed
-  // agent-scope loads for the rows (this XCD's L2 can hold the previous launch's rows of the same scratch buffer) and still lost
-  // one channel at 8-pixel test shapes.  Kept behind MI355_BN_FIN=1 in its first, correct form as the record of the experiment.
-  const char* ff = getenv("MI355_BN_FIN");
-  c->fuse_fin = ff && ff[0] == '1';
   const char* sf = getenv("MI355_STEM_FUSED");
   c->stem_fused_bwd = !(sf && sf[0] == '0');
   const char* ov = getenv("MI355_WGRAD_STREAM");
@@ -1106,10 +1047,8 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
     build_stem_fwd_args(a, N, c->H, c->W);
     a.in = c->xpad; a.wt = c->stem_pack; a.out = c->stem.y;
     a.stat_partial = training ? c->bn_partial : nullptr;
-    if (training) a.fin = fin_fwd(c, c->stem, bn_momentum, s);
     Prof p(c, PC_IGEMM64, conv_flops(c, c->stem), 0, s);
     MI355_TRY(launch_igemm(c->dtype, a, 1, s, &c->stem.stat_rows));
-    c->stem.fin_done = a.fin.mode != 0 && c->stem.stat_rows > 0;
   }
   MI355_TRY(bn_prepare(c, c->stem, training, bn_momentum, s));
   {

@@ -355,7 +355,7 @@ unsigned magic32_3(unsigned d) { return (unsigned)((1ull << 32) / d + 1); }
 // NHWC4 rows, stride 2, 64 output channels), no addend, no BN-backward sums
 bool stem_direct_legal(const IgemmArgs& a, int nclass) {
   if (nclass != 1 || a.Ck != STEM_CK || a.Ncols != C3 || a.pix_stride != STEM_PS || a.IS != 2 || a.OS != 1 || a.wtaps != 4 || a.cls[0].ntaps != 4) return false;
-  if (a.pair_delta != a.Win * STEM_PS - 32 || a.addend || a.bn_y || a.fin.mode != 0) return false;
+  if (a.pair_delta != a.Win * STEM_PS - 32 || a.addend || a.bn_y) return false;
   if (a.Hsub != a.Hout || a.Wsub != a.Wout || a.Hin != 2 * a.Hout + 2 * STEM_PAD || a.Win < 2 * a.Wout + 6) return false;
   for (int t = 0; t < 4; ++t)
     if (a.cls[0].taps[t].dh != 2 * t || a.cls[0].taps[t].dw != 0 || a.cls[0].taps[t].wtap != t) return false;

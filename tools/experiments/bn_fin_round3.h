@@ -1,3 +1,8 @@
+// EXPERIMENT RECORD (round 3; removed from the product library in round 4) — BatchNorm finalize by the last-arriving workgroup of the
+// launch that sums the statistics.  Measured: 20.4 -> 33.3 ms per step with it on (agent-scope ticket atomics on one address run at
+// ~4 M/s across the 8 XCDs: ~120 us per launch); a K-arriver variant 32.9 ms; a flag-polling variant without atomics 20.8-21.0 ms
+// against 20.0 (profiles/README.md, round 3).  The call sites it had (bn.hip, conv_igemm.hip, conv_igemm8.hip, resnet_exec.cpp) are in
+// the history before the commit that moved this file here; it does not build on its own.
 // bn_fin.h — BatchNorm finalize carried out by the LAST-ARRIVING workgroup of the launch that produced the partial rows.
 //
 // The conv epilogues (conv_igemm.hip / conv_igemm8.hip, STATS 1 / 2) and the standalone reduce kernel (bn.hip) leave one row of
