@@ -46,7 +46,8 @@ struct ConvBN {
   void* w_cast = nullptr;                         // bf16 copy (bf16 ctx)
   void* w_tr = nullptr;                           // transposed copy for dgrad
   float* stat = nullptr;                          // [4][Cout]: save_mean, save_invstd, scale, shift
-  int splits = 1;
+  int splits = 1;   // split count of the weight-gradient launch (plan_wgrad)
+  int splits8 = 1;  // ... of its e4m3 form (fp8 step: the implicit-GEMM kernel with its own plan)
   int stat_rows = 0;  // partial rows the last forward conv left in bn_partial (0: none)
   int bwd_rows = 0;   // partial rows of THIS layer's BN-backward sums left in bn_partial by the dgrad that produced its
                       // activation gradient (0: none, bn_backward runs the standalone reduce kernel)
@@ -355,9 +356,9 @@ int conv_wgrad(mi355_ctx* c, ConvBN& l, const void* dy, const void* x, float bet
     a.dy = dyq; a.x = l.in_q;
     {
       Prof p(c, wgrad_class(l.Cout), conv_flops(c, l), by, s, 2);
-      MI355_TRY(launch_wgrad(MI355_FP8, a, l.splits, s));
+      MI355_TRY(launch_wgrad(MI355_FP8, a, l.splits8, s));
     }
-    return launch_splitk_reduce(c->wg_partial, l.splits, n, c->grads + l.w_off, n, beta_acc, s, c->q_scale + l.qid_dy, c->q_scale + l.qid_in);
+    return launch_splitk_reduce(c->wg_partial, l.splits8, n, c->grads + l.w_off, n, beta_acc, s, c->q_scale + l.qid_dy, c->q_scale + l.qid_in);
   }
   {
     Prof p(c, wgrad_class(l.Cout), conv_flops(c, l), by, s);
@@ -417,9 +418,11 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
       }
       WgradArgs wa;
       build_wgrad_args(wa, N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
-      // (the fp8 step launches e4m3 twins with the same split count: it keeps the implicit-GEMM plan)
-      l.splits = c->fp8 ? plan_wgrad_splits(c->dtype, N * l.Hout * l.Wout, l.Cout, l.K * l.K, l.Cin) : plan_wgrad(c->dtype, wa);
-      max_wg = std::max(max_wg, (size_t)l.splits * wn * 4);
+      // (the e4m3 twins of the fp8 step run on the implicit-GEMM kernel with its own plan; the bf16 launches of the same ctx —
+      // calibration step, layers kept in bf16 — take the plan, and so the kernels and the bits, of the bf16 step)
+      l.splits = plan_wgrad(c->dtype, wa);
+      l.splits8 = c->fp8 ? plan_wgrad_splits(c->dtype, N * l.Hout * l.Wout, l.Cout, l.K * l.K, l.Cin) : l.splits;
+      max_wg = std::max(max_wg, (size_t)std::max(l.splits, l.splits8) * wn * 4);
     } else {
       l.splits = plan_wgrad_splits(c->dtype, N * l.Hout * l.Wout, 64, 4, STEM_CK);
       max_wg = std::max(max_wg, (size_t)l.splits * 64 * 4 * 64 * 4);
