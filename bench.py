@@ -37,8 +37,8 @@ KERNEL_NAMES = {0: ["igemm_kernel<{T},128,128>", "igemm_kernel<{T},256,256>", "i
                 1: ["igemm_kernel<{T},128,64>"],
                 # (wg3_* / wg1_*: the generated kernels of asm/wg_gen.py / asm/wg1_gen.py, bf16 only; class by Cout % 128 as the executor files them)
                 2: ["wgrad_kernel<{T},128,128>", "wgrad_kernel<{T},128,64>", "wg3_l2", "wg3_l3", "wg3_l4", "wg1_c1024_o256", "wg1_c256_o1024", "wg1_c2048_o512",
-                    "wg1_c512_o2048", "wg1_c512_o256", "wg1_c1024_o512", "wg1_c128_o512", "wg1_c512_o128", "wg1_c256_o128", "wg1_c64_o256"],
-                3: ["wgrad_kernel<{T},64,128>", "wgrad_kernel<{T},64,64>", "wg3_l1", "wg1_c256_o64"]}
+                    "wg1_c512_o2048", "wg1_c512_o256", "wg1_c1024_o512", "wg1_c512_o128", "wg1_c64_o256"],
+                3: ["wgrad_kernel<{T},64,128>", "wgrad_kernel<{T},64,64>", "wg3_l1"]}
 
 
 def runner_rate(N, S, steps):

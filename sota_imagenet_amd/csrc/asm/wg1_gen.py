@@ -323,16 +323,19 @@ VARIANTS = {
     # first blocks of layers 3 and 4 (conv1 runs before the stride), layer 2 (512 <-> 128, 256 -> 128), layer 1 (256 <-> 64)
     "wg1_c512_o256": W1Cfg("wg1_c512_o256", C=512, CO=256),
     "wg1_c1024_o512": W1Cfg("wg1_c1024_o512", C=1024, CO=512),
-    "wg1_c128_o512": W1Cfg("wg1_c128_o512", C=128, CO=512),
     "wg1_c512_o128": W1Cfg("wg1_c512_o128", C=512, CO=128, XP=4, DP=2),
-    "wg1_c256_o128": W1Cfg("wg1_c256_o128", C=256, CO=128, XP=4, DP=2),
     "wg1_c64_o256": W1Cfg("wg1_c64_o256", C=64, CO=256, XP=1, DP=4),
-    "wg1_c256_o64": W1Cfg("wg1_c256_o64", C=256, CO=64, XP=4, DP=1),
+    # measured in the executor and NOT shipped (the implicit-GEMM kernel is as fast or faster there; all are HBM-bound at ~3.8 TB/s):
+    #   C=128 -> CO=512 (layer 2 conv3): 53.1 vs 51.5 us;  C=256 -> CO=128 (XP=4, DP=2; layer 2 block 0 conv1): 142 vs 136 us;
+    #   C=256 -> CO=64 (XP=4, DP=1; layer 1 conv1): 106.8 vs 95.8 us.  The generator still builds them (tests run the DP=1 form).
 }
 
 
+EXTRA = {"wg1_c256_o64": W1Cfg("wg1_c256_o64", C=256, CO=64, XP=4, DP=1)}  # test-only tile shape (see above)
+
+
 def generate(name, **over):
-    c = VARIANTS[name]
+    c = VARIANTS.get(name) or EXTRA[name]
     if over:
         c = W1Cfg(**{**c.__dict__, **over})
     g = Gen(c)
