@@ -413,16 +413,25 @@ class Gen(dconv_gen.Gen):
         return text
 
 
-VARIANTS = {
-    # layer 3 (14 x 14): conv1 forward 1024 -> 256 with BN statistics (and without), conv3 data gradient 1024 -> 256 with the BN-backward sums
-    "pk_k1024_w196_s1": mk("pk_k1024_w196_s1", 196, 1024, 256, 1),
-    "pk_k1024_w196_s0": mk("pk_k1024_w196_s0", 196, 1024, 256, 0),
-    "pk_k1024_w196_s2": mk("pk_k1024_w196_s2", 196, 1024, 256, 2),
-    # layer 4 (7 x 7, two images per tile): 2048 -> 512
-    "pk_k2048_w98_s1": mk("pk_k2048_w98_s1", 98, 2048, 512, 1, NB=3),
-    "pk_k2048_w98_s0": mk("pk_k2048_w98_s0", 98, 2048, 512, 0, NB=3),
-    "pk_k2048_w98_s2": mk("pk_k2048_w98_s2", 98, 2048, 512, 2, NB=3),
-}
+def _variants():
+    v = {}
+    for (K, N, W, NB, stats) in (
+            # layer 3 (14 x 14, tile = one image): conv1 forward 1024 -> 256 with BN statistics (and without), conv3 data gradient with the BN-backward sums
+            (1024, 256, 196, 2, (0, 1, 2)),
+            # layer 4 (7 x 7, tile = two images): 2048 -> 512
+            (2048, 512, 98, 3, (0, 1, 2)),
+            # conv1 of the first blocks (it runs before the stride): layer 3 512 -> 256 at 28 x 28, layer 4 1024 -> 512 at 14 x 14
+            (512, 256, 196, 2, (0, 1)),
+            (1024, 512, 196, 2, (0, 1)),
+            # layer 4 conv3 forward 512 -> 2048 (tile = four images)
+            (512, 2048, 196, 2, (0, 1))):
+        for st in stats:
+            name = "pk_k%d_n%d_w%d_s%d" % (K, N, W, st)
+            v[name] = mk(name, W, K, N, st, NB=NB)
+    return v
+
+
+VARIANTS = _variants()
 
 
 def generate(name, **over):

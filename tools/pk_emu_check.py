@@ -69,8 +69,8 @@ def run(name, tiles=(0,), ntile=0, ntiles=None, seed=0, check=True, **over):
 
 if __name__ == "__main__":
     import time
-    for name, kw in (("pk_k1024_w196_s1", dict(tiles=(1,), Cin=256)), ("pk_k1024_w196_s2", dict(tiles=(0, 2), Cin=448)), ("pk_k2048_w98_s1", dict(tiles=(1,), ntile=1, Cin=320)),
-                     ("pk_k2048_w98_s2", dict(tiles=(0,), ntile=1, Cin=192)), ("pk_k1024_w196_s0", dict(tiles=(0,), Cin=64))):
+    for name, kw in (("pk_k1024_n256_w196_s1", dict(tiles=(1,), Cin=256)), ("pk_k1024_n256_w196_s2", dict(tiles=(0, 2), Cin=448)), ("pk_k2048_n512_w98_s1", dict(tiles=(1,), ntile=1, Cin=320)),
+                     ("pk_k2048_n512_w98_s2", dict(tiles=(0,), ntile=1, Cin=192)), ("pk_k1024_n256_w196_s0", dict(tiles=(0,), Cin=64))):
         t0 = time.time()
         r = run(name, **kw)
         print(name, kw, {k: v for k, v in r.items() if k != "cfg"}, "%.1f s" % (time.time() - t0))
