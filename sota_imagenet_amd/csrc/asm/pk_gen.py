@@ -424,6 +424,7 @@ def _variants():
             (512, 256, 196, 2, (0, 1)),
             (1024, 512, 196, 2, (0, 1)),
             # layer 4 conv3 forward 512 -> 2048 (tile = four images)
+            # (not shipped: 256 -> 1024, layer 3 conv3 forward — 4 chunks per workgroup; 57-61 us against 47.7 us of pw_gen.py's resident-K kernel)
             (512, 2048, 196, 2, (0, 1))):
         for st in stats:
             name = "pk_k%d_n%d_w%d_s%d" % (K, N, W, st)

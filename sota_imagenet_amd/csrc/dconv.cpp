@@ -309,7 +309,8 @@ int launch_wg3(const WgradArgs& a, int splits, hipStream_t stream) {
 }
 
 bool pw_legal(const IgemmArgs& a, int nclass) {
-  if (!dconv_enabled()) return false;
+  static const bool on = !(getenv("MI355_PW") && getenv("MI355_PW")[0] == '0');
+  if (!on || !dconv_enabled()) return false;
   return find_pw(a, nclass, wanted_stats(a)) >= 0;
 }
 
