@@ -339,6 +339,18 @@ int mi355_bresnet50_forward(mi355_bctx* ctx, const float* x_nchw, float* logits,
                             void* stream);
 int mi355_bresnet50_backward(mi355_bctx* ctx, const float* dlogits, int accumulate, void* stream);
 int mi355_bresnet50_flops(const mi355_bctx* ctx, double* fwd_flops, double* train_flops);
+/* Data parallelism of this executor (reference: DistributedDataParallel at /root/reference/train.py:113-114 around the configs[3] model):
+ * the backward call runs mi355_bresnet50_num_segments() segments — 0 = the head, then the bottlenecks last to first, then the stem;
+ * the flat gradient array is laid out in FORWARD (pytorch_tools registration) order, so the segments descend through it — and, with a
+ * communicator attached, issues ONE mean all-reduce per bucket of consecutive segments (>= bucket_cap_mb MiB, the last bucket cut once
+ * more: the rule of mi355_resnet50_set_comm) on the communicator's stream as soon as the bucket's last segment has been enqueued on
+ * both streams; the caller's stream waits for the last one before the call returns.  set_grad_sync(0): no collective (DDP.no_sync()). */
+typedef struct mi355_comm mi355_comm;
+int mi355_bresnet50_num_segments(const mi355_bctx* ctx);
+int mi355_bresnet50_segment_range(const mi355_bctx* ctx, int seg, size_t* grad_begin, size_t* grad_end);
+int mi355_bresnet50_bucket_plan(const mi355_bctx* ctx, double bucket_cap_mb, int cap, int* n_out, size_t* begins, size_t* ends, int* last_segs);
+int mi355_bresnet50_set_comm(mi355_bctx* ctx, mi355_comm* comm, double bucket_cap_mb);
+int mi355_bresnet50_set_grad_sync(mi355_bctx* ctx, int on);
 
 /* ---- gradient collective inside the boundary: RCCL over xGMI, one process per GPU ---------------------------------
  * replaces torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) — train.py:113-114, process group
@@ -359,7 +371,7 @@ int mi355_bresnet50_flops(const mi355_bctx* ctx, double* fwd_flops, double* trai
  *              cap would produce (works on a layout-only ctx; n_out = number of buckets, arrays filled up to `cap`).
  *   xGMI is point-to-point (7 links per GPU, ring collectives are per-link bound): keep buckets few and large.      */
 #define MI355_COMM_ID_BYTES 128
-typedef struct mi355_comm mi355_comm;
+/* (mi355_comm: declared above, with the BResNet-50 executor's data-parallel entry points) */
 int mi355_comm_available(void);
 int mi355_comm_unique_id(void* id_out);
 int mi355_comm_create(mi355_comm** out, const void* id, int nranks, int rank, int device);

@@ -371,7 +371,12 @@ def _layout(dtype_code, num_classes, wstd):
             kind, off, nd, sh = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_int(), (ctypes.c_int * 4)()
             native.check(L.mi355_bresnet50_tensor_info(ctx, i, name, 128, ctypes.byref(kind), ctypes.byref(off), ctypes.byref(nd), sh))
             table.append((name.value.decode(), kind.value, off.value, tuple(sh[j] for j in range(nd.value))))
-        return table, L.mi355_bresnet50_flat_param_elems(ctx), L.mi355_bresnet50_flat_buffer_elems(ctx)
+        segs = []
+        for i in range(L.mi355_bresnet50_num_segments(ctx)):
+            b, e = ctypes.c_size_t(), ctypes.c_size_t()
+            native.check(L.mi355_bresnet50_segment_range(ctx, i, ctypes.byref(b), ctypes.byref(e)))
+            segs.append((b.value, e.value))
+        return table, L.mi355_bresnet50_flat_param_elems(ctx), L.mi355_bresnet50_flat_buffer_elems(ctx), segs
     finally:
         L.mi355_bresnet50_destroy(ctx)
 
@@ -395,8 +400,9 @@ class BResNet50(_DropStream, _FlatModel):
         self.num_classes, self.drop_rate, self.drop_connect_rate, self.seed = int(num_classes), float(drop_rate), float(drop_connect_rate), int(seed or 0)
         self._seed_given = seed is not None
         self.weight_standardization = bool(weight_standardization)
-        self._table, self._nparam, self._nbuf = _layout(self._dt, self.num_classes, self.weight_standardization)
-        self._segments = [(0, self._nparam)]  # one backward call completes every gradient
+        self._table, self._nparam, self._nbuf, self._segments = _layout(self._dt, self.num_classes, self.weight_standardization)
+        # (backward segments of the ONE native backward call: head, bottlenecks last to first, stem — descending through the flat array)
+        self._comm = None  # (mi355_comm*, bucket cap in MiB) once a native communicator is attached: the all-reduces run inside the call
         self._flat_params = torch.zeros(self._nparam, dtype=torch.float32)
         self._flat_grads = torch.zeros(self._nparam, dtype=torch.float32)
         self._flat_buffers = torch.zeros(self._nbuf, dtype=torch.float32)
@@ -467,6 +473,10 @@ class BResNet50(_DropStream, _FlatModel):
             dev = self._flat_params.device.index or 0
             native.check(L.mi355_bresnet50_create(ctypes.byref(c), dev, self._dt, N, H, W, self.num_classes, int(self.weight_standardization)))
             native.check(L.mi355_bresnet50_bind(c, native.ptr(self._flat_params), native.ptr(self._flat_grads), native.ptr(self._flat_buffers)))
+            if self._comm is not None:
+                native.check(L.mi355_bresnet50_set_comm(c, self._comm[0], float(self._comm[1])))
+            if not self._sync_grads:
+                native.check(L.mi355_bresnet50_set_grad_sync(c, 0))
             self._ctxs[key] = c
         else:
             self._ctxs.move_to_end(key)
@@ -523,13 +533,43 @@ class BResNet50(_DropStream, _FlatModel):
         self._attach_grads()
         native.check(native.lib().mi355_bresnet50_backward(c, native.ptr(dlogits.contiguous()), int(self._grads_dirty), native.cur_stream()))
         self._last = None  # the context may be evicted again
-        if self._grad_sync is not None and self._sync_grads:
-            self._grad_sync(0, 0, self._nparam)
+        if self._grad_sync is not None and self._sync_grads and self._comm is None:  # (torch.distributed stand-in: after the one call)
+            for k, (b, e) in enumerate(self._segments):
+                if self._grad_sync_points is None or k in self._grad_sync_points:
+                    self._grad_sync(k, b, e)
         self._grads_dirty = True
 
+    def set_comm(self, comm, bucket_cap_mb=32.0):
+        """attaches a native RCCL communicator (parallel.FlatBucketDDP owns it): the backward call then reduces the flat gradient array
+        bucket by bucket behind the segments that complete it (mi355_bresnet50_set_comm)"""
+        from . import native
+
+        self._comm = None if comm is None else (comm, float(bucket_cap_mb))
+        for c in self._ctxs.values():
+            native.check(native.lib().mi355_bresnet50_set_comm(c, comm, float(bucket_cap_mb)))
+
     def set_grad_sync(self, on):
-        """DDP.no_sync(): off -> backward leaves the gradients rank-local"""
+        """DDP.no_sync(): off -> backward leaves the gradients rank-local (mi355_bresnet50_set_grad_sync)"""
+        from . import native
+
         self._sync_grads = bool(on)
+        for c in self._ctxs.values():
+            native.check(native.lib().mi355_bresnet50_set_grad_sync(c, int(self._sync_grads)))
+
+    def bucket_plan(self, bucket_cap_mb):
+        """[(begin, end, last_segment)] the native executor would reduce at this cap (layout-only: works on the CPU)"""
+        from . import native
+
+        L = native.lib()
+        ctx = ctypes.c_void_p()
+        native.check(L.mi355_bresnet50_create(ctypes.byref(ctx), -1, self._dt, 1, 32, 32, self.num_classes, int(self.weight_standardization)))
+        try:
+            n = ctypes.c_int()
+            B, E, S = (ctypes.c_size_t * 32)(), (ctypes.c_size_t * 32)(), (ctypes.c_int * 32)()
+            native.check(L.mi355_bresnet50_bucket_plan(ctx, float(bucket_cap_mb), 32, ctypes.byref(n), B, E, S))
+            return [(B[i], E[i], S[i]) for i in range(n.value)]
+        finally:
+            L.mi355_bresnet50_destroy(ctx)
 
     def forward(self, x):
         if self.training and torch.is_grad_enabled():

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/mi355rn.h"
+#include "comm.h"
 #include "common.h"
 
 namespace mi355 {
@@ -140,6 +141,14 @@ struct mi355_bctx {
   std::vector<hipEvent_t> ev;
   size_t ev_next = 0;
   bool overlap = true, w_dirty = false;
+  // gradient collective inside the boundary (comm.cpp), as in resnet_exec.cpp: backward segments (0 = head, then the bottlenecks last
+  // to first, then the stem; the flat array is laid out in FORWARD order, so segments descend through it) form buckets, each reduced by
+  // one mean all-reduce on the communicator's stream as soon as its last segment has been enqueued on both streams
+  struct Bucket { size_t begin, end; int last_seg; };
+  std::vector<std::pair<size_t, size_t>> segs;
+  std::vector<Bucket> buckets;
+  mi355_comm* comm = nullptr;
+  bool grad_sync = true, comm_dirty = false;
   bool fused_add = true;   // shortcut gradient added in conv1's dgrad epilogue (MI355_BRESNET_FUSED_ADD=0: its own launch, as the per-op graph)
   bool use_bits = true;    // leaky-ReLU masks travel as one bit per element (MI355_BRESNET_BITS=0: backward reads the activation itself)
   bool lazy_dz3 = true;    // bn3's backward forms its input gradient from the ECA backward on the fly (MI355_BRESNET_LAZY_DZ3=0: stored)
@@ -378,6 +387,59 @@ void for_each_conv(mi355_bctx* c, F f) {
 
 }  // namespace
 
+// consecutive backward segments form buckets of >= cap_elems gradient elements; a bucket is the contiguous span of its segments.  The
+// LAST bucket (nothing left to overlap its all-reduce with) is cut once more: its trailing segments up to cap_elems / 8 form a bucket
+// of their own (the rule of resnet_exec.cpp plan_buckets and parallel.plan_buckets, stated for any segment order).
+static std::vector<mi355_bctx::Bucket> plan_bbuckets(const mi355_bctx* c, size_t cap_elems) {
+  std::vector<mi355_bctx::Bucket> out;
+  std::vector<int> firsts;
+  const int nseg = (int)c->segs.size();
+  auto span = [&](int f, int l) {
+    size_t lo = c->segs[f].first, hi = c->segs[f].second;
+    for (int i = f; i <= l; ++i) { lo = std::min(lo, c->segs[i].first); hi = std::max(hi, c->segs[i].second); }
+    return mi355_bctx::Bucket{lo, hi, l};
+  };
+  int first = -1;
+  size_t size = 0;
+  for (int i = 0; i < nseg; ++i) {
+    if (first < 0) { first = i; size = 0; }
+    size += c->segs[i].second - c->segs[i].first;
+    if (size >= cap_elems || i == nseg - 1) {
+      out.push_back(span(first, i));
+      firsts.push_back(first);
+      first = -1;
+    }
+  }
+  const size_t tail_cap = cap_elems / 8;
+  if (!out.empty() && out.back().end - out.back().begin > tail_cap) {
+    const int f = firsts.back(), l = out.back().last_seg;
+    int cut = l + 1;
+    size_t tail = 0;
+    for (int i = l; i > f; --i) {
+      const size_t n = c->segs[i].second - c->segs[i].first;
+      if (tail + n > tail_cap) break;
+      tail += n;
+      cut = i;
+    }
+    if (cut > f && cut <= l) {
+      out.back() = span(f, cut - 1);
+      out.push_back(span(cut, l));
+    }
+  }
+  return out;
+}
+
+// segment `seg` of this backward call is enqueued on both streams: reduce the buckets it completes
+static int after_segment(mi355_bctx* c, int seg, hipStream_t s) {
+  if (!c->comm || !c->grad_sync) return 0;
+  for (const auto& bk : c->buckets)
+    if (bk.last_seg == seg) {
+      MI355_TRY(comm_allreduce_bucket(c->comm, c->grads, bk.begin, bk.end, s, c->overlap && c->w_dirty ? c->wstream : nullptr));
+      c->comm_dirty = true;
+    }
+  return 0;
+}
+
 extern "C" {
 
 int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H, int W, int num_classes, int weight_std) {
@@ -429,6 +491,13 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
   c->param_elems = align_up(c->param_elems, 64);
   c->buffer_elems = align_up(c->buffer_elems, 64);
   c->fwd_flops += 2.0 * N * 2048.0 * num_classes;
+  // backward segments over the flat gradient array
+  {
+    const int nb = (int)c->blocks.size();
+    c->segs.push_back({c->fc_w_off, c->param_elems});
+    for (int i = nb - 1; i >= 0; --i) c->segs.push_back({c->blocks[i].c1.w_off, i + 1 < nb ? c->blocks[i + 1].c1.w_off : c->fc_w_off});
+    c->segs.push_back({0, c->blocks[0].c1.w_off});
+  }
   *out = c;
   if (device < 0) return 0;  // layout-only context (no GPU): tensor table and sizes
 
@@ -713,6 +782,7 @@ int mi355_bresnet50_backward(mi355_bctx* c, const float* dlogits, int accumulate
   if (c->dropped) MI355_TRY(mi355_mul_f32(c->dpooled, c->do_mask, c->dpooled, (size_t)N * 2048, s));
   const VBlock& last = c->blocks.back();
   MI355_TRY(mi355_gap_bwd(dt, c->dpooled, c->dlast, N, last.Ho * last.Wo, 2048, s));
+  MI355_TRY(after_segment(c, 0, s));
   // ---- bottlenecks, last to first ------------------------------------------------------------------------------------------------
   const void* g = c->dlast;  // gradient wrt the block output
   for (int i = (int)c->blocks.size() - 1; i >= 0; --i) {
@@ -772,6 +842,7 @@ int mi355_bresnet50_backward(mi355_bctx* c, const float* dlogits, int accumulate
       MI355_TRY(mi355_residual_act_fwd(dt, b.dxb, nullptr, gs, b.dx, N, (size_t)b.H * b.W * b.cin, ACT_NONE, s));  // (the autograd sum of the per-op graph)
     }
     g = b.dx;
+    MI355_TRY(after_segment(c, (int)c->blocks.size() - i, s));
   }
   // ---- stem ------------------------------------------------------------------------------------------------------------------------
   MI355_TRY(mi355_blurpool_bwd(dt, g, c->dm, N, c->H / 2, c->W / 2, 64, s));
@@ -784,7 +855,51 @@ int mi355_bresnet50_backward(mi355_bctx* c, const float* dlogits, int accumulate
   MI355_TRY(conv_dgrad(c, c->s1, c->sb0.dout, nullptr, s));
   MI355_TRY(bn_back(c, c->s0, c->sb0, c->sb0.dout, beta, s));
   MI355_TRY(conv_wgrad(c, c->s0, c->h0, beta, s));
-  return join(c, s);
+  MI355_TRY(after_segment(c, (int)c->blocks.size() + 1, s));
+  MI355_TRY(join(c, s));
+  if (c->comm && c->comm_dirty) {
+    MI355_TRY(comm_join(c->comm, s));
+    c->comm_dirty = false;
+  }
+  return 0;
+}
+
+int mi355_bresnet50_num_segments(const mi355_bctx* c) { return c ? (int)c->segs.size() : 0; }
+
+int mi355_bresnet50_segment_range(const mi355_bctx* c, int seg, size_t* grad_begin, size_t* grad_end) {
+  MI355_ARG(c && grad_begin && grad_end && seg >= 0 && seg < (int)c->segs.size(), "bresnet50_segment_range: bad arguments");
+  *grad_begin = c->segs[seg].first;
+  *grad_end = c->segs[seg].second;
+  return 0;
+}
+
+int mi355_bresnet50_bucket_plan(const mi355_bctx* c, double bucket_cap_mb, int cap, int* n_out, size_t* begins, size_t* ends, int* last_segs) {
+  MI355_ARG(c && n_out && bucket_cap_mb > 0, "bresnet50_bucket_plan: bad arguments");
+  const auto bk = plan_bbuckets(c, (size_t)(bucket_cap_mb * (1 << 20) / 4));
+  *n_out = (int)bk.size();
+  for (int i = 0; i < (int)bk.size() && i < cap; ++i) {
+    if (begins) begins[i] = bk[i].begin;
+    if (ends) ends[i] = bk[i].end;
+    if (last_segs) last_segs[i] = bk[i].last_seg;
+  }
+  return 0;
+}
+
+int mi355_bresnet50_set_comm(mi355_bctx* c, mi355_comm* comm, double bucket_cap_mb) {
+  MI355_ARG(c && (comm == nullptr || bucket_cap_mb > 0), "bresnet50_set_comm: bad arguments");
+  if (c->device < 0) {
+    set_error("bresnet50_set_comm: layout-only ctx (created with device < 0)");
+    return MI355_E_STATE;
+  }
+  c->comm = comm;
+  c->buckets = comm ? plan_bbuckets(c, (size_t)(bucket_cap_mb * (1 << 20) / 4)) : std::vector<mi355_bctx::Bucket>();
+  return 0;
+}
+
+int mi355_bresnet50_set_grad_sync(mi355_bctx* c, int on) {
+  MI355_ARG(c, "bresnet50_set_grad_sync: null ctx");
+  c->grad_sync = on != 0;
+  return 0;
 }
 
 }  // extern "C"

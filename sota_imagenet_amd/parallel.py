@@ -28,18 +28,24 @@ import torch.nn as nn
 
 
 def plan_buckets(segments, cap_elems):
-    """[(begin, end)] per backward segment -> [(begin, end, last_segment_index)] buckets of >= cap_elems elements.  The last bucket
-    (nothing left to overlap its all-reduce with) is cut once more: its trailing segments up to cap_elems // 8 form a bucket of their
-    own, the part before them is reduced while those last blocks still compute (same rule as csrc/resnet_exec.cpp plan_buckets)."""
+    """[(begin, end)] per backward segment -> [(begin, end, last_segment_index)] buckets of >= cap_elems elements; a bucket is the
+    contiguous span of its segments (ascending for the ResNet-50 executor, whose flat array is laid out in backward order; descending for
+    the BResNet-50 executor, laid out in forward order).  The last bucket (nothing left to overlap its all-reduce with) is cut once more:
+    its trailing segments up to cap_elems // 8 form a bucket of their own, the part before them is reduced while those last blocks still
+    compute (same rule as csrc/resnet_exec.cpp plan_buckets and csrc/bresnet_exec.cpp plan_bbuckets)."""
+    def span(f, l):
+        return (min(b for b, _ in segments[f:l + 1]), max(e for _, e in segments[f:l + 1]), l)
+
     buckets, firsts = [], []
-    start = None
+    first, size = None, 0
     for i, (b, e) in enumerate(segments):
-        if start is None:
-            start, first = b, i
-        if e - start >= cap_elems or i == len(segments) - 1:
-            buckets.append((start, e, i))
+        if first is None:
+            first, size = i, 0
+        size += e - b
+        if size >= cap_elems or i == len(segments) - 1:
+            buckets.append(span(first, i))
             firsts.append(first)
-            start = None
+            first = None
     tail_cap = cap_elems // 8
     if buckets and buckets[-1][1] - buckets[-1][0] > tail_cap:
         f, l = firsts[-1], buckets[-1][2]
@@ -51,9 +57,8 @@ def plan_buckets(segments, cap_elems):
             tail += e - b
             cut = i
         if f < cut <= l:
-            b0, e0, _ = buckets[-1]
-            buckets[-1] = (b0, segments[cut][0], cut - 1)
-            buckets.append((segments[cut][0], e0, l))
+            buckets[-1] = span(f, cut - 1)
+            buckets.append(span(cut, l))
     return buckets
 
 

@@ -13,19 +13,24 @@ from sota_imagenet_amd.parallel import FlatBucketDDP, plan_buckets
 class FakeFlatModel(torch.nn.Module):
     """18 segments like the real executor; backward fills each segment with rank-dependent values and reports it."""
 
-    def __init__(self, rank):
+    def __init__(self, rank, kind="resnet50"):
         super().__init__()
         # the REAL executor's segment table (fc, 16 blocks, stem — a layout-only native context, no GPU), scaled down
-        # 1:64 so the stand-in's flat arrays stay small; boundaries keep their order and relative sizes
+        # 1:64 so the stand-in's flat arrays stay small; boundaries keep their order and relative sizes.  resnet50: the flat array is
+        # laid out in backward order (segments ascend); bresnet50: in forward order (segments DESCEND through it)
         from sota_imagenet_amd.models import resnet50
 
-        real = resnet50().grad_segments
+        real = resnet50().grad_segments if kind == "resnet50" else resnet50(stem_type="deep", antialias=True, attn_type="eca", norm_layer="inplaceabn",
+                                                                              norm_act="leaky_relu", weight_standardization=True).grad_segments
         assert len(real) == 18
         sizes = [max(16, (e - b) // 64) for b, e in real]
+        descending = real[0][0] > real[-1][0]
         self._segments, off = [], 0
-        for s in sizes:
+        for s in (reversed(sizes) if descending else sizes):
             self._segments.append((off, off + s))
             off += s
+        if descending:
+            self._segments.reverse()
         self.flat_params = torch.full((off,), float(rank + 1))
         self.flat_grads = torch.zeros(off)
         self._flat_buffers = torch.full((128,), float(10 * (rank + 1)))
@@ -49,11 +54,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, kind="resnet50"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        m = FakeFlatModel(rank)
+        m = FakeFlatModel(rank, kind)
         ddp = FlatBucketDDP(m, bucket_cap_mb=32.0 / 64)  # the default 32 MiB cap at the same 1:64 scale
         # C2: everyone holds rank 0's parameters and buffers after construction
         ok = bool((m.flat_params == 1.0).all()) and bool((m._flat_buffers == 10.0).all())
@@ -101,6 +106,31 @@ def test_flat_bucket_ddp_world2_gloo():
     from sota_imagenet_amd.models import resnet50
 
     assert all(nb == len(resnet50().bucket_plan(32.0)) for _, _, nb in res), res
+
+
+def test_flat_bucket_ddp_world2_gloo_descending_segments():
+    """the BResNet-50 executor's layout: forward-ordered flat array, backward segments descend through it"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "bresnet50")) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    from sota_imagenet_amd.bresnet import BResNet50
+
+    m = BResNet50()
+    assert all(nb == len(m.bucket_plan(32.0)) for _, _, nb in res), res
+    segs = m.grad_segments
+    assert segs[0][1] == m._nparam and segs[-1][0] == 0 and all(a[0] == b[1] for a, b in zip(segs, segs[1:]))
+    for cap in (0.5, 2.0, 8.0, 32.0, 500.0):
+        bk = m.bucket_plan(cap)
+        assert bk == plan_buckets(segs, int(cap * (1 << 20) / 4)), cap
+        assert bk[0][1] == m._nparam and bk[-1][0] == 0 and all(a[0] == b[1] for a, b in zip(bk, bk[1:]))
 
 
 def test_bucket_plan_covers_every_segment_once():

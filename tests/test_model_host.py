@@ -95,7 +95,8 @@ def test_bresnet50_executor_facade_layout_matches_the_per_op_graph():
     w = dict(m.named_parameters())["layer3.0.conv2.weight"]
     assert w.shape == (256, 256, 3, 3) and w.stride() == (2304, 1, 768, 256)  # OIHW logical over [Cout][KH][KW][Cin] memory
     assert w.untyped_storage().data_ptr() == m.flat_params.untyped_storage().data_ptr() and w.grad.shape == w.shape
-    assert m.grad_segments == [(0, m.flat_params.numel())]
+    segs = m.grad_segments  # head, 16 bottlenecks last to first, stem: descending through the forward-ordered flat array, tiling it
+    assert len(segs) == 18 and segs[0][1] == m.flat_params.numel() and segs[-1][0] == 0 and all(a[0] == b[1] for a, b in zip(segs, segs[1:]))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(2, 3, 64, 64))
     with pytest.raises(ValueError):

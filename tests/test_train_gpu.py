@@ -264,22 +264,38 @@ m = resnet50(**kw).cuda(); m.train()
 with torch.no_grad():
     for p in m.parameters():
         p.mul_(1.0 + 0.1 * rank)
-ddp = FlatBucketDDP(m, device_ids=[torch.cuda.current_device()])
+ddp = FlatBucketDDP(m, device_ids=[torch.cuda.current_device()], bucket_cap_mb=8.0)
 assert all(torch.equal(a, b) for a, b in zip(m.parameters(), ref.parameters())), "rank-0 broadcast"
+ddp.comm_stats()
 data, target = batches[rank]
 crit(ddp(data), target).backward()
 torch.cuda.synchronize()
 g = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
 err = ((g - gmean).abs().max() / gmean.abs().max()).item()
 assert err < 1e-6, err
+# the static executor reduces INSIDE its one backward call, bucket after bucket behind the segments that complete them: the
+# communicator's own record is the plan, the buckets descend through the forward-ordered flat array and tile it exactly once
+log = ddp.comm_stats()
+plan = [(0, b, e) for b, e, _ in ddp.buckets]
+assert len(plan) >= 3 and log == plan, (log, plan)
+assert log[0][2] == m.flat_grads.numel() and log[-1][1] == 0 and all(a[1] == b[2] for a, b in zip(log, log[1:])), log
+assert ddp.buckets == m.bucket_plan(8.0)
+m.mark_grads_clean()
+with ddp.no_sync():
+    crit(ddp(data), target).backward()
+assert ddp.comm_stats() == []
+crit(ddp(data), target).backward()
+assert ddp.comm_stats() == plan
+torch.cuda.synchronize()
 print(f"DDPV-OK rank {rank} err {err:.2e}")
 dist.barrier(); dist.destroy_process_group()
 """
 
 
 def test_native_rccl_allreduce_variant_model_single_rank(dev):
-    """the BResNet-50 graph has no flat gradient array: FlatBucketDDP coalesces, reduces through the native communicator and
-    scatters back after backward (1-rank RCCL rehearsal with numbers; 2 ranks where available)"""
+    """BResNet-50 on its static executor under FlatBucketDDP: bucketed mean all-reduces inside the ONE backward call
+    (mi355_bresnet50_set_comm), checked against the mean of the per-rank gradients and against the communicator's own record
+    (1-rank RCCL rehearsal with numbers; 2 ranks where available)"""
     path = os.path.join(ROOT, "tests", "_ddpv_check.py")
     with open(path, "w") as f:
         f.write(_DDP_VARIANT_CHECK)
