@@ -382,6 +382,13 @@ int mi355_comm_nranks(const mi355_comm* comm);
 int mi355_comm_broadcast(mi355_comm* comm, float* buf, size_t n, int root, void* stream);
 int mi355_comm_allreduce_mean(mi355_comm* comm, float* buf, size_t n, void* stream);
 int mi355_resnet50_set_comm(mi355_ctx* ctx, mi355_comm* comm, double bucket_cap_mb);
+/* CUs this library leaves to the communication library's kernels while a step runs (RCCL's all-reduce kernels need CUs of their own;
+ * the reference leaves that to NCCL and the CUDA scheduler, /root/reference/train.py:113-114): every grid sized from the CU count plans
+ * for CUs - n.  n: a non-negative multiple of 8 (the same number per XCD).  Process-global; call before creating contexts.        */
+int mi355_set_reserved_cus(int n);
+/* measurement stand-in for a collective's CU footprint on one GPU: `workgroups` 256-thread workgroups (16 KiB of LDS each) that hold
+ * their CU slots for `usec` microseconds without memory traffic (tools/reserve_cus_ab.py; not part of the training path)           */
+int mi355_comm_standin(int workgroups, int usec, void* stream);
 /* DistributedDataParallel.no_sync() (gradient accumulation, accumulate_steps > 1 — arg_parser.py:85-86, the Runner's inner step):
  * on == 0 makes the following backward calls of this ctx skip the bucket all-reduces (gradients stay rank-local and keep
  * accumulating); the last micro-step runs with on != 0 (the default) and reduces the accumulated sums once.        */

@@ -121,6 +121,14 @@ int comm_join(mi355_comm* cm, hipStream_t s) {
 
 }  // namespace mi355
 
+// (see mi355_comm_standin) every wave polls the 100 MHz wall clock with s_sleep between reads: a CU slot held, no memory traffic
+__global__ void standin_kernel(long long ticks) {
+  extern __shared__ char standin_lds[];
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+  if (ticks < 0) standin_lds[threadIdx.x] = 0;  // (keeps the LDS allocation)
+}
+
 extern "C" {
 
 int mi355_comm_available(void) { return rccl() ? 1 : 0; }
@@ -208,6 +216,16 @@ int mi355_comm_stats(mi355_comm* c, int reset, int cap, int* n_out, int* kinds, 
     if (ends) ends[i] = c->log[i].end;
   }
   if (reset) c->log.clear();
+  return 0;
+}
+
+// Measurement stand-in for a collective's CU footprint on ONE GPU (no curve can be measured without a node: this only shows what the
+// executor's grids pay when `workgroups` CUs' worth of another library's persistent kernels sit beside them for `usec` microseconds —
+// RCCL's ring kernels are one 256-thread workgroup per channel that spins on flags).  tools/reserve_cus_ab.py uses it.
+int mi355_comm_standin(int workgroups, int usec, void* stream) {
+  MI355_ARG(workgroups >= 1 && workgroups <= 256 && usec >= 1 && usec <= 100000, "comm_standin: workgroups=%d usec=%d", workgroups, usec);
+  hipLaunchKernelGGL(standin_kernel, dim3(workgroups), dim3(256), 16 * 1024, (hipStream_t)stream, (long long)usec * 100);  // s_memrealtime: 100 MHz
+  MI355_LAUNCH_CHECK();
   return 0;
 }
 

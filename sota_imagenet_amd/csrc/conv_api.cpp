@@ -1,5 +1,6 @@
 // conv_api.cpp — geometry builders and the per-op C-ABI entry points declared in include/mi355rn.h.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -37,6 +38,12 @@ int probe_env(const char* name) {
 
 // compute units of the current device (hipDeviceProp), the unit every persistent-grid size in this library is a multiple of;
 // 256 (MI355X) while no device is visible — layout-only contexts plan on a GPU-less host
+// CUs left to a communication library's kernels (mi355_set_reserved_cus / MI355_RESERVE_CUS, a multiple of 8 = the same number per XCD):
+// every grid in this library that is sized from the CU count (persistent implicit-GEMM grids, the split plans of the weight-gradient
+// kernels, the pointwise kernels' units per workgroup) then plans for CUs - reserved.  Grids that are tile counts (one image per
+// workgroup) do not change.  Process-global; set before contexts are created (split plans are made at context creation).
+static std::atomic<int> g_reserved_cus{-1};
+
 int device_cus() {
   static int cached[64] = {0};
   int n = 0, dev = 0;
@@ -46,7 +53,21 @@ int device_cus() {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cached[dev] = v;
   }
-  return cached[dev] ? cached[dev] : 256;
+  int r = g_reserved_cus.load();
+  if (r < 0) {  // first use: the environment's value (A/B runs), else none
+    const char* e = getenv("MI355_RESERVE_CUS");
+    r = e ? atoi(e) / 8 * 8 : 0;
+    if (r < 0) r = 0;
+    g_reserved_cus.store(r);
+  }
+  const int cus = cached[dev] ? cached[dev] : 256;
+  return cus - r >= 64 ? cus - r : (cus >= 64 ? 64 : cus);
+}
+
+extern "C" int mi355_set_reserved_cus(int n) {
+  MI355_ARG(n >= 0 && n % 8 == 0, "set_reserved_cus: %d (a non-negative multiple of 8: the same number per XCD)", n);
+  g_reserved_cus.store(n);
+  return 0;
 }
 
 static int out_dim(int H, int K, int s, int p) { return (H + 2 * p - K) / s + 1; }
