@@ -124,3 +124,28 @@ def test_pointwise_weight_gradient_is_exact_on_integer_data(dev, N, H, Cin, Cout
     dw = ops.conv2d_wgrad(dy, x, 1, 1, 1, 0)
     assert torch.equal(dw, ref)
     assert torch.equal(ops.conv2d_wgrad(dy, x, 1, 1, 1, 0, dw=dw.clone(), beta=1.0), 2 * ref)
+
+
+def test_reserved_cus_change_the_plans_not_the_results(dev):
+    """mi355_set_reserved_cus: grids sized from the CU count plan for fewer CUs (other split counts for the generated weight-gradient
+    kernels, fewer persistent workgroups); results stay exact.  mi355_comm_standin (the measurement stand-in of tools/reserve_cus_ab.py)
+    launches and returns."""
+    from sota_imagenet_amd import native, ops
+
+    L = native.lib()
+    torch.manual_seed(6)
+    x = torch.randint(-2, 3, (64, 14, 14, 256), device=dev).to(torch.bfloat16)
+    dy = torch.randint(-2, 3, (64, 14, 14, 256), device=dev).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (1024, 1, 1, 256), device=dev).to(torch.bfloat16)
+    ref = _wgrad_ref(dy, x)
+    try:
+        native.check(L.mi355_set_reserved_cus(32))
+        assert torch.equal(ops.conv2d_wgrad(dy, x, 3, 3, 1, 1), ref)
+        y = ops.conv2d_fwd(x, w, 1, 0)  # persistent pointwise kernel: units per workgroup from the CU count
+        assert torch.equal(y, _ref(x, w, 1).to(torch.bfloat16))
+        assert L.mi355_set_reserved_cus(12) != 0  # not a multiple of 8
+    finally:
+        native.check(L.mi355_set_reserved_cus(0))
+    assert torch.equal(ops.conv2d_wgrad(dy, x, 3, 3, 1, 1), ref)
+    native.check(L.mi355_comm_standin(4, 20, native.cur_stream()))
+    torch.cuda.synchronize()
