@@ -28,8 +28,8 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2516.6, "fp8": 5033.2}  # MI355X_MICROARCH.md: dense MFMA peaks (no sparsity)
 FP8_KIND = 9  # profile_read kind: the conv launches that ran on e4m3 operands
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-EVENT_STEPS = 2  # timed steps whose conv / BN launches carry HIP-event pairs for `roofline` (each pair is a barrier on its stream: such a
-                 # step is ~1.2 ms slower, and that is part of `value` — 2 steps = ~200 timed launches of the dominant class are enough)
+EVENT_STEPS = 1  # timed steps whose conv / BN launches carry HIP-event pairs for `roofline` (each pair is a barrier on its stream: such a
+                 # step is ~1.8 ms slower, and that is part of `value` — 1 step = 90 timed launches of the dominant class, 53 of the HBM kernel)
 HBM_CLASS = 7  # executor profile class of bn_bwd_apply_kernel, the largest HBM-bound kernel of the step
 # profile class -> kernel symbols (template instances of one source; names as tools/pmc_traffic.py writes them)
 KERNEL_NAMES = {0: ["igemm_kernel<{T},128,128>", "igemm_kernel<{T},256,256>", "igemm_kernel<{T},256,128>", "igemm8_kernel<224,256>", "igemm8_kernel<256,128>",
