@@ -242,6 +242,7 @@ int mi355_conv2d_fwd_stats(int dtype, const void* x, const void* w, void* y, flo
   build_fwd_args(a, N, H, W, Cin, Cout, KH, KW, stride, pad);
   a.in = x; a.wt = w; a.out = y;
   a.stat_partial = partial;
+  a.stat_rows_cap = (int)std::min<size_t>(partial_bytes / ((size_t)2 * Cout * sizeof(float)), 1u << 20);  // (the generated kernels write one row per pixel tile)
   return launch_igemm(dtype, a, 1, (hipStream_t)stream, nblk);
 }
 
