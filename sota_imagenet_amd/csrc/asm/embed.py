@@ -41,7 +41,7 @@ def main():
     with open(os.path.join(out_dir, "pk_meta.inc"), "w") as f:
         for name in pk_gen.VARIANTS:
             c, g, _ = pk_gen.generate(name)
-            f.write('{"%s", %d, %d, %d, %d, %d, %d},\n' % (name, c.W, c.Cin, c.NCOLS, c.stats, g.lds_bytes, pk_gen.Gen.KA["size"]))
+            f.write('{"%s", %d, %d, %d, %d, %d, %d, %d},\n' % (name, c.W, c.Cin, c.NCOLS, c.BN, c.stats, g.lds_bytes, pk_gen.Gen.KA["size"]))
 
 
 if __name__ == "__main__":

@@ -54,9 +54,9 @@ class PkCfg(dconv_gen.Cfg):
         return self.Cin * 2
 
 
-def mk(name, W, Cin, NCOLS, stats, NB=2, NA=3):
+def mk(name, W, Cin, NCOLS, stats, NB=2, NA=3, NT=4):
     P = (W + 15) // 16 * 16
-    return PkCfg(name, H=1, W=W, P=P, IPT=1, Cin=Cin, NCOLS=NCOLS, stats=stats, WM=1, WN=4, NT=4, NB=NB, NA_=NA)
+    return PkCfg(name, H=1, W=W, P=P, IPT=1, Cin=Cin, NCOLS=NCOLS, stats=stats, WM=1, WN=4, NT=NT, NB=NB, NA_=NA)
 
 
 class Gen(dconv_gen.Gen):
@@ -65,7 +65,7 @@ class Gen(dconv_gen.Gen):
     def gen(self):
         c = self.c
         S, V = self.S, self.V
-        assert c.WM == 1 and c.WN == 4 and c.NT == 4 and c.BN == 256 and c.H == 1 and c.IPT == 1 and not c.ROWS_T
+        assert c.WM == 1 and c.WN == 4 and c.NT in (2, 4) and c.BN in (128, 256) and c.H == 1 and c.IPT == 1 and not c.ROWS_T
         self.NPA = c.APIECES
         self.s_tile, self.s_nt = 2, 3
         self.srdA = S.get(4, 4)
@@ -100,8 +100,11 @@ class Gen(dconv_gen.Gen):
         if c.stats == 2:
             # BN-backward inputs of the two tile pairs.  Where two full sets do not fit (13 fragments), the second set is loaded at the
             # start of the epilogue INTO the fragment registers (free by then; the epilogue's temporaries use the first 51 of them)
-            self.late_pair1 = c.MFR > 8
-            if self.late_pair1:
+            self.late_pair1 = c.MFR > 8 and c.NT >= 4
+            if c.NT < 4:  # one tile pair per wave: one register set
+                y0, b0, m0 = [V.get(4, 4) for m in range(c.MFR)], [V.get() for m in range(c.MFR)], V.get(16, 4)
+                self.ysets, self.bsets, self.msets = [y0, y0], [b0, b0], [m0, m0]
+            elif self.late_pair1:
                 f0, f1 = self.F[0][0], self.F[1][0]
                 free = list(range(f0 + 52, f0 + 4 * c.MFR + 16)) + list(range(f1, f1 + 4 * c.MFR + 16))
                 free4 = [r for r in free if r % 4 == 0 and all(r + i in free for i in range(4))]
@@ -197,7 +200,7 @@ class Gen(dconv_gen.Gen):
         e("s_mul_i32 %s, %s, %d" % (R("s", self.s_ldsBw), R("s", self.s_w), c.BSTAGE // 4), "this wave's quarter of a weight stage")
         e("s_lshl_b32 %s, %s, 10" % (R("s", self.s_ldsAw), R("s", self.s_w)), "this wave's 8-pixel block of every 32 pixels")
         e("s_mul_i32 %s, %s, %d" % (R("s", self.s_srcAw), R("s", self.s_w), 8 * c.Cin * 2))
-        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_srcBw), R("s", self.s_w), 64 * c.w_row))
+        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_srcBw), R("s", self.s_w), c.NT * 16 * c.w_row))
         # ---- DMA lane parts.  A: row-in-block = lane >> 3; logical chunk = (lane & 7) ^ ((row >> 1) & 7), row = (4k + w)*8 + (lane >> 3)
         l3, l7, j, x, off = v[3], v[4], v[5], v[6], v[7]
         e("v_lshrrev_b32 %s, 3, %s" % (R("v", l3), R("v", lane)))
@@ -318,7 +321,7 @@ class Gen(dconv_gen.Gen):
             e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_wn), c.NT * 16 * 4))
             e("v_lshl_add_u32 %s, %s, 5, %s" % (R("v", self.v_chan), R("v", self.v_kg), R("s", t0)), "this lane's 8 floats of mean / invstd")
             self.epi_issue_loads(0)
-            if not self.late_pair1:
+            if not self.late_pair1 and c.NT >= 4:
                 self.epi_issue_loads(1)
             first_loads()
         else:
@@ -415,7 +418,7 @@ class Gen(dconv_gen.Gen):
 
 def _variants():
     v = {}
-    for (K, N, W, NB, stats) in (
+    for (K, N, W, NB, stats, *rest) in (
             # layer 3 (14 x 14, tile = one image): conv1 forward 1024 -> 256 with BN statistics (and without), conv3 data gradient with the BN-backward sums
             (1024, 256, 196, 2, (0, 1, 2)),
             # layer 4 (7 x 7, tile = two images): 2048 -> 512
@@ -425,10 +428,12 @@ def _variants():
             (1024, 512, 196, 2, (0, 1)),
             # layer 4 conv3 forward 512 -> 2048 (tile = four images)
             # (not shipped: 256 -> 1024, layer 3 conv3 forward — 4 chunks per workgroup; 57-61 us against 47.7 us of pw_gen.py's resident-K kernel)
-            (512, 2048, 196, 2, (0, 1))):
+            (512, 2048, 196, 2, (0, 1)),
+            # layer 2 (28 x 28): conv1 forward 512 -> 128 and conv3 data gradient: 128-column tiles (two 16-column tiles per wave)
+            (512, 128, 196, 2, (0, 1, 2), 2)):
         for st in stats:
             name = "pk_k%d_n%d_w%d_s%d" % (K, N, W, st)
-            v[name] = mk(name, W, K, N, st, NB=NB)
+            v[name] = mk(name, W, K, N, st, NB=NB, NT=rest[0] if rest else 4)
     return v
 
 

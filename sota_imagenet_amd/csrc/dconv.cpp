@@ -33,10 +33,10 @@ const PwVariant g_pw[] = {
 };
 constexpr int NPW = (int)(sizeof(g_pw) / sizeof(g_pw[0]));
 
-// long-reduction pointwise kernels (asm/pk_gen.py): tiles of W pixels x 256 columns
+// long-reduction pointwise kernels (asm/pk_gen.py): tiles of W pixels x BN (256 | 128) columns
 struct PkVariant {
   const char* name;
-  int W, K, N, stats, lds, kernarg;
+  int W, K, N, BN, stats, lds, kernarg;
 };
 const PkVariant g_pk[] = {
 #include "build/asm/pk_meta.inc"
@@ -398,7 +398,7 @@ int launch_pk(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
   const unsigned tiles = (unsigned)((long)a.N * a.Hin * a.Win / v.W);
   size_t ksize = sizeof(k);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
-  const hipError_t e = hipModuleLaunchKernel(d->pk[vi], tiles, (unsigned)(v.N / 256), 1, 256, 1, 1, 0, stream, nullptr, extra);
+  const hipError_t e = hipModuleLaunchKernel(d->pk[vi], tiles, (unsigned)(v.N / v.BN), 1, 256, 1, 1, 0, stream, nullptr, extra);
   if (e != hipSuccess) {
     set_error("pk: hipModuleLaunchKernel(%s) -> %s", v.name, hipGetErrorString(e));
     return MI355_E_HIP;

@@ -101,7 +101,8 @@ def test_pointwise_weight_gradient_kernels_are_exact_in_the_emulator(name, kw):
 
 @pytest.mark.parametrize("name,kw", [("pk_k1024_n256_w196_s1", dict(tiles=(1,), Cin=256)), ("pk_k1024_n256_w196_s2", dict(tiles=(0, 2), Cin=448)),
                                      ("pk_k2048_n512_w98_s1", dict(tiles=(1,), ntile=1, Cin=320)), ("pk_k2048_n512_w98_s2", dict(tiles=(0,), ntile=1, Cin=192)),
-                                     ("pk_k1024_n256_w196_s0", dict(tiles=(0,), Cin=64)), ("pk_k2048_n512_w98_s0", dict(tiles=(2,), Cin=384))])
+                                     ("pk_k1024_n256_w196_s0", dict(tiles=(0,), Cin=64)), ("pk_k2048_n512_w98_s0", dict(tiles=(2,), Cin=384)),
+                                     ("pk_k512_n128_w196_s1", dict(tiles=(1,), Cin=192)), ("pk_k512_n128_w196_s2", dict(tiles=(0,), Cin=128))])
 def test_long_reduction_pointwise_kernels_are_exact_in_the_emulator(name, kw):
     """csrc/asm/pk_gen.py with 1 .. 7 chunks of 64 channels (every exit of the unrolled buffer rotation), both column tiles, the three
     epilogues (none / BN statistics / BN-backward sums, the latter with the late second register set at 13 fragments)"""

@@ -42,7 +42,7 @@ def run(name, tiles=(0,), ntile=0, ntiles=None, seed=0, check=True, **over):
     got = from_bf16_bits(mem.array(a_out, np.uint16, out0.shape)).astype(np.float64)
     ref = x.astype(np.float64) @ w.astype(np.float64).T
     refr = bf16_round(ref.astype(np.float32)).astype(np.float64)
-    cols = slice(ntile * 256, ntile * 256 + 256)
+    cols = slice(ntile * c.BN, ntile * c.BN + c.BN)
     rows = lambda t: slice(t * c.W, (t + 1) * c.W)
     res = {"insts": total, "cfg": c}
     res["max_err"] = float(max(np.abs(got[rows(t), cols] - refr[rows(t), cols]).max() for t in tiles))
