@@ -386,6 +386,9 @@ int mi355_resnet50_set_comm(mi355_ctx* ctx, mi355_comm* comm, double bucket_cap_
  * the reference leaves that to NCCL and the CUDA scheduler, /root/reference/train.py:113-114): every grid sized from the CU count plans
  * for CUs - n.  n: a non-negative multiple of 8 (the same number per XCD).  Process-global; call before creating contexts.        */
 int mi355_set_reserved_cus(int n);
+/* the per-launch tile knobs (MI355_IGEMM8, MI355_IGEMM_BIG, MI355_STEM_DIRECT, MI355_STEM_TH, MI355_STEM_DBG: test hooks / A/B switches)
+ * are read from the environment once; this re-reads them (tests flip them between launches of one process)                          */
+int mi355_reload_knobs(void);
 /* measurement stand-in for a collective's CU footprint on one GPU: `workgroups` 256-thread workgroups (16 KiB of LDS each) that hold
  * their CU slots for `usec` microseconds without memory traffic (tools/reserve_cus_ab.py; not part of the training path)           */
 int mi355_comm_standin(int workgroups, int usec, void* stream);

@@ -128,6 +128,18 @@ int launch_igemm_fp8(const IgemmArgs& a, int nclass, float oscale, hipStream_t s
 int plan_wgrad_splits(int dtype, int M, int Cout, int ntaps, int Ck);
 // plan_wgrad: the split count for THIS launch — the generated 3x3 kernels (asm/wg_gen.py, dconv.cpp) have their own, every other
 // launch plan_wgrad_splits' — and what launch_wgrad must be given for the launch to take the kernel the plan was made for
+// Per-launch tile knobs of the conv launchers (test hooks and A/B switches: MI355_IGEMM8, MI355_IGEMM_BIG, MI355_STEM_DIRECT, MI355_STEM_TH,
+// MI355_STEM_DBG): read from the environment ONCE and on mi355_reload_knobs() — no getenv on a launch path.
+struct Knobs {
+  bool has_igemm8 = false;
+  char igemm8[32] = {0};     // MI355_IGEMM8: "0" never, "<BM>x<BN>[k][f]" forces a tile; unset: the measured rule
+  int igemm_big = -1;        // MI355_IGEMM_BIG: -1 unset, 0 never, 1 256 x 256 wherever legal, 3 256 x 128
+  bool has_igemm_big = false;
+  int stem_direct = 1;       // MI355_STEM_DIRECT=0: the row-pair implicit GEMM
+  int stem_th = 0;           // MI355_STEM_TH: a smaller stem tile (0: the plan)
+  bool stem_dbg = false;     // MI355_STEM_DBG: print the stem launch plan
+};
+const Knobs& knobs();
 int plan_wgrad(int dtype, const WgradArgs& a);
 int wg3_plan(int dtype, const WgradArgs& a);  // 0: the launch is not served by a generated kernel
 int launch_wg3(const WgradArgs& a, int splits, hipStream_t stream);

@@ -70,6 +70,45 @@ extern "C" int mi355_set_reserved_cus(int n) {
   return 0;
 }
 
+static Knobs g_knobs;
+static std::atomic<bool> g_knobs_loaded{false};
+static std::mutex g_knobs_mu;
+
+static void load_knobs() {
+  Knobs k;
+  if (const char* e = getenv("MI355_IGEMM8")) {
+    k.has_igemm8 = true;
+    strncpy(k.igemm8, e, sizeof(k.igemm8) - 1);
+  }
+  if (const char* e = getenv("MI355_IGEMM_BIG")) {
+    k.has_igemm_big = true;
+    k.igemm_big = atoi(e);
+  }
+  if (const char* e = getenv("MI355_STEM_DIRECT")) k.stem_direct = e[0] == '0' ? 0 : 1;
+  if (const char* e = getenv("MI355_STEM_TH")) k.stem_th = atoi(e);
+  k.stem_dbg = getenv("MI355_STEM_DBG") != nullptr;
+  g_knobs = k;
+}
+
+const Knobs& knobs() {
+  if (!g_knobs_loaded.load(std::memory_order_acquire)) {
+    std::lock_guard<std::mutex> lock(g_knobs_mu);
+    if (!g_knobs_loaded.load()) {
+      load_knobs();
+      g_knobs_loaded.store(true, std::memory_order_release);
+    }
+  }
+  return g_knobs;
+}
+
+// re-reads the per-launch tile knobs (tests flip them between launches of one process; not thread-safe against running launches)
+extern "C" int mi355_reload_knobs(void) {
+  std::lock_guard<std::mutex> lock(g_knobs_mu);
+  load_knobs();
+  g_knobs_loaded.store(true, std::memory_order_release);
+  return 0;
+}
+
 static int out_dim(int H, int K, int s, int p) { return (H + 2 * p - K) / s + 1; }
 
 void build_fwd_args(IgemmArgs& a, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {

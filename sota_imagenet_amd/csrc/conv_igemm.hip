@@ -828,7 +828,7 @@ int launch_igemm8(const IgemmArgs& a, int nclass, int bm, int bn, int korder, in
 //   "0" never;  "<BM>x<BN>[k][f]" (e.g. 256x256, 224x128kf) forces that tile wherever it is legal (k: channel chunks
 //   outer, taps inner; f: the fat-phase form);  unset: the measured rule below.
 static bool choose_igemm8(const IgemmArgs& a, int nclass, int* bm, int* bn, int* korder, int* fat) {
-  const char* env = getenv("MI355_IGEMM8");
+  const char* env = knobs().has_igemm8 ? knobs().igemm8 : nullptr;
   if (env && env[0] == '0') return false;
   if (env && env[0]) {
     int m = 0, n = 0;
@@ -897,8 +897,7 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
     if (pk_legal(a, nclass)) return launch_pk(a, nclass, stream, stat_rows);
     {
       // the stem as a direct convolution out of raw input rows (stem_direct.hip; MI355_STEM_DIRECT=0: the row-pair implicit GEMM)
-      const char* sd = getenv("MI355_STEM_DIRECT");
-      if (!(sd && sd[0] == '0') && stem_direct_legal(a, nclass)) return launch_stem_direct(a, stream, stat_rows);
+      if (knobs().stem_direct && stem_direct_legal(a, nclass)) return launch_stem_direct(a, stream, stat_rows);
     }
     {
       int bm8 = 0, bn8 = 0, ko8 = 0, fat8 = 0;
@@ -908,8 +907,7 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
     // shape at batch 256 (tools/one_conv.py): they win when the 256 single-workgroup CUs are still mostly filled
     // (>= 192 tiles) and the reduction is long enough to amortise the larger epilogue (K >= 256); they lose on the
     // HBM-bound layer-1/2 shapes and when layer 4's 98 row tiles leave most CUs idle.
-    const char* big_env = getenv("MI355_IGEMM_BIG");  // 0 never / 1 wherever N % 256 == 0 (tests, A/B); unset: the rule
-    const int big_mode = big_env ? atoi(big_env) : -1;
+    const int big_mode = knobs().has_igemm_big ? knobs().igemm_big : -1;  // MI355_IGEMM_BIG: 0 never / 1 wherever N % 256 == 0 (tests, A/B); unset: the rule
     const long items256 = (long)cdiv(a.N * a.Hsub * a.Wsub, 256) * nclass * (a.Ncols / 256);
     int max_taps = 0;
     for (int ci = 0; ci < nclass; ++ci) max_taps = a.cls[ci].ntaps > max_taps ? a.cls[ci].ntaps : max_taps;

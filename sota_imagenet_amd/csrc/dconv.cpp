@@ -229,7 +229,7 @@ int find_pk(const IgemmArgs& a, int nclass, int stats) {
 // (MI355_IGEMM8 / MI355_IGEMM_BIG, the per-launch knobs of the tile tests) is left to those kernels too.
 static bool dconv_enabled() {
   static const bool on = !(getenv("MI355_DCONV") && getenv("MI355_DCONV")[0] == '0');
-  return on && getenv("MI355_IGEMM8") == nullptr && getenv("MI355_IGEMM_BIG") == nullptr;
+  return on && !knobs().has_igemm8 && !knobs().has_igemm_big;
 }
 
 // split count of the generated weight-gradient kernel for this launch (0: not served).  One workgroup per CU: the (ci tile, co tile)

@@ -369,8 +369,8 @@ int launch_stem_direct(const IgemmArgs& a, hipStream_t stream, int* stat_rows) {
   k.k.a = a;
   k.pitch = a.Win * STEM_PS * 2;
   k.k.TH = plan_stem(a.Hout, a.Wout, k.pitch);
-  if (const char* e = getenv("MI355_STEM_TH")) {  // A/B knob: a smaller tile (must divide Hout)
-    const int th = atoi(e);
+  if (knobs().stem_th > 0) {  // MI355_STEM_TH, A/B knob: a smaller tile (must divide Hout)
+    const int th = knobs().stem_th;
     if (th >= 1 && th <= k.k.TH && a.Hout % th == 0) k.k.TH = th;
   }
   k.FR = a.Wout / 16;
@@ -385,7 +385,7 @@ int launch_stem_direct(const IgemmArgs& a, hipStream_t stream, int* stat_rows) {
   MI355_ARG((size_t)a.N * k.img_bytes < 0xfffffff0ull, "stem: input beyond 32-bit offsets");
   const bool stats = a.stat_partial != nullptr;
   if (stat_rows) *stat_rows = stats ? grid : 0;
-  if (getenv("MI355_STEM_DBG")) {
+  if (knobs().stem_dbg) {
     int nb = -1;
     lds_opt_in3((const void*)stem_direct_kernel<1>);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)stem_direct_kernel<1>, 256, lds);

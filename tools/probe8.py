@@ -3,7 +3,7 @@ what remains is MFMA + epilogue + stores.  python tools/probe8.py"""
 import os, sys, time
 import torch
 sys.path.insert(0, ".")
-from sota_imagenet_amd import ops
+from sota_imagenet_amd import native, ops
 dt = torch.bfloat16
 N = 256
 for (name, H, Cin, Cout, K, tile) in [("l3.c3 fwd", 14, 256, 1024, 1, "224x256"), ("l3.c1 fwd", 14, 1024, 256, 1, "224x256"), ("l2.c3 fwd", 28, 128, 512, 1, "224x256"),
@@ -13,6 +13,7 @@ for (name, H, Cin, Cout, K, tile) in [("l3.c3 fwd", 14, 256, 1024, 1, "224x256")
     xs = [torch.randn(N, H, H, Cin, device="cuda").to(dt) for _ in range(nset)]
     w = (torch.randn(Cout, K, K, Cin, device="cuda") * 0.05).to(dt)
     os.environ["MI355_IGEMM8"] = tile
+    native.lib().mi355_reload_knobs()  # (the library reads its tile knobs once)
     out = []
     for dbg in ("0", "1", "2", "3"):
         os.environ["MI355_IGEMM8_DBG"] = dbg
@@ -32,6 +33,7 @@ for (name, H, Cin, Cout, K, tile) in [("l3.c3 fwd", 14, 256, 1024, 1, "224x256")
 # the 4-wave kernel (conv_igemm.hip): MI355_IGEMM_DBG 1 = no epilogue at all, 2 = full epilogue but its stores hit one trash page
 # (compiled in only by `make -C sota_imagenet_amd/csrc probes`; run this script with MI355RN_LIB=sota_imagenet_amd/lib/variant_probes.so)
 os.environ["MI355_IGEMM8"] = "0"
+native.lib().mi355_reload_knobs()  # (the library reads its tile knobs once)
 os.environ.pop("MI355_IGEMM8_DBG", None)
 for (name, H, Cin, Cout, K) in [("l1.c3 fwd", 56, 64, 256, 1), ("l1.c1 fwd", 56, 256, 64, 1), ("l2.c3 fwd", 28, 128, 512, 1), ("l2.c1 fwd", 28, 512, 128, 1),
                                 ("l3.c3 fwd", 14, 256, 1024, 1), ("l1.c2 fwd", 56, 64, 64, 3), ("l2.c2 fwd", 28, 128, 128, 3)]:
@@ -81,6 +83,7 @@ for (name, H, Cin, Cout) in [("l3.c1 dgrad", 14, 1024, 256), ("l2.c1 dgrad", 28,
 
 # weight gradients: MI355_WGRAD_DBG=3 replaces both operand loads by zero-record reads (no L2 / HBM traffic)
 os.environ.pop("MI355_IGEMM8", None)
+native.lib().mi355_reload_knobs()  # (the library reads its tile knobs once)
 for (name, H, Cin, Cout, K) in [("l3.c2.w", 14, 256, 256, 3), ("l3.c1.w", 14, 1024, 256, 1), ("l3.c3.w", 14, 256, 1024, 1), ("l4.c2.w", 7, 512, 512, 3),
                                 ("l2.c2.w", 28, 128, 128, 3), ("l2.c1.w", 28, 512, 128, 1), ("l1.c3.w", 56, 64, 256, 1), ("l1.c2.w", 56, 64, 64, 3)]:
     M = N * H * H
