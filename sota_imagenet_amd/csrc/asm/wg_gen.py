@@ -44,6 +44,8 @@ class WCfg:
     geom: str     # "img": a tile is one image | "rows": DR rows of one image | "pack": IPT images of 8 rows each (H = 7)
     DR: int       # dy rows of a tile
     IPT: int = 1  # images per tile (pack)
+    rspan: int = 100  # tuning: reads / LDS-DMA of a k-step are issued within the first rspan % of its MFMAs
+    noxwin: bool = False  # tuning: the 9-fragment form even where the x window applies
 
     @property
     def K(self):          # positions per tile
@@ -208,12 +210,23 @@ class Gen:
         self.v_dma = {k: [V.get() for _ in self.plan[k]["variants"]] for k in ("d", "x")}
         self.v_tmp = [V.get(), V.get()]
         self.v_out = V.get()
+        # x window (P = 16 or 64): tap (ky, kx) at k-step s reads positions 32 s + ky P + kx ... — whole half fragments (16 positions) of
+        # the SAME position stream per kx, so the stream of a tile is read ONCE into NH consecutive register pairs per kx and the 3 ky taps
+        # of a step are three overlapping 4-register windows of it: 6 + 8 transposed reads per k-step instead of 18 + 8.  (The transposed
+        # read occupies the LDS pipe like a 64-byte-per-clock access: with 26 per step the kernel is bound by it)
+        self.HS = c.P // 16
+        self.NH = 2 * c.KS + 2 * self.HS
+        self.xwin = c.P in (16, 64) and self.NH == 16 and not getattr(c, "noxwin", False)
         self.F = []
         for s in range(2):
             fd = V.get(16, 4)
-            fx = V.get(36, 4)
+            fx = None if self.xwin else V.get(36, 4)
             self.F.append((fd, fx))
-        self.v_t = [self.F[1][1] + i for i in range(12)]   # prologue temporaries: fragment set 1 is first written by the main loop
+        if self.xwin:
+            self.XW = [[V.get(2 * self.NH, 4) for kx in range(3)] for b in range(2)]
+            self.v_t = [self.XW[1][0] + i for i in range(12)]   # prologue temporaries: buffer 1's window is first written by the main loop
+        else:
+            self.v_t = [self.F[1][1] + i for i in range(12)]   # prologue temporaries: fragment set 1 is first written by the main loop
         self.nvgpr = V.n
         self.accum_offset = (self.nvgpr + 7) // 8 * 8
         self.nagpr = 144
@@ -282,33 +295,48 @@ class Gen:
         return ["s_add_u32 %s, %s, 1" % (R("s", self.s_tile), R("s", self.s_tile)),
                 "s_min_u32 %s, %s, %s" % (R("s", self.s_tile), R("s", self.s_tile), R("s", self.s_tend))]
 
-    def frag_reads(self, fset, step, buf):
+    def x_halves(self, buf, js):
+        """x window: half fragments js of the tile in buffer buf, for the three kx streams"""
+        out = []
+        for j in js:
+            for kx in range(3):
+                out.append("ds_read_b64_tr_b16 %s, %s offset:%d" % (R("v", self.XW[buf][kx] + 2 * j, 2), R("v", self.vX_rd[buf][kx]), j * 2048))
+        return out
+
+    def frag_reads(self, fset, step, buf, first=False):
+        """reads that must be done before k-step `step` of the tile in buffer buf can start: its dy fragments and (x window) the half
+        fragments that step is the first to use — all of the first step's when `first`"""
         c = self.c
         fd, fx = self.F[fset]
         out = []
         for n in range(4):
             for h in range(2):
                 out.append("ds_read_b64_tr_b16 %s, %s offset:%d" % (R("v", fd + 4 * n + 2 * h, 2), R("v", self.vD_rd[buf][n]), step * 4096 + h * 2048))
+        if self.xwin:
+            hi = 2 * step + 2 * self.HS + 1
+            return out + self.x_halves(buf, range(0, hi + 1) if first else (hi - 1, hi))
         for t in range(9):
             ky, kx = divmod(t, 3)
             for h in range(2):
                 out.append("ds_read_b64_tr_b16 %s, %s offset:%d" % (R("v", fx + 4 * t + 2 * h, 2), R("v", self.vX_rd[buf][kx]), step * 4096 + h * 2048 + ky * c.P * 128))
         return out
 
-    def mfmas(self, fset):
+    def mfmas(self, fset, step=0, buf=0):
         fd, fx = self.F[fset]
         out = []
         for t in range(9):
+            ky, kx = divmod(t, 3)
+            xr = self.XW[buf][kx] + 2 * (2 * step + ky * self.HS) if self.xwin else fx + 4 * t
             for n in range(4):
                 acc = (t * 4 + n) * 4
-                out.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (R("a", acc, 4), R("v", fx + 4 * t, 4), R("v", fd + 4 * n, 4), R("a", acc, 4)))
+                out.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (R("a", acc, 4), R("v", xr, 4), R("v", fd + 4 * n, 4), R("a", acc, 4)))
         return out
 
     def interleave(self, mf, groups, first=1):
         n, k = len(mf), len(groups)
         slots = {}
         if k:
-            span = n - first
+            span = int((n - first) * getattr(self.c, "rspan", 100) / 100)  # (tuning knob: issue everything within the first rspan % of the MFMAs)
             for j, grp in enumerate(groups):
                 pos = first + (j * span) // k
                 slots.setdefault(pos, []).extend(grp)
@@ -455,7 +483,7 @@ class Gen:
         for grp in ps[:(len(ps) + 1) // 2]:   # (the second half is issued by the first k-step of the main loop)
             for ins in grp:
                 e(ins)
-        for ins in self.frag_reads(0, 0, 0):
+        for ins in self.frag_reads(0, 0, 0, first=True):
             e(ins)
 
     def mainloop(self):
@@ -477,7 +505,7 @@ class Gen:
                     # the tile in the other buffer has landed for every wave; this buffer's fragments have all been read
                     e("s_waitcnt vmcnt(0)")
                     e("s_barrier")
-                    groups = [[r] for r in self.frag_reads(fset ^ 1, 0, b ^ 1)]
+                    groups = [[r] for r in self.frag_reads(fset ^ 1, 0, b ^ 1, first=True)]
                     ps = self.all_pieces(b)
                     half = (len(ps) + 1) // 2
                     setup = self.next_tile_insts() + self.tile_setup()
@@ -491,7 +519,7 @@ class Gen:
                         ps = self.all_pieces(b ^ 1)
                         half = (len(ps) + 1) // 2
                         groups = self.merge(groups, ps[half:])
-                self.interleave(self.mfmas(fset), groups)
+                self.interleave(self.mfmas(fset, s, b), groups)
                 fset ^= 1
             e("s_sub_u32 %s, %s, 1" % (R("s", self.s_cnt), R("s", self.s_cnt)))
             e("s_cmp_eq_u32 %s, 0" % R("s", self.s_cnt))
