@@ -77,6 +77,17 @@ int mi355_conv2d_fwd_stats(int dtype, const void* x, const void* w, void* y, flo
 int mi355_conv2d_dgrad(int dtype, const void* dy, const void* w, void* dx, const void* addend, int N,
                        int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* ws,
                        size_t ws_bytes, void* stream);
+/* the data gradient as the executor's backward launches it (loss.backward(), /root/reference/sota_imagenet/callbacks.py:317; the
+ * residual add + ReLU + BatchNorm backward autograd runs around cuDNN's dgrad there, fused into the conv's epilogue here):
+ *   dx = conv_transpose(dy, w) + (addend under addend_bits — the shortcut gradient under the block output's ReLU bit mask; bits null: plain)
+ * and, when `partial` is non-null, the BN-backward sums of the layer whose post-ReLU activation dx is the gradient of, as partial
+ * rows [*nblk][2][Cin] floats: sum dz and sum dz * xhat, dz = dx (as stored) under bn_bits, xhat = (bn_y - bn_mean) * bn_invstd
+ * (bn_y laid out like dx, masks one byte per 16-byte vector).  *nblk = 0 when the launch shape cannot produce them.
+ * partial: >= 768 * 2 * Cin floats.  dx may alias addend.                                                                          */
+int mi355_conv2d_dgrad_bn(int dtype, const void* dy, const void* w, void* dx, const void* addend, const uint8_t* addend_bits,
+                          const void* bn_y, const uint8_t* bn_bits, const float* bn_mean, const float* bn_invstd, float* partial,
+                          size_t partial_bytes, int* nblk, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                          void* ws, size_t ws_bytes, void* stream);
 
 /* dw[Cout,KH,KW,Cin] (fp32) = sum_{n,oh,ow} dy (x) x.  beta=0 overwrites, beta=1 accumulates.
  * replaces cuDNN wgrad under loss.backward() — callbacks.py:317 (K8)                                */
@@ -389,6 +400,11 @@ int mi355_set_reserved_cus(int n);
 /* the per-launch tile knobs (MI355_IGEMM8, MI355_IGEMM_BIG, MI355_STEM_DIRECT, MI355_STEM_TH, MI355_STEM_DBG: test hooks / A/B switches)
  * are read from the environment once; this re-reads them (tests flip them between launches of one process)                          */
 int mi355_reload_knobs(void);
+/* name of the kernel the calling thread's last convolution / weight-gradient launch went to: the symbol of a generated gfx950 kernel
+ * (dconv_l3_s1, po_k256_b256_s2_a2, wg3_l2 ...) or the implicit-GEMM tile family (igemm<bf16,128,128,2> ...).  A debugging query: the
+ * tests pin the selection rules with it (cuDNN's own algorithm choice under /root/reference/sota_imagenet/callbacks.py:316-317 is not
+ * observable in the reference).  The string stays valid until the thread's next launch.                                            */
+const char* mi355_last_conv_kernel(void);
 /* measurement stand-in for a collective's CU footprint on one GPU: `workgroups` 256-thread workgroups (16 KiB of LDS each) that hold
  * their CU slots for `usec` microseconds without memory traffic (tools/reserve_cus_ab.py; not part of the training path)           */
 int mi355_comm_standin(int workgroups, int usec, void* stream);
@@ -421,6 +437,12 @@ int mi355_resnet50_fp8_state(const mi355_ctx* ctx, int* fwd_on, int* bwd_on, int
 
 /* algorithmic work of the ctx's conv/FC kernels (2 FLOP/MAC, padding-free): forward and fwd+bwd */
 int mi355_resnet50_flops(const mi355_ctx* ctx, double* fwd_flops, double* train_flops);
+/* which kernel each convolution of the network went to in its last forward / data-gradient / weight-gradient launch, one text line
+ * per layer: "<conv name> fwd=<kernel> dgrad=<kernel> wgrad=<kernel>" ('-' = not launched yet; names as mi355_last_conv_kernel).
+ * Writes at most cap bytes (NUL-terminated) and the size a complete table needs.  A debugging query: the tests assert the selection
+ * rules of the bs-256 plan with it (the reference's counterpart, cuDNN's algorithm choice under
+ * /root/reference/sota_imagenet/callbacks.py:316-317, is not observable).                                                         */
+int mi355_resnet50_kernel_table(const mi355_ctx* ctx, char* out, size_t cap, size_t* needed);
 
 /* Test hook: device pointer / shape of an internal tensor of the last step, by name:
  *   "<conv>.y" raw conv output, "<block>.a1|a2|out" post-activation tensors (e.g. "layer1.0.out"),

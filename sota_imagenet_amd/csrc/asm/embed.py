@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """embed.py <out dir> <linked .hsaco> — writes the include files dconv.cpp embeds: the code object as a byte array
 (dconv_blob.inc) and one initialiser per generated kernel (dconv_meta.inc: direct 3x3 kernels, pw_meta.inc: pointwise, wg_meta.inc / wg1_meta.inc: 3x3 / 1x1 weight gradient,
-pk_meta.inc: long-reduction pointwise)."""
+pk_meta.inc: long-reduction pointwise, po_meta.inc: output-heavy pointwise with resident weights)."""
 import os
 import sys
 
@@ -11,6 +11,7 @@ import pw_gen  # noqa: E402
 import wg_gen  # noqa: E402
 import wg1_gen  # noqa: E402
 import pk_gen  # noqa: E402
+import po_gen  # noqa: E402
 
 
 def main():
@@ -42,6 +43,10 @@ def main():
         for name in pk_gen.VARIANTS:
             c, g, _ = pk_gen.generate(name)
             f.write('{"%s", %d, %d, %d, %d, %d, %d, %d},\n' % (name, c.W, c.Cin, c.NCOLS, c.BN, c.stats, g.lds_bytes, pk_gen.Gen.KA["size"]))
+    with open(os.path.join(out_dir, "po_meta.inc"), "w") as f:
+        for name in po_gen.VARIANTS:
+            c, g, _ = po_gen.generate(name)
+            f.write('{"%s", %d, %d, %d, %d, %d, %d, %d},\n' % (name, c.K, c.BN, c.stats, c.add, c.TP, g.lds_bytes, po_gen.Gen.KA["size"]))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,757 @@
+#!/usr/bin/env python3
+"""po_gen.py — generator of the hand-scheduled gfx950 (MI355X) pointwise convolution kernels for the OUTPUT-HEAVY, HBM-bound 1x1
+launches of ResNet-50's train step: a short reduction K (64 .. 512 channels) into 4K columns under a streaming epilogue —
+  * conv3 forward / the stride-1 downsample forward (BN statistics rows of the output),
+  * conv1's data gradient: + the shortcut gradient (addend, under its ReLU bit mask or plain) + the BN-backward sums of the layer
+    whose activation gradient the output is (that layer's y and ReLU bit mask are read in the epilogue) —
+the IgemmArgs contract of launch_igemm() (conv forward / data gradient under `model(data)` / `loss.backward()`,
+/root/reference/sota_imagenet/callbacks.py:316-317).
+
+Why its own structure.  These launches move 3 .. 13 bytes of epilogue traffic per byte of GEMM input and carry 10 us of MFMA work
+against 60 .. 250 us of HBM time: what bounds them is bytes in flight per CU and the epilogue's instruction count, not the matrix
+pipe.  So:
+  weights     RESIDENT IN AGPRs.  Waves are 1 (M) x 4 (N); a wave owns BN/4 columns, and its whole K x BN/4 weight slab (8 .. 32 KiB)
+              is loaded ONCE per workgroup straight into accumulation registers (MFMA reads its weight operand from AGPRs): no weight
+              stream, no weight ring, no LDS traffic for weights for the rest of the kernel.
+  workgroups  persistent: one per CU, a workgroup owns ONE column tile and a contiguous run of 64-pixel tiles; the workgroups of the
+              column tiles of one pixel run sit on one XCD (workgroup id % 8), so the pixel tile and the 128-byte mask lines they
+              share are fetched from HBM once.
+  A operand   the 64 x K pixel tile by LDS-DMA ([plane of 64 channels][pixel][128 B], XOR-swizzled chunks), two buffers: tile t + 1
+              is requested right behind the barrier of tile t.
+  epilogue    straight from the accumulators, one (fragment, tile pair) ITEM at a time: 8 consecutive channels of one pixel per lane;
+              the y / mask / addend vectors of an item live in 10 registers that are re-requested for the NEXT tile the moment the
+              item has consumed them (rolling refill): a full tile's worth of epilogue operands (20 KiB per wave) is in flight at
+              every moment, and every wait is a counted vmcnt with a constant derived below.
+  statistics  per-lane sums stay in registers across ALL tiles of the workgroup; one DPP row reduction and one partial row per
+              workgroup at the end.
+Tensor extents are enforced by the buffer descriptors (num_records = bytes left from the tile's base, moved tile by tile), so a
+ragged last tile (pixel count not a multiple of 64) reads zeros and drops its stores; no SGPR offset takes part in a range check.
+"""
+import argparse
+import os
+import sys
+from dataclasses import dataclass
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from dconv_gen import Alloc, R  # noqa: E402
+
+
+@dataclass
+class PoCfg:
+    name: str
+    K: int            # input channels (reduction), multiple of 64
+    BN: int           # output columns per workgroup (256 | 128)
+    stats: int        # 0 none, 1 BN statistics of the output, 2 BN-backward sums
+    add: int = 0      # 0 no addend, 1 addend, 2 addend under its ReLU bit mask
+    MFR: int = 4      # 16-pixel fragments per tile
+    NBUF: int = 2     # A tile buffers
+    nt: int = 0       # non-temporal cache policy: 1 epilogue operand loads, 2 output stores, 4 A pieces
+    probe: int = 0    # timing probes (WRONG results): 1 no MFMAs, 2 no epilogue arithmetic, 4 no operand loads, 8 no stores
+
+    @property
+    def NT(self):     # 16-column tiles per wave
+        return self.BN // 64
+
+    @property
+    def KS(self):     # 32-channel k-steps
+        return self.K // 32
+
+    @property
+    def NPL(self):    # planes of 64 channels
+        return self.K // 64
+
+    @property
+    def TP(self):     # pixels per tile
+        return self.MFR * 16
+
+    @property
+    def PLANE(self):
+        return self.TP * 128
+
+    @property
+    def ABUF(self):
+        return self.NPL * self.PLANE
+
+    @property
+    def LDS(self):
+        return self.NBUF * self.ABUF
+
+    @property
+    def NPW(self):    # LDS-DMA pieces per wave and tile
+        return self.NPL * self.TP // 8 // 4
+
+    @property
+    def NI(self):     # epilogue items per tile: (fragment, tile pair)
+        return self.MFR * self.NT // 2
+
+    @property
+    def L(self):      # vector-memory loads per item
+        return (2 if self.stats == 2 else 0) + self.add
+
+    @property
+    def FULL(self):   # full-line stores: a wave owns 128 bytes of every pixel row (two tile pairs), a store instruction writes 8 pixels x 128 bytes
+        return self.NT == 4
+
+
+class Gen:
+    KA = dict(in_=0, wt=8, out=16, stat=24, bn_y=32, bn_bits=40, bn_mean=48, bn_invstd=56, addend=64, addend_bits=72,
+              npix=80, ncols=84, tpg=88, ngroups=92, ntiles=96, lognct=100, size=128)
+
+    def __init__(self, c: PoCfg):
+        self.c = c
+        self.out = []
+        self.nlabel = 0
+        self.S = Alloc("s", 4, 102)
+        self.V = Alloc("v", 1, 256)
+
+    def e(self, s, comment=None):
+        self.out.append("\t" + s + ("\t; " + comment if comment else ""))
+
+    def label(self, name):
+        self.out.append(name + ":")
+
+    def newlabel(self, stem):
+        self.nlabel += 1
+        return "L_%s_%s_%d" % (self.c.name, stem, self.nlabel)
+
+    def comment(self, s):
+        self.out.append("\t; " + s)
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def gen(self):
+        c, S, V = self.c, self.S, self.V
+        assert c.BN in (128, 256) and c.K % 64 == 0 and c.MFR % 2 == 0 and c.NT % 2 == 0
+        assert (c.L + 1) * c.NI + c.NPW <= 63, "vmcnt range"
+        assert c.LDS <= 160 * 1024
+        self.s_wg = 2
+        self.srdA, self.srdB, self.srdO, self.srdX = S.get(4, 4), S.get(4, 4), S.get(4, 4), S.get(4, 4)
+        self.srdY = self.srdM = self.srdAD = self.srdAB = None
+        if c.stats == 2:
+            self.srdY, self.srdM = S.get(4, 4), S.get(4, 4)
+        if c.add:
+            self.srdAD = S.get(4, 4)
+        if c.add == 2:
+            self.srdAB = S.get(4, 4)
+        self.s_ka = S.get(20, 4)
+        self.s_kp = S.get(8, 4)
+        (self.s_w, self.s_t0, self.s_t1, self.s_t2, self.s_t3, self.s_cnt, self.s_pf, self.s_tout, self.s_tbits, self.s_g, self.s_ct, self.s_ldsA, self.s_n4,
+         self.s_ia, self.s_io, self.s_ib, self.s_8rows) = [S.get() for _ in range(17)]
+        self.s_lo8 = S.get(2, 2)   # lanes 0 .. 7 of every row of 16
+        self.vA_rd = [[V.get() for kk in range(2)] for b in range(c.NBUF)]
+        self.vA_dma = V.get()
+        self.v_tmp = [V.get(), V.get()]
+        self.v_out_m = [V.get() for m in range(c.MFR)]
+        self.v_bits_m = [V.get() for m in range(c.MFR)] if (c.stats == 2 or c.add == 2) else None
+        self.v_chan = V.get()
+        self.v_st_m = [V.get() for m in range(c.MFR)] if c.FULL else None   # full-line stores: (m*16 + (r & 7)) rows, chunk (r >> 3)*64 + kg*16
+        # per-item operand registers
+        self.it = []
+        for i in range(c.NI):
+            d = {}
+            if c.stats == 2:
+                d["y"] = V.get(4, 4)
+            if c.add:
+                d["ad"] = V.get(4, 4)
+            if c.stats == 2:
+                d["yb"] = V.get()
+            if c.add == 2:
+                d["ab"] = V.get()
+            self.it.append(d)
+        npair = c.NT // 2
+        self.s1 = [V.get(8, 4) for p in range(npair)] if c.stats else None
+        self.s2 = [V.get(8, 4) for p in range(npair)] if c.stats else None
+        self.F = [V.get(4 * c.MFR, 4) for s in range(2)]
+        self.tv = V.get(8, 2)
+        self.dsets = [V.get(4, 4) for _ in range(4)]
+        self.v_xc = V.get(4, 4) if c.FULL else None   # exchange temporary
+        self.xr = V.get(8, 2)
+        self.yv = V.get(2, 2)
+        self.v_m = V.get()
+        self.nvgpr = V.n
+        self.accum_offset = (self.nvgpr + 7) // 8 * 8
+        self.aB = 0
+        self.aACC = c.NT * c.KS * 4
+        self.nagpr = self.aACC + c.MFR * c.NT * 4
+        assert self.nagpr <= 256 and self.accum_offset + self.nagpr <= 512
+        self.tmp_i = 0
+        self.prologue()
+        self.mainloop()
+        self.finale()
+        return self.finish()
+
+    def acc(self, m, n):
+        return self.aACC + (m * self.c.NT + n) * 4
+
+    def breg(self, n, ks):
+        return self.aB + (n * self.c.KS + ks) * 4
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def desc_from(self, srd, ptr_lo, off_lo, off_hi, total, comment=None):
+        """srd = raw buffer at ptr + (off_hi:off_lo) with num_records = total - off_lo (total, off: SGPRs; total < 2^32 bytes)"""
+        e = self.e
+        e("s_add_u32 %s, %s, %s" % (R("s", srd), R("s", ptr_lo), R("s", off_lo)), comment)
+        e("s_addc_u32 %s, %s, %s" % (R("s", srd + 1), R("s", ptr_lo + 1), R("s", off_hi) if off_hi is not None else "0"))
+        e("s_and_b32 %s, %s, 0xffff" % (R("s", srd + 1), R("s", srd + 1)))
+        e("s_sub_u32 %s, %s, %s" % (R("s", srd + 2), R("s", total), R("s", off_lo)))
+        e("s_mov_b32 %s, 0x00020000" % R("s", srd + 3))
+
+    def desc_adv(self, srd, inc):
+        return ["s_add_u32 %s, %s, %s" % (R("s", srd), R("s", srd), R("s", inc)),
+                "s_addc_u32 %s, %s, 0" % (R("s", srd + 1), R("s", srd + 1)),
+                "s_sub_u32 %s, %s, %s" % (R("s", srd + 2), R("s", srd + 2), R("s", inc))]
+
+    def a_piece(self, j, buf):
+        """A piece j of this wave: 8-pixel block 4 * (j % (RB / 4)) + w of plane j // (RB / 4), RB = blocks per plane"""
+        c = self.c
+        rb4 = c.TP // 8 // 4
+        blk4, plane = j % rb4, j // rb4
+        vt = self.v_tmp[self.tmp_i & 1]
+        self.tmp_i += 1
+        return ["s_add_u32 m0, %s, %d" % (R("s", self.s_ldsA), buf * c.ABUF + plane * c.PLANE + blk4 * 4096),
+                "v_add_u32 %s, %d, %s" % (R("v", vt), blk4 * 32 * c.K * 2 + plane * 128, R("v", self.vA_dma)),
+                "buffer_load_dwordx4 %s, %s, 0 offen%s lds" % (R("v", vt), R("s", self.srdA, 4), " nt" if c.nt & 4 else "")]
+
+    def item_loads(self, i):
+        """the epilogue operand loads of item i = (fragment m, pair p) from the PREFETCH descriptors"""
+        c = self.c
+        if c.probe & 4:
+            return []
+        m, p = divmod(i, c.NT // 2)
+        d = self.it[i]
+        out = []
+        nt = " nt" if c.nt & 1 else ""
+        nomask, nobig = c.probe & 16, c.probe & 32   # (probes: the mask-byte loads / the 16-byte loads replaced by a scalar no-op each: same counts)
+        if c.stats == 2:
+            out.append("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["y"], 4), R("v", self.v_out_m[m]), R("s", self.srdY, 4), p * 64, nt) if not nobig else "s_nop 0")
+            out.append("buffer_load_ubyte %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["yb"]), R("v", self.v_bits_m[m]), R("s", self.srdM, 4), p * 4, nt) if not nomask else "s_nop 0")
+        if c.add:
+            out.append("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["ad"], 4), R("v", self.v_out_m[m]), R("s", self.srdAD, 4), p * 64, nt) if not nobig else "s_nop 0")
+        if c.add == 2:
+            out.append("buffer_load_ubyte %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["ab"]), R("v", self.v_bits_m[m]), R("s", self.srdAB, 4), p * 4, nt) if not nomask else "s_nop 0")
+        return out
+
+    def frag_reads(self, fset, ks, buf):
+        c = self.c
+        plane, kk = ks // 2, ks % 2
+        return ["ds_read_b128 %s, %s offset:%d" % (R("v", self.F[fset] + 4 * m, 4), R("v", self.vA_rd[buf][kk]), plane * c.PLANE + m * 2048) for m in range(c.MFR)]
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def prologue(self):
+        c, e = self.c, self.e
+        ka, kp = self.s_ka, self.s_kp
+        t0, t1, t2, t3 = self.s_t0, self.s_t1, self.s_t2, self.s_t3
+        v = [self.F[1] + i for i in range(12)]
+        self.comment("---- prologue: kernel arguments, this workgroup's column tile and pixel run, descriptors, the weight slab into AGPRs")
+        e("s_load_dwordx16 %s, s[0:1], 0x0" % R("s", ka, 16))
+        e("s_load_dwordx4 %s, s[0:1], 0x40" % R("s", ka + 16, 4))
+        e("s_load_dwordx8 %s, s[0:1], 0x50" % R("s", kp, 8), "npix, ncols, tpg, ngroups, ntiles, lognct")
+        lane, r, kg = v[0], v[1], v[2]
+        e("v_lshrrev_b32 %s, 6, v0" % R("v", v[3]))
+        e("v_and_b32 %s, 63, v0" % R("v", lane))
+        e("v_readfirstlane_b32 %s, %s" % (R("s", self.s_w), R("v", v[3])))
+        e("v_and_b32 %s, 15, v0" % R("v", r))
+        e("v_bfe_u32 %s, v0, 4, 2" % R("v", kg))
+        e("s_waitcnt lgkmcnt(0)")
+        M, N, TPG, G, T, LG = kp, kp + 1, kp + 2, kp + 3, kp + 4, kp + 5
+        # group g (pixel run) and column tile ct: the NCT workgroups of a group are consecutive multiples of 8 apart -> same XCD
+        e("s_and_b32 %s, %s, 7" % (R("s", t0), R("s", self.s_wg)), "XCD")
+        e("s_lshr_b32 %s, %s, 3" % (R("s", t1), R("s", self.s_wg)))
+        e("s_lshl_b32 %s, 1, %s" % (R("s", t2), R("s", LG)))
+        e("s_sub_u32 %s, %s, 1" % (R("s", t2), R("s", t2)))
+        e("s_and_b32 %s, %s, %s" % (R("s", self.s_ct), R("s", t1), R("s", t2)), "column tile")
+        e("s_lshr_b32 %s, %s, %s" % (R("s", t1), R("s", t1), R("s", LG)))
+        e("s_lshl_b32 %s, %s, 3" % (R("s", t1), R("s", t1)))
+        e("s_add_u32 %s, %s, %s" % (R("s", self.s_g), R("s", t1), R("s", t0)), "group")
+        e("s_cmp_ge_u32 %s, %s" % (R("s", self.s_g), R("s", G)))
+        lab_run = self.newlabel("run")
+        e("s_cbranch_scc0 %s" % lab_run)
+        e("s_endpgm")
+        self.label(lab_run)
+        # tiles [g*tpg, min(g*tpg + tpg, T))
+        e("s_mul_i32 %s, %s, %s" % (R("s", t0), R("s", self.s_g), R("s", TPG)), "first tile")
+        e("s_add_u32 %s, %s, %s" % (R("s", t1), R("s", t0), R("s", TPG)))
+        e("s_min_u32 %s, %s, %s" % (R("s", t1), R("s", t1), R("s", T)))
+        e("s_sub_u32 %s, %s, %s" % (R("s", self.s_cnt), R("s", t1), R("s", t0)), "tiles of this workgroup (>= 1)")
+        e("s_sub_u32 %s, %s, 1" % (R("s", self.s_pf), R("s", self.s_cnt)), "prefetch advances left")
+        self.s_first = S_first = self.S.get()
+        e("s_mov_b32 %s, %s" % (R("s", S_first), R("s", t0)))
+        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_tout), R("s", N), c.TP * 2), "bytes of a tile of an output-shaped tensor")
+        e("s_lshr_b32 %s, %s, 4" % (R("s", self.s_tbits), R("s", self.s_tout)))
+        e("s_lshl_b32 %s, %s, 2" % (R("s", self.s_n4), R("s", N)))
+        e("s_lshl_b32 %s, %s, 10" % (R("s", self.s_ldsA), R("s", self.s_w)), "this wave's 8-pixel block of every 32 pixels")
+        # ---- A: base = in + first*TP*K*2 ; records = npix*K*2 - that
+        tin = c.TP * c.K * 2
+        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", S_first), tin))
+        e("s_mul_hi_u32 %s, %s, %d" % (R("s", t1), R("s", S_first), tin))
+        e("s_mul_i32 %s, %s, %d" % (R("s", t2), R("s", M), c.K * 2))
+        self.desc_from(self.srdA, ka + 0, t0, t1, t2, "A: this run's pixels")
+        # ---- B: this wave's NT*16 weight rows
+        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_ct), c.BN * c.K * 2))
+        e("s_mul_i32 %s, %s, %d" % (R("s", t1), R("s", self.s_w), c.NT * 16 * c.K * 2))
+        e("s_add_u32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", t1)))
+        e("s_add_u32 %s, %s, %s" % (R("s", self.srdB), R("s", ka + 2), R("s", t0)))
+        e("s_addc_u32 %s, %s, 0" % (R("s", self.srdB + 1), R("s", ka + 3)))
+        e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdB + 1), R("s", self.srdB + 1)))
+        e("s_mov_b32 %s, %d" % (R("s", self.srdB + 2), c.NT * 16 * c.K * 2))
+        e("s_mov_b32 %s, 0x00020000" % R("s", self.srdB + 3))
+        # B lane offsets: tile n = 2p + odd, MFMA row rho = lane & 15 -> channel p*32 + (rho >> 2)*8 + odd*4 + (rho & 3); k bytes kg*16
+        vb = [v[4], v[5]]
+        e("v_lshrrev_b32 %s, 2, %s" % (R("v", v[6]), R("v", r)))
+        e("v_and_b32 %s, 3, %s" % (R("v", v[7]), R("v", r)))
+        e("v_lshl_add_u32 %s, %s, 3, %s" % (R("v", v[6]), R("v", v[6]), R("v", v[7])), "(rho >> 2)*8 + (rho & 3)")
+        for odd in range(2):
+            e("v_add_u32 %s, %d, %s" % (R("v", v[7]), 4 * odd, R("v", v[6])))
+            e("v_mov_b32 %s, %d" % (R("v", v[8]), c.K * 2))
+            e("v_mul_lo_u32 %s, %s, %s" % (R("v", v[7]), R("v", v[7]), R("v", v[8])))
+            e("v_lshl_add_u32 %s, %s, 4, %s" % (R("v", vb[odd]), R("v", kg), R("v", v[7])))
+        self.comment("the weight slab: NT x KS fragments, once")
+        for n in range(c.NT):
+            p, odd = n >> 1, n & 1
+            if odd == 0:
+                e("s_mov_b32 %s, %d" % (R("s", t0), p * 32 * c.K * 2))
+            for ks in range(c.KS):
+                e("buffer_load_dwordx4 %s, %s, %s, %s offen offset:%d" % (R("a", self.breg(n, ks), 4), R("v", vb[odd]), R("s", self.srdB, 4), R("s", t0), ks * 64))
+        # ---- A DMA lane part: row-in-block = lane >> 3; logical chunk = (lane & 7) ^ ((row >> 1) & 7), row = (4j + w)*8 + (lane >> 3)
+        l3, l7, j = v[6], v[7], v[8]
+        e("v_lshrrev_b32 %s, 3, %s" % (R("v", l3), R("v", lane)))
+        e("v_and_b32 %s, 7, %s" % (R("v", l7), R("v", lane)))
+        e("v_lshrrev_b32 %s, 4, %s" % (R("v", j), R("v", lane)))
+        e("s_and_b32 %s, %s, 1" % (R("s", t0), R("s", self.s_w)))
+        e("s_lshl_b32 %s, %s, 2" % (R("s", t0), R("s", t0)), "+ 4 for the odd blocks (block = 4j + w)")
+        e("v_or_b32 %s, %s, %s" % (R("v", j), R("s", t0), R("v", j)))
+        e("v_xor_b32 %s, %s, %s" % (R("v", j), R("v", l7), R("v", j)))
+        e("v_lshlrev_b32 %s, 4, %s" % (R("v", j), R("v", j)))
+        e("v_mov_b32 %s, %d" % (R("v", v[9]), c.K * 2))
+        e("v_mad_u32_u24 %s, %s, %s, %s" % (R("v", self.vA_dma), R("v", l3), R("v", v[9]), R("v", j)))
+        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_w), 8 * c.K * 2))
+        e("v_add_u32 %s, %s, %s" % (R("v", self.vA_dma), R("s", t0), R("v", self.vA_dma)))
+        self.comment("A tile of the first tile")
+        for jj in range(c.NPW):
+            for ins in self.a_piece(jj, 0):
+                e(ins)
+        # ---- output-shaped tensors: base offset = first*tout + ct*BN*2 (64-bit), records = npix*N*2 - that
+        e("s_mul_i32 %s, %s, %s" % (R("s", t0), R("s", S_first), R("s", self.s_tout)))
+        e("s_mul_hi_u32 %s, %s, %s" % (R("s", t1), R("s", S_first), R("s", self.s_tout)))
+        e("s_mul_i32 %s, %s, %d" % (R("s", t2), R("s", self.s_ct), c.BN * 2))
+        e("s_add_u32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", t2)))
+        e("s_addc_u32 %s, %s, 0" % (R("s", t1), R("s", t1)))
+        e("s_mul_i32 %s, %s, %s" % (R("s", t2), R("s", M), R("s", N)))
+        e("s_lshl_b32 %s, %s, 1" % (R("s", t2), R("s", t2)), "bytes of an output-shaped tensor")
+        self.desc_from(self.srdO, ka + 4, t0, t1, t2, "O")
+        if c.stats == 2:
+            self.desc_from(self.srdY, ka + 8, t0, t1, t2, "y of the BN layer")
+        if c.add:
+            self.desc_from(self.srdAD, ka + 16, t0, t1, t2, "addend")
+        if c.stats == 2 or c.add == 2:
+            # mask bytes: 1/16 of the byte offsets
+            e("s_lshr_b32 %s, %s, 4" % (R("s", t0), R("s", t0)))
+            e("s_lshl_b32 %s, %s, 28" % (R("s", t3), R("s", t1)))
+            e("s_or_b32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", t3)))
+            e("s_lshr_b32 %s, %s, 4" % (R("s", t1), R("s", t1)))
+            e("s_lshr_b32 %s, %s, 4" % (R("s", t2), R("s", t2)))
+            if c.stats == 2:
+                self.desc_from(self.srdM, ka + 10, t0, t1, t2, "ReLU bits of the BN layer")
+            if c.add == 2:
+                self.desc_from(self.srdAB, ka + 18, t0, t1, t2, "ReLU bits of the addend")
+        # ---- lane offsets of the output-shaped tensors: (m*16 + r)*N*2 + (w*NT*16 + kg*8)*2
+        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_w), c.NT * 16 * 2))
+        e("v_lshl_add_u32 %s, %s, 4, %s" % (R("v", v[6]), R("v", kg), R("s", t0)))
+        e("s_lshl_b32 %s, %s, 1" % (R("s", t1), R("s", N)))
+        for m in range(c.MFR):
+            e("v_add_u32 %s, %d, %s" % (R("v", v[7]), 16 * m, R("v", r)))
+            e("v_mul_lo_u32 %s, %s, %s" % (R("v", v[7]), R("v", v[7]), R("s", t1)))
+            e("v_add_u32 %s, %s, %s" % (R("v", self.v_out_m[m]), R("v", v[7]), R("v", v[6])))
+            if self.v_bits_m:
+                e("v_lshrrev_b32 %s, 4, %s" % (R("v", self.v_bits_m[m]), R("v", self.v_out_m[m])), "mask bytes: one per 16-byte vector")
+        e("v_lshlrev_b32 %s, 5, %s" % (R("v", self.v_chan), R("v", kg)), "this lane's 8 floats of a per-channel row")
+        if c.FULL:
+            # full-line stores: after the lane exchange of the epilogue a lane holds, of pixel m*16 + (r & 7) [store 1] and of pixel
+            # m*16 + 8 + (r & 7) [store 2], the 16 bytes at w*128 + (r >> 3)*64 + kg*16: 8 lanes cover a pixel's 128 bytes
+            e("s_lshl_b32 %s, %s, 4" % (R("s", self.s_8rows), R("s", N)), "8 pixel rows of an output-shaped tensor")
+            e("s_mov_b32 %s, 0x00ff00ff" % R("s", self.s_lo8))
+            e("s_mov_b32 %s, 0x00ff00ff" % R("s", self.s_lo8 + 1))
+            e("v_lshrrev_b32 %s, 3, %s" % (R("v", v[8]), R("v", r)))
+            e("v_lshlrev_b32 %s, 6, %s" % (R("v", v[8]), R("v", v[8])))
+            e("v_add_u32 %s, %s, %s" % (R("v", v[8]), R("v", v[8]), R("v", v[6])), "w*128 + kg*16 + (r >> 3)*64")
+            e("v_and_b32 %s, 7, %s" % (R("v", v[9]), R("v", r)))
+            for m in range(c.MFR):
+                e("v_add_u32 %s, %d, %s" % (R("v", v[7]), 16 * m, R("v", v[9])))
+                e("v_mul_lo_u32 %s, %s, %s" % (R("v", v[7]), R("v", v[7]), R("s", t1)))
+                e("v_add_u32 %s, %s, %s" % (R("v", self.v_st_m[m]), R("v", v[7]), R("v", v[8])))
+        # ---- first tile's epilogue operands, then the prefetch descriptors move one tile ahead
+        for i in range(c.NI):
+            for ins in self.item_loads(i):
+                e(ins)
+        for ins in self.prefetch_advance():
+            e(ins)
+        # ---- A read bases: row r of a fragment, chunk (kg + 4kk) ^ ((r >> 1) & 7)
+        sw, cc = v[6], v[7]
+        e("v_bfe_u32 %s, %s, 1, 3" % (R("v", sw), R("v", r)))
+        e("v_xor_b32 %s, %s, %s" % (R("v", cc), R("v", kg), R("v", sw)))
+        e("v_lshlrev_b32 %s, 4, %s" % (R("v", cc), R("v", cc)))
+        e("v_lshl_add_u32 %s, %s, 7, %s" % (R("v", cc), R("v", r), R("v", cc)))
+        for b in range(c.NBUF):
+            e("v_add_u32 %s, %d, %s" % (R("v", self.vA_rd[b][0]), b * c.ABUF, R("v", cc)))
+            e("v_xor_b32 %s, 64, %s" % (R("v", self.vA_rd[b][1]), R("v", self.vA_rd[b][0])))
+        if c.stats:
+            for p in range(c.NT // 2):
+                for i in range(8):
+                    e("v_mov_b32 %s, 0" % R("v", self.s1[p] + i))
+                    e("v_mov_b32 %s, 0" % R("v", self.s2[p] + i))
+        e("s_waitcnt vmcnt(0)", "weights, first tile, first operands")
+
+    def prefetch_advance(self):
+        """the prefetch descriptors (A, y, addend, masks) move to the next tile while one is left, else stay (re-reads, never used)"""
+        c = self.c
+        out = ["s_cmp_gt_u32 %s, 0" % R("s", self.s_pf),
+               "s_cselect_b32 %s, %d, 0" % (R("s", self.s_ia), c.TP * c.K * 2),
+               "s_cselect_b32 %s, %s, 0" % (R("s", self.s_io), R("s", self.s_tout)),
+               "s_cselect_b32 %s, %s, 0" % (R("s", self.s_ib), R("s", self.s_tbits)),
+               "s_cselect_b32 %s, 1, 0" % R("s", self.s_t3),
+               "s_sub_u32 %s, %s, %s" % (R("s", self.s_pf), R("s", self.s_pf), R("s", self.s_t3))]
+        out += self.desc_adv(self.srdA, self.s_ia)
+        if c.stats == 2:
+            out += self.desc_adv(self.srdY, self.s_io) + self.desc_adv(self.srdM, self.s_ib)
+        if c.add:
+            out += self.desc_adv(self.srdAD, self.s_io)
+        if c.add == 2:
+            out += self.desc_adv(self.srdAB, self.s_ib)
+        return out
+
+    # -----------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def spread(mf, others, first=1):
+        """MFMA list with the instruction groups `others` placed evenly between them"""
+        n, k = len(mf), len(others)
+        slots = {}
+        if k:
+            span = max(1, n - first - 1)
+            for j, grp in enumerate(others):
+                slots.setdefault(min(n - 1, first + (j * span) // k), []).extend(grp)
+        out = []
+        for i, m in enumerate(mf):
+            out.append(m)
+            out.extend(slots.get(i, []))
+        return out
+
+    def mainloop(self):
+        c, e = self.c, self.e
+        self.comment("---- main loop: one 64-pixel tile per trip (unrolled over the %d A buffers)" % c.NBUF)
+        top, done = self.newlabel("loop"), self.newlabel("done")
+        npair = c.NT // 2
+        # younger than an item's (a fragment's) loads when it waits for them: the stores + refills of the other items (fragments) of a
+        # tile and the A pieces of the next tile
+        CW = ((c.L + 1) * (c.NI - 1) if not c.FULL else 2 * (c.L + 1) * (c.MFR - 1)) + c.NPW
+        self.label(top)
+        for b in range(c.NBUF):
+            nb = (b + 1) % c.NBUF
+            self.comment("tile in A buffer %d" % b)
+            e("s_waitcnt vmcnt(%d)" % (c.NI * (c.L + 1)), "this tile's A pieces have landed (younger: the last tile's stores and refills)")
+            e("s_barrier")
+            for jj in range(c.NPW):
+                for ins in self.a_piece(jj, nb):
+                    e(ins)
+            # ---- MFMA phase
+            for ins in self.frag_reads(0, 0, b):
+                e(ins)
+            for ks in range(c.KS):
+                e("s_waitcnt lgkmcnt(0)")
+                fs = self.F[ks & 1]
+                mf = []
+                for n in range(c.NT):
+                    for m in range(c.MFR):
+                        a = self.acc(m, n)
+                        csrc = "0" if ks == 0 else R("a", a, 4)
+                        mf.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (R("a", a, 4), R("a", self.breg(n, ks), 4), R("v", fs + 4 * m, 4), csrc))
+                if c.probe & 1:
+                    mf = mf[:c.MFR] if ks == 0 else []
+                nxt = [[r] for r in self.frag_reads((ks + 1) & 1, ks + 1, b)] if ks + 1 < c.KS else []
+                for ins in (self.spread(mf, nxt) if mf else [x for g in nxt for x in g]):
+                    e(ins)
+            # ---- epilogue items (the accumulators are read by VALU instructions: the matrix pipe must have retired the last MFMAs)
+            e("s_nop 15")
+            e("s_nop 7")
+            if c.FULL:
+                for m in range(c.MFR):
+                    self.unit(m, CW)
+            else:
+                for i in range(c.NI):
+                    m, p = divmod(i, npair)
+                    self.item(i, m, p, CW)
+            # ---- next tile
+            for ins in self.desc_adv(self.srdO, self.s_tout):
+                e(ins)
+            for ins in self.prefetch_advance():
+                e(ins)
+            e("s_sub_u32 %s, %s, 1" % (R("s", self.s_cnt), R("s", self.s_cnt)))
+            e("s_cmp_eq_u32 %s, 0" % R("s", self.s_cnt))
+            if b < c.NBUF - 1:
+                e("s_cbranch_scc1 %s" % done)
+            else:
+                e("s_cbranch_scc0 %s" % top)
+        self.label(done)
+
+    def pair_math(self, i, m, p, ds):
+        """accumulators of (fragment m, tile pair p) -> + addend -> bf16 in ds; statistics of the pair"""
+        c, e = self.c, self.e
+        d = self.it[i]
+        tv, xr, yv, vm = self.tv, self.xr, self.yv, self.v_m
+        for k in range(4):
+            e("v_accvgpr_read_b32 %s, a%d" % (R("v", tv + k), self.acc(m, 2 * p) + k))
+            e("v_accvgpr_read_b32 %s, a%d" % (R("v", tv + 4 + k), self.acc(m, 2 * p + 1) + k))
+        if c.add and not (c.probe & 2):
+            for k in range(8):
+                src = R("v", d["ad"] + k // 2)
+                if k & 1:
+                    e("v_and_b32 %s, 0xffff0000, %s" % (R("v", xr + k), src))
+                else:
+                    e("v_lshlrev_b32 %s, 16, %s" % (R("v", xr + k), src))
+                if c.add == 2:
+                    e("v_bfe_i32 %s, %s, %d, 1" % (R("v", vm), R("v", d["ab"]), k), "0 / -1: ReLU bit of addend element %d" % k)
+                    e("v_and_b32 %s, %s, %s" % (R("v", xr + k), R("v", xr + k), R("v", vm)))
+                e("v_add_f32 %s, %s, %s" % (R("v", tv + k), R("v", tv + k), R("v", xr + k)))
+        for k in range(4):
+            e("v_cvt_pk_bf16_f32 %s, %s, %s" % (R("v", ds + k), R("v", tv + 2 * k), R("v", tv + 2 * k + 1)))
+        if c.stats and not (c.probe & 2):
+            s1, s2 = self.s1[p], self.s2[p]
+            for k in range(4):
+                e("v_lshlrev_b32 %s, 16, %s" % (R("v", xr + 2 * k), R("v", ds + k)))
+                e("v_and_b32 %s, 0xffff0000, %s" % (R("v", xr + 2 * k + 1), R("v", ds + k)))
+            if c.stats == 1:
+                for k in range(8):
+                    e("v_add_f32 %s, %s, %s" % (R("v", s1 + k), R("v", s1 + k), R("v", xr + k)))
+                    e("v_fma_f32 %s, %s, %s, %s" % (R("v", s2 + k), R("v", xr + k), R("v", xr + k), R("v", s2 + k)))
+            else:
+                for k in range(8):
+                    e("v_bfe_i32 %s, %s, %d, 1" % (R("v", vm), R("v", d["yb"]), k), "0 / -1: ReLU bit of element %d" % k)
+                    e("v_and_b32 %s, %s, %s" % (R("v", xr + k), R("v", xr + k), R("v", vm)), "dz")
+                    if k & 1:
+                        e("v_and_b32 %s, 0xffff0000, %s" % (R("v", yv + 1), R("v", d["y"] + k // 2)))
+                    else:
+                        e("v_lshlrev_b32 %s, 16, %s" % (R("v", yv), R("v", d["y"] + k // 2)))
+                    e("v_add_f32 %s, %s, %s" % (R("v", s1 + k), R("v", s1 + k), R("v", xr + k)))
+                    e("v_fma_f32 %s, %s, %s, %s" % (R("v", s2 + k), R("v", xr + k), R("v", yv + (k & 1)), R("v", s2 + k)), "sum dz*y")
+
+    def unit(self, m, CW):
+        """fragment m, both tile pairs: a lane ends with the two 16-byte chunks (pair 0, pair 1) of pixel r; lanes r and r + 8 of a row
+        swap one chunk each, so that store 1 writes pixels 0 .. 7 and store 2 pixels 8 .. 15 of the fragment as whole 128-byte lines
+        (tools/micro/seg_read.hip: stores of 64-byte half lines run at 0.7 of the rate of whole lines)"""
+        c, e = self.c, self.e
+        i0, i1 = 2 * m, 2 * m + 1
+        A, B, C = self.dsets[(2 * m) % 4], self.dsets[(2 * m + 1) % 4], self.v_xc
+        self.comment("fragment %d" % m)
+        if c.L and not (c.probe & 4):
+            e("s_waitcnt vmcnt(%d)" % CW)
+        self.pair_math(i0, m, 0, A)
+        self.pair_math(i1, m, 1, B)
+        e("s_nop 1")
+        for k in range(4):   # C = the partner lane's pair-0 chunk
+            e("v_mov_b32_dpp %s, %s row_ror:8 row_mask:0xf bank_mask:0xf" % (R("v", C + k), R("v", A + k)))
+        for k in range(4):   # lanes 8 .. 15: the partner's pair-1 chunk (pixel r - 8) -> store 1 holds pixels 0 .. 7
+            e("v_mov_b32_dpp %s, %s row_ror:8 row_mask:0xf bank_mask:0xc" % (R("v", A + k), R("v", B + k)))
+        for k in range(4):   # lanes 0 .. 7: the partner's pair-0 chunk (pixel r + 8) -> store 2 holds pixels 8 .. 15
+            e("v_cndmask_b32 %s, %s, %s, %s" % (R("v", B + k), R("v", B + k), R("v", C + k), R("s", self.s_lo8, 2)))
+        if not (c.probe & 8):
+            vt = self.v_tmp[0]
+            e("v_add_u32 %s, %s, %s" % (R("v", vt), R("s", self.s_8rows), R("v", self.v_st_m[m])))
+            nt = " nt" if c.nt & 2 else ""
+            e("buffer_store_dwordx4 %s, %s, %s, 0 offen%s" % (R("v", A, 4), R("v", self.v_st_m[m]), R("s", self.srdO, 4), nt))
+            e("buffer_store_dwordx4 %s, %s, %s, 0 offen%s" % (R("v", B, 4), R("v", vt), R("s", self.srdO, 4), nt))
+        for ins in self.item_loads(i0) + self.item_loads(i1):   # rolling refill: the same vectors of the NEXT tile
+            e(ins)
+
+    def item(self, i, m, p, CW):
+        c, e = self.c, self.e
+        d = self.it[i]
+        tv, xr, yv, vm = self.tv, self.xr, self.yv, self.v_m
+        ds = self.dsets[i % 4]
+        self.comment("item %d: fragment %d, tile pair %d" % (i, m, p))
+        if c.L and not (c.probe & 4):
+            e("s_waitcnt vmcnt(%d)" % CW)
+        for k in range(4):
+            e("v_accvgpr_read_b32 %s, a%d" % (R("v", tv + k), self.acc(m, 2 * p) + k))
+            e("v_accvgpr_read_b32 %s, a%d" % (R("v", tv + 4 + k), self.acc(m, 2 * p + 1) + k))
+        if c.add and not (c.probe & 2):
+            for k in range(8):
+                src = R("v", d["ad"] + k // 2)
+                if k & 1:
+                    e("v_and_b32 %s, 0xffff0000, %s" % (R("v", xr + k), src))
+                else:
+                    e("v_lshlrev_b32 %s, 16, %s" % (R("v", xr + k), src))
+                if c.add == 2:
+                    e("v_bfe_i32 %s, %s, %d, 1" % (R("v", vm), R("v", d["ab"]), k), "0 / -1: ReLU bit of addend element %d" % k)
+                    e("v_and_b32 %s, %s, %s" % (R("v", xr + k), R("v", xr + k), R("v", vm)))
+                e("v_add_f32 %s, %s, %s" % (R("v", tv + k), R("v", tv + k), R("v", xr + k)))
+        for k in range(4):
+            e("v_cvt_pk_bf16_f32 %s, %s, %s" % (R("v", ds + k), R("v", tv + 2 * k), R("v", tv + 2 * k + 1)))
+        if not (c.probe & 8):
+            e("buffer_store_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", ds, 4), R("v", self.v_out_m[m]), R("s", self.srdO, 4), p * 64))
+        if c.stats and not (c.probe & 2):
+            s1, s2 = self.s1[p], self.s2[p]
+            for k in range(4):
+                e("v_lshlrev_b32 %s, 16, %s" % (R("v", xr + 2 * k), R("v", ds + k)))
+                e("v_and_b32 %s, 0xffff0000, %s" % (R("v", xr + 2 * k + 1), R("v", ds + k)))
+            if c.stats == 1:
+                for k in range(8):
+                    e("v_add_f32 %s, %s, %s" % (R("v", s1 + k), R("v", s1 + k), R("v", xr + k)))
+                    e("v_fma_f32 %s, %s, %s, %s" % (R("v", s2 + k), R("v", xr + k), R("v", xr + k), R("v", s2 + k)))
+            else:
+                for k in range(8):
+                    e("v_bfe_i32 %s, %s, %d, 1" % (R("v", vm), R("v", d["yb"]), k), "0 / -1: ReLU bit of element %d" % k)
+                    e("v_and_b32 %s, %s, %s" % (R("v", xr + k), R("v", xr + k), R("v", vm)), "dz")
+                    if k & 1:
+                        e("v_and_b32 %s, 0xffff0000, %s" % (R("v", yv + 1), R("v", d["y"] + k // 2)))
+                    else:
+                        e("v_lshlrev_b32 %s, 16, %s" % (R("v", yv), R("v", d["y"] + k // 2)))
+                    e("v_add_f32 %s, %s, %s" % (R("v", s1 + k), R("v", s1 + k), R("v", xr + k)))
+                    e("v_fma_f32 %s, %s, %s, %s" % (R("v", s2 + k), R("v", xr + k), R("v", yv + (k & 1)), R("v", s2 + k)), "sum dz*y")
+        for ins in self.item_loads(i):   # rolling refill: the same vectors of the NEXT tile
+            e(ins)
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def finale(self):
+        c, e = self.c, self.e
+        ka = self.s_ka
+        t0, t1 = self.s_t0, self.s_t1
+        npair = c.NT // 2
+        self.comment("---- end of the run: statistics row of this workgroup")
+        e("s_waitcnt vmcnt(0)")
+        if not c.stats:
+            e("s_endpgm")
+            return
+        # row g: [2][N] floats; this wave's channels start at ct*BN + w*NT*16
+        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_ct), c.BN * 4))
+        e("s_mul_i32 %s, %s, %d" % (R("s", t1), R("s", self.s_w), c.NT * 16 * 4))
+        e("s_add_u32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", t1)), "byte offset of this wave's channels in a per-channel float row")
+        mu = isd = None
+        if c.stats == 2:
+            # mean / invstd of this lane's 8 channels per pair (the fragment registers are free)
+            for name, k0 in (("mu", 12), ("is", 14)):
+                srd = self.srdY if name == "mu" else self.srdM
+                e("s_add_u32 %s, %s, %s" % (R("s", srd), R("s", ka + k0), R("s", t0)))
+                e("s_addc_u32 %s, %s, 0" % (R("s", srd + 1), R("s", ka + k0 + 1)))
+                e("s_and_b32 %s, %s, 0xffff" % (R("s", srd + 1), R("s", srd + 1)))
+                e("s_mov_b32 %s, %d" % (R("s", srd + 2), c.NT * 16 * 4))
+                e("s_mov_b32 %s, 0x00020000" % R("s", srd + 3))
+            mu = [self.F[0] + 8 * p for p in range(npair)]
+            isd = [self.F[1] + 8 * p for p in range(npair)]
+            assert 8 * npair <= 4 * c.MFR
+            for p in range(npair):
+                for h in range(2):
+                    e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", mu[p] + 4 * h, 4), R("v", self.v_chan), R("s", self.srdY, 4), p * 128 + 16 * h))
+                    e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", isd[p] + 4 * h, 4), R("v", self.v_chan), R("s", self.srdM, 4), p * 128 + 16 * h))
+        # statistics row descriptor: stat + g*2*N*4 + channel offset
+        e("s_mul_i32 %s, %s, %s" % (R("s", t1), R("s", self.s_g), R("s", self.s_n4)))
+        e("s_lshl_b32 %s, %s, 1" % (R("s", t1), R("s", t1)))
+        e("s_add_u32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", t1)))
+        e("s_add_u32 %s, %s, %s" % (R("s", self.srdX), R("s", ka + 6), R("s", t0)))
+        e("s_addc_u32 %s, %s, 0" % (R("s", self.srdX + 1), R("s", ka + 7)))
+        e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdX + 1), R("s", self.srdX + 1)))
+        e("s_mov_b32 %s, 0x7fffffff" % R("s", self.srdX + 2))
+        e("s_mov_b32 %s, 0x00020000" % R("s", self.srdX + 3))
+        for sh in (1, 2, 4, 8):
+            for p in range(npair):
+                for arr in (self.s1[p], self.s2[p]):
+                    for k in range(8):
+                        rr = R("v", arr + k)
+                        e("v_add_f32_dpp %s, %s, %s row_shr:%d row_mask:0xf bank_mask:0xf bound_ctrl:1" % (rr, rr, rr, sh))
+        if c.stats == 2:
+            e("s_waitcnt vmcnt(0)")
+            tv = self.tv
+            for p in range(npair):
+                # sum dz*xhat = invstd * (sum dz*y - mean * sum dz)
+                for k in range(8):
+                    e("v_mul_f32 %s, %s, %s" % (R("v", tv + k), R("v", mu[p] + k), R("v", self.s1[p] + k)))
+                for k in range(8):
+                    e("v_sub_f32 %s, %s, %s" % (R("v", self.s2[p] + k), R("v", self.s2[p] + k), R("v", tv + k)))
+                for k in range(8):
+                    e("v_mul_f32 %s, %s, %s" % (R("v", self.s2[p] + k), R("v", isd[p] + k), R("v", self.s2[p] + k)))
+        e("s_mov_b32 exec_lo, 0x80008000", "lanes 15 of every row hold the row sums")
+        e("s_mov_b32 exec_hi, 0x80008000")
+        for p in range(npair):
+            for h in range(2):
+                e("buffer_store_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", self.s1[p] + 4 * h, 4), R("v", self.v_chan), R("s", self.srdX, 4), p * 128 + 16 * h))
+                e("buffer_store_dwordx4 %s, %s, %s, %s offen offset:%d" % (R("v", self.s2[p] + 4 * h, 4), R("v", self.v_chan), R("s", self.srdX, 4), R("s", self.s_n4), p * 128 + 16 * h))
+        e("s_waitcnt vmcnt(0)")
+        e("s_endpgm")
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def finish(self):
+        c = self.c
+        name = c.name
+        lds = c.LDS
+        total_v = self.accum_offset + self.nagpr
+        hdr = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.amdhsa_code_object_version 6", "\t.text", "\t.protected\t%s" % name, "\t.globl\t%s" % name,
+               "\t.p2align\t8", "\t.type\t%s,@function" % name, "%s:" % name]
+        tail = ["\t.section\t.rodata,\"a\",@progbits", "\t.p2align\t6, 0x0", "\t.amdhsa_kernel %s" % name]
+        kd = dict(group_segment_fixed_size=lds, private_segment_fixed_size=0, kernarg_size=self.KA["size"],
+                  user_sgpr_count=2, user_sgpr_dispatch_ptr=0, user_sgpr_queue_ptr=0, user_sgpr_kernarg_segment_ptr=1,
+                  user_sgpr_dispatch_id=0, user_sgpr_kernarg_preload_length=0, user_sgpr_kernarg_preload_offset=0,
+                  user_sgpr_private_segment_size=0, uses_dynamic_stack=0, enable_private_segment=0,
+                  system_sgpr_workgroup_id_x=1, system_sgpr_workgroup_id_y=0, system_sgpr_workgroup_id_z=0,
+                  system_sgpr_workgroup_info=0, system_vgpr_workitem_id=0, next_free_vgpr=total_v,
+                  next_free_sgpr=self.S.n, accum_offset=self.accum_offset, reserve_vcc=1, float_round_mode_32=0,
+                  float_round_mode_16_64=0, float_denorm_mode_32=3, float_denorm_mode_16_64=3, dx10_clamp=1, ieee_mode=1,
+                  fp16_overflow=0, tg_split=0)
+        for k, v in kd.items():
+            tail.append("\t\t.amdhsa_%s %d" % (k, v))
+        tail += ["\t.end_amdhsa_kernel", "\t.text", "\t.amdgpu_metadata", "---", "amdhsa.kernels:", "  - .agpr_count:     %d" % self.nagpr, "    .args:"]
+        off = 0
+        for i in range(10):
+            tail.append("      - .address_space:  global\n        .offset:         %d\n        .size:           8\n        .value_kind:     global_buffer" % off)
+            off += 8
+        for i in range(6):
+            tail.append("      - .offset:         %d\n        .size:           4\n        .value_kind:     by_value" % off)
+            off += 4
+        tail.append("      - .offset:         %d\n        .size:           %d\n        .value_kind:     by_value" % (off, self.KA["size"] - off))
+        tail += ["    .group_segment_fixed_size: %d" % lds, "    .kernarg_segment_align: 8", "    .kernarg_segment_size: %d" % self.KA["size"],
+                 "    .max_flat_workgroup_size: 256", "    .name:           %s" % name, "    .private_segment_fixed_size: 0",
+                 "    .sgpr_count:     %d" % (self.S.n + 6), "    .sgpr_spill_count: 0", "    .symbol:         %s.kd" % name,
+                 "    .uniform_work_group_size: 1", "    .uses_dynamic_stack: false", "    .vgpr_count:     %d" % total_v, "    .vgpr_spill_count: 0",
+                 "    .wavefront_size: 64", "amdhsa.target:   amdgcn-amd-amdhsa--gfx950", "amdhsa.version:\n  - 1\n  - 2", "...", "\t.end_amdgpu_metadata"]
+        body = self.out + ["\t.p2align 8", ".Lend_%s:" % name, "\t.size\t%s, .Lend_%s-%s" % (name, name, name)]
+        self.lds_bytes = lds
+        return "\n".join(hdr + body + tail) + "\n"
+
+
+def _variants():
+    v = {}
+    for (K, BN) in ((64, 256), (128, 256), (256, 256), (512, 128)):
+        for (st, add) in ((0, 0), (1, 0), (2, 0), (2, 1), (2, 2), (0, 1), (0, 2)):
+            name = "po_k%d_b%d_s%d_a%d" % (K, BN, st, add)
+            v[name] = PoCfg(name, K=K, BN=BN, stats=st, add=add)
+    return v
+
+
+VARIANTS = _variants()
+
+
+def generate(base, **over):
+    c = VARIANTS[base]
+    if over:
+        c = PoCfg(**{**c.__dict__, **over})
+    g = Gen(c)
+    return c, g, g.gen()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--set", action="append", default=[], help="tuning: override a PoCfg field (key=int), with --suffix names the kernel")
+    ap.add_argument("--suffix", default="")
+    ap.add_argument("names", nargs="*")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    over = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.set}
+    for name in (a.names or VARIANTS):
+        if a.suffix:
+            over["name"] = name + a.suffix
+        c, g, text = generate(name, **over)
+        name = c.name
+        with open(os.path.join(a.out, name + ".s"), "w") as f:
+            f.write(text)
+        print("%s: %d vgpr + %d agpr, %d sgpr, lds %d, %d lines" % (name, g.accum_offset, g.nagpr, g.S.n, g.lds_bytes, text.count("\n")))
+
+
+if __name__ == "__main__":
+    main()

@@ -138,10 +138,20 @@ struct Knobs {
   int stem_direct = 1;       // MI355_STEM_DIRECT=0: the row-pair implicit GEMM
   int stem_th = 0;           // MI355_STEM_TH: a smaller stem tile (0: the plan)
   bool stem_dbg = false;     // MI355_STEM_DBG: print the stem launch plan
+  // kernel-selection switches of the generated gfx950 kernels (A/B): "0" keeps the launches they serve on the implicit-GEMM kernels
+  int dconv = 1;             // MI355_DCONV: every generated kernel
+  int wg3 = 1;               // MI355_WG3: the generated weight-gradient kernels (asm/wg_gen.py, wg1_gen.py)
+  int pw = 1;                // MI355_PW: the persistent pointwise kernel (asm/pw_gen.py)
+  int pk = 1;                // MI355_PK: the long-reduction pointwise kernels (asm/pk_gen.py)
+  int po = 1;                // MI355_PO: the output-heavy pointwise kernels with resident weights (asm/po_gen.py); 1: the measured per-shape rule, 2: wherever a variant is legal
+  char error[160] = {0};     // a switch with a value outside its domain: every conv launch fails with MI355_E_ARG and this text
 };
 const Knobs& knobs();
 int plan_wgrad(int dtype, const WgradArgs& a);
 int wg3_plan(int dtype, const WgradArgs& a);  // 0: the launch is not served by a generated kernel
+// name of the kernel the last conv / weight-gradient launch of this thread went to (a generated kernel's symbol, or the implicit-GEMM
+// tile family): tests assert the selection rules with it (mi355_last_conv_kernel)
+void note_kernel(const char* fmt, ...);
 int launch_wg3(const WgradArgs& a, int splits, hipStream_t stream);
 int launch_wgrad(int dtype, const WgradArgs& a, int splits, hipStream_t stream);
 // dst[i] = beta*dst[i] + sum_s partial[s][i], i < n  (n multiple of 4); deterministic order

@@ -84,9 +84,27 @@ static void load_knobs() {
     k.has_igemm_big = true;
     k.igemm_big = atoi(e);
   }
-  if (const char* e = getenv("MI355_STEM_DIRECT")) k.stem_direct = e[0] == '0' ? 0 : 1;
   if (const char* e = getenv("MI355_STEM_TH")) k.stem_th = atoi(e);
   k.stem_dbg = getenv("MI355_STEM_DBG") != nullptr;
+  // switches with a closed domain: anything else is an error, not a silent default (a stale MI355_DCONV=off in a job script would
+  // otherwise cost a millisecond per step without a word)
+  auto sw = [&](const char* name, int* dst, int maxv) {
+    const char* e = getenv(name);
+    if (!e) return;
+    if (e[0] >= '0' && e[0] <= '0' + maxv && e[1] == 0) {
+      *dst = e[0] - '0';
+    } else if (!k.error[0]) {
+      snprintf(k.error, sizeof(k.error), "%s=%s: not one of 0..%d", name, e, maxv);
+    }
+  };
+  sw("MI355_STEM_DIRECT", &k.stem_direct, 1);
+  sw("MI355_DCONV", &k.dconv, 1);
+  sw("MI355_WG3", &k.wg3, 1);
+  sw("MI355_PW", &k.pw, 1);
+  sw("MI355_PK", &k.pk, 1);
+  sw("MI355_PO", &k.po, 2);
+  if (k.has_igemm_big && k.igemm_big != 0 && k.igemm_big != 1 && k.igemm_big != 3 && !k.error[0])
+    snprintf(k.error, sizeof(k.error), "MI355_IGEMM_BIG=%d: not one of 0, 1, 3", k.igemm_big);
   g_knobs = k;
 }
 
@@ -106,8 +124,22 @@ extern "C" int mi355_reload_knobs(void) {
   std::lock_guard<std::mutex> lock(g_knobs_mu);
   load_knobs();
   g_knobs_loaded.store(true, std::memory_order_release);
+  MI355_ARG(!g_knobs.error[0], "%s", g_knobs.error);
   return 0;
 }
+
+static thread_local char g_last_kernel[96] = "";
+void note_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+  va_end(ap);
+  static const bool trace = getenv("MI355_TRACE_KERNELS") != nullptr;  // debugging aid: one line per conv / weight-gradient launch
+  if (trace) fprintf(stderr, "mi355 kernel: %s\n", g_last_kernel);
+  static const bool dsync = getenv("MI355_TRACE_SYNC") != nullptr;  // debugging aid: every conv launch drains the device (exposes missing stream dependencies)
+  if (dsync) (void)hipDeviceSynchronize();
+}
+extern "C" const char* mi355_last_conv_kernel(void) { return g_last_kernel; }
 
 static int out_dim(int H, int K, int s, int p) { return (H + 2 * p - K) / s + 1; }
 
@@ -300,6 +332,31 @@ int mi355_conv2d_dgrad(int dtype, const void* dy, const void* w, void* dx, const
   if (nclass < 0) return nclass;
   a.in = dy; a.wt = ws; a.out = dx; a.addend = addend;
   return launch_igemm(dtype, a, nclass, s);
+}
+
+int mi355_conv2d_dgrad_bn(int dtype, const void* dy, const void* w, void* dx, const void* addend, const uint8_t* addend_bits, const void* bn_y,
+                          const uint8_t* bn_bits, const float* bn_mean, const float* bn_invstd, float* partial, size_t partial_bytes, int* nblk, int N,
+                          int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+  MI355_TRY(check_conv(dtype, Cin, Cout, KH, KW, stride));
+  const size_t es = dtype_size(dtype);
+  const size_t wbytes = (size_t)Cin * KH * KW * Cout * es;
+  MI355_ARG(ws && ws_bytes >= wbytes, "dgrad_bn: workspace too small (%zu < %zu)", ws_bytes, wbytes);
+  MI355_ARG(addend || !addend_bits, "dgrad_bn: addend_bits without an addend");
+  MI355_ARG(!partial || (bn_y && bn_bits && bn_mean && bn_invstd && nblk), "dgrad_bn: the BN-backward sums need bn_y, bn_bits, bn_mean, bn_invstd and nblk");
+  MI355_ARG(!partial || partial_bytes >= (size_t)768 * 2 * Cin * sizeof(float), "dgrad_bn: partial buffer needs 768 * 2 * Cin floats");
+  hipStream_t s = (hipStream_t)stream;
+  MI355_TRY(launch_transpose_any(dtype, w, ws, Cout, KH * KW, Cin, s));
+  IgemmArgs a;
+  const int nclass = build_dgrad_args(a, N, H, W, Cin, Cout, KH, KW, stride, pad);
+  if (nclass < 0) return nclass;
+  a.in = dy; a.wt = ws; a.out = dx; a.addend = addend; a.addend_bits = addend_bits;
+  if (partial) {
+    a.stat_partial = partial;
+    a.stat_rows_cap = (int)std::min<size_t>(partial_bytes / ((size_t)2 * Cin * sizeof(float)), 1u << 20);
+    a.bn_y = bn_y; a.bn_bits = bn_bits; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd;
+  }
+  if (nblk) *nblk = 0;
+  return launch_igemm(dtype, a, nclass, s, partial ? nblk : nullptr);
 }
 
 int mi355_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw, float beta, int N, int H, int W, int Cin,

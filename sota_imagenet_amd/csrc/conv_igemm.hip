@@ -801,6 +801,7 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WMW, NSTG, 0>), dim3(grid), dim3(NT), lds, stream, k);
   }
   MI355_LAUNCH_CHECK();
+  note_kernel("igemm<%s,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, NSTG);
   return 0;
 }
 
@@ -819,6 +820,8 @@ bool pw_legal(const IgemmArgs& a, int nclass);  // the persistent pointwise kern
 int launch_pw(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows);
 bool pk_legal(const IgemmArgs& a, int nclass);  // the long-reduction pointwise kernels (asm/pk_gen.py): K = 1024 / 2048 -> 256-column tiles
 int launch_pk(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows);
+bool po_legal(const IgemmArgs& a, int nclass);  // the output-heavy pointwise kernels with resident weights (asm/po_gen.py): K <= 512 -> 4K columns, shortcut addend, BN-backward sums
+int launch_po(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows);
 
 // conv_igemm8.hip
 bool igemm8_legal(const IgemmArgs& a, int nclass, int bn);
@@ -884,6 +887,7 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
   MI355_ARG(nclass >= 1 && nclass <= 4, "igemm: nclass=%d", nclass);
   MI355_ARG(((size_t)a.pix_stride * dtype_size(dtype)) % 8 == 0, "igemm: pixel stride not 8-byte aligned");
   MI355_ARG(a.N > 0 && a.Hsub > 0 && a.Wsub > 0, "igemm: empty problem");
+  MI355_ARG(!knobs().error[0], "%s", knobs().error);
   // BN = 128 unless that leaves most of the 256 CUs without a tile (the FC layer: 256 rows): then 64-wide tiles double
   // the workgroups
   const long tiles128 = (long)cdiv(a.N * a.Hsub * a.Wsub, 128) * nclass * (a.Ncols / 128);
@@ -893,6 +897,7 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
     return wide ? launch_t<float, 128, 128>(a, nclass, stream, stat_rows) : launch_t<float, 128, 64>(a, nclass, stream, stat_rows);
   if (dtype == MI355_BF16) {
     if (dconv_legal(a, nclass)) return launch_dconv(a, nclass, stream, stat_rows);
+    if (po_legal(a, nclass)) return launch_po(a, nclass, stream, stat_rows);
     if (pw_legal(a, nclass)) return launch_pw(a, nclass, stream, stat_rows);
     if (pk_legal(a, nclass)) return launch_pk(a, nclass, stream, stat_rows);
     {

@@ -863,6 +863,7 @@ int launch8_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
     hipLaunchKernelGGL((igemm8_kernel<BM, BN, 0, FAT, EB>), dim3(grid), dim3(512), lds, stream, k);
   }
   MI355_LAUNCH_CHECK();
+  note_kernel("igemm8<%d,%d%s%s>", BM, BN, FAT ? ",fat" : "", EB == 1 ? ",e4m3" : "");
   return 0;
 }
 

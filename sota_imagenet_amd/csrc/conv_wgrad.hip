@@ -474,6 +474,7 @@ int launch_t(const WgradArgs& a, int splits, hipStream_t stream) {
   }
   hipLaunchKernelGGL((wgrad_kernel<T, BMC, BNC, TPI>), dim3(grid), dim3(256), lds, stream, k);
   MI355_LAUNCH_CHECK();
+  note_kernel("wgrad<%s,%d,%d,%d>", sizeof(T) == 4 ? "f32" : (sizeof(T) == 2 ? "bf16" : "e4m3"), BMC, BNC, TPI);
   return 0;
 }
 
@@ -523,6 +524,7 @@ int plan_wgrad(int dtype, const WgradArgs& a) {
 
 int launch_wgrad(int dtype, const WgradArgs& a, int splits, hipStream_t stream) {
   MI355_ARG(a.dy && a.x && a.partial, "wgrad: null pointer");
+  MI355_ARG(!knobs().error[0], "%s", knobs().error);
   if (splits > 0 && wg3_plan(dtype, a) == splits) return launch_wg3(a, splits, stream);
   MI355_ARG(a.Cout % 64 == 0 && a.Ck % 64 == 0, "wgrad: Cout=%d Ck=%d must be multiples of 64", a.Cout, a.Ck);
   MI355_ARG(splits >= 1, "wgrad: splits=%d", splits);

@@ -63,23 +63,37 @@ const Wg1Variant g_wg1[] = {
 };
 constexpr int NWG1 = (int)(sizeof(g_wg1) / sizeof(g_wg1[0]));
 
+// output-heavy pointwise kernels with the weights resident in AGPRs (asm/po_gen.py): persistent workgroups, 64-pixel tiles x BN columns
+struct PoVariant {
+  const char* name;
+  int K, BN, stats, add, TP, lds, kernarg;
+};
+const PoVariant g_po[] = {
+#include "build/asm/po_meta.inc"
+};
+constexpr int NPO = (int)(sizeof(g_po) / sizeof(g_po[0]));
+
 alignas(4096) const unsigned char g_blob[] = {
 #include "build/asm/dconv_blob.inc"
 };
 
 struct DevState {
-  bool tried = false, ok = false;
+  bool ok = false;
+  int attempts = 0;
   hipModule_t mod = nullptr;
   hipFunction_t fn[NVAR] = {};
   hipFunction_t pw[NPW] = {};
   hipFunction_t wg[NWG] = {};
   hipFunction_t pk[NPK] = {};
   hipFunction_t wg1[NWG1] = {};
+  hipFunction_t po[NPO] = {};
 };
 DevState g_dev[64];
 std::mutex g_mu;
 
-// loads the module on the current device (once); false with the error set when the runtime refuses it
+// loads the module on the current device (once); false with the error set when the runtime refuses it.  A refusal is remembered per
+// device ("failed"): the *_legal() checks below then keep every launch on the implicit-GEMM kernels instead of failing it, and one line
+// on stderr says so.  A transient refusal (out of memory at load time) is retried a few times before it is taken as final.
 bool dev_state(DevState** out) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
@@ -88,47 +102,31 @@ bool dev_state(DevState** out) {
   }
   std::lock_guard<std::mutex> lock(g_mu);
   DevState& d = g_dev[dev];
-  if (!d.tried) {
-    d.tried = true;
-    hipError_t e = hipModuleLoadData(&d.mod, g_blob);
+  if (!d.ok && d.attempts < 3) {
+    ++d.attempts;
+    hipError_t e = hipSuccess;
+    const char* what = "hipModuleLoadData";
+    if (d.mod == nullptr) e = hipModuleLoadData(&d.mod, g_blob);
+    auto get = [&](hipFunction_t* f, const char* name) {
+      if (e != hipSuccess) return;
+      e = hipModuleGetFunction(f, d.mod, name);
+      if (e != hipSuccess) what = name;
+    };
+    for (int i = 0; i < NVAR; ++i) get(&d.fn[i], g_variants[i].name);
+    for (int i = 0; i < NPW; ++i) get(&d.pw[i], g_pw[i].name);
+    for (int i = 0; i < NWG; ++i) get(&d.wg[i], g_wg[i].name);
+    for (int i = 0; i < NPK; ++i) get(&d.pk[i], g_pk[i].name);
+    for (int i = 0; i < NWG1; ++i) get(&d.wg1[i], g_wg1[i].name);
+    for (int i = 0; i < NPO; ++i) get(&d.po[i], g_po[i].name);
     if (e != hipSuccess) {
-      set_error("dconv: hipModuleLoadData -> %s", hipGetErrorString(e));
+      (void)hipGetLastError();
+      set_error("dconv: %s -> %s", what, hipGetErrorString(e));
+      if (e != hipErrorOutOfMemory || d.attempts >= 3) {
+        d.attempts = 3;
+        fprintf(stderr, "mi355rn: the generated gfx950 kernels are unavailable on device %d (%s -> %s); every convolution stays on the implicit-GEMM kernels\n",
+                dev, what, hipGetErrorString(e));
+      }
       return false;
-    }
-    for (int i = 0; i < NVAR; ++i) {
-      e = hipModuleGetFunction(&d.fn[i], d.mod, g_variants[i].name);
-      if (e != hipSuccess) {
-        set_error("dconv: hipModuleGetFunction(%s) -> %s", g_variants[i].name, hipGetErrorString(e));
-        return false;
-      }
-    }
-    for (int i = 0; i < NPW; ++i) {
-      e = hipModuleGetFunction(&d.pw[i], d.mod, g_pw[i].name);
-      if (e != hipSuccess) {
-        set_error("dconv: hipModuleGetFunction(%s) -> %s", g_pw[i].name, hipGetErrorString(e));
-        return false;
-      }
-    }
-    for (int i = 0; i < NWG; ++i) {
-      e = hipModuleGetFunction(&d.wg[i], d.mod, g_wg[i].name);
-      if (e != hipSuccess) {
-        set_error("dconv: hipModuleGetFunction(%s) -> %s", g_wg[i].name, hipGetErrorString(e));
-        return false;
-      }
-    }
-    for (int i = 0; i < NPK; ++i) {
-      e = hipModuleGetFunction(&d.pk[i], d.mod, g_pk[i].name);
-      if (e != hipSuccess) {
-        set_error("dconv: hipModuleGetFunction(%s) -> %s", g_pk[i].name, hipGetErrorString(e));
-        return false;
-      }
-    }
-    for (int i = 0; i < NWG1; ++i) {
-      e = hipModuleGetFunction(&d.wg1[i], d.mod, g_wg1[i].name);
-      if (e != hipSuccess) {
-        set_error("dconv: hipModuleGetFunction(%s) -> %s", g_wg1[i].name, hipGetErrorString(e));
-        return false;
-      }
     }
     d.ok = true;
   }
@@ -138,6 +136,12 @@ bool dev_state(DevState** out) {
   }
   *out = &d;
   return true;
+}
+
+// the generated kernels can be launched on the current device (loads the module on first use)
+bool module_ok() {
+  DevState* d = nullptr;
+  return dev_state(&d);
 }
 
 // the 9 taps of a stride-1 3x3 class as wtap[(dh + 1)*3 + (dw + 1)], false when the class is not that pattern
@@ -225,21 +229,31 @@ int find_pk(const IgemmArgs& a, int nclass, int stats) {
 
 }  // namespace
 
-// MI355_DCONV=0 keeps every launch on the implicit-GEMM kernels (A/B; read once).  A launch that FORCES an implicit-GEMM tile
-// (MI355_IGEMM8 / MI355_IGEMM_BIG, the per-launch knobs of the tile tests) is left to those kernels too.
+// MI355_DCONV=0 keeps every launch on the implicit-GEMM kernels (A/B; a switch of struct Knobs: read once and on mi355_reload_knobs()).
+// A launch that FORCES an implicit-GEMM tile (MI355_IGEMM8 / MI355_IGEMM_BIG, the per-launch knobs of the tile tests) is left to those
+// kernels too, and so is every launch on a device whose runtime refused the embedded code object (dev_state()).
 static bool dconv_enabled() {
-  static const bool on = !(getenv("MI355_DCONV") && getenv("MI355_DCONV")[0] == '0');
-  return on && !knobs().has_igemm8 && !knobs().has_igemm_big;
+  return knobs().dconv && !knobs().has_igemm8 && !knobs().has_igemm_big;
+}
+
+// plans are also made on GPU-less hosts (layout-only contexts): there the kernels count as available
+static bool module_usable() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return true;
+  }
+  return module_ok();
 }
 
 // split count of the generated weight-gradient kernel for this launch (0: not served).  One workgroup per CU: the (ci tile, co tile)
 // pairs times the splits fill the device once; a split is a run of whole tiles.
 int wg3_plan(int dtype, const WgradArgs& a) {
-  static const bool on = !(getenv("MI355_WG3") && getenv("MI355_WG3")[0] == '0');
-  if (!on || !dconv_enabled()) return 0;
+  if (!knobs().wg3 || !dconv_enabled()) return 0;
   const int vi = find_wg(dtype, a);
   const int v1 = vi < 0 ? find_wg1(dtype, a) : -1;
   if (vi < 0 && v1 < 0) return 0;
+  if (!module_usable()) return 0;
   int pairs, ntiles;
   if (vi >= 0) {
     const WgVariant& v = g_wg[vi];
@@ -286,6 +300,7 @@ int launch_wg3(const WgradArgs& a, int splits, hipStream_t stream) {
       set_error("wg1: hipModuleLaunchKernel(%s) -> %s", v.name, hipGetErrorString(e));
       return MI355_E_HIP;
     }
+    note_kernel("%s", v.name);
     return 0;
   }
   const WgVariant& v = g_wg[vi];
@@ -305,13 +320,13 @@ int launch_wg3(const WgradArgs& a, int splits, hipStream_t stream) {
     set_error("wg3: hipModuleLaunchKernel(%s) -> %s", v.name, hipGetErrorString(e));
     return MI355_E_HIP;
   }
+  note_kernel("%s", v.name);
   return 0;
 }
 
 bool pw_legal(const IgemmArgs& a, int nclass) {
-  static const bool on = !(getenv("MI355_PW") && getenv("MI355_PW")[0] == '0');
-  if (!on || !dconv_enabled()) return false;
-  return find_pw(a, nclass, wanted_stats(a)) >= 0;
+  if (!knobs().pw || !dconv_enabled()) return false;
+  return find_pw(a, nclass, wanted_stats(a)) >= 0 && module_ok();
 }
 
 int launch_pw(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
@@ -352,16 +367,16 @@ int launch_pw(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
     return MI355_E_HIP;
   }
   if (stat_rows) *stat_rows = a.stat_partial ? (int)grid : 0;
+  note_kernel("%s", v.name);
   return 0;
 }
 
 bool pk_legal(const IgemmArgs& a, int nclass) {
-  static const bool on = !(getenv("MI355_PK") && getenv("MI355_PK")[0] == '0');
-  if (!on || !dconv_enabled()) return false;
+  if (!knobs().pk || !dconv_enabled()) return false;
   const int v = find_pk(a, nclass, wanted_stats(a));
   if (v < 0) return false;
   const long tiles = (long)a.N * a.Hin * a.Win / g_pk[v].W;   // one partial statistics row per pixel tile
-  return a.stat_partial == nullptr || tiles <= (a.stat_rows_cap > 0 ? a.stat_rows_cap : 768);
+  return (a.stat_partial == nullptr || tiles <= (a.stat_rows_cap > 0 ? a.stat_rows_cap : 768)) && module_ok();
 }
 
 int launch_pk(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
@@ -404,6 +419,7 @@ int launch_pk(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
     return MI355_E_HIP;
   }
   if (stat_rows) *stat_rows = a.stat_partial ? (int)tiles : 0;
+  note_kernel("%s", v.name);
   return 0;
 }
 
@@ -413,7 +429,7 @@ bool dconv_legal(const IgemmArgs& a, int nclass) {
   if (v < 0) return false;
   // one partial statistics row per tile: the caller's buffer must hold them (bn_finalize adds any number of rows, 512 per pass)
   if (a.stat_partial != nullptr && a.N * g_variants[v].TPI / g_variants[v].IPT > (a.stat_rows_cap > 0 ? a.stat_rows_cap : 768)) return false;
-  return true;
+  return module_ok();
 }
 
 int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
@@ -463,6 +479,120 @@ int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_r
     return MI355_E_HIP;
   }
   if (stat_rows) *stat_rows = a.stat_partial ? tiles : 0;
+  note_kernel("%s", v.name);
+  return 0;
+}
+
+// ---- output-heavy pointwise kernels with resident weights (asm/po_gen.py) ---------------------------------------------------------
+namespace {
+
+struct PoPlan {
+  int vi = -1;
+  unsigned T = 0, nct = 0, tpg = 0, G = 0, grid = 0, lognct = 0;
+};
+
+// 1x1 / stride 1, K = the variant's, columns a power-of-two multiple of its BN; statistics 0 / 1 / 2; addend none / plain / under its mask
+bool plan_po(const IgemmArgs& a, int nclass, PoPlan* pl) {
+  if (nclass != 1 || a.IS != 1 || a.OS != 1 || a.pair_delta != 0 || a.wtaps != 1 || a.cls[0].ntaps != 1) return false;
+  if (a.cls[0].taps[0].dh != 0 || a.cls[0].taps[0].dw != 0 || a.cls[0].taps[0].wtap != 0 || a.cls[0].ph != 0 || a.cls[0].pw != 0) return false;
+  if (a.Hsub != a.Hin || a.Wsub != a.Win || a.Hout != a.Hin || a.Wout != a.Win) return false;
+  if (a.pix_stride != a.Ck || a.q_scale_in != nullptr || a.q_scale_wt != nullptr) return false;
+  const int stats = wanted_stats(a);
+  const int add = a.addend == nullptr ? 0 : (a.addend_bits != nullptr ? 2 : 1);
+  if (a.addend == nullptr && a.addend_bits != nullptr) return false;
+  const long M = (long)a.N * a.Hin * a.Win;
+  if (M * a.Ck * 2 >= (1L << 32) || M * a.Ncols * 2 >= (1L << 32)) return false;  // 32-bit num_records of the tile-by-tile descriptors
+  for (int i = 0; i < NPO; ++i) {
+    const PoVariant& v = g_po[i];
+    if (v.K != a.Ck || v.stats != stats || v.add != add || a.Ncols % v.BN != 0) continue;
+    const unsigned nct = (unsigned)(a.Ncols / v.BN);
+    if ((nct & (nct - 1)) != 0 || nct > 32) continue;
+    pl->vi = i;
+    pl->nct = nct;
+    pl->lognct = 0;
+    while ((1u << pl->lognct) < nct) ++pl->lognct;
+    pl->T = (unsigned)((M + v.TP - 1) / v.TP);
+    const unsigned cus = (unsigned)device_cus();
+    const unsigned gmax = cus / nct > 0 ? cus / nct : 1;       // pixel runs: one workgroup per CU over all column tiles
+    pl->tpg = (pl->T + gmax - 1) / gmax;
+    pl->G = (pl->T + pl->tpg - 1) / pl->tpg;
+    pl->grid = (pl->G + 7) / 8 * 8 * nct;                      // workgroup x: XCD x % 8, column tile (x / 8) % nct, run (x / 8 / nct) * 8 + x % 8
+    return true;
+  }
+  return false;
+}
+
+}  // namespace
+
+bool po_legal(const IgemmArgs& a, int nclass) {
+  const int mode = knobs().po;
+  if (!mode || !dconv_enabled()) return false;
+  PoPlan pl;
+  if (!plan_po(a, nclass, &pl)) return false;
+  if (a.stat_partial != nullptr && (int)pl.G > (a.stat_rows_cap > 0 ? a.stat_rows_cap : 768)) return false;
+  if (mode < 2) {
+    // MI355_PO=1 (default): the measured rule, per launch shape of the bs-256 step in a serial trace (profiles/r05_ab_po_*.txt):
+    //  - 64 -> 256 under the shortcut addend + BN-backward sums (layer 1's conv1 data gradient, 1.39 GB per launch): the implicit-GEMM
+    //    kernel streams it at 5.5 TB/s with two workgroups per CU out of phase, this kernel at 5.1: stays there;
+    //  - K = 512 with an addend (layer 4's conv1 data gradient): 128-column tiles give a wave 64 bytes of a pixel row (half-line
+    //    stores) and re-stage the 64 KiB pixel tile for 16 column tiles: 74 us against 67;
+    //  - 512 -> 2048 forward (layer 4's conv3): pk's four-image tiles win by 2 us.
+    const PoVariant& v = g_po[pl.vi];
+    if (v.K == 64 && v.add != 0 && v.stats == 2) return false;
+    if (v.K == 512 && v.add != 0) return false;
+    if (v.K == 512 && a.Ncols >= 2048 && pk_legal(a, nclass)) return false;
+  }
+  return module_ok();
+}
+
+int launch_po(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
+  PoPlan pl;
+  MI355_ARG(plan_po(a, nclass, &pl), "po: no kernel variant for this launch");
+  const PoVariant& v = g_po[pl.vi];
+  DevState* d = nullptr;
+  if (!dev_state(&d)) return MI355_E_HIP;
+  struct __attribute__((packed)) KArgs {
+    const void* in;
+    const void* wt;
+    void* out;
+    float* stat;
+    const void* bn_y;
+    const void* bn_bits;
+    const float* bn_mean;
+    const float* bn_invstd;
+    const void* addend;
+    const void* addend_bits;
+    unsigned npix, ncols, tpg, ngroups, ntiles, lognct;
+    unsigned pad[6];
+  } k;
+  static_assert(sizeof(KArgs) == 128, "kernarg layout of asm/po_gen.py (Gen.KA)");
+  MI355_ARG((int)sizeof(KArgs) == v.kernarg, "po: kernarg size mismatch");
+  memset(&k, 0, sizeof(k));
+  k.in = a.in;
+  k.wt = a.wt;
+  k.out = a.out;
+  k.stat = a.stat_partial;
+  k.bn_y = a.bn_y;
+  k.bn_bits = a.bn_bits;
+  k.bn_mean = a.bn_mean;
+  k.bn_invstd = a.bn_invstd;
+  k.addend = a.addend;
+  k.addend_bits = a.addend_bits;
+  k.npix = (unsigned)((long)a.N * a.Hin * a.Win);
+  k.ncols = (unsigned)a.Ncols;
+  k.tpg = pl.tpg;
+  k.ngroups = pl.G;
+  k.ntiles = pl.T;
+  k.lognct = pl.lognct;
+  size_t ksize = sizeof(k);
+  void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
+  const hipError_t e = hipModuleLaunchKernel(d->po[pl.vi], pl.grid, 1, 1, 256, 1, 1, 0, stream, nullptr, extra);
+  if (e != hipSuccess) {
+    set_error("po: hipModuleLaunchKernel(%s) -> %s", v.name, hipGetErrorString(e));
+    return MI355_E_HIP;
+  }
+  if (stat_rows) *stat_rows = a.stat_partial ? (int)pl.G : 0;
+  note_kernel("%s", v.name);
   return 0;
 }
 

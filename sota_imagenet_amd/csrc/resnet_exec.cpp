@@ -58,6 +58,8 @@ struct ConvBN {
   void* w_trq = nullptr;        // e4m3 [Cin][taps][Cout]
   const void* in_q = nullptr;   // e4m3 twin of the layer's input activation (written by the bn_apply that produced it)
   int qid_w = -1, qid_in = -1, qid_dy = -1;  // slots of the per-tensor scale / amax tables
+  // the kernels this layer's last forward / data-gradient / weight-gradient launch went to (mi355_resnet50_kernel_table)
+  char k_fwd[48] = "", k_dgrad[48] = "", k_wgrad[48] = "";
 };
 
 struct Block {
@@ -269,6 +271,7 @@ int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, float mo
   } else {
     MI355_TRY(launch_igemm(c->dtype, a, 1, s, &l.stat_rows));
   }
+  snprintf(l.k_fwd, sizeof(l.k_fwd), "%s", mi355_last_conv_kernel());
   return 0;
 }
 
@@ -364,6 +367,7 @@ int conv_wgrad(mi355_ctx* c, ConvBN& l, const void* dy, const void* x, float bet
     Prof p(c, wgrad_class(l.Cout), conv_flops(c, l), by, s);
     MI355_TRY(launch_wgrad(c->dtype, a, l.splits, s));
   }
+  snprintf(l.k_wgrad, sizeof(l.k_wgrad), "%s", mi355_last_conv_kernel());
   return launch_splitk_reduce(c->wg_partial, l.splits, n, c->grads + l.w_off, n, beta_acc, s);
 }
 
@@ -396,6 +400,7 @@ int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* ad
   } else {
     MI355_TRY(launch_igemm(c->dtype, a, nclass, s, rows));
   }
+  snprintf(l.k_dgrad, sizeof(l.k_dgrad), "%s", mi355_last_conv_kernel());
   return 0;
 }
 
@@ -757,6 +762,7 @@ int backward_stem(mi355_ctx* c, float beta_acc, hipStream_t s) {
   {
     Prof p(c, PC_WGRAD64, conv_flops(c, l), 0, ws);
     MI355_TRY(launch_wgrad(c->dtype, a, l.splits, ws));
+    snprintf(l.k_wgrad, sizeof(l.k_wgrad), "%s", mi355_last_conv_kernel());
   }
   MI355_TRY(launch_stem_unpack(c->wg_partial, l.splits, c->grads + l.w_off, beta_acc, ws));
   return release_set(c, par);
@@ -1052,6 +1058,7 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
     a.stat_partial = training ? c->bn_partial : nullptr;
     Prof p(c, PC_IGEMM64, conv_flops(c, c->stem), 0, s);
     MI355_TRY(launch_igemm(c->dtype, a, 1, s, &c->stem.stat_rows));
+    snprintf(c->stem.k_fwd, sizeof(c->stem.k_fwd), "%s", mi355_last_conv_kernel());
   }
   MI355_TRY(bn_prepare(c, c->stem, training, bn_momentum, s));
   {
@@ -1267,6 +1274,26 @@ int mi355_resnet50_flops(const mi355_ctx* c, double* fwd, double* train) {
   MI355_ARG(c, "flops: null ctx");
   if (fwd) *fwd = c->fwd_flops;
   if (train) *train = c->train_flops;
+  return 0;
+}
+
+int mi355_resnet50_kernel_table(const mi355_ctx* c, char* out, size_t cap, size_t* needed) {
+  MI355_ARG(c && (out || cap == 0), "kernel_table: bad arguments");
+  std::string t;
+  auto line = [&](const ConvBN& l) {
+    t += l.conv_name + " fwd=" + (l.k_fwd[0] ? l.k_fwd : "-") + " dgrad=" + (l.k_dgrad[0] ? l.k_dgrad : "-") + " wgrad=" + (l.k_wgrad[0] ? l.k_wgrad : "-") + "\n";
+  };
+  line(c->stem);
+  for (const Block& b : c->blocks) {
+    line(b.c1); line(b.c2); line(b.c3);
+    if (b.has_ds) line(b.ds);
+  }
+  if (needed) *needed = t.size() + 1;
+  if (cap > 0) {
+    const size_t n = std::min(cap - 1, t.size());
+    memcpy(out, t.data(), n);
+    out[n] = 0;
+  }
   return 0;
 }
 

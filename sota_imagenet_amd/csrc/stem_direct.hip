@@ -399,6 +399,7 @@ int launch_stem_direct(const IgemmArgs& a, hipStream_t stream, int* stat_rows) {
     hipLaunchKernelGGL(stem_direct_kernel<0>, dim3(grid), dim3(256), lds, stream, k);
   }
   MI355_LAUNCH_CHECK();
+  note_kernel("stem_direct");
   return 0;
 }
 

@@ -381,6 +381,20 @@ class ResNet50(_FlatModel):
         L.mi355_resnet50_destroy(ctx)
         return f.value, t.value
 
+    def kernel_table(self, shape):
+        """{conv name: {"fwd": kernel, "dgrad": kernel, "wgrad": kernel}} of the last step at batch shape (N,H,W) — which kernel each
+        convolution's launches went to (mi355_resnet50_kernel_table; '-' = not launched)."""
+        L = native.lib()
+        need = ctypes.c_size_t(0)
+        check(L.mi355_resnet50_kernel_table(self._ctx(*shape), None, 0, ctypes.byref(need)))
+        buf = ctypes.create_string_buffer(need.value)
+        check(L.mi355_resnet50_kernel_table(self._ctx(*shape), buf, need.value, None))
+        out = {}
+        for ln in buf.value.decode().splitlines():
+            name, *kv = ln.split()
+            out[name] = dict(x.split("=", 1) for x in kv)
+        return out
+
     def debug_tensor(self, shape, name):
         """copy of an internal tensor of the last step at batch shape (N,H,W) — test hook (mi355_resnet50_debug_tensor)."""
         L = native.lib()

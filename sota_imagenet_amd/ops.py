@@ -130,6 +130,33 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None):
     return dx
 
 
+def conv2d_dgrad_bn(dy, w, x_shape, stride=1, pad=0, addend=None, addend_bits=None, bn_y=None, bn_bits=None, bn_mean=None, bn_invstd=None):
+    """the data gradient as the executor's backward launches it: dx = dgrad(dy) + addend (under the ReLU bits addend_bits), and — with
+    bn_y / bn_bits / bn_mean / bn_invstd — the BN-backward partial rows [nblk][2][Cin] (sum dz, sum dz * xhat) of the layer dx is the
+    activation gradient of.  Returns (dx, partial or None)."""
+    _need_cuda(dy, w, addend, addend_bits, bn_y, bn_bits, bn_mean, bn_invstd)
+    N, H, W, Cin = x_shape
+    Cout, KH, KW, _ = w.shape
+    dt = dtype_code(dy.dtype)
+    ws, n = _conv_ws(dt, N, H, W, Cin, Cout, KH, KW, stride, pad, dy.device)
+    dx = torch.empty((N, H, W, Cin), dtype=dy.dtype, device=dy.device)
+    part = None
+    nblk = ctypes.c_int(0)
+    if bn_y is not None:
+        part = torch.empty((4096, 2, Cin), dtype=torch.float32, device=dy.device)
+    check(_L().mi355_conv2d_dgrad_bn(dt, ptr(dy), ptr(w), ptr(dx), ptr(addend), ptr(addend_bits), ptr(bn_y), ptr(bn_bits), ptr(bn_mean), ptr(bn_invstd),
+                                     ptr(part), 0 if part is None else part.numel() * 4, ctypes.byref(nblk), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                     ptr(ws), n, cur_stream()))
+    if part is not None:
+        part = part[:nblk.value] if nblk.value > 0 else None
+    return dx, part
+
+
+def last_conv_kernel():
+    """name of the kernel the last conv / weight-gradient launch of this thread went to (mi355_last_conv_kernel)"""
+    return _L().mi355_last_conv_kernel().decode()
+
+
 def conv2d_wgrad(dy, x, KH, KW, stride=1, pad=0, dw=None, beta=0.0):
     _need_cuda(dy, x, dw)
     N, H, W, Cin = x.shape

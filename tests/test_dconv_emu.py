@@ -113,6 +113,62 @@ def test_long_reduction_pointwise_kernels_are_exact_in_the_emulator(name, kw):
     assert r["max_err"] == 0.0 and r["untouched_ok"] and r.get("stat_err", 0.0) <= 1e-6
 
 
+@pytest.mark.parametrize("name,kw", [
+    ("po_k64_b256_s1_a0", dict(M=200, groups=((0, 0),))),                                   # forward + BN statistics, ragged last tile
+    ("po_k64_b256_s2_a2", dict(M=300, N=512, tpg=3, groups=((1, 1), (0, 0)))),              # two runs, second column tile, masked addend, BN-backward sums
+    ("po_k256_b256_s2_a2", dict(M=130, N=1024, groups=((0, 3),))),                          # 4 column tiles (layer 3's conv1 data gradient)
+    ("po_k256_b256_s2_a1", dict(M=640, N=512, tpg=1, groups=((9, 1), (3, 0)))),             # one tile per run, run index above 8 (second workgroup row of an XCD)
+    ("po_k256_b256_s1_a0", dict(M=192, N=256, tpg=2, groups=((1, 0),))),
+    ("po_k256_b256_s0_a0", dict(M=64, N=256, groups=((0, 0),))),
+    ("po_k512_b128_s2_a2", dict(M=150, N=1024, tpg=2, groups=((1, 7), (0, 2)))),            # 128-column tiles: one tile pair per wave
+    ("po_k512_b128_s1_a0", dict(M=128, N=256, groups=((0, 1),))),
+    ("po_k128_b256_s2_a2", dict(M=330, N=512, tpg=4, groups=((1, 0), (0, 1)))),
+    ("po_k128_b256_s0_a2", dict(M=100, N=256, groups=((0, 0),))),
+    ("po_k64_b256_s0_a1", dict(M=70, N=256, groups=((0, 0),))),
+    ("po_k64_b256_s2_a0", dict(M=640, N=256, tpg=1, groups=((8, 0), (9, 0)))),
+])
+def test_output_heavy_pointwise_kernels_are_exact_in_the_emulator(name, kw):
+    """csrc/asm/po_gen.py (weights resident in AGPRs, rolling refill of the epilogue operands): every (K, BN) family with each epilogue —
+    none / BN statistics / BN-backward sums x no addend / addend / addend under its ReLU bits; pixel counts that are not multiples of the
+    64-pixel tile; 1 .. 5 tiles per workgroup (both exits of the two-buffer loop); the statistics row of a run; nothing else written; no
+    register consumed before its load was waited for and no LDS-DMA protocol violation"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import po_emu_check
+
+    r = po_emu_check.run(name, **kw)
+    assert r["max_err"] == 0.0 and r["untouched_ok"] and r.get("stat_err", 0.0) <= 1e-6, r
+
+
+def test_a_workgroup_beyond_the_last_run_of_a_launch_exits_without_touching_memory():
+    """the grid is rounded up to whole XCD rows: workgroups whose run index is >= the run count end at once"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import po_emu_check
+
+    r = po_emu_check.run("po_k64_b256_s1_a0", M=128, N=256, tpg=1, groups=(), extra_wgs=(2, 7))
+    assert r["untouched_ok"] and r["insts"] < 400, r
+
+
+def test_the_launch_plan_covers_every_tile_once_at_the_shapes_of_the_step():
+    """dconv.cpp plan_po restated (tools/po_emu_check.plan): runs x tiles per run cover the tile count exactly once, every run has a
+    tile, and the grid holds whole XCD rows of (run, column tile) pairs"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import po_emu_check
+
+    for (M, N, BN) in ((256 * 3136, 256, 256), (256 * 784, 512, 256), (256 * 196, 1024, 256), (256 * 49, 2048, 128), (256 * 3136, 256, 256), (8 * 49, 2048, 128),
+                       (512 * 1600, 256, 256), (3 * 196, 1024, 256)):
+        T, nct, tpg, G, grid = po_emu_check.plan(M, N, BN, 64)
+        assert (G - 1) * tpg < T <= G * tpg and grid % (8 * nct) == 0 and grid >= G * nct
+        seen = set()
+        for x in range(grid):
+            xcd, l = x % 8, x // 8
+            g, ct = (l // nct) * 8 + xcd, l % nct
+            if g < G:
+                assert (g, ct) not in seen
+                seen.add((g, ct))
+                assert po_emu_check.wg_of(g, ct, nct) == x
+        assert len(seen) == G * nct
+
+
 def test_the_transposed_lds_read_of_the_emulator_follows_the_documented_lane_map():
     """ds_read_b64_tr_b16 (guide T10): per 16 lanes a 4 x 16 block; lane 4q + p addresses row q, columns 4p .. 4p + 3; lane i receives
     column i, row q in element q"""
@@ -168,10 +224,11 @@ def test_every_shipped_variant_assembles_for_gfx950_within_the_register_and_lds_
     import dconv_gen
     import pw_gen
     import pk_gen
+    import po_gen
     import wg1_gen
     import wg_gen
 
-    for mod in (dconv_gen, pw_gen, pk_gen, wg_gen, wg1_gen):
+    for mod in (dconv_gen, pw_gen, pk_gen, po_gen, wg_gen, wg1_gen):
         for name in mod.VARIANTS:
             c, g, text = mod.generate(name)
             assert g.accum_offset + g.nagpr <= 512

@@ -52,6 +52,161 @@ def test_forward_on_random_data_is_within_one_bf16_rounding(dev, N, H, Cin, Cout
     assert ((y - ref).abs() <= tol + 1e-6).all()
 
 
+def _pack_bits(mask):
+    """bool [..., C] -> uint8 [..., C / 8]: bit e of byte j = channel 8j + e (the ReLU bit masks bn_apply writes)"""
+    m = mask.reshape(*mask.shape[:-1], -1, 8).to(torch.int32)
+    return (m << torch.arange(8, device=mask.device, dtype=torch.int32)).sum(-1).to(torch.uint8)
+
+
+# (batch, H, channels of dx = 4 * channels of dy ... , channels of dy, kernel family): conv1's data gradient of every bottleneck shape of the
+# network at the BASELINE batch, the first blocks (dy at the previous stage's resolution), and batches whose pixel count is not a multiple
+# of the 64-pixel tile
+PO_DGRAD = [(256, 56, 256, 64, "po_k64_b256"), (256, 56, 256, 128, "po_k128_b256"), (256, 28, 512, 128, "po_k128_b256"), (256, 28, 512, 256, "po_k256_b256"),
+            (256, 14, 1024, 256, "po_k256_b256"), (256, 14, 1024, 512, "po_k512_b128"), (256, 7, 2048, 512, "po_k512_b128"),
+            (3, 14, 1024, 256, "po_k256_b256"), (5, 7, 2048, 512, "po_k512_b128"), (1, 56, 256, 64, "po_k64_b256")]
+
+
+@pytest.mark.parametrize("N,H,Cx,Cy,fam", PO_DGRAD)
+@pytest.mark.parametrize("add,sums", [(2, True), (1, True), (0, True), (2, False), (1, False)])
+def test_conv1_data_gradient_with_shortcut_addend_and_bn_backward_sums_is_exact(dev, N, H, Cx, Cy, fam, add, sums, monkeypatch):
+    monkeypatch.setenv("MI355_PO", "2")  # every variant, also where the default rule keeps a launch on another kernel
+    """the generated output-heavy pointwise kernels (csrc/asm/po_gen.py) through mi355_conv2d_dgrad_bn, the launch form of the executor's
+    backward: dx = dgrad(dy) + shortcut gradient (plain / under the block output's ReLU bits), bit for bit against the fp32 reference on
+    integer data, and the BN-backward partial rows (sum dz, sum dz * xhat) against fp64 sums over the same tensors; the kernel that ran
+    is asserted by name (a selection regression must fail here, not in a profile)"""
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(7)
+    dy = torch.randint(-2, 3, (N, H, H, Cy), device=dev).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (Cy, 1, 1, Cx), device=dev).to(torch.bfloat16)   # forward weights [Cout = Cy][1][1][Cin = Cx]
+    ad = torch.randint(-3, 4, (N, H, H, Cx), device=dev).to(torch.bfloat16) if add else None
+    abits = torch.randint(0, 256, (N, H, H, Cx // 8), device=dev, dtype=torch.uint8) if add == 2 else None
+    y = torch.randint(-3, 4, (N, H, H, Cx), device=dev).to(torch.bfloat16) if sums else None
+    ybits = torch.randint(0, 256, (N, H, H, Cx // 8), device=dev, dtype=torch.uint8) if sums else None
+    mean = (torch.randint(-4, 5, (Cx,), device=dev) * 0.25).float() if sums else None
+    invstd = (torch.randint(1, 5, (Cx,), device=dev) * 0.5).float() if sums else None
+    dx, part = ops.conv2d_dgrad_bn(dy, w, (N, H, H, Cx), 1, 0, addend=ad, addend_bits=abits, bn_y=y, bn_bits=ybits, bn_mean=mean, bn_invstd=invstd)
+    assert ops.last_conv_kernel() == "%s_s%d_a%d" % (fam, 2 if sums else 0, add)
+    _check_dgrad_bn(dev, dx, part, dy, w, ad, abits, y, ybits, mean, invstd, add, sums)
+
+
+def _check_dgrad_bn(dev, dx, part, dy, w, ad, abits, y, ybits, mean, invstd, add, sums):
+    Cy, Cx = w.shape[0], w.shape[3]
+    ref = dy.float().reshape(-1, Cy) @ w.float().reshape(Cy, Cx)
+    if add:
+        a = ad.float().reshape(-1, Cx)
+        if add == 2:
+            bit = ((abits.reshape(-1, Cx // 8, 1).to(torch.int32) >> torch.arange(8, device=dev, dtype=torch.int32)) & 1).reshape(-1, Cx)
+            a = a * bit
+        ref = ref + a
+    ref = ref.to(torch.bfloat16)
+    assert torch.equal(dx.reshape(-1, Cx), ref)
+    if sums:
+        assert part is not None and part.shape[1:] == (2, Cx)
+        bit = ((ybits.reshape(-1, Cx // 8, 1).to(torch.int32) >> torch.arange(8, device=dev, dtype=torch.int32)) & 1).reshape(-1, Cx)
+        dz = ref.double() * bit
+        xhat = (y.double().reshape(-1, Cx) - mean.double()) * invstd.double()
+        s1, s2 = dz.sum(0), (dz * xhat).sum(0)
+        assert (part[:, 0].double().sum(0) - s1).abs().max() <= 1e-6 * max(1.0, s1.abs().max().item())
+        assert (part[:, 1].double().sum(0) - s2).abs().max() <= 1e-6 * max(1.0, s2.abs().max().item())
+    else:
+        assert part is None
+
+
+def test_bn_backward_sums_of_the_data_gradient_against_the_oracle(dev):
+    """the same launch against oracle/ops_ref at a batch the CPU oracle handles: y -> BatchNorm (batch statistics) -> ReLU, the data
+    gradient of the next conv as the gradient of that activation; the partial rows must add up to the oracle's dbeta / dgamma / (gamma = 1)"""
+    from oracle import ops_ref
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(8)
+    N, H, Cx, Cy = 8, 14, 1024, 256
+    y = torch.randint(-3, 4, (N, H, H, Cx)).to(torch.bfloat16)
+    gamma, beta = torch.ones(Cx), (torch.randint(-2, 3, (Cx,)) * 0.25).float()
+    out, _, _, mean, invstd = ops_ref.bn_train(y, gamma, beta, torch.zeros(Cx), torch.ones(Cx), relu=True)
+    dy = torch.randint(-2, 3, (N, H, H, Cy)).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (Cy, 1, 1, Cx)).to(torch.bfloat16)
+    g_ref = (dy.float().reshape(-1, Cy) @ w.float().reshape(Cy, Cx)).reshape(N, H, H, Cx)  # exact integers: the activation gradient
+    _, dgamma, dbeta, _ = ops_ref.bn_train_bwd(y, gamma, beta, g_ref, relu=True)
+    bits = _pack_bits(out > 0)
+    dx, part = ops.conv2d_dgrad_bn(dy.to(dev), w.to(dev), (N, H, H, Cx), 1, 0, bn_y=y.to(dev), bn_bits=bits.to(dev), bn_mean=mean.to(dev), bn_invstd=invstd.to(dev))
+    assert ops.last_conv_kernel() == "po_k256_b256_s2_a0"
+    assert torch.equal(dx.cpu().float(), g_ref)
+    s = part.double().sum(0).cpu()
+    assert (s[0] - dbeta.double()).abs().max() <= 1e-4 * dbeta.abs().max()
+    assert (s[1] - dgamma.double()).abs().max() <= 1e-4 * dgamma.abs().max()
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout,fam", [(256, 56, 64, 256, "po_k64_b256"), (256, 28, 128, 512, "po_k128_b256"), (7, 28, 128, 512, "po_k128_b256")])
+def test_conv3_forward_of_layers_1_and_2_takes_the_resident_weight_kernel(dev, N, H, Cin, Cout, fam):
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(9)
+    x = torch.randint(-2, 3, (N, H, H, Cin), device=dev).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (Cout, 1, 1, Cin), device=dev).to(torch.bfloat16)
+    y, part = ops.conv2d_fwd(x, w, 1, 0, stats=True)
+    assert ops.last_conv_kernel() == fam + "_s1_a0"
+    ref = _ref(x, w, 1).to(torch.bfloat16)
+    assert torch.equal(y, ref)
+    s1, s2 = ref.float().sum(dim=(0, 1, 2)).double(), (ref.float() ** 2).sum(dim=(0, 1, 2)).double()
+    assert (part[:, 0].double().sum(0) - s1).abs().max() <= 1e-6 * s1.abs().max()
+    assert (part[:, 1].double().sum(0) - s2).abs().max() <= 1e-6 * s2.abs().max()
+    assert torch.equal(ops.conv2d_fwd(x, w, 1, 0), ref) and ops.last_conv_kernel() == fam + "_s0_a0"
+
+
+def test_the_default_rule_keeps_three_launch_shapes_on_the_older_kernels(dev):
+    """MI355_PO=1 (default): layer 1's and layer 4's conv1 data gradient (shortcut addend + BN-backward sums) stay on the implicit-GEMM
+    kernel, layer 4's conv3 forward on the long-reduction kernel — and their results are the same bits"""
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(11)
+    for (N, H, Cx, Cy, want) in ((64, 56, 256, 64, "igemm<bf16,"), (64, 7, 2048, 512, "igemm<bf16,")):
+        dy = torch.randint(-2, 3, (N, H, H, Cy), device=dev).to(torch.bfloat16)
+        w = torch.randint(-2, 3, (Cy, 1, 1, Cx), device=dev).to(torch.bfloat16)
+        ad = torch.randint(-3, 4, (N, H, H, Cx), device=dev).to(torch.bfloat16)
+        abits = torch.randint(0, 256, (N, H, H, Cx // 8), device=dev, dtype=torch.uint8)
+        y = torch.randint(-3, 4, (N, H, H, Cx), device=dev).to(torch.bfloat16)
+        ybits = torch.randint(0, 256, (N, H, H, Cx // 8), device=dev, dtype=torch.uint8)
+        mean, invstd = (torch.randint(-4, 5, (Cx,), device=dev) * 0.25).float(), (torch.randint(1, 5, (Cx,), device=dev) * 0.5).float()
+        dx, part = ops.conv2d_dgrad_bn(dy, w, (N, H, H, Cx), 1, 0, addend=ad, addend_bits=abits, bn_y=y, bn_bits=ybits, bn_mean=mean, bn_invstd=invstd)
+        assert ops.last_conv_kernel().startswith(want)
+        _check_dgrad_bn(dev, dx, part, dy, w, ad, abits, y, ybits, mean, invstd, 2, True)
+    x = torch.randint(-2, 3, (256, 7, 7, 512), device=dev).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (2048, 1, 1, 512), device=dev).to(torch.bfloat16)
+    assert torch.equal(ops.conv2d_fwd(x, w, 1, 0, stats=True)[0], _ref(x, w, 1).to(torch.bfloat16)) and ops.last_conv_kernel() == "pk_k512_n2048_w196_s1"
+
+
+def test_every_resident_weight_family_where_the_older_kernels_also_serve(dev, monkeypatch):
+    """MI355_PO=2 sends the launches the default rule leaves to pk (layer 4's conv3 forward) to the resident-weight kernels, and layer 3's
+    conv3 forward takes them by default: same results"""
+    from sota_imagenet_amd import ops
+
+    monkeypatch.setenv("MI355_PO", "2")
+    torch.manual_seed(10)
+    for (N, H, Cin, Cout, fam) in ((256, 14, 256, 1024, "po_k256_b256"), (256, 7, 512, 2048, "po_k512_b128")):
+        x = torch.randint(-2, 3, (N, H, H, Cin), device=dev).to(torch.bfloat16)
+        w = torch.randint(-2, 3, (Cout, 1, 1, Cin), device=dev).to(torch.bfloat16)
+        y, part = ops.conv2d_fwd(x, w, 1, 0, stats=True)
+        assert ops.last_conv_kernel() == fam + "_s1_a0"
+        ref = _ref(x, w, 1).to(torch.bfloat16)
+        assert torch.equal(y, ref)
+        s2 = (ref.float() ** 2).sum(dim=(0, 1, 2)).double()
+        assert (part[:, 1].double().sum(0) - s2).abs().max() <= 1e-6 * s2.abs().max()
+
+
+def test_a_switch_outside_its_domain_fails_the_launch(dev, monkeypatch):
+    from sota_imagenet_amd import native, ops
+
+    x = torch.zeros(1, 8, 8, 64, device=dev, dtype=torch.bfloat16)
+    w = torch.zeros(64, 1, 1, 64, device=dev, dtype=torch.bfloat16)
+    monkeypatch.setenv("MI355_DCONV", "off")
+    assert native.lib().mi355_reload_knobs() != 0 and "MI355_DCONV=off" in native.last_error()
+    with pytest.raises(RuntimeError, match="MI355_DCONV=off"):
+        ops.conv2d_fwd(x, w, 1, 0)
+    monkeypatch.delenv("MI355_DCONV")
+    ops.conv2d_fwd(x, w, 1, 0)
+
+
 def test_other_batch_sizes_take_the_same_kernels(dev):
     """8 images: 8 tiles (layer 3) / 4 tiles (layer 4, two images each) / 14 pixel tiles of 112 (pointwise)"""
     from sota_imagenet_amd import ops

@@ -10,6 +10,8 @@ yardstick: the native path's distance to the fp64 oracle must not exceed ~the to
 to it in the same precision (factor + floor written at each assert).  Layer-wise, teacher-forced checks
 (test_teacher_forced_layers) pin every stage without the chaotic amplification.
 """
+import os
+
 import pytest
 import torch
 
@@ -454,6 +456,16 @@ def test_baseline_batch_rule_selected_variants(dev, dtype, monkeypatch):
     loss.backward()
     torch.cuda.synchronize()
     g_rule = m.flat_grads.detach().clone().cpu()
+    if dtype == "bf16":
+        # WHICH kernel every convolution of the step went to: the executor's own record against the committed table (a regression in
+        # a selection rule — a row capacity, a divisibility test — would leave every number below green and cost a millisecond)
+        want = {}
+        for ln in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kernel_table_bs256_bf16.txt")):
+            name, *kv = ln.split()
+            want[name] = dict(x.split("=", 1) for x in kv)
+        got = m.kernel_table(key)
+        diff = {k: (got.get(k), want[k]) for k in want if got.get(k) != want[k]}
+        assert not diff and set(got) == set(want), f"kernel selection changed (tools/kernel_table.py --write refreshes the table): {diff}"
     P = {k: v.float() for k, v in sd.items()}
     T = lambda name: m.debug_tensor(key, name)
     q = lambda t: t.to(tdt).float()

@@ -293,7 +293,11 @@ def test_static_executor_matches_the_per_op_graph(dev, dtype, wstd, monkeypatch)
     for name in ("fc.weight", "fc.bias", "layer4.2.se_module.conv.weight", "layer4.2.conv3.weight", "layer2.0.downsample.0.weight", "layer1.0.bn1.weight",
                  "conv1.0.weight", "conv1.1.weight", "conv1.2.weight", "bn1.bias"):
         r = rel(gm[name].grad, gg[name].grad)
-        assert r < (1e-3 if dtype == "fp32" else 0.1), f"{name}: {r:.2e}"
+        # bf16: the two heads differ in the last fp32 bits (fc_kernel / torch GEMM), so whether ONE element of the pooled gradient rounds
+        # to the neighbouring bf16 value is chance (about two of its 8192 elements sit that close to a rounding boundary), and a single
+        # flip at the top grows layer by layer on the way down (measured: 5e-6 at layer4.2 -> 2e-2 at layer1 -> 0.13 at the stem's bias
+        # with a flip, exactly 0 everywhere without one; tools/dbg_bres.py).  The bound is the drift bound of the ResNet-50 tests.
+        assert r < (1e-3 if dtype == "fp32" else 0.3), f"{name}: {r:.2e}"
     # a second backward into the same flat array accumulates (accumulate_steps > 1)
     g1 = m.flat_grads.clone()
     R.smooth_ce(m(data), target, 0.1).backward()

@@ -311,6 +311,8 @@ class Emulator:
                 self.err(ins, "v%d consumed before the load that writes it was waited for" % (o.idx + sub))
             return wv.v[o.idx + sub]
         if k == "a":
+            if self.check and (1000 + o.idx + sub) in wv.pending_v:
+                self.err(ins, "a%d consumed before the load that writes it was waited for" % (o.idx + sub))
             return wv.a[o.idx + sub]
         if k in ("s", "imm", "m0", "vcc_lo", "exec_lo", "vcc_hi", "exec_hi"):
             return np.full(64, self.sval(wv, o, ins), dtype=np.uint32)
@@ -339,6 +341,8 @@ class Emulator:
                 self.err(ins, "v%d overwritten while a load into it is in flight" % idx)
             wv.v[idx] = np.where(mask, val, wv.v[idx])
         elif o.kind == "a":
+            if self.check and (1000 + o.idx + sub) in wv.pending_v:
+                self.err(ins, "a%d overwritten while a load into it is in flight" % (o.idx + sub))
             wv.a[o.idx + sub] = np.where(mask, val, wv.a[o.idx + sub])
         else:
             self.err(ins, "bad vector destination")
@@ -643,10 +647,21 @@ class Emulator:
 
     def i_v_mov_b32(self, wv, ins):
         src = self.vval(wv, ins.ops[1], ins)
+        mask = None
         if "row_shr" in ins.mods or "row_shl" in ins.mods:
             src, valid = self._dpp(ins, src)
             src = np.where(valid, src, 0 if ins.mods.get("bound_ctrl") else wv.v[ins.ops[0].idx])
-        self.vwrite(wv, ins.ops[0], src, ins)
+        elif "row_ror" in ins.mods:
+            # rotate right within each row of 16 lanes: lane i receives lane (i - n) mod 16 of its row
+            n = int(ins.mods["row_ror"])
+            lane = np.arange(64)
+            src = src[(lane & ~15) | ((lane - n) & 15)]
+        if "row_ror" in ins.mods or "row_shr" in ins.mods or "row_shl" in ins.mods:
+            # bank_mask bit b enables lanes 4b .. 4b + 3 of every row, row_mask bit r enables row r (destination write only)
+            lane = np.arange(64)
+            bm, rm = int(ins.mods.get("bank_mask", 0xF)), int(ins.mods.get("row_mask", 0xF))
+            mask = self.lanes(wv) & (((bm >> ((lane & 15) >> 2)) & 1) == 1) & (((rm >> (lane >> 4)) & 1) == 1)
+        self.vwrite(wv, ins.ops[0], src, ins, mask=mask)
 
     def i_v_add_u32(self, wv, ins):
         a, b = self._v2(wv, ins)
@@ -1034,7 +1049,9 @@ class Emulator:
         base, off, soff, nrec = self._buf_addr(wv, ins, vaddr_o, srd_o, soff_o)
         mask = self.lanes(wv)
         nd = max(1, nbytes // 4)
-        rec = {"kind": "load", "vgprs": list(range(dst.idx, dst.idx + nd))}
+        # (a load may target accumulation registers: they are tracked as registers 1000 + index)
+        bank, koff = (wv.a, 1000) if dst.kind == "a" else (wv.v, 0)
+        rec = {"kind": "load", "vgprs": list(range(koff + dst.idx, koff + dst.idx + nd))}
         for l in np.nonzero(mask)[0]:
             o = int(off[l])
             if o + nbytes > nrec - soff or o < 0:
@@ -1046,10 +1063,10 @@ class Emulator:
                 else:
                     raw = np.array([int.from_bytes(bytes(b), "little")], dtype=np.uint32)
             for i in range(nd):
-                wv.v[dst.idx + i, l] = raw[i]
+                bank[dst.idx + i, l] = raw[i]
         for r in rec["vgprs"]:
             if self.check and r in wv.pending_v:
-                self.err(ins, "v%d is the destination of two loads in flight" % r)
+                self.err(ins, "register %d is the destination of two loads in flight" % r)
             wv.pending_v[r] = rec
         wv.vm_ops.append(rec)
 

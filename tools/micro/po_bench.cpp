@@ -1,0 +1,110 @@
+// po_bench.cpp — standalone timing harness for the generated output-heavy pointwise kernels (asm/po_gen.py), tuning only.
+//   hipcc -O2 --offload-arch=gfx950 tools/micro/po_bench.cpp -o /tmp/po_bench
+//   /tmp/po_bench <file.hsaco> <kernel> K BN stats add M N [iters]
+// Launches the kernel with the launch plan of dconv.cpp (plan_po) on random bf16 data; every launch takes its tensors from a pool
+// larger than the Infinity Cache (the condition inside the train step) and the output overwrites the addend in place, as the
+// executor's conv1 data gradient does.  Prints the median / minimum time per launch and the algorithmic TB/s.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(x)                                                                   \
+  do {                                                                          \
+    hipError_t e_ = (x);                                                        \
+    if (e_ != hipSuccess) {                                                     \
+      fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      exit(1);                                                                  \
+    }                                                                           \
+  } while (0)
+
+int main(int argc, char** argv) {
+  if (argc < 9) {
+    fprintf(stderr, "usage: %s hsaco kernel K BN stats add M N [iters] [TP]\n", argv[0]);
+    return 2;
+  }
+  const char* hsaco = argv[1];
+  const char* kname = argv[2];
+  const int K = atoi(argv[3]), BN = atoi(argv[4]), stats = atoi(argv[5]), add = atoi(argv[6]);
+  const long M = atol(argv[7]);
+  const int N = atoi(argv[8]);
+  const int iters = argc > 9 ? atoi(argv[9]) : 30;
+  const int TP = argc > 10 ? atoi(argv[10]) : 64;
+  hipModule_t mod;
+  hipFunction_t fn;
+  CK(hipModuleLoad(&mod, hsaco));
+  CK(hipModuleGetFunction(&fn, mod, kname));
+  const size_t in_b = (size_t)M * K * 2, out_b = (size_t)M * N * 2, bits_b = (size_t)M * N / 8;
+  const double alg = (double)in_b + out_b * (1 + (add ? 1 : 0) + (stats == 2 ? 1 : 0)) + bits_b * ((add == 2 ? 1 : 0) + (stats == 2 ? 1 : 0));
+  const int POOL = (int)std::max<size_t>(3, (size_t)(1.2e9 / alg) + 1);
+  std::vector<unsigned short> h(std::max(in_b, out_b) / 2);
+  srand(1);
+  for (auto& v : h) v = (unsigned short)(0x3c00 + (rand() & 0x3ff)) ^ (unsigned short)((rand() & 1) << 15);
+  std::vector<void*> d_in(POOL), d_out(POOL), d_y(POOL), d_yb(POOL), d_ab(POOL);
+  for (int p = 0; p < POOL; ++p) {
+    CK(hipMalloc(&d_in[p], in_b));
+    CK(hipMemcpy(d_in[p], h.data(), in_b, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_out[p], out_b));
+    CK(hipMemcpy(d_out[p], h.data(), out_b, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_y[p], out_b));
+    CK(hipMemcpy(d_y[p], h.data(), out_b, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_yb[p], bits_b));
+    CK(hipMemcpy(d_yb[p], h.data(), bits_b, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_ab[p], bits_b));
+    CK(hipMemcpy(d_ab[p], h.data(), bits_b, hipMemcpyHostToDevice));
+  }
+  void *d_wt, *d_stat, *d_mu;
+  CK(hipMalloc(&d_wt, (size_t)N * K * 2));
+  CK(hipMemcpy(d_wt, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc(&d_stat, (size_t)1024 * 2 * N * 4));
+  CK(hipMalloc(&d_mu, (size_t)N * 4));
+  CK(hipMemset(d_mu, 0, (size_t)N * 4));
+  struct __attribute__((packed)) KArgs {
+    const void* in;
+    const void* wt;
+    void* out;
+    void* stat;
+    const void* bn_y;
+    const void* bn_bits;
+    const void* bn_mean;
+    const void* bn_invstd;
+    const void* addend;
+    const void* addend_bits;
+    unsigned npix, ncols, tpg, ngroups, ntiles, lognct;
+    unsigned pad[6];
+  } k;
+  memset(&k, 0, sizeof(k));
+  const unsigned nct = (unsigned)(N / BN);
+  unsigned lognct = 0;
+  while ((1u << lognct) < nct) ++lognct;
+  const unsigned T = (unsigned)((M + TP - 1) / TP);
+  const unsigned gmax = 256 / nct > 0 ? 256 / nct : 1;
+  const unsigned tpg = (T + gmax - 1) / gmax, G = (T + tpg - 1) / tpg, grid = (G + 7) / 8 * 8 * nct;
+  k.wt = d_wt; k.stat = d_stat; k.bn_mean = d_mu; k.bn_invstd = d_mu;
+  k.npix = (unsigned)M; k.ncols = (unsigned)N; k.tpg = tpg; k.ngroups = G; k.ntiles = T; k.lognct = lognct;
+  size_t ksize = sizeof(k);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  std::vector<float> ts;
+  for (int it = 0; it < iters + 5; ++it) {
+    const int p = it % POOL;
+    k.in = d_in[p]; k.out = d_out[p]; k.addend = d_out[p]; k.addend_bits = d_ab[p]; k.bn_y = d_y[p]; k.bn_bits = d_yb[p];
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
+    CK(hipEventRecord(e0, 0));
+    CK(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, 0, nullptr, extra));
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (it >= 5) ts.push_back(ms * 1000.f);
+  }
+  std::sort(ts.begin(), ts.end());
+  const double med = ts[ts.size() / 2];
+  printf("%-32s M %ld N %d grid %u tpg %u: median %7.1f us  min %7.1f us  %5.2f TB/s algorithmic (%.0f MB), %6.1f TF/s\n", kname, M, N, grid, tpg, med, ts[0],
+         alg / med * 1e-6, alg * 1e-6, 2.0 * M * N * K / med * 1e-6);
+  return 0;
+}

@@ -7,7 +7,7 @@ def load(c):
     f = glob.glob(f"{root}/pmc_{c}/*/*_counter_collection.csv")[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    return [r for r in rows if any(k in r["Kernel_Name"] for k in ("igemm_kernel", "igemm8_kernel", "wgrad_kernel", "stem_direct_kernel", "dconv_", "pw_k", "pk_k", "wg3_", "wg1_"))]
+    return [r for r in rows if any(k in r["Kernel_Name"] for k in ("igemm_kernel", "igemm8_kernel", "wgrad_kernel", "stem_direct_kernel", "dconv_", "pw_k", "pk_k", "po_k", "wg3_", "wg1_"))]
 fe, wr = load("FETCH_SIZE"), load("WRITE_SIZE")
 seq = []
 def el(h, c): return N * h * h * c
@@ -30,7 +30,7 @@ for name, hin, ho, ci, p, ds in reversed(blocks):
 seq.append(("wgrad", "stem.w", None))
 n = len(seq)
 for (kind, name, alg), f, w in zip(seq, fe[-n:], wr[-n:]):
-    assert kind in f["Kernel_Name"] or (kind == "igemm" and any(k in f["Kernel_Name"] for k in ("stem_direct_kernel", "dconv_", "pw_k", "pk_k"))) or (kind == "wgrad" and f["Kernel_Name"].startswith(("wg3_", "wg1_"))), (kind, name, f["Kernel_Name"][:50])
+    assert kind in f["Kernel_Name"] or (kind == "igemm" and any(k in f["Kernel_Name"] for k in ("stem_direct_kernel", "dconv_", "pw_k", "pk_k", "po_k"))) or (kind == "wgrad" and f["Kernel_Name"].startswith(("wg3_", "wg1_"))), (kind, name, f["Kernel_Name"][:50])
     hbm = (2 * float(f["Counter_Value"]) + float(w["Counter_Value"])) * 1024
     a = f"{alg*ES/1e6:8.1f}" if alg else "       -"
     r = f"{hbm/(alg*ES):5.2f}x" if alg else ""

@@ -19,7 +19,7 @@ import sys
 
 
 def short(n):
-    m0 = re.match(r"(dconv_l\d|pw_k\d+_n\d+|pk_k\d+_n\d+_w\d+|wg3_l\d|wg1_c\d+_o\d+)", n)  # generated assembly kernels (asm/dconv_gen.py, asm/pw_gen.py): one symbol per layer shape
+    m0 = re.match(r"(dconv_l\d|pw_k\d+_n\d+|pk_k\d+_n\d+_w\d+|po_k\d+_b\d+|wg3_l\d|wg1_c\d+_o\d+)", n)  # generated assembly kernels (asm/dconv_gen.py, asm/pw_gen.py): one symbol per layer shape
     if m0:
         return m0.group(1)
     m = re.search(r"(igemm8_kernel|igemm_kernel|wgrad_kernel|bn_reduce_kernel|bn_apply_kernel|bn_bwd_apply_kernel|bn_finalize_kernel|"

@@ -1,0 +1,114 @@
+"""po_emu_check.py — run a generated output-heavy pointwise kernel (csrc/asm/po_gen.py) in the CPU emulator (tools/gcn_emu.py) against numpy
+on exact small-integer data: output (with the shortcut addend under its ReLU bits), BN statistics rows / BN-backward sums, untouched memory.
+Test infrastructure; used by tests/test_dconv_emu.py."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "sota_imagenet_amd", "csrc", "asm"))
+
+import gcn_emu  # noqa: E402
+import po_gen  # noqa: E402
+from dconv_emu_check import bf16_round, from_bf16_bits, to_bf16_bits  # noqa: E402
+
+
+def plan(M, N, BN, TP, cus=256):
+    """the host-side launch plan of dconv.cpp launch_po(): tiles, column tiles, tiles per group, groups, grid"""
+    T = -(-M // TP)
+    nct = N // BN
+    gmax = max(1, cus // nct)
+    tpg = -(-T // gmax)
+    G = -(-T // tpg)
+    grid = -(-G // 8) * 8 * nct
+    return T, nct, tpg, G, grid
+
+
+def wg_of(g, ct, nct):
+    """workgroup id of (group, column tile): xcd = g % 8, l = (g // 8) * nct + ct"""
+    return ((g // 8) * nct + ct) * 8 + g % 8
+
+
+def run(name, M=200, N=None, groups=((0, 0),), tpg=None, seed=0, check=True, extra_wgs=(), **over):
+    c, g, text = po_gen.generate(name, **over)
+    N = N or c.BN
+    rng = np.random.default_rng(seed)
+    T = -(-M // c.TP)
+    nct = N // c.BN
+    tpg = tpg or T
+    G = -(-T // tpg)
+    x = rng.integers(-2, 3, size=(M, c.K)).astype(np.float32)
+    w = rng.integers(-2, 3, size=(N, c.K)).astype(np.float32)
+    ad = rng.integers(-3, 4, size=(M, N)).astype(np.float32)
+    abits = rng.integers(0, 256, size=(M, N // 8)).astype(np.uint8)
+    yb = rng.integers(-3, 4, size=(M, N)).astype(np.float32)
+    bits = rng.integers(0, 256, size=(M, N // 8)).astype(np.uint8)
+    mean = (rng.integers(-4, 5, size=N) * 0.25).astype(np.float32)
+    invstd = (rng.integers(1, 5, size=N) * 0.5).astype(np.float32)
+    mem = gcn_emu.Memory()
+    a_in, a_wt = mem.alloc(to_bf16_bits(x)), mem.alloc(to_bf16_bits(w))
+    out0 = np.full((M, N), 0x7FC0, dtype=np.uint16)
+    a_out = mem.alloc(out0)
+    a_stat = mem.alloc(np.full((G, 2, N), np.nan, dtype=np.float32))
+    a_y, a_bits, a_mu, a_is = mem.alloc(to_bf16_bits(yb)), mem.alloc(bits), mem.alloc(mean), mem.alloc(invstd)
+    a_ad, a_ab = mem.alloc(to_bf16_bits(ad)), mem.alloc(abits)
+    lognct = nct.bit_length() - 1
+    assert 1 << lognct == nct
+    ka = gcn_emu.pack_kernarg([("q", a_in), ("q", a_wt), ("q", a_out), ("q", a_stat), ("q", a_y), ("q", a_bits), ("q", a_mu), ("q", a_is), ("q", a_ad), ("q", a_ab),
+                               ("I", M), ("I", N), ("I", tpg), ("I", G), ("I", T), ("I", lognct)] + [("I", 0)] * 6)
+    assert len(ka) == po_gen.Gen.KA["size"], len(ka)
+    a_ka = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
+    total = 0
+    for (gi, ct) in groups:
+        emu = gcn_emu.Emulator(text, mem, lds_bytes=g.lds_bytes, check=check)
+        total += emu.run_workgroup(4, a_ka, wg_id=(wg_of(gi, ct, nct), 0, 0))
+    for gi in extra_wgs:  # run indices >= G: the workgroup must end without a store
+        emu = gcn_emu.Emulator(text, mem, lds_bytes=g.lds_bytes, check=check)
+        assert gi >= G
+        total += emu.run_workgroup(4, a_ka, wg_id=(wg_of(gi, 0, nct), 0, 0))
+    got = from_bf16_bits(mem.array(a_out, np.uint16, out0.shape)).astype(np.float64)
+    ref = (x.astype(np.float64) @ w.astype(np.float64).T).astype(np.float32)
+    if c.add:
+        amask = ((abits[..., None] >> np.arange(8)) & 1).reshape(M, N).astype(np.float32) if c.add == 2 else np.ones((M, N), dtype=np.float32)
+        ref = ref + ad * amask
+    refr = bf16_round(ref).astype(np.float64)
+    res = {"insts": total, "cfg": c}
+    touched = np.zeros(out0.shape, dtype=bool)
+    rows_of = lambda gi: slice(gi * tpg * c.TP, min((gi + 1) * tpg * c.TP, M))
+    cols_of = lambda ct: slice(ct * c.BN, (ct + 1) * c.BN)
+    for (gi, ct) in groups:
+        touched[rows_of(gi), cols_of(ct)] = True
+    res["max_err"] = (float(np.abs(np.where(touched, got - refr, 0.0)).max()) if not np.isnan(got[touched]).any() else float("nan")) if touched.any() else 0.0
+    res["untouched_ok"] = bool(np.isnan(got[~touched]).all())
+    st = mem.array(a_stat, np.float32, (G, 2, N))
+    if c.stats:
+        err = 0.0
+        scale = 1.0
+        for (gi, ct) in groups:
+            blk = refr[rows_of(gi), cols_of(ct)]
+            if c.stats == 1:
+                s1, s2 = blk.sum(axis=0), (blk ** 2).sum(axis=0)
+            else:
+                mask = ((bits[..., None] >> np.arange(8)) & 1).reshape(M, N).astype(np.float64)[rows_of(gi), cols_of(ct)]
+                dz = blk * mask
+                xhat = (yb.astype(np.float64)[rows_of(gi), cols_of(ct)] - mean[cols_of(ct)]) * invstd[cols_of(ct)]
+                s1, s2 = dz.sum(axis=0), (dz * xhat).sum(axis=0)
+            scale = max(scale, np.abs(s1).max(), np.abs(s2).max())
+            err = max(err, np.abs(st[gi, 0, cols_of(ct)] - s1).max(), np.abs(st[gi, 1, cols_of(ct)] - s2).max())
+        res["stat_err"] = float(err / scale)
+        tst = np.zeros((G, 2, N), dtype=bool)
+        for (gi, ct) in groups:
+            tst[gi, :, cols_of(ct)] = True
+        res["untouched_ok"] = res["untouched_ok"] and bool(np.isnan(st[~tst]).all()) and not np.isnan(st[tst]).any()
+    return res
+
+
+if __name__ == "__main__":
+    import time
+    for name, kw in (("po_k64_b256_s1_a0", dict(M=200, groups=((0, 0),))),
+                     ("po_k64_b256_s2_a2", dict(M=300, N=512, tpg=3, groups=((1, 1), (0, 0)))),):
+        t0 = time.time()
+        r = run(name, **kw)
+        print(name, kw, {k: v for k, v in r.items() if k != "cfg"}, "%.1f s" % (time.time() - t0))

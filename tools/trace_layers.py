@@ -6,7 +6,7 @@ d = sys.argv[1]
 f = (glob.glob(d + "/*/*_kernel_trace.csv") + glob.glob(d + "/*_kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))  # valid for single-stream runs (MI355_WGRAD_STREAM=0)
-conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("igemm_kernel", "igemm8_kernel", "wgrad_kernel", "conv3_kernel", "stem_direct_kernel", "dconv_", "pw_k", "pk_k", "wg3_", "wg1_"))]
+conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("igemm_kernel", "igemm8_kernel", "wgrad_kernel", "conv3_kernel", "stem_direct_kernel", "dconv_", "pw_k", "pk_k", "po_k", "wg3_", "wg1_"))]
 # expected launch sequence of one training step (see csrc/resnet_exec.cpp)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 224  # image size
@@ -37,11 +37,11 @@ n = len(seq)
 last = conv[-n:]
 tot = 0
 for (kind, name, flops), r in zip(seq, last):
-    assert kind in r["Kernel_Name"] or (kind == "igemm" and any(k in r["Kernel_Name"] for k in ("conv3_kernel", "stem_direct_kernel", "dconv_", "pw_k", "pk_k"))) or (kind == "wgrad" and r["Kernel_Name"].startswith(("wg3_", "wg1_"))), (kind, name, r["Kernel_Name"][:60])
+    assert kind in r["Kernel_Name"] or (kind == "igemm" and any(k in r["Kernel_Name"] for k in ("conv3_kernel", "stem_direct_kernel", "dconv_", "pw_k", "pk_k", "po_k"))) or (kind == "wgrad" and r["Kernel_Name"].startswith(("wg3_", "wg1_"))), (kind, name, r["Kernel_Name"][:60])
     us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     tot += us
     grid = (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
     kn = r["Kernel_Name"]
-    tag = kn if kn.startswith(("dconv_", "pw_k", "pk_k", "wg3_", "wg1_")) else ("igemm8" if "igemm8" in kn else "")
+    tag = kn if kn.startswith(("dconv_", "pw_k", "pk_k", "po_k", "wg3_", "wg1_")) else ("igemm8" if "igemm8" in kn else "")
     print(f"{name:12s} {kind:5s} {us:9.1f} us  {flops/us/1e6:8.1f} TF/s  grid {grid}  {tag}")
 print("total conv us", tot)
