@@ -45,6 +45,7 @@ class PoCfg:
     add: int = 0      # 0 no addend, 1 addend, 2 addend under its ReLU bit mask
     MFR: int = 4      # 16-pixel fragments per tile
     NBUF: int = 2     # A tile buffers
+    weave: int = 1    # 1: two accumulator sets, the MFMAs of tile t + 1 issued between the epilogue instructions of tile t
     nt: int = 0       # non-temporal cache policy: 1 epilogue operand loads, 2 output stores, 4 A pieces
     probe: int = 0    # timing probes (WRONG results): 1 no MFMAs, 2 no epilogue arithmetic, 4 no operand loads, 8 no stores
 
@@ -135,7 +136,7 @@ class Gen:
         self.s_ka = S.get(20, 4)
         self.s_kp = S.get(8, 4)
         (self.s_w, self.s_t0, self.s_t1, self.s_t2, self.s_t3, self.s_cnt, self.s_pf, self.s_tout, self.s_tbits, self.s_g, self.s_ct, self.s_ldsA, self.s_n4,
-         self.s_ia, self.s_io, self.s_ib, self.s_8rows) = [S.get() for _ in range(17)]
+         self.s_ia, self.s_io, self.s_ib, self.s_8rows, self.s_pfa) = [S.get() for _ in range(18)]
         self.s_lo8 = S.get(2, 2)   # lanes 0 .. 7 of every row of 16
         self.vA_rd = [[V.get() for kk in range(2)] for b in range(c.NBUF)]
         self.vA_dma = V.get()
@@ -171,7 +172,9 @@ class Gen:
         self.accum_offset = (self.nvgpr + 7) // 8 * 8
         self.aB = 0
         self.aACC = c.NT * c.KS * 4
-        self.nagpr = self.aACC + c.MFR * c.NT * 4
+        self.nacc = 2 if c.weave else 1
+        self.accset = 0   # the set the epilogue being emitted reads
+        self.nagpr = self.aACC + self.nacc * c.MFR * c.NT * 4
         assert self.nagpr <= 256 and self.accum_offset + self.nagpr <= 512
         self.tmp_i = 0
         self.prologue()
@@ -179,8 +182,9 @@ class Gen:
         self.finale()
         return self.finish()
 
-    def acc(self, m, n):
-        return self.aACC + (m * self.c.NT + n) * 4
+    def acc(self, m, n, aset=None):
+        aset = self.accset if aset is None else aset
+        return self.aACC + aset * self.c.MFR * self.c.NT * 4 + (m * self.c.NT + n) * 4
 
     def breg(self, n, ks):
         return self.aB + (n * self.c.KS + ks) * 4
@@ -273,6 +277,7 @@ class Gen:
         e("s_min_u32 %s, %s, %s" % (R("s", t1), R("s", t1), R("s", T)))
         e("s_sub_u32 %s, %s, %s" % (R("s", self.s_cnt), R("s", t1), R("s", t0)), "tiles of this workgroup (>= 1)")
         e("s_sub_u32 %s, %s, 1" % (R("s", self.s_pf), R("s", self.s_cnt)), "prefetch advances left")
+        e("s_mov_b32 %s, %s" % (R("s", self.s_pfa), R("s", self.s_pf)), "... of the A descriptor (it runs one tile further ahead when the loop is woven)")
         self.s_first = S_first = self.S.get()
         e("s_mov_b32 %s, %s" % (R("s", S_first), R("s", t0)))
         e("s_mul_i32 %s, %s, %d" % (R("s", self.s_tout), R("s", N), c.TP * 2), "bytes of a tile of an output-shaped tensor")
@@ -329,6 +334,8 @@ class Gen:
         for jj in range(c.NPW):
             for ins in self.a_piece(jj, 0):
                 e(ins)
+        for ins in self.a_advance():
+            e(ins)
         # ---- output-shaped tensors: base offset = first*tout + ct*BN*2 (64-bit), records = npix*N*2 - that
         e("s_mul_i32 %s, %s, %s" % (R("s", t0), R("s", S_first), R("s", self.s_tout)))
         e("s_mul_hi_u32 %s, %s, %s" % (R("s", t1), R("s", S_first), R("s", self.s_tout)))
@@ -400,16 +407,24 @@ class Gen:
                     e("v_mov_b32 %s, 0" % R("v", self.s2[p] + i))
         e("s_waitcnt vmcnt(0)", "weights, first tile, first operands")
 
-    def prefetch_advance(self):
-        """the prefetch descriptors (A, y, addend, masks) move to the next tile while one is left, else stay (re-reads, never used)"""
+    def a_advance(self):
+        """the A descriptor moves to the next tile while one is left, else stays (re-reads of the last tile, never used)"""
         c = self.c
+        return ["s_cmp_gt_u32 %s, 0" % R("s", self.s_pfa),
+                "s_cselect_b32 %s, %d, 0" % (R("s", self.s_ia), c.TP * c.K * 2),
+                "s_cselect_b32 %s, 1, 0" % R("s", self.s_t3),
+                "s_sub_u32 %s, %s, %s" % (R("s", self.s_pfa), R("s", self.s_pfa), R("s", self.s_t3))] + self.desc_adv(self.srdA, self.s_ia)
+
+    def prefetch_advance(self):
+        """the prefetch descriptors of the epilogue operands (y, addend, masks) move to the next tile while one is left, else stay"""
+        c = self.c
+        if not c.L:
+            return []
         out = ["s_cmp_gt_u32 %s, 0" % R("s", self.s_pf),
-               "s_cselect_b32 %s, %d, 0" % (R("s", self.s_ia), c.TP * c.K * 2),
                "s_cselect_b32 %s, %s, 0" % (R("s", self.s_io), R("s", self.s_tout)),
                "s_cselect_b32 %s, %s, 0" % (R("s", self.s_ib), R("s", self.s_tbits)),
                "s_cselect_b32 %s, 1, 0" % R("s", self.s_t3),
                "s_sub_u32 %s, %s, %s" % (R("s", self.s_pf), R("s", self.s_pf), R("s", self.s_t3))]
-        out += self.desc_adv(self.srdA, self.s_ia)
         if c.stats == 2:
             out += self.desc_adv(self.srdY, self.s_io) + self.desc_adv(self.srdM, self.s_ib)
         if c.add:
@@ -434,50 +449,110 @@ class Gen:
             out.extend(slots.get(i, []))
         return out
 
+    def capture(self, fn, *args):
+        """the instructions fn(*args) emits, as a list"""
+        keep, self.out = self.out, []
+        fn(*args)
+        got, self.out = self.out, keep
+        return got
+
+    def mfma_phase(self, buf, aset):
+        """tile in A buffer buf -> accumulator set aset: KS k-steps of MFR x NT MFMAs, the fragment reads of step ks + 1 between the MFMAs of step ks"""
+        c, e = self.c, self.e
+        for ins in self.frag_reads(0, 0, buf):
+            e(ins)
+        for ks in range(c.KS):
+            e("s_waitcnt lgkmcnt(0)")
+            fs = self.F[ks & 1]
+            mf = []
+            for n in range(c.NT):
+                for m in range(c.MFR):
+                    a = self.acc(m, n, aset)
+                    csrc = "0" if ks == 0 else R("a", a, 4)
+                    mf.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (R("a", a, 4), R("a", self.breg(n, ks), 4), R("v", fs + 4 * m, 4), csrc))
+            if c.probe & 1:
+                mf = mf[:c.MFR] if ks == 0 else []
+            nxt = [[r] for r in self.frag_reads((ks + 1) & 1, ks + 1, buf)] if ks + 1 < c.KS else []
+            for ins in (self.spread(mf, nxt) if mf else [x for g in nxt for x in g]):
+                e(ins)
+
+    def epilogue_tile(self, CW):
+        c = self.c
+        if c.FULL:
+            for m in range(c.MFR):
+                self.unit(m, CW)
+        else:
+            for i in range(c.NI):
+                m, p = divmod(i, c.NT // 2)
+                self.item(i, m, p, CW)
+
+    @staticmethod
+    def weave(primary, secondary):
+        """secondary (the MFMA phase of the next tile, order kept) spread evenly through primary (the epilogue of this tile, order kept).  An
+        s_waitcnt of either list keeps its place relative to its own list: lgkmcnt waits belong to the MFMA phase's fragment reads (the
+        epilogue has no LDS operation), vmcnt waits to the epilogue's loads (the MFMA phase has no vector-memory operation)."""
+        np_, ns = len(primary), len(secondary)
+        out, j = [], 0
+        for i, ins in enumerate(primary):
+            out.append(ins)
+            while j < ns and (j + 1) * np_ <= (i + 1) * ns:
+                out.append(secondary[j])
+                j += 1
+        out.extend(secondary[j:])
+        return out
+
     def mainloop(self):
         c, e = self.c, self.e
-        self.comment("---- main loop: one 64-pixel tile per trip (unrolled over the %d A buffers)" % c.NBUF)
         top, done = self.newlabel("loop"), self.newlabel("done")
-        npair = c.NT // 2
         # younger than an item's (a fragment's) loads when it waits for them: the stores + refills of the other items (fragments) of a
-        # tile and the A pieces of the next tile
+        # tile and the A pieces requested at the top of this tile's trip
         CW = ((c.L + 1) * (c.NI - 1) if not c.FULL else 2 * (c.L + 1) * (c.MFR - 1)) + c.NPW
+        if c.weave:
+            self.comment("---- first tile: its MFMAs alone (A buffer 0 -> accumulator set 0), the second tile requested")
+            e("s_barrier")
+            for jj in range(c.NPW):
+                for ins in self.a_piece(jj, 1):
+                    e(ins)
+            for ins in self.a_advance():
+                e(ins)
+            self.mfma_phase(0, 0)
+            e("s_waitcnt vmcnt(0)", "the second tile has landed (the counted wait at the top of the first trip has nothing younger to count yet)")
+            self.comment("---- main loop: per trip the epilogue of tile t out of one accumulator set, the MFMAs of tile t + 1 into the other woven through it")
+        else:
+            self.comment("---- main loop: one 64-pixel tile per trip (unrolled over the %d A buffers)" % c.NBUF)
         self.label(top)
         for b in range(c.NBUF):
             nb = (b + 1) % c.NBUF
             self.comment("tile in A buffer %d" % b)
-            e("s_waitcnt vmcnt(%d)" % (c.NI * (c.L + 1)), "this tile's A pieces have landed (younger: the last tile's stores and refills)")
-            e("s_barrier")
-            for jj in range(c.NPW):
-                for ins in self.a_piece(jj, nb):
+            if c.weave:
+                # at the top of the trip of tile t: tile t + 1 (requested a trip ago) has landed for every wave; buffer b (tile t: its MFMAs ran
+                # in the previous trip) takes tile t + 2
+                e("s_waitcnt vmcnt(%d)" % (c.NI * (c.L + 1)), "tile t + 1's A pieces have landed (younger: the last trip's stores and refills)")
+                e("s_barrier")
+                for jj in range(c.NPW):
+                    for ins in self.a_piece(jj, b):
+                        e(ins)
+                for ins in self.a_advance():
                     e(ins)
-            # ---- MFMA phase
-            for ins in self.frag_reads(0, 0, b):
-                e(ins)
-            for ks in range(c.KS):
-                e("s_waitcnt lgkmcnt(0)")
-                fs = self.F[ks & 1]
-                mf = []
-                for n in range(c.NT):
-                    for m in range(c.MFR):
-                        a = self.acc(m, n)
-                        csrc = "0" if ks == 0 else R("a", a, 4)
-                        mf.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (R("a", a, 4), R("a", self.breg(n, ks), 4), R("v", fs + 4 * m, 4), csrc))
-                if c.probe & 1:
-                    mf = mf[:c.MFR] if ks == 0 else []
-                nxt = [[r] for r in self.frag_reads((ks + 1) & 1, ks + 1, b)] if ks + 1 < c.KS else []
-                for ins in (self.spread(mf, nxt) if mf else [x for g in nxt for x in g]):
-                    e(ins)
-            # ---- epilogue items (the accumulators are read by VALU instructions: the matrix pipe must have retired the last MFMAs)
-            e("s_nop 15")
-            e("s_nop 7")
-            if c.FULL:
-                for m in range(c.MFR):
-                    self.unit(m, CW)
+                self.accset = b
+                epi = self.capture(self.epilogue_tile, CW)
+                mfm = self.capture(self.mfma_phase, nb, nb)
+                for ins in self.weave(epi, mfm):
+                    self.out.append(ins)
             else:
-                for i in range(c.NI):
-                    m, p = divmod(i, npair)
-                    self.item(i, m, p, CW)
+                e("s_waitcnt vmcnt(%d)" % (c.NI * (c.L + 1)), "this tile's A pieces have landed (younger: the last tile's stores and refills)")
+                e("s_barrier")
+                for jj in range(c.NPW):
+                    for ins in self.a_piece(jj, nb):
+                        e(ins)
+                for ins in self.a_advance():
+                    e(ins)
+                self.accset = 0
+                self.mfma_phase(b, 0)
+                # (the accumulators are read by VALU instructions: the matrix pipe must have retired the last MFMAs)
+                e("s_nop 15")
+                e("s_nop 7")
+                self.epilogue_tile(CW)
             # ---- next tile
             for ins in self.desc_adv(self.srdO, self.s_tout):
                 e(ins)
@@ -633,13 +708,14 @@ class Gen:
                 e("s_and_b32 %s, %s, 0xffff" % (R("s", srd + 1), R("s", srd + 1)))
                 e("s_mov_b32 %s, %d" % (R("s", srd + 2), c.NT * 16 * 4))
                 e("s_mov_b32 %s, 0x00020000" % R("s", srd + 3))
-            mu = [self.F[0] + 8 * p for p in range(npair)]
-            isd = [self.F[1] + 8 * p for p in range(npair)]
-            assert 8 * npair <= 4 * c.MFR
+            # registers: the (now dead) y vectors of the first items hold mean, the packed-output sets hold invstd, 4 floats per block
+            mu = [[self.it[2 * p + h]["y"] + k for h in range(2) for k in range(4)] for p in range(npair)]
+            isd = [[self.dsets[2 * p + h] + k for h in range(2) for k in range(4)] for p in range(npair)]
+            assert 2 * npair <= c.NI and 2 * npair <= 4
             for p in range(npair):
                 for h in range(2):
-                    e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", mu[p] + 4 * h, 4), R("v", self.v_chan), R("s", self.srdY, 4), p * 128 + 16 * h))
-                    e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", isd[p] + 4 * h, 4), R("v", self.v_chan), R("s", self.srdM, 4), p * 128 + 16 * h))
+                    e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", mu[p][4 * h], 4), R("v", self.v_chan), R("s", self.srdY, 4), p * 128 + 16 * h))
+                    e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", isd[p][4 * h], 4), R("v", self.v_chan), R("s", self.srdM, 4), p * 128 + 16 * h))
         # statistics row descriptor: stat + g*2*N*4 + channel offset
         e("s_mul_i32 %s, %s, %s" % (R("s", t1), R("s", self.s_g), R("s", self.s_n4)))
         e("s_lshl_b32 %s, %s, 1" % (R("s", t1), R("s", t1)))
@@ -661,11 +737,11 @@ class Gen:
             for p in range(npair):
                 # sum dz*xhat = invstd * (sum dz*y - mean * sum dz)
                 for k in range(8):
-                    e("v_mul_f32 %s, %s, %s" % (R("v", tv + k), R("v", mu[p] + k), R("v", self.s1[p] + k)))
+                    e("v_mul_f32 %s, %s, %s" % (R("v", tv + k), R("v", mu[p][k]), R("v", self.s1[p] + k)))
                 for k in range(8):
                     e("v_sub_f32 %s, %s, %s" % (R("v", self.s2[p] + k), R("v", self.s2[p] + k), R("v", tv + k)))
                 for k in range(8):
-                    e("v_mul_f32 %s, %s, %s" % (R("v", self.s2[p] + k), R("v", isd[p] + k), R("v", self.s2[p] + k)))
+                    e("v_mul_f32 %s, %s, %s" % (R("v", self.s2[p] + k), R("v", isd[p][k]), R("v", self.s2[p] + k)))
         e("s_mov_b32 exec_lo, 0x80008000", "lanes 15 of every row hold the row sums")
         e("s_mov_b32 exec_hi, 0x80008000")
         for p in range(npair):

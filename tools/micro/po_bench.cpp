@@ -23,7 +23,7 @@
 
 int main(int argc, char** argv) {
   if (argc < 9) {
-    fprintf(stderr, "usage: %s hsaco kernel K BN stats add M N [iters] [TP]\n", argv[0]);
+    fprintf(stderr, "usage: %s hsaco kernel K BN stats add M N [iters] [TP] [WPC]\n", argv[0]);
     return 2;
   }
   const char* hsaco = argv[1];
@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
   const int N = atoi(argv[8]);
   const int iters = argc > 9 ? atoi(argv[9]) : 30;
   const int TP = argc > 10 ? atoi(argv[10]) : 64;
+  const int WPC = argc > 11 ? atoi(argv[11]) : 1;  // workgroups per CU the plan aims at
   hipModule_t mod;
   hipFunction_t fn;
   CK(hipModuleLoad(&mod, hsaco));
@@ -81,7 +82,7 @@ int main(int argc, char** argv) {
   unsigned lognct = 0;
   while ((1u << lognct) < nct) ++lognct;
   const unsigned T = (unsigned)((M + TP - 1) / TP);
-  const unsigned gmax = 256 / nct > 0 ? 256 / nct : 1;
+  const unsigned gmax = 256u * WPC / nct > 0 ? 256u * WPC / nct : 1;
   const unsigned tpg = (T + gmax - 1) / gmax, G = (T + tpg - 1) / tpg, grid = (G + 7) / 8 * 8 * nct;
   k.wt = d_wt; k.stat = d_stat; k.bn_mean = d_mu; k.bn_invstd = d_mu;
   k.npix = (unsigned)M; k.ncols = (unsigned)N; k.tpg = tpg; k.ngroups = G; k.ntiles = T; k.lognct = lognct;

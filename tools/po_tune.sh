@@ -6,17 +6,17 @@ set -e
 base=$1; M=$2; N=$3; shift 3
 out=gpurun_out/tune; mkdir -p $out
 LLVM=/opt/rocm/lib/llvm/bin
-[ -x $out/po_bench ] || hipcc -O2 --offload-arch=gfx950 tools/micro/po_bench.cpp -o $out/po_bench
+hipcc -O2 --offload-arch=gfx950 tools/micro/po_bench.cpp -o $out/po_bench
 K=$(echo $base | sed 's/po_k\([0-9]*\)_.*/\1/'); BN=$(echo $base | sed 's/.*_b\([0-9]*\)_.*/\1/')
 ST=$(echo $base | sed 's/.*_s\([0-9]\)_.*/\1/'); AD=$(echo $base | sed 's/.*_a\([0-9]\)$/\1/')
 i=0
 for sets in "$@"; do
-  args=""; TP=64; for kv in $sets; do args="$args --set $kv"; case $kv in MFR=*) TP=$((16 * ${kv#MFR=}));; esac; done
+  args=""; TP=64; WPC=1; for kv in $sets; do case $kv in WPC=*) WPC=${kv#WPC=}; continue;; MFR=*) TP=$((16 * ${kv#MFR=}));; esac; args="$args --set $kv"; done
   sfx="_t$i"
   python3 sota_imagenet_amd/csrc/asm/po_gen.py --out $out $args --suffix $sfx $base > /dev/null
   $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $out/$base$sfx.s -o $out/$base$sfx.o
   $LLVM/ld.lld -shared $out/$base$sfx.o -o $out/$base$sfx.hsaco
   printf "%-22s " "[$sets]"
-  $out/po_bench $out/$base$sfx.hsaco $base$sfx $K $BN $ST $AD $M $N 30 $TP
+  $out/po_bench $out/$base$sfx.hsaco $base$sfx $K $BN $ST $AD $M $N 30 $TP $WPC
   i=$((i+1))
 done
