@@ -1090,6 +1090,29 @@ VARIANTS = {
 }
 
 
+def _other_sizes():
+    """the same four layers at the other two sizes of the progressive-resize recipe (BASELINE configs[4]: 160 -> 224 -> 320 px, stage schema
+    /root/reference/sota_imagenet/arg_parser.py:63-72): a = 160 px (40 / 20 / 10 / 5), b = 320 px (80 / 40 / 20 / 10).  The row pitch is 8 or a
+    multiple of 16 positions (a fragment never straddles two image rows), so these widths pad 17 .. 37 % of a row (12.5 % at 224 px)."""
+    geo = {
+        "l1a": dict(H=40, W=40, P=48, IPT=1, Cin=64, NCOLS=64, WM=4, WN=1, NT=4, ROWS_T=8),
+        "l2a": dict(H=20, W=20, P=32, IPT=1, Cin=128, NCOLS=128, WM=4, WN=1, ROWS_T=10),
+        "l3a": dict(H=10, W=10, P=16, IPT=1, Cin=256, NCOLS=256),
+        "l4a": dict(H=5, W=5, P=8, IPT=4, Cin=512, NCOLS=512, NB=3),
+        "l1b": dict(H=80, W=80, P=96, IPT=1, Cin=64, NCOLS=64, WM=4, WN=1, NT=4, ROWS_T=4),
+        "l2b": dict(H=40, W=40, P=48, IPT=1, Cin=128, NCOLS=128, WM=4, WN=1, ROWS_T=8),
+        "l3b": dict(H=20, W=20, P=32, IPT=1, Cin=256, NCOLS=256, ROWS_T=5),
+        "l4b": dict(H=10, W=10, P=16, IPT=1, Cin=512, NCOLS=512, NB=3),
+    }
+    for tag, kw in geo.items():
+        for st in (0, 1, 2):
+            name = "dconv_%s_s%d" % (tag, st)
+            VARIANTS[name] = Cfg(name, stats=st, **kw)
+
+
+_other_sizes()
+
+
 def generate(base, **over):
     c = VARIANTS[base]
     if over:

@@ -418,7 +418,7 @@ class Gen(dconv_gen.Gen):
 
 def _variants():
     v = {}
-    for (K, N, W, NB, stats, *rest) in (
+    fam = (
             # layer 3 (14 x 14, tile = one image): conv1 forward 1024 -> 256 with BN statistics (and without), conv3 data gradient with the BN-backward sums
             (1024, 256, 196, 2, (0, 1, 2)),
             # layer 4 (7 x 7, tile = two images): 2048 -> 512
@@ -430,7 +430,12 @@ def _variants():
             # (not shipped: 256 -> 1024, layer 3 conv3 forward — 4 chunks per workgroup; 57-61 us against 47.7 us of pw_gen.py's resident-K kernel)
             (512, 2048, 196, 2, (0, 1)),
             # layer 2 (28 x 28): conv1 forward 512 -> 128 and conv3 data gradient: 128-column tiles (two 16-column tiles per wave)
-            (512, 128, 196, 2, (0, 1, 2), 2)):
+            (512, 128, 196, 2, (0, 1, 2), 2),
+            # layer 2's first block: conv1 forward 256 -> 128 at 56 x 56 (it runs before the stride)
+            (256, 128, 196, 2, (0, 1), 2))
+    # the same families with tiles of 200 / 100 pixels: the pixel counts of the 160 px and 320 px stages of the progressive-resize recipe
+    # (BASELINE configs[4]: 10 x 10 and 20 x 20 at layer 3, 5 x 5 and 10 x 10 at layer 4) are multiples of 100, not of 49
+    for (K, N, W, NB, stats, *rest) in fam + tuple((K, N, {196: 200, 98: 100}[W], NB, st, *rest) for (K, N, W, NB, st, *rest) in fam):
         for st in stats:
             name = "pk_k%d_n%d_w%d_s%d" % (K, N, W, st)
             v[name] = mk(name, W, K, N, st, NB=NB, NT=rest[0] if rest else 4)

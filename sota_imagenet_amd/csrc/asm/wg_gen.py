@@ -124,21 +124,48 @@ def rows_of(c, kind):
 
 
 def pieces(c, kind):
-    """per wave: list of (LDS byte offset inside the buffer, source byte constant, 8-position block of the row, dead)"""
+    """per wave: list of (LDS byte offset inside the buffer, source byte constant, 8-position block of the row, dead).  The pieces of a
+    tile are dealt to the four waves so that piece j of wave w is affine in (w, j) (piece_plan): flat round-robin where the blocks per
+    row divide or are divided by 4, else rows x blocks as 2 x 2 or 4 x 1 (widths of 40: five or six blocks per row)."""
     ch = c.CO if kind == "d" else c.C
     rowb = c.W * ch * 2
     base = 0 if kind == "d" else c.DYB
     bpr = c.P // 8
-    nblk = -(-(c.W + (0 if kind == "d" else 1)) // 8)      # blocks of a row that hold data (dy: columns 0 .. W-1, in: 0 .. W)
-    nrows = len(rows_of(c, kind))
-    while (nrows * nblk) % 4 and nblk < bpr:               # a block of padding only is written with zeros (all lanes out of range)
+    nblk0 = -(-(c.W + (0 if kind == "d" else 1)) // 8)     # blocks of a row that hold data (dy: columns 0 .. W-1, in: 0 .. W)
+    rows = rows_of(c, kind)
+    nrows = len(rows)
+
+    def piece(lrow, src, xb):
+        return (base + (lrow * c.P + xb * 8) * 128, (src if src is not None else 0) * rowb, xb, src is None)
+
+    def affine(pw):
+        n = len(pw[0])
+        return all(len(x) == n for x in pw) and all(
+            pw[w][j][0] - pw[w][0][0] == pw[0][j][0] - pw[0][0][0] and (pw[w][j][3] or pw[w][0][3] or pw[0][j][3] or pw[0][0][3] or
+                                                                         pw[w][j][1] - pw[w][0][1] == pw[0][j][1] - pw[0][0][1])
+            for w in range(4) for j in range(n))
+
+    # flat dealing (a block of padding only is written with zeros: all its lanes are out of range)
+    nblk = nblk0
+    while (nrows * nblk) % 4 and nblk < bpr:
         nblk += 1
-    allp = []
-    for lrow, src in rows_of(c, kind):
-        for xb in range(nblk):
-            allp.append((base + (lrow * c.P + xb * 8) * 128, (src if src is not None else 0) * rowb, xb, src is None))
-    assert len(allp) % 4 == 0, (kind, len(allp))
-    return [allp[w::4] for w in range(4)]
+    allp = [piece(lrow, src, xb) for lrow, src in rows for xb in range(nblk)]
+    if len(allp) % 4 == 0:
+        pw = [allp[w::4] for w in range(4)]
+        if affine(pw):
+            return pw
+    # rows x blocks dealing: wave (wr, wb) takes rows = wr (mod a), blocks = wb (mod b)
+    for a, b in ((2, 2), (4, 1), (1, 4)):
+        nblk = -(-nblk0 // b) * b
+        if nrows % a or nblk > bpr:
+            continue
+        pw = []
+        for w in range(4):
+            wr, wb = w // b, w % b
+            pw.append([piece(lrow, src, xb) for (lrow, src) in rows[wr::a] for xb in range(wb, nblk, b)])
+        if affine(pw):
+            return pw
+    raise AssertionError("no affine dealing of the %s pieces: %d rows x %d blocks" % (kind, nrows, nblk0))
 
 
 def piece_plan(c, kind):
@@ -609,6 +636,15 @@ VARIANTS = {
     "wg3_l1": WCfg("wg3_l1", H=56, W=56, P=64, C=64, CO=64, geom="rows", DR=2),
     # BResNet-50's deep stem (configs[3]): the 3x3 convolutions at 112 x 112 with channels padded to 64 (one-row tiles, 112 per image)
     "wg3_s112": WCfg("wg3_s112", H=112, W=112, P=128, C=64, CO=64, geom="rows", DR=1),
+    # the same layers at the other sizes of the progressive-resize recipe (BASELINE configs[4]): a = 160 px (40 / 20 / 10), b = 320 px
+    # (80 / 40 / 20 / 10).  (Layer 4 at 160 px, 5 x 5, stays on the implicit-GEMM kernel: its packed tile would be 61 % padding.)
+    "wg3_l1a": WCfg("wg3_l1a", H=40, W=40, P=48, C=64, CO=64, geom="rows", DR=4),
+    "wg3_l2a": WCfg("wg3_l2a", H=20, W=20, P=32, C=128, CO=128, geom="rows", DR=5),
+    "wg3_l3a": WCfg("wg3_l3a", H=10, W=10, P=16, C=256, CO=256, geom="img", DR=10),
+    "wg3_l1b": WCfg("wg3_l1b", H=80, W=80, P=96, C=64, CO=64, geom="rows", DR=2),
+    "wg3_l2b": WCfg("wg3_l2b", H=40, W=40, P=48, C=128, CO=128, geom="rows", DR=4),
+    "wg3_l3b": WCfg("wg3_l3b", H=20, W=20, P=32, C=256, CO=256, geom="rows", DR=5),
+    "wg3_l4b": WCfg("wg3_l4b", H=10, W=10, P=16, C=512, CO=512, geom="img", DR=10),
 }
 
 

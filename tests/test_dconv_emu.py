@@ -31,6 +31,11 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang"
     ("dconv_l2_s2", dict(Cin=64, tiles=(3,), dgrad_taps=True)),
     ("dconv_l1_s1", dict(tiles=(0, 1, 13))),                                           # 14 row tiles per image: first / middle / last, one chunk
     ("dconv_l1_s2", dict(tiles=(14, 27), dgrad_taps=True)),
+    # the other sizes of the progressive-resize recipe: a = 160 px (40 / 20 / 10 / 5), b = 320 px (80 / 40 / 20 / 10)
+    ("dconv_l3a_s1", dict(Cin=128, tiles=(0, 1))), ("dconv_l4a_s2", dict(Cin=128, tiles=(1,))),                 # 10 x 10 images; four 5 x 5 images per tile
+    ("dconv_l2a_s2", dict(Cin=64, tiles=(3,), dgrad_taps=True)), ("dconv_l1a_s1", dict(tiles=(0, 1, 4))),      # 10-row / 8-row tiles at pitch 32 / 48
+    ("dconv_l4b_s1", dict(Cin=64, ntile=1)), ("dconv_l3b_s2", dict(Cin=64, tiles=(4, 6), dgrad_taps=True)),    # 5-row tiles of 20 x 20 images
+    ("dconv_l2b_s1", dict(Cin=64, tiles=(0, 2, 4))), ("dconv_l1b_s2", dict(tiles=(20, 39), dgrad_taps=True)),  # pitch 48 / 96: three / six fragments per row
 ])
 def test_direct_conv_kernels_are_exact_in_the_emulator(name, kw):
     r = D.run(name, **kw)
@@ -74,7 +79,11 @@ def test_the_emulator_rejects_an_lds_read_before_the_dma_wait():
 
 @pytest.mark.parametrize("name,kw", [("wg3_l3", dict(splits=2, tps=3, pairs=((3, 2),))), ("wg3_l3", dict(splits=3, tps=1, pairs=((0, 1),))),
                                      ("wg3_l2", dict(splits=3, tps=2, pairs=((1, 0),))), ("wg3_l4", dict(splits=2, tps=2, pairs=((5, 7),))),
-                                     ("wg3_l1", dict(splits=1, tps=29)), ("wg3_s112", dict(splits=2, tps=3))])
+                                     ("wg3_l1", dict(splits=1, tps=29)), ("wg3_s112", dict(splits=2, tps=3)),
+                                     # 160 / 320 px: pitch 48 (six 8-position blocks per row: pieces dealt rows x blocks as 2 x 2), 5-row tiles, 10 x 10 images
+                                     ("wg3_l1a", dict(splits=2, tps=6)), ("wg3_l2a", dict(splits=3, tps=3, pairs=((1, 0),))), ("wg3_l3a", dict(splits=2, tps=2, pairs=((3, 2),))),
+                                     ("wg3_l1b", dict(splits=1, tps=5)), ("wg3_l2b", dict(splits=2, tps=3, pairs=((0, 1),))), ("wg3_l3b", dict(splits=3, tps=3, pairs=((2, 3),))),
+                                     ("wg3_l4b", dict(splits=2, tps=1, pairs=((5, 7),)))])
 def test_weight_gradient_kernels_are_exact_in_the_emulator(name, kw):
     """csrc/asm/wg_gen.py: odd and single tile counts per split, splits that end inside an image (row tiles), last channel tiles;
     every slab element of the run workgroups exact, nothing else written, no LDS-DMA protocol violation"""
@@ -102,7 +111,11 @@ def test_pointwise_weight_gradient_kernels_are_exact_in_the_emulator(name, kw):
 @pytest.mark.parametrize("name,kw", [("pk_k1024_n256_w196_s1", dict(tiles=(1,), Cin=256)), ("pk_k1024_n256_w196_s2", dict(tiles=(0, 2), Cin=448)),
                                      ("pk_k2048_n512_w98_s1", dict(tiles=(1,), ntile=1, Cin=320)), ("pk_k2048_n512_w98_s2", dict(tiles=(0,), ntile=1, Cin=192)),
                                      ("pk_k1024_n256_w196_s0", dict(tiles=(0,), Cin=64)), ("pk_k2048_n512_w98_s0", dict(tiles=(2,), Cin=384)),
-                                     ("pk_k512_n128_w196_s1", dict(tiles=(1,), Cin=192)), ("pk_k512_n128_w196_s2", dict(tiles=(0,), Cin=128))])
+                                     ("pk_k512_n128_w196_s1", dict(tiles=(1,), Cin=192)), ("pk_k512_n128_w196_s2", dict(tiles=(0,), Cin=128)),
+                                     ("pk_k256_n128_w196_s1", dict(tiles=(1,))),
+                                     # tiles of 200 / 100 pixels (the 160 px and 320 px stages)
+                                     ("pk_k1024_n256_w200_s2", dict(tiles=(1,), Cin=192)), ("pk_k2048_n512_w100_s1", dict(tiles=(0, 2), ntile=1, Cin=128)),
+                                     ("pk_k512_n128_w200_s2", dict(tiles=(1,), Cin=128))])
 def test_long_reduction_pointwise_kernels_are_exact_in_the_emulator(name, kw):
     """csrc/asm/pk_gen.py with 1 .. 7 chunks of 64 channels (every exit of the unrolled buffer rotation), both column tiles, the three
     epilogues (none / BN statistics / BN-backward sums, the latter with the late second register set at 13 fragments)"""

@@ -12,6 +12,14 @@ SHAPES = [(256, 14, 256, 256, 3), (256, 7, 512, 512, 3), (256, 28, 128, 128, 3),
           (256, 7, 2048, 512, 1), (256, 7, 512, 2048, 1), (256, 28, 512, 256, 1), (256, 14, 1024, 512, 1), (256, 28, 512, 128, 1)]
 
 
+# the other sizes of the progressive-resize recipe (BASELINE configs[4]: 160 / 320 px), at batches the plans of a 512-image step reduce to:
+# (N, H, Cin, Cout, K, kernel family of the forward)
+SHAPES_OTHER = [(32, 40, 64, 64, 3, "dconv_l1a"), (32, 20, 128, 128, 3, "dconv_l2a"), (64, 10, 256, 256, 3, "dconv_l3a"), (64, 5, 512, 512, 3, "dconv_l4a"),
+                (8, 80, 64, 64, 3, "dconv_l1b"), (16, 40, 128, 128, 3, "dconv_l2b"), (32, 20, 256, 256, 3, "dconv_l3b"), (64, 10, 512, 512, 3, "dconv_l4b"),
+                (64, 10, 1024, 256, 1, "pk_k1024_n256_w200"), (64, 5, 2048, 512, 1, "pk_k2048_n512_w100"), (32, 20, 512, 128, 1, "po_k512_b128"),
+                (16, 40, 256, 128, 1, "pk_k256_n128_w200"), (64, 10, 1024, 512, 1, "pk_k1024_n512_w200")]
+
+
 def _ref(x, w, K):
     return torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=K // 2).permute(0, 2, 3, 1)
 
@@ -36,6 +44,28 @@ def test_forward_statistics_and_dgrad_are_exact_on_integer_data(dev, N, H, Cin, 
     dx = ops.conv2d_dgrad(dy, w, (N, H, H, Cin), 1, K // 2)
     refd = torch.nn.functional.conv_transpose2d(dy.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=K // 2).permute(0, 2, 3, 1)
     assert torch.equal(dx, refd.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout,K,fam", SHAPES_OTHER)
+def test_the_160_and_320_px_shapes_take_generated_kernels_and_are_exact(dev, N, H, Cin, Cout, K, fam):
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(12)
+    x = torch.randint(-2, 3, (N, H, H, Cin), device=dev).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (Cout, K, K, Cin), device=dev).to(torch.bfloat16)
+    y, part = ops.conv2d_fwd(x, w, 1, K // 2, stats=True)
+    assert ops.last_conv_kernel().startswith(fam + "_s1"), ops.last_conv_kernel()
+    ref = _ref(x, w, K).to(torch.bfloat16)
+    assert torch.equal(y, ref)
+    s1, s2 = ref.float().sum(dim=(0, 1, 2)).double(), (ref.float() ** 2).sum(dim=(0, 1, 2)).double()
+    assert (part[:, 0].double().sum(0) - s1).abs().max() <= 1e-6 * s1.abs().max()
+    assert (part[:, 1].double().sum(0) - s2).abs().max() <= 1e-6 * s2.abs().max()
+    dy = torch.randint(-2, 3, (N, H, H, Cout), device=dev).to(torch.bfloat16)
+    dx = ops.conv2d_dgrad(dy, w, (N, H, H, Cin), 1, K // 2)
+    refd = torch.nn.functional.conv_transpose2d(dy.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=K // 2).permute(0, 2, 3, 1)
+    assert torch.equal(dx, refd.to(torch.bfloat16))
+    if K == 3:
+        assert ops.last_conv_kernel().startswith(fam + "_s0"), ops.last_conv_kernel()
 
 
 @pytest.mark.parametrize("N,H,Cin,Cout,K", SHAPES)
@@ -220,7 +250,9 @@ def test_other_batch_sizes_take_the_same_kernels(dev):
 
 
 WG_SHAPES = [(256, 14, 256, 256), (256, 28, 128, 128), (256, 7, 512, 512), (256, 56, 64, 64), (8, 14, 256, 256), (12, 28, 128, 128), (20, 7, 512, 512),
-             (5, 56, 64, 64), (64, 112, 64, 64)]
+             (5, 56, 64, 64), (64, 112, 64, 64),
+             # 160 / 320 px (wg3_l{1,2,3}a, wg3_l{1,2,3,4}b)
+             (24, 40, 64, 64), (40, 20, 128, 128), (100, 10, 256, 256), (6, 80, 64, 64), (12, 40, 128, 128), (36, 20, 256, 256), (100, 10, 512, 512)]
 
 
 def _wgrad_ref(dy, x):
@@ -247,6 +279,7 @@ def test_weight_gradient_is_exact_on_integer_data(dev, N, H, Cin, Cout, monkeypa
     dy = torch.randint(-2, 3, (N, H, H, Cout), device=dev).to(torch.bfloat16)
     ref = _wgrad_ref(dy, x)
     dw = ops.conv2d_wgrad(dy, x, 3, 3, 1, 1)
+    assert ops.last_conv_kernel().startswith("wg3_"), ops.last_conv_kernel()
     assert torch.equal(dw, ref)
     dw2 = ops.conv2d_wgrad(dy, x, 3, 3, 1, 1, dw=dw.clone(), beta=1.0)
     assert torch.equal(dw2, 2 * ref)
