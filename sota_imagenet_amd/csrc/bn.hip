@@ -240,19 +240,30 @@ struct FinalizeArgs {
   float* coef;
 };
 
-template <int MODE>
+// MI355_BN_FIN_WIDE=0: the four-channel form for every layer (A/B switch, read once)
+static bool fin_wide() {
+  static const bool on = !(getenv("MI355_BN_FIN_WIDE") && getenv("MI355_BN_FIN_WIDE")[0] == '0');
+  return on;
+}
+
+template <int MODE, int CPW = 4>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const FinalizeArgs p) {
-  // 4 channels x 64 slices per workgroup: every thread has <= 8 independent partial rows to add (nblk <= 512), then a
-  // fixed-shape LDS tree — the summation order depends only on nblk, so results are bitwise reproducible.
-  __shared__ double red[2][64][4];
-  const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
-  const int c = blockIdx.x * 4 + cl;
+  // CPW channels x 256 / CPW slices per workgroup: every thread has <= 8 independent partial rows to add per pass, then a fixed-shape
+  // LDS tree — the summation order depends only on nblk (and CPW, itself a function of C and nblk), so results are bitwise reproducible.
+  // CPW = 4: 64 slices, one pass up to 512 rows.  CPW = 1 (few channels, many rows: the 64-channel layers whose direct-conv kernels
+  // leave one row per 4-row tile, 3584 at batch 256): 256 slices, so 3584 rows are two passes instead of seven dependent ones — the
+  // kernel is a chain of load latencies, and beside an HBM-bound weight-gradient kernel each pass takes 10 us
+  // (profiles/r05_bn_finalize_per_launch.txt: 35 us serial / 70-150 us in the step -> 8 / 15).
+  constexpr int SL = 256 / CPW;
+  __shared__ double red[2][SL][CPW];
+  const int cl = threadIdx.x % CPW, sl = threadIdx.x / CPW;
+  const int c = blockIdx.x * CPW + cl;
   double a = 0.0, b = 0.0;
-  for (int k0 = sl; k0 < p.nblk; k0 += 64 * 8) {
+  for (int k0 = sl; k0 < p.nblk; k0 += SL * 8) {
     float va[8], vb[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int k = k0 + 64 * u;
+      const int k = k0 + SL * u;
       const bool in = k < p.nblk;
       va[u] = in ? p.partial[((size_t)k * 2 + 0) * p.C + c] : 0.f;
       vb[u] = in ? p.partial[((size_t)k * 2 + 1) * p.C + c] : 0.f;
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const FinalizeArgs p) 
   red[1][sl][cl] = b;
   __syncthreads();
 #pragma unroll
-  for (int s = 32; s > 0; s >>= 1) {
+  for (int s = SL / 2; s > 0; s >>= 1) {
     if (sl < s) {
       red[0][sl][cl] += red[0][sl + s][cl];
       red[1][sl][cl] += red[1][sl + s][cl];
@@ -770,7 +781,8 @@ int launch_bn_finalize(const float* partial, const float* pivot, int nblk, int M
   a.shift = shift;
   a.eps = eps;
   a.momentum = momentum;
-  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(C / 4), dim3(256), 0, s, a);
+  if (fin_wide() && C <= 128 && nblk > 512) hipLaunchKernelGGL((bn_finalize_kernel<0, 1>), dim3(C), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((bn_finalize_kernel<0, 4>), dim3(C / 4), dim3(256), 0, s, a);
   MI355_LAUNCH_CHECK();
   return 0;
 }
@@ -907,7 +919,8 @@ int launch_bn_bwd_finalize(const float* partial, int nblk, int M, int C, const f
   a.dbeta = dbeta;
   a.beta_acc = beta_acc;
   a.coef = coef;
-  hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(C / 4), dim3(256), 0, s, a);
+  if (fin_wide() && C <= 128 && nblk > 512) hipLaunchKernelGGL((bn_finalize_kernel<1, 1>), dim3(C), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((bn_finalize_kernel<1, 4>), dim3(C / 4), dim3(256), 0, s, a);
   MI355_LAUNCH_CHECK();
   return 0;
 }

@@ -525,7 +525,15 @@ int plan_wgrad(int dtype, const WgradArgs& a) {
 int launch_wgrad(int dtype, const WgradArgs& a, int splits, hipStream_t stream) {
   MI355_ARG(a.dy && a.x && a.partial, "wgrad: null pointer");
   MI355_ARG(!knobs().error[0], "%s", knobs().error);
-  if (splits > 0 && wg3_plan(dtype, a) == splits) return launch_wg3(a, splits, stream);
+  // the split count is a PLAN made earlier (context creation, or the per-op call a moment ago) from process-wide state — reserved CUs,
+  // the kernel switches: if that state changed in between, the launch would take a kernel the plan was not made for (and the caller's
+  // slab buffer was sized for the old plan).  Re-derive and refuse instead.  (fp8 twins always take the implicit-GEMM plan.)
+  if (dtype != MI355_FP8) {
+    const int now = plan_wgrad(dtype, a);
+    const int generic = plan_wgrad_splits(dtype, a.N * a.Ho * a.Wo, a.Cout, a.ntaps, a.Ck);
+    MI355_ARG(splits == now || splits == generic, "wgrad: %d splits were planned, the plan is now %d (reserved CUs / kernel switches changed after the plan was made)", splits, now);
+    if (splits == now && wg3_plan(dtype, a) == splits) return launch_wg3(a, splits, stream);
+  }
   MI355_ARG(a.Cout % 64 == 0 && a.Ck % 64 == 0, "wgrad: Cout=%d Ck=%d must be multiples of 64", a.Cout, a.Ck);
   MI355_ARG(splits >= 1, "wgrad: splits=%d", splits);
   MI355_ARG(((size_t)a.pix_stride * dtype_size(dtype)) % 8 == 0, "wgrad: pixel stride not 8-byte aligned");

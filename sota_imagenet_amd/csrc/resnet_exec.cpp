@@ -502,6 +502,12 @@ void plan_fp8(mi355_ctx* c) {
     l.fp8_fwd = igemm_fp8_legal(a, 1) && l.Cin * l.K * l.K >= 256;
     const int nclass = build_dgrad_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
     l.fp8_dgrad = nclass > 0 && igemm_fp8_legal(a, nclass) && !is_c1;
+    // Round 5: re-derived against the GENERATED bf16 kernels (profiles/r05_config5_conv_per_layer_{bf16,fp8}_224.txt, batch 512): the e4m3
+    // implicit-GEMM kernel loses to the direct 3x3 kernel of layer 2 (forward 114 against 139 us, data gradient 141 / 159) and to the
+    // resident-weight pointwise kernel on layer 3's conv3 forward (71 / 92); it still wins on layer 4's 3x3 (86 / 114), on every long
+    // 1x1 reduction (conv1 forward of layers 2-4, conv3's data gradient) and on the stride-2 / downsample launches of the first blocks.
+    if (l.K == 3 && l.stride == 1 && l.Cin == 128) l.fp8_fwd = l.fp8_dgrad = false;
+    if (l.K == 1 && l.stride == 1 && l.Cin == 256 && l.Cout == 1024) l.fp8_fwd = false;
     if (l.fp8_fwd || l.fp8_dgrad) l.qid_w = n++;
     if (l.fp8_dgrad) l.qid_dy = n++;
   };
@@ -528,6 +534,10 @@ void plan_fp8(mi355_ctx* c) {
     // (its forward reads it) and both channel counts are multiples of 128; the gradient twin is then written for conv1 too
     auto wg_plan = [&](ConvBN& l) {
       l.fp8_wgrad = c->fp8_use_wgrad && l.fp8_fwd && l.qid_in >= 0 && l.Cin % 128 == 0 && l.Cout % 128 == 0;
+      // (round 5: the generated bf16 weight-gradient kernels beat the e4m3 implicit-GEMM form on every stride-1 3x3 — 83-94 against
+      // 115-126 us — and on layer 4's 1x1s, 50 / 60; the e4m3 form keeps layer 2's conv1, 70 / 110, and the first blocks)
+      if (l.K == 3 && l.stride == 1) l.fp8_wgrad = false;
+      if (l.K == 1 && l.stride == 1 && l.Cin * l.Cout == 2048 * 512) l.fp8_wgrad = false;
       if (l.fp8_wgrad && l.qid_dy < 0) l.qid_dy = n++;
     };
     wg_plan(b.c1); wg_plan(b.c2); wg_plan(b.c3);

@@ -86,9 +86,13 @@ def conv2d_wgrad_fp8(dyq, xq, KH, KW, stride=1, pad=0, oscale=1.0):
     N, H, W, Cin = xq.shape
     Cout = dyq.shape[-1]
     n = _L().mi355_conv2d_workspace_bytes(native.BF16, N, H, W, Cin, Cout, KH, KW, stride, pad)
-    key = (dyq.device, n)
-    ws = _WGRAD_WS.get(key)  # split-K slabs + the two scale words: one workspace per (device, size), reused on the caller's stream
+    # split-K slabs + the two scale words: one workspace per (device, stream, size) — calls on different streams must not share slabs —
+    # and at most 8 of them (the oldest goes first)
+    key = (dyq.device, torch.cuda.current_stream(dyq.device).cuda_stream, n)
+    ws = _WGRAD_WS.get(key)
     if ws is None:
+        while len(_WGRAD_WS) >= 8:
+            _WGRAD_WS.pop(next(iter(_WGRAD_WS)))
         ws = _WGRAD_WS[key] = torch.empty(n + 256, dtype=torch.uint8, device=dyq.device)
     dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=dyq.device)
     check(_L().mi355_conv2d_wgrad_fp8(ptr(dyq), ptr(xq), ptr(dw), 0.0, float(oscale), N, H, W, Cin, Cout, KH, KW, stride, pad, ptr(ws), n + 256, cur_stream()))

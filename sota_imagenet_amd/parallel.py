@@ -79,18 +79,14 @@ class FlatBucketDDP(nn.Module):
         self._buckets = plan_buckets(module.grad_segments, int(bucket_cap_mb * (1 << 20) / 4))
         self._by_last = {last: (b, e) for b, e, last in self._buckets}
         self._nseg = len(module.grad_segments)
-        self._side = None
         backend = dist.get_backend(process_group)
         self._avg = backend == "nccl"  # ReduceOp.AVG is an (R)CCL op; gloo sums and we scale
         if self._cuda and hasattr(module, "set_comm"):
             self._native_init(flat.device, bucket_cap_mb, broadcast)
             return
-        if self._cuda:  # a flat model whose executor has no collective inside (bresnet.BResNet50: one backward call, one segment)
-            self._native_flat_init(flat.device, broadcast)
-            return
         if self._cuda:
-            self._side = torch.cuda.Stream(device=flat.device)
-        if broadcast:
+            raise RuntimeError("FlatBucketDDP: a flat-array model on the GPU must carry its collective inside the executor (set_comm)")
+        if broadcast:  # (CPU tensors from here on: the torch.distributed stand-in path of the gloo tests)
             self.broadcast_state()
         module._grad_sync = self._on_segment
         module._grad_sync_points = set(self._by_last)
@@ -120,39 +116,6 @@ class FlatBucketDDP(nn.Module):
         native_plan = self.module.bucket_plan(bucket_cap_mb)
         assert native_plan == self._buckets, (native_plan, self._buckets)  # one plan, stated twice (C++ / plan_buckets)
 
-    # ---- flat model, collective outside the executor: ONE native mean all-reduce over the whole flat gradient array, enqueued on
-    # the caller's stream right behind the single backward call (the optimizer step that follows on that stream sees the mean)
-    def _native_flat_init(self, device, broadcast):
-        from . import native
-
-        L = native.lib()
-        if not L.mi355_comm_available():
-            raise RuntimeError("FlatBucketDDP: librccl.so.1 not found (the MI355X data-parallel path has no fallback)")
-        rank = dist.get_rank(self.group)
-        uid = (ctypes.c_char * 128)()
-        if rank == 0:
-            native.check(L.mi355_comm_unique_id(uid))
-        box = [bytes(uid)]
-        dist.broadcast_object_list(box, src=0, group=self.group)
-        comm = ctypes.c_void_p()
-        native.check(L.mi355_comm_create(ctypes.byref(comm), box[0], self.world, rank, device.index or 0))
-        self._comm = comm
-        m = self.module
-        if broadcast:
-            st = native.cur_stream()
-            native.check(L.mi355_comm_broadcast(comm, native.ptr(m.flat_params), m.flat_params.numel(), 0, st))
-            native.check(L.mi355_comm_broadcast(comm, native.ptr(m._flat_buffers), m._flat_buffers.numel(), 0, st))
-
-        def on_backward(seg, begin, end):
-            if seg == self._nseg - 1 and not getattr(self, "_skip_sync", False):
-                native.check(L.mi355_comm_allreduce_mean(comm, native.ptr(m.flat_grads), m.flat_grads.numel(), native.cur_stream()))
-
-        m._grad_sync = on_backward
-        m._grad_sync_points = None
-
-    # ---- models without a flat gradient array (the per-op BResNet-50 graph): gradients are coalesced into one fp32 buffer
-    # when backward has finished, reduced with ONE native mean all-reduce (RCCL through the C-ABI), and copied back.
-    # No overlap with backward — that graph is driven op by op from Python and is launch-bound anyway.
     def _generic_init(self, bucket_cap_mb, broadcast):
         from . import native
 
@@ -272,17 +235,8 @@ class FlatBucketDDP(nn.Module):
             return
         rng = self._by_last.get(seg)
         if rng is not None:
-            view = self.module.flat_grads[rng[0]: rng[1]]
-            if self._cuda:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                with torch.cuda.stream(self._side):
-                    self._side.wait_event(ev)
-                    self._reduce(view)
-            else:
-                self._reduce(view)
-        if seg == self._nseg - 1 and self._cuda:
-            torch.cuda.current_stream().wait_stream(self._side)
+            # (CPU path only: on the GPU the executor reduces its own buckets, _native_init)
+            self._reduce(self.module.flat_grads[rng[0]: rng[1]])
 
     def _reduce(self, view):
         if self._avg:
