@@ -83,8 +83,11 @@ int mi355_conv2d_dgrad(int dtype, const void* dy, const void* w, void* dx, const
  * and, when `partial` is non-null, the BN-backward sums of the layer whose post-ReLU activation dx is the gradient of, as partial
  * rows [*nblk][2][Cin] floats: sum dz and sum dz * xhat, dz = dx (as stored) under bn_bits, xhat = (bn_y - bn_mean) * bn_invstd
  * (bn_y laid out like dx, masks one byte per 16-byte vector).  *nblk = 0 when the launch shape cannot produce them.
- * partial: >= 768 * 2 * Cin floats.  dx may alias addend.                                                                          */
-int mi355_conv2d_dgrad_bn(int dtype, const void* dy, const void* w, void* dx, const void* addend, const uint8_t* addend_bits,
+ * partial: >= 768 * 2 * Cin floats.  dx may alias addend.
+ * addend_sub2 = 1: `addend` is [N][H/2][W/2][Cin] and stands for the full-resolution tensor that is zero at odd rows / columns — the
+ * data gradient of the stride-2 1x1 downsample convolution of a stage's first block, which the executor then never writes at full size
+ * (bf16, 1x1 / stride 1 launches with even H and W; MI355_E_ARG elsewhere).                                                         */
+int mi355_conv2d_dgrad_bn(int dtype, const void* dy, const void* w, void* dx, const void* addend, const uint8_t* addend_bits, int addend_sub2,
                           const void* bn_y, const uint8_t* bn_bits, const float* bn_mean, const float* bn_invstd, float* partial,
                           size_t partial_bytes, int* nblk, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                           void* ws, size_t ws_bytes, void* stream);

@@ -42,7 +42,9 @@ class PoCfg:
     K: int            # input channels (reduction), multiple of 64
     BN: int           # output columns per workgroup (256 | 128)
     stats: int        # 0 none, 1 BN statistics of the output, 2 BN-backward sums
-    add: int = 0      # 0 no addend, 1 addend, 2 addend under its ReLU bit mask
+    add: int = 0      # 0 no addend, 1 addend, 2 addend under its ReLU bit mask, 3 addend given at HALF resolution: a compact [N][H/2][W/2][cols]
+                      # tensor that stands for a full-resolution one whose odd rows / columns are zero (the data gradient of a stride-2 1x1
+                      # convolution — the downsample branch of a stage's first block — which is then never written at full size)
     MFR: int = 4      # 16-pixel fragments per tile
     NBUF: int = 2     # A tile buffers
     weave: int = 1    # 1: two accumulator sets, the MFMAs of tile t + 1 issued between the epilogue instructions of tile t
@@ -87,7 +89,7 @@ class PoCfg:
 
     @property
     def L(self):      # vector-memory loads per item
-        return (2 if self.stats == 2 else 0) + self.add
+        return (2 if self.stats == 2 else 0) + (1 if self.add else 0) + (1 if self.add == 2 else 0)
 
     @property
     def FULL(self):   # full-line stores: a wave owns 128 bytes of every pixel row (two tile pairs), a store instruction writes 8 pixels x 128 bytes
@@ -96,7 +98,7 @@ class PoCfg:
 
 class Gen:
     KA = dict(in_=0, wt=8, out=16, stat=24, bn_y=32, bn_bits=40, bn_mean=48, bn_invstd=56, addend=64, addend_bits=72,
-              npix=80, ncols=84, tpg=88, ngroups=92, ntiles=96, lognct=100, size=128)
+              npix=80, ncols=84, tpg=88, ngroups=92, ntiles=96, lognct=100, W=104, H=108, magic_w=112, magic_h=116, size=128)
 
     def __init__(self, c: PoCfg):
         self.c = c
@@ -144,7 +146,14 @@ class Gen:
         self.v_out_m = [V.get() for m in range(c.MFR)]
         self.v_bits_m = [V.get() for m in range(c.MFR)] if (c.stats == 2 or c.add == 2) else None
         self.v_chan = V.get()
-        self.v_st_m = [V.get() for m in range(c.MFR)] if c.FULL else None   # full-line stores: (m*16 + (r & 7)) rows, chunk (r >> 3)*64 + kg*16
+        self.v_st_m = [V.get() for m in range(c.MFR)] if c.FULL else None
+        if c.add == 3:
+            self.v_ad_m = [V.get() for m in range(c.MFR)]   # this tile's half-resolution addend offsets (or out of range)
+            self.v_r = V.get()                              # lane & 15
+            self.v_col = V.get()                            # this lane's column bytes
+            self.s_kq = S.get(4, 4)                         # magic_w, magic_h, -, -
+            self.s_qpf = S.get()                            # first pixel of the prefetch tile
+            self.s_vcc2 = S.get(2, 2)   # full-line stores: (m*16 + (r & 7)) rows, chunk (r >> 3)*64 + kg*16
         # per-item operand registers
         self.it = []
         for i in range(c.NI):
@@ -215,6 +224,44 @@ class Gen:
                 "v_add_u32 %s, %d, %s" % (R("v", vt), blk4 * 32 * c.K * 2 + plane * 128, R("v", self.vA_dma)),
                 "buffer_load_dwordx4 %s, %s, 0 offen%s lds" % (R("v", vt), R("s", self.srdA, 4), " nt" if c.nt & 4 else "")]
 
+    def sub2_addr(self, m):
+        """add == 3: v_ad_m[m] = byte offset of pixel q = (prefetch tile's first pixel) + 16 m + (lane & 15) in the half-resolution addend, or an
+        out-of-range offset where the pixel has an odd row or column (the buffer then returns zeros: that pixel's addend is zero).
+        q = (n*H + h)*W + w;  the addend's pixel is (n*(H/2) + h/2)*(W/2) + w/2.  Divisions by multiplication with floor(2^32 / d) + 1:
+        exact while q * d < 2^32 (the host checks it)."""
+        c = self.c
+        if c.add != 3:
+            return []
+        t = [self.tv + i for i in range(6)]
+        q, a, w, n, h, x = (R("v", r) for r in t)
+        M, N, W, H = (R("s", self.s_kp + i) for i in (0, 1, 6, 7))
+        mw, mh = R("s", self.s_kq), R("s", self.s_kq + 1)
+        s0 = R("s", self.s_t3)
+        return ["s_add_u32 %s, %s, %d" % (s0, R("s", self.s_qpf), 16 * m),
+                "v_add_u32 %s, %s, %s" % (q, s0, R("v", self.v_r)),
+                "v_mul_hi_u32 %s, %s, %s" % (a, q, mw),                      # a = q / W
+                "v_mul_lo_u32 %s, %s, %s" % (x, a, W),
+                "v_sub_u32 %s, %s, %s" % (w, q, x),                          # w = q % W
+                "v_mul_hi_u32 %s, %s, %s" % (n, a, mh),                      # n = a / H
+                "v_mul_lo_u32 %s, %s, %s" % (x, n, H),
+                "v_sub_u32 %s, %s, %s" % (h, a, x),                          # h = a % H
+                "v_or_b32 %s, %s, %s" % (x, w, h),
+                "v_and_b32 %s, 1, %s" % (x, x),
+                "v_cmp_eq_u32 vcc, 0, %s" % x,                               # both even
+                "v_cmp_gt_u32 s[%d:%d], %s, %s" % (self.s_vcc2, self.s_vcc2 + 1, M, q),   # and a pixel of the tensor
+                "s_and_b64 vcc, vcc, s[%d:%d]" % (self.s_vcc2, self.s_vcc2 + 1),
+                "s_lshr_b32 %s, %s, 1" % (s0, H),
+                "v_lshrrev_b32 %s, 1, %s" % (h, h),
+                "v_mad_u32_u24 %s, %s, %s, %s" % (n, n, s0, h),              # n*(H/2) + h/2
+                "s_lshr_b32 %s, %s, 1" % (s0, W),
+                "v_lshrrev_b32 %s, 1, %s" % (w, w),
+                "v_mad_u32_u24 %s, %s, %s, %s" % (n, n, s0, w),              # ... *(W/2) + w/2
+                "s_lshl_b32 %s, %s, 1" % (s0, N),
+                "v_mul_lo_u32 %s, %s, %s" % (n, n, s0),
+                "v_add_u32 %s, %s, %s" % (n, n, R("v", self.v_col)),
+                "v_mov_b32 %s, 0x80000000" % x,
+                "v_cndmask_b32 %s, %s, %s, vcc" % (R("v", self.v_ad_m[m]), x, n)]
+
     def item_loads(self, i):
         """the epilogue operand loads of item i = (fragment m, pair p) from the PREFETCH descriptors"""
         c = self.c
@@ -229,7 +276,8 @@ class Gen:
             out.append("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["y"], 4), R("v", self.v_out_m[m]), R("s", self.srdY, 4), p * 64, nt) if not nobig else "s_nop 0")
             out.append("buffer_load_ubyte %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["yb"]), R("v", self.v_bits_m[m]), R("s", self.srdM, 4), p * 4, nt) if not nomask else "s_nop 0")
         if c.add:
-            out.append("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["ad"], 4), R("v", self.v_out_m[m]), R("s", self.srdAD, 4), p * 64, nt) if not nobig else "s_nop 0")
+            va = self.v_ad_m[m] if c.add == 3 else self.v_out_m[m]
+            out.append("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["ad"], 4), R("v", va), R("s", self.srdAD, 4), p * 64, nt) if not nobig else "s_nop 0")
         if c.add == 2:
             out.append("buffer_load_ubyte %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["ab"]), R("v", self.v_bits_m[m]), R("s", self.srdAB, 4), p * 4, nt) if not nomask else "s_nop 0")
         return out
@@ -248,7 +296,9 @@ class Gen:
         self.comment("---- prologue: kernel arguments, this workgroup's column tile and pixel run, descriptors, the weight slab into AGPRs")
         e("s_load_dwordx16 %s, s[0:1], 0x0" % R("s", ka, 16))
         e("s_load_dwordx4 %s, s[0:1], 0x40" % R("s", ka + 16, 4))
-        e("s_load_dwordx8 %s, s[0:1], 0x50" % R("s", kp, 8), "npix, ncols, tpg, ngroups, ntiles, lognct")
+        e("s_load_dwordx8 %s, s[0:1], 0x50" % R("s", kp, 8), "npix, ncols, tpg, ngroups, ntiles, lognct, W, H")
+        if c.add == 3:
+            e("s_load_dwordx4 %s, s[0:1], 0x70" % R("s", self.s_kq, 4), "floor(2^32 / W) + 1, floor(2^32 / H) + 1")
         lane, r, kg = v[0], v[1], v[2]
         e("v_lshrrev_b32 %s, 6, v0" % R("v", v[3]))
         e("v_and_b32 %s, 63, v0" % R("v", lane))
@@ -347,7 +397,17 @@ class Gen:
         self.desc_from(self.srdO, ka + 4, t0, t1, t2, "O")
         if c.stats == 2:
             self.desc_from(self.srdY, ka + 8, t0, t1, t2, "y of the BN layer")
-        if c.add:
+        if c.add == 3:
+            # the whole half-resolution tensor from this column tile's first column on: npix / 4 pixels
+            e("s_mul_i32 %s, %s, %d" % (R("s", t3), R("s", self.s_ct), c.BN * 2))
+            e("s_add_u32 %s, %s, %s" % (R("s", self.srdAD), R("s", ka + 16), R("s", t3)))
+            e("s_addc_u32 %s, %s, 0" % (R("s", self.srdAD + 1), R("s", ka + 17)))
+            e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdAD + 1), R("s", self.srdAD + 1)))
+            e("s_lshr_b32 %s, %s, 2" % (R("s", self.srdAD + 2), R("s", t2)))
+            e("s_sub_u32 %s, %s, %s" % (R("s", self.srdAD + 2), R("s", self.srdAD + 2), R("s", t3)))
+            e("s_mov_b32 %s, 0x00020000" % R("s", self.srdAD + 3))
+            e("s_mul_i32 %s, %s, %d" % (R("s", self.s_qpf), R("s", S_first), c.TP))
+        elif c.add:
             self.desc_from(self.srdAD, ka + 16, t0, t1, t2, "addend")
         if c.stats == 2 or c.add == 2:
             # mask bytes: 1/16 of the byte offsets
@@ -371,6 +431,9 @@ class Gen:
             if self.v_bits_m:
                 e("v_lshrrev_b32 %s, 4, %s" % (R("v", self.v_bits_m[m]), R("v", self.v_out_m[m])), "mask bytes: one per 16-byte vector")
         e("v_lshlrev_b32 %s, 5, %s" % (R("v", self.v_chan), R("v", kg)), "this lane's 8 floats of a per-channel row")
+        if c.add == 3:
+            e("v_mov_b32 %s, %s" % (R("v", self.v_r), R("v", r)))
+            e("v_mov_b32 %s, %s" % (R("v", self.v_col), R("v", v[6])))
         if c.FULL:
             # full-line stores: after the lane exchange of the epilogue a lane holds, of pixel m*16 + (r & 7) [store 1] and of pixel
             # m*16 + 8 + (r & 7) [store 2], the 16 bytes at w*128 + (r >> 3)*64 + kg*16: 8 lanes cover a pixel's 128 bytes
@@ -386,6 +449,10 @@ class Gen:
                 e("v_mul_lo_u32 %s, %s, %s" % (R("v", v[7]), R("v", v[7]), R("s", t1)))
                 e("v_add_u32 %s, %s, %s" % (R("v", self.v_st_m[m]), R("v", v[7]), R("v", v[8])))
         # ---- first tile's epilogue operands, then the prefetch descriptors move one tile ahead
+        e("s_waitcnt lgkmcnt(0)")
+        for m in range(c.MFR):
+            for ins in self.sub2_addr(m):
+                e(ins)
         for i in range(c.NI):
             for ins in self.item_loads(i):
                 e(ins)
@@ -425,9 +492,12 @@ class Gen:
                "s_cselect_b32 %s, %s, 0" % (R("s", self.s_ib), R("s", self.s_tbits)),
                "s_cselect_b32 %s, 1, 0" % R("s", self.s_t3),
                "s_sub_u32 %s, %s, %s" % (R("s", self.s_pf), R("s", self.s_pf), R("s", self.s_t3))]
+        if c.add == 3:
+            out += ["s_mul_i32 %s, %s, %d" % (R("s", self.s_t3), R("s", self.s_t3), c.TP),
+                    "s_add_u32 %s, %s, %s" % (R("s", self.s_qpf), R("s", self.s_qpf), R("s", self.s_t3))]
         if c.stats == 2:
             out += self.desc_adv(self.srdY, self.s_io) + self.desc_adv(self.srdM, self.s_ib)
-        if c.add:
+        if c.add in (1, 2):
             out += self.desc_adv(self.srdAD, self.s_io)
         if c.add == 2:
             out += self.desc_adv(self.srdAB, self.s_ib)
@@ -632,7 +702,7 @@ class Gen:
             nt = " nt" if c.nt & 2 else ""
             e("buffer_store_dwordx4 %s, %s, %s, 0 offen%s" % (R("v", A, 4), R("v", self.v_st_m[m]), R("s", self.srdO, 4), nt))
             e("buffer_store_dwordx4 %s, %s, %s, 0 offen%s" % (R("v", B, 4), R("v", vt), R("s", self.srdO, 4), nt))
-        for ins in self.item_loads(i0) + self.item_loads(i1):   # rolling refill: the same vectors of the NEXT tile
+        for ins in self.sub2_addr(m) + self.item_loads(i0) + self.item_loads(i1):   # rolling refill: the same vectors of the NEXT tile
             e(ins)
 
     def item(self, i, m, p, CW):
@@ -680,7 +750,7 @@ class Gen:
                         e("v_lshlrev_b32 %s, 16, %s" % (R("v", yv), R("v", d["y"] + k // 2)))
                     e("v_add_f32 %s, %s, %s" % (R("v", s1 + k), R("v", s1 + k), R("v", xr + k)))
                     e("v_fma_f32 %s, %s, %s, %s" % (R("v", s2 + k), R("v", xr + k), R("v", yv + (k & 1)), R("v", s2 + k)), "sum dz*y")
-        for ins in self.item_loads(i):   # rolling refill: the same vectors of the NEXT tile
+        for ins in (self.sub2_addr(m) if p == 0 else []) + self.item_loads(i):   # rolling refill: the same vectors of the NEXT tile
             e(ins)
 
     # -----------------------------------------------------------------------------------------------------------------
@@ -793,7 +863,7 @@ class Gen:
 def _variants():
     v = {}
     for (K, BN) in ((64, 256), (128, 256), (256, 256), (512, 128)):
-        for (st, add) in ((0, 0), (1, 0), (2, 0), (2, 1), (2, 2), (0, 1), (0, 2)):
+        for (st, add) in ((0, 0), (1, 0), (2, 0), (2, 1), (2, 2), (0, 1), (0, 2), (2, 3), (0, 3)):
             name = "po_k%d_b%d_s%d_a%d" % (K, BN, st, add)
             v[name] = PoCfg(name, K=K, BN=BN, stats=st, add=add)
     return v

@@ -79,6 +79,9 @@ struct IgemmArgs {
   void* out;           // [N][Hout][Wout][Ncols]
   const void* addend;  // optional, laid out like out
   const uint8_t* addend_bits = nullptr;  // optional ReLU mask of the addend (1 byte per 16-byte vector): masked before the add
+  int addend_sub2 = 0;  // 1: `addend` is a compact [N][Hout/2][Wout/2][Ncols] tensor standing for a full-resolution one whose odd rows /
+                        // columns are zero (the data gradient of a stride-2 1x1 convolution, never written at full size); only the
+                        // generated pointwise kernels take it (igemm_sub2_legal)
   int stat_rows_cap = 0;  // rows `stat_partial` can hold (0: the per-op API's 768); a launch never writes more partial rows than this
   float* stat_partial; // optional [stat_rows][2][Ncols]: per-workgroup-row sums of out and out^2 (BN statistics), or,
                        // when bn_y is set, of dz and dz*xhat (BN backward of the layer whose activation gradient `out`
@@ -116,6 +119,7 @@ struct WgradArgs {
 // ---- kernel launchers (all enqueue on `stream`, return mi355_status) -------------------------------
 // stat_rows (optional): number of partial rows written to a.stat_partial, 0 if the statistics were not produced
 int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows = nullptr);
+bool igemm_sub2_legal(int dtype, const IgemmArgs& a, int nclass);  // a launch with a.addend_sub2 has a kernel (else: materialise the addend)
 static constexpr size_t IGEMM_SK_FLAG_BYTES = 4096;  // 512 flags + an error word, padded
 static constexpr int IGEMM_SK_ERR_WORD = 512;        // index of the error word in the flag block: nonzero = a stream-K
                                                      // hand-off timed out in some launch that used this scratch

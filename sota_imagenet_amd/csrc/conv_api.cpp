@@ -334,7 +334,7 @@ int mi355_conv2d_dgrad(int dtype, const void* dy, const void* w, void* dx, const
   return launch_igemm(dtype, a, nclass, s);
 }
 
-int mi355_conv2d_dgrad_bn(int dtype, const void* dy, const void* w, void* dx, const void* addend, const uint8_t* addend_bits, const void* bn_y,
+int mi355_conv2d_dgrad_bn(int dtype, const void* dy, const void* w, void* dx, const void* addend, const uint8_t* addend_bits, int addend_sub2, const void* bn_y,
                           const uint8_t* bn_bits, const float* bn_mean, const float* bn_invstd, float* partial, size_t partial_bytes, int* nblk, int N,
                           int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
   MI355_TRY(check_conv(dtype, Cin, Cout, KH, KW, stride));
@@ -349,7 +349,8 @@ int mi355_conv2d_dgrad_bn(int dtype, const void* dy, const void* w, void* dx, co
   IgemmArgs a;
   const int nclass = build_dgrad_args(a, N, H, W, Cin, Cout, KH, KW, stride, pad);
   if (nclass < 0) return nclass;
-  a.in = dy; a.wt = ws; a.out = dx; a.addend = addend; a.addend_bits = addend_bits;
+  a.in = dy; a.wt = ws; a.out = dx; a.addend = addend; a.addend_bits = addend_bits; a.addend_sub2 = addend_sub2;
+  MI355_ARG(!addend_sub2 || igemm_sub2_legal(dtype, a, nclass), "dgrad_bn: no kernel takes a half-resolution addend for this launch (bf16 1x1 / stride 1, even H and W)");
   if (partial) {
     a.stat_partial = partial;
     a.stat_rows_cap = (int)std::min<size_t>(partial_bytes / ((size_t)2 * Cin * sizeof(float)), 1u << 20);

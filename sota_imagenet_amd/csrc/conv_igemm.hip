@@ -893,11 +893,13 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
   const long tiles128 = (long)cdiv(a.N * a.Hsub * a.Wsub, 128) * nclass * (a.Ncols / 128);
   static const int narrow_env = getenv("MI355_IGEMM_NARROW") ? atoi(getenv("MI355_IGEMM_NARROW")) : 0;  // A/B knob
   const bool wide = (a.Ncols % 128 == 0) && tiles128 * 2 >= device_cus() && !narrow_env;
+  MI355_ARG(dtype == MI355_BF16 || !a.addend_sub2, "igemm: a half-resolution addend needs the generated pointwise kernel (igemm_sub2_legal)");
   if (dtype == MI355_F32)
     return wide ? launch_t<float, 128, 128>(a, nclass, stream, stat_rows) : launch_t<float, 128, 64>(a, nclass, stream, stat_rows);
   if (dtype == MI355_BF16) {
     if (dconv_legal(a, nclass)) return launch_dconv(a, nclass, stream, stat_rows);
     if (po_legal(a, nclass)) return launch_po(a, nclass, stream, stat_rows);
+    MI355_ARG(!a.addend_sub2, "igemm: a half-resolution addend needs the generated pointwise kernel (igemm_sub2_legal)");
     if (pw_legal(a, nclass)) return launch_pw(a, nclass, stream, stat_rows);
     if (pk_legal(a, nclass)) return launch_pk(a, nclass, stream, stat_rows);
     {

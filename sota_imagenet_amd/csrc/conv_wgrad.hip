@@ -525,14 +525,16 @@ int plan_wgrad(int dtype, const WgradArgs& a) {
 int launch_wgrad(int dtype, const WgradArgs& a, int splits, hipStream_t stream) {
   MI355_ARG(a.dy && a.x && a.partial, "wgrad: null pointer");
   MI355_ARG(!knobs().error[0], "%s", knobs().error);
-  // the split count is a PLAN made earlier (context creation, or the per-op call a moment ago) from process-wide state — reserved CUs,
-  // the kernel switches: if that state changed in between, the launch would take a kernel the plan was not made for (and the caller's
-  // slab buffer was sized for the old plan).  Re-derive and refuse instead.  (fp8 twins always take the implicit-GEMM plan.)
-  if (dtype != MI355_FP8) {
-    const int now = plan_wgrad(dtype, a);
-    const int generic = plan_wgrad_splits(dtype, a.N * a.Ho * a.Wo, a.Cout, a.ntaps, a.Ck);
-    MI355_ARG(splits == now || splits == generic, "wgrad: %d splits were planned, the plan is now %d (reserved CUs / kernel switches changed after the plan was made)", splits, now);
-    if (splits == now && wg3_plan(dtype, a) == splits) return launch_wg3(a, splits, stream);
+  // The split count is a PLAN made earlier (context creation, or the per-op call a moment ago) from process-wide state — reserved CUs,
+  // the kernel switches.  If that state changed in between (the tile tests flip MI355_IGEMM8 between two backward calls of one context),
+  // the generated kernel the plan was made for may no longer be the one this launch takes: the implicit-GEMM kernel then runs with the
+  // planned count, which is fine as long as every split still has pixels — a split without any would leave its slab unwritten and
+  // splitk_reduce would add stale memory.  That case is refused.  (fp8 twins always take the implicit-GEMM plan.)
+  if (dtype != MI355_FP8 && splits > 0 && wg3_plan(dtype, a) == splits) return launch_wg3(a, splits, stream);
+  {
+    const long M = (long)a.N * a.Ho * a.Wo;
+    const long pps = (long)cdiv(cdiv((int)M, 64), splits > 0 ? splits : 1) * 64;
+    MI355_ARG(splits >= 1 && (long)(splits - 1) * pps < M, "wgrad: %d splits of %ld pixels leave a split without pixels (M = %ld): the plan is stale", splits, pps, M);
   }
   MI355_ARG(a.Cout % 64 == 0 && a.Ck % 64 == 0, "wgrad: Cout=%d Ck=%d must be multiples of 64", a.Cout, a.Ck);
   MI355_ARG(splits >= 1, "wgrad: splits=%d", splits);

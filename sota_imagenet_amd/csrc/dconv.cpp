@@ -498,10 +498,12 @@ bool plan_po(const IgemmArgs& a, int nclass, PoPlan* pl) {
   if (a.Hsub != a.Hin || a.Wsub != a.Win || a.Hout != a.Hin || a.Wout != a.Win) return false;
   if (a.pix_stride != a.Ck || a.q_scale_in != nullptr || a.q_scale_wt != nullptr) return false;
   const int stats = wanted_stats(a);
-  const int add = a.addend == nullptr ? 0 : (a.addend_bits != nullptr ? 2 : 1);
-  if (a.addend == nullptr && a.addend_bits != nullptr) return false;
+  const int add = a.addend == nullptr ? 0 : (a.addend_sub2 ? 3 : (a.addend_bits != nullptr ? 2 : 1));
+  if (a.addend == nullptr && (a.addend_bits != nullptr || a.addend_sub2)) return false;
+  if (a.addend_sub2 && (a.addend_bits != nullptr || a.Hout % 2 || a.Wout % 2)) return false;
   const long M = (long)a.N * a.Hin * a.Win;
   if (M * a.Ck * 2 >= (1L << 32) || M * a.Ncols * 2 >= (1L << 32)) return false;  // 32-bit num_records of the tile-by-tile descriptors
+  if (a.addend_sub2 && (M + 64) * (a.Wout > a.Hout ? a.Wout : a.Hout) >= (1L << 32)) return false;  // exactness of the kernel's divisions
   for (int i = 0; i < NPO; ++i) {
     const PoVariant& v = g_po[i];
     if (v.K != a.Ck || v.stats != stats || v.add != add || a.Ncols % v.BN != 0) continue;
@@ -539,11 +541,13 @@ bool po_legal(const IgemmArgs& a, int nclass) {
     //  - 512 -> 2048 forward (layer 4's conv3): pk's four-image tiles win by 2 us.
     const PoVariant& v = g_po[pl.vi];
     if (v.K == 64 && v.add != 0 && v.stats == 2) return false;
-    if (v.K == 512 && v.add != 0) return false;
+    if (v.K == 512 && (v.add == 1 || v.add == 2)) return false;
     if (v.K == 512 && a.Ncols >= 2048 && pk_legal(a, nclass)) return false;
   }
   return module_ok();
 }
+
+bool igemm_sub2_legal(int dtype, const IgemmArgs& a, int nclass) { return dtype == MI355_BF16 && a.addend_sub2 && po_legal(a, nclass); }
 
 int launch_po(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
   PoPlan pl;
@@ -562,8 +566,8 @@ int launch_po(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
     const float* bn_invstd;
     const void* addend;
     const void* addend_bits;
-    unsigned npix, ncols, tpg, ngroups, ntiles, lognct;
-    unsigned pad[6];
+    unsigned npix, ncols, tpg, ngroups, ntiles, lognct, W, H, magic_w, magic_h;
+    unsigned pad[2];
   } k;
   static_assert(sizeof(KArgs) == 128, "kernarg layout of asm/po_gen.py (Gen.KA)");
   MI355_ARG((int)sizeof(KArgs) == v.kernarg, "po: kernarg size mismatch");
@@ -584,6 +588,10 @@ int launch_po(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
   k.ngroups = pl.G;
   k.ntiles = pl.T;
   k.lognct = pl.lognct;
+  k.W = (unsigned)a.Wout;
+  k.H = (unsigned)a.Hout;
+  k.magic_w = (unsigned)((1ull << 32) / (unsigned)a.Wout + 1);  // q / W = mulhi(q, magic) while q * W < 2^32 (plan_po checks)
+  k.magic_h = (unsigned)((1ull << 32) / (unsigned)a.Hout + 1);
   size_t ksize = sizeof(k);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
   const hipError_t e = hipModuleLaunchKernel(d->po[pl.vi], pl.grid, 1, 1, 256, 1, 1, 0, stream, nullptr, extra);

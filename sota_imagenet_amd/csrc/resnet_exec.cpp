@@ -146,6 +146,9 @@ struct mi355_ctx {
   // gradients (dy3, dy_ds, dy2, dy1) of the blocks of parity p — two sets so that the weight-gradient stream may
   // still be reading block k's gradients while block k+1 is written
   void* gG[2] = {nullptr, nullptr};
+  void* gsub = nullptr;    // the downsample branch's data gradient at HALF resolution (first blocks of layers 2-4): conv1's data gradient
+                           // adds it at the even pixels (IgemmArgs::addend_sub2), the zero-filled full-size tensor is never written
+  bool ds_compact = true;  // MI355_DS_COMPACT=0: the stride-2 data gradient written at full size (A/B; the fp32 / fp8 paths always do)
   void* gset[MAX_GSETS][4] = {};
   size_t max_c = 64;  // widest BatchNorm of the network (sizes bn_partial)
   int nsets = 2;  // gradient buffer sets in rotation (MI355_GSETS, read at ctx creation): the main stream waits for the weight gradients of
@@ -374,12 +377,13 @@ int conv_wgrad(mi355_ctx* c, ConvBN& l, const void* dy, const void* x, float bet
 // dx = dgrad(dy) (+ addend under its mask).  bn (optional): the conv+BN layer whose post-ReLU activation dx is the
 // gradient of — the epilogue then also leaves that layer's BN-backward sums in bn_partial (bn->bwd_rows), which saves
 // the standalone reduce pass over dx and bn->y.
+// sub2: `addend` is the half-resolution tensor conv_dgrad_compact() left (IgemmArgs::addend_sub2)
 int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* addend, hipStream_t s,
-               const uint8_t* addend_bits = nullptr, ConvBN* bn = nullptr, const uint8_t* bn_bits = nullptr, float beta_acc = 0.f) {
+               const uint8_t* addend_bits = nullptr, ConvBN* bn = nullptr, const uint8_t* bn_bits = nullptr, float beta_acc = 0.f, bool sub2 = false) {
   IgemmArgs a;
   const int nclass = build_dgrad_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
   if (nclass < 0) return nclass;
-  a.in = dy; a.wt = l.w_tr; a.out = dx; a.addend = addend; a.addend_bits = addend_bits;
+  a.in = dy; a.wt = l.w_tr; a.out = dx; a.addend = addend; a.addend_bits = addend_bits; a.addend_sub2 = sub2 ? 1 : 0;
   a.sk_ws = sk_ws_of(c, s);
   if (bn && c->fuse_bn_bwd) {
     a.stat_partial = bn_partial_of(c, s);
@@ -389,7 +393,7 @@ int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* ad
   const double dx_elems = (double)c->N * l.Hin * l.Win * l.Cin;
   void* dyq = c->fp8_bwd_on && l.fp8_dgrad ? grad_twin(c, dy) : nullptr;
   // dy read, dx written, + the addend and (fused BN-backward sums) that layer's y read in the epilogue, masks at 1/16
-  const double by = dx_elems * (1 + (addend ? 1 : 0) + (a.bn_y ? 1 : 0)) * c->es + (double)c->N * l.Hout * l.Wout * l.Cout * (dyq ? 1 : c->es) +
+  const double by = dx_elems * (1 + (addend ? (sub2 ? 0.25 : 1) : 0) + (a.bn_y ? 1 : 0)) * c->es + (double)c->N * l.Hout * l.Wout * l.Cout * (dyq ? 1 : c->es) +
                     dx_elems * c->es / 16 * ((addend_bits ? 1 : 0) + (a.bn_y ? 1 : 0));
   Prof p(c, igemm_class(l.Cin), conv_flops(c, l), by, s, (l.K == 3 ? 1 : 0) | (dyq ? 2 : 0));
   int* rows = bn && c->fuse_bn_bwd ? &bn->bwd_rows : nullptr;
@@ -402,6 +406,38 @@ int conv_dgrad(mi355_ctx* c, ConvBN& l, const void* dy, void* dx, const void* ad
   }
   snprintf(l.k_dgrad, sizeof(l.k_dgrad), "%s", mi355_last_conv_kernel());
   return 0;
+}
+
+// the stride-2 1x1 downsample convolution's data gradient at the OUTPUT resolution: dxs[n][ho][wo] = dy[n][ho][wo] * W^T, i.e. the only
+// pixels of the full-size gradient that are not zero, as a dense 1x1 launch (the generated pointwise kernels instead of a four-class
+// implicit GEMM that writes 3/4 zeros)
+int conv_dgrad_compact(mi355_ctx* c, ConvBN& l, const void* dy, void* dxs, hipStream_t s) {
+  IgemmArgs a;
+  const int nclass = build_dgrad_args(a, c->N, l.Hout, l.Wout, l.Cin, l.Cout, 1, 1, 1, 0);
+  if (nclass < 0) return nclass;
+  a.in = dy; a.wt = l.w_tr; a.out = dxs;
+  const double px = (double)c->N * l.Hout * l.Wout;
+  Prof p(c, igemm_class(l.Cin), 2.0 * px * l.Cin * l.Cout, px * (l.Cin + l.Cout) * c->es, s, 0);
+  MI355_TRY(launch_igemm(c->dtype, a, nclass, s, nullptr));
+  snprintf(l.k_dgrad, sizeof(l.k_dgrad), "%s", mi355_last_conv_kernel());
+  return 0;
+}
+
+// conv1's data gradient of a first block can take the downsample gradient at half resolution (a generated kernel serves that launch)
+bool sub2_ok(mi355_ctx* c, Block& b, Block* prev) {
+  if (!c->ds_compact || c->dtype != MI355_BF16 || c->fp8 || !b.has_ds || b.ds.stride != 2 || b.ds.K != 1) return false;
+  IgemmArgs a;
+  ConvBN& l = b.c1;
+  const int nclass = build_dgrad_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
+  if (nclass < 0) return false;
+  a.in = a.wt = a.addend = (const void*)1;  // (geometry only: the legality test looks at which pointers are set, not where they point)
+  a.out = (void*)1;
+  a.addend_sub2 = 1;
+  if (prev && c->fuse_bn_bwd) {
+    a.stat_partial = (float*)1; a.bn_y = (const void*)1; a.bn_bits = (const uint8_t*)1; a.bn_mean = a.bn_invstd = (const float*)1;
+    a.stat_rows_cap = (int)((size_t)bn_max_blocks() * c->max_c / prev->c3.Cout);
+  }
+  return igemm_sub2_legal(c->dtype, a, nclass);
 }
 
 int plan_arena(mi355_ctx* c, Arena& ar) {
@@ -473,6 +509,7 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
   ar.add((void**)&c->bn_coef2, (size_t)3 * max_c * 4);
   ar.add((void**)&c->wg_partial, max_wg);
   for (int i = 0; i < 2; ++i) ar.add(&c->gG[i], max_act);
+  ar.add(&c->gsub, max_act / 4);
   for (int p = 0; p < c->nsets; ++p)
     for (int i = 0; i < 4; ++i) ar.add(&c->gset[p][i], max_act);
   if (c->fp8) {
@@ -704,6 +741,7 @@ int backward_block(mi355_ctx* c, Block& b, Block* prev, float beta_acc, hipStrea
   void** S = c->gset[par];
   void *B1 = S[0], *B2 = S[1], *B3 = S[2], *B4 = S[3];
   hipStream_t ws;
+  const bool sub2 = sub2_ok(c, b, prev);
   MI355_TRY(acquire_set(c, par, s));
   MI355_TRY(bn_backward(c, b.c3, G, b.out_bits, nullptr, B1, beta_acc, s));  // B1 = dy3
   MI355_TRY(fork(c, s, &ws));
@@ -711,7 +749,8 @@ int backward_block(mi355_ctx* c, Block& b, Block* prev, float beta_acc, hipStrea
   if (b.has_ds) {
     // the whole downsample branch runs beside the conv3 -> conv1 chain (same fork: it only needs G)
     MI355_TRY(bn_backward(c, b.ds, G, b.out_bits, nullptr, B2, beta_acc, ws));  // B2 = dyd
-    MI355_TRY(conv_dgrad(c, b.ds, B2, Gn, nullptr, ws));                        // Gn = shortcut gradient
+    if (sub2) MI355_TRY(conv_dgrad_compact(c, b.ds, B2, c->gsub, ws));           // gsub = shortcut gradient at half resolution
+    else MI355_TRY(conv_dgrad(c, b.ds, B2, Gn, nullptr, ws));                   // Gn = shortcut gradient
     if (c->overlap) MI355_HIP(hipEventRecord(c->ds_done, ws));
     MI355_TRY(conv_wgrad(c, b.ds, B2, b.in, beta_acc, ws));
   }
@@ -726,7 +765,7 @@ int backward_block(mi355_ctx* c, Block& b, Block* prev, float beta_acc, hipStrea
   if (b.has_ds) {
     if (c->overlap) MI355_HIP(hipStreamWaitEvent(s, c->ds_done, 0));
     // Gn = dx_in = conv1 dgrad + shortcut gradient (+ the sums of the previous block's bn3)
-    MI355_TRY(conv_dgrad(c, b.c1, B4, Gn, Gn, s, nullptr, prev ? &prev->c3 : nullptr, prev ? prev->out_bits : nullptr, beta_acc));
+    MI355_TRY(conv_dgrad(c, b.c1, B4, Gn, sub2 ? c->gsub : Gn, s, nullptr, prev ? &prev->c3 : nullptr, prev ? prev->out_bits : nullptr, beta_acc, sub2));
     c->cur_dout = Gn;
   } else {
     // G = dx_in = conv1 dgrad + masked G (+ the sums of the previous block's bn3)
@@ -953,6 +992,10 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
   c->stem_fused_bwd = !(sf && sf[0] == '0');
   const char* ov = getenv("MI355_WGRAD_STREAM");
   c->overlap = !(ov && ov[0] == '0');
+  {
+    const char* dc = getenv("MI355_DS_COMPACT");
+    c->ds_compact = !(dc && dc[0] == '0');
+  }
   if (c->overlap) {
     // the weight-gradient stream runs at the highest priority: it is the busier of the two during backward and the main stream ends
     // up waiting for it (profiles/r04_ab_side_stream_priority.txt: -0.07..-0.13 ms per step on three boxes); MI355_SIDE_PRIO=0 restores

@@ -139,6 +139,10 @@ def test_long_reduction_pointwise_kernels_are_exact_in_the_emulator(name, kw):
     ("po_k128_b256_s0_a2", dict(M=100, N=256, groups=((0, 0),))),
     ("po_k64_b256_s0_a1", dict(M=70, N=256, groups=((0, 0),))),
     ("po_k64_b256_s2_a0", dict(M=640, N=256, tpg=1, groups=((8, 0), (9, 0)))),
+    # the addend at half resolution (the downsample branch's data gradient: even pixels only), 10 x 20 / 4 x 6 / 6 x 10 pixel images
+    ("po_k256_b256_s2_a3", dict(M=400, N=512, HW=(10, 20), tpg=4, groups=((1, 1), (0, 0)))),
+    ("po_k128_b256_s0_a3", dict(M=192, N=256, HW=(4, 6), groups=((0, 0),))),
+    ("po_k512_b128_s2_a3", dict(M=120, N=256, HW=(6, 10), groups=((0, 1),))),
 ])
 def test_output_heavy_pointwise_kernels_are_exact_in_the_emulator(name, kw):
     """csrc/asm/po_gen.py (weights resident in AGPRs, rolling refill of the epilogue operands): every (K, BN) family with each epilogue —

@@ -143,6 +143,29 @@ def _check_dgrad_bn(dev, dx, part, dy, w, ad, abits, y, ybits, mean, invstd, add
         assert part is None
 
 
+@pytest.mark.parametrize("N,H,Cx,Cy,fam", [(256, 56, 256, 128, "po_k128_b256"), (256, 28, 512, 256, "po_k256_b256"), (256, 14, 1024, 512, "po_k512_b128"), (6, 28, 512, 256, "po_k256_b256")])
+@pytest.mark.parametrize("sums", [True, False])
+def test_conv1_data_gradient_with_the_downsample_gradient_at_half_resolution(dev, N, H, Cx, Cy, fam, sums):
+    """the first block of a stage: conv1's data gradient adds the downsample branch's gradient, which exists only at the even pixels
+    (stride-2 1x1 convolution): the kernel takes it as the compact [N][H/2][W/2][C] tensor (addend_sub2) — same bits as adding the
+    zero-filled full-size tensor"""
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(13)
+    dy = torch.randint(-2, 3, (N, H, H, Cy), device=dev).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (Cy, 1, 1, Cx), device=dev).to(torch.bfloat16)
+    adc = torch.randint(-3, 4, (N, H // 2, H // 2, Cx), device=dev).to(torch.bfloat16)
+    full = torch.zeros((N, H, H, Cx), device=dev, dtype=torch.bfloat16)
+    full[:, ::2, ::2] = adc
+    y = torch.randint(-3, 4, (N, H, H, Cx), device=dev).to(torch.bfloat16) if sums else None
+    ybits = torch.randint(0, 256, (N, H, H, Cx // 8), device=dev, dtype=torch.uint8) if sums else None
+    mean = (torch.randint(-4, 5, (Cx,), device=dev) * 0.25).float() if sums else None
+    invstd = (torch.randint(1, 5, (Cx,), device=dev) * 0.5).float() if sums else None
+    dx, part = ops.conv2d_dgrad_bn(dy, w, (N, H, H, Cx), 1, 0, addend=adc, addend_sub2=True, bn_y=y, bn_bits=ybits, bn_mean=mean, bn_invstd=invstd)
+    assert ops.last_conv_kernel() == "%s_s%d_a3" % (fam, 2 if sums else 0)
+    _check_dgrad_bn(dev, dx, part, dy, w, full, None, y, ybits, mean, invstd, 1, sums)
+
+
 def test_bn_backward_sums_of_the_data_gradient_against_the_oracle(dev):
     """the same launch against oracle/ops_ref at a batch the CPU oracle handles: y -> BatchNorm (batch statistics) -> ReLU, the data
     gradient of the next conv as the gradient of that activation; the partial rows must add up to the oracle's dbeta / dgamma / (gamma = 1)"""

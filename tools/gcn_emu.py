@@ -679,6 +679,10 @@ class Emulator:
         a, b = self._v2(wv, ins)
         self._vw(wv, ins, a * b)
 
+    def i_v_mul_hi_u32(self, wv, ins):
+        a, b = self._v2(wv, ins)
+        self._vw(wv, ins, (a.astype(np.uint64) * b.astype(np.uint64)) >> np.uint64(32))
+
     def i_v_mul_u32_u24(self, wv, ins):
         a, b = self._v2(wv, ins)
         self._vw(wv, ins, (a & 0xFFFFFF) * (b & 0xFFFFFF))

@@ -31,7 +31,7 @@ def wg_of(g, ct, nct):
     return ((g // 8) * nct + ct) * 8 + g % 8
 
 
-def run(name, M=200, N=None, groups=((0, 0),), tpg=None, seed=0, check=True, extra_wgs=(), **over):
+def run(name, M=200, N=None, groups=((0, 0),), tpg=None, seed=0, check=True, extra_wgs=(), HW=(10, 20), **over):
     c, g, text = po_gen.generate(name, **over)
     N = N or c.BN
     rng = np.random.default_rng(seed)
@@ -42,6 +42,15 @@ def run(name, M=200, N=None, groups=((0, 0),), tpg=None, seed=0, check=True, ext
     x = rng.integers(-2, 3, size=(M, c.K)).astype(np.float32)
     w = rng.integers(-2, 3, size=(N, c.K)).astype(np.float32)
     ad = rng.integers(-3, 4, size=(M, N)).astype(np.float32)
+    H, W = HW
+    if c.add == 3:
+        # the addend at half resolution: M = images * H * W pixels; only pixels with even row and column have one
+        assert M % (H * W) == 0 and H % 2 == 0 and W % 2 == 0
+        nimg = M // (H * W)
+        adc = rng.integers(-3, 4, size=(nimg, H // 2, W // 2, N)).astype(np.float32)
+        full = np.zeros((nimg, H, W, N), dtype=np.float32)
+        full[:, ::2, ::2] = adc
+        ad = full.reshape(M, N)
     abits = rng.integers(0, 256, size=(M, N // 8)).astype(np.uint8)
     yb = rng.integers(-3, 4, size=(M, N)).astype(np.float32)
     bits = rng.integers(0, 256, size=(M, N // 8)).astype(np.uint8)
@@ -53,11 +62,12 @@ def run(name, M=200, N=None, groups=((0, 0),), tpg=None, seed=0, check=True, ext
     a_out = mem.alloc(out0)
     a_stat = mem.alloc(np.full((G, 2, N), np.nan, dtype=np.float32))
     a_y, a_bits, a_mu, a_is = mem.alloc(to_bf16_bits(yb)), mem.alloc(bits), mem.alloc(mean), mem.alloc(invstd)
-    a_ad, a_ab = mem.alloc(to_bf16_bits(ad)), mem.alloc(abits)
+    a_ad, a_ab = mem.alloc(to_bf16_bits(adc if c.add == 3 else ad)), mem.alloc(abits)
     lognct = nct.bit_length() - 1
     assert 1 << lognct == nct
     ka = gcn_emu.pack_kernarg([("q", a_in), ("q", a_wt), ("q", a_out), ("q", a_stat), ("q", a_y), ("q", a_bits), ("q", a_mu), ("q", a_is), ("q", a_ad), ("q", a_ab),
-                               ("I", M), ("I", N), ("I", tpg), ("I", G), ("I", T), ("I", lognct)] + [("I", 0)] * 6)
+                               ("I", M), ("I", N), ("I", tpg), ("I", G), ("I", T), ("I", lognct), ("I", W), ("I", H), ("I", (1 << 32) // W + 1), ("I", (1 << 32) // H + 1),
+                               ("I", 0), ("I", 0)])
     assert len(ka) == po_gen.Gen.KA["size"], len(ka)
     a_ka = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     total = 0
@@ -71,7 +81,7 @@ def run(name, M=200, N=None, groups=((0, 0),), tpg=None, seed=0, check=True, ext
     got = from_bf16_bits(mem.array(a_out, np.uint16, out0.shape)).astype(np.float64)
     ref = (x.astype(np.float64) @ w.astype(np.float64).T).astype(np.float32)
     if c.add:
-        amask = ((abits[..., None] >> np.arange(8)) & 1).reshape(M, N).astype(np.float32) if c.add == 2 else np.ones((M, N), dtype=np.float32)
+        amask = ((abits[..., None] >> np.arange(8)) & 1).reshape(M, N).astype(np.float32) if c.add == 2 else np.ones((M, N), dtype=np.float32)  # (add == 3: `ad` is the zero-filled full tensor)
         ref = ref + ad * amask
     refr = bf16_round(ref).astype(np.float64)
     res = {"insts": total, "cfg": c}
