@@ -33,7 +33,7 @@ EVENT_STEPS = 1  # timed steps whose conv / BN launches carry HIP-event pairs fo
 HBM_CLASS = 7  # executor profile class of bn_bwd_apply_kernel, the largest HBM-bound kernel of the step
 # profile class -> kernel symbols (template instances of one source; names as tools/pmc_traffic.py writes them)
 KERNEL_NAMES = {0: ["igemm_kernel<{T},128,128>", "igemm_kernel<{T},256,256>", "igemm_kernel<{T},256,128>", "igemm8_kernel<224,256>", "igemm8_kernel<256,128>",
-                    "dconv_l2", "dconv_l3", "dconv_l4", "pw_k256_n1024", "pk_k1024_n256_w196", "pk_k2048_n512_w98", "pk_k512_n256_w196", "pk_k1024_n512_w196", "pk_k512_n2048_w196", "pk_k512_n128_w196", "pk_k256_n128_w196",
+                    "dconv_l2", "dconv_l3", "dconv_l4", "pw_k256_n1024", "pk_k1024_n256_w196", "pk_k2048_n512_w98", "pk_k512_n256_w196", "pk_k1024_n512_w196", "pk_k512_n2048_w196", "pk_k512_n128_w196",
                     "po_k64_b256", "po_k128_b256", "po_k256_b256", "po_k512_b128"],  # (bf16 only: the generated assembly kernels of asm/dconv_gen.py, pw_gen.py, pk_gen.py, po_gen.py; class by Cout % 128 as the executor files them)
                 1: ["igemm_kernel<{T},128,64>", "dconv_l1"],
                 # (wg3_* / wg1_*: the generated kernels of asm/wg_gen.py / asm/wg1_gen.py, bf16 only; class by Cout % 128 as the executor files them)

@@ -430,9 +430,8 @@ def _variants():
             # (not shipped: 256 -> 1024, layer 3 conv3 forward — 4 chunks per workgroup; 57-61 us against 47.7 us of pw_gen.py's resident-K kernel)
             (512, 2048, 196, 2, (0, 1)),
             # layer 2 (28 x 28): conv1 forward 512 -> 128 and conv3 data gradient: 128-column tiles (two 16-column tiles per wave)
-            (512, 128, 196, 2, (0, 1, 2), 2),
-            # layer 2's first block: conv1 forward 256 -> 128 at 56 x 56 (it runs before the stride)
-            (256, 128, 196, 2, (0, 1), 2))
+            (512, 128, 196, 2, (0, 1, 2), 2))
+    # (not shipped: 256 -> 128 at 56 x 56, layer 2's first conv1 — 173 us against 156 us of the implicit-GEMM kernel, profiles/r05_*)
     # the same families with tiles of 200 / 100 pixels: the pixel counts of the 160 px and 320 px stages of the progressive-resize recipe
     # (BASELINE configs[4]: 10 x 10 and 20 x 20 at layer 3, 5 x 5 and 10 x 10 at layer 4) are multiples of 100, not of 49
     for (K, N, W, NB, stats, *rest) in fam + tuple((K, N, {196: 200, 98: 100}[W], NB, st, *rest) for (K, N, W, NB, st, *rest) in fam):

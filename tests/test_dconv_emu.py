@@ -112,7 +112,6 @@ def test_pointwise_weight_gradient_kernels_are_exact_in_the_emulator(name, kw):
                                      ("pk_k2048_n512_w98_s1", dict(tiles=(1,), ntile=1, Cin=320)), ("pk_k2048_n512_w98_s2", dict(tiles=(0,), ntile=1, Cin=192)),
                                      ("pk_k1024_n256_w196_s0", dict(tiles=(0,), Cin=64)), ("pk_k2048_n512_w98_s0", dict(tiles=(2,), Cin=384)),
                                      ("pk_k512_n128_w196_s1", dict(tiles=(1,), Cin=192)), ("pk_k512_n128_w196_s2", dict(tiles=(0,), Cin=128)),
-                                     ("pk_k256_n128_w196_s1", dict(tiles=(1,))),
                                      # tiles of 200 / 100 pixels (the 160 px and 320 px stages)
                                      ("pk_k1024_n256_w200_s2", dict(tiles=(1,), Cin=192)), ("pk_k2048_n512_w100_s1", dict(tiles=(0, 2), ntile=1, Cin=128)),
                                      ("pk_k512_n128_w200_s2", dict(tiles=(1,), Cin=128))])

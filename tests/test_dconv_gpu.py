@@ -17,7 +17,7 @@ SHAPES = [(256, 14, 256, 256, 3), (256, 7, 512, 512, 3), (256, 28, 128, 128, 3),
 SHAPES_OTHER = [(32, 40, 64, 64, 3, "dconv_l1a"), (32, 20, 128, 128, 3, "dconv_l2a"), (64, 10, 256, 256, 3, "dconv_l3a"), (64, 5, 512, 512, 3, "dconv_l4a"),
                 (8, 80, 64, 64, 3, "dconv_l1b"), (16, 40, 128, 128, 3, "dconv_l2b"), (32, 20, 256, 256, 3, "dconv_l3b"), (64, 10, 512, 512, 3, "dconv_l4b"),
                 (64, 10, 1024, 256, 1, "pk_k1024_n256_w200"), (64, 5, 2048, 512, 1, "pk_k2048_n512_w100"), (32, 20, 512, 128, 1, "po_k512_b128"),
-                (16, 40, 256, 128, 1, "pk_k256_n128_w200"), (64, 10, 1024, 512, 1, "pk_k1024_n512_w200")]
+                (64, 10, 1024, 512, 1, "pk_k1024_n512_w200")]
 
 
 def _ref(x, w, K):
