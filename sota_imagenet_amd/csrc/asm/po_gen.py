@@ -47,6 +47,8 @@ class PoCfg:
                       # convolution — the downsample branch of a stage's first block — which is then never written at full size)
     MFR: int = 4      # 16-pixel fragments per tile
     NBUF: int = 2     # A tile buffers
+    tmask: int = 1    # 1: the ReLU mask bytes of a whole 64-pixel tile by ONE load per mask tensor (lane = pixel, 8 or 4 bytes = this wave's columns),
+                      #    handed to the lanes that need them by ds_bpermute; 0: one byte load per (fragment, tile pair) and lane
     weave: int = 1    # 1: two accumulator sets, the MFMAs of tile t + 1 issued between the epilogue instructions of tile t
     nt: int = 0       # non-temporal cache policy: 1 epilogue operand loads, 2 output stores, 4 A pieces
     probe: int = 0    # timing probes (WRONG results): 1 no MFMAs, 2 no epilogue arithmetic, 4 no operand loads, 8 no stores
@@ -88,8 +90,16 @@ class PoCfg:
         return self.MFR * self.NT // 2
 
     @property
+    def NM(self):     # mask tensors (BN layer's ReLU bits, addend's ReLU bits)
+        return (1 if self.stats == 2 else 0) + (1 if self.add == 2 else 0)
+
+    @property
     def L(self):      # vector-memory loads per item
-        return (2 if self.stats == 2 else 0) + (1 if self.add else 0) + (1 if self.add == 2 else 0)
+        return (1 if self.stats == 2 else 0) + (1 if self.add else 0) + (0 if self.tmask else self.NM)
+
+    @property
+    def NMT(self):    # mask loads per tile (tmask)
+        return self.NM if self.tmask else 0
 
     @property
     def FULL(self):   # full-line stores: a wave owns 128 bytes of every pixel row (two tile pairs), a store instruction writes 8 pixels x 128 bytes
@@ -124,7 +134,7 @@ class Gen:
     def gen(self):
         c, S, V = self.c, self.S, self.V
         assert c.BN in (128, 256) and c.K % 64 == 0 and c.MFR % 2 == 0 and c.NT % 2 == 0
-        assert (c.L + 1) * c.NI + c.NPW <= 63, "vmcnt range"
+        assert (c.L + 1) * c.NI + c.NPW + c.NMT <= 63, "vmcnt range"
         assert c.LDS <= 160 * 1024
         self.s_wg = 2
         self.srdA, self.srdB, self.srdO, self.srdX = S.get(4, 4), S.get(4, 4), S.get(4, 4), S.get(4, 4)
@@ -144,7 +154,14 @@ class Gen:
         self.vA_dma = V.get()
         self.v_tmp = [V.get(), V.get()]
         self.v_out_m = [V.get() for m in range(c.MFR)]
-        self.v_bits_m = [V.get() for m in range(c.MFR)] if (c.stats == 2 or c.add == 2) else None
+        self.v_bits_m = [V.get() for m in range(c.MFR)] if (c.NM and not c.tmask) else None
+        if c.NMT:
+            nd = c.NT // 2                       # dwords of a pixel's mask bytes owned by this wave (4 bytes per tile pair)
+            self.v_mk = V.get()                  # lane = pixel: byte offset of its mask bytes
+            self.v_bp = V.get()                  # (lane & 15) * 4: ds_bpermute address of fragment 0's pixel (+ 64 m by the offset field)
+            self.v_kg8 = V.get()                 # (lane >> 4) * 8: this lane's byte of a tile pair's dword
+            self.mk = {T: [V.get(nd, 2) for b in range(2)] for T in (["y"] if c.stats == 2 else []) + (["a"] if c.add == 2 else [])}
+            self.mkt = {T: [V.get() for p in range(nd)] for T in self.mk}   # the unit's mask dwords after the permute / shift
         self.v_chan = V.get()
         self.v_st_m = [V.get() for m in range(c.MFR)] if c.FULL else None
         if c.add == 3:
@@ -163,9 +180,9 @@ class Gen:
             if c.add:
                 d["ad"] = V.get(4, 4)
             if c.stats == 2:
-                d["yb"] = V.get()
+                d["yb"] = self.mkt["y"][i % (c.NT // 2)] if c.tmask else V.get()
             if c.add == 2:
-                d["ab"] = V.get()
+                d["ab"] = self.mkt["a"][i % (c.NT // 2)] if c.tmask else V.get()
             self.it.append(d)
         npair = c.NT // 2
         self.s1 = [V.get(8, 4) for p in range(npair)] if c.stats else None
@@ -262,6 +279,34 @@ class Gen:
                 "v_mov_b32 %s, 0x80000000" % x,
                 "v_cndmask_b32 %s, %s, %s, vcc" % (R("v", self.v_ad_m[m]), x, n)]
 
+    def mask_loads(self, buf):
+        """tmask: the mask bytes of the PREFETCH tile, lane = pixel, into mask buffer buf"""
+        c = self.c
+        if not c.NMT or (c.probe & 4):
+            return []
+        op = "buffer_load_dwordx2" if c.NT == 4 else "buffer_load_dword"
+        out = []
+        for T in self.mk:
+            srd = self.srdM if T == "y" else self.srdAB
+            out.append("%s %s, %s, %s, 0 offen" % (op, R("v", self.mk[T][buf], c.NT // 2), R("v", self.v_mk), R("s", srd, 4)) if not (c.probe & 16) else "s_nop 0")
+        return out
+
+    def mask_fetch(self, m, buf):
+        """tmask: this lane's mask dwords of fragment m (pixel m*16 + (lane & 15) lives in lane m*16 + (lane & 15) of the tile's mask
+        registers), shifted so that bit k of the low byte is the bit of this lane's element k"""
+        c = self.c
+        if not c.NMT or (c.probe & 4):
+            return []
+        out = []
+        for T in self.mk:
+            for p in range(c.NT // 2):
+                out.append("ds_bpermute_b32 %s, %s, %s offset:%d" % (R("v", self.mkt[T][p]), R("v", self.v_bp), R("v", self.mk[T][buf] + p), 64 * m))
+        out.append("s_waitcnt lgkmcnt(0)")
+        for T in self.mk:
+            for p in range(c.NT // 2):
+                out.append("v_lshrrev_b32 %s, %s, %s" % (R("v", self.mkt[T][p]), R("v", self.v_kg8), R("v", self.mkt[T][p])))
+        return out
+
     def item_loads(self, i):
         """the epilogue operand loads of item i = (fragment m, pair p) from the PREFETCH descriptors"""
         c = self.c
@@ -274,12 +319,14 @@ class Gen:
         nomask, nobig = c.probe & 16, c.probe & 32   # (probes: the mask-byte loads / the 16-byte loads replaced by a scalar no-op each: same counts)
         if c.stats == 2:
             out.append("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["y"], 4), R("v", self.v_out_m[m]), R("s", self.srdY, 4), p * 64, nt) if not nobig else "s_nop 0")
-            out.append("buffer_load_ubyte %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["yb"]), R("v", self.v_bits_m[m]), R("s", self.srdM, 4), p * 4, nt) if not nomask else "s_nop 0")
+            if not c.tmask:
+                out.append("buffer_load_ubyte %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["yb"]), R("v", self.v_bits_m[m]), R("s", self.srdM, 4), p * 4, nt) if not nomask else "s_nop 0")
         if c.add:
             va = self.v_ad_m[m] if c.add == 3 else self.v_out_m[m]
             out.append("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["ad"], 4), R("v", va), R("s", self.srdAD, 4), p * 64, nt) if not nobig else "s_nop 0")
         if c.add == 2:
-            out.append("buffer_load_ubyte %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["ab"]), R("v", self.v_bits_m[m]), R("s", self.srdAB, 4), p * 4, nt) if not nomask else "s_nop 0")
+            if not c.tmask:
+                out.append("buffer_load_ubyte %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["ab"]), R("v", self.v_bits_m[m]), R("s", self.srdAB, 4), p * 4, nt) if not nomask else "s_nop 0")
         return out
 
     def frag_reads(self, fset, ks, buf):
@@ -431,6 +478,13 @@ class Gen:
             if self.v_bits_m:
                 e("v_lshrrev_b32 %s, 4, %s" % (R("v", self.v_bits_m[m]), R("v", self.v_out_m[m])), "mask bytes: one per 16-byte vector")
         e("v_lshlrev_b32 %s, 5, %s" % (R("v", self.v_chan), R("v", kg)), "this lane's 8 floats of a per-channel row")
+        if c.NMT:
+            e("s_lshr_b32 %s, %s, 3" % (R("s", t3), R("s", N)), "mask bytes of a pixel row")
+            e("v_mul_lo_u32 %s, %s, %s" % (R("v", self.v_mk), R("v", lane), R("s", t3)))
+            e("s_mul_i32 %s, %s, %d" % (R("s", t3), R("s", self.s_w), c.NT * 2))
+            e("v_add_u32 %s, %s, %s" % (R("v", self.v_mk), R("s", t3), R("v", self.v_mk)), "lane = pixel of the tile: its mask bytes for this wave's columns")
+            e("v_lshlrev_b32 %s, 2, %s" % (R("v", self.v_bp), R("v", r)))
+            e("v_lshlrev_b32 %s, 3, %s" % (R("v", self.v_kg8), R("v", kg)))
         if c.add == 3:
             e("v_mov_b32 %s, %s" % (R("v", self.v_r), R("v", r)))
             e("v_mov_b32 %s, %s" % (R("v", self.v_col), R("v", v[6])))
@@ -453,6 +507,8 @@ class Gen:
         for m in range(c.MFR):
             for ins in self.sub2_addr(m):
                 e(ins)
+        for ins in self.mask_loads(0):
+            e(ins)
         for i in range(c.NI):
             for ins in self.item_loads(i):
                 e(ins)
@@ -548,6 +604,8 @@ class Gen:
 
     def epilogue_tile(self, CW):
         c = self.c
+        for ins in self.mask_loads(self.mbuf ^ 1):   # the NEXT tile's mask bytes (waited for by the next tile's first counted wait: they are older)
+            self.e(ins)
         if c.FULL:
             for m in range(c.MFR):
                 self.unit(m, CW)
@@ -576,7 +634,8 @@ class Gen:
         top, done = self.newlabel("loop"), self.newlabel("done")
         # younger than an item's (a fragment's) loads when it waits for them: the stores + refills of the other items (fragments) of a
         # tile and the A pieces requested at the top of this tile's trip
-        CW = ((c.L + 1) * (c.NI - 1) if not c.FULL else 2 * (c.L + 1) * (c.MFR - 1)) + c.NPW
+        CW = ((c.L + 1) * (c.NI - 1) if not c.FULL else 2 * (c.L + 1) * (c.MFR - 1)) + c.NPW + c.NMT
+        TOPW = c.NI * (c.L + 1) + c.NMT   # younger than a tile's A pieces at the top of the trip that needs them
         if c.weave:
             self.comment("---- first tile: its MFMAs alone (A buffer 0 -> accumulator set 0), the second tile requested")
             e("s_barrier")
@@ -597,7 +656,7 @@ class Gen:
             if c.weave:
                 # at the top of the trip of tile t: tile t + 1 (requested a trip ago) has landed for every wave; buffer b (tile t: its MFMAs ran
                 # in the previous trip) takes tile t + 2
-                e("s_waitcnt vmcnt(%d)" % (c.NI * (c.L + 1)), "tile t + 1's A pieces have landed (younger: the last trip's stores and refills)")
+                e("s_waitcnt vmcnt(%d)" % TOPW, "tile t + 1's A pieces have landed (younger: the last trip's stores and refills)")
                 e("s_barrier")
                 for jj in range(c.NPW):
                     for ins in self.a_piece(jj, b):
@@ -605,12 +664,13 @@ class Gen:
                 for ins in self.a_advance():
                     e(ins)
                 self.accset = b
+                self.mbuf = b
                 epi = self.capture(self.epilogue_tile, CW)
                 mfm = self.capture(self.mfma_phase, nb, nb)
                 for ins in self.weave(epi, mfm):
                     self.out.append(ins)
             else:
-                e("s_waitcnt vmcnt(%d)" % (c.NI * (c.L + 1)), "this tile's A pieces have landed (younger: the last tile's stores and refills)")
+                e("s_waitcnt vmcnt(%d)" % TOPW, "this tile's A pieces have landed (younger: the last tile's stores and refills)")
                 e("s_barrier")
                 for jj in range(c.NPW):
                     for ins in self.a_piece(jj, nb):
@@ -618,6 +678,7 @@ class Gen:
                 for ins in self.a_advance():
                     e(ins)
                 self.accset = 0
+                self.mbuf = b
                 self.mfma_phase(b, 0)
                 # (the accumulators are read by VALU instructions: the matrix pipe must have retired the last MFMAs)
                 e("s_nop 15")
@@ -685,8 +746,10 @@ class Gen:
         i0, i1 = 2 * m, 2 * m + 1
         A, B, C = self.dsets[(2 * m) % 4], self.dsets[(2 * m + 1) % 4], self.v_xc
         self.comment("fragment %d" % m)
-        if c.L and not (c.probe & 4):
+        if (c.L or c.NMT) and not (c.probe & 4):
             e("s_waitcnt vmcnt(%d)" % CW)
+        for ins in self.mask_fetch(m, self.mbuf):
+            e(ins)
         self.pair_math(i0, m, 0, A)
         self.pair_math(i1, m, 1, B)
         e("s_nop 1")
@@ -711,8 +774,11 @@ class Gen:
         tv, xr, yv, vm = self.tv, self.xr, self.yv, self.v_m
         ds = self.dsets[i % 4]
         self.comment("item %d: fragment %d, tile pair %d" % (i, m, p))
-        if c.L and not (c.probe & 4):
+        if (c.L or c.NMT) and not (c.probe & 4):
             e("s_waitcnt vmcnt(%d)" % CW)
+        if p == 0:
+            for ins in self.mask_fetch(m, self.mbuf):
+                e(ins)
         for k in range(4):
             e("v_accvgpr_read_b32 %s, a%d" % (R("v", tv + k), self.acc(m, 2 * p) + k))
             e("v_accvgpr_read_b32 %s, a%d" % (R("v", tv + 4 + k), self.acc(m, 2 * p + 1) + k))

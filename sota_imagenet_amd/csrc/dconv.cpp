@@ -536,12 +536,11 @@ bool po_legal(const IgemmArgs& a, int nclass) {
     // MI355_PO=1 (default): the measured rule, per launch shape of the bs-256 step in a serial trace (profiles/r05_ab_po_*.txt):
     //  - 64 -> 256 under the shortcut addend + BN-backward sums (layer 1's conv1 data gradient, 1.39 GB per launch): the implicit-GEMM
     //    kernel streams it at 5.5 TB/s with two workgroups per CU out of phase, this kernel at 5.1: stays there;
-    //  - K = 512 with an addend (layer 4's conv1 data gradient): 128-column tiles give a wave 64 bytes of a pixel row (half-line
-    //    stores) and re-stage the 64 KiB pixel tile for 16 column tiles: 74 us against 67;
+    //  - (K = 512 with an addend, layer 4's conv1 data gradient: 74 us against 67 with one mask byte load per lane and item; 63 with the
+    //    tile-wide mask loads: served here since)
     //  - 512 -> 2048 forward (layer 4's conv3): pk's four-image tiles win by 2 us.
     const PoVariant& v = g_po[pl.vi];
     if (v.K == 64 && v.add != 0 && v.stats == 2) return false;
-    if (v.K == 512 && (v.add == 1 || v.add == 2)) return false;
     if (v.K == 512 && a.Ncols >= 2048 && pk_legal(a, nclass)) return false;
   }
   return module_ok();

@@ -207,13 +207,13 @@ def test_conv3_forward_of_layers_1_and_2_takes_the_resident_weight_kernel(dev, N
     assert torch.equal(ops.conv2d_fwd(x, w, 1, 0), ref) and ops.last_conv_kernel() == fam + "_s0_a0"
 
 
-def test_the_default_rule_keeps_three_launch_shapes_on_the_older_kernels(dev):
-    """MI355_PO=1 (default): layer 1's and layer 4's conv1 data gradient (shortcut addend + BN-backward sums) stay on the implicit-GEMM
-    kernel, layer 4's conv3 forward on the long-reduction kernel — and their results are the same bits"""
+def test_the_default_rule_keeps_two_launch_shapes_on_the_older_kernels(dev):
+    """MI355_PO=1 (default): layer 1's conv1 data gradient (shortcut addend + BN-backward sums) stays on the implicit-GEMM kernel, layer 4's
+    conv3 forward on the long-reduction kernel — and their results are the same bits"""
     from sota_imagenet_amd import ops
 
     torch.manual_seed(11)
-    for (N, H, Cx, Cy, want) in ((64, 56, 256, 64, "igemm<bf16,"), (64, 7, 2048, 512, "igemm<bf16,")):
+    for (N, H, Cx, Cy, want) in ((64, 56, 256, 64, "igemm<bf16,"), (64, 7, 2048, 512, "po_k512_b128_s2_a2")):
         dy = torch.randint(-2, 3, (N, H, H, Cy), device=dev).to(torch.bfloat16)
         w = torch.randint(-2, 3, (Cy, 1, 1, Cx), device=dev).to(torch.bfloat16)
         ad = torch.randint(-3, 4, (N, H, H, Cx), device=dev).to(torch.bfloat16)

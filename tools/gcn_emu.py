@@ -948,6 +948,20 @@ class Emulator:
             wv.pending_v[r] = rec
         wv.lgkm_ops.append(rec)
 
+    def i_ds_bpermute_b32(self, wv, ins):
+        """backward permute through the LDS crossbar (no LDS memory): lane i receives src of lane ((addr[i] + offset) / 4) % 64"""
+        dst, addr_o, src_o = ins.ops
+        addrs = self._ds_addr(wv, ins, addr_o)
+        src = self.vval(wv, src_o, ins)
+        val = src[(addrs // 4) % 64]
+        mask = self.lanes(wv)
+        wv.v[dst.idx] = np.where(mask, val, wv.v[dst.idx])
+        rec = {"kind": "lds", "vgprs": [dst.idx]}
+        if self.check and dst.idx in wv.pending_v:
+            self.err(ins, "v%d is the destination of two loads in flight" % dst.idx)
+        wv.pending_v[dst.idx] = rec
+        wv.lgkm_ops.append(rec)
+
     def i_ds_read_b64(self, wv, ins):
         self._ds_read(wv, ins, 8)
 
