@@ -309,9 +309,9 @@ class Gen:
             # this lane's 8 channels per tile pair.  The sets of pairs 0 and 1 are loaded in the PROLOGUE (the main loop does not
             # touch these registers), pairs 2 and 3 under the arithmetic of pairs 0 and 1.
             self.ysets = [[V.get(4, 4) for m in range(c.MFR)] for _ in range(2)]
-            self.bsets = [[V.get() for m in range(c.MFR)] for _ in range(2)]
             self.msets = [V.get(16, 4) for _ in range(2)]   # mean[8], invstd[8]
-            self.v_bits, self.v_chan = V.get(), V.get()
+            self.v_chan = V.get()
+            self.alloc_tile_masks()
         self.nvgpr = V.n
         self.accum_offset = (self.nvgpr + 7) // 8 * 8
         self.nagpr = c.MFR * c.NT * 4
@@ -539,7 +539,7 @@ class Gen:
             # of the main loop is unaffected), so the epilogue finds them in registers
             descriptors_out()
             lane_out()
-            e("v_lshrrev_b32 %s, 4, %s" % (R("v", self.v_bits), R("v", self.v_out)), "mask bytes: one per 16-byte output vector")
+            self.tile_mask_loads()
             e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_wn), c.NT * 16 * 4))
             e("v_lshl_add_u32 %s, %s, 5, %s" % (R("v", self.v_chan), R("v", self.v_kg), R("s", t0)), "this lane's 8 floats of mean / invstd")
             self.epi_issue_loads(0)
@@ -848,19 +848,95 @@ class Gen:
                     e("s_cselect_b32 exec_lo, 0x%x, exec_lo" % (masks[wm] & 0xFFFFFFFF))
                     e("s_cselect_b32 exec_hi, 0x%x, exec_hi" % (masks[wm] >> 32))
 
+    # ---- ReLU mask bytes of the BN-backward sums: the whole tile's bytes by one load per 64 positions (lane = position: the NT*2 bytes of
+    # this wave's columns), handed to the lanes that need them by ds_bpermute — a byte load per lane and (fragment, tile pair) costs as
+    # many cache-line requests as a 16-byte load (profiles/r05_po_probe_matrix.txt: 10-13 us per launch)
+    def alloc_tile_masks(self):
+        c, V = self.c, self.V
+        self.MKG = (c.MFR + 3) // 4                                  # groups of 4 fragments = 64 positions
+        nd = c.NT // 2                                               # dwords per position: 4 bytes (4 lane groups) per tile pair
+        self.mk = [V.get(nd, min(nd, 4)) for j in range(self.MKG)]
+        self.v_mkoff = V.get()
+        self.v_bp = V.get()
+        self.v_kg8 = V.get()
+        self.v_mb = V.get()
+
+    def tile_mask_loads(self):
+        """prologue (EXEC all ones): lane l of group j holds position 64 j + l of this wave row = fragment 4 j + (l >> 4), row r = l & 15"""
+        c, e = self.c, self.e
+        if c.probe & 8:
+            return
+        v = self.v_t
+        l4, r, off, t = v[3], v[1], self.v_mkoff, v[4]
+        nd = c.NT // 2
+        op = {1: "buffer_load_dword", 2: "buffer_load_dwordx2", 4: "buffer_load_dwordx4"}[nd]
+        rowb = c.NCOLS // 8                                          # mask bytes of a pixel
+        e("v_lshrrev_b32 %s, 4, %s" % (R("v", l4), R("v", v[0])), "lane >> 4 (v_t[0] = lane)")
+        e("v_lshlrev_b32 %s, 2, %s" % (R("v", self.v_bp), R("v", r)))
+        e("v_lshlrev_b32 %s, 3, %s" % (R("v", self.v_kg8), R("v", self.v_kg)))
+        # pixel part of lane r inside a fragment, in mask bytes
+        if c.P >= 16:
+            e("v_mul_u32_u24 %s, %d, %s" % (R("v", t), rowb, R("v", r)))
+        else:   # P == 8: two image rows per fragment
+            e("v_lshrrev_b32 %s, 3, %s" % (R("v", t), R("v", r)))
+            e("v_mul_u32_u24 %s, %d, %s" % (R("v", t), c.W, R("v", t)))
+            e("v_and_b32 %s, 7, %s" % (R("v", off), R("v", r)))
+            e("v_add_u32 %s, %s, %s" % (R("v", t), R("v", t), R("v", off)))
+            e("v_mul_u32_u24 %s, %d, %s" % (R("v", t), rowb, R("v", t)))
+        e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t1), R("s", self.s_wn), c.NT * 2))
+        e("v_add_u32 %s, %s, %s" % (R("v", t), R("s", self.s_t1), R("v", t)), "+ this wave's first mask byte of a pixel")
+        for j in range(self.MKG):
+            # per (wave row, 16-lane group k): the fragment's first pixel in mask bytes, and which of its 16 rows are pixels
+            consts, masks = [], []
+            for wm in range(c.WM):
+                cw, mw = [], 0
+                for k in range(4):
+                    f = 4 * j + k
+                    if f < c.MFR:
+                        fm, fo = self.frag_out(wm * c.MFR + f)
+                        cw.append(fo // (c.NCOLS * 2) * rowb)
+                        mw |= (fm & 0xFFFF) << (16 * k)
+                    else:
+                        cw.append(0)
+                consts.append(cw)
+                masks.append(mw)
+            e("v_mov_b32 %s, 0x80000000" % R("v", off), "positions that are no pixel: out of range (the load returns zeros)")
+            for k in range(4):
+                e("s_mov_b32 %s, %d" % (R("s", self.s_t0), consts[0][k]))
+                for wm in range(1, c.WM):
+                    if consts[wm][k] != consts[0][k]:
+                        e("s_cmp_eq_u32 %s, %d" % (R("s", self.s_wm), wm))
+                        e("s_cselect_b32 %s, %d, %s" % (R("s", self.s_t0), consts[wm][k], R("s", self.s_t0)))
+                e("s_mov_b32 exec_lo, 0x%x" % ((masks[0] >> (16 * k) & 0xFFFF) << (16 * k) & 0xFFFFFFFF))
+                e("s_mov_b32 exec_hi, 0x%x" % (((masks[0] >> (16 * k) & 0xFFFF) << (16 * k)) >> 32))
+                for wm in range(1, c.WM):
+                    if masks[wm] != masks[0]:
+                        mk = (masks[wm] >> (16 * k) & 0xFFFF) << (16 * k)
+                        e("s_cmp_eq_u32 %s, %d" % (R("s", self.s_wm), wm))
+                        e("s_cselect_b32 exec_lo, 0x%x, exec_lo" % (mk & 0xFFFFFFFF))
+                        e("s_cselect_b32 exec_hi, 0x%x, exec_hi" % (mk >> 32))
+                e("v_add_u32 %s, %s, %s" % (R("v", off), R("s", self.s_t0), R("v", t)))
+            e("s_mov_b64 exec, -1")
+            e("%s %s, %s, %s, 0 offen" % (op, R("v", self.mk[j], nd), R("v", off), R("s", self.srdM, 4)))
+
+    def tile_mask_fetch(self, m, p):
+        """v_mb = the mask dword of (fragment m, tile pair p), shifted so that bit k of its low byte is this lane's element k (EXEC all ones)"""
+        return ["s_mov_b64 exec, -1",
+                "ds_bpermute_b32 %s, %s, %s offset:%d" % (R("v", self.v_mb), R("v", self.v_bp), R("v", self.mk[m // 4] + p), 64 * (m % 4)),
+                "s_waitcnt lgkmcnt(0)",
+                "v_lshrrev_b32 %s, %s, %s" % (R("v", self.v_mb), R("v", self.v_kg8), R("v", self.v_mb))]
+
     def epi_issue_loads(self, p):
         """BN-backward inputs of tile pair p into register set p & 1"""
         c, e = self.c, self.e
         k = p & 1
         if c.probe & 8:
-            for i in range(2 * c.MFR + 4):
+            for i in range(c.MFR + 4):
                 e("s_nop 0")
             return
         for m in range(c.MFR):
             self.emit_frag(m, set_mask=False)
-            e("s_lshr_b32 %s, %s, 4" % (R("s", self.s_t1), R("s", self.s_t0)))
             e("buffer_load_dwordx4 %s, %s, %s, %s offen offset:%d" % (R("v", self.ysets[k][m], 4), R("v", self.v_out), R("s", self.srdY, 4), R("s", self.s_t0), p * 64))
-            e("buffer_load_ubyte %s, %s, %s, %s offen offset:%d" % (R("v", self.bsets[k][m]), R("v", self.v_bits), R("s", self.srdM, 4), R("s", self.s_t1), p * 4))
         for h in range(2):
             e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", self.msets[k] + 4 * h, 4), R("v", self.v_chan), R("s", self.srdMu, 4), p * 128 + 16 * h))
             e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", self.msets[k] + 8 + 4 * h, 4), R("v", self.v_chan), R("s", self.srdIs, 4), p * 128 + 16 * h))
@@ -880,9 +956,9 @@ class Gen:
         assert base + 51 <= self.F[1][1] + 4 * c.NT
         npair = c.NT // 2
         if c.stats == 2:
-            ysets, bsets, msets = self.ysets, self.bsets, self.msets
+            ysets, msets = self.ysets, self.msets
             issue_loads = self.epi_issue_loads
-            GL = 2 * c.MFR + 4
+            GL = c.MFR + 4
         e("s_waitcnt vmcnt(0)")
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier", "every LDS-DMA of the (unused) lookahead has landed: the ring is free for the statistics scratch")
@@ -907,6 +983,9 @@ class Gen:
                 # pair p's loads were issued behind pair p - 2; younger: pair p - 1's stores (+ pair p + 1's loads)
                 e("s_waitcnt vmcnt(%d)" % (0 if c.probe & 40 else c.MFR + (GL if p + 1 < npair else 0)))
             for m in range(c.MFR):
+                if c.stats == 2 and not (c.probe & 24):
+                    for ins in self.tile_mask_fetch(m, p):
+                        e(ins)
                 self.emit_frag(m)
                 d = dsets[m % 4]
                 for i in range(4):
@@ -927,7 +1006,7 @@ class Gen:
                         e("v_add_f32 %s, %s, %s" % (R("v", s1[i]), R("v", s1[i]), R("v", xr[i])))
                         e("v_fma_f32 %s, %s, %s, %s" % (R("v", s2[i]), R("v", xr[i]), R("v", xr[i]), R("v", s2[i])))
                 if c.stats == 2 and not (c.probe & 16):
-                    yr, br = ysets[p & 1][m], bsets[p & 1][m]
+                    yr, br = ysets[p & 1][m], self.v_mb
                     for i in range(8):
                         t = tv[i]  # (the accumulator copies are dead after the conversion)
                         e("v_bfe_i32 %s, %s, %d, 1" % (R("v", t), R("v", br), i), "0 / -1: ReLU mask bit of element %d" % i)

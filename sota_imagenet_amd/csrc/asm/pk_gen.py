@@ -102,8 +102,8 @@ class Gen(dconv_gen.Gen):
             # start of the epilogue INTO the fragment registers (free by then; the epilogue's temporaries use the first 51 of them)
             self.late_pair1 = c.MFR > 8 and c.NT >= 4
             if c.NT < 4:  # one tile pair per wave: one register set
-                y0, b0, m0 = [V.get(4, 4) for m in range(c.MFR)], [V.get() for m in range(c.MFR)], V.get(16, 4)
-                self.ysets, self.bsets, self.msets = [y0, y0], [b0, b0], [m0, m0]
+                y0, m0 = [V.get(4, 4) for m in range(c.MFR)], V.get(16, 4)
+                self.ysets, self.msets = [y0, y0], [m0, m0]
             elif self.late_pair1:
                 f0, f1 = self.F[0][0], self.F[1][0]
                 free = list(range(f0 + 52, f0 + 4 * c.MFR + 16)) + list(range(f1, f1 + 4 * c.MFR + 16))
@@ -113,17 +113,13 @@ class Gen(dconv_gen.Gen):
                 rest4 = [r for r in free4 if r not in used]
                 m1 = rest4[:4]
                 assert len(y1) == c.MFR and len(m1) == 4 and m1 == list(range(m1[0], m1[0] + 16, 4)), "no room for the late register set"
-                used |= {r + i for r in m1 for i in range(4)}
-                b1 = [r for r in free if r not in used][:c.MFR]
-                assert len(b1) == c.MFR
                 self.ysets = [[V.get(4, 4) for m in range(c.MFR)], y1]
-                self.bsets = [[V.get() for m in range(c.MFR)], b1]
                 self.msets = [V.get(16, 4), m1[0]]
             else:
                 self.ysets = [[V.get(4, 4) for m in range(c.MFR)] for _ in range(2)]
-                self.bsets = [[V.get() for m in range(c.MFR)] for _ in range(2)]
                 self.msets = [V.get(16, 4) for _ in range(2)]
-            self.v_bits, self.v_chan = V.get(), V.get()
+            self.v_chan = V.get()
+            self.alloc_tile_masks()
         self.nvgpr = V.n
         self.accum_offset = (self.nvgpr + 7) // 8 * 8
         self.nagpr = c.MFR * c.NT * 4
@@ -317,7 +313,7 @@ class Gen(dconv_gen.Gen):
         if c.stats == 2:
             descriptors_out()
             lane_out()
-            e("v_lshrrev_b32 %s, 4, %s" % (R("v", self.v_bits), R("v", self.v_out)), "mask bytes: one per 16-byte output vector")
+            self.tile_mask_loads()
             e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_wn), c.NT * 16 * 4))
             e("v_lshl_add_u32 %s, %s, 5, %s" % (R("v", self.v_chan), R("v", self.v_kg), R("s", t0)), "this lane's 8 floats of mean / invstd")
             self.epi_issue_loads(0)

@@ -166,6 +166,38 @@ def test_conv1_data_gradient_with_the_downsample_gradient_at_half_resolution(dev
     _check_dgrad_bn(dev, dx, part, dy, w, full, None, y, ybits, mean, invstd, 1, sums)
 
 
+# (N, H, channels of dx, channels of dy, kernel size, family): conv2's data gradient (3x3: the BN-backward sums of bn1) and conv3's (long 1x1 reduction: bn2)
+S2_OTHER = [(256, 56, 64, 64, 3, "dconv_l1"), (256, 28, 128, 128, 3, "dconv_l2"), (256, 14, 256, 256, 3, "dconv_l3"), (256, 7, 512, 512, 3, "dconv_l4"),
+            (256, 14, 256, 1024, 1, "pk_k1024_n256_w196"), (256, 7, 512, 2048, 1, "pk_k2048_n512_w98"), (256, 28, 128, 512, 1, "po_k512_b128"),
+            (64, 10, 256, 256, 3, "dconv_l3a"), (64, 5, 512, 512, 3, "dconv_l4a"), (16, 40, 128, 128, 3, "dconv_l2b"), (8, 80, 64, 64, 3, "dconv_l1b"),
+            (64, 10, 256, 1024, 1, "pk_k1024_n256_w200")]
+
+
+@pytest.mark.parametrize("N,H,Cx,Cy,K,fam", S2_OTHER)
+def test_bn_backward_sums_epilogue_of_the_3x3_and_long_reduction_kernels_is_exact(dev, N, H, Cx, Cy, K, fam):
+    """every `_s2` variant of dconv / pk (and po without an addend) through mi355_conv2d_dgrad_bn: dx bit for bit, the partial rows against
+    fp64 sums of the same integer tensors (round 4 checked these epilogues only through the executor)"""
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(14)
+    dy = torch.randint(-2, 3, (N, H, H, Cy), device=dev).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (Cy, K, K, Cx), device=dev).to(torch.bfloat16)
+    y = torch.randint(-3, 4, (N, H, H, Cx), device=dev).to(torch.bfloat16)
+    ybits = torch.randint(0, 256, (N, H, H, Cx // 8), device=dev, dtype=torch.uint8)
+    mean, invstd = (torch.randint(-4, 5, (Cx,), device=dev) * 0.25).float(), (torch.randint(1, 5, (Cx,), device=dev) * 0.5).float()
+    dx, part = ops.conv2d_dgrad_bn(dy, w, (N, H, H, Cx), 1, K // 2, bn_y=y, bn_bits=ybits, bn_mean=mean, bn_invstd=invstd)
+    assert ops.last_conv_kernel().startswith(fam + "_s2"), ops.last_conv_kernel()
+    ref = torch.nn.functional.conv_transpose2d(dy.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=K // 2).permute(0, 2, 3, 1).to(torch.bfloat16)
+    assert torch.equal(dx, ref)
+    bit = ((ybits.reshape(-1, Cx // 8, 1).to(torch.int32) >> torch.arange(8, device=dev, dtype=torch.int32)) & 1).reshape(-1, Cx)
+    dz = ref.reshape(-1, Cx).double() * bit
+    xhat = (y.double().reshape(-1, Cx) - mean.double()) * invstd.double()
+    s1, s2 = dz.sum(0), (dz * xhat).sum(0)
+    assert part is not None and part.shape[1:] == (2, Cx)
+    assert (part[:, 0].double().sum(0) - s1).abs().max() <= 1e-6 * max(1.0, s1.abs().max().item())
+    assert (part[:, 1].double().sum(0) - s2).abs().max() <= 1e-6 * max(1.0, s2.abs().max().item())
+
+
 def test_bn_backward_sums_of_the_data_gradient_against_the_oracle(dev):
     """the same launch against oracle/ops_ref at a batch the CPU oracle handles: y -> BatchNorm (batch statistics) -> ReLU, the data
     gradient of the next conv as the gradient of that activation; the partial rows must add up to the oracle's dbeta / dgamma / (gamma = 1)"""
