@@ -134,6 +134,7 @@ def test_long_reduction_pointwise_kernels_are_exact_in_the_emulator(name, kw):
     ("po_k256_b256_s0_a0", dict(M=64, N=256, groups=((0, 0),))),
     ("po_k512_b128_s2_a2", dict(M=150, N=1024, tpg=2, groups=((1, 7), (0, 2)))),            # 128-column tiles: one tile pair per wave
     ("po_k512_b128_s1_a0", dict(M=128, N=256, groups=((0, 1),))),
+    ("po_k256_b128_s1_a0", dict(M=200, N=128, tpg=2, groups=((1, 0),))),                    # 256 -> 128 (layer 2's first conv1): ragged last tile
     ("po_k128_b256_s2_a2", dict(M=330, N=512, tpg=4, groups=((1, 0), (0, 1)))),
     ("po_k128_b256_s0_a2", dict(M=100, N=256, groups=((0, 0),))),
     ("po_k64_b256_s0_a1", dict(M=70, N=256, groups=((0, 0),))),

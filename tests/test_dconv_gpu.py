@@ -222,7 +222,8 @@ def test_bn_backward_sums_of_the_data_gradient_against_the_oracle(dev):
     assert (s[1] - dgamma.double()).abs().max() <= 1e-4 * dgamma.abs().max()
 
 
-@pytest.mark.parametrize("N,H,Cin,Cout,fam", [(256, 56, 64, 256, "po_k64_b256"), (256, 28, 128, 512, "po_k128_b256"), (7, 28, 128, 512, "po_k128_b256")])
+@pytest.mark.parametrize("N,H,Cin,Cout,fam", [(256, 56, 64, 256, "po_k64_b256"), (256, 28, 128, 512, "po_k128_b256"), (7, 28, 128, 512, "po_k128_b256"),
+                                                (256, 56, 256, 128, "po_k256_b128"), (5, 20, 256, 128, "po_k256_b128")])
 def test_conv3_forward_of_layers_1_and_2_takes_the_resident_weight_kernel(dev, N, H, Cin, Cout, fam):
     from sota_imagenet_amd import ops
 
