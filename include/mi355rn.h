@@ -324,6 +324,7 @@ int mi355_resnet50_segment_range(const mi355_ctx* ctx, int seg, size_t* grad_beg
 int mi355_resnet50_backward(mi355_ctx* ctx, const float* dlogits, int seg_begin, int seg_end,
                             int accumulate, void* stream);
 
+
 /* ---- BResNet-50 (BASELINE configs[3]) as a static executor — csrc/bresnet_exec.cpp -------------------------------------
  * The model the reference builds with `_target_: pytorch_tools.models.resnet50` and the model_params of
  * configs/_old_configs/_first_attempts/BResNet50_encoder.yaml:41-51 (deep stem, anti-aliasing, ECA, leaky-ReLU ABN, drop-connect,
@@ -365,6 +366,13 @@ int mi355_bresnet50_segment_range(const mi355_bctx* ctx, int seg, size_t* grad_b
 int mi355_bresnet50_bucket_plan(const mi355_bctx* ctx, double bucket_cap_mb, int cap, int* n_out, size_t* begins, size_t* ends, int* last_segs);
 int mi355_bresnet50_set_comm(mi355_bctx* ctx, mi355_comm* comm, double bucket_cap_mb);
 int mi355_bresnet50_set_grad_sync(mi355_bctx* ctx, int on);
+
+/* Test hook of the BResNet-50 executor (as mi355_resnet50_debug_tensor): device pointer / shape of a tensor of the last forward, by
+ * name: "<conv>.y" (conv output, channels padded to a multiple of 64), "<bn>.out" (where the last forward stored it: bn3 / the
+ * downsample BN are applied inside the fused ECA pass by default and have none), "<bn>.save_mean|save_invstd", "stem.p" (the
+ * anti-aliased pool's output = layer1.0's input), "<block>.out|gate|keep|a2b|scin" (block output, ECA gate [N][C], drop-connect
+ * scales [N] when sampled, blur-pooled a2 / average-pooled input of a striding block).  Read-only use.                             */
+int mi355_bresnet50_debug_tensor(const mi355_bctx* ctx, const char* name, void** ptr, int* dtype, int* ndim, int shape[4]);
 
 /* ---- gradient collective inside the boundary: RCCL over xGMI, one process per GPU ---------------------------------
  * replaces torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) — train.py:113-114, process group
@@ -450,10 +458,18 @@ int mi355_resnet50_kernel_table(const mi355_ctx* ctx, char* out, size_t cap, siz
 /* Test hook: device pointer / shape of an internal tensor of the last step, by name:
  *   "<conv>.y" raw conv output, "<block>.a1|a2|out" post-activation tensors (e.g. "layer1.0.out"),
  *   "<bn>.save_mean|save_invstd", "stem.p0" (the stem's BN+ReLU+maxpool output; the 112x112 activation itself
- *   is never stored), "pooled", "dpooled", "gG0".."gG1" (block-output gradients of the last backward).
+ *   is never stored), "pooled", "dpooled", "gG0".."gG1" (block-output gradients of the last backward),
+ *   "grad.cur" (between two backward segments: the gradient the next segment starts from).
  * shape is NHWC (ndim 4) or [n] / [N,C]; dtype is MI355_F32 or the ctx dtype.  Read-only use.     */
 int mi355_resnet50_debug_tensor(const mi355_ctx* ctx, const char* name, void** ptr, int* dtype, int* ndim,
                                 int shape[4]);
+/* Test hook (teacher forcing): between two calls of mi355_resnet50_backward() that split the segments, replace the gradient the next
+ * segment starts from ("grad.cur": wrt that block's output, or wrt the stem's pooled output before the last segment) by `g` (device
+ * memory, the ctx dtype, exactly the tensor's bytes).  The BN-backward sums the producing kernel's epilogue left for that tensor are
+ * dropped (the next segment re-reduces them from g).  Two kernel selections fed the SAME incoming gradient per segment differ by
+ * that segment's own kernels only: what autograd's per-node gradcheck does for the graph under loss.backward()
+ * (/root/reference/sota_imagenet/callbacks.py:317).  MI355_E_STATE outside a split backward.                                       */
+int mi355_resnet50_force_grad(mi355_ctx* ctx, const void* g, size_t bytes, void* stream);
 
 /* HIP-event timing of kernel classes inside a step, recorded on the stream the kernels are launched on.
  * mi355_resnet50_profile(ctx, class_mask): bit k set => every launch of class k is bracketed by a pair of

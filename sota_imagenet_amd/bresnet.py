@@ -539,6 +539,23 @@ class BResNet50(_DropStream, _FlatModel):
                     self._grad_sync(k, b, e)
         self._grads_dirty = True
 
+    def debug_tensor(self, shape, name):
+        """copy of an internal tensor of the last forward at batch shape (N,H,W) — test hook (mi355_bresnet50_debug_tensor)."""
+        from . import native
+
+        L = native.lib()
+        p, dt, nd, sh = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int(), (ctypes.c_int * 4)()
+        native.check(L.mi355_bresnet50_debug_tensor(self._ctx(*shape), name.encode(), ctypes.byref(p), ctypes.byref(dt), ctypes.byref(nd), sh))
+        dims = [sh[i] for i in range(nd.value)]
+        out = torch.empty(dims, dtype={native.F32: torch.float32, native.BF16: torch.bfloat16}[dt.value], device=self._flat_params.device)
+        torch.cuda.synchronize()
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        rc = hip.hipMemcpy(ctypes.c_void_p(out.data_ptr()), p, out.numel() * out.element_size(), 3)
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpy failed ({rc})")
+        return out
+
     def set_comm(self, comm, bucket_cap_mb=32.0):
         """attaches a native RCCL communicator (parallel.FlatBucketDDP owns it): the backward call then reduces the flat gradient array
         bucket by bucket behind the segments that complete it (mi355_bresnet50_set_comm)"""

@@ -864,6 +864,45 @@ int mi355_bresnet50_backward(mi355_bctx* c, const float* dlogits, int accumulate
   return 0;
 }
 
+int mi355_bresnet50_debug_tensor(const mi355_bctx* c, const char* name, void** ptr, int* dtype, int* ndim, int shape[4]) {
+  MI355_ARG(c && c->arena && name && ptr && dtype && ndim && shape, "bresnet50_debug_tensor: null argument / layout-only ctx");
+  const std::string n(name);
+  auto set4 = [&](const void* p, int h, int w, int ch) {
+    if (!p) return 1;
+    *ptr = const_cast<void*>(p); *dtype = c->dtype; *ndim = 4;
+    shape[0] = c->N; shape[1] = h; shape[2] = w; shape[3] = ch;
+    return 0;
+  };
+  auto setf = [&](const float* p, int d0, int d1) {
+    if (!p) return 1;
+    *ptr = const_cast<float*>(p); *dtype = MI355_F32; *ndim = d1 ? 2 : 1;
+    shape[0] = d0; shape[1] = d1; shape[2] = shape[3] = 0;
+    return 0;
+  };
+  auto layer = [&](const VConv& v, const VBN& b) -> int {
+    if (n == v.name + ".y") return set4(v.y, v.Hout, v.Wout, v.Coutp);
+    if (n == b.name + ".out" && !b.lazy) return set4(b.out, v.Hout, v.Wout, b.Cp);
+    if (n == b.name + ".save_mean") return setf(b.mean, b.Cp, 0);
+    if (n == b.name + ".save_invstd") return setf(b.invstd, b.Cp, 0);
+    return 1;
+  };
+  if (layer(c->s0, c->sb0) == 0 || layer(c->s1, c->sb1) == 0 || layer(c->s2, c->sb2) == 0) return 0;
+  if (n == "stem.p") return set4(c->p, c->H / 4, c->W / 4, 64);
+  for (const auto& b : c->blocks) {
+    if (layer(b.c1, b.b1) == 0 || layer(b.c2, b.b2) == 0 || layer(b.c3, b.b3) == 0) return 0;
+    if (b.has_ds && layer(b.ds, b.bd) == 0) return 0;
+    const std::string pre = b.c1.name.substr(0, b.c1.name.size() - 5);  // strip "conv1"
+    const int C4 = 4 * b.planes;
+    if (n == pre + "out") return set4(b.out, b.Ho, b.Wo, C4);
+    if (n == pre + "a2b" && b.stride == 2) return set4(b.a2b, b.Ho, b.Wo, b.c2.Coutp);
+    if (n == pre + "scin" && b.stride == 2 && b.has_ds) return set4(b.scin, b.Ho, b.Wo, b.ds.Cinp);
+    if (n == pre + "gate") return setf(b.gate, c->N, C4);
+    if (n == pre + "keep" && b.scaled) return setf(b.keep, c->N, 0);
+  }
+  set_error("bresnet50_debug_tensor: unknown tensor '%s' (or not stored by the last forward)", name);
+  return MI355_E_ARG;
+}
+
 int mi355_bresnet50_num_segments(const mi355_bctx* c) { return c ? (int)c->segs.size() : 0; }
 
 int mi355_bresnet50_segment_range(const mi355_bctx* c, int seg, size_t* grad_begin, size_t* grad_end) {

@@ -1301,8 +1301,38 @@ int mi355_resnet50_debug_tensor(const mi355_ctx* c, const char* name, void** ptr
   }
   for (int i = 0; i < 2; ++i)
     if (n == "gG" + std::to_string(i)) return set4(c->gG[i], c->dtype, last.Hout, last.Wout, last.Cout);
+  if (n == "grad.cur") {  // between two backward segments: the gradient the NEXT segment starts from (wrt that block's output, before its ReLU mask)
+    const int nb = (int)c->blocks.size();
+    if (c->next_seg >= 1 && c->next_seg <= nb) {
+      const Block& b = c->blocks[nb - c->next_seg];
+      return set4(c->cur_dout, c->dtype, b.Hout, b.Wout, b.Cout);
+    }
+    if (c->next_seg == nb + 1) return set4(c->cur_dout, c->dtype, c->stem.Hout / 2, c->stem.Wout / 2, 64);
+    set_error("debug_tensor: 'grad.cur' exists between backward segments only (next segment %d)", c->next_seg);
+    return MI355_E_STATE;
+  }
   set_error("debug_tensor: unknown tensor '%s'", name);
   return MI355_E_ARG;
+}
+
+int mi355_resnet50_force_grad(mi355_ctx* c, const void* g, size_t bytes, void* stream) {
+  MI355_ARG(c && g, "force_grad: null argument");
+  const int nb = (int)c->blocks.size();
+  if (!c->fwd_training_done || c->next_seg < 1 || c->next_seg > nb + 1) {
+    set_error("force_grad: only between two backward segments (next segment %d)", c->next_seg);
+    return MI355_E_STATE;
+  }
+  size_t want;
+  if (c->next_seg <= nb) {
+    Block& b = c->blocks[nb - c->next_seg];
+    want = (size_t)c->N * b.Hout * b.Wout * b.Cout * c->es;
+    b.c3.bwd_rows = 0;  // the BN-backward sums the producing epilogue left belong to the replaced tensor: bn3's backward re-reduces
+  } else {
+    want = (size_t)c->N * (c->stem.Hout / 2) * (c->stem.Wout / 2) * 64 * c->es;
+  }
+  MI355_ARG(bytes == want, "force_grad: %zu bytes given, the pending gradient has %zu", bytes, want);
+  MI355_HIP(hipMemcpyAsync(c->cur_dout, g, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
 }
 
 int mi355_resnet50_fp8_state(const mi355_ctx* c, int* fwd_on, int* bwd_on, int* n_fwd_layers, int* n_dgrad_layers) {

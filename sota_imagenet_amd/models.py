@@ -411,6 +411,12 @@ class ResNet50(_FlatModel):
             raise RuntimeError(f"hipMemcpy failed ({rc})")
         return out
 
+    def force_grad(self, shape, g):
+        """teacher forcing between two backward segments: the next segment starts from `g` instead of the gradient the previous one left
+        (test hook, mi355_resnet50_force_grad)"""
+        g = g.contiguous()
+        check(native.lib().mi355_resnet50_force_grad(self._ctx(*shape), ptr(g), g.numel() * g.element_size(), native.cur_stream()))
+
     def fp8_state(self, shape):
         """(forward twins in use, gradient twins in use, fp8 forward layers, fp8 dgrad layers) of the last training step at
         batch shape (N,H,W) — mi355_resnet50_fp8_state"""

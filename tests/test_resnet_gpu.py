@@ -521,6 +521,66 @@ def test_baseline_batch_rule_selected_variants(dev, dtype, monkeypatch):
     assert max(errs) < 0.3, f"per-segment drift {['%.1e' % x for x in errs]}"
 
 
+def _segmented_backward(m, loss, key, record=None, replay=None):
+    """loss.backward() as one native call per segment (the data-parallel hook's path); after segment k the gradient the next segment
+    starts from is copied into `record`, or replaced by replay[k] (mi355_resnet50_force_grad)"""
+    nseg = len(m.grad_segments)
+
+    def hook(k, b, e):
+        if k >= nseg - 1:
+            return
+        if record is not None:
+            record.append(m.debug_tensor(key, "grad.cur"))
+        if replay is not None:
+            m.force_grad(key, replay[k])
+
+    m._grad_sync, m._grad_sync_points = hook, None
+    try:
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        m._grad_sync = None
+
+
+def test_backward_of_the_baseline_batch_teacher_forced_segment_by_segment(dev, monkeypatch):
+    """BASELINE.json's batch, bf16: the backward of the default kernel selection (generated po / pk / pw / dconv / wg kernels, 8-wave
+    tiles) against the backward of the round-3 implicit-GEMM kernels with the small tiles — fed the SAME incoming gradient segment by
+    segment (arm A's, replayed into arm B before each block), so a segment's gradients differ by that segment's own kernels only and the
+    band does not have to absorb sixteen blocks of drift: every segment within 2e-3 (measured 1e-4 at most; the free-running comparison
+    allows 0.3 at the stem).
+    The replaced tensor's BN-backward sums are re-reduced from it (bn_reduce), so bn3 of every block is also the check of the fused
+    epilogue sums against the stand-alone reduction."""
+    from sota_imagenet_amd.losses import CrossEntropyLoss
+
+    N, S = 256, 224
+    key = (N, S, S)
+    m, _ = build("bf16")
+    data, target = synthetic_batch(N, S, seed=3, index=0)
+    m.train()
+    crit = CrossEntropyLoss(smoothing=0.1).cuda()
+    rec = []
+    _segmented_backward(m, crit(m(data.cuda()), target.cuda()), key, record=rec)
+    g_a = m.flat_grads.detach().clone()
+    assert len(rec) == len(m.grad_segments) - 1 and rec[0].shape == (N, 7, 7, 2048) and rec[-1].shape == (N, 56, 56, 64)
+    # the same split backward again, nothing replaced: the same bits (splitting the native call changes no kernel)
+    m.mark_grads_clean()
+    _segmented_backward(m, crit(m(data.cuda()), target.cuda()), key)
+    assert torch.equal(m.flat_grads, g_a)
+    # arm B: every generated family and the large tiles off for the backward; the forward (and so every saved activation) is arm A's
+    m.mark_grads_clean()
+    loss = crit(m(data.cuda()), target.cuda())
+    for k, v in (("MI355_DCONV", "0"), ("MI355_IGEMM8", "0"), ("MI355_IGEMM_BIG", "0")):
+        monkeypatch.setenv(k, v)  # (the fixture re-reads the library's switches)
+    _segmented_backward(m, loss, key, replay=rec)
+    g_b = m.flat_grads.detach().clone()
+    table = m.kernel_table(key)
+    assert all(v["dgrad"].startswith(("igemm<", "-")) and v["wgrad"].startswith("wgrad<") for v in table.values()), table
+    errs = [l2err(g_a[b:e].cpu(), g_b[b:e].cpu()) for b, e in m.grad_segments]
+    print("teacher-forced per-segment errors:", ["%.1e" % x for x in errs])
+    assert errs[0] == 0.0, errs[0]
+    assert max(errs) < 2e-3, f"per-segment error under teacher forcing {['%.1e' % x for x in errs]}"
+
+
 @pytest.mark.parametrize("S", [160, 224, 320])
 def test_config5_batch_512_progressive_sizes(dev, S):
     """BASELINE.json configs[4]'s per-GPU shapes: batch 512 at the progressive-resize sizes 160 / 224 / 320 px, bf16, default

@@ -339,6 +339,74 @@ def test_static_executor_at_the_baseline_batch(dev, monkeypatch):
     torch.cuda.empty_cache()
 
 
+def test_static_executor_at_the_baseline_batch_default_fused_tail_against_the_oracle(dev):
+    """BASELINE configs[3] at its own size (bs 256, 224 px, bf16) in the DEFAULT environment — the fused ECA x drop-connect x shortcut x
+    leaky-ReLU pass with bn3 / the downsample BN applied inside it (MI355_BRESNET_FUSED_ECA, MI355_BRESNET_LAZY_BN at their defaults),
+    drop-connect sampled on the device — teacher-forced against the oracle (oracle/bresnet50_ref.py's definitions, oracle/ops_ref.py's
+    convolution) on a few images: six convolutions of the kinds the launch rules treat differently there (zero-padded 32-channel stem conv,
+    3x3 of layers 1 and 4, conv3 behind the blur pool, the striding block's downsample conv behind its average pool, a long 1x1), each
+    re-derived from the executor's own input and the oracle's standardised weights, with whole-batch BN statistics; and the fused tail of a
+    striding block and of an identity block re-derived from the executor's conv outputs, statistics, gate inputs and keep scales."""
+    from sota_imagenet_amd.bresnet import BResNet50
+    from sota_imagenet_amd.synth import synthetic_batch
+
+    N, S = 256, 224
+    key = (N, S, S)
+    m = BResNet50(dtype="bf16", drop_rate=0.2, drop_connect_rate=0.2, weight_standardization=True, seed=5).cuda()
+    data, target = synthetic_batch(N, S, seed=0, index=0, device="cuda")
+    m.train()
+    loss = R.smooth_ce(m(data), target, 0.1)
+    assert abs(loss.item() - 6.9078) < 0.3
+    P = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    T = lambda name: m.debug_tensor(key, name)
+    img = [0, 100, 255]
+    q = lambda t: t.bfloat16().float()
+    stats = {}
+
+    def bn_stats(conv, bn):
+        y = T(conv + ".y")
+        y2 = y.reshape(-1, y.shape[-1]).double()
+        mean, invstd = T(bn + ".save_mean"), T(bn + ".save_invstd")
+        C = P[bn + ".weight"].numel()
+        assert nerr(mean[:C], y2.mean(0).float()[:C]) < 1e-4, bn
+        assert nerr(invstd[:C], (y2.var(0, unbiased=False) + 1e-5).rsqrt().float()[:C]) < 1e-4, bn
+        stats[bn] = (mean[:C].cpu(), invstd[:C].cpu())
+        return y
+
+    # (conv, its BN, the tensor it reads, real input channels)
+    for conv, bn, src in [("conv1.2", "conv1.3", "conv1.1.out"), ("layer1.0.conv2", "layer1.0.bn2", "layer1.0.bn1.out"),
+                          ("layer2.0.conv3", "layer2.0.bn3", "layer2.0.a2b"), ("layer2.0.downsample.0", "layer2.0.downsample.1", "layer2.0.scin"),
+                          ("layer3.2.conv1", "layer3.2.bn1", "layer3.1.out"), ("layer3.2.conv3", "layer3.2.bn3", "layer3.2.bn2.out"),
+                          ("layer4.1.conv2", "layer4.1.bn2", "layer4.1.bn1.out")]:
+        w = P[conv + ".weight"]
+        Co, Ci, K = w.shape[0], w.shape[1], w.shape[2]
+        y = bn_stats(conv, bn)[img].float().cpu()
+        x = T(src)[img].float().cpu()
+        assert x[..., Ci:].abs().max().item() == 0 if x.shape[-1] > Ci else True, src  # (padded channels carry zeros)
+        ref = R.conv2d_fwd(x[..., :Ci], q(R.oihw_to_krsc(B.ws(w))), 1, K // 2)
+        assert nerr(y[..., :Co], ref) < 2e-2, conv
+        if y.shape[-1] > Co:
+            assert y[..., Co:].abs().max().item() == 0, conv
+
+    def normalised(y, bn):
+        mean, invstd = stats[bn]
+        return (y - mean) * invstd * P[bn + ".weight"] + P[bn + ".bias"]
+
+    for blk, prev in (("layer2.0", None), ("layer3.2", "layer3.1")):
+        z = normalised(T(blk + ".conv3.y")[img].float().cpu(), blk + ".bn3")        # [n][H][W][C]
+        cw = P[blk + ".se_module.conv.weight"].reshape(1, 1, 3)
+        gate = torch.sigmoid(torch.nn.functional.conv1d(z.mean((1, 2))[:, None, :], cw, padding=1))[:, 0]
+        assert nerr(T(blk + ".gate")[img], gate) < 1e-3, blk
+        keep = T(blk + ".keep")[img].cpu()
+        assert set(torch.unique(T(blk + ".keep")).cpu().tolist()) <= {0.0, keep.max().item()} and keep.max().item() > 1.0
+        sc = T(prev + ".out")[img].float().cpu() if prev else normalised(T(blk + ".downsample.0.y")[img].float().cpu(), blk + ".downsample.1")
+        ref = torch.nn.functional.leaky_relu(z * gate[:, None, None, :] * keep[:, None, None, None] + sc, B.LEAKY)
+        assert nerr(T(blk + ".out")[img], ref) < 2e-2, blk
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(m.flat_grads).all()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_epilogue_statistics_feed_the_next_batchnorm(dev, dtype):
     """ops.conv2d_fwd(stats=True) returns (y, partial rows); ops.bn_fwd_train(y, ..., stats=partial) takes the sums the conv
