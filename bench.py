@@ -233,10 +233,14 @@ def main():
         # both executors keep their parameters in one flat array: the native SGD updates it in a handful of launches
         opt = SGD([{"params": list(model.parameters())}], lr=0.0, momentum=0.9, weight_decay=3e-5)
         opt.attach_model(model)
-        mixer = None
+        mixer = ema_buf = None
         if variant:
             from sota_imagenet_amd.callbacks import CutmixMixup
             mixer = CutmixMixup(1.0, 0.2, prob=0.5)
+            # the recipe's ModelEma (BResNet50_encoder.yaml:59 ema_decay 0.9999, train.py:111-112) IN the step: the parameter average inside the SGD
+            # kernel (optim.SGD.attach_ema, what fit_wrapper.ModelEma does under the Runner), the BN buffers' average by one lerp
+            ema_par, ema_buf = model.flat_params.detach().clone(), model._flat_buffers.detach().clone()
+            opt.attach_ema(model.flat_params, ema_par, 0.9999)
         net = model
         if use_ddp:
             from sota_imagenet_amd.parallel import FlatBucketDDP
@@ -256,6 +260,8 @@ def main():
             opt.zero_grad()
             loss.backward()
             opt.step()
+            if ema_buf is not None:
+                ema_buf.lerp_(model._flat_buffers, 1.0 - 0.9999)
             return loss
 
         dom = None
@@ -372,7 +378,7 @@ def main():
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                               "config": {"workload": "BASELINE configs[3]: BResNet-50 (deep stem, anti-alias, ECA, leaky ABN, WS, drop-connect) train step "
-                                                     "with CutmixMixup on, static executor (csrc/bresnet_exec.cpp)", "global_batch": world * N, "image_size": S,
+                                                     "with CutmixMixup + ModelEma(0.9999) on, static executor (csrc/bresnet_exec.cpp)", "global_batch": world * N, "image_size": S,
                                          "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
                               # whole step (every kernel, not one class): algorithmic conv + FC FLOPs of a training step / step time
                               "roofline": {"bound": "mfma", "scope": "whole step", "achieved": round(model.flops(N, S, S)[1] / (ms * 1e-3) / 1e12, 2),
@@ -465,7 +471,7 @@ def main():
                 del mb
                 torch.cuda.empty_cache()
                 out["secondary_bresnet50"] = {"dtype": "bf16", "workload": "BASELINE configs[3] on one MI355X: BResNet-50 (deep stem, anti-alias, ECA, leaky ABN, WS, "
-                                                                           f"drop-connect) bs=256 {S}px, CutmixMixup on, static executor (csrc/bresnet_exec.cpp)",
+                                                                           f"drop-connect) bs=256 {S}px, CutmixMixup + ModelEma(0.9999) on, static executor (csrc/bresnet_exec.cpp)",
                                               "value": round(256 * kb / dtb, 1), "unit": "images/sec", "steps": kb, "ms_per_step": round(dtb / kb * 1e3, 3),
                                               "final_loss": round(lossb, 4), "step_tflops": round(flb / (dtb / kb) / 1e12, 1)}
             except Exception as e:

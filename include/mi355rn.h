@@ -212,6 +212,12 @@ int mi355_ce_loss(const float* logits, const float* target, float smoothing, flo
  * replaces torch.optim._multi_tensor.SGD.step — arg_parser.py:136-138, callbacks.py:309 (K10)       */
 int mi355_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float momentum,
                    float weight_decay, float grad_scale, void* stream);
+/* the same step + the exponential moving average of the updated parameters in the same pass:
+ *   ema += (1 - ema_decay) * (p_new - ema)      (= ema_decay * ema + (1 - ema_decay) * p_new)
+ * replaces pytorch_tools' ModelEma callback over the parameters (train.py:111-112, `ema_decay` of
+ * configs/_old_configs/_first_attempts/BResNet50_encoder.yaml:59) when the optimizer steps every batch */
+int mi355_sgd_step_ema(float* p, const float* g, float* m, float* ema, size_t n, float lr, float momentum,
+                       float weight_decay, float grad_scale, float ema_decay, void* stream);
 
 /* ---- BResNet-50 variant blocks (BASELINE configs[3]) ---------------------------------------------------------------
  * The reference builds that model as pytorch_tools.models.resnet50(stem_type="deep", antialias=True, attn_type="eca",

@@ -274,7 +274,7 @@ int launch_gap_bwd(int dtype, const float* dpooled, void* dx, int N, int HW, int
 int launch_ce(const float* logits, const float* target, float smoothing, float grad_scale, float* loss,
               float* row_loss, float* dlogits, int N, int C, hipStream_t s);
 int launch_sgd(float* p, const float* g, float* m, size_t n, float lr, float mom, float wd, float gscale,
-               hipStream_t s);
+               hipStream_t s, float* ema = nullptr, float ema_decay = 0.f);
 int launch_stem_ingest(int dtype, const float* x, void* xpad, int N, int H, int W, hipStream_t s);
 // logits[n][o] = tmp[n*ld + o] + bias[o]
 int launch_bias_slice(const float* tmp, int ld, const float* bias, float* out, int N, int O, hipStream_t s);

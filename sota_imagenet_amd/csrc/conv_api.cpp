@@ -491,5 +491,10 @@ int mi355_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float
                    float grad_scale, void* stream) {
   return launch_sgd(p, g, m, n, lr, momentum, weight_decay, grad_scale, (hipStream_t)stream);
 }
+int mi355_sgd_step_ema(float* p, const float* g, float* m, float* ema, size_t n, float lr, float momentum, float weight_decay,
+                       float grad_scale, float ema_decay, void* stream) {
+  MI355_ARG(ema, "sgd_step_ema: null ema");
+  return launch_sgd(p, g, m, n, lr, momentum, weight_decay, grad_scale, (hipStream_t)stream, ema, ema_decay);
+}
 
 }  // extern "C"

@@ -432,20 +432,26 @@ __global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                  size_t n4, size_t n, float lr, float mom, float wd, float gscale) {
+// EMA: also ema = ema + (1 - decay) * (p_new - ema) — the recipe's ModelEma (train.py:111-112) in the pass that has p in registers anyway
+template <bool EMA>
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ ema,
+                                                  size_t n4, size_t n, float lr, float mom, float wd, float gscale, float ema_w) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
     const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
     f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 ev;
+    if constexpr (EMA) ev = reinterpret_cast<f32x4*>(ema)[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float ge = gv[e] * gscale + wd * pv[e];
       mv[e] = mom * mv[e] + ge;
       pv[e] = pv[e] - lr * mv[e];
+      if constexpr (EMA) ev[e] = ev[e] + ema_w * (pv[e] - ev[e]);
     }
     reinterpret_cast<f32x4*>(m)[i] = mv;
     reinterpret_cast<f32x4*>(p)[i] = pv;
+    if constexpr (EMA) reinterpret_cast<f32x4*>(ema)[i] = ev;
   }
   // tail (n not a multiple of 4)
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -453,7 +459,9 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     const float ge = g[i] * gscale + wd * p[i];
     const float me = mom * m[i] + ge;
     m[i] = me;
-    p[i] = p[i] - lr * me;
+    const float pn = p[i] - lr * me;
+    p[i] = pn;
+    if constexpr (EMA) ema[i] = ema[i] + ema_w * (pn - ema[i]);
   }
 }
 
@@ -618,12 +626,14 @@ int launch_ce(const float* logits, const float* target, float smoothing, float g
 }
 
 int launch_sgd(float* p, const float* g, float* m, size_t n, float lr, float mom, float wd, float gscale,
-               hipStream_t s) {
+               hipStream_t s, float* ema, float ema_decay) {
   MI355_ARG(p && g && m, "sgd: null pointer");
-  MI355_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0),
+  MI355_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)ema % 16 == 0),
             "sgd: pointers must be 16-byte aligned");
+  MI355_ARG(!ema || (ema_decay >= 0.f && ema_decay <= 1.f), "sgd: ema_decay=%g outside [0, 1]", (double)ema_decay);
   const size_t n4 = n / 4;
-  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n4, 4096)), dim3(256), 0, s, p, g, m, n4, n, lr, mom, wd, gscale);
+  if (ema) hipLaunchKernelGGL(sgd_kernel<true>, dim3(grid_for(n4, 4096)), dim3(256), 0, s, p, g, m, ema, n4, n, lr, mom, wd, gscale, 1.f - ema_decay);
+  else hipLaunchKernelGGL(sgd_kernel<false>, dim3(grid_for(n4, 4096)), dim3(256), 0, s, p, g, m, ema, n4, n, lr, mom, wd, gscale, 0.f);
   MI355_LAUNCH_CHECK();
   return 0;
 }

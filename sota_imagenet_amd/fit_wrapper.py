@@ -381,6 +381,15 @@ class ModelEma(Callback):
         else:
             self.ema = [t.detach().clone() for t in self.model.state_dict().values()]
         self._swapped = False
+        self._fused = False  # the optimizer's step kernel advances ema[0] (optim.SGD.attach_ema)
+
+    def on_begin(self):
+        # one optimizer step per batch and a flat-array model under the native SGD: the parameter average moves inside the step kernel
+        # (mi355_sgd_step_ema), this callback keeps the buffers (BN running statistics) only
+        opt = getattr(self.state, "optimizer", None)
+        if self._flat and hasattr(opt, "attach_ema") and getattr(self.state, "accumulate_steps", 1) == 1 and self.model.flat_params.is_cuda:
+            opt.attach_ema(self.model.flat_params, self.ema[0], self.decay)
+            self._fused = True
 
     def _live(self):
         if self._flat:
@@ -391,7 +400,9 @@ class ModelEma(Callback):
     def on_batch_end(self):
         if not self.state.is_train:
             return
-        for e, p in zip(self.ema, self._live()):
+        for k, (e, p) in enumerate(zip(self.ema, self._live())):
+            if k == 0 and self._fused:
+                continue
             if e.dtype.is_floating_point:
                 e.lerp_(p.detach(), 1.0 - self.decay)
             else:

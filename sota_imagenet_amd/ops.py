@@ -304,9 +304,15 @@ def ce_loss(logits, target, smoothing=0.0, grad_scale=1.0, need_grad=True):
     return loss, dl
 
 
-def sgd_step(p, g, m, lr, momentum=0.0, weight_decay=0.0, grad_scale=1.0):
+def sgd_step(p, g, m, lr, momentum=0.0, weight_decay=0.0, grad_scale=1.0, ema=None, ema_decay=0.0):
+    """ema (optional, same shape as p): the moving average of the updated parameters, advanced in the same kernel (mi355_sgd_step_ema)"""
     _need_cuda(p, g, m)
-    check(_L().mi355_sgd_step(ptr(p), ptr(g), ptr(m), p.numel(), lr, momentum, weight_decay, grad_scale, cur_stream()))
+    if ema is None:
+        check(_L().mi355_sgd_step(ptr(p), ptr(g), ptr(m), p.numel(), lr, momentum, weight_decay, grad_scale, cur_stream()))
+        return
+    _need_cuda(ema)
+    assert ema.numel() == p.numel() and ema.dtype == torch.float32 and ema.is_contiguous()
+    check(_L().mi355_sgd_step_ema(ptr(p), ptr(g), ptr(m), ptr(ema), p.numel(), lr, momentum, weight_decay, grad_scale, ema_decay, cur_stream()))
 
 
 # ---- BResNet-50 variant blocks (include/mi355rn.h, csrc/variant.hip) ---------------------------------------------------

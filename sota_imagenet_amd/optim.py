@@ -38,6 +38,7 @@ class SGD(Optimizer):
         self._plans = None
         self._models = []
         self.grad_scale = 1.0  # e.g. 1/world_size when gradients were summed, not averaged
+        self._ema = None       # (flat parameter array, its moving average, decay): attach_ema()
 
     def attach_model(self, model):
         """lets zero_grad() tell the model that the next backward may overwrite its flat gradients, and the range
@@ -45,7 +46,20 @@ class SGD(Optimizer):
         self._models.append(model)
         self._plans = None
 
-    # one plan per param group: list of (p_flat_slice, g_flat_slice, m_flat_slice)
+    def attach_ema(self, flat_params, flat_ema, decay):
+        """the moving average of a model's flat parameter array (fit_wrapper.ModelEma, train.py:111-112) is advanced by the step kernel
+        itself: ema += (1 - decay) * (p_new - ema) over every range this optimizer updates (ranges it does not update never change, so
+        their average stays what it was cloned from).  detach_ema() hands the job back to the callback."""
+        if not (flat_ema.is_cuda and flat_ema.dtype == torch.float32 and flat_ema.is_contiguous() and flat_ema.numel() == flat_params.numel()):
+            raise ValueError("attach_ema: the average must be a contiguous CUDA fp32 tensor of the flat array's size")
+        self._ema = (flat_params, flat_ema, float(decay))
+        self._plans = None
+
+    def detach_ema(self):
+        self._ema = None
+        self._plans = None
+
+    # one plan per param group: list of (p_flat_slice, g_flat_slice, m_flat_slice, ema_flat_slice or None)
     def _build_plans(self):
         entries = []  # (param base, grad base, first elem, numel, group index, param)
         for gi, group in enumerate(self.param_groups):
@@ -100,7 +114,14 @@ class SGD(Optimizer):
                 if old is not None:  # loaded from a checkpoint (train.py:144) or kept across a re-plan: carry it over
                     view.copy_(old.to(device=dev, dtype=torch.float32))
                 self.state[p]["momentum_buffer"] = view
-            plans[gi].append((fp, fg, fm))
+            fe = None
+            if self._ema is not None:
+                r = _dense_range(self._ema[0])
+                if r is not None and r[0] == pb and r[1] <= b and e <= r[1] + r[2]:
+                    fe = self._ema[1][b - r[1]: e - r[1]]
+            plans[gi].append((fp, fg, fm, fe))
+        if self._ema is not None and not any(fe is not None for segs in plans for *_, fe in segs):
+            raise RuntimeError("SGD.attach_ema: none of the updated ranges lies in the attached flat array")
         self._plans = plans
 
     @torch.no_grad()
@@ -112,8 +133,9 @@ class SGD(Optimizer):
         if self._plans is None:
             self._build_plans()
         for group, segs in zip(self.param_groups, self._plans):
-            for fp, fg, fm in segs:
-                ops.sgd_step(fp, fg, fm, float(group["lr"]), float(group["momentum"]), float(group["weight_decay"]), float(self.grad_scale))
+            for fp, fg, fm, fe in segs:
+                ops.sgd_step(fp, fg, fm, float(group["lr"]), float(group["momentum"]), float(group["weight_decay"]), float(self.grad_scale),
+                             ema=fe, ema_decay=self._ema[2] if fe is not None else 0.0)
         return loss
 
     def zero_grad(self, set_to_none=False):

@@ -248,3 +248,22 @@ def test_sgd(dev):
     for g in grads:
         ops.sgd_step(p, g.to(dev), m, 0.1, 0.9, 3e-5)
     assert nerr(p, p_ref) < 1e-6 and nerr(m, m_ref) < 1e-6
+
+
+def test_sgd_with_the_moving_average_in_the_same_pass(dev):
+    """mi355_sgd_step_ema: the same parameters / momenta bit for bit as the plain step, and the average = what ModelEma's lerp after each
+    step gives (ema + (1 - decay) * (p - ema), the callback's arithmetic: train.py:111-112)"""
+    from sota_imagenet_amd import ops
+
+    n = 100003
+    p0 = rnd((n,), 71, torch.float32)
+    grads = [rnd((n,), 72 + i, torch.float32).to(dev) for i in range(3)]
+    p, pe = p0.to(dev).clone(), p0.to(dev).clone()
+    m, me = torch.zeros_like(p), torch.zeros_like(p)
+    ema, ema_ref = pe.clone(), p.clone()
+    for g in grads:
+        ops.sgd_step(p, g, m, 0.1, 0.9, 3e-5)
+        ema_ref.lerp_(p, 1.0 - 0.99)
+        ops.sgd_step(pe, g, me, 0.1, 0.9, 3e-5, ema=ema, ema_decay=0.99)
+    assert torch.equal(p, pe) and torch.equal(m, me)
+    assert nerr(ema, ema_ref) < 1e-6 and not torch.equal(ema, pe)

@@ -361,6 +361,43 @@ def test_runner_with_cutmix_mixup_soft_targets(dev):
     assert not torch.equal(before, m.flat_params)
 
 
+def test_model_ema_inside_the_sgd_kernel_matches_the_callback(dev):
+    """ModelEma (train.py:111-112) over a flat-array model under the native SGD: the parameter average is advanced by the step kernel
+    (optim.SGD.attach_ema).  The same three steps with the callback doing its own lerp (accumulate_steps = 2 keeps it unfused; here:
+    forced by detaching) must leave the same average, and validation must run on the averaged weights and hand the live ones back."""
+    from sota_imagenet_amd import fit_wrapper as fw
+    from sota_imagenet_amd.losses import CrossEntropyLoss
+    from sota_imagenet_amd.models import resnet50
+    from sota_imagenet_amd.optim import SGD
+    from sota_imagenet_amd.synth import synthetic_batch
+
+    class Loader:
+        batch_size = 4
+
+        def __len__(self):
+            return 3
+
+        def __iter__(self):
+            return iter([synthetic_batch(4, 64, seed=6, index=i, device="cuda") for i in range(3)])
+
+    res = []
+    for fused in (True, False):
+        m = resnet50(dtype="fp32").cuda()
+        opt = SGD([{"params": list(m.parameters())}], lr=0.0, momentum=0.9, weight_decay=3e-5)
+        opt.attach_model(m)
+        ema = fw.ModelEma(m, 0.9)
+        if not fused:
+            ema.on_begin = lambda: None  # the callback's own lerp after every batch
+        runner = fw.Runner(m, opt, CrossEntropyLoss(smoothing=0.1), callbacks=[fw.PhasesScheduler([dict(ep=(0, 1), lr=(0.01, 0.02))]), ema])
+        runner.fit(Loader(), val_loader=Loader(), epochs=1)
+        assert ema._fused == fused and not ema._swapped
+        res.append((m.flat_params.clone(), ema.ema[0].clone(), ema.ema[1].clone()))
+    (p_a, e_a, b_a), (p_b, e_b, b_b) = res
+    assert torch.equal(p_a, p_b) and torch.equal(b_a, b_b)
+    assert not torch.equal(e_a, p_a)
+    assert ((e_a - e_b).abs().max() / e_b.abs().max()).item() < 1e-6
+
+
 def _tiny_steps(m, opt, idxs, N=4, S=64):
     from sota_imagenet_amd.losses import CrossEntropyLoss
     from sota_imagenet_amd.synth import synthetic_batch
