@@ -46,6 +46,9 @@ class PoCfg:
                       # tensor that stands for a full-resolution one whose odd rows / columns are zero (the data gradient of a stride-2 1x1
                       # convolution — the downsample branch of a stage's first block — which is then never written at full size)
     MFR: int = 4      # 16-pixel fragments per tile
+    WM: int = 1       # waves along the pixel dimension: 1 -> waves 1 (M) x 4 (N), every wave computes all MFR fragments of its BN/4 columns;
+                      # 2 -> waves 2 x 2: a wave computes MFR/2 fragments of BN/2 columns (the 64-column launches of layer 1: a wave still owns a
+                      # tile pair = 8 consecutive channels per lane; two partial rows per workgroup)
     NBUF: int = 2     # A tile buffers
     tmask: int = 1    # 1: the ReLU mask bytes of a whole 64-pixel tile by ONE load per mask tensor (lane = pixel, 8 or 4 bytes = this wave's columns),
                       #    handed to the lanes that need them by ds_bpermute; 0: one byte load per (fragment, tile pair) and lane
@@ -54,8 +57,16 @@ class PoCfg:
     probe: int = 0    # timing probes (WRONG results): 1 no MFMAs, 2 no epilogue arithmetic, 4 no operand loads, 8 no stores
 
     @property
+    def WN(self):     # waves along the output columns
+        return 4 // self.WM
+
+    @property
+    def MFRW(self):   # fragments per wave
+        return self.MFR // self.WM
+
+    @property
     def NT(self):     # 16-column tiles per wave
-        return self.BN // 64
+        return self.BN // (16 * self.WN)
 
     @property
     def KS(self):     # 32-channel k-steps
@@ -87,7 +98,7 @@ class PoCfg:
 
     @property
     def NI(self):     # epilogue items per tile: (fragment, tile pair)
-        return self.MFR * self.NT // 2
+        return self.MFRW * self.NT // 2
 
     @property
     def NM(self):     # mask tensors (BN layer's ReLU bits, addend's ReLU bits)
@@ -133,7 +144,8 @@ class Gen:
     # -----------------------------------------------------------------------------------------------------------------
     def gen(self):
         c, S, V = self.c, self.S, self.V
-        assert c.BN in (128, 256) and c.K % 64 == 0 and c.MFR % 2 == 0 and c.NT % 2 == 0
+        assert c.BN in (64, 128, 256) and c.K % 64 == 0 and c.MFR % 2 == 0 and c.NT % 2 == 0 and c.WM in (1, 2) and c.MFR % c.WM == 0
+        assert c.WM == 1 or (not c.FULL and (not c.NMT or c.MFRW == 4)), "2 x 2 waves: half-line stores; the tile-wide mask load is one lane per pixel of the wave's 64"
         assert (c.L + 1) * c.NI + c.NPW + c.NMT <= 63, "vmcnt range"
         assert c.LDS <= 160 * 1024
         self.s_wg = 2
@@ -150,11 +162,12 @@ class Gen:
         (self.s_w, self.s_t0, self.s_t1, self.s_t2, self.s_t3, self.s_cnt, self.s_pf, self.s_tout, self.s_tbits, self.s_g, self.s_ct, self.s_ldsA, self.s_n4,
          self.s_ia, self.s_io, self.s_ib, self.s_8rows, self.s_pfa) = [S.get() for _ in range(18)]
         self.s_lo8 = S.get(2, 2)   # lanes 0 .. 7 of every row of 16
+        self.s_wn, self.s_wm = (S.get(), S.get()) if c.WM > 1 else (self.s_w, None)   # this wave's column / pixel part
         self.vA_rd = [[V.get() for kk in range(2)] for b in range(c.NBUF)]
         self.vA_dma = V.get()
         self.v_tmp = [V.get(), V.get()]
-        self.v_out_m = [V.get() for m in range(c.MFR)]
-        self.v_bits_m = [V.get() for m in range(c.MFR)] if (c.NM and not c.tmask) else None
+        self.v_out_m = [V.get() for m in range(c.MFRW)]
+        self.v_bits_m = [V.get() for m in range(c.MFRW)] if (c.NM and not c.tmask) else None
         if c.NMT:
             nd = c.NT // 2                       # dwords of a pixel's mask bytes owned by this wave (4 bytes per tile pair)
             self.v_mk = V.get()                  # lane = pixel: byte offset of its mask bytes
@@ -163,9 +176,9 @@ class Gen:
             self.mk = {T: [V.get(nd, 2) for b in range(2)] for T in (["y"] if c.stats == 2 else []) + (["a"] if c.add == 2 else [])}
             self.mkt = {T: [V.get() for p in range(nd)] for T in self.mk}   # the unit's mask dwords after the permute / shift
         self.v_chan = V.get()
-        self.v_st_m = [V.get() for m in range(c.MFR)] if c.FULL else None
+        self.v_st_m = [V.get() for m in range(c.MFRW)] if c.FULL else None
         if c.add == 3:
-            self.v_ad_m = [V.get() for m in range(c.MFR)]   # this tile's half-resolution addend offsets (or out of range)
+            self.v_ad_m = [V.get() for m in range(c.MFRW)]   # this tile's half-resolution addend offsets (or out of range)
             self.v_r = V.get()                              # lane & 15
             self.v_col = V.get()                            # this lane's column bytes
             self.s_kq = S.get(4, 4)                         # magic_w, magic_h, -, -
@@ -187,7 +200,7 @@ class Gen:
         npair = c.NT // 2
         self.s1 = [V.get(8, 4) for p in range(npair)] if c.stats else None
         self.s2 = [V.get(8, 4) for p in range(npair)] if c.stats else None
-        self.F = [V.get(4 * c.MFR, 4) for s in range(2)]
+        self.F = [V.get(4 * max(c.MFRW, 3), 4) for s in range(2)]
         self.tv = V.get(8, 2)
         self.dsets = [V.get(4, 4) for _ in range(4)]
         self.v_xc = V.get(4, 4) if c.FULL else None   # exchange temporary
@@ -200,7 +213,7 @@ class Gen:
         self.aACC = c.NT * c.KS * 4
         self.nacc = 2 if c.weave else 1
         self.accset = 0   # the set the epilogue being emitted reads
-        self.nagpr = self.aACC + self.nacc * c.MFR * c.NT * 4
+        self.nagpr = self.aACC + self.nacc * c.MFRW * c.NT * 4
         assert self.nagpr <= 256 and self.accum_offset + self.nagpr <= 512
         self.tmp_i = 0
         self.prologue()
@@ -210,7 +223,7 @@ class Gen:
 
     def acc(self, m, n, aset=None):
         aset = self.accset if aset is None else aset
-        return self.aACC + aset * self.c.MFR * self.c.NT * 4 + (m * self.c.NT + n) * 4
+        return self.aACC + aset * self.c.MFRW * self.c.NT * 4 + (m * self.c.NT + n) * 4
 
     def breg(self, n, ks):
         return self.aB + (n * self.c.KS + ks) * 4
@@ -332,7 +345,7 @@ class Gen:
     def frag_reads(self, fset, ks, buf):
         c = self.c
         plane, kk = ks // 2, ks % 2
-        return ["ds_read_b128 %s, %s offset:%d" % (R("v", self.F[fset] + 4 * m, 4), R("v", self.vA_rd[buf][kk]), plane * c.PLANE + m * 2048) for m in range(c.MFR)]
+        return ["ds_read_b128 %s, %s offset:%d" % (R("v", self.F[fset] + 4 * m, 4), R("v", self.vA_rd[buf][kk]), plane * c.PLANE + m * 2048) for m in range(c.MFRW)]
 
     # -----------------------------------------------------------------------------------------------------------------
     def prologue(self):
@@ -352,6 +365,9 @@ class Gen:
         e("v_readfirstlane_b32 %s, %s" % (R("s", self.s_w), R("v", v[3])))
         e("v_and_b32 %s, 15, v0" % R("v", r))
         e("v_bfe_u32 %s, v0, 4, 2" % R("v", kg))
+        if c.WM > 1:
+            e("s_and_b32 %s, %s, %d" % (R("s", self.s_wn), R("s", self.s_w), c.WN - 1), "waves %d (M) x %d (N)" % (c.WM, c.WN))
+            e("s_lshr_b32 %s, %s, %d" % (R("s", self.s_wm), R("s", self.s_w), c.WN.bit_length() - 1))
         e("s_waitcnt lgkmcnt(0)")
         M, N, TPG, G, T, LG = kp, kp + 1, kp + 2, kp + 3, kp + 4, kp + 5
         # group g (pixel run) and column tile ct: the NCT workgroups of a group are consecutive multiples of 8 apart -> same XCD
@@ -389,7 +405,7 @@ class Gen:
         self.desc_from(self.srdA, ka + 0, t0, t1, t2, "A: this run's pixels")
         # ---- B: this wave's NT*16 weight rows
         e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_ct), c.BN * c.K * 2))
-        e("s_mul_i32 %s, %s, %d" % (R("s", t1), R("s", self.s_w), c.NT * 16 * c.K * 2))
+        e("s_mul_i32 %s, %s, %d" % (R("s", t1), R("s", self.s_wn), c.NT * 16 * c.K * 2))
         e("s_add_u32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", t1)))
         e("s_add_u32 %s, %s, %s" % (R("s", self.srdB), R("s", ka + 2), R("s", t0)))
         e("s_addc_u32 %s, %s, 0" % (R("s", self.srdB + 1), R("s", ka + 3)))
@@ -468,11 +484,17 @@ class Gen:
             if c.add == 2:
                 self.desc_from(self.srdAB, ka + 18, t0, t1, t2, "ReLU bits of the addend")
         # ---- lane offsets of the output-shaped tensors: (m*16 + r)*N*2 + (w*NT*16 + kg*8)*2
-        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_w), c.NT * 16 * 2))
+        e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_wn), c.NT * 16 * 2))
         e("v_lshl_add_u32 %s, %s, 4, %s" % (R("v", v[6]), R("v", kg), R("s", t0)))
         e("s_lshl_b32 %s, %s, 1" % (R("s", t1), R("s", N)))
-        for m in range(c.MFR):
-            e("v_add_u32 %s, %d, %s" % (R("v", v[7]), 16 * m, R("v", r)))
+        rp, lanep = r, lane   # pixel of the tile: fragment row / lane, + this wave's first fragment
+        if c.WM > 1:
+            rp, lanep = v[10], v[11]
+            e("s_mul_i32 %s, %s, %d" % (R("s", t3), R("s", self.s_wm), c.MFRW * 16))
+            e("v_add_u32 %s, %s, %s" % (R("v", rp), R("s", t3), R("v", r)))
+            e("v_add_u32 %s, %s, %s" % (R("v", lanep), R("s", t3), R("v", lane)))
+        for m in range(c.MFRW):
+            e("v_add_u32 %s, %d, %s" % (R("v", v[7]), 16 * m, R("v", rp)))
             e("v_mul_lo_u32 %s, %s, %s" % (R("v", v[7]), R("v", v[7]), R("s", t1)))
             e("v_add_u32 %s, %s, %s" % (R("v", self.v_out_m[m]), R("v", v[7]), R("v", v[6])))
             if self.v_bits_m:
@@ -480,13 +502,13 @@ class Gen:
         e("v_lshlrev_b32 %s, 5, %s" % (R("v", self.v_chan), R("v", kg)), "this lane's 8 floats of a per-channel row")
         if c.NMT:
             e("s_lshr_b32 %s, %s, 3" % (R("s", t3), R("s", N)), "mask bytes of a pixel row")
-            e("v_mul_lo_u32 %s, %s, %s" % (R("v", self.v_mk), R("v", lane), R("s", t3)))
-            e("s_mul_i32 %s, %s, %d" % (R("s", t3), R("s", self.s_w), c.NT * 2))
+            e("v_mul_lo_u32 %s, %s, %s" % (R("v", self.v_mk), R("v", lanep), R("s", t3)))
+            e("s_mul_i32 %s, %s, %d" % (R("s", t3), R("s", self.s_wn), c.NT * 2))
             e("v_add_u32 %s, %s, %s" % (R("v", self.v_mk), R("s", t3), R("v", self.v_mk)), "lane = pixel of the tile: its mask bytes for this wave's columns")
             e("v_lshlrev_b32 %s, 2, %s" % (R("v", self.v_bp), R("v", r)))
             e("v_lshlrev_b32 %s, 3, %s" % (R("v", self.v_kg8), R("v", kg)))
         if c.add == 3:
-            e("v_mov_b32 %s, %s" % (R("v", self.v_r), R("v", r)))
+            e("v_mov_b32 %s, %s" % (R("v", self.v_r), R("v", rp)))
             e("v_mov_b32 %s, %s" % (R("v", self.v_col), R("v", v[6])))
         if c.FULL:
             # full-line stores: after the lane exchange of the epilogue a lane holds, of pixel m*16 + (r & 7) [store 1] and of pixel
@@ -498,13 +520,13 @@ class Gen:
             e("v_lshlrev_b32 %s, 6, %s" % (R("v", v[8]), R("v", v[8])))
             e("v_add_u32 %s, %s, %s" % (R("v", v[8]), R("v", v[8]), R("v", v[6])), "w*128 + kg*16 + (r >> 3)*64")
             e("v_and_b32 %s, 7, %s" % (R("v", v[9]), R("v", r)))
-            for m in range(c.MFR):
+            for m in range(c.MFRW):
                 e("v_add_u32 %s, %d, %s" % (R("v", v[7]), 16 * m, R("v", v[9])))
                 e("v_mul_lo_u32 %s, %s, %s" % (R("v", v[7]), R("v", v[7]), R("s", t1)))
                 e("v_add_u32 %s, %s, %s" % (R("v", self.v_st_m[m]), R("v", v[7]), R("v", v[8])))
         # ---- first tile's epilogue operands, then the prefetch descriptors move one tile ahead
         e("s_waitcnt lgkmcnt(0)")
-        for m in range(c.MFR):
+        for m in range(c.MFRW):
             for ins in self.sub2_addr(m):
                 e(ins)
         for ins in self.mask_loads(0):
@@ -520,6 +542,9 @@ class Gen:
         e("v_xor_b32 %s, %s, %s" % (R("v", cc), R("v", kg), R("v", sw)))
         e("v_lshlrev_b32 %s, 4, %s" % (R("v", cc), R("v", cc)))
         e("v_lshl_add_u32 %s, %s, 7, %s" % (R("v", cc), R("v", r), R("v", cc)))
+        if c.WM > 1:
+            e("s_mul_i32 %s, %s, %d" % (R("s", t3), R("s", self.s_wm), c.MFRW * 2048))
+            e("v_add_u32 %s, %s, %s" % (R("v", cc), R("s", t3), R("v", cc)), "this wave's first fragment")
         for b in range(c.NBUF):
             e("v_add_u32 %s, %d, %s" % (R("v", self.vA_rd[b][0]), b * c.ABUF, R("v", cc)))
             e("v_xor_b32 %s, 64, %s" % (R("v", self.vA_rd[b][1]), R("v", self.vA_rd[b][0])))
@@ -592,12 +617,12 @@ class Gen:
             fs = self.F[ks & 1]
             mf = []
             for n in range(c.NT):
-                for m in range(c.MFR):
+                for m in range(c.MFRW):
                     a = self.acc(m, n, aset)
                     csrc = "0" if ks == 0 else R("a", a, 4)
                     mf.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (R("a", a, 4), R("a", self.breg(n, ks), 4), R("v", fs + 4 * m, 4), csrc))
             if c.probe & 1:
-                mf = mf[:c.MFR] if ks == 0 else []
+                mf = mf[:c.MFRW] if ks == 0 else []
             nxt = [[r] for r in self.frag_reads((ks + 1) & 1, ks + 1, buf)] if ks + 1 < c.KS else []
             for ins in (self.spread(mf, nxt) if mf else [x for g in nxt for x in g]):
                 e(ins)
@@ -607,7 +632,7 @@ class Gen:
         for ins in self.mask_loads(self.mbuf ^ 1):   # the NEXT tile's mask bytes (waited for by the next tile's first counted wait: they are older)
             self.e(ins)
         if c.FULL:
-            for m in range(c.MFR):
+            for m in range(c.MFRW):
                 self.unit(m, CW)
         else:
             for i in range(c.NI):
@@ -634,7 +659,7 @@ class Gen:
         top, done = self.newlabel("loop"), self.newlabel("done")
         # younger than an item's (a fragment's) loads when it waits for them: the stores + refills of the other items (fragments) of a
         # tile and the A pieces requested at the top of this tile's trip
-        CW = ((c.L + 1) * (c.NI - 1) if not c.FULL else 2 * (c.L + 1) * (c.MFR - 1)) + c.NPW + c.NMT
+        CW = ((c.L + 1) * (c.NI - 1) if not c.FULL else 2 * (c.L + 1) * (c.MFRW - 1)) + c.NPW + c.NMT
         TOPW = c.NI * (c.L + 1) + c.NMT   # younger than a tile's A pieces at the top of the trip that needs them
         if c.weave:
             self.comment("---- first tile: its MFMAs alone (A buffer 0 -> accumulator set 0), the second tile requested")
@@ -832,7 +857,7 @@ class Gen:
             return
         # row g: [2][N] floats; this wave's channels start at ct*BN + w*NT*16
         e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_ct), c.BN * 4))
-        e("s_mul_i32 %s, %s, %d" % (R("s", t1), R("s", self.s_w), c.NT * 16 * 4))
+        e("s_mul_i32 %s, %s, %d" % (R("s", t1), R("s", self.s_wn), c.NT * 16 * 4))
         e("s_add_u32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", t1)), "byte offset of this wave's channels in a per-channel float row")
         mu = isd = None
         if c.stats == 2:
@@ -853,7 +878,12 @@ class Gen:
                     e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", mu[p][4 * h], 4), R("v", self.v_chan), R("s", self.srdY, 4), p * 128 + 16 * h))
                     e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", isd[p][4 * h], 4), R("v", self.v_chan), R("s", self.srdM, 4), p * 128 + 16 * h))
         # statistics row descriptor: stat + g*2*N*4 + channel offset
-        e("s_mul_i32 %s, %s, %s" % (R("s", t1), R("s", self.s_g), R("s", self.s_n4)))
+        if c.WM > 1:   # row g * WM + wm: the waves that share columns leave a row each
+            e("s_lshl_b32 %s, %s, %d" % (R("s", t1), R("s", self.s_g), c.WM.bit_length() - 1))
+            e("s_add_u32 %s, %s, %s" % (R("s", t1), R("s", t1), R("s", self.s_wm)))
+            e("s_mul_i32 %s, %s, %s" % (R("s", t1), R("s", t1), R("s", self.s_n4)))
+        else:
+            e("s_mul_i32 %s, %s, %s" % (R("s", t1), R("s", self.s_g), R("s", self.s_n4)))
         e("s_lshl_b32 %s, %s, 1" % (R("s", t1), R("s", t1)))
         e("s_add_u32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", t1)))
         e("s_add_u32 %s, %s, %s" % (R("s", self.srdX), R("s", ka + 6), R("s", t0)))
@@ -928,12 +958,14 @@ class Gen:
 
 def _variants():
     v = {}
-    for (K, BN) in ((64, 256), (128, 256), (256, 256), (512, 128), (256, 128)):
+    for (K, BN) in ((64, 256), (128, 256), (256, 256), (512, 128), (256, 128), (256, 64), (64, 64)):
         for (st, add) in ((0, 0), (1, 0), (2, 0), (2, 1), (2, 2), (0, 1), (0, 2), (2, 3), (0, 3)):
             if (K, BN) == (256, 128) and add != 0:   # 256 -> 128 columns: layer 2's first conv1 forward (129 us against 159)
                 continue
+            if BN == 64 and add == 3:                # the 64-column launches of layer 1 (waves 2 x 2, 128-pixel tiles) meet no striding block
+                continue
             name = "po_k%d_b%d_s%d_a%d" % (K, BN, st, add)
-            v[name] = PoCfg(name, K=K, BN=BN, stats=st, add=add)
+            v[name] = PoCfg(name, K=K, BN=BN, stats=st, add=add, **(dict(WM=2, MFR=8) if BN == 64 else {}))
     return v
 
 

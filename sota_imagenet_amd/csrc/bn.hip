@@ -716,7 +716,13 @@ int reduce_grid(int dtype, int M, int C, dim3* grid) {
   const int rpp = 256 / tpr;
   const int gy = tpr_full / tpr;
   int nblk = cdiv(M, rpp * 8);
-  if (nblk > MAXBLK / gy) nblk = MAXBLK / gy;
+  // MI355_BN_REDUCE_BLOCKS (A/B switch, read once): partial rows of the stand-alone reductions, 512 (two workgroups per CU) .. bn_max_blocks()
+  static const int cap = [] {
+    const char* e = getenv("MI355_BN_REDUCE_BLOCKS");
+    const int v = e ? atoi(e) : MAXBLK;
+    return v >= 64 && v <= 2 * MAXBLK ? v : MAXBLK;
+  }();
+  if (nblk > cap / gy) nblk = cap / gy;
   if (nblk < 1) nblk = 1;
   *grid = dim3(nblk, gy);
   return nblk;

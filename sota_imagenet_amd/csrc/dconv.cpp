@@ -63,10 +63,11 @@ const Wg1Variant g_wg1[] = {
 };
 constexpr int NWG1 = (int)(sizeof(g_wg1) / sizeof(g_wg1[0]));
 
-// output-heavy pointwise kernels with the weights resident in AGPRs (asm/po_gen.py): persistent workgroups, 64-pixel tiles x BN columns
+// output-heavy pointwise kernels with the weights resident in AGPRs (asm/po_gen.py): persistent workgroups, TP-pixel tiles x BN columns;
+// WM = 2 (the 64-column forms): the two waves that share columns leave a statistics row each -> 2 rows per workgroup
 struct PoVariant {
   const char* name;
-  int K, BN, stats, add, TP, lds, kernarg;
+  int K, BN, stats, add, TP, WM, lds, kernarg;
 };
 const PoVariant g_po[] = {
 #include "build/asm/po_meta.inc"
@@ -531,7 +532,7 @@ bool po_legal(const IgemmArgs& a, int nclass) {
   if (!mode || !dconv_enabled()) return false;
   PoPlan pl;
   if (!plan_po(a, nclass, &pl)) return false;
-  if (a.stat_partial != nullptr && (int)pl.G > (a.stat_rows_cap > 0 ? a.stat_rows_cap : 768)) return false;
+  if (a.stat_partial != nullptr && (int)pl.G * g_po[pl.vi].WM > (a.stat_rows_cap > 0 ? a.stat_rows_cap : 768)) return false;
   if (mode < 2) {
     // MI355_PO=1 (default): the measured rule, per launch shape of the bs-256 step in a serial trace (profiles/r05_ab_po_*.txt):
     //  - 64 -> 256 under the shortcut addend + BN-backward sums (layer 1's conv1 data gradient, 1.39 GB per launch): the implicit-GEMM
@@ -540,6 +541,9 @@ bool po_legal(const IgemmArgs& a, int nclass) {
     //    tile-wide mask loads: served here since)
     //  - 512 -> 2048 forward (layer 4's conv3): pk's four-image tiles win by 2 us.
     const PoVariant& v = g_po[pl.vi];
+    if (v.BN == 64 && knobs().po64 < 2) {
+      if (!knobs().po64) return false;
+    }
     if (v.K == 64 && v.add != 0 && v.stats == 2) return false;
     if (v.K == 512 && a.Ncols >= 2048 && pk_legal(a, nclass)) return false;
   }
@@ -598,7 +602,7 @@ int launch_po(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
     set_error("po: hipModuleLaunchKernel(%s) -> %s", v.name, hipGetErrorString(e));
     return MI355_E_HIP;
   }
-  if (stat_rows) *stat_rows = a.stat_partial ? (int)pl.G : 0;
+  if (stat_rows) *stat_rows = a.stat_partial ? (int)pl.G * v.WM : 0;
   note_kernel("%s", v.name);
   return 0;
 }

@@ -143,6 +143,12 @@ def test_long_reduction_pointwise_kernels_are_exact_in_the_emulator(name, kw):
     ("po_k256_b256_s2_a3", dict(M=400, N=512, HW=(10, 20), tpg=4, groups=((1, 1), (0, 0)))),
     ("po_k128_b256_s0_a3", dict(M=192, N=256, HW=(4, 6), groups=((0, 0),))),
     ("po_k512_b128_s2_a3", dict(M=120, N=256, HW=(6, 10), groups=((0, 1),))),
+    # 64 columns (layer 1's launches into 64 channels): waves 2 x 2, 128-pixel tiles, two statistics rows per workgroup
+    ("po_k256_b64_s1_a0", dict(M=300, N=64, tpg=2, groups=((1, 0), (0, 0)))),               # ragged last tile in the second wave pair's half
+    ("po_k256_b64_s2_a0", dict(M=200, N=64, groups=((0, 0),))),                             # conv3's data gradient + bn2's sums
+    ("po_k256_b64_s0_a0", dict(M=129, N=64, groups=((0, 0),))),                             # the downsample branch's data gradient
+    ("po_k64_b64_s2_a2", dict(M=260, N=128, tpg=1, groups=((2, 1), (0, 0)))),               # two column tiles, masked addend
+    ("po_k64_b64_s0_a1", dict(M=70, N=64, groups=((0, 0),))),                               # layer1.0's conv1 data gradient + the shortcut gradient
 ])
 def test_output_heavy_pointwise_kernels_are_exact_in_the_emulator(name, kw):
     """csrc/asm/po_gen.py (weights resident in AGPRs, rolling refill of the epilogue operands): every (K, BN) family with each epilogue —

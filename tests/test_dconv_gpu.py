@@ -93,7 +93,9 @@ def _pack_bits(mask):
 # of the 64-pixel tile
 PO_DGRAD = [(256, 56, 256, 64, "po_k64_b256"), (256, 56, 256, 128, "po_k128_b256"), (256, 28, 512, 128, "po_k128_b256"), (256, 28, 512, 256, "po_k256_b256"),
             (256, 14, 1024, 256, "po_k256_b256"), (256, 14, 1024, 512, "po_k512_b128"), (256, 7, 2048, 512, "po_k512_b128"),
-            (3, 14, 1024, 256, "po_k256_b256"), (5, 7, 2048, 512, "po_k512_b128"), (1, 56, 256, 64, "po_k64_b256")]
+            (3, 14, 1024, 256, "po_k256_b256"), (5, 7, 2048, 512, "po_k512_b128"), (1, 56, 256, 64, "po_k64_b256"),
+            # into 64 columns (waves 2 x 2, 128-pixel tiles): conv3's / the downsample conv's data gradient of layer 1, layer1.0's conv1
+            (256, 56, 64, 256, "po_k256_b64"), (256, 56, 64, 64, "po_k64_b64"), (3, 20, 64, 256, "po_k256_b64"), (1, 10, 64, 64, "po_k64_b64")]
 
 
 @pytest.mark.parametrize("N,H,Cx,Cy,fam", PO_DGRAD)
@@ -223,7 +225,8 @@ def test_bn_backward_sums_of_the_data_gradient_against_the_oracle(dev):
 
 
 @pytest.mark.parametrize("N,H,Cin,Cout,fam", [(256, 56, 64, 256, "po_k64_b256"), (256, 28, 128, 512, "po_k128_b256"), (7, 28, 128, 512, "po_k128_b256"),
-                                                (256, 56, 256, 128, "po_k256_b128"), (5, 20, 256, 128, "po_k256_b128")])
+                                                (256, 56, 256, 128, "po_k256_b128"), (5, 20, 256, 128, "po_k256_b128"),
+                                                (256, 56, 256, 64, "po_k256_b64"), (256, 56, 64, 64, "po_k64_b64"), (3, 10, 256, 64, "po_k256_b64")])
 def test_conv3_forward_of_layers_1_and_2_takes_the_resident_weight_kernel(dev, N, H, Cin, Cout, fam):
     from sota_imagenet_amd import ops
 

@@ -60,7 +60,7 @@ def run(name, M=200, N=None, groups=((0, 0),), tpg=None, seed=0, check=True, ext
     a_in, a_wt = mem.alloc(to_bf16_bits(x)), mem.alloc(to_bf16_bits(w))
     out0 = np.full((M, N), 0x7FC0, dtype=np.uint16)
     a_out = mem.alloc(out0)
-    a_stat = mem.alloc(np.full((G, 2, N), np.nan, dtype=np.float32))
+    a_stat = mem.alloc(np.full((G * c.WM, 2, N), np.nan, dtype=np.float32))   # (waves 2 x 2: the two waves that share columns leave a row each)
     a_y, a_bits, a_mu, a_is = mem.alloc(to_bf16_bits(yb)), mem.alloc(bits), mem.alloc(mean), mem.alloc(invstd)
     a_ad, a_ab = mem.alloc(to_bf16_bits(adc if c.add == 3 else ad)), mem.alloc(abits)
     lognct = nct.bit_length() - 1
@@ -92,8 +92,9 @@ def run(name, M=200, N=None, groups=((0, 0),), tpg=None, seed=0, check=True, ext
         touched[rows_of(gi), cols_of(ct)] = True
     res["max_err"] = (float(np.abs(np.where(touched, got - refr, 0.0)).max()) if not np.isnan(got[touched]).any() else float("nan")) if touched.any() else 0.0
     res["untouched_ok"] = bool(np.isnan(got[~touched]).all())
-    st = mem.array(a_stat, np.float32, (G, 2, N))
+    st = mem.array(a_stat, np.float32, (G * c.WM, 2, N))
     if c.stats:
+        stsum = st.reshape(G, c.WM, 2, N).astype(np.float64).sum(axis=1)
         err = 0.0
         scale = 1.0
         for (gi, ct) in groups:
@@ -106,11 +107,11 @@ def run(name, M=200, N=None, groups=((0, 0),), tpg=None, seed=0, check=True, ext
                 xhat = (yb.astype(np.float64)[rows_of(gi), cols_of(ct)] - mean[cols_of(ct)]) * invstd[cols_of(ct)]
                 s1, s2 = dz.sum(axis=0), (dz * xhat).sum(axis=0)
             scale = max(scale, np.abs(s1).max(), np.abs(s2).max())
-            err = max(err, np.abs(st[gi, 0, cols_of(ct)] - s1).max(), np.abs(st[gi, 1, cols_of(ct)] - s2).max())
+            err = max(err, np.abs(stsum[gi, 0, cols_of(ct)] - s1).max(), np.abs(stsum[gi, 1, cols_of(ct)] - s2).max())
         res["stat_err"] = float(err / scale)
-        tst = np.zeros((G, 2, N), dtype=bool)
+        tst = np.zeros((G * c.WM, 2, N), dtype=bool)
         for (gi, ct) in groups:
-            tst[gi, :, cols_of(ct)] = True
+            tst[gi * c.WM:(gi + 1) * c.WM, :, cols_of(ct)] = True
         res["untouched_ok"] = res["untouched_ok"] and bool(np.isnan(st[~tst]).all()) and not np.isnan(st[tst]).any()
     return res
 

@@ -11,7 +11,7 @@ K=$(echo $base | sed 's/po_k\([0-9]*\)_.*/\1/'); BN=$(echo $base | sed 's/.*_b\(
 ST=$(echo $base | sed 's/.*_s\([0-9]\)_.*/\1/'); AD=$(echo $base | sed 's/.*_a\([0-9]\)$/\1/')
 i=0
 for sets in "$@"; do
-  args=""; TP=64; WPC=1; for kv in $sets; do case $kv in WPC=*) WPC=${kv#WPC=}; continue;; MFR=*) TP=$((16 * ${kv#MFR=}));; esac; args="$args --set $kv"; done
+  args=""; TP=64; [ "$BN" = 64 ] && TP=128; WPC=1; for kv in $sets; do case $kv in WPC=*) WPC=${kv#WPC=}; continue;; MFR=*) TP=$((16 * ${kv#MFR=}));; esac; args="$args --set $kv"; done
   sfx="_t$i"
   python3 sota_imagenet_amd/csrc/asm/po_gen.py --out $out $args --suffix $sfx $base > /dev/null
   $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $out/$base$sfx.s -o $out/$base$sfx.o
