@@ -241,9 +241,20 @@ struct FinalizeArgs {
 };
 
 // MI355_BN_FIN_WIDE=0: the four-channel form for every layer (A/B switch, read once)
-static bool fin_wide() {
-  static const bool on = !(getenv("MI355_BN_FIN_WIDE") && getenv("MI355_BN_FIN_WIDE")[0] == '0');
-  return on;
+static int fin_wide_mode() {
+  static const int m = getenv("MI355_BN_FIN_WIDE") ? atoi(getenv("MI355_BN_FIN_WIDE")) : 2;
+  return m;
+}
+// one channel per workgroup?  0 never; 1: few channels and more than one pass of rows (round 5's first rule); 2 (default): also up to 512
+// channels from 128 rows on — four-channel workgroups leave most of the chip idle there and the kernel is a chain of load latencies
+// (same box: 18.15 -> 18.05 ms per step, 17.75 -> 17.69 on a faster box); 3 / 4: wider still (no further gain)
+static bool fin_one_channel(int C, int nblk) {
+  const int m = fin_wide_mode();
+  if (m <= 0) return false;
+  if (m == 1) return C <= 128 && nblk > 512;
+  if (m == 3) return (C <= 128 && nblk > 512) || (C <= 1024 && nblk >= 64);
+  if (m == 4) return true;
+  return (C <= 128 && nblk > 512) || (C <= 512 && nblk >= 128);
 }
 
 template <int MODE, int CPW = 4>
@@ -787,7 +798,7 @@ int launch_bn_finalize(const float* partial, const float* pivot, int nblk, int M
   a.shift = shift;
   a.eps = eps;
   a.momentum = momentum;
-  if (fin_wide() && C <= 128 && nblk > 512) hipLaunchKernelGGL((bn_finalize_kernel<0, 1>), dim3(C), dim3(256), 0, s, a);
+  if (fin_one_channel(C, nblk)) hipLaunchKernelGGL((bn_finalize_kernel<0, 1>), dim3(C), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((bn_finalize_kernel<0, 4>), dim3(C / 4), dim3(256), 0, s, a);
   MI355_LAUNCH_CHECK();
   return 0;
@@ -925,7 +936,7 @@ int launch_bn_bwd_finalize(const float* partial, int nblk, int M, int C, const f
   a.dbeta = dbeta;
   a.beta_acc = beta_acc;
   a.coef = coef;
-  if (fin_wide() && C <= 128 && nblk > 512) hipLaunchKernelGGL((bn_finalize_kernel<1, 1>), dim3(C), dim3(256), 0, s, a);
+  if (fin_one_channel(C, nblk)) hipLaunchKernelGGL((bn_finalize_kernel<1, 1>), dim3(C), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((bn_finalize_kernel<1, 4>), dim3(C / 4), dim3(256), 0, s, a);
   MI355_LAUNCH_CHECK();
   return 0;
