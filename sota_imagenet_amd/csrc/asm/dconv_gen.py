@@ -1192,6 +1192,26 @@ def _other_sizes():
 _other_sizes()
 
 
+def _variant_model_sizes():
+    """BASELINE configs[3]'s 3x3 launches that ResNet-50 does not have (anti-aliased BResNet-50: the stride of a striding block moves behind
+    conv2 into the blur pool, so its conv2 runs at the INPUT resolution — 56 x 56 x 128, 28 x 28 x 256, 14 x 14 x 512 — and the deep stem has two
+    3x3 convolutions at 112 x 112 on 32 channels zero-padded to 64; /root/reference/configs/_old_configs/_first_attempts/BResNet50_encoder.yaml:41-51).
+    The backward of that model has no fused BN-backward sums (leaky ReLU): forward (s1) and plain data gradient (s0) only."""
+    geo = {
+        "v0": dict(H=112, W=112, P=128, IPT=1, Cin=64, NCOLS=64, WM=4, WN=1, NT=4, ROWS_T=4),
+        "v2": dict(H=56, W=56, P=64, IPT=1, Cin=128, NCOLS=128, WM=4, WN=1, ROWS_T=4),
+        "v3": dict(H=28, W=28, P=32, IPT=1, Cin=256, NCOLS=256, ROWS_T=7),
+        "v4": dict(H=14, W=14, P=16, IPT=1, Cin=512, NCOLS=512),
+    }
+    for tag, kw in geo.items():
+        for st in (0, 1):
+            name = "dconv_%s_s%d" % (tag, st)
+            VARIANTS[name] = Cfg(name, stats=st, **kw)
+
+
+_variant_model_sizes()
+
+
 def generate(base, **over):
     c = VARIANTS[base]
     if over:

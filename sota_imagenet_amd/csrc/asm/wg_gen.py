@@ -645,6 +645,10 @@ VARIANTS = {
     "wg3_l2b": WCfg("wg3_l2b", H=40, W=40, P=48, C=128, CO=128, geom="rows", DR=4),
     "wg3_l3b": WCfg("wg3_l3b", H=20, W=20, P=32, C=256, CO=256, geom="rows", DR=5),
     "wg3_l4b": WCfg("wg3_l4b", H=10, W=10, P=16, C=512, CO=512, geom="img", DR=10),
+    # BResNet-50 (configs[3]): conv2 of a striding block runs at the block's INPUT resolution (the stride sits in the blur pool behind it)
+    "wg3_v2": WCfg("wg3_v2", H=56, W=56, P=64, C=128, CO=128, geom="rows", DR=2),
+    "wg3_v3": WCfg("wg3_v3", H=28, W=28, P=32, C=256, CO=256, geom="rows", DR=7),
+    "wg3_v4": WCfg("wg3_v4", H=14, W=14, P=16, C=512, CO=512, geom="img", DR=14),
 }
 
 

@@ -153,6 +153,7 @@ struct mi355_bctx {
   bool use_bits = true;    // leaky-ReLU masks travel as one bit per element (MI355_BRESNET_BITS=0: backward reads the activation itself)
   bool lazy_dz3 = true;    // bn3's backward forms its input gradient from the ECA backward on the fly (MI355_BRESNET_LAZY_DZ3=0: stored)
   bool lazy_bn = true;     // bn3 / downsample BN normalised inside the fused ECA pass, their outputs never stored (MI355_BRESNET_LAZY_BN=0: stored)
+  bool eca_sums = true;    // bn3's BatchNorm-backward sums from the per-image sums of the fused ECA backward: no reduction pass over the tensors (MI355_BRESNET_ECA_SUMS=0: its own pass)
   bool fused_eca = true;   // ECA gate x drop-connect x shortcut add x activation in one pass each way (MI355_BRESNET_FUSED_ECA=0: op by op)
   bool have_fwd = false, dropped = false;  // state of the last forward: training pass / dropout mask in use
   double fwd_flops = 0;
@@ -319,7 +320,8 @@ int conv_bn(mi355_bctx* c, VConv& v, VBN& b, const void* in, bool training, floa
 
 // v.dy = gradient wrt the conv output, from the gradient wrt the activation b.dout (dout may be another buffer)
 // eg (optional): `dout` is the gradient wrt an ECA module's OUTPUT side (see EcaGrad): both passes form the module's input gradient on the fly
-int bn_back(mi355_bctx* c, VConv& v, VBN& b, const void* dout, float beta, hipStream_t s, const EcaGrad* eg = nullptr) {
+// have_rows > 0: the partial rows of the sums are already in c->bn_ws (left by the fused ECA backward): no reduction pass
+int bn_back(mi355_bctx* c, VConv& v, VBN& b, const void* dout, float beta, hipStream_t s, const EcaGrad* eg = nullptr, int have_rows = 0) {
   const int M = c->N * v.Hout * v.Wout;
   BNP q;
   MI355_TRY(bn_params(c, b, q, false, s));  // (the staged gamma of this step's forward is still there)
@@ -330,8 +332,8 @@ int bn_back(mi355_bctx* c, VConv& v, VBN& b, const void* dout, float beta, hipSt
     const uint8_t* bits = b.has_bits ? b.bits : nullptr;
     const void* mask = (b.act != ACT_NONE && !bits) ? b.out : nullptr;
     const float slope = b.act == ACT_LEAKY ? 0.01f : 0.f;
-    int nblk = 0;
-    MI355_TRY(launch_bn_bwd_reduce(c->dtype, dout, mask, v.y, b.mean, b.invstd, nullptr, partial, &nblk, M, b.Cp, s, bits, slope, eg));
+    int nblk = have_rows;
+    if (nblk == 0) MI355_TRY(launch_bn_bwd_reduce(c->dtype, dout, mask, v.y, b.mean, b.invstd, nullptr, partial, &nblk, M, b.Cp, s, bits, slope, eg));
     MI355_TRY(launch_bn_bwd_finalize(partial, nblk, M, b.Cp, q.g, b.invstd, q.dg, q.db, staged ? 0.f : beta, coef, s));
     MI355_TRY(launch_bn_bwd_apply(c->dtype, dout, mask, v.y, b.mean, b.invstd, coef, v.dy, M, b.Cp, s, bits, slope, QuantOut(), eg));
   }
@@ -560,7 +562,7 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
   c->wg_ws_bytes = std::max(ws_max, fc_wg);
   ar.add(&c->wg_ws, c->wg_ws_bytes);
   ar.add(&c->dw_tmp, dw_max * 4);
-  ar.add(&c->eca_ws, ((size_t)2 * N * 2048 + 1152) * 4);
+  ar.add(&c->eca_ws, ((size_t)5 * N * 2048 + 1152) * 4);  // [s][dpool][dw parts][3 per-image sums for bn3's backward]
   c->arena_bytes = ar.size;
   if (hipMalloc((void**)&c->arena, c->arena_bytes) != hipSuccess) {
     set_error("bresnet50_create: hipMalloc(%zu bytes) failed: %s", c->arena_bytes, hipGetErrorString(hipGetLastError()));
@@ -593,6 +595,8 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
   c->lazy_bn = !(lb && lb[0] == '0');
   const char* fe = getenv("MI355_BRESNET_FUSED_ECA");
   c->fused_eca = !(fe && fe[0] == '0');
+  const char* esw = getenv("MI355_BRESNET_ECA_SUMS");
+  c->eca_sums = !(esw && esw[0] == '0');
   bool ok = true;
   if (c->overlap) {
     ok = hipStreamCreateWithFlags(&c->wstream, hipStreamNonBlocking) == hipSuccess;
@@ -789,14 +793,15 @@ int mi355_bresnet50_backward(mi355_bctx* c, const float* dlogits, int accumulate
     VBlock& b = c->blocks[i];
     const void* xin = i > 0 ? c->blocks[i - 1].out : c->p;
     const int C4 = 4 * b.planes;
-    bool lazy_dz = false;
+    bool lazy_dz = false, sums_row = false;
     if (c->fused_eca) {
       // pass 2 of the ECA backward (dz3 = dsc * keep * gate + dpool) is left to bn3's backward, which forms it on the fly from dsc in
       // both of its passes: the gradient wrt bn3's output is never stored
       lazy_dz = c->lazy_dz3;
+      sums_row = lazy_dz && b.b3.lazy && c->eca_sums && b.b3.Cp == C4;  // pass 1 leaves what bn3's backward needs from the tensors
       MI355_TRY(launch_eca_residual_bwd(dt, g, b.out, b.b3.lazy ? b.c3.y : b.b3.out, b.scaled ? b.keep : nullptr, c->params + b.eca_off, 3, b.pooled, b.gate,
                                         b.dsc, lazy_dz ? nullptr : b.b3.dout, c->grads + b.eca_off, beta, c->eca_ws, N, b.Ho * b.Wo, C4, ACT_LEAKY, s,
-                                        b.b3.lazy ? b.b3.scale : nullptr, b.b3.shift));
+                                        b.b3.lazy ? b.b3.scale : nullptr, b.b3.shift, sums_row ? (float*)c->bn_ws : nullptr, b.b3.mean, b.b3.invstd));
     } else {
       MI355_TRY(mi355_residual_act_bwd(dt, g, b.out, b.scaled ? b.keep : nullptr, b.de, b.dsc, N, (size_t)b.Ho * b.Wo * C4, ACT_LEAKY, s));
       MI355_TRY(mi355_eca_bwd(dt, b.de, b.b3.out, c->params + b.eca_off, 3, b.pooled, b.gate, b.b3.dout, c->grads + b.eca_off, beta, c->eca_ws, N,
@@ -805,7 +810,7 @@ int mi355_bresnet50_backward(mi355_bctx* c, const float* dlogits, int accumulate
     if (lazy_dz) {
       EcaGrad eg;
       eg.keep = b.scaled ? b.keep : nullptr; eg.gate = b.gate; eg.dpool = c->eca_ws + (size_t)N * C4; eg.hw = b.Ho * b.Wo;
-      MI355_TRY(bn_back(c, b.c3, b.b3, b.dsc, beta, s, &eg));
+      MI355_TRY(bn_back(c, b.c3, b.b3, b.dsc, beta, s, &eg, sums_row ? 1 : 0));
     } else {
       MI355_TRY(bn_back(c, b.c3, b.b3, b.b3.dout, beta, s));
     }

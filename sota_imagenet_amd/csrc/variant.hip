@@ -384,19 +384,21 @@ __global__ __launch_bounds__(256) void eca_residual_fwd_kernel(const T* x, const
 // Backward, pass 1: dz = dout * act'(out) is the shortcut gradient (stored) and, times keep[n], the gradient of the gated tensor, whose
 // product with x summed over the pixels is what the gate's backward needs: s[n][c] = sum_hw dz * keep[n] * x.  Work layout and summation
 // order of eca_prod_reduce_kernel.
-template <typename T>
+// SUMS: also a[n][c] = sum_hw dz, b[n][c] = sum_hw dz * x (x raw: the conv output under the on-the-fly BatchNorm), y[n][c] = sum_hw x into
+// sums[0 .. 2][N][C] — everything the BatchNorm backward of x's layer needs from the big tensors (eca_bn_sums_kernel below)
+template <typename T, bool SUMS>
 __global__ __launch_bounds__(256) void eca_residual_bwd_reduce_kernel(const T* dout, const T* out, const T* x, const float* keep, T* dshortcut, float* s, int N,
-                                                                      int HW, int C, int act, const float* xs, const float* xh) {
+                                                                      int HW, int C, int act, const float* xs, const float* xh, float* sums) {
   constexpr int V = Vec16<T>::N;
   __shared__ float red[32][8 * V + 1];
   const int slabs = C / (8 * V);
   const int n = blockIdx.x / slabs, c0 = (blockIdx.x % slabs) * 8 * V;
   const int cv = threadIdx.x & 7, r = threadIdx.x >> 3;
   const float kn = keep ? keep[n] : 1.f;
-  float acc[V], sc[V], sh[V];
+  float acc[V], sc[V], sh[V], sa[V], sb[V], sy[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) {
-    acc[e] = 0.f;
+    acc[e] = sa[e] = sb[e] = sy[e] = 0.f;
     sc[e] = xs ? xs[c0 + cv * V + e] : 1.f;
     sh[e] = xs ? xh[c0 + cv * V + e] : 0.f;
   }
@@ -410,22 +412,81 @@ __global__ __launch_bounds__(256) void eca_residual_bwd_reduce_kernel(const T* d
     for (int e = 0; e < V; ++e) {
       g[e] *= act_slope(ov[e], act);
       acc[e] += g[e] * kn * fmaf(xv[e], sc[e], sh[e]);
+      if constexpr (SUMS) {
+        const float gr = (float)(T)g[e];  // the value stored below: what the later passes read
+        sa[e] += gr;
+        sb[e] = fmaf(gr, xv[e], sb[e]);
+        sy[e] += xv[e];
+      }
     }
     Vec16<T>::store(dshortcut + o, g);
   }
+  // rows r = 8w .. 8w + 7 of a channel vector sit in one wave (lane = (r & 7) * 8 + cv): shuffles across them, then the four waves through LDS
+  auto wave_sum = [&](float (&v)[V]) __attribute__((always_inline)) {
 #pragma unroll
-  for (int e = 0; e < V; ++e) red[r][cv * V + e] = acc[e];
-  __syncthreads();
-  for (int st = 16; st > 0; st >>= 1) {
-    if (r < st) {
+    for (int off = 8; off < 64; off <<= 1) {
 #pragma unroll
-      for (int e = 0; e < V; ++e) red[r][cv * V + e] += red[r + st][cv * V + e];
+      for (int e = 0; e < V; ++e) v[e] += __shfl_xor(v[e], off);
     }
-    __syncthreads();
+  };
+  wave_sum(acc);
+  if constexpr (SUMS) {
+    wave_sum(sa);
+    wave_sum(sb);
+    wave_sum(sy);
   }
-  if (r == 0) {
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < 8) {  // (rows 4 * k of `red`: array k; columns: wave, channel)
 #pragma unroll
-    for (int e = 0; e < V; ++e) s[(size_t)n * C + c0 + cv * V + e] = red[0][cv * V + e];
+    for (int e = 0; e < V; ++e) {
+      red[wv][cv * V + e] = acc[e];
+      if constexpr (SUMS) {
+        red[4 + wv][cv * V + e] = sa[e];
+        red[8 + wv][cv * V + e] = sb[e];
+        red[12 + wv][cv * V + e] = sy[e];
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int NARR = SUMS ? 4 : 1;
+  for (int i = threadIdx.x; i < NARR * 8 * V; i += 256) {
+    const int k = i / (8 * V), ch = i % (8 * V);
+    const float t = (red[4 * k][ch] + red[4 * k + 1][ch]) + (red[4 * k + 2][ch] + red[4 * k + 3][ch]);
+    float* dst = k == 0 ? s : sums + (size_t)(k - 1) * N * C;
+    dst[(size_t)n * C + c0 + ch] = t;
+  }
+}
+// BatchNorm-backward sums of the layer under the ECA module WITHOUT a second pass over the tensors: with dz3 = dz * keep[n] * gate[n][c] + dpool[n][c],
+//   sum dz3        = sum_n keep gate a + HW dpool
+//   sum dz3 * xhat = invstd * sum_n [ keep gate (b - mean a) + dpool (y - HW mean) ]          (xhat = (x - mean) * invstd)
+// from the per-image sums of pass 1 — one partial row [2][C] for bn_finalize (fp64 over the images, in image order)
+__global__ __launch_bounds__(256) void eca_bn_sums_kernel(const float* sums, const float* gate, const float* dpool, const float* keep, const float* mean,
+                                                          const float* invstd, float* row, int N, int C, int HW) {
+  // 16 channels x 16 image slices per workgroup (a serial walk over the images is a chain of 256 load latencies); slices added in slice order
+  __shared__ double red[2][16][16];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const double mu = (double)mean[c], hw = (double)HW;
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+  for (int n = sl; n < N; n += 16) {
+    const size_t o = (size_t)n * C + c;
+    const double kg = (double)(keep ? keep[n] : 1.f) * (double)gate[o], dp = (double)dpool[o];
+    const double a = (double)sums[o], b = (double)sums[(size_t)N * C + o], y = (double)sums[(size_t)2 * N * C + o];
+    s1 += kg * a + hw * dp;
+    s2 += kg * (b - mu * a) + dp * (y - hw * mu);
+  }
+  red[0][sl][cl] = s1;
+  red[1][sl][cl] = s2;
+  __syncthreads();
+  if (sl == 0) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int k = 0; k < 16; ++k) {
+      t1 += red[0][k][cl];
+      t2 += red[1][k][cl];
+    }
+    row[c] = (float)t1;
+    row[C + c] = (float)(t2 * (double)invstd[c]);
   }
 }
 // pass 2: dx = dz * keep[n] * gate[n][c] + dpool[n][c]
@@ -638,17 +699,30 @@ int launch_eca_residual_fwd(int dtype, const void* x, const float* w, int k, con
 // its backward from dout: dshortcut (the shortcut operand's gradient), dx (the ECA input's), dw[k] (beta 0 / 1); ws: 2*N*C + 1152 floats
 int launch_eca_residual_bwd(int dtype, const void* dout, const void* out, const void* x, const float* keep, const float* w, int k, const float* pooled,
                             const float* gate, void* dshortcut, void* dx, float* dw, float beta, float* ws, int N, int HW, int C, int act, hipStream_t s,
-                            const float* xs, const float* xh) {
+                            const float* xs, const float* xh, float* bn_row, const float* bn_mean, const float* bn_invstd) {
   // dx == nullptr: pass 2 is left to the consumer — dx = dshortcut * keep[n] * gate[n][c] + dpool[n][c] with dpool = ws + N * C (EcaGrad)
-  float *sprod = ws, *dpool = ws + (size_t)N * C, *dwpart = ws + (size_t)2 * N * C;
-  if (dtype == MI355_F32)
-    hipLaunchKernelGGL(eca_residual_bwd_reduce_kernel<float>, dim3(N * (C / 32)), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)x, keep,
-                       (float*)dshortcut, sprod, N, HW, C, act, xs, xh);
-  else
-    hipLaunchKernelGGL(eca_residual_bwd_reduce_kernel<bf16_t>, dim3(N * (C / 64)), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x,
-                       keep, (bf16_t*)dshortcut, sprod, N, HW, C, act, xs, xh);
+  // bn_row (with dx == nullptr and x given raw under xs / xh; ws then holds 5*N*C + 1152 floats): the BatchNorm-backward sums of x's layer as one
+  // partial row [2][C], from the per-image sums of pass 1 (eca_bn_sums_kernel)
+  float *sprod = ws, *dpool = ws + (size_t)N * C, *dwpart = ws + (size_t)2 * N * C, *sums = ws + (size_t)2 * N * C + 1152;
+  MI355_ARG(!bn_row || (!dx && xs && xh && bn_mean && bn_invstd), "eca_residual_bwd: the BatchNorm sums need the raw tensor form and no stored dx");
+  if (dtype == MI355_F32) {
+    if (bn_row)
+      hipLaunchKernelGGL((eca_residual_bwd_reduce_kernel<float, true>), dim3(N * (C / 32)), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)x, keep,
+                         (float*)dshortcut, sprod, N, HW, C, act, xs, xh, sums);
+    else
+      hipLaunchKernelGGL((eca_residual_bwd_reduce_kernel<float, false>), dim3(N * (C / 32)), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)x, keep,
+                         (float*)dshortcut, sprod, N, HW, C, act, xs, xh, nullptr);
+  } else {
+    if (bn_row)
+      hipLaunchKernelGGL((eca_residual_bwd_reduce_kernel<bf16_t, true>), dim3(N * (C / 64)), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x,
+                         keep, (bf16_t*)dshortcut, sprod, N, HW, C, act, xs, xh, sums);
+    else
+      hipLaunchKernelGGL((eca_residual_bwd_reduce_kernel<bf16_t, false>), dim3(N * (C / 64)), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x,
+                         keep, (bf16_t*)dshortcut, sprod, N, HW, C, act, xs, xh, nullptr);
+  }
   hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3(ECA_GB), dim3(256), 0, s, sprod, gate, pooled, w, k, dpool, dwpart, N, C, 1.f / (float)HW);
   hipLaunchKernelGGL(eca_dw_finish_kernel, dim3(1), dim3(64), 0, s, dwpart, dw, k, beta);
+  if (bn_row) hipLaunchKernelGGL(eca_bn_sums_kernel, dim3(C / 16), dim3(256), 0, s, sums, gate, dpool, keep, bn_mean, bn_invstd, bn_row, N, C, HW);
   if (!dx) {
     MI355_LAUNCH_CHECK();
     return 0;

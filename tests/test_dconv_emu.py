@@ -36,6 +36,9 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang"
     ("dconv_l2a_s2", dict(Cin=64, tiles=(3,), dgrad_taps=True)), ("dconv_l1a_s1", dict(tiles=(0, 1, 4))),      # 10-row / 8-row tiles at pitch 32 / 48
     ("dconv_l4b_s1", dict(Cin=64, ntile=1)), ("dconv_l3b_s2", dict(Cin=64, tiles=(4, 6), dgrad_taps=True)),    # 5-row tiles of 20 x 20 images
     ("dconv_l2b_s1", dict(Cin=64, tiles=(0, 2, 4))), ("dconv_l1b_s2", dict(tiles=(20, 39), dgrad_taps=True)),  # pitch 48 / 96: three / six fragments per row
+    # BASELINE configs[3] (BResNet-50): the deep stem's 3x3s at 112 x 112 (pitch 128), conv2 of the striding blocks at their input resolution
+    ("dconv_v0_s1", dict(tiles=(0, 27, 29))), ("dconv_v0_s0", dict(tiles=(30,), dgrad_taps=True)),
+    ("dconv_v2_s1", dict(Cin=64, tiles=(0, 13, 14))), ("dconv_v3_s1", dict(Cin=64, tiles=(0, 3, 5))), ("dconv_v4_s0", dict(Cin=64, tiles=(1,), ntile=1, dgrad_taps=True)),
 ])
 def test_direct_conv_kernels_are_exact_in_the_emulator(name, kw):
     r = D.run(name, **kw)
@@ -83,7 +86,9 @@ def test_the_emulator_rejects_an_lds_read_before_the_dma_wait():
                                      # 160 / 320 px: pitch 48 (six 8-position blocks per row: pieces dealt rows x blocks as 2 x 2), 5-row tiles, 10 x 10 images
                                      ("wg3_l1a", dict(splits=2, tps=6)), ("wg3_l2a", dict(splits=3, tps=3, pairs=((1, 0),))), ("wg3_l3a", dict(splits=2, tps=2, pairs=((3, 2),))),
                                      ("wg3_l1b", dict(splits=1, tps=5)), ("wg3_l2b", dict(splits=2, tps=3, pairs=((0, 1),))), ("wg3_l3b", dict(splits=3, tps=3, pairs=((2, 3),))),
-                                     ("wg3_l4b", dict(splits=2, tps=1, pairs=((5, 7),)))])
+                                     ("wg3_l4b", dict(splits=2, tps=1, pairs=((5, 7),))),
+                                     # BResNet-50's striding blocks (conv2 at the input resolution)
+                                     ("wg3_v2", dict(splits=2, tps=3, pairs=((1, 0),))), ("wg3_v3", dict(splits=1, tps=5, pairs=((3, 2),))), ("wg3_v4", dict(splits=2, tps=2, pairs=((7, 1),)))])
 def test_weight_gradient_kernels_are_exact_in_the_emulator(name, kw):
     """csrc/asm/wg_gen.py: odd and single tile counts per split, splits that end inside an image (row tiles), last channel tiles;
     every slab element of the run workgroups exact, nothing else written, no LDS-DMA protocol violation"""

@@ -17,7 +17,9 @@ SHAPES = [(256, 14, 256, 256, 3), (256, 7, 512, 512, 3), (256, 28, 128, 128, 3),
 SHAPES_OTHER = [(32, 40, 64, 64, 3, "dconv_l1a"), (32, 20, 128, 128, 3, "dconv_l2a"), (64, 10, 256, 256, 3, "dconv_l3a"), (64, 5, 512, 512, 3, "dconv_l4a"),
                 (8, 80, 64, 64, 3, "dconv_l1b"), (16, 40, 128, 128, 3, "dconv_l2b"), (32, 20, 256, 256, 3, "dconv_l3b"), (64, 10, 512, 512, 3, "dconv_l4b"),
                 (64, 10, 1024, 256, 1, "pk_k1024_n256_w200"), (64, 5, 2048, 512, 1, "pk_k2048_n512_w100"), (32, 20, 512, 128, 1, "po_k512_b128"),
-                (64, 10, 1024, 512, 1, "pk_k1024_n512_w200")]
+                (64, 10, 1024, 512, 1, "pk_k1024_n512_w200"),
+                # BASELINE configs[3] (anti-aliased BResNet-50): conv2 of the striding blocks at their input resolution, the deep stem's 3x3s at 112 x 112
+                (16, 112, 64, 64, 3, "dconv_v0"), (32, 56, 128, 128, 3, "dconv_v2"), (64, 28, 256, 256, 3, "dconv_v3"), (256, 14, 512, 512, 3, "dconv_v4")]
 
 
 def _ref(x, w, K):
@@ -311,7 +313,9 @@ def test_other_batch_sizes_take_the_same_kernels(dev):
 WG_SHAPES = [(256, 14, 256, 256), (256, 28, 128, 128), (256, 7, 512, 512), (256, 56, 64, 64), (8, 14, 256, 256), (12, 28, 128, 128), (20, 7, 512, 512),
              (5, 56, 64, 64), (64, 112, 64, 64),
              # 160 / 320 px (wg3_l{1,2,3}a, wg3_l{1,2,3,4}b)
-             (24, 40, 64, 64), (40, 20, 128, 128), (100, 10, 256, 256), (6, 80, 64, 64), (12, 40, 128, 128), (36, 20, 256, 256), (100, 10, 512, 512)]
+             (24, 40, 64, 64), (40, 20, 128, 128), (100, 10, 256, 256), (6, 80, 64, 64), (12, 40, 128, 128), (36, 20, 256, 256), (100, 10, 512, 512),
+             # BResNet-50's striding blocks (wg3_v{2,3,4})
+             (9, 56, 128, 128), (20, 28, 256, 256), (256, 14, 512, 512)]
 
 
 def _wgrad_ref(dy, x):

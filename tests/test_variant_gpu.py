@@ -339,6 +339,30 @@ def test_static_executor_at_the_baseline_batch(dev, monkeypatch):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_bn3_backward_sums_from_the_eca_pass_match_the_reduction_pass(dev, dtype, monkeypatch):
+    """default: the BatchNorm-backward sums of bn3 come out of the fused ECA backward's per-image sums (no pass over the tensors:
+    sum dz3 = sum_n keep gate a + HW dpool, ...); MI355_BRESNET_ECA_SUMS=0: the reduction pass that forms dz3 on the fly.  Same arithmetic up to
+    the summation order (fp32) and the bf16 rounding of dz3 the reduction pass applies before summing."""
+    from sota_imagenet_amd.bresnet import BResNet50
+    from sota_imagenet_amd.synth import synthetic_batch
+
+    N, S = 8, 64
+    data, target = synthetic_batch(N, S, seed=0, index=3, device="cuda")
+    grads = []
+    for sw in ("1", "0"):
+        monkeypatch.setenv("MI355_BRESNET_ECA_SUMS", sw)
+        m = BResNet50(dtype=dtype, drop_rate=0.0, drop_connect_rate=0.2, weight_standardization=True, seed=4).cuda()
+        m.train()
+        R.smooth_ce(m(data), target, 0.1).backward()
+        torch.cuda.synchronize()
+        grads.append(m.flat_grads.detach().clone())
+        segs = m._segments
+    errs = [((grads[0][b:e] - grads[1][b:e]).norm() / grads[1][b:e].norm().clamp_min(1e-30)).item() for b, e in segs]
+    assert max(errs) < (1e-4 if dtype == "fp32" else 5e-2), ["%.1e" % x for x in errs]
+    assert not torch.equal(grads[0], grads[1]) or dtype == "fp32"
+
+
 def test_static_executor_at_the_baseline_batch_default_fused_tail_against_the_oracle(dev):
     """BASELINE configs[3] at its own size (bs 256, 224 px, bf16) in the DEFAULT environment — the fused ECA x drop-connect x shortcut x
     leaky-ReLU pass with bn3 / the downsample BN applied inside it (MI355_BRESNET_FUSED_ECA, MI355_BRESNET_LAZY_BN at their defaults),
