@@ -88,6 +88,8 @@ struct VBlock {
   void *e = nullptr, *de = nullptr;      // ECA output
   float *pooled = nullptr, *gate = nullptr, *keep = nullptr;
   void *out = nullptr;            // block output
+  uint8_t* out_bits = nullptr;    // its sign bits (one byte per 16-byte vector), written by the fused ECA forward for the backward's activation slope
+  bool has_out_bits = false;      // ... by the last forward
   void *dsc = nullptr;            // gradient wrt the shortcut operand
   void *dxb = nullptr, *dxs = nullptr, *dx = nullptr;  // gradient wrt the block input: branch, shortcut, sum
   bool scaled = false;            // the last forward scaled the branch by `keep` (drop-connect)
@@ -535,6 +537,7 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
       plan_conv(c, ar, b.ds); plan_bn(c, ar, b.bd, b.Ho, b.Wo, false);
     }
     ar.add(&b.out, o);
+    ar.add(&b.out_bits, o / 16);
     ar.add(&b.dsc, o);
     const size_t ib = act_bytes(b.H, b.W, b.cin);
     ar.add(&b.dxb, ib);
@@ -731,10 +734,11 @@ int mi355_bresnet50_forward(mi355_bctx* c, const float* x_nchw, float* logits, i
       MI355_TRY(mi355_keep_scale(b.keep, (size_t)N, c->drop_connect * (float)i / (float)nblocks, c->seed, step * 64 + (unsigned long long)i, s));
       b.scaled = true;
     }
+    b.has_out_bits = c->fused_eca && c->use_bits && tr;
     if (c->fused_eca)  // gate, drop-connect scale, shortcut add and activation in one pass: the gated tensor is never stored
       MI355_TRY(launch_eca_residual_fwd(dt, b.b3.lazy ? b.c3.y : b.b3.out, c->params + b.eca_off, 3, b.scaled ? b.keep : nullptr, sc, b.out, b.pooled, b.gate, N,
                                         b.Ho * b.Wo, C4, ACT_LEAKY, s, b.b3.lazy ? b.b3.scale : nullptr, b.b3.shift,
-                                        (b.has_ds && b.bd.lazy) ? b.bd.scale : nullptr, b.bd.shift));
+                                        (b.has_ds && b.bd.lazy) ? b.bd.scale : nullptr, b.bd.shift, b.has_out_bits ? b.out_bits : nullptr));
     else
       MI355_TRY(mi355_residual_act_fwd(dt, b.e, b.scaled ? b.keep : nullptr, sc, b.out, N, (size_t)b.Ho * b.Wo * C4, ACT_LEAKY, s));
     x = b.out;
@@ -801,7 +805,8 @@ int mi355_bresnet50_backward(mi355_bctx* c, const float* dlogits, int accumulate
       sums_row = lazy_dz && b.b3.lazy && c->eca_sums && b.b3.Cp == C4;  // pass 1 leaves what bn3's backward needs from the tensors
       MI355_TRY(launch_eca_residual_bwd(dt, g, b.out, b.b3.lazy ? b.c3.y : b.b3.out, b.scaled ? b.keep : nullptr, c->params + b.eca_off, 3, b.pooled, b.gate,
                                         b.dsc, lazy_dz ? nullptr : b.b3.dout, c->grads + b.eca_off, beta, c->eca_ws, N, b.Ho * b.Wo, C4, ACT_LEAKY, s,
-                                        b.b3.lazy ? b.b3.scale : nullptr, b.b3.shift, sums_row ? (float*)c->bn_ws : nullptr, b.b3.mean, b.b3.invstd));
+                                        b.b3.lazy ? b.b3.scale : nullptr, b.b3.shift, sums_row ? (float*)c->bn_ws : nullptr, b.b3.mean, b.b3.invstd,
+                                        b.has_out_bits ? b.out_bits : nullptr));
     } else {
       MI355_TRY(mi355_residual_act_bwd(dt, g, b.out, b.scaled ? b.keep : nullptr, b.de, b.dsc, N, (size_t)b.Ho * b.Wo * C4, ACT_LEAKY, s));
       MI355_TRY(mi355_eca_bwd(dt, b.de, b.b3.out, c->params + b.eca_off, 3, b.pooled, b.gate, b.b3.dout, c->grads + b.eca_off, beta, c->eca_ws, N,

@@ -256,11 +256,11 @@ int launch_axpby(const float* src, float* dst, float beta, size_t n, hipStream_t
 // xs / xh (optional): x stands for x * xs[c] + xh[c] (a BatchNorm with identity activation applied on the fly); ss / sh2: the same for the shortcut
 int launch_eca_residual_fwd(int dtype, const void* x, const float* w, int k, const float* keep, const void* shortcut, void* out, float* pooled, float* gate,
                             int N, int HW, int C, int act, hipStream_t s, const float* xs = nullptr, const float* xh = nullptr, const float* ss = nullptr,
-                            const float* sh2 = nullptr);
+                            const float* sh2 = nullptr, uint8_t* out_bits = nullptr);
 int launch_eca_residual_bwd(int dtype, const void* dout, const void* out, const void* x, const float* keep, const float* w, int k, const float* pooled,
                             const float* gate, void* dshortcut, void* dx, float* dw, float beta, float* ws, int N, int HW, int C, int act, hipStream_t s,
                             const float* xs = nullptr, const float* xh = nullptr, float* bn_row = nullptr, const float* bn_mean = nullptr,
-                            const float* bn_invstd = nullptr);
+                            const float* bn_invstd = nullptr, const uint8_t* out_bits = nullptr);
 // fp8 step: scale[i] = amax[i] > 0 ? 448 / (headroom * amax[i]) : scale[i];  amax[i] = 0   (delayed per-tensor scaling)
 int launch_fp8_scale_update(float* scale, unsigned* amax, int n, float headroom, hipStream_t s);
 

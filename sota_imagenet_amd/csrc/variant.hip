@@ -357,7 +357,7 @@ struct Affine {
 };
 template <typename T>
 __global__ __launch_bounds__(256) void eca_residual_fwd_kernel(const T* x, const float* gate, const float* keep, const T* shortcut, T* out, int N, int HW,
-                                                               int C, int act, Affine af) {
+                                                               int C, int act, Affine af, uint8_t* bits) {
   constexpr int V = Vec16<T>::N;
   const int CV = C / V;
   const size_t total = (size_t)N * HW * CV;
@@ -379,6 +379,12 @@ __global__ __launch_bounds__(256) void eca_residual_fwd_kernel(const T* x, const
 #pragma unroll
     for (int e = 0; e < V; ++e) v[e] = act_fwd(v[e] * gate[(size_t)n * C + cv * V + e] * kn + s[e], act);
     Vec16<T>::store(out + i * V, v);
+    if (bits) {  // the sign of the STORED value, one byte per 16-byte vector: what the backward's activation slope needs of `out`
+      unsigned b = 0;
+#pragma unroll
+      for (int e = 0; e < V; ++e) b |= ((float)(T)v[e] > 0.f ? 1u : 0u) << e;
+      __builtin_nontemporal_store((uint8_t)b, bits + i);
+    }
   }
 }
 // Backward, pass 1: dz = dout * act'(out) is the shortcut gradient (stored) and, times keep[n], the gradient of the gated tensor, whose
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(256) void eca_residual_fwd_kernel(const T* x, const
 // sums[0 .. 2][N][C] — everything the BatchNorm backward of x's layer needs from the big tensors (eca_bn_sums_kernel below)
 template <typename T, bool SUMS>
 __global__ __launch_bounds__(256) void eca_residual_bwd_reduce_kernel(const T* dout, const T* out, const T* x, const float* keep, T* dshortcut, float* s, int N,
-                                                                      int HW, int C, int act, const float* xs, const float* xh, float* sums) {
+                                                                      int HW, int C, int act, const float* xs, const float* xh, float* sums, const uint8_t* bits) {
   constexpr int V = Vec16<T>::N;
   __shared__ float red[32][8 * V + 1];
   const int slabs = C / (8 * V);
@@ -406,7 +412,13 @@ __global__ __launch_bounds__(256) void eca_residual_bwd_reduce_kernel(const T* d
     const size_t o = ((size_t)n * HW + p) * C + c0 + cv * V;
     float g[V], ov[V], xv[V];
     Vec16<T>::load(dout + o, g);
-    Vec16<T>::load(out + o, ov);
+    if (bits) {  // (uniform branch) the forward's sign bits stand for `out`: 1 byte instead of 16
+      const unsigned b = bits[o / V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) ov[e] = (b >> e) & 1u ? 1.f : -1.f;
+    } else {
+      Vec16<T>::load(out + o, ov);
+    }
     Vec16<T>::load(x + o, xv);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
@@ -683,23 +695,24 @@ int launch_weight_unpad(const float* dwp, float* dw, float beta, int Cout, int t
 }
 // out = act(eca(x) * keep[n] + shortcut); pooled / gate [N][C] are kept for backward (k = 3 ... 9 odd)
 int launch_eca_residual_fwd(int dtype, const void* x, const float* w, int k, const float* keep, const void* shortcut, void* out, float* pooled, float* gate,
-                            int N, int HW, int C, int act, hipStream_t s, const float* xs, const float* xh, const float* ss, const float* sh2) {
+                            int N, int HW, int C, int act, hipStream_t s, const float* xs, const float* xh, const float* ss, const float* sh2, uint8_t* out_bits) {
   MI355_TRY(mi355_gap_fwd(dtype, x, pooled, N, HW, C, s));
   if (xs) hipLaunchKernelGGL(pooled_affine_kernel, dim3(grid_for((size_t)N * C)), dim3(256), 0, s, pooled, xs, xh, N, C);
   hipLaunchKernelGGL(eca_gate_kernel, dim3(grid_for((size_t)N * C)), dim3(256), 0, s, pooled, w, k, gate, N, C);
   const Affine af{xs, xh, ss, sh2};
   const size_t total = (size_t)N * HW * C;
   if (dtype == MI355_F32)
-    hipLaunchKernelGGL(eca_residual_fwd_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)x, gate, keep, (const float*)shortcut, (float*)out, N, HW, C, act, af);
+    hipLaunchKernelGGL(eca_residual_fwd_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)x, gate, keep, (const float*)shortcut, (float*)out, N, HW, C, act, af, out_bits);
   else
-    hipLaunchKernelGGL(eca_residual_fwd_kernel<bf16_t>, dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)x, gate, keep, (const bf16_t*)shortcut, (bf16_t*)out, N, HW, C, act, af);
+    hipLaunchKernelGGL(eca_residual_fwd_kernel<bf16_t>, dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)x, gate, keep, (const bf16_t*)shortcut, (bf16_t*)out, N, HW, C, act, af, out_bits);
   MI355_LAUNCH_CHECK();
   return 0;
 }
 // its backward from dout: dshortcut (the shortcut operand's gradient), dx (the ECA input's), dw[k] (beta 0 / 1); ws: 2*N*C + 1152 floats
 int launch_eca_residual_bwd(int dtype, const void* dout, const void* out, const void* x, const float* keep, const float* w, int k, const float* pooled,
                             const float* gate, void* dshortcut, void* dx, float* dw, float beta, float* ws, int N, int HW, int C, int act, hipStream_t s,
-                            const float* xs, const float* xh, float* bn_row, const float* bn_mean, const float* bn_invstd) {
+                            const float* xs, const float* xh, float* bn_row, const float* bn_mean, const float* bn_invstd, const uint8_t* out_bits) {
+  // out_bits (optional): the sign bits the forward left for `out` (then `out` itself is not read)
   // dx == nullptr: pass 2 is left to the consumer — dx = dshortcut * keep[n] * gate[n][c] + dpool[n][c] with dpool = ws + N * C (EcaGrad)
   // bn_row (with dx == nullptr and x given raw under xs / xh; ws then holds 5*N*C + 1152 floats): the BatchNorm-backward sums of x's layer as one
   // partial row [2][C], from the per-image sums of pass 1 (eca_bn_sums_kernel)
@@ -708,17 +721,17 @@ int launch_eca_residual_bwd(int dtype, const void* dout, const void* out, const 
   if (dtype == MI355_F32) {
     if (bn_row)
       hipLaunchKernelGGL((eca_residual_bwd_reduce_kernel<float, true>), dim3(N * (C / 32)), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)x, keep,
-                         (float*)dshortcut, sprod, N, HW, C, act, xs, xh, sums);
+                         (float*)dshortcut, sprod, N, HW, C, act, xs, xh, sums, out_bits);
     else
       hipLaunchKernelGGL((eca_residual_bwd_reduce_kernel<float, false>), dim3(N * (C / 32)), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)x, keep,
-                         (float*)dshortcut, sprod, N, HW, C, act, xs, xh, nullptr);
+                         (float*)dshortcut, sprod, N, HW, C, act, xs, xh, nullptr, out_bits);
   } else {
     if (bn_row)
       hipLaunchKernelGGL((eca_residual_bwd_reduce_kernel<bf16_t, true>), dim3(N * (C / 64)), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x,
-                         keep, (bf16_t*)dshortcut, sprod, N, HW, C, act, xs, xh, sums);
+                         keep, (bf16_t*)dshortcut, sprod, N, HW, C, act, xs, xh, sums, out_bits);
     else
       hipLaunchKernelGGL((eca_residual_bwd_reduce_kernel<bf16_t, false>), dim3(N * (C / 64)), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x,
-                         keep, (bf16_t*)dshortcut, sprod, N, HW, C, act, xs, xh, nullptr);
+                         keep, (bf16_t*)dshortcut, sprod, N, HW, C, act, xs, xh, nullptr, out_bits);
   }
   hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3(ECA_GB), dim3(256), 0, s, sprod, gate, pooled, w, k, dpool, dwpart, N, C, 1.f / (float)HW);
   hipLaunchKernelGGL(eca_dw_finish_kernel, dim3(1), dim3(64), 0, s, dwpart, dw, k, beta);
