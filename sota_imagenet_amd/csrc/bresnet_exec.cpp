@@ -323,7 +323,9 @@ int conv_bn(mi355_bctx* c, VConv& v, VBN& b, const void* in, bool training, floa
 // v.dy = gradient wrt the conv output, from the gradient wrt the activation b.dout (dout may be another buffer)
 // eg (optional): `dout` is the gradient wrt an ECA module's OUTPUT side (see EcaGrad): both passes form the module's input gradient on the fly
 // have_rows > 0: the partial rows of the sums are already in c->bn_ws (left by the fused ECA backward): no reduction pass
-int bn_back(mi355_bctx* c, VConv& v, VBN& b, const void* dout, float beta, hipStream_t s, const EcaGrad* eg = nullptr, int have_rows = 0) {
+// rows_at: ... kept elsewhere (the downsample BatchNorm's row waits there while other layers use c->bn_ws)
+int bn_back(mi355_bctx* c, VConv& v, VBN& b, const void* dout, float beta, hipStream_t s, const EcaGrad* eg = nullptr, int have_rows = 0,
+            const float* rows_at = nullptr) {
   const int M = c->N * v.Hout * v.Wout;
   BNP q;
   MI355_TRY(bn_params(c, b, q, false, s));  // (the staged gamma of this step's forward is still there)
@@ -336,7 +338,7 @@ int bn_back(mi355_bctx* c, VConv& v, VBN& b, const void* dout, float beta, hipSt
     const float slope = b.act == ACT_LEAKY ? 0.01f : 0.f;
     int nblk = have_rows;
     if (nblk == 0) MI355_TRY(launch_bn_bwd_reduce(c->dtype, dout, mask, v.y, b.mean, b.invstd, nullptr, partial, &nblk, M, b.Cp, s, bits, slope, eg));
-    MI355_TRY(launch_bn_bwd_finalize(partial, nblk, M, b.Cp, q.g, b.invstd, q.dg, q.db, staged ? 0.f : beta, coef, s));
+    MI355_TRY(launch_bn_bwd_finalize(have_rows && rows_at ? rows_at : partial, nblk, M, b.Cp, q.g, b.invstd, q.dg, q.db, staged ? 0.f : beta, coef, s));
     MI355_TRY(launch_bn_bwd_apply(c->dtype, dout, mask, v.y, b.mean, b.invstd, coef, v.dy, M, b.Cp, s, bits, slope, QuantOut(), eg));
   }
   if (staged) {
@@ -565,7 +567,7 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
   c->wg_ws_bytes = std::max(ws_max, fc_wg);
   ar.add(&c->wg_ws, c->wg_ws_bytes);
   ar.add(&c->dw_tmp, dw_max * 4);
-  ar.add(&c->eca_ws, ((size_t)5 * N * 2048 + 1152) * 4);  // [s][dpool][dw parts][3 per-image sums for bn3's backward]
+  ar.add(&c->eca_ws, ((size_t)6 * N * 2048 + 1152 + 2 * 2048) * 4);  // [s][dpool][dw parts][4 per-image sums for bn3's / the downsample BN's backward][the latter's row]
   c->arena_bytes = ar.size;
   if (hipMalloc((void**)&c->arena, c->arena_bytes) != hipSuccess) {
     set_error("bresnet50_create: hipMalloc(%zu bytes) failed: %s", c->arena_bytes, hipGetErrorString(hipGetLastError()));
@@ -797,16 +799,18 @@ int mi355_bresnet50_backward(mi355_bctx* c, const float* dlogits, int accumulate
     VBlock& b = c->blocks[i];
     const void* xin = i > 0 ? c->blocks[i - 1].out : c->p;
     const int C4 = 4 * b.planes;
-    bool lazy_dz = false, sums_row = false;
+    bool lazy_dz = false, sums_row = false, ds_row = false;
+    float* ds_row_at = c->eca_ws + (size_t)6 * N * 2048 + 1152;
     if (c->fused_eca) {
       // pass 2 of the ECA backward (dz3 = dsc * keep * gate + dpool) is left to bn3's backward, which forms it on the fly from dsc in
       // both of its passes: the gradient wrt bn3's output is never stored
       lazy_dz = c->lazy_dz3;
       sums_row = lazy_dz && b.b3.lazy && c->eca_sums && b.b3.Cp == C4;  // pass 1 leaves what bn3's backward needs from the tensors
+      ds_row = sums_row && b.has_ds && b.bd.lazy && b.bd.Cp == C4;      // ... and the downsample BatchNorm's (its output gradient is dsc itself)
       MI355_TRY(launch_eca_residual_bwd(dt, g, b.out, b.b3.lazy ? b.c3.y : b.b3.out, b.scaled ? b.keep : nullptr, c->params + b.eca_off, 3, b.pooled, b.gate,
                                         b.dsc, lazy_dz ? nullptr : b.b3.dout, c->grads + b.eca_off, beta, c->eca_ws, N, b.Ho * b.Wo, C4, ACT_LEAKY, s,
                                         b.b3.lazy ? b.b3.scale : nullptr, b.b3.shift, sums_row ? (float*)c->bn_ws : nullptr, b.b3.mean, b.b3.invstd,
-                                        b.has_out_bits ? b.out_bits : nullptr));
+                                        b.has_out_bits ? b.out_bits : nullptr, ds_row ? b.ds.y : nullptr, ds_row ? ds_row_at : nullptr, b.bd.mean, b.bd.invstd));
     } else {
       MI355_TRY(mi355_residual_act_bwd(dt, g, b.out, b.scaled ? b.keep : nullptr, b.de, b.dsc, N, (size_t)b.Ho * b.Wo * C4, ACT_LEAKY, s));
       MI355_TRY(mi355_eca_bwd(dt, b.de, b.b3.out, c->params + b.eca_off, 3, b.pooled, b.gate, b.b3.dout, c->grads + b.eca_off, beta, c->eca_ws, N,
@@ -835,7 +839,7 @@ int mi355_bresnet50_backward(mi355_bctx* c, const float* dlogits, int accumulate
     // shortcut gradient first: it is the addend of conv1's input gradient
     const void* gs = b.dsc;
     if (b.has_ds) {
-      MI355_TRY(bn_back(c, b.ds, b.bd, b.dsc, beta, s));
+      MI355_TRY(bn_back(c, b.ds, b.bd, b.dsc, beta, s, nullptr, ds_row ? 1 : 0, ds_row_at));
       MI355_TRY(conv_wgrad(c, b.ds, b.stride == 2 ? b.scin : xin, beta, s));
       if (b.stride == 2) {
         MI355_TRY(conv_dgrad(c, b.ds, b.dscin, nullptr, s));

@@ -260,7 +260,8 @@ int launch_eca_residual_fwd(int dtype, const void* x, const float* w, int k, con
 int launch_eca_residual_bwd(int dtype, const void* dout, const void* out, const void* x, const float* keep, const float* w, int k, const float* pooled,
                             const float* gate, void* dshortcut, void* dx, float* dw, float beta, float* ws, int N, int HW, int C, int act, hipStream_t s,
                             const float* xs = nullptr, const float* xh = nullptr, float* bn_row = nullptr, const float* bn_mean = nullptr,
-                            const float* bn_invstd = nullptr, const uint8_t* out_bits = nullptr);
+                            const float* bn_invstd = nullptr, const uint8_t* out_bits = nullptr, const void* ds_y = nullptr, float* ds_row = nullptr,
+                            const float* ds_mean = nullptr, const float* ds_invstd = nullptr);
 // fp8 step: scale[i] = amax[i] > 0 ? 448 / (headroom * amax[i]) : scale[i];  amax[i] = 0   (delayed per-tensor scaling)
 int launch_fp8_scale_update(float* scale, unsigned* amax, int n, float headroom, hipStream_t s);
 

@@ -392,19 +392,22 @@ __global__ __launch_bounds__(256) void eca_residual_fwd_kernel(const T* x, const
 // order of eca_prod_reduce_kernel.
 // SUMS: also a[n][c] = sum_hw dz, b[n][c] = sum_hw dz * x (x raw: the conv output under the on-the-fly BatchNorm), y[n][c] = sum_hw x into
 // sums[0 .. 2][N][C] — everything the BatchNorm backward of x's layer needs from the big tensors (eca_bn_sums_kernel below)
+// x2 (SUMS only, optional): the raw output of the downsample convolution, whose BatchNorm (identity activation) has dz itself as the gradient of its
+// output: d[n][c] = sum_hw dz * x2 into sums[3] — with a[n][c] all that layer's backward sums need (eca_ds_sums_kernel)
 template <typename T, bool SUMS>
 __global__ __launch_bounds__(256) void eca_residual_bwd_reduce_kernel(const T* dout, const T* out, const T* x, const float* keep, T* dshortcut, float* s, int N,
-                                                                      int HW, int C, int act, const float* xs, const float* xh, float* sums, const uint8_t* bits) {
+                                                                      int HW, int C, int act, const float* xs, const float* xh, float* sums, const uint8_t* bits,
+                                                                      const T* x2) {
   constexpr int V = Vec16<T>::N;
   __shared__ float red[32][8 * V + 1];
   const int slabs = C / (8 * V);
   const int n = blockIdx.x / slabs, c0 = (blockIdx.x % slabs) * 8 * V;
   const int cv = threadIdx.x & 7, r = threadIdx.x >> 3;
   const float kn = keep ? keep[n] : 1.f;
-  float acc[V], sc[V], sh[V], sa[V], sb[V], sy[V];
+  float acc[V], sc[V], sh[V], sa[V], sb[V], sy[V], sd[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) {
-    acc[e] = sa[e] = sb[e] = sy[e] = 0.f;
+    acc[e] = sa[e] = sb[e] = sy[e] = sd[e] = 0.f;
     sc[e] = xs ? xs[c0 + cv * V + e] : 1.f;
     sh[e] = xs ? xh[c0 + cv * V + e] : 0.f;
   }
@@ -431,6 +434,14 @@ __global__ __launch_bounds__(256) void eca_residual_bwd_reduce_kernel(const T* d
         sy[e] += xv[e];
       }
     }
+    if constexpr (SUMS) {
+      if (x2) {  // (uniform branch)
+        float dv[V];
+        Vec16<T>::load(x2 + o, dv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) sd[e] = fmaf((float)(T)g[e], dv[e], sd[e]);
+      }
+    }
     Vec16<T>::store(dshortcut + o, g);
   }
   // rows r = 8w .. 8w + 7 of a channel vector sit in one wave (lane = (r & 7) * 8 + cv): shuffles across them, then the four waves through LDS
@@ -446,6 +457,7 @@ __global__ __launch_bounds__(256) void eca_residual_bwd_reduce_kernel(const T* d
     wave_sum(sa);
     wave_sum(sb);
     wave_sum(sy);
+    wave_sum(sd);
   }
   const int wv = threadIdx.x >> 6;
   if ((threadIdx.x & 63) < 8) {  // (rows 4 * k of `red`: array k; columns: wave, channel)
@@ -456,11 +468,12 @@ __global__ __launch_bounds__(256) void eca_residual_bwd_reduce_kernel(const T* d
         red[4 + wv][cv * V + e] = sa[e];
         red[8 + wv][cv * V + e] = sb[e];
         red[12 + wv][cv * V + e] = sy[e];
+        red[16 + wv][cv * V + e] = sd[e];
       }
     }
   }
   __syncthreads();
-  constexpr int NARR = SUMS ? 4 : 1;
+  const int NARR = SUMS ? (x2 ? 5 : 4) : 1;
   for (int i = threadIdx.x; i < NARR * 8 * V; i += 256) {
     const int k = i / (8 * V), ch = i % (8 * V);
     const float t = (red[4 * k][ch] + red[4 * k + 1][ch]) + (red[4 * k + 2][ch] + red[4 * k + 3][ch]);
@@ -499,6 +512,31 @@ __global__ __launch_bounds__(256) void eca_bn_sums_kernel(const float* sums, con
     }
     row[c] = (float)t1;
     row[C + c] = (float)(t2 * (double)invstd[c]);
+  }
+}
+// the downsample BatchNorm's backward sums (identity activation: its output gradient is dz): sum dz = sum_n a, sum dz * xhat = invstd (sum_n d - mean sum_n a)
+__global__ __launch_bounds__(256) void eca_ds_sums_kernel(const float* sums, const float* mean, const float* invstd, float* row, int N, int C) {
+  __shared__ double red[2][16][16];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+  for (int n = sl; n < N; n += 16) {
+    const size_t o = (size_t)n * C + c;
+    s1 += (double)sums[o];
+    s2 += (double)sums[(size_t)3 * N * C + o];
+  }
+  red[0][sl][cl] = s1;
+  red[1][sl][cl] = s2;
+  __syncthreads();
+  if (sl == 0) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int k = 0; k < 16; ++k) {
+      t1 += red[0][k][cl];
+      t2 += red[1][k][cl];
+    }
+    row[c] = (float)t1;
+    row[C + c] = (float)((t2 - (double)mean[c] * t1) * (double)invstd[c]);
   }
 }
 // pass 2: dx = dz * keep[n] * gate[n][c] + dpool[n][c]
@@ -711,31 +749,35 @@ int launch_eca_residual_fwd(int dtype, const void* x, const float* w, int k, con
 // its backward from dout: dshortcut (the shortcut operand's gradient), dx (the ECA input's), dw[k] (beta 0 / 1); ws: 2*N*C + 1152 floats
 int launch_eca_residual_bwd(int dtype, const void* dout, const void* out, const void* x, const float* keep, const float* w, int k, const float* pooled,
                             const float* gate, void* dshortcut, void* dx, float* dw, float beta, float* ws, int N, int HW, int C, int act, hipStream_t s,
-                            const float* xs, const float* xh, float* bn_row, const float* bn_mean, const float* bn_invstd, const uint8_t* out_bits) {
+                            const float* xs, const float* xh, float* bn_row, const float* bn_mean, const float* bn_invstd, const uint8_t* out_bits,
+                            const void* ds_y, float* ds_row, const float* ds_mean, const float* ds_invstd) {
+  // ds_y / ds_row (with bn_row; ws then holds 6*N*C + 1152 floats): the same for the downsample BatchNorm from the raw downsample conv output
   // out_bits (optional): the sign bits the forward left for `out` (then `out` itself is not read)
   // dx == nullptr: pass 2 is left to the consumer — dx = dshortcut * keep[n] * gate[n][c] + dpool[n][c] with dpool = ws + N * C (EcaGrad)
   // bn_row (with dx == nullptr and x given raw under xs / xh; ws then holds 5*N*C + 1152 floats): the BatchNorm-backward sums of x's layer as one
   // partial row [2][C], from the per-image sums of pass 1 (eca_bn_sums_kernel)
   float *sprod = ws, *dpool = ws + (size_t)N * C, *dwpart = ws + (size_t)2 * N * C, *sums = ws + (size_t)2 * N * C + 1152;
   MI355_ARG(!bn_row || (!dx && xs && xh && bn_mean && bn_invstd), "eca_residual_bwd: the BatchNorm sums need the raw tensor form and no stored dx");
+  MI355_ARG(!ds_row || (bn_row && ds_y && ds_mean && ds_invstd), "eca_residual_bwd: the downsample sums come with the bn3 sums");
   if (dtype == MI355_F32) {
     if (bn_row)
       hipLaunchKernelGGL((eca_residual_bwd_reduce_kernel<float, true>), dim3(N * (C / 32)), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)x, keep,
-                         (float*)dshortcut, sprod, N, HW, C, act, xs, xh, sums, out_bits);
+                         (float*)dshortcut, sprod, N, HW, C, act, xs, xh, sums, out_bits, (const float*)(ds_row ? ds_y : nullptr));
     else
       hipLaunchKernelGGL((eca_residual_bwd_reduce_kernel<float, false>), dim3(N * (C / 32)), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)x, keep,
-                         (float*)dshortcut, sprod, N, HW, C, act, xs, xh, nullptr, out_bits);
+                         (float*)dshortcut, sprod, N, HW, C, act, xs, xh, nullptr, out_bits, nullptr);
   } else {
     if (bn_row)
       hipLaunchKernelGGL((eca_residual_bwd_reduce_kernel<bf16_t, true>), dim3(N * (C / 64)), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x,
-                         keep, (bf16_t*)dshortcut, sprod, N, HW, C, act, xs, xh, sums, out_bits);
+                         keep, (bf16_t*)dshortcut, sprod, N, HW, C, act, xs, xh, sums, out_bits, (const bf16_t*)(ds_row ? ds_y : nullptr));
     else
       hipLaunchKernelGGL((eca_residual_bwd_reduce_kernel<bf16_t, false>), dim3(N * (C / 64)), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x,
-                         keep, (bf16_t*)dshortcut, sprod, N, HW, C, act, xs, xh, nullptr, out_bits);
+                         keep, (bf16_t*)dshortcut, sprod, N, HW, C, act, xs, xh, nullptr, out_bits, nullptr);
   }
   hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3(ECA_GB), dim3(256), 0, s, sprod, gate, pooled, w, k, dpool, dwpart, N, C, 1.f / (float)HW);
   hipLaunchKernelGGL(eca_dw_finish_kernel, dim3(1), dim3(64), 0, s, dwpart, dw, k, beta);
   if (bn_row) hipLaunchKernelGGL(eca_bn_sums_kernel, dim3(C / 16), dim3(256), 0, s, sums, gate, dpool, keep, bn_mean, bn_invstd, bn_row, N, C, HW);
+  if (ds_row) hipLaunchKernelGGL(eca_ds_sums_kernel, dim3(C / 16), dim3(256), 0, s, sums, ds_mean, ds_invstd, ds_row, N, C);
   if (!dx) {
     MI355_LAUNCH_CHECK();
     return 0;
