@@ -155,6 +155,7 @@ struct mi355_bctx {
   bool use_bits = true;    // leaky-ReLU masks travel as one bit per element (MI355_BRESNET_BITS=0: backward reads the activation itself)
   bool lazy_dz3 = true;    // bn3's backward forms its input gradient from the ECA backward on the fly (MI355_BRESNET_LAZY_DZ3=0: stored)
   bool lazy_bn = true;     // bn3 / downsample BN normalised inside the fused ECA pass, their outputs never stored (MI355_BRESNET_LAZY_BN=0: stored)
+  bool stem_im2col = true; // the first stem convolution (3 -> 32, 3x3 / 2) as a 1x1 convolution over its 27-value patches (MI355_BRESNET_STEM_IM2COL=0: 3x3 over the 64-channel input)
   bool eca_sums = true;    // bn3's BatchNorm-backward sums from the per-image sums of the fused ECA backward: no reduction pass over the tensors (MI355_BRESNET_ECA_SUMS=0: its own pass)
   bool fused_eca = true;   // ECA gate x drop-connect x shortcut add x activation in one pass each way (MI355_BRESNET_FUSED_ECA=0: op by op)
   bool have_fwd = false, dropped = false;  // state of the last forward: training pass / dropout mask in use
@@ -461,6 +462,16 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
   c->fc_pad = (int)align_up((size_t)num_classes, 128);
   // ---- graph + tensor table (pytorch_tools names, registration order of bresnet.py) -------------------------------------------
   init_conv(c, c->s0, "conv1.0", 3, 32, 3, 2, H, W);
+  {
+    const char* im = getenv("MI355_BRESNET_STEM_IM2COL");
+    c->stem_im2col = !(im && im[0] == '0');
+    if (c->stem_im2col) {
+      // the same parameter tensor [32][3][3][3] read as [32][27], the same output grid: a pointwise convolution over the patch tensor the input
+      // conversion writes (launch_nchw_im2col3s2)
+      VConv& v = c->s0;
+      v.Cin = 27; v.K = 1; v.stride = 1; v.pad = 0; v.Hin = v.Hout; v.Win = v.Wout; v.Cinp = 64;
+    }
+  }
   init_bn(c, c->sb0, "conv1.1", 32, ACT_LEAKY);
   init_conv(c, c->s1, "conv1.2", 32, 32, 3, 1, H / 2, W / 2);
   init_bn(c, c->sb1, "conv1.3", 32, ACT_LEAKY);
@@ -511,7 +522,7 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
   Arena ar;
   const size_t es = c->es;
   auto act_bytes = [&](int hh, int ww, int ch) { return (size_t)N * hh * ww * ch * es; };
-  ar.add(&c->h0, act_bytes(H, W, 64));
+  ar.add(&c->h0, c->stem_im2col ? act_bytes(H / 2, W / 2, 64) : act_bytes(H, W, 64));
   plan_conv(c, ar, c->s0); plan_bn(c, ar, c->sb0, H / 2, W / 2);
   plan_conv(c, ar, c->s1); plan_bn(c, ar, c->sb1, H / 2, W / 2);
   plan_conv(c, ar, c->s2); plan_bn(c, ar, c->sb2, H / 2, W / 2);
@@ -692,7 +703,8 @@ int mi355_bresnet50_forward(mi355_bctx* c, const float* x_nchw, float* logits, i
   if (rc) return rc;
   if (tr) MI355_TRY(launch_weight_prep(MI355_F32, c->params + c->fc_w_off, nullptr, c->fc_wtr, c->fc_pad, 1, 2048, ps));
   // ---- stem --------------------------------------------------------------------------------------------------------------------
-  MI355_TRY(launch_nchw_pad64(dt, x_nchw, c->h0, N, c->H * c->W, s));
+  if (c->stem_im2col) MI355_TRY(launch_nchw_im2col3s2(dt, x_nchw, c->h0, N, c->H, c->W, s));
+  else MI355_TRY(launch_nchw_pad64(dt, x_nchw, c->h0, N, c->H * c->W, s));
   MI355_TRY(conv_bn(c, c->s0, c->sb0, c->h0, tr, bn_momentum, s));
   MI355_TRY(join(c, s));  // the prepared weights of every later layer
   MI355_TRY(conv_bn(c, c->s1, c->sb1, c->sb0.out, tr, bn_momentum, s));

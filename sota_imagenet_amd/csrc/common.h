@@ -251,6 +251,7 @@ int bn_max_blocks();
 // variant.hip: glue kernels of the static BResNet-50 executor
 int launch_nchw_pad64(int dtype, const float* x_nchw, void* h_nhwc64, int N, int HW, hipStream_t s);
 int launch_weight_pad_cast(int dtype, const float* w, void* wp, int Cout, int taps, int Cin, int Coutp, int Cinp, hipStream_t s);
+int launch_nchw_im2col3s2(int dtype, const float* x, void* h, int N, int H, int W, hipStream_t s);  // 3x3 / stride-2 patches of an NCHW fp32 batch, 27 of 64 channels
 int launch_weight_unpad(const float* dwp, float* dw, float beta, int Cout, int taps, int Cin, int Cinp, hipStream_t s);
 int launch_axpby(const float* src, float* dst, float beta, size_t n, hipStream_t s);
 // xs / xh (optional): x stands for x * xs[c] + xh[c] (a BatchNorm with identity activation applied on the fly); ss / sh2: the same for the shortcut

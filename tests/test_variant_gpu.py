@@ -157,9 +157,11 @@ def test_bresnet50_fp32_matches_oracle(dev):
     gr = torch.cat([p.grad.detach().flatten() for p in ref.parameters()])
     rel = ((gn - gr).norm() / gr.norm()).item()
     assert rel < 2e-2, f"gradients vs the fp32 oracle: rel L2 {rel:.3e}"
+    # per tensor in the L2 norm: at 2 x 2 pixels x 4 images one leaky-ReLU sign that two fp32 summation orders decide differently moves single elements by
+    # O(1) of the tensor's maximum (seen: 0.27 at one element of layer4.2.conv3.weight after the first conv changed its summation order) and the norm by 1e-3
     for name in ("fc.weight", "layer4.2.se_module.conv.weight", "layer4.2.conv3.weight", "conv1.0.weight"):
-        a, b = dict(m.named_parameters())[name].grad, dict(ref.named_parameters())[name].grad
-        assert nerr(a, b) < 5e-2, name
+        a, b = dict(m.named_parameters())[name].grad.detach().float().cpu(), dict(ref.named_parameters())[name].grad
+        assert ((a - b).norm() / b.norm()).item() < 5e-2, name
 
 
 def test_bresnet50_bf16_trains(dev):
@@ -270,6 +272,7 @@ def test_static_executor_matches_the_per_op_graph(dev, dtype, wstd, monkeypatch)
 
     monkeypatch.setenv("MI355_BRESNET_FUSED_ADD", "0")
     monkeypatch.setenv("MI355_BRESNET_FUSED_ECA", "0")
+    monkeypatch.setenv("MI355_BRESNET_STEM_IM2COL", "0")  # (the graph's first conv is the 3x3 over the padded input: the patch form sums in another order)
     N, S = 4, 64
     kw = dict(dtype=dtype, drop_rate=0.2, drop_connect_rate=0.2, weight_standardization=wstd)
     m, g = BResNet50(**kw), BResNet50Graph(**kw)
@@ -313,6 +316,7 @@ def test_static_executor_at_the_baseline_batch(dev, monkeypatch):
     from sota_imagenet_amd.synth import synthetic_batch
 
     monkeypatch.setenv("MI355_BRESNET_FUSED_ECA", "0")  # (the fused tail skips one bf16 rounding of the gated tensor: not the graph's bits)
+    monkeypatch.setenv("MI355_BRESNET_STEM_IM2COL", "0")  # (the first conv as a 1x1 over its patches sums in another order: not the graph's bits either)
     N, S = 256, 224
     kw = dict(dtype="bf16", drop_rate=0.0, drop_connect_rate=0.0, weight_standardization=True)
     m, g = BResNet50(**kw), BResNet50Graph(**kw)
@@ -411,6 +415,12 @@ def test_static_executor_at_the_baseline_batch_default_fused_tail_against_the_or
         assert nerr(y[..., :Co], ref) < 2e-2, conv
         if y.shape[-1] > Co:
             assert y[..., Co:].abs().max().item() == 0, conv
+
+    # the first stem convolution (default: a 1x1 convolution over the 27-value patches the input conversion writes) against the oracle's 3x3 / stride-2
+    # convolution of the bf16-rounded input
+    y0 = bn_stats("conv1.0", "conv1.1")[img].float().cpu()
+    x0 = q(data[img].cpu().permute(0, 2, 3, 1))
+    assert nerr(y0[..., :32], R.conv2d_fwd(x0, q(R.oihw_to_krsc(B.ws(P["conv1.0.weight"]))), 2, 1)) < 2e-2 and y0[..., 32:].abs().max().item() == 0
 
     def normalised(y, bn):
         mean, invstd = stats[bn]
