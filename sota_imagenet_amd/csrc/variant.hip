@@ -24,6 +24,13 @@ __device__ __forceinline__ float act_slope(float out, int act) { return act == 0
 
 #define GRID_STRIDE(i, total) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (size_t)gridDim.x * blockDim.x)
 
+// pixels per thread of the row-walking pools (MI355_POOL_SEG: A/B, read once)
+static int pool_seg(int W) {
+  static const int env = getenv("MI355_POOL_SEG") ? atoi(getenv("MI355_POOL_SEG")) : 0;
+  if (env == 1) return 0;  // the point-wise kernels
+  const int sgm = env >= 3 ? env : 112;
+  return sgm < W ? sgm : W;
+}
 static int grid_for(size_t total) { return (int)std::min<size_t>((total + 255) / 256, (size_t)256 * 8); }
 
 // ---- blur pool -----------------------------------------------------------------------------------------------------
@@ -231,6 +238,142 @@ __global__ __launch_bounds__(256) void maxpool3s1_bwd_kernel(const T* dy, const 
       }
     }
     Vec16<T>::store(dx + i * V, acc);
+  }
+}
+
+// The same two operators with one thread per (image row, channel vector) WALKING along the row: the 3 x 3 window lives in registers as three columns
+// that rotate, so a pixel costs 3 vector loads instead of 9 (the point-wise forms above are bound by L2 traffic: 9 x 411 MB at the stem's 112 x 112 x 64).
+// Same window scan order, same first-maximum rule, same order of the backward's additions: bit-identical results.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3s1_fwd_rows_kernel(const T* x, T* y, uint8_t* idx, int N, int H, int W, int C, int SEG) {
+  constexpr int V = Vec16<T>::N;
+  const int CV = C / V;
+  const int nseg = (W + SEG - 1) / SEG;   // a thread walks one segment of SEG pixels of a row (more threads in flight: the walk is a chain of load latencies)
+  const size_t rows = (size_t)N * H * nseg * CV;
+  GRID_STRIDE(i, rows) {
+    const int cv = (int)(i % CV);
+    size_t t = i / CV;
+    const int sg = (int)(t % nseg); t /= nseg;
+    const int h = (int)(t % H), n = (int)(t / H);
+    const int wb = sg * SEG, we = min(W, wb + SEG);
+    float col[3][3][V];
+    auto load_col = [&](float (&c)[3][V], int iw) __attribute__((always_inline)) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int ih = h - 1 + a;
+        if (iw >= 0 && iw < W && ih >= 0 && ih < H) {
+          Vec16<T>::load(x + (((size_t)n * H + ih) * W + iw) * C + cv * V, c[a]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < V; ++e) c[a][e] = -3.0e38f;  // (never greater than the running best: a skipped position)
+        }
+      }
+    };
+    auto emit = [&](const float (&c0)[3][V], const float (&c1)[3][V], const float (&c2)[3][V], int w) __attribute__((always_inline)) {
+      float best[V];
+      int bi[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) { best[e] = -3.0e38f; bi[e] = 4; }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          if (c0[a][e] > best[e]) { best[e] = c0[a][e]; bi[e] = a * 3; }
+          if (c1[a][e] > best[e]) { best[e] = c1[a][e]; bi[e] = a * 3 + 1; }
+          if (c2[a][e] > best[e]) { best[e] = c2[a][e]; bi[e] = a * 3 + 2; }
+        }
+      }
+      const size_t o = ((((size_t)n * H + h) * W + w) * CV + cv) * V;
+      Vec16<T>::store(y + o, best);
+      uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w0 |= (uint32_t)bi[e] << (8 * e);
+      if constexpr (V == 8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w1 |= (uint32_t)bi[4 + e] << (8 * e);
+        *reinterpret_cast<uint2*>(idx + o) = make_uint2(w0, w1);
+      } else {
+        *reinterpret_cast<uint32_t*>(idx + o) = w0;
+      }
+    };
+    load_col(col[0], wb - 1);
+    load_col(col[1], wb);
+    int w = wb;
+    for (; w + 3 <= we; w += 3) {
+      load_col(col[2], w + 1); emit(col[0], col[1], col[2], w);
+      load_col(col[0], w + 2); emit(col[1], col[2], col[0], w + 1);
+      load_col(col[1], w + 3); emit(col[2], col[0], col[1], w + 2);
+    }
+    if (w < we) { load_col(col[2], w + 1); emit(col[0], col[1], col[2], w); ++w; }
+    if (w < we) { load_col(col[0], w + 1); emit(col[1], col[2], col[0], w); }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3s1_bwd_rows_kernel(const T* dy, const uint8_t* idx, T* dx, int N, int H, int W, int C, int SEG) {
+  constexpr int V = Vec16<T>::N;
+  const int CV = C / V;
+  const int nseg = (W + SEG - 1) / SEG;
+  const size_t rows = (size_t)N * H * nseg * CV;
+  GRID_STRIDE(i, rows) {
+    const int cv = (int)(i % CV);
+    size_t t = i / CV;
+    const int sg = (int)(t % nseg); t /= nseg;
+    const int h = (int)(t % H), n = (int)(t / H);
+    const int wb = sg * SEG, we = min(W, wb + SEG);
+    // column slot: the windows centred in one column ow, rows oh = h + 1, h, h - 1 (tap row a = 0, 1, 2 of the pixel in row h)
+    float g[3][3][V];
+    uint32_t code[3][3][V / 4];
+    auto load_col = [&](float (&gc)[3][V], uint32_t (&cc)[3][V / 4], int ow) __attribute__((always_inline)) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int oh = h + 1 - a;
+        if (ow >= 0 && ow < W && oh >= 0 && oh < H) {
+          const size_t o = (((size_t)n * H + oh) * W + ow) * C + cv * V;
+          Vec16<T>::load(dy + o, gc[a]);
+          if constexpr (V == 8) {
+            const uint2 t2 = *reinterpret_cast<const uint2*>(idx + o);
+            cc[a][0] = t2.x;
+            cc[a][1] = t2.y;
+          } else {
+            cc[a][0] = *reinterpret_cast<const uint32_t*>(idx + o);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < V; ++e) gc[a][e] = 0.f;
+#pragma unroll
+          for (int q = 0; q < V / 4; ++q) cc[a][q] = 0xffffffffu;  // (no tap has code 255)
+        }
+      }
+    };
+    // pixel w: column ow = w + 1 is tap column b = 0, ow = w is b = 1, ow = w - 1 is b = 2; additions in (a, b) order as the point-wise kernel
+    auto emit = [&](const float (&gl)[3][V], const uint32_t (&cl)[3][V / 4], const float (&gm)[3][V], const uint32_t (&cm)[3][V / 4], const float (&gr)[3][V],
+                    const uint32_t (&cr)[3][V / 4], int w) __attribute__((always_inline)) {
+      float acc[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const int sh = 8 * (e & 3);
+          // (a skipped window of the point-wise form adds nothing; here it adds an exact 0.f: the same sum)
+          acc[e] += ((cr[a][e >> 2] >> sh) & 0xffu) == (unsigned)(a * 3) ? gr[a][e] : 0.f;
+          acc[e] += ((cm[a][e >> 2] >> sh) & 0xffu) == (unsigned)(a * 3 + 1) ? gm[a][e] : 0.f;
+          acc[e] += ((cl[a][e >> 2] >> sh) & 0xffu) == (unsigned)(a * 3 + 2) ? gl[a][e] : 0.f;
+        }
+      }
+      Vec16<T>::store(dx + ((((size_t)n * H + h) * W + w) * CV + cv) * V, acc);
+    };
+    load_col(g[0], code[0], wb - 1);
+    load_col(g[1], code[1], wb);
+    int w = wb;
+    for (; w + 3 <= we; w += 3) {
+      load_col(g[2], code[2], w + 1); emit(g[0], code[0], g[1], code[1], g[2], code[2], w);
+      load_col(g[0], code[0], w + 2); emit(g[1], code[1], g[2], code[2], g[0], code[0], w + 1);
+      load_col(g[1], code[1], w + 3); emit(g[2], code[2], g[0], code[0], g[1], code[1], w + 2);
+    }
+    if (w < we) { load_col(g[2], code[2], w + 1); emit(g[0], code[0], g[1], code[1], g[2], code[2], w); ++w; }
+    if (w < we) { load_col(g[0], code[0], w + 1); emit(g[1], code[1], g[2], code[2], g[0], code[0], w); }
   }
 }
 
@@ -888,6 +1031,14 @@ int mi355_maxpool3s1_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N,
   MI355_ARG(x && y && idx && N > 0 && H > 0 && W > 0 && C % 8 == 0, "maxpool3s1: C=%d (multiple of 8)", C);
   hipStream_t s = (hipStream_t)stream;
   const size_t total = (size_t)N * H * W * C;
+  if (W >= 16 && (size_t)N * H * C / 8 >= 16384 && pool_seg(W) > 0) {  // enough rows to fill the chip: the row-walking form (3 loads per pixel instead of 9)
+    const int SEG = pool_seg(W);
+    const size_t rows = (size_t)N * H * ((W + SEG - 1) / SEG) * C;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool3s1_fwd_rows_kernel<float>, dim3(grid_for(rows / 4)), dim3(256), 0, s, (const float*)x, (float*)y, idx, N, H, W, C, SEG),
+               hipLaunchKernelGGL(maxpool3s1_fwd_rows_kernel<bf16_t>, dim3(grid_for(rows / 8)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C, SEG));
+    MI355_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool3s1_fwd_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)x, (float*)y, idx, N, H, W, C),
              hipLaunchKernelGGL(maxpool3s1_fwd_kernel<bf16_t>, dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C));
   MI355_LAUNCH_CHECK();
@@ -897,6 +1048,14 @@ int mi355_maxpool3s1_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx
   MI355_ARG(dy && dx && idx && N > 0 && H > 0 && W > 0 && C % 8 == 0, "maxpool3s1: C=%d (multiple of 8)", C);
   hipStream_t s = (hipStream_t)stream;
   const size_t total = (size_t)N * H * W * C;
+  if (W >= 16 && (size_t)N * H * C / 8 >= 16384 && pool_seg(W) > 0) {
+    const int SEG = pool_seg(W);
+    const size_t rows = (size_t)N * H * ((W + SEG - 1) / SEG) * C;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool3s1_bwd_rows_kernel<float>, dim3(grid_for(rows / 4)), dim3(256), 0, s, (const float*)dy, idx, (float*)dx, N, H, W, C, SEG),
+               hipLaunchKernelGGL(maxpool3s1_bwd_rows_kernel<bf16_t>, dim3(grid_for(rows / 8)), dim3(256), 0, s, (const bf16_t*)dy, idx, (bf16_t*)dx, N, H, W, C, SEG));
+    MI355_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool3s1_bwd_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)dy, idx, (float*)dx, N, H, W, C),
              hipLaunchKernelGGL(maxpool3s1_bwd_kernel<bf16_t>, dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)dy, idx, (bf16_t*)dx, N, H, W, C));
   MI355_LAUNCH_CHECK();

@@ -50,6 +50,26 @@ def test_pools(dev, dtype, shape):
     assert nerr(ops.maxpool3s1_bwd(dy.to(dev, dtype), idx), dx_ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype,shape", [(torch.bfloat16, (32, 64, 20, 64)), (torch.bfloat16, (32, 64, 16, 64)), (torch.float32, (16, 64, 22, 128))])
+def test_maxpool3s1_row_walking_kernels(dev, dtype, shape):
+    """the stem-sized launches of the 3x3 / stride-1 max pool take the row-walking kernels (three loads per pixel from a rotating register window; widths with
+    W % 3 = 2, 1, 1): values equal to torch's max pool, ties (ReLU zeros) routed to exactly one position, and on tie-free data the gradient torch routes"""
+    from sota_imagenet_amd import ops
+
+    F = torch.nn.functional
+    x = torch.relu(rnd(shape, 5, dtype)).to(dev, dtype)
+    y, idx = ops.maxpool3s1_fwd(x)
+    assert torch.equal(y.float(), F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 1, 1).permute(0, 2, 3, 1))
+    dy = rnd(shape, 6, dtype).to(dev, dtype)
+    dx = ops.maxpool3s1_bwd(dy, idx)
+    assert abs(dx.double().sum().item() - dy.double().sum().item()) < 1e-3 * dy.double().abs().sum().item()
+    xu = (rnd(shape, 7, torch.float32) + torch.arange(shape[1] * shape[2]).view(1, shape[1], shape[2], 1) * 1e-2).to(dtype).to(dev)
+    y, idx = ops.maxpool3s1_fwd(xu)
+    xt = xu.float().permute(0, 3, 1, 2).requires_grad_(True)
+    F.max_pool2d(xt, 3, 1, 1).backward(dy.float().permute(0, 3, 1, 2))
+    assert nerr(ops.maxpool3s1_bwd(dy, idx), xt.grad.permute(0, 2, 3, 1)) < TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("k", [3, 5])
 def test_eca(dev, dtype, k):
