@@ -109,6 +109,23 @@ def step_traffic(dtype, batch, size):
     return int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in table.values()) / steps), os.path.basename(files[-1])
 
 
+def bresnet_step_hbm(batch, size, ms):
+    """the BResNet-50 step (configs[3]) against the HBM roof: every kernel's counter traffic of one step (profiles/*_pmc_traffic_bresnet50_bf16.json, made by
+    tools/profile_bres.sh -> tools/pmc_total.py from separate --pmc passes of this same command) over the step time.  None outside bs 256 / 224 px."""
+    import glob
+
+    if (batch, size) != (256, 224):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_bresnet50_bf16.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        tb = json.load(f)["hbm_bytes_per_step"]
+    gbs = tb / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "traffic": tb, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "source": f"profiles/{os.path.basename(files[-1])}: every kernel of a serial step, separate --pmc passes"}
+
+
 def cpu_baseline():
     """BASELINE.md §3 protocol: the oracle's train step (fwd + CE + bwd + SGD) and its forward alone on the host cores,
     BASELINE.json configs[0] (bs 32, fp32, 224 px): 3 warm-up + 10 timed steps each, median; threads printed."""
@@ -385,6 +402,7 @@ def main():
                                            "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                                            "frac": round(model.flops(N, S, S)[1] / (ms * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
                                            "alg_gflop_per_step": round(model.flops(N, S, S)[1] / 1e9, 1)},
+                              "step_hbm": bresnet_step_hbm(N, S, ms) if args.dtype == "bf16" else None,
                               "cpu_baseline": None}), flush=True)
             if use_ddp:
                 import torch.distributed as dist
@@ -473,7 +491,8 @@ def main():
                 out["secondary_bresnet50"] = {"dtype": "bf16", "workload": "BASELINE configs[3] on one MI355X: BResNet-50 (deep stem, anti-alias, ECA, leaky ABN, WS, "
                                                                            f"drop-connect) bs=256 {S}px, CutmixMixup + ModelEma(0.9999) on, static executor (csrc/bresnet_exec.cpp)",
                                               "value": round(256 * kb / dtb, 1), "unit": "images/sec", "steps": kb, "ms_per_step": round(dtb / kb * 1e3, 3),
-                                              "final_loss": round(lossb, 4), "step_tflops": round(flb / (dtb / kb) / 1e12, 1)}
+                                              "final_loss": round(lossb, 4), "step_tflops": round(flb / (dtb / kb) / 1e12, 1),
+                                              "step_hbm": bresnet_step_hbm(256, S, dtb / kb * 1e3)}
             except Exception as e:
                 out["secondary_bresnet50"] = {"error": str(e)[:200]}
         if world == 1 and not use_ddp and args.dtype == "bf16" and not args.no_secondary and args.model != "bresnet50":
