@@ -544,6 +544,9 @@ bool po_legal(const IgemmArgs& a, int nclass) {
     if (v.BN == 64 && knobs().po64 < 2) {
       if (!knobs().po64) return false;
     }
+    // 64 -> 256 under the shortcut addend + sums (layer 1's conv1 data gradient): a tie per launch since the tile-wide mask loads (250-252 us here,
+    // 250-257 on the implicit-GEMM kernel), but the step is 0.06 ms SLOWER with it here (18.03 -> 18.09, four alternations on one box): the 768-workgroup
+    // grid shares the chip with the weight-gradient stream better than 256 persistent workgroups do
     if (v.K == 64 && v.add != 0 && v.stats == 2) return false;
     if (v.K == 512 && a.Ncols >= 2048 && pk_legal(a, nclass)) return false;
   }
