@@ -148,7 +148,7 @@ struct mi355_ctx {
   void* gG[2] = {nullptr, nullptr};
   void* gsub = nullptr;    // the downsample branch's data gradient at HALF resolution (first blocks of layers 2-4): conv1's data gradient
                            // adds it at the even pixels (IgemmArgs::addend_sub2), the zero-filled full-size tensor is never written
-  bool ds_compact = true;  // MI355_DS_COMPACT=0: the stride-2 data gradient written at full size (A/B; the fp32 / fp8 paths always do)
+  bool ds_compact = true;  // MI355_DS_COMPACT=0: the stride-2 data gradient written at full size (A/B; the fp32 path always does)
   void* gset[MAX_GSETS][4] = {};
   size_t max_c = 64;  // widest BatchNorm of the network (sizes bn_partial)
   int nsets = 2;  // gradient buffer sets in rotation (MI355_GSETS, read at ctx creation): the main stream waits for the weight gradients of
@@ -425,7 +425,8 @@ int conv_dgrad_compact(mi355_ctx* c, ConvBN& l, const void* dy, void* dxs, hipSt
 
 // conv1's data gradient of a first block can take the downsample gradient at half resolution (a generated kernel serves that launch)
 bool sub2_ok(mi355_ctx* c, Block& b, Block* prev) {
-  if (!c->ds_compact || c->dtype != MI355_BF16 || c->fp8 || !b.has_ds || b.ds.stride != 2 || b.ds.K != 1) return false;
+  if (!c->ds_compact || c->dtype != MI355_BF16 || !b.has_ds || b.ds.stride != 2 || b.ds.K != 1) return false;
+  if (c->fp8 && b.ds.fp8_dgrad) return false;  // (the e4m3 step keeps the downsample data gradient on bf16 operands for this: plan_fp8)
   IgemmArgs a;
   ConvBN& l = b.c1;
   const int nclass = build_dgrad_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
@@ -526,6 +527,10 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
 // MI355_FP8_LAYERS=<substring> restricts the set to layers whose conv name contains it (A/B, tests).
 void plan_fp8(mi355_ctx* c) {
   const char* only = getenv("MI355_FP8_LAYERS");
+  const char* pa = getenv("MI355_FP8_PLAN");  // "all": every legal launch on e4m3 operands (for re-deriving the per-layer rule below)
+  const bool plan_all = pa && pa[0] == 'a';
+  const char* dce = getenv("MI355_DS_COMPACT");
+  const bool ds_compact_env = !(dce && dce[0] == '0');
   int n = 0;
   // Measured per layer at batch 256 / 224 px (profiles/r03a_conv_per_layer_fp8_vs_bf16.txt): the e4m3 form wins 4-10 us per launch
   // wherever the reduction spans >= 2 of its 128-channel k-tiles, and loses 15-90 us on the output-heavy launches — the 128 -> 512
@@ -543,8 +548,14 @@ void plan_fp8(mi355_ctx* c) {
     // implicit-GEMM kernel loses to the direct 3x3 kernel of layer 2 (forward 114 against 139 us, data gradient 141 / 159) and to the
     // resident-weight pointwise kernel on layer 3's conv3 forward (71 / 92); it still wins on layer 4's 3x3 (86 / 114), on every long
     // 1x1 reduction (conv1 forward of layers 2-4, conv3's data gradient) and on the stride-2 / downsample launches of the first blocks.
-    if (l.K == 3 && l.stride == 1 && l.Cin == 128) l.fp8_fwd = l.fp8_dgrad = false;
-    if (l.K == 1 && l.stride == 1 && l.Cin == 256 && l.Cout == 1024) l.fp8_fwd = false;
+    if (!plan_all) {
+      if (l.K == 3 && l.stride == 1 && l.Cin == 128) l.fp8_fwd = l.fp8_dgrad = false;
+      if (l.K == 1 && l.stride == 1 && l.Cin == 256 && l.Cout == 1024) l.fp8_fwd = false;
+    }
+    // the downsample conv's data gradient stays on bf16 operands: dense at half resolution + conv1's data gradient reading it there
+    // (conv_dgrad_compact / sub2_ok) beats the four-class e4m3 launch at full size by 0.49 ms per step at batch 512 (148 / 283, 444 / 609,
+    // 113 / 182, 222 / 311, 160 / 194 us: tools/fp8_plan_table.sh)
+    if (ds_compact_env && l.K == 1 && l.stride == 2) l.fp8_dgrad = false;
     if (l.fp8_fwd || l.fp8_dgrad) l.qid_w = n++;
     if (l.fp8_dgrad) l.qid_dy = n++;
   };
@@ -573,8 +584,10 @@ void plan_fp8(mi355_ctx* c) {
       l.fp8_wgrad = c->fp8_use_wgrad && l.fp8_fwd && l.qid_in >= 0 && l.Cin % 128 == 0 && l.Cout % 128 == 0;
       // (round 5: the generated bf16 weight-gradient kernels beat the e4m3 implicit-GEMM form on every stride-1 3x3 — 83-94 against
       // 115-126 us — and on layer 4's 1x1s, 50 / 60; the e4m3 form keeps layer 2's conv1, 70 / 110, and the first blocks)
-      if (l.K == 3 && l.stride == 1) l.fp8_wgrad = false;
-      if (l.K == 1 && l.stride == 1 && l.Cin * l.Cout == 2048 * 512) l.fp8_wgrad = false;
+      if (!plan_all) {
+        if (l.K == 3 && l.stride == 1) l.fp8_wgrad = false;
+        if (l.K == 1 && l.stride == 1 && l.Cin * l.Cout == 2048 * 512) l.fp8_wgrad = false;
+      }
       if (l.fp8_wgrad && l.qid_dy < 0) l.qid_dy = n++;
     };
     wg_plan(b.c1); wg_plan(b.c2); wg_plan(b.c3);
