@@ -645,6 +645,9 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
       }
       ITEMSTAMP(1);
 
+      // (the e4m3 path issues its matrix instructions as text: the compiler does not know their result latency, so the wait states in front of the
+      //  first read of an accumulator are spelled out)
+      if constexpr (EB == 1) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
       // ---- epilogue: both wave rows in the same barrier interval ---------------------------------------------------
       if (wr == 0) __builtin_amdgcn_s_barrier();
       {

@@ -262,36 +262,51 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
           }
         }
       } else if constexpr (ES == 1) {
-        constexpr int NS = BKP / 16;
+        // The four k-steps of 16 pixels of a slab as ONE v_mfma_f32_32x32x64_f8f6f4 per accumulator tile: the 4 x 8 bytes a lane reads (transposed) for them are the
+        // 32-byte operand of the K = 64 form — the same bytes of dy and of x on both sides, so which pixel a byte belongs to need not be known (the pixel is
+        // a summation index) — at twice the rate of four 32x32x16 fp8 instructions (tools/micro/mfma_rate.hip).
+        static_assert(BKP == 64, "one K = 64 instruction per slab");
+        typedef int i32x8v __attribute__((ext_vector_type(8)));
+        i32x8v df[MI];
 #pragma unroll
-        for (int ks = 0; ks < NS; ++ks) {
-          const int k0 = ks * 16 + t8_krow;
-          long df[MI];
+        for (int q = 0; q < 4; ++q) {
+          const int k0 = q * 16 + t8_krow;
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) {
             const int byte = cobase + mi * 32 + t8_col;
             const char* ap = Ad + k0 * RB_A + ((((byte >> 4) ^ row_swz<ES, RB_A>(k0)) << 4) | (byte & 15));
-            df[mi] = __builtin_bit_cast(long, __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i32_ptr)(ap)));
+            const auto v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i32_ptr)(ap));
+            df[mi][2 * q] = v[0];
+            df[mi][2 * q + 1] = v[1];
           }
           if (lv) {
 #pragma unroll
-            for (int j = ks * NPC / NS; j < (ks + 1) * NPC / NS; ++j) L_piece(j);
+            for (int j = q * NPC / 4; j < (q + 1) * NPC / 4; ++j) L_piece(j);
           }
+        }
 #pragma unroll
-          for (int jt = 0; jt < TPI; ++jt) {
-            long xf[NI];
+        for (int jt = 0; jt < TPI; ++jt) {
+          i32x8v xf[NI];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int k0 = q * 16 + t8_krow;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
               const int byte = cibase + ni * 32 + t8_col;
               const char* ap = Bx + jt * B_BYTES + k0 * RB_B + ((((byte >> 4) ^ row_swz<ES, RB_B>(k0)) << 4) | (byte & 15));
-              xf[ni] = __builtin_bit_cast(long, __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i32_ptr)(ap)));
+              const auto v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i32_ptr)(ap));
+              xf[ni][2 * q] = v[0];
+              xf[ni][2 * q + 1] = v[1];
             }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < NI; ++ni)
-                acc[jt][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(xf[ni], df[mi], acc[jt][mi][ni], 0, 0, 0);
           }
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              auto c = acc[jt][mi][ni];
+              asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0" : "+v"(c) : "v"(xf[ni]), "v"(df[mi]));
+              acc[jt][mi][ni] = c;
+            }
         }
       } else {
         constexpr int NS = BKP / 16;
@@ -336,6 +351,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
       stage ^= 1;
     }
 
+    // (the e4m3 path issues its matrix instructions as text: the compiler does not know their result latency, so the wait states in front of the first
+    //  read of an accumulator are spelled out)
+    if constexpr (ES == 1) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     // partial[split][co][wtap][ci]: D rows (registers) = input channels, D columns (lanes) = output channels
     float* outp = p.partial + (size_t)split * p.Cout * p.wtaps * p.Ck;
 #pragma unroll
