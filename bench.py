@@ -103,7 +103,7 @@ def step_traffic(dtype, batch, size):
         return None, None
     with open(files[-1]) as f:
         table = json.load(f)["kernels"]
-    steps = table.get("sgd_kernel", {}).get("launches", 0)
+    steps = sum(r["launches"] for k, r in table.items() if k.startswith("sgd_kernel"))  # (sgd_kernel<false> since the EMA form exists)
     if not steps:
         return None, None
     return int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in table.values()) / steps), os.path.basename(files[-1])
