@@ -45,6 +45,17 @@ __global__ void k_f8x128s(int iters, float* out) {
   LOOP8(I_F8S)
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ void k_bf16_32(int iters, float* out) {
+  i32x4 a = {(int)threadIdx.x, 1, 2, 3}, b = {4, 5, 6, (int)threadIdx.x};
+  f32x16 c0 = {0}, c1 = c0, c2 = c0, c3 = c0;
+  for (int i = 0; i < iters; ++i) {
+#define I_BF32(c) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    I_BF32(c0) I_BF32(c1) I_BF32(c2) I_BF32(c3) I_BF32(c0) I_BF32(c1) I_BF32(c2) I_BF32(c3)
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+}
+
 template <typename K>
 static void run(const char* name, K kern, int K_, int wpc) {
   const int cus = 256, iters = 20000;
@@ -72,6 +83,7 @@ static void run(const char* name, K kern, int K_, int wpc) {
 int main() {
   for (int wpc : {4, 8}) {
     run("v_mfma_f32_16x16x32_bf16", k_bf16, 32, wpc);
+    run("v_mfma_f32_32x32x16_bf16 (x4 work)", k_bf16_32, 64, wpc);  // 2*32*32*16 = 2*16*16*64
     run("v_mfma_f32_16x16x32_fp8_fp8", k_fp8, 32, wpc);
     run("v_mfma_f32_16x16x128_f8f6f4", k_f8x128, 128, wpc);
     run("v_mfma_scale_f32_16x16x128_f8f6f4", k_f8x128s, 128, wpc);
