@@ -28,6 +28,16 @@ __global__ void k_bf16(int iters, float* out) {
 #define I_BF16(c) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
   LOOP8(I_BF16)
 }
+__global__ void k_bf16_agpr(int iters, float* out) {  // accumulators in AGPRs, as in the generated kernels
+  i32x4 a = {(int)threadIdx.x, 1, 2, 3}, b = {4, 5, 6, (int)threadIdx.x};
+#define I_BF16A(c) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  LOOP8(I_BF16A)
+}
+__global__ void k_bf16_agpr_b(int iters, float* out) {  // ... and the weight operand too (asm/po_gen.py)
+  i32x4 a = {(int)threadIdx.x, 1, 2, 3}, b = {4, 5, 6, (int)threadIdx.x};
+#define I_BF16AB(c) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "a"(a), "v"(b));
+  LOOP8(I_BF16AB)
+}
 __global__ void k_fp8(int iters, float* out) {
   i32x2 a = {(int)threadIdx.x, 1}, b = {4, (int)threadIdx.x};
 #define I_FP8(c) asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
@@ -83,6 +93,8 @@ static void run(const char* name, K kern, int K_, int wpc) {
 int main() {
   for (int wpc : {4, 8}) {
     run("v_mfma_f32_16x16x32_bf16", k_bf16, 32, wpc);
+    run("v_mfma_f32_16x16x32_bf16, AGPR acc", k_bf16_agpr, 32, wpc);
+    run("v_mfma_f32_16x16x32_bf16, AGPR acc + A", k_bf16_agpr_b, 32, wpc);
     run("v_mfma_f32_32x32x16_bf16 (x4 work)", k_bf16_32, 64, wpc);  // 2*32*32*16 = 2*16*16*64
     run("v_mfma_f32_16x16x32_fp8_fp8", k_fp8, 32, wpc);
     run("v_mfma_f32_16x16x128_f8f6f4", k_f8x128, 128, wpc);
