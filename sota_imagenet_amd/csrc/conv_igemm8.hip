@@ -647,7 +647,11 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
 
       // (the e4m3 path issues its matrix instructions as text: the compiler does not know their result latency, so the wait states in front of the
       //  first read of an accumulator are spelled out)
-      if constexpr (EB == 1) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+      if constexpr (EB == 1) {
+        __builtin_amdgcn_sched_barrier(0);  // (nothing that reads an accumulator may be scheduled above the wait states)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // ---- epilogue: both wave rows in the same barrier interval ---------------------------------------------------
       if (wr == 0) __builtin_amdgcn_s_barrier();
       {

@@ -353,7 +353,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradKArgs kp) {
 
     // (the e4m3 path issues its matrix instructions as text: the compiler does not know their result latency, so the wait states in front of the first
     //  read of an accumulator are spelled out)
-    if constexpr (ES == 1) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+      if constexpr (ES == 1) {
+        __builtin_amdgcn_sched_barrier(0);  // (nothing that reads an accumulator may be scheduled above the wait states)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
     // partial[split][co][wtap][ci]: D rows (registers) = input channels, D columns (lanes) = output channels
     float* outp = p.partial + (size_t)split * p.Cout * p.wtaps * p.Ck;
 #pragma unroll
