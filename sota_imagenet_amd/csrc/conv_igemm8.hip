@@ -501,19 +501,17 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const Igemm8KArgs kp) {
                   // the 2 x 16 bytes a lane read are the operands of four k-steps of 32 (the SAME bytes of the weight and the pixel row on both sides, so
                   // the assignment of k values to lanes need not be known: k is a summation index) = ONE k-step of the 16x16x128 f8f6f4 form, which
                   // runs at twice the rate of four 16x16x32 fp8 instructions (tools/micro/mfma_rate.hip: 5.0 against 2.1 PFLOP/s).
-                  if constexpr (true) {
-                    if (ks == 0) {
-                      typedef int i32x8 __attribute__((ext_vector_type(8)));
-                      const i32x4 w0 = __builtin_bit_cast(i32x4, bf[nt][0]), w1 = __builtin_bit_cast(i32x4, bf[nt][1]);
-                      const i32x4 x0 = __builtin_bit_cast(i32x4, af[base + mt][0]), x1 = __builtin_bit_cast(i32x4, af[base + mt][1]);
-                      const i32x8 wv = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
-                      const i32x8 xv = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-                      // (as text: the builtin of the block-scaled form takes its accumulators in VGPRs here and the 128 of them spill; the
-                      //  non-scaled form with cbsz = blgp = 0 is e4m3 x e4m3 and needs no scale operands)
-                      f32x4 c = acc[mhalf * MT0 + mt][nhalf * 2 + nt];
-                      asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+v"(c) : "v"(wv), "v"(xv));
-                      acc[mhalf * MT0 + mt][nhalf * 2 + nt] = c;
-                    }
+                  if (ks == 0) {  // (compile-time under the unroll: the instruction consumes both halves of the k-tile)
+                    typedef int i32x8 __attribute__((ext_vector_type(8)));
+                    const i32x4 w0 = __builtin_bit_cast(i32x4, bf[nt][0]), w1 = __builtin_bit_cast(i32x4, bf[nt][1]);
+                    const i32x4 x0 = __builtin_bit_cast(i32x4, af[base + mt][0]), x1 = __builtin_bit_cast(i32x4, af[base + mt][1]);
+                    const i32x8 wv = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                    const i32x8 xv = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                    // (as text: the builtin of the block-scaled form takes its accumulators in VGPRs beside scale registers and the kernel spills 64-193
+                    //  dwords; the non-scaled form with cbsz = blgp = 0 is e4m3 x e4m3 and needs no scale operands)
+                    f32x4 c = acc[mhalf * MT0 + mt][nhalf * 2 + nt];
+                    asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+v"(c) : "v"(wv), "v"(xv));
+                    acc[mhalf * MT0 + mt][nhalf * 2 + nt] = c;
                   }
                 }
         };
