@@ -176,6 +176,24 @@ def test_fp8_lean_step_equals_the_step_that_keeps_the_bf16_tensors(dev, monkeypa
         assert la == lb and torch.equal(ga, gb)
 
 
+def test_fp8_plan_switch_selects_the_per_layer_rule(dev, monkeypatch):
+    """MI355_FP8_PLAN=rule: mid round 5's exclusions (layer 2's 3x3, layer 3's conv3 forward, the stride-1 3x3 and layer 4's 1x1 weight gradients stay on bf16
+    operands) — fewer e4m3 launches than the default plan, the same state machine, a finite step that tracks the bf16 one"""
+    from sota_imagenet_amd.losses import CrossEntropyLoss
+
+    N, S = 8, 64
+    key = (N, S, S)
+    crit = CrossEntropyLoss(smoothing=0.1).cuda()
+    monkeypatch.setenv("MI355_FP8_PLAN", "rule")
+    m8, m16 = _model("fp8"), _model("bf16")
+    data, target = synthetic_batch(N, S, seed=5, index=0, device="cuda")
+    for i in range(2):
+        l8, l16 = _step(m8, crit, data, target), _step(m16, crit, data, target)
+    st = m8.fp8_state(key)
+    assert st[:2] == (True, True) and (st[2], st[3]) == (29, 23), st
+    assert math.isfinite(l8) and abs(l8 - l16) < 0.05 * l16, (l8, l16)
+
+
 def test_fp8_step_trains(dev):
     """the fp8 step as an optimiser: 40 SGD steps on ONE fixed batch (16 x 64 px, lr 0.02) must memorise it about as fast as the
     bf16 step does — a scale that lags, saturates or zeroes gradients would stall the loss."""
