@@ -10,7 +10,7 @@ B="python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bf16 -- $B --dtype bf16 > $OUT/bench_bf16.jsonl 2> $OUT/bench_bf16.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_fp32 -- $B --dtype fp32 --steps 6 > $OUT/bench_fp32.jsonl 2> $OUT/bench_fp32.err
 export MI355_WGRAD_STREAM=0
-S="python3 bench.py --steps 9 --warmup 3 --no-cpu-baseline --no-roofline --no-secondary --dtype bf16"  # >= 10 steps: the host has to fill the launch queue before a step is in steady state
+S="python3 bench.py --steps 20 --warmup 6 --no-cpu-baseline --no-roofline --no-secondary --dtype bf16"  # >= 10 steps: the host has to fill the launch queue before a step is in steady state
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_serial -- $S > /dev/null 2> $OUT/trace_serial.err
 for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- $S > /dev/null 2> $OUT/pmc_$c.err; done
 unset MI355_WGRAD_STREAM
