@@ -34,7 +34,7 @@ HBM_CLASS = 7  # executor profile class of bn_bwd_apply_kernel, the largest HBM-
 # profile class -> kernel symbols (template instances of one source; names as tools/pmc_traffic.py writes them)
 KERNEL_NAMES = {0: ["igemm_kernel<{T},128,128>", "igemm_kernel<{T},256,256>", "igemm_kernel<{T},256,128>", "igemm8_kernel<224,256>", "igemm8_kernel<256,128>",
                     "dconv_l2", "dconv_l3", "dconv_l4", "pw_k256_n1024", "pk_k1024_n256_w196", "pk_k2048_n512_w98", "pk_k512_n256_w196", "pk_k1024_n512_w196", "pk_k512_n2048_w196", "pk_k512_n128_w196",
-                    "po_k64_b256", "po_k128_b256", "po_k256_b256", "po_k512_b128"],  # (bf16 only: the generated assembly kernels of asm/dconv_gen.py, pw_gen.py, pk_gen.py, po_gen.py; class by Cout % 128 as the executor files them)
+                    "po_k64_b256", "po_k128_b256", "po_k256_b256", "po_k512_b128", "po_k256_b128"],  # (bf16 only: the generated assembly kernels of asm/dconv_gen.py, pw_gen.py, pk_gen.py, po_gen.py; class by Cout % 128 as the executor files them)
                 1: ["igemm_kernel<{T},128,64>", "dconv_l1"],
                 # (wg3_* / wg1_*: the generated kernels of asm/wg_gen.py / asm/wg1_gen.py, bf16 only; class by Cout % 128 as the executor files them)
                 2: ["wgrad_kernel<{T},128,128>", "wgrad_kernel<{T},128,64>", "wg3_l2", "wg3_l3", "wg3_l4", "wg1_c1024_o256", "wg1_c256_o1024", "wg1_c2048_o512",
@@ -88,6 +88,7 @@ def pmc_traffic(kernels, dtype, batch, size):
         table = json.load(f)["kernels"]
     recs = [table[k] for k in kernels if k in table]
     n = sum(r["launches"] for r in recs)
+    pmc_traffic.source = "profiles/%s: separate --pmc passes of a serial step, not measured in this run" % os.path.basename(files[-1])
     return int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in recs) / n) if n else None
 
 
@@ -327,7 +328,7 @@ def main():
             knames = ["igemm8_kernel<224,256,EB=1>", "igemm8_kernel<256,128,EB=1>"] if dtype == "fp8" else \
                 [n.format(T=tdt) for n in KERNEL_NAMES[dom] if not (dtype == "fp32" and n.startswith(("igemm8", "dconv_", "pw_", "pk_", "po_", "wg3_", "wg1_")))]
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": pmc_traffic(knames, dtype, N, S), "kernel": " + ".join(knames),
+                    "traffic": pmc_traffic(knames, dtype, N, S), "traffic_source": getattr(pmc_traffic, "source", None), "kernel": " + ".join(knames),
                     "launches": launches, "avg_launch_ms": round(tot_ms / launches, 4),
                     "alg_gflop_per_launch": round(flops / launches / 1e9, 3),
                     "alg_bytes_per_launch": int(nbytes / launches),
@@ -344,7 +345,7 @@ def main():
         if n_l:
             gbs = nbytes / (t_ms * 1e-3) / 1e9
             roof_hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": pmc_traffic([f"bn_bwd_apply_kernel<{tdt}>"], dtype, N, S),
+                        "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": pmc_traffic([f"bn_bwd_apply_kernel<{tdt}>"], dtype, N, S), "traffic_source": getattr(pmc_traffic, "source", None),
                         "kernel": f"bn_bwd_apply_kernel<{tdt}>", "launches": n_l, "avg_launch_ms": round(t_ms / n_l, 4),
                         "alg_bytes_per_launch": int(nbytes / n_l)}
         # BASELINE's conv target is quoted on the 3x3 convolutions: the same events, restricted to those launches

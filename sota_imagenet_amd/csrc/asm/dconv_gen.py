@@ -54,6 +54,8 @@ class Cfg:
     NT: int = 8       # 16-column tiles per wave
     NB: int = 2       # stages of the weight ring (3 where LDS allows: the pieces of stage s + 3 then have two stages to land)
     ROWS_T: int = 0   # 0: a tile is IPT whole images; else a tile is ROWS_T consecutive output rows of ONE image (H % ROWS_T == 0)
+    s2d: int = 0      # 1: the data gradient of a 3x3 / stride-2 convolution: H x W is the dy image the tile stages, the output is 2H x 2W; four
+                      # kernel classes (output parities, Gen.class_stages), workgroup id y = class * column tiles + column tile
 
     @property
     def BN(self):     # output columns per workgroup
@@ -269,7 +271,7 @@ class Gen:
         self.srdO = S.get(4, 4)
         self.srdX = S.get(4, 4)   # statistics rows
         # the piece table of this wave: in SGPRs (scalar loads, as many as 24 words) or, when larger, in a VGPR read with v_readlane
-        self.tab_sgpr = (2 * NPA + c.NPB <= 24) and c.TPI == 1
+        self.tab_sgpr = (2 * NPA + c.NPB <= 24) and c.TPI == 1 and not (c.s2d and c.stats == 2)   # (s2d + BN-backward sums: out of SGPRs)
         if not self.tab_sgpr:
             self.srdK = S.get(4, 4)   # the piece tables in the kernarg segment
         if c.stats == 2:
@@ -286,6 +288,8 @@ class Gen:
             self.s_a, self.s_b, self.s_par, self.s_img = S.get(), S.get(), S.get(), S.get()
         self.s_ka = S.get(16, 4)         # the 8 pointers
         self.s_kb = S.get(4, 4)
+        if c.s2d:
+            self.s_cls, self.s_clsoff, self.s_cNN = S.get(), S.get(), S.get()
 
         self.v_tid = 0
         self.vA_rd = [[V.get() for kk in range(2)] for kx in range(3)]
@@ -357,6 +361,17 @@ class Gen:
         e("v_and_b32 %s, 15, v0" % R("v", r))
         e("v_bfe_u32 %s, v0, 4, 2" % R("v", kg))
         e("s_nop 3")
+        if c.s2d:
+            # workgroup id y = class * column tiles + column tile; the class's first output pixel (ph, pw) as a byte offset into the tile's window
+            nct = c.NCOLS // c.BN
+            assert nct & (nct - 1) == 0
+            e("s_lshr_b32 %s, %s, %d" % (R("s", self.s_cls), R("s", self.s_nt), nct.bit_length() - 1))
+            e("s_and_b32 %s, %s, %d" % (R("s", self.s_nt), R("s", self.s_nt), nct - 1))
+            offs = [(ph * 2 * c.W + pw) * c.NCOLS * 2 for (ph, pw), _ in self.S2D_CLASSES]
+            e("s_mov_b32 %s, %d" % (R("s", self.s_clsoff), offs[0]))
+            for k in range(1, 4):
+                e("s_cmp_eq_u32 %s, %d" % (R("s", self.s_cls), k))
+                e("s_cselect_b32 %s, %d, %s" % (R("s", self.s_clsoff), offs[k], R("s", self.s_clsoff)))
         if self.tab_sgpr:
             # this wave's piece table: kernarg + 128 + w*256, 24 words by scalar loads (they do not wait for the loads above)
             e("s_lshl_b32 %s, %s, 8" % (R("s", t0), R("s", self.s_w)))
@@ -373,10 +388,14 @@ class Gen:
             e("s_mov_b32 %s, %d" % (R("s", self.srdK + 2), NCLS * 1024))
             e("s_mov_b32 %s, 0x00020000" % R("s", self.srdK + 3))
             # tile -> image (s_img), row tile t inside it (s_par), class (first 0 / middle 1 / last 2)
-            magic = ((1 << 32) + c.TPI - 1) // c.TPI
-            e("s_mul_hi_u32 %s, %s, 0x%x" % (R("s", self.s_img), R("s", self.s_tile), magic), "tile / TPI (exact for tiles < 2^32 / TPI)")
-            e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_img), c.TPI))
-            e("s_sub_u32 %s, %s, %s" % (R("s", self.s_par), R("s", self.s_tile), R("s", t0)))
+            if c.TPI == 1:
+                e("s_mov_b32 %s, %s" % (R("s", self.s_img), R("s", self.s_tile)))
+                e("s_mov_b32 %s, 0" % R("s", self.s_par))
+            else:
+                magic = ((1 << 32) + c.TPI - 1) // c.TPI
+                e("s_mul_hi_u32 %s, %s, 0x%x" % (R("s", self.s_img), R("s", self.s_tile), magic), "tile / TPI (exact for tiles < 2^32 / TPI)")
+                e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_img), c.TPI))
+                e("s_sub_u32 %s, %s, %s" % (R("s", self.s_par), R("s", self.s_tile), R("s", t0)))
             e("s_cmp_eq_u32 %s, %d" % (R("s", self.s_par), c.TPI - 1))
             e("s_cselect_b32 %s, 2, 1" % R("s", t1))
             e("s_cmp_eq_u32 %s, 0" % R("s", self.s_par))
@@ -426,7 +445,7 @@ class Gen:
         # ---- descriptors ------------------------------------------------------------------------------------------
         e("s_waitcnt lgkmcnt(0)")
         self.comment("descriptors: A = this tile's images, B = this column tile's weight rows, O = this tile's output pixels")
-        tile_out = c.tile_rows * c.W * c.NCOLS * 2
+        tile_out = c.tile_rows * c.W * c.NCOLS * 2 * (4 if c.s2d else 1)
         rowb = c.W * c.Cin * 2
         if c.ROWS_T:
             # A window of a row tile: LROWS image rows starting ONE ROW ABOVE the tile (the first tile of an image never touches
@@ -461,7 +480,7 @@ class Gen:
             if not self.tab_sgpr:
                 e("s_waitcnt vmcnt(0)", "the piece table")
             e("s_mov_b32 %s, 0" % R("s", self.s_cC))
-            self.b_stage_issue_all(0, 0, self.s_cC)
+            self.first_stage_issue(0)
             if self.dynamic_halo_blocks():
                 # rows that are data in one tile parity and zero halo in the other: zeroed by every tile BEFORE its pieces land
                 self.zero_blocks([c.ABASE + b * c.ASTRIDE + o for b in range(c.NA) for o in self.dynamic_halo_blocks()])
@@ -471,7 +490,7 @@ class Gen:
                 for ins in self.a_piece_insts(i, 0, self.s_cC):
                     e(ins)
             for st in range(1, c.NB):
-                self.b_stage_issue_all(st, st, self.s_cC)
+                self.first_stage_issue(st)
 
 
         def descriptors_out():
@@ -524,9 +543,11 @@ class Gen:
                 e("v_mov_b32 %s, %s" % (R("v", x), R("v", r)))
             else:  # P == 8: two image rows per fragment
                 e("v_lshrrev_b32 %s, 3, %s" % (R("v", x), R("v", r)))
-                e("v_mul_u32_u24 %s, %d, %s" % (R("v", x), c.W, R("v", x)))
+                e("v_mul_u32_u24 %s, %d, %s" % (R("v", x), c.W * (2 if c.s2d else 1), R("v", x)))   # (s2d: 2 output rows of 2W pixels, halved here, doubled below)
                 e("v_and_b32 %s, 7, %s" % (R("v", off), R("v", r)))
                 e("v_add_u32 %s, %s, %s" % (R("v", x), R("v", x), R("v", off)))
+            if c.s2d:
+                e("v_lshlrev_b32 %s, 1, %s" % (R("v", x), R("v", x)), "dy position (i, j) -> output pixel (2i, 2j) of the class's plane")
             e("v_mov_b32 %s, %d" % (R("v", off), c.NCOLS * 2))
             e("v_mul_lo_u32 %s, %s, %s" % (R("v", x), R("v", x), R("v", off)))
             e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_wn), c.NT * 16 * 2))
@@ -585,7 +606,9 @@ class Gen:
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier")
         # fragments of (stage 0, kk 0)
-        for ins in self.frag_reads(0, 0, 0, 0):
+        rt0 = {stg[0][0] for stg in self.class_stages()}
+        assert len(rt0) == 1, "every class starts with the same read tap (the first fragment reads are common)"
+        for ins in self.frag_reads(0, rt0.pop(), 0, 0):
             e(ins)
         e("s_mov_b32 %s, %s" % (R("s", self.s_cnt), R("s", self.s_nch)))
 
@@ -637,6 +660,37 @@ class Gen:
                 "s_add_u32 m0, %s, %d" % (R("s", self.s_ldsBw), c.BBASE + bp * c.BSTAGE + i * 1024),
                 "s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", s_stage), R("s", self.s_b)),
                 "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vB_dma[i & 1]), R("s", self.srdB, 4), R("s", self.s_t0))]
+
+    def first_stage_issue(self, st):
+        """prologue: the weight pieces of the workgroup's stage st (< NB) into ring stage st.  One class: tap st of chunk 0.  Several classes
+        (Cfg.s2d): the class's tap st % T of chunk st / T, weight slot and chunk offset selected by s_cls (a chunk past the reduction re-loads
+        chunk 0: valid memory, never used)"""
+        c, e = self.c, self.e
+        cls = self.class_stages()
+        if len(cls) == 1:
+            assert st < len(cls[0])
+            self.b_stage_issue_all(cls[0][st][1], st, self.s_cC)
+            return
+        sel = [(stg[st % len(stg)][1], st // len(stg)) for stg in cls]
+        tmp, tmp2 = self.s_cN, self.s_cNN     # (not live before the main loop)
+        e("s_mov_b32 %s, %s" % (R("s", self.s_stg), R("s", self.s_wt + sel[0][0])))
+        for k in range(1, len(cls)):
+            if sel[k][0] != sel[0][0]:
+                e("s_cmp_eq_u32 %s, %d" % (R("s", self.s_cls), k))
+                e("s_cselect_b32 %s, %s, %s" % (R("s", self.s_stg), R("s", self.s_wt + sel[k][0]), R("s", self.s_stg)))
+        if any(d for _, d in sel):
+            e("s_mov_b32 %s, %d" % (R("s", tmp), 128 * sel[0][1]))
+            for k in range(1, len(cls)):
+                if sel[k][1] != sel[0][1]:
+                    e("s_cmp_eq_u32 %s, %d" % (R("s", self.s_cls), k))
+                    e("s_cselect_b32 %s, %d, %s" % (R("s", tmp), 128 * sel[k][1], R("s", tmp)))
+            e("s_lshl_b32 %s, %s, 7" % (R("s", tmp2), R("s", self.s_nch)))
+            e("s_cmp_ge_u32 %s, %s" % (R("s", tmp), R("s", tmp2)))
+            e("s_cselect_b32 %s, 0, %s" % (R("s", tmp), R("s", tmp)))
+            e("s_add_u32 %s, %s, %s" % (R("s", self.s_stg), R("s", self.s_stg), R("s", tmp)))
+        for i in range(c.NPB):
+            for ins in self.b_piece_insts(i, st, self.s_stg):
+                e(ins)
 
     def b_stage_issue_all(self, tap, bp, s_chunk):
         e = self.e
@@ -702,9 +756,76 @@ class Gen:
             e("s_nop %d" % (c.skew - 1))
         self.label(lab)
 
+    # ---- kernel classes: a class = the taps one workgroup accumulates over every chunk, as (read tap, weight slot): read tap ky*3 + kx = the LDS
+    # shift of the A fragment reads (position p reads p + ky*P + kx), weight slot = index into the kernel argument wtap[9]
+    S2D_CLASSES = (((1, 1), ((0, 0), (0, 1), (1, 0), (1, 1))), ((1, 0), ((0, 0), (1, 0))), ((0, 1), ((0, 0), (0, 1))), ((0, 0), ((0, 0),)))
+
+    def class_stages(self):
+        """stride 1: ONE class of 9 taps.  Stride-2 data gradient (Cfg.s2d): the four output-parity classes (ph, pw) of
+        dx[n][2i + ph][2j + pw] = sum over the class's taps of dy[n][i + dh][j + dw] * w[tap], longest first (class = workgroup id y / column tiles: the
+        long classes are dispatched first); the staged dy tile is dconv's own, a shift (dh, dw) in {0, 1}^2 is read tap (dh + 1, dw + 1)."""
+        if not getattr(self.c, "s2d", 0):
+            return [[(t, t) for t in range(9)]]
+        out, slot = [], 0
+        for (ph, pw), taps in self.S2D_CLASSES:
+            out.append([((dh + 1) * 3 + (dw + 1), slot + i) for i, (dh, dw) in enumerate(taps)])
+            slot += len(taps)
+        assert slot == 9
+        return out
+
+    def a_carriers(self, T):
+        """(taps whose first substep carries A pieces of the next chunk, pieces per such tap): every tap but the last, at most 8"""
+        n = max(1, min(T - 1, 8))
+        aps = (self.NPA + n - 1) // n
+        return (self.NPA + aps - 1) // aps, aps
+
+    def npc(self, T, t):
+        """A pieces issued in the first substep of tap t (of T)"""
+        if self.c.NA != 2:
+            return 0
+        ntap, aps = self.a_carriers(T)
+        return max(0, min((t + 1) * aps, self.NPA) - t * aps) if t < ntap else 0
+
+    def wait_count(self, T, t):
+        """vmcnt at the stage barrier of tap t (steady state): the weight group of the NEXT stage has landed, and behind the chunk's last tap
+        every A piece of the next chunk; the count = vector-memory operations issued after the youngest of those"""
+        c = self.c
+        j = 4 * T * c.NB + t
+        ops = []
+        for s in range(j - c.NB - 2 * T - 1, j + 1):
+            ops += [("A", s)] * self.npc(T, s % T)
+            if s < j:
+                ops += [("B", s + c.NB)] * c.NPB
+        need = [i for i, (k, s) in enumerate(ops) if (k == "B" and s <= j + 1) or (k == "A" and t == T - 1)]
+        return len(ops) - 1 - max(need)
+
     def mainloop(self):
         c, e = self.c, self.e
-        self.comment("---- main loop: chunks (2 per trip: the A buffer and the weight-stage parity alternate) x 9 taps x 2 substeps")
+        cls = self.class_stages()
+        if len(cls) == 1:
+            self.mainloop_of(cls[0])
+            return
+        labs = [self.newlabel("class") for _ in cls]
+        l_epi = self.newlabel("epi")
+        for k in range(1, len(cls)):
+            e("s_cmp_eq_u32 %s, %d" % (R("s", self.s_cls), k))
+            e("s_cbranch_scc1 %s" % labs[k])
+        for k, st in enumerate(cls):
+            self.label(labs[k])
+            self.mainloop_of(st)
+            if k + 1 < len(cls):
+                e("s_branch %s" % l_epi)
+        self.label(l_epi)
+
+    def mainloop_of(self, stages):
+        c, e = self.c, self.e
+        T = len(stages)
+        assert (c.NA * T) % c.NB == 0 or c.NA == 1, "the ring stage of a tap must not depend on the trip"
+        D = (T - 1 + c.NB) // T            # chunks ahead a weight stage is requested
+        s_c = [self.s_cC, self.s_cN] + ([self.s_cNN] if D >= 2 else [])
+        assert D <= 2
+        ntap_a, aps = self.a_carriers(T)
+        self.comment("---- main loop: chunks (2 per trip: the A buffer and the weight-stage parity alternate) x %d taps x 2 substeps" % T)
         top, done = self.newlabel("loop"), self.newlabel("done")
         self.label(top)
         for cp in range(c.NA):
@@ -717,47 +838,50 @@ class Gen:
                 e("s_cbranch_scc0 %s" % (lab := self.newlabel("notlast")))
                 e("s_mov_b32 %s, 0" % R("s", self.s_cN))
                 self.label(lab)
-            for t in range(9):
-                bp = (cp * 9 + t) % c.NB          # ring stage of (chunk parity, tap): 9 % 3 == 0, so NB = 3 does not depend on cp
-                bp1 = (cp * 9 + t + 1) % c.NB     # ... of the next stage
+                if D >= 2:
+                    e("s_add_u32 %s, %s, 256" % (R("s", self.s_cNN), R("s", self.s_cC)))
+                    e("s_cmp_lt_u32 %s, 3" % R("s", self.s_cnt))
+                    e("s_cselect_b32 %s, 0, %s" % (R("s", self.s_cNN), R("s", self.s_cNN)))
+            for t in range(T):
+                rt, ws = stages[t]
+                bp = (cp * T + t) % c.NB          # ring stage of (chunk parity, tap): 9 % 3 == 0, so NB = 3 does not depend on cp
+                bp1 = (cp * T + t + 1) % c.NB     # ... of the next stage
                 # ---- substep kk = 0: compute on set 0, read (t, kk 1) into set 1, one A piece of the next chunk
                 self.comment("chunk parity %d tap %d substep 0" % (cp, t))
                 e("s_waitcnt lgkmcnt(0)")
-                groups = [[r] for r in self.frag_reads(1, t, 1, bp)]
+                groups = [[r] for r in self.frag_reads(1, rt, 1, bp)]
                 mf = self.mfmas(0)
-                pieces = [self.a_piece_insts(k, cp ^ 1, self.s_cN) for k in range(t * self.APS, min((t + 1) * self.APS, self.NPA))] if c.NA == 2 else []
+                pieces = [self.a_piece_insts(k, cp ^ 1, self.s_cN) for k in range(t * aps, min((t + 1) * aps, self.NPA))] if (c.NA == 2 and t < ntap_a) else []
                 if c.probe & 1:
                     pieces = []
                 if c.probe & 2:
                     groups = []
                 self.interleave(mf, self.merge(groups, pieces))
-                # ---- the stage barrier: stage t+1's weights (and after tap 8 the next A tile) have landed for every wave
+                # ---- the stage barrier: stage t+1's weights (and after the last tap the next A tile) have landed for every wave
                 self.comment("chunk parity %d tap %d substep 1" % (cp, t))
-                # younger than stage t+1's pieces: the weight groups of stages t+2 .. t+NB-1 and the A pieces issued since; at tap 8
-                # the A pieces must have landed too (they are older than those groups: NPA <= 8)
-                npc = lambda j: max(0, min((j + 1) * self.APS, self.NPA) - j * self.APS) if (j >= 0 and c.NA == 2) else 0
-                ayoung = sum(npc(j) for j in range(t + 2 - c.NB, t + 1))
-                e("s_waitcnt vmcnt(%d)" % (c.NPB * (c.NB - 2) + (ayoung if t < 8 else 0)))
+                # younger than stage t+1's pieces: the weight groups of stages t+2 .. t+NB-1 and the A pieces issued since; at the last tap
+                # the A pieces must have landed too
+                e("s_waitcnt vmcnt(%d)" % self.wait_count(T, t))
                 e("s_waitcnt lgkmcnt(0)")
                 if not c.probe & 4:
                     e("s_barrier")
                 self.skew()
-                t2 = (t + 1) % 9
-                if t == 8 and c.NA == 2:  # next chunk: the A bases move to the other buffer
+                t2 = (t + 1) % T
+                if t == T - 1 and c.NA == 2:  # next chunk: the A bases move to the other buffer
                     d = c.ASTRIDE if cp == 0 else -c.ASTRIDE
                     for kx in range(3):
                         for kk in range(2):
                             rr = R("v", self.vA_rd[kx][kk])
                             e("v_add_u32 %s, %d, %s" % (rr, d, rr) if d > 0 else "v_subrev_u32 %s, %d, %s" % (rr, -d, rr))
-                groups = [[r] for r in self.frag_reads(0, t2, 0, bp1)]
+                groups = [[r] for r in self.frag_reads(0, stages[t2][0], 0, bp1)]
                 # weight stage t+NB into ring stage bp (just released by the barrier)
-                t3 = (t + c.NB) % 9
-                s_ch = self.s_cC if t + c.NB < 9 else self.s_cN
+                t3 = (t + c.NB) % T
+                s_ch = s_c[(t + c.NB) // T]
                 pieces = []
                 for i in range(c.NPB):
                     g = self.b_piece_insts(i, bp, self.s_stg)
                     if i == 0:
-                        g = ["s_add_u32 %s, %s, %s" % (R("s", self.s_stg), R("s", self.s_wt + t3), R("s", s_ch))] + g
+                        g = ["s_add_u32 %s, %s, %s" % (R("s", self.s_stg), R("s", self.s_wt + stages[t3][1]), R("s", s_ch))] + g
                     pieces.append(g)
                 mf = self.mfmas(1)
                 if c.probe & 1:
@@ -817,6 +941,8 @@ class Gen:
         else:
             i, y = 0, go
         pix = (i * c.H + y) * c.W + xo
+        if c.s2d:   # the class's plane: dy position (y, xo) -> output pixel (2y [+ ph], 2xo [+ pw]) of a 2H x 2W image
+            pix = (i * 2 * c.H + 2 * y) * 2 * c.W + 2 * xo
         return mask, pix * c.NCOLS * 2
 
     def emit_frag(self, m, set_mask=True):
@@ -835,6 +961,8 @@ class Gen:
             for wm in range(1, c.WM):
                 e("s_cmp_eq_u32 %s, %d" % (R("s", self.s_wm), wm))
                 e("s_cselect_b32 %s, %d, %s" % (R("s", self.s_t0), offs[wm], R("s", self.s_t0)))
+        if c.s2d:
+            e("s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", self.s_t0), R("s", self.s_clsoff)))
         if not set_mask:
             return
         if len(set(masks)) == 1:
@@ -875,14 +1003,18 @@ class Gen:
         e("v_lshlrev_b32 %s, 2, %s" % (R("v", self.v_bp), R("v", r)))
         e("v_lshlrev_b32 %s, 3, %s" % (R("v", self.v_kg8), R("v", self.v_kg)))
         # pixel part of lane r inside a fragment, in mask bytes
+        s2 = 2 if c.s2d else 1   # (s2d: dy position (i, j) -> output pixel (2i, 2j) of a 2W-wide image, + the class's first pixel)
         if c.P >= 16:
-            e("v_mul_u32_u24 %s, %d, %s" % (R("v", t), rowb, R("v", r)))
+            e("v_mul_u32_u24 %s, %d, %s" % (R("v", t), rowb * s2, R("v", r)))
         else:   # P == 8: two image rows per fragment
             e("v_lshrrev_b32 %s, 3, %s" % (R("v", t), R("v", r)))
-            e("v_mul_u32_u24 %s, %d, %s" % (R("v", t), c.W, R("v", t)))
+            e("v_mul_u32_u24 %s, %d, %s" % (R("v", t), c.W * s2, R("v", t)))
             e("v_and_b32 %s, 7, %s" % (R("v", off), R("v", r)))
             e("v_add_u32 %s, %s, %s" % (R("v", t), R("v", t), R("v", off)))
-            e("v_mul_u32_u24 %s, %d, %s" % (R("v", t), rowb, R("v", t)))
+            e("v_mul_u32_u24 %s, %d, %s" % (R("v", t), rowb * s2, R("v", t)))
+        if c.s2d:
+            e("s_lshr_b32 %s, %s, 4" % (R("s", self.s_t1), R("s", self.s_clsoff)))
+            e("v_add_u32 %s, %s, %s" % (R("v", t), R("s", self.s_t1), R("v", t)))
         e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t1), R("s", self.s_wn), c.NT * 2))
         e("v_add_u32 %s, %s, %s" % (R("v", t), R("s", self.s_t1), R("v", t)), "+ this wave's first mask byte of a pixel")
         for j in range(self.MKG):
@@ -1055,7 +1187,12 @@ class Gen:
             e("v_add_u32 %s, %d, %s" % (R("v", ad), c.BBASE, R("v", ad)))
             e("ds_read_b64 %s, %s" % (R("v", a0, 2), R("v", ad)))
             # global offset: (tile*2*NCOLS + nt*BN + tid)*4
-            e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_tile), 2 * c.NCOLS * 4))
+            if c.s2d:   # one partial row per (tile, class)
+                e("s_lshl_b32 %s, %s, 2" % (R("s", self.s_t0), R("s", self.s_tile)))
+                e("s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", self.s_t0), R("s", self.s_cls)))
+                e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_t0), 2 * c.NCOLS * 4))
+            else:
+                e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t0), R("s", self.s_tile), 2 * c.NCOLS * 4))
             e("s_mul_i32 %s, %s, %d" % (R("s", self.s_t1), R("s", self.s_nt), c.BN * 4))
             e("s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", self.s_t0), R("s", self.s_t1)))
             e("v_lshlrev_b32 %s, 2, v0" % R("v", go))
@@ -1167,6 +1304,24 @@ VARIANTS = {
     "dconv_l1_s1": Cfg("dconv_l1_s1", H=56, W=56, P=64, IPT=1, Cin=64, NCOLS=64, stats=1, WM=4, WN=1, NT=4, ROWS_T=4),
     "dconv_l1_s2": Cfg("dconv_l1_s2", H=56, W=56, P=64, IPT=1, Cin=64, NCOLS=64, stats=2, WM=4, WN=1, NT=4, ROWS_T=4),
 }
+
+
+def _stride2_dgrad():
+    """the data gradient of the three 3x3 / stride-2 convolutions of ResNet-50 (conv2 of layer2.0 / layer3.0 / layer4.0; torchvision v1.5 strides in the
+    3x3): the stride-1 tile geometry of the layer whose resolution dy has, four output-parity classes per tile (Gen.class_stages), BN-backward sums of
+    the block's bn1 in the epilogue as in every other data gradient of the step (_s2), or none (_s0: the per-op entry point)."""
+    geo = {
+        "l2": dict(H=28, W=28, P=32, IPT=1, Cin=128, NCOLS=128, WM=4, WN=1, ROWS_T=14),
+        "l3": dict(H=14, W=14, P=16, IPT=1, Cin=256, NCOLS=256),
+        "l4": dict(H=7, W=7, P=8, IPT=2, Cin=512, NCOLS=512),
+    }
+    for tag, kw in geo.items():
+        for st in (0, 2):
+            name = "dconv_%s_d2_s%d" % (tag, st)
+            VARIANTS[name] = Cfg(name, stats=st, s2d=1, **kw)
+
+
+_stride2_dgrad()
 
 
 def _other_sizes():

@@ -150,6 +150,7 @@ struct Knobs {
   int po = 1;                // MI355_PO: the output-heavy pointwise kernels with resident weights (asm/po_gen.py); 1: the measured per-shape rule, 2: wherever a variant is legal
   int po64 = 1;              // MI355_PO64: the 64-column forms of po (layer 1's 1x1 launches into 64 channels): 0 leaves them on the implicit-GEMM kernel,
                              // 1: the measured per-shape rule, 2: wherever legal
+  int dconv_s2 = 1;          // MI355_DCONV_S2: the generated kernels of the stride-2 3x3 convolutions (dconv_*_d2: the data gradient by output-parity classes)
   char error[160] = {0};     // a switch with a value outside its domain: every conv launch fails with MI355_E_ARG and this text
 };
 const Knobs& knobs();

@@ -13,7 +13,8 @@ namespace {
 
 struct DconvVariant {
   const char* name;
-  int H, W, IPT, TPI, BN, Cin, NCOLS, stats, lds, kernarg;  // IPT images per tile, or TPI tiles per image; BN columns per workgroup
+  int H, W, IPT, TPI, BN, Cin, NCOLS, stats, s2d, lds, kernarg;  // IPT images per tile, or TPI tiles per image; BN columns per workgroup;
+                                                                 // s2d: the data gradient of a stride-2 3x3 (H x W = the dy image, four classes)
   unsigned table[3 * 4 * 64];  // [tile class][wave] LDS-DMA piece tables (asm/dconv_gen.py tables())
 };
 
@@ -160,7 +161,46 @@ bool tap_table(const TapClass& c, int wtap[9]) {
   return true;
 }
 
+// the stride-2 data gradient's classes in the kernel's order ((ph, pw) = (1, 1), (1, 0), (0, 1), (0, 0); asm/dconv_gen.py Gen.S2D_CLASSES) and, per class,
+// its taps (dh, dw) in {0, 1}^2: wtap[slot] = the weight tap of kernel slot `slot` (4 + 2 + 2 + 1 slots); false when the launch is not that pattern
+bool s2d_tap_table(const IgemmArgs& a, int nclass, int wtap[9]) {
+  static const int kcls[4][2] = {{1, 1}, {1, 0}, {0, 1}, {0, 0}};
+  static const int ktaps[4][4][2] = {{{0, 0}, {0, 1}, {1, 0}, {1, 1}}, {{0, 0}, {1, 0}, {-1, -1}, {-1, -1}}, {{0, 0}, {0, 1}, {-1, -1}, {-1, -1}}, {{0, 0}, {-1, -1}, {-1, -1}, {-1, -1}}};
+  static const int kn[4] = {4, 2, 2, 1};
+  if (nclass != 4) return false;
+  int slot = 0;
+  for (int k = 0; k < 4; ++k) {
+    const TapClass* c = nullptr;
+    for (int i = 0; i < 4; ++i)
+      if (a.cls[i].ph == kcls[k][0] && a.cls[i].pw == kcls[k][1]) c = &a.cls[i];
+    if (c == nullptr || c->ntaps != kn[k]) return false;
+    for (int j = 0; j < kn[k]; ++j, ++slot) {
+      int w = -1;
+      for (int t = 0; t < c->ntaps; ++t)
+        if (c->taps[t].dh == ktaps[k][j][0] && c->taps[t].dw == ktaps[k][j][1]) w = c->taps[t].wtap;
+      if (w < 0 || w >= 9) return false;
+      wtap[slot] = w;
+    }
+  }
+  return slot == 9;
+}
+
+int find_variant_s2d(const IgemmArgs& a, int nclass, int stats) {
+  if (nclass != 4 || a.IS != 1 || a.OS != 2 || a.pair_delta != 0 || a.wtaps != 9) return -1;
+  if (a.Hsub != a.Hin || a.Wsub != a.Win || a.Hout != 2 * a.Hin || a.Wout != 2 * a.Win) return -1;
+  if (a.pix_stride != a.Ck || a.addend != nullptr || a.q_scale_in != nullptr || a.q_scale_wt != nullptr) return -1;
+  if (stats == 1) return -1;
+  int wtap[9];
+  if (!s2d_tap_table(a, nclass, wtap)) return -1;
+  for (int i = 0; i < NVAR; ++i) {
+    const DconvVariant& v = g_variants[i];
+    if (v.s2d && v.H == a.Hin && v.W == a.Win && v.Cin == a.Ck && v.NCOLS == a.Ncols && v.stats == stats && a.N % v.IPT == 0) return i;
+  }
+  return -1;
+}
+
 int find_variant(const IgemmArgs& a, int nclass, int stats) {
+  if (nclass == 4) return find_variant_s2d(a, nclass, stats);
   if (nclass != 1 || a.IS != 1 || a.OS != 1 || a.pair_delta != 0 || a.wtaps != 9) return -1;
   if (a.Hsub != a.Hin || a.Wsub != a.Win || a.Hout != a.Hin || a.Wout != a.Win) return -1;
   if (a.pix_stride != a.Ck || a.addend != nullptr) return -1;  // (sk_ws is optional scratch: not needed here)
@@ -169,7 +209,7 @@ int find_variant(const IgemmArgs& a, int nclass, int stats) {
   if (!tap_table(a.cls[0], wtap)) return -1;
   for (int i = 0; i < NVAR; ++i) {
     const DconvVariant& v = g_variants[i];
-    if (v.H == a.Hin && v.W == a.Win && v.Cin == a.Ck && v.NCOLS == a.Ncols && v.stats == stats && a.N % v.IPT == 0) return i;
+    if (!v.s2d && v.H == a.Hin && v.W == a.Win && v.Cin == a.Ck && v.NCOLS == a.Ncols && v.stats == stats && a.N % v.IPT == 0) return i;
   }
   return -1;
 }
@@ -428,8 +468,9 @@ bool dconv_legal(const IgemmArgs& a, int nclass) {
   if (!dconv_enabled()) return false;
   const int v = find_variant(a, nclass, wanted_stats(a));
   if (v < 0) return false;
-  // one partial statistics row per tile: the caller's buffer must hold them (bn_finalize adds any number of rows, 512 per pass)
-  if (a.stat_partial != nullptr && a.N * g_variants[v].TPI / g_variants[v].IPT > (a.stat_rows_cap > 0 ? a.stat_rows_cap : 768)) return false;
+  if (g_variants[v].s2d && !knobs().dconv_s2) return false;
+  // one partial statistics row per tile (and class): the caller's buffer must hold them (bn_finalize adds any number of rows, 512 per pass)
+  if (a.stat_partial != nullptr && a.N * g_variants[v].TPI / g_variants[v].IPT * (g_variants[v].s2d ? 4 : 1) > (a.stat_rows_cap > 0 ? a.stat_rows_cap : 768)) return false;
   return module_ok();
 }
 
@@ -440,7 +481,8 @@ int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_r
   DevState* d = nullptr;
   if (!dev_state(&d)) return MI355_E_HIP;
   int wtap[9];
-  tap_table(a.cls[0], wtap);
+  if (v.s2d) s2d_tap_table(a, nclass, wtap);
+  else tap_table(a.cls[0], wtap);
   struct __attribute__((packed)) KArgs {
     const void* in;
     const void* wt;
@@ -474,12 +516,13 @@ int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_r
   size_t ksize = sizeof(k);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
   const int tiles = a.N * v.TPI / v.IPT;
-  const hipError_t e = hipModuleLaunchKernel(d->fn[vi], (unsigned)tiles, (unsigned)(a.Ncols / v.BN), 1, 256, 1, 1, 0, stream, nullptr, extra);
+  const int ncls = v.s2d ? 4 : 1;   // workgroup id y = class * column tiles + column tile: the long classes (4 taps) are dispatched first
+  const hipError_t e = hipModuleLaunchKernel(d->fn[vi], (unsigned)tiles, (unsigned)(a.Ncols / v.BN * ncls), 1, 256, 1, 1, 0, stream, nullptr, extra);
   if (e != hipSuccess) {
     set_error("dconv: hipModuleLaunchKernel(%s) -> %s", v.name, hipGetErrorString(e));
     return MI355_E_HIP;
   }
-  if (stat_rows) *stat_rows = a.stat_partial ? tiles : 0;
+  if (stat_rows) *stat_rows = a.stat_partial ? tiles * ncls : 0;
   note_kernel("%s", v.name);
   return 0;
 }

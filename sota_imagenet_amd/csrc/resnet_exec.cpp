@@ -364,6 +364,7 @@ int conv_wgrad(mi355_ctx* c, ConvBN& l, const void* dy, const void* x, float bet
       Prof p(c, wgrad_class(l.Cout), conv_flops(c, l), by, s, 2);
       MI355_TRY(launch_wgrad(MI355_FP8, a, l.splits8, s));
     }
+    snprintf(l.k_wgrad, sizeof(l.k_wgrad), "%s", mi355_last_conv_kernel());
     return launch_splitk_reduce(c->wg_partial, l.splits8, n, c->grads + l.w_off, n, beta_acc, s, c->q_scale + l.qid_dy, c->q_scale + l.qid_in);
   }
   {

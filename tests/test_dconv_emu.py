@@ -48,6 +48,20 @@ def test_direct_conv_kernels_are_exact_in_the_emulator(name, kw):
 
 
 @pytest.mark.parametrize("name,kw", [
+    ("dconv_l3_d2_s2", dict(Cin=128, tiles=(1,))),                                 # whole-image tiles, 2 chunks, BN-backward sums, all four classes
+    ("dconv_l3_d2_s0", dict(Cin=192, classes=(0, 3))),                             # odd chunk count: the 1-tap class requests weights two chunks ahead
+    ("dconv_l3_d2_s0", dict(Cin=64, NCOLS=512, ntile=1, classes=(1, 2))),          # one chunk; class and column tile from workgroup id y
+    ("dconv_l2_d2_s2", dict(Cin=128, tiles=(0, 3))),                               # half-image tiles: first / last rows of an image, 4 x 1 waves
+    ("dconv_l4_d2_s2", dict(Cin=128, tiles=(1,), ntile=1)),                        # two 7 x 7 images per tile (two rows per fragment), 2nd column tile
+])
+def test_stride2_data_gradient_kernels_are_exact_in_the_emulator(name, kw):
+    """the data gradient of the stride-2 3x3 convolutions by output-parity classes (Cfg.s2d) against the transposed convolution in numpy"""
+    r = D.run_s2d(name, **kw)
+    assert r["max_err"] == 0.0 and r["untouched_ok"], r
+    assert r["stat_err"] < 1e-6, r
+
+
+@pytest.mark.parametrize("name,kw", [
     ("pw_k256_n1024_s1", dict(mtiles=2, grid=2, N=512)),   # pixel-tile change inside a workgroup's range, statistics rows
     ("pw_k256_n1024_s1", dict(mtiles=3, grid=2)),          # 6 units per workgroup: both accumulator sets, refill path and not
     ("pw_k256_n1024_s0", dict(mtiles=2, grid=3, N=256)),   # one column tile: every unit refills

@@ -202,6 +202,57 @@ def test_bn_backward_sums_epilogue_of_the_3x3_and_long_reduction_kernels_is_exac
     assert (part[:, 1].double().sum(0) - s2).abs().max() <= 1e-6 * max(1.0, s2.abs().max().item())
 
 
+# (N, H of dx, channels, family): conv2 of layer2.0 / layer3.0 / layer4.0 — the stride sits in the 3x3 (torchvision v1.5) — and a ragged batch
+S2D = [(256, 56, 128, "dconv_l2_d2"), (256, 28, 256, "dconv_l3_d2"), (256, 14, 512, "dconv_l4_d2"), (6, 28, 256, "dconv_l3_d2"), (2, 14, 512, "dconv_l4_d2")]
+
+
+@pytest.mark.parametrize("N,H,C,fam", S2D)
+@pytest.mark.parametrize("sums", [True, False])
+def test_stride2_3x3_data_gradient_by_output_parity_classes_is_exact(dev, N, H, C, fam, sums):
+    """the generated data gradient of the stride-2 3x3 convolutions (asm/dconv_gen.py Cfg.s2d: one workgroup per (tile, output parity class), the staged
+    dy tile read at the class's taps) through mi355_conv2d_dgrad_bn: dx bit for bit against torch's transposed convolution on integer data, the
+    BN-backward partial rows (one per tile and class) against fp64 sums; MI355_DCONV_S2=0 is the implicit-GEMM kernel on the same operands"""
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(21)
+    Ho = H // 2
+    dy = torch.randint(-2, 3, (N, Ho, Ho, C), device=dev).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (C, 3, 3, C), device=dev).to(torch.bfloat16)
+    y = torch.randint(-3, 4, (N, H, H, C), device=dev).to(torch.bfloat16)
+    ybits = torch.randint(0, 256, (N, H, H, C // 8), device=dev, dtype=torch.uint8)
+    mean, invstd = (torch.randint(-4, 5, (C,), device=dev) * 0.25).float(), (torch.randint(1, 5, (C,), device=dev) * 0.5).float()
+    kw = dict(bn_y=y, bn_bits=ybits, bn_mean=mean, bn_invstd=invstd) if sums else {}
+    dx, part = ops.conv2d_dgrad_bn(dy, w, (N, H, H, C), 2, 1, **kw)
+    assert ops.last_conv_kernel() == fam + ("_s2" if sums else "_s0"), ops.last_conv_kernel()
+    ref = torch.nn.functional.conv_transpose2d(dy.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), stride=2, padding=1, output_padding=1)
+    ref = ref.permute(0, 2, 3, 1).to(torch.bfloat16)
+    assert torch.equal(dx, ref)
+    if sums:
+        bit = ((ybits.reshape(-1, C // 8, 1).to(torch.int32) >> torch.arange(8, device=dev, dtype=torch.int32)) & 1).reshape(-1, C)
+        dz = ref.reshape(-1, C).double() * bit
+        xhat = (y.double().reshape(-1, C) - mean.double()) * invstd.double()
+        s1, s2 = dz.sum(0), (dz * xhat).sum(0)
+        assert part is not None and part.shape[1:] == (2, C)
+        assert (part[:, 0].double().sum(0) - s1).abs().max() <= 1e-6 * max(1.0, s1.abs().max().item())
+        assert (part[:, 1].double().sum(0) - s2).abs().max() <= 1e-6 * max(1.0, s2.abs().max().item())
+
+
+def test_stride2_data_gradient_switch_keeps_the_implicit_gemm_kernel(dev, monkeypatch):
+    from sota_imagenet_amd import native, ops
+
+    torch.manual_seed(22)
+    N, H, C = 4, 28, 256
+    dy = torch.randint(-2, 3, (N, H // 2, H // 2, C), device=dev).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (C, 3, 3, C), device=dev).to(torch.bfloat16)
+    a, _ = ops.conv2d_dgrad_bn(dy, w, (N, H, H, C), 2, 1)
+    assert ops.last_conv_kernel() == "dconv_l3_d2_s0"
+    monkeypatch.setenv("MI355_DCONV_S2", "0")
+    native.lib().mi355_reload_knobs()
+    b, _ = ops.conv2d_dgrad_bn(dy, w, (N, H, H, C), 2, 1)
+    assert not ops.last_conv_kernel().startswith("dconv"), ops.last_conv_kernel()
+    assert torch.equal(a, b)
+
+
 def test_bn_backward_sums_of_the_data_gradient_against_the_oracle(dev):
     """the same launch against oracle/ops_ref at a batch the CPU oracle handles: y -> BatchNorm (batch statistics) -> ReLU, the data
     gradient of the next conv as the gradient of that activation; the partial rows must add up to the oracle's dbeta / dgamma / (gamma = 1)"""

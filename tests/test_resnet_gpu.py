@@ -465,7 +465,7 @@ def test_baseline_batch_rule_selected_variants(dev, dtype, monkeypatch):
             want[name] = dict(x.split("=", 1) for x in kv)
         got = m.kernel_table(key)
         diff = {k: (got.get(k), want[k]) for k in want if got.get(k) != want[k]}
-        assert not diff and set(got) == set(want), f"kernel selection changed (tools/kernel_table.py --write refreshes the table): {diff}"
+        assert not diff and set(got) == set(want), f"kernel selection changed (`python tools/kernel_table.py --write` on the GPU box writes gpurun_out/kernel_table_bs256_bf16.txt: copy it to tests/golden/): {diff}"
     P = {k: v.float() for k, v in sd.items()}
     T = lambda name: m.debug_tensor(key, name)
     q = lambda t: t.to(tdt).float()

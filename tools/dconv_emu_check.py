@@ -111,6 +111,81 @@ def run(name, tiles=(0,), ntile=0, seed=0, dgrad_taps=False, check=True, **over)
     return res
 
 
+def run_s2d(name, tiles=(0,), ntile=0, classes=(0, 1, 2, 3), seed=0, check=True, **over):
+    """a stride-2 data-gradient kernel (Cfg.s2d): dx[n][2i + ph][2j + pw] = sum over the class's taps of dy[n][i + dh][j + dw] * w[.][kh*3 + kw][.] with
+    kh = ph + 1 - 2 dh, kw = pw + 1 - 2 dw (pad 1); one workgroup per (tile, class), checked against the transposed convolution in numpy"""
+    c, g, text = dconv_gen.generate(name, **over)
+    assert c.s2d
+    rng = np.random.default_rng(seed)
+    ntiles = max(tiles) + 1
+    N = -(-ntiles // c.TPI) if c.ROWS_T else ntiles * c.IPT
+    H, W, H2, W2 = c.H, c.W, 2 * c.H, 2 * c.W
+    dy = rng.integers(-2, 3, size=(N, H, W, c.Cin)).astype(np.float32)
+    w = rng.integers(-2, 3, size=(c.NCOLS, 9, c.Cin)).astype(np.float32)      # [Ncols][wtaps][Ck]: the transposed weights of the data gradient
+    wtap_of, ref = [0] * 9, np.zeros((N, H2, W2, c.NCOLS))
+    dyp = np.zeros((N, H + 1, W + 1, c.Cin))
+    dyp[:, :H, :W] = dy
+    slot = 0
+    for (ph, pw), taps in dconv_gen.Gen.S2D_CLASSES:
+        for dh, dw in taps:
+            kh, kw = ph + 1 - 2 * dh, pw + 1 - 2 * dw
+            assert 0 <= kh < 3 and 0 <= kw < 3
+            wtap_of[slot] = kh * 3 + kw
+            slot += 1
+            ref[:, ph::2, pw::2] += np.einsum("nhwc,oc->nhwo", dyp[:, dh:dh + H, dw:dw + W], w[:, kh * 3 + kw].astype(np.float64))
+    mem = gcn_emu.Memory()
+    a_in, a_wt = mem.alloc(to_bf16_bits(dy)), mem.alloc(to_bf16_bits(w))
+    out0 = np.full((N, H2, W2, c.NCOLS), 0x7FC0, dtype=np.uint16)
+    a_out = mem.alloc(out0)
+    ntiles_all = N * c.TPI if c.ROWS_T else ntiles
+    a_stat = mem.alloc(np.full((ntiles_all * 4, 2, c.NCOLS), np.nan, dtype=np.float32))
+    yb = rng.integers(-3, 4, size=(N, H2, W2, c.NCOLS)).astype(np.float32)
+    bits = rng.integers(0, 256, size=(N, H2, W2, c.NCOLS // 8)).astype(np.uint8)
+    mean = (rng.integers(-4, 5, size=c.NCOLS) * 0.25).astype(np.float32)
+    invstd = (rng.integers(1, 5, size=c.NCOLS) * 0.5).astype(np.float32)
+    a_y, a_bits, a_mu, a_is = mem.alloc(to_bf16_bits(yb)), mem.alloc(bits), mem.alloc(mean), mem.alloc(invstd)
+    fields = [("q", a_in), ("q", a_wt), ("q", a_out), ("q", a_stat), ("q", a_y), ("q", a_bits), ("q", a_mu), ("q", a_is),
+              ("q", 0)] + [("I", wtap_of[t] * c.Cin * 2) for t in range(9)] + [("I", c.Cin // 64)] + [("I", 0)] * 4
+    fields += [("I", x) for par in dconv_gen.tables(c) for row in par for x in row]
+    ka = gcn_emu.pack_kernarg(fields)
+    assert len(ka) == dconv_gen.Gen.KA["size"], len(ka)
+    a_ka = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
+    nct = c.NCOLS // c.BN
+    total = 0
+    for t in tiles:
+        for k in classes:
+            emu = gcn_emu.Emulator(text, mem, lds_bytes=g.lds_bytes, check=check, dontcare=[(c.ABASE + (b + 1) * c.ABUF, c.ABASE + (b + 1) * c.ABUF + 256) for b in range(2)])
+            total += emu.run_workgroup(4, a_ka, wg_id=(t, k * nct + ntile, 0))
+    got = from_bf16_bits(mem.array(a_out, np.uint16, out0.shape)).astype(np.float64).reshape(N * H2, W2, c.NCOLS)
+    refr = bf16_round(ref.astype(np.float32)).astype(np.float64).reshape(N * H2, W2, c.NCOLS)
+    cols = slice(ntile * c.BN, ntile * c.BN + c.BN)
+    rows_of = lambda t: slice(t * 2 * c.tile_rows, (t + 1) * 2 * c.tile_rows)
+    res = {"insts": total, "cfg": c, "max_err": 0.0, "untouched_ok": True, "stat_err": 0.0}
+    mask = ((bits[..., None] >> np.arange(8)) & 1).reshape(N * H2, W2, c.NCOLS).astype(np.float64)
+    dz = refr * mask
+    dzx = dz * ((yb.astype(np.float64).reshape(N * H2, W2, c.NCOLS) - mean) * invstd)
+    st = mem.array(a_stat, np.float32, (ntiles_all * 4, 2, c.NCOLS))
+    scale = max(np.abs(dz).sum(axis=(0, 1)).max(), np.abs(dzx).sum(axis=(0, 1)).max(), 1.0)
+    for t in tiles:
+        for k, ((ph, pw), _) in enumerate(dconv_gen.Gen.S2D_CLASSES):
+            g_, r_ = got[rows_of(t)][ph::2, pw::2][..., cols], refr[rows_of(t)][ph::2, pw::2][..., cols]
+            if k in classes:
+                res["max_err"] = max(res["max_err"], float(np.abs(g_ - r_).max()))   # (NaN = an unwritten output: fails the == 0.0 assertion)
+                if np.isnan(g_).any():
+                    res["max_err"] = float("nan")
+                if c.stats == 2:
+                    s1 = dz[rows_of(t)][ph::2, pw::2].sum(axis=(0, 1))[cols]
+                    s2 = dzx[rows_of(t)][ph::2, pw::2].sum(axis=(0, 1))[cols]
+                    res["stat_err"] = max(res["stat_err"], float(max(np.abs(st[4 * t + k, 0][cols] - s1).max(), np.abs(st[4 * t + k, 1][cols] - s2).max()) / scale))
+            else:
+                res["untouched_ok"] &= bool(np.isnan(g_).all())
+    if c.NCOLS > c.BN:
+        other = np.ones(c.NCOLS, dtype=bool)
+        other[cols] = False
+        res["untouched_ok"] &= bool(np.isnan(got[..., other]).all())
+    return res
+
+
 if __name__ == "__main__":
     import time
     t0 = time.time()

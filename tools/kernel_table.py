@@ -1,7 +1,8 @@
 """kernel_table.py [dtype] [N] [S] — one training step of ResNet-50 on the GPU, then the executor's record of which kernel every convolution's
-forward / data-gradient / weight-gradient launch went to (mi355_resnet50_kernel_table).  `--write` refreshes the fixture
-tests/golden/kernel_table_bs256_bf16.txt that tests/test_resnet_gpu.py::test_baseline_batch_rule_selected_variants asserts: do that
-deliberately, after a selection rule was changed on purpose."""
+forward / data-gradient / weight-gradient launch went to (mi355_resnet50_kernel_table).  `--write` also stores the table as
+gpurun_out/kernel_table_bs<N>_<dtype>.txt (the GPU box only hands gpurun_out/ back); copying that file over the fixture
+tests/golden/kernel_table_bs256_bf16.txt — which tests/test_resnet_gpu.py::test_baseline_batch_rule_selected_variants asserts — is the deliberate step
+after a selection rule was changed on purpose."""
 import os
 import sys
 

@@ -1,0 +1,127 @@
+// mfma_shape_random.hip — v_mfma_f32_16x16x32_bf16 against v_mfma_f32_32x32x16_bf16 at ONE wave per SIMD (the occupancy of every generated conv
+// kernel of this repo), operands in registers, on RANDOM bf16 data and on all-zero data, with the in-kernel clock (s_memtime / s_memrealtime) beside
+// the wall time.  Why: tools/micro/mfma_rate.hip ranked the two shapes on trivial operands (small integers as bf16 bit patterns = denormals), where the
+// chip holds ~2.4 GHz and the ranking is the cycle ratio; MI355X_MICROARCH.md (DVFS give-back, item 7) says the clock the chip holds under load depends
+// on the MFMA shape and that only random data shows it.  VERDICT r05 item 1(a) asked for dconv / wg3 on the 32x32x16 form on the strength of the
+// trivial-operand numbers: this is the measurement that decides it.
+//   hipcc -O2 --offload-arch=gfx950 tools/micro/mfma_shape_random.hip -o gpurun_out/mfma_shape_random && gpurun_out/mfma_shape_random
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// 8 x 16x16x32 per trip = 4 x 32x32x16 per trip = 131072 FLOP per wave and trip; 8 (4) operand pairs per lane, loaded once
+__global__ void k16(int iters, const i32x4* __restrict__ src, float* out, unsigned long long* st) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  i32x4 a[8], b[8];
+  for (int i = 0; i < 8; ++i) { a[i] = src[(size_t)t * 16 + i]; b[i] = src[(size_t)t * 16 + 8 + i]; }
+  f32x4 c[8];
+  for (int i = 0; i < 8; ++i) c[i] = f32x4{0, 0, 0, 0};
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c[i]) : "v"(a[i]), "v"(b[i]));
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0;
+  for (int i = 0; i < 8; ++i) s += c[i][0] + c[i][3];
+  out[t] = s;
+  if ((threadIdx.x & 63) == 0) { st[(size_t)(t >> 6) * 2] = t1 - t0; st[(size_t)(t >> 6) * 2 + 1] = r1 - r0; }
+}
+
+__global__ void k32(int iters, const i32x4* __restrict__ src, float* out, unsigned long long* st) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  i32x4 a[4], b[4];
+  for (int i = 0; i < 4; ++i) { a[i] = src[(size_t)t * 16 + i]; b[i] = src[(size_t)t * 16 + 8 + i]; }
+  f32x16 c[4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 16; ++j) c[i][j] = 0;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c[i]) : "v"(a[i]), "v"(b[i]));
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0;
+  for (int i = 0; i < 4; ++i) s += c[i][0] + c[i][15];
+  out[t] = s;
+  if ((threadIdx.x & 63) == 0) { st[(size_t)(t >> 6) * 2] = t1 - t0; st[(size_t)(t >> 6) * 2 + 1] = r1 - r0; }
+}
+
+static uint16_t bf16_of(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return (uint16_t)((u + 0x7FFF + ((u >> 16) & 1)) >> 16);
+}
+
+template <typename K>
+static void run(const char* name, const char* data, K kern, int per_trip, const i32x4* src, float* out, unsigned long long* st, int nwaves) {
+  const int cus = 256, wpc = 4, iters = 400000;   // ~0.3-0.5 s per launch: long enough for the clock to settle
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  float best = 1e9f;
+  for (int r = 0; r < 3; ++r) {
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(kern, dim3(cus), dim3(64 * wpc), 0, 0, iters, src, out, st);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0 && ms < best) best = ms;
+  }
+  std::vector<unsigned long long> h((size_t)nwaves * 2);
+  CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<double> cyc, clk;
+  for (int w = 0; w < nwaves; ++w) {
+    cyc.push_back((double)h[2 * w] / ((double)iters * per_trip));
+    clk.push_back((double)h[2 * w] / (double)h[2 * w + 1] * 100e6 / 1e9);
+  }
+  std::sort(cyc.begin(), cyc.end());
+  std::sort(clk.begin(), clk.end());
+  const double flop = 131072.0 * iters * cus * wpc;
+  printf("%-26s %-7s %8.1f TFLOP/s   %6.2f cycles per instruction and wave (median)   in-kernel clock %.3f GHz (median; min %.3f max %.3f)   %.1f ms\n", name, data,
+         flop / (best * 1e-3) * 1e-12, cyc[cyc.size() / 2], clk[clk.size() / 2], clk.front(), clk.back(), best);
+}
+
+int main() {
+  const int nwaves = 256 * 4, nthreads = nwaves * 64;
+  std::vector<uint16_t> hr((size_t)nthreads * 16 * 8), hz(hr.size(), 0);
+  uint64_t s = 0x9E3779B97F4A7C15ull;
+  auto u01 = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return ((s >> 11) + 1) * (1.0 / 9007199254740993.0); };
+  for (size_t i = 0; i < hr.size(); i += 2) {
+    const double r = sqrt(-2.0 * log(u01())), th = 6.283185307179586 * u01();
+    hr[i] = bf16_of((float)(r * cos(th)));
+    hr[i + 1] = bf16_of((float)(r * sin(th)));
+  }
+  i32x4 *dr, *dz;
+  float* out;
+  unsigned long long* st;
+  CK(hipMalloc(&dr, hr.size() * 2));
+  CK(hipMalloc(&dz, hz.size() * 2));
+  CK(hipMalloc(&out, (size_t)nthreads * 4));
+  CK(hipMalloc(&st, (size_t)nwaves * 16));
+  CK(hipMemcpy(dr, hr.data(), hr.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dz, hz.data(), hz.size() * 2, hipMemcpyHostToDevice));
+  printf("one wave per SIMD (4 per CU, 256 workgroups), operands in VGPRs, accumulators in AGPRs, 131072 FLOP per wave and trip, 400000 trips\n");
+  for (int rep = 0; rep < 2; ++rep) {
+    run("v_mfma_f32_16x16x32_bf16", "random", k16, 8, dr, out, st, nwaves);
+    run("v_mfma_f32_32x32x16_bf16", "random", k32, 4, dr, out, st, nwaves);
+    run("v_mfma_f32_16x16x32_bf16", "zeros", k16, 8, dz, out, st, nwaves);
+    run("v_mfma_f32_32x32x16_bf16", "zeros", k32, 4, dz, out, st, nwaves);
+  }
+  return 0;
+}
