@@ -69,7 +69,7 @@ static uint16_t bf16_of(float f) {
 
 template <typename K>
 static void run(const char* name, const char* data, K kern, int per_trip, const i32x4* src, float* out, unsigned long long* st, int nwaves) {
-  const int cus = 256, wpc = 4, iters = 400000;   // ~0.3-0.5 s per launch: long enough for the clock to settle
+  const int cus = 256, wpc = 4, iters = 4000000;   // ~0.3-0.5 s per launch: long enough for the clock to settle
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -116,7 +116,7 @@ int main() {
   CK(hipMalloc(&st, (size_t)nwaves * 16));
   CK(hipMemcpy(dr, hr.data(), hr.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(dz, hz.data(), hz.size() * 2, hipMemcpyHostToDevice));
-  printf("one wave per SIMD (4 per CU, 256 workgroups), operands in VGPRs, accumulators in AGPRs, 131072 FLOP per wave and trip, 400000 trips\n");
+  printf("one wave per SIMD (4 per CU, 256 workgroups), operands in VGPRs, accumulators in AGPRs, 131072 FLOP per wave and trip, 4000000 trips\n");
   for (int rep = 0; rep < 2; ++rep) {
     run("v_mfma_f32_16x16x32_bf16", "random", k16, 8, dr, out, st, nwaves);
     run("v_mfma_f32_32x32x16_bf16", "random", k32, 4, dr, out, st, nwaves);
