@@ -77,6 +77,17 @@ int mi355_conv2d_fwd_stats(int dtype, const void* x, const void* w, void* y, flo
 int mi355_conv2d_dgrad(int dtype, const void* dy, const void* w, void* dx, const void* addend, int N,
                        int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* ws,
                        size_t ws_bytes, void* stream);
+/* the forward conv with the PREVIOUS layer's BatchNorm + ReLU in its operand path, as the executor's training forward launches conv2 of a
+ * bottleneck (model(data), /root/reference/sota_imagenet/callbacks.py:316: BatchNorm2d -> ReLU -> Conv2d of pytorch_tools' Bottleneck; BN
+ * semantics /root/reference/train.py:76, /root/reference/sota_imagenet/arg_parser.py:132):
+ *   a = relu(y_in * scale[c] + shift[c]) rounded to `dtype` (what mi355_bn_apply computes from the coefficients mi355_bn_fwd_train leaves),
+ *   y = conv(a, w), + the BatchNorm statistics rows of y as mi355_conv2d_fwd_stats leaves them.
+ * a_out [N,H,W,Cin] and a_bits (its ReLU mask, 1 byte per 8 channels) are written by the same launch as a by-product: the weight gradient and
+ * the BatchNorm backward read them; no separate bn_apply pass runs.  scale_shift: [2][Cin] floats.  bf16, 3x3 / stride 1 at the shapes the
+ * generated kernels cover (MI355_E_ARG elsewhere: apply the BatchNorm with mi355_bn_apply and call mi355_conv2d_fwd_stats).                  */
+int mi355_conv2d_fwd_bn_in(int dtype, const void* y_in, const float* scale_shift, const void* w, void* y, void* a_out, uint8_t* a_bits,
+                           float* partial, size_t partial_bytes, int* nblk, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                           int pad, void* stream);
 /* the data gradient as the executor's backward launches it (loss.backward(), /root/reference/sota_imagenet/callbacks.py:317; the
  * residual add + ReLU + BatchNorm backward autograd runs around cuDNN's dgrad there, fused into the conv's epilogue here):
  *   dx = conv_transpose(dy, w) + (addend under addend_bits — the shortcut gradient under the block output's ReLU bit mask; bits null: plain)

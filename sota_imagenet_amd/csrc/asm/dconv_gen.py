@@ -54,6 +54,9 @@ class Cfg:
     NT: int = 8       # 16-column tiles per wave
     NB: int = 2       # stages of the weight ring (3 where LDS allows: the pieces of stage s + 3 then have two stages to land)
     ROWS_T: int = 0   # 0: a tile is IPT whole images; else a tile is ROWS_T consecutive output rows of ONE image (H % ROWS_T == 0)
+    bnin: int = 0     # 1: the input is the RAW output y of the previous convolution: its BatchNorm + ReLU (a = relu(y * scale[c] + shift[c]), what
+                      # bn_apply_kernel computes) is applied to the staged tile in LDS before the taps read it, and the kernel leaves a and its ReLU
+                      # bit mask in memory as a by-product (every later reader of a — the weight gradient, the BN backward — is unchanged); forward only
     s2d: int = 0      # 1: the data gradient of a 3x3 / stride-2 convolution: H x W is the dy image the tile stages, the output is 2H x 2W; four
                       # kernel classes (output parities, Gen.class_stages), workgroup id y = class * column tiles + column tile
 
@@ -214,6 +217,42 @@ def tables(c):
     return out
 
 
+TR_SKIP = 0x80000000   # transform-slot flag (ttables): write the block back unchanged, store nothing
+
+
+def ttables(c):
+    """Cfg.bnin: [tile class][wave] -> 64 words: [NPA LDS offsets][NPA source constants | flags] of the blocks this wave TRANSFORMS (BatchNorm + ReLU in
+    LDS), slot for slot the pieces of a_slots().  Unlike the LDS-DMA table a slot without a row for this wave, or whose row is zero halo in this tile
+    class, is not replaced by a duplicate (a block must be transformed once): it carries TR_SKIP and names one of the wave's own blocks, which is
+    read and not written."""
+    sl = a_slots(c)
+    bpr = c.P // 8
+    out = []
+    for cls in range(NCLS):
+        src = dict(a_rows(c, cls if cls in tile_classes(c) else tile_classes(c)[0]))
+        rows = []
+        for w in range(4):
+            lds, srcs = [], []
+            for xb, grp in sl:
+                g = grp[w]
+                if g is None:      # no block of this variant for the wave: any of its own blocks, unchanged
+                    g2 = [gg[w] for x2, gg in sl if x2 == xb and gg[w] is not None][0]
+                    lds.append((g2 * bpr + xb) * 1024)
+                    srcs.append(TR_SKIP)
+                elif src[g] is None:   # halo row of this tile class: zeros stay zeros
+                    lds.append((g * bpr + xb) * 1024)
+                    srcs.append(TR_SKIP)
+                else:
+                    assert 0 <= src[g] < TR_SKIP // 2
+                    lds.append((g * bpr + xb) * 1024)
+                    srcs.append(src[g])
+            words = lds + srcs
+            assert len(words) <= 64
+            rows.append(words + [0] * (64 - len(words)))
+        out.append(rows)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 class Alloc:
     def __init__(self, prefix, first, limit):
@@ -271,7 +310,7 @@ class Gen:
         self.srdO = S.get(4, 4)
         self.srdX = S.get(4, 4)   # statistics rows
         # the piece table of this wave: in SGPRs (scalar loads, as many as 24 words) or, when larger, in a VGPR read with v_readlane
-        self.tab_sgpr = (2 * NPA + c.NPB <= 24) and c.TPI == 1 and not (c.s2d and c.stats == 2)   # (s2d + BN-backward sums: out of SGPRs)
+        self.tab_sgpr = (2 * NPA + c.NPB <= 24) and c.TPI == 1 and not (c.s2d and c.stats == 2) and not c.bnin   # (s2d + BN-backward sums, bnin: out of SGPRs)
         if not self.tab_sgpr:
             self.srdK = S.get(4, 4)   # the piece tables in the kernarg segment
         if c.stats == 2:
@@ -290,6 +329,13 @@ class Gen:
         self.s_kb = S.get(4, 4)
         if c.s2d:
             self.s_cls, self.s_clsoff, self.s_cNN = S.get(), S.get(), S.get()
+        if c.bnin:
+            assert c.stats in (0, 1) and not c.s2d
+            self.srdA1 = S.get(4, 4)     # a (the normalised input) out: the window of srdA on the other tensor
+            self.srdBt = S.get(4, 4)     # its ReLU bits out: 1 byte per 16-byte vector = the same offsets >> 4
+            self.srdSS = S.get(4, 4)     # [2][Cin] floats: scale, shift
+            self.s_sel = S.get(2, 2)
+            self.s_ta, self.s_tb, self.s_tb2, self.s_dead, self.s_last = [S.get() for _ in range(5)]
 
         self.v_tid = 0
         self.vA_rd = [[V.get() for kk in range(2)] for kx in range(3)]
@@ -316,6 +362,16 @@ class Gen:
             self.msets = [V.get(16, 4) for _ in range(2)]   # mean[8], invstd[8]
             self.v_chan = V.get()
             self.alloc_tile_masks()
+        if c.bnin:
+            self.v_tab2 = V.get()            # this wave's transform table (ttables): word i in lane i
+            self.v_lane16 = V.get()          # lane * 16: a lane transforms the 16 bytes its LDS-DMA lane wrote
+            self.v_ssoff = V.get()           # byte offset of this lane's 8 channels in a chunk's 64 floats of scale / shift
+            self.v_sc = V.get(8, 4)
+            self.v_sh = V.get(8, 4)
+            # two register sets, alternating by piece: LDS address, raw data, work / packed result, bits, store offsets
+            # (2 x pieces per substep sets: a block is read into one set in the substep before the one that works on it)
+            nsets = 2 * (self.tr_plan(9)[2] if c.NA == 2 else 1)
+            self.tr = [dict(ta=V.get(), d=V.get(4, 4), f=V.get(8, 4), bits=V.get(), o=V.get(), o2=V.get()) for _ in range(nsets)]
         self.nvgpr = V.n
         self.accum_offset = (self.nvgpr + 7) // 8 * 8
         self.nagpr = c.MFR * c.NT * 4
@@ -385,7 +441,7 @@ class Gen:
             e("s_add_u32 %s, s0, 128" % R("s", self.srdK))
             e("s_addc_u32 %s, s1, 0" % R("s", self.srdK + 1))
             e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdK + 1), R("s", self.srdK + 1)))
-            e("s_mov_b32 %s, %d" % (R("s", self.srdK + 2), NCLS * 1024))
+            e("s_mov_b32 %s, %d" % (R("s", self.srdK + 2), NCLS * 1024 * (2 if c.bnin else 1)))
             e("s_mov_b32 %s, 0x00020000" % R("s", self.srdK + 3))
             # tile -> image (s_img), row tile t inside it (s_par), class (first 0 / middle 1 / last 2)
             if c.TPI == 1:
@@ -405,6 +461,8 @@ class Gen:
             e("s_lshl_b32 %s, %s, 8" % (R("s", t0), R("s", t0)))
             e("v_lshl_add_u32 %s, %s, 2, %s" % (R("v", v[3]), R("v", lane), R("s", t0)))
             e("buffer_load_dword %s, %s, %s, 0 offen" % (R("v", self.v_tab), R("v", v[3]), R("s", self.srdK, 4)))
+            if c.bnin:   # the transform table: behind the piece tables
+                e("buffer_load_dword %s, %s, %s, 0 offen offset:%d" % (R("v", self.v_tab2), R("v", v[3]), R("s", self.srdK, 4), NCLS * 1024))
         lgn = c.WN.bit_length() - 1
         e("s_lshr_b32 %s, %s, %d" % (R("s", self.s_wm), R("s", self.s_w), lgn))
         e("s_and_b32 %s, %s, %d" % (R("s", self.s_wn), R("s", self.s_w), c.WN - 1))
@@ -418,6 +476,9 @@ class Gen:
         e("v_sub_u32 %s, %s, %s" % (R("v", j), R("v", l7), R("v", j)))
         e("v_and_b32 %s, 7, %s" % (R("v", j), R("v", j)))
         e("v_lshlrev_b32 %s, 4, %s" % (R("v", j), R("v", j)))
+        if c.bnin:
+            e("v_lshlrev_b32 %s, 1, %s" % (R("v", self.v_ssoff), R("v", j)), "this lane's 16 bytes of a pixel's chunk = 8 channels = 32 bytes of scale / shift")
+            e("v_lshlrev_b32 %s, 4, %s" % (R("v", self.v_lane16), R("v", lane)))
         for xb in range(c.P // 8):
             if xb * 8 > c.W:
                 continue
@@ -464,6 +525,33 @@ class Gen:
         e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdA + 1), R("s", self.srdA + 1)))
         e("s_mov_b32 %s, %d" % (R("s", self.srdA + 2), tile_in))
         e("s_mov_b32 %s, 0x00020000" % R("s", self.srdA + 3))
+        if c.bnin:
+            # a out: the same window on the other tensor; its ReLU bits: 1 byte per 16 bytes of it (the window's offset / 16: rowb is a multiple of 16);
+            # scale / shift: [2][Cin] floats
+            e("s_add_u32 %s, %s, %s" % (R("s", self.srdA1), R("s", ka + 8), R("s", t0)))
+            e("s_addc_u32 %s, %s, %s" % (R("s", self.srdA1 + 1), R("s", ka + 9), R("s", t1)))
+            e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdA1 + 1), R("s", self.srdA1 + 1)))
+            e("s_mov_b32 %s, %d" % (R("s", self.srdA1 + 2), tile_in))
+            e("s_mov_b32 %s, 0x00020000" % R("s", self.srdA1 + 3))
+            assert rowb % 16 == 0 and tile_in % 16 == 0
+            if c.ROWS_T:
+                e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_tile), c.ROWS_T * rowb // 16))
+                e("s_mul_hi_u32 %s, %s, %d" % (R("s", t1), R("s", self.s_tile), c.ROWS_T * rowb // 16))
+                e("s_sub_u32 %s, %s, %d" % (R("s", t0), R("s", t0), rowb // 16))
+                e("s_subb_u32 %s, %s, 0" % (R("s", t1), R("s", t1)))
+            else:
+                e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_tile), tile_in // 16))
+                e("s_mul_hi_u32 %s, %s, %d" % (R("s", t1), R("s", self.s_tile), tile_in // 16))
+            e("s_add_u32 %s, %s, %s" % (R("s", self.srdBt), R("s", ka + 10), R("s", t0)))
+            e("s_addc_u32 %s, %s, %s" % (R("s", self.srdBt + 1), R("s", ka + 11), R("s", t1)))
+            e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdBt + 1), R("s", self.srdBt + 1)))
+            e("s_mov_b32 %s, %d" % (R("s", self.srdBt + 2), tile_in // 16))
+            e("s_mov_b32 %s, 0x00020000" % R("s", self.srdBt + 3))
+            e("s_mov_b32 %s, %s" % (R("s", self.srdSS), R("s", ka + 12)))
+            e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdSS + 1), R("s", ka + 13)))
+            e("s_mov_b32 %s, %d" % (R("s", self.srdSS + 2), 2 * c.Cin * 4))
+            e("s_mov_b32 %s, 0x00020000" % R("s", self.srdSS + 3))
+            e("s_mov_b32 %s, 0" % R("s", self.s_last))
         # B: rows nt*BN .. + BN
         e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_nt), c.BN * c.w_row))
         e("s_add_u32 %s, %s, %s" % (R("s", self.srdB), R("s", ka + 2), R("s", t0)))
@@ -480,6 +568,9 @@ class Gen:
             if not self.tab_sgpr:
                 e("s_waitcnt vmcnt(0)", "the piece table")
             e("s_mov_b32 %s, 0" % R("s", self.s_cC))
+            if c.bnin:
+                for ins in self.ss_loads(self.s_cC, tagged=False):
+                    e(ins)
             self.first_stage_issue(0)
             if self.dynamic_halo_blocks():
                 # rows that are data in one tile parity and zero halo in the other: zeroed by every tile BEFORE its pieces land
@@ -605,6 +696,23 @@ class Gen:
         e("s_waitcnt vmcnt(%d)" % (c.NPB * (c.NB - 1)))
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier")
+        if c.bnin:
+            # chunk 0's tile has landed for every wave: BatchNorm + ReLU of this wave's blocks (the next block's read under the work on this one),
+            # published by a second barrier
+            self.comment("BatchNorm + ReLU of the staged tile of chunk 0")
+            ns = len(self.tr)
+            for ins in self.tr_read(0, 0, 0):
+                e(ins)
+            for k in range(self.NPA):
+                e("s_waitcnt lgkmcnt(0)")
+                if k + 1 < self.NPA:
+                    for ins in self.tr_read(k + 1, 0, (k + 1) % ns):
+                        e(ins)
+                for grp in self.tr_work(k, self.s_cC, k % ns, tagged=False):
+                    for ins in grp:
+                        e(ins)
+            e("s_waitcnt lgkmcnt(0)")
+            e("s_barrier")
         # fragments of (stage 0, kk 0)
         rt0 = {stg[0][0] for stg in self.class_stages()}
         assert len(rt0) == 1, "every class starts with the same read tap (the first fragment reads are common)"
@@ -635,31 +743,69 @@ class Gen:
             e("v_add_u32 %s, %s, %s" % (R("v", v[9]), R("s", t0), R("v", v[8])))
             e("ds_write_b128 %s, %s" % (R("v", v[9]), R("v", z, 4)))
 
-    def a_piece_insts(self, k, buf, s_chunk):
+    VMTAG = "\t;vm:"   # main-loop bookkeeping (stripped before the text is returned): tags a vector-memory operation for the counted waits
+
+    def a_piece_insts(self, k, buf, s_chunk, tag=""):
         """A piece slot k (table entries k and NPA + k of this wave) of the chunk at byte offset s_chunk into A buffer `buf`"""
         c = self.c
         var = a_slots(c)[k][0]
+        tag = self.VMTAG + tag if tag else ""
         if self.tab_sgpr:
             return ["s_add_u32 m0, %s, %d" % (R("s", self.s_tbl + k), c.ABASE + buf * c.ASTRIDE),
                     "s_add_u32 %s, %s, %s" % (R("s", self.s_t1), R("s", s_chunk), R("s", self.s_tbl + self.NPA + k)),
-                    "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vA_dma[var]), R("s", self.srdA, 4), R("s", self.s_t1))]
+                    "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vA_dma[var]), R("s", self.srdA, 4), R("s", self.s_t1)) + tag]
         return ["v_readlane_b32 %s, %s, %d" % (R("s", self.s_a), R("v", self.v_tab), k),
                 "v_readlane_b32 %s, %s, %d" % (R("s", self.s_b), R("v", self.v_tab), self.NPA + k),
                 "s_add_u32 m0, %s, %d" % (R("s", self.s_a), c.ABASE + buf * c.ASTRIDE),
                 "s_add_u32 %s, %s, %s" % (R("s", self.s_t1), R("s", s_chunk), R("s", self.s_b)),
-                "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vA_dma[var]), R("s", self.srdA, 4), R("s", self.s_t1))]
+                "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vA_dma[var]), R("s", self.srdA, 4), R("s", self.s_t1)) + tag]
 
-    def b_piece_insts(self, i, bp, s_stage):
+    def b_piece_insts(self, i, bp, s_stage, tag=""):
         """weight piece i into ring stage bp; s_stage holds (wtap*Cin + chunk*64)*2"""
         c = self.c
+        tag = self.VMTAG + tag if tag else ""
         if self.tab_sgpr:
             return ["s_add_u32 m0, %s, %d" % (R("s", self.s_ldsBw), c.BBASE + bp * c.BSTAGE + i * 1024),
                     "s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", s_stage), R("s", self.s_tbl + 2 * self.NPA + i)),
-                    "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vB_dma[i & 1]), R("s", self.srdB, 4), R("s", self.s_t0))]
+                    "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vB_dma[i & 1]), R("s", self.srdB, 4), R("s", self.s_t0)) + tag]
         return ["v_readlane_b32 %s, %s, %d" % (R("s", self.s_b), R("v", self.v_tab), 2 * self.NPA + i),
                 "s_add_u32 m0, %s, %d" % (R("s", self.s_ldsBw), c.BBASE + bp * c.BSTAGE + i * 1024),
                 "s_add_u32 %s, %s, %s" % (R("s", self.s_t0), R("s", s_stage), R("s", self.s_b)),
-                "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vB_dma[i & 1]), R("s", self.srdB, 4), R("s", self.s_t0))]
+                "buffer_load_dwordx4 %s, %s, %s offen lds" % (R("v", self.vB_dma[i & 1]), R("s", self.srdB, 4), R("s", self.s_t0)) + tag]
+
+    def patch_waits(self, start):
+        """the stage-barrier waits of the main-loop trip emitted since self.out[start]: a wait line carries `@need:<tags>@`; its count = vector-memory
+        operations issued after the youngest operation it names (the most recent one of each tag, looking back cyclically through the trip: steady
+        state; the first trip only has MORE younger operations in flight, from the prologue, which makes a counted wait stronger, never weaker)"""
+        import re
+        ops = []      # (line index, tag) of the tagged operations, in issue order; every other buffer_ instruction of the trip must be tagged
+        waits = []    # (line index, number of operations issued before it, needed tags)
+        for i in range(start, len(self.out)):
+            line = self.out[i]
+            m = re.search(r";vm:(\S+)", line)
+            if m:
+                ops.append((i, m.group(1)))
+            elif re.match(r"\tbuffer_", line):
+                raise AssertionError("untagged vector-memory operation in the main loop: " + line)
+            w = re.search(r"@need:([^@]*)@", line)
+            if w:
+                waits.append((i, len(ops), w.group(1).split(",")))
+        n = len(ops)
+        for i, before, need in waits:
+            best = None
+            for tag in need:
+                # distance back to the most recent operation with this tag (cyclic)
+                for d in range(1, n + 1):
+                    if ops[(before - d) % n][1] == tag:
+                        best = d if best is None else min(best, d)
+                        break
+                else:
+                    raise AssertionError("no operation tagged %s in the trip" % tag)
+            cnt = best - 1
+            assert 0 <= cnt <= 63
+            self.out[i] = re.sub(r"vmcnt\(@need:[^@]*@\)", "vmcnt(%d)" % cnt, self.out[i])
+        for i in range(start, len(self.out)):
+            self.out[i] = re.sub(r"\t;vm:\S+", "", self.out[i])
 
     def first_stage_issue(self, st):
         """prologue: the weight pieces of the workgroup's stage st (< NB) into ring stage st.  One class: tap st of chunk 0.  Several classes
@@ -774,10 +920,28 @@ class Gen:
         return out
 
     def a_carriers(self, T):
-        """(taps whose first substep carries A pieces of the next chunk, pieces per such tap): every tap but the last, at most 8"""
+        """(taps whose first substep carries A pieces of the next chunk, pieces per such tap): every tap but the last, at most 8.  Cfg.bnin: the pieces
+        must have landed for EVERY wave early enough for the transform to run between that barrier and the chunk's last one: see tr_plan()"""
         n = max(1, min(T - 1, 8))
+        if self.c.bnin and self.c.NA == 2:
+            n = self.tr_plan(T)[0]
         aps = (self.NPA + n - 1) // n
         return (self.NPA + aps - 1) // aps, aps
+
+    def tr_plan(self, T):
+        """Cfg.bnin, multi-chunk kernels: (n_a, tc, pps, substeps).  The next chunk's A pieces are issued in the first substeps of taps 0 .. n_a-1; the
+        stage barrier of tap tc = n_a + NB - 2 is the first whose counted wait covers all of them (it waits for the weight group issued behind tap
+        n_a's... tap tc+1-NB's barrier, which is younger than every A piece), so from the second substep of tap tc on every wave may read any landed
+        block.  A block is read (ds_read_b128) in one substep and worked on in the next: the work substeps are (tc+1, 0) .. (T-1, 0), pps pieces each."""
+        c = self.c
+        assert T == 9
+        for pps in (1, 2, 3):
+            for n_a in range(6, 0, -1):
+                tc = n_a + c.NB - 2
+                subs = [(t, sub) for t in range(tc + 1, T) for sub in (0, 1)][:-1]   # (T-1, 1) is behind the publishing barrier
+                if len(subs) * pps >= self.NPA and tc + 1 < T:
+                    return n_a, tc, pps, subs
+        raise AssertionError("no transform plan")
 
     def npc(self, T, t):
         """A pieces issued in the first substep of tap t (of T)"""
@@ -786,18 +950,75 @@ class Gen:
         ntap, aps = self.a_carriers(T)
         return max(0, min((t + 1) * aps, self.NPA) - t * aps) if t < ntap else 0
 
-    def wait_count(self, T, t):
-        """vmcnt at the stage barrier of tap t (steady state): the weight group of the NEXT stage has landed, and behind the chunk's last tap
-        every A piece of the next chunk; the count = vector-memory operations issued after the youngest of those"""
-        c = self.c
-        j = 4 * T * c.NB + t
-        ops = []
-        for s in range(j - c.NB - 2 * T - 1, j + 1):
-            ops += [("A", s)] * self.npc(T, s % T)
-            if s < j:
-                ops += [("B", s + c.NB)] * c.NPB
-        need = [i for i, (k, s) in enumerate(ops) if (k == "B" and s <= j + 1) or (k == "A" and t == T - 1)]
-        return len(ops) - 1 - max(need)
+    # ---- Cfg.bnin: BatchNorm + ReLU of the staged tile, one 1 KiB block (transform slot k of ttables) at a time ---------------------------------------
+    def tr_inv_mask(self, var):
+        """64-bit mask of the lanes of a variant-`var` block that hold no pixel (x = var*8 - 1 + (lane >> 3) outside [0, W)): their bytes are zeros and stay"""
+        m = 0
+        for lane in range(64):
+            x = var * 8 - 1 + (lane >> 3)
+            if not (0 <= x < self.c.W):
+                m |= 1 << lane
+        return m
+
+    def tr_read(self, k, buf, i):
+        """read slot k's block of A buffer `buf` into register set i"""
+        c, r = self.c, self.tr[i]
+        return ["v_readlane_b32 %s, %s, %d" % (R("s", self.s_ta), R("v", self.v_tab2), k),
+                "s_add_u32 %s, %s, %d" % (R("s", self.s_ta), R("s", self.s_ta), c.ABASE + buf * c.ASTRIDE),
+                "v_add_u32 %s, %s, %s" % (R("v", r["ta"]), R("s", self.s_ta), R("v", self.v_lane16)),
+                "ds_read_b128 %s, %s" % (R("v", r["d"], 4), R("v", r["ta"]))]
+
+    def tr_work(self, k, s_chunk, i, tagged=True):
+        """a = relu(y * scale + shift) of the block in register set i, as groups of at most two instructions: back to LDS, to the `a` tensor
+        (the LDS-DMA's own offsets) and its ReLU bits (offsets >> 4).  A TR_SKIP slot, and the lanes without a pixel, write nothing to LDS (EXEC
+        around the ds_write: their bytes are zeros and stay) and store nothing (offset out of range)."""
+        c, r = self.c, self.tr[i]
+        var = a_slots(c)[k][0]
+        d, f = r["d"], r["f"]
+        inv = self.tr_inv_mask(var)
+        tag = (self.VMTAG + "S") if tagged else ""
+        g = []
+        g.append(["v_readlane_b32 %s, %s, %d" % (R("s", self.s_tb), R("v", self.v_tab2), self.NPA + k),
+                  "s_or_b32 %s, %s, %s" % (R("s", self.s_tb), R("s", self.s_tb), R("s", self.s_last))])
+        g.append(["s_and_b32 %s, %s, 0x%x" % (R("s", self.s_dead), R("s", self.s_tb), TR_SKIP),
+                  "s_cselect_b64 %s, -1, 0" % R("s", self.s_sel, 2)])
+        g.append(["s_and_b32 %s, %s, 0x%x" % (R("s", self.s_tb), R("s", self.s_tb), TR_SKIP - 1),
+                  "s_add_u32 %s, %s, %s" % (R("s", self.s_tb), R("s", self.s_tb), R("s", s_chunk))])
+        if inv & 0xFFFFFFFF:
+            g.append(["s_or_b32 %s, %s, 0x%x" % (R("s", self.s_sel), R("s", self.s_sel), inv & 0xFFFFFFFF)])
+        if inv >> 32:
+            g.append(["s_or_b32 %s, %s, 0x%x" % (R("s", self.s_sel + 1), R("s", self.s_sel + 1), inv >> 32)])
+        g.append(["v_or_b32 %s, %s, %s" % (R("v", r["o"]), R("s", self.s_dead), R("v", self.vA_dma[var])),
+                  "s_lshr_b32 %s, %s, 4" % (R("s", self.s_tb2), R("s", self.s_tb))])
+        for j in range(4):
+            g.append(["v_lshlrev_b32 %s, 16, %s" % (R("v", f + 2 * j), R("v", d + j)),
+                      "v_and_b32 %s, 0xffff0000, %s" % (R("v", f + 2 * j + 1), R("v", d + j))])
+        for j in range(4):
+            g.append(["v_fma_f32 %s, %s, %s, %s" % (R("v", f + 2 * j + q), R("v", f + 2 * j + q), R("v", self.v_sc + 2 * j + q), R("v", self.v_sh + 2 * j + q)) for q in range(2)])
+        g.append(["v_mov_b32 %s, 0" % R("v", r["bits"]), "v_lshrrev_b32 %s, 4, %s" % (R("v", r["o2"]), R("v", r["o"]))])
+        for el in range(7, -1, -1):   # bits = (bits << 1) + (value > 0), element 7 first: bit el of the byte is element el
+            g.append(["v_cmp_lt_f32 vcc, 0, %s" % R("v", f + el),
+                      "v_addc_co_u32 %s, vcc, %s, %s, vcc" % (R("v", r["bits"]), R("v", r["bits"]), R("v", r["bits"]))])
+        for j in range(4):
+            g.append(["v_max_f32 %s, 0, %s" % (R("v", f + 2 * j + q), R("v", f + 2 * j + q)) for q in range(2)])
+        for j in range(0, 4, 2):
+            g.append(["v_cvt_pk_bf16_f32 %s, %s, %s" % (R("v", f + j + q), R("v", f + 2 * (j + q)), R("v", f + 2 * (j + q) + 1)) for q in range(2)])
+        # (one group: nothing else runs under the partial EXEC)
+        g.append(["s_andn2_b64 exec, exec, %s" % R("s", self.s_sel, 2), "ds_write_b128 %s, %s" % (R("v", r["ta"]), R("v", f, 4)), "s_mov_b64 exec, -1"])
+        g.append(["buffer_store_dwordx4 %s, %s, %s, %s offen" % (R("v", f, 4), R("v", r["o"]), R("s", self.srdA1, 4), R("s", self.s_tb)) + tag])
+        g.append(["buffer_store_byte %s, %s, %s, %s offen" % (R("v", r["bits"]), R("v", r["o2"]), R("s", self.srdBt, 4), R("s", self.s_tb2)) + tag])
+        return g
+
+    def ss_loads(self, s_chunk, tagged=True):
+        """scale / shift of this lane's 8 channels of the chunk at byte offset s_chunk (64 channels = 128 bytes of a pixel = 256 bytes of floats)"""
+        tag = (self.VMTAG + "C") if tagged else ""
+        out = ["s_lshl_b32 %s, %s, 1" % (R("s", self.s_tb), R("s", s_chunk))]
+        for h in range(2):
+            out.append("buffer_load_dwordx4 %s, %s, %s, %s offen offset:%d" % (R("v", self.v_sc + 4 * h, 4), R("v", self.v_ssoff), R("s", self.srdSS, 4), R("s", self.s_tb), 16 * h) + tag)
+        out.append("s_add_u32 %s, %s, %d" % (R("s", self.s_tb), R("s", self.s_tb), self.c.Cin * 4))
+        for h in range(2):
+            out.append("buffer_load_dwordx4 %s, %s, %s, %s offen offset:%d" % (R("v", self.v_sh + 4 * h, 4), R("v", self.v_ssoff), R("s", self.srdSS, 4), R("s", self.s_tb), 16 * h) + tag)
+        return out
 
     def mainloop(self):
         c, e = self.c, self.e
@@ -820,14 +1041,23 @@ class Gen:
     def mainloop_of(self, stages):
         c, e = self.c, self.e
         T = len(stages)
-        assert (c.NA * T) % c.NB == 0 or c.NA == 1, "the ring stage of a tap must not depend on the trip"
+        L = c.NA * T                       # stages per trip
+        assert L % c.NB == 0 or c.NA == 1, "the ring stage of a tap must not depend on the trip"
         D = (T - 1 + c.NB) // T            # chunks ahead a weight stage is requested
         s_c = [self.s_cC, self.s_cN] + ([self.s_cNN] if D >= 2 else [])
         assert D <= 2
         ntap_a, aps = self.a_carriers(T)
+        bn = c.bnin and c.NA == 2
+        if bn:
+            n_a, tc, pps, subs = self.tr_plan(T)
+            work_at = {ts: list(range(i * pps, min((i + 1) * pps, self.NPA))) for i, ts in enumerate(subs)}   # (tap, substep) -> slots worked on
+            prev = {(t, sub): ((t, 0) if sub else (t - 1, 1)) for t in range(T) for sub in (0, 1)}
+            read_at = {prev[ts]: ks for ts, ks in work_at.items()}                                                # ... -> slots read (one substep earlier)
+            assert min(read_at) >= (tc, 1)
         self.comment("---- main loop: chunks (2 per trip: the A buffer and the weight-stage parity alternate) x %d taps x 2 substeps" % T)
         top, done = self.newlabel("loop"), self.newlabel("done")
         self.label(top)
+        body = len(self.out)
         for cp in range(c.NA):
             if c.NA == 1:
                 e("s_mov_b32 %s, 0" % R("s", self.s_cN), "one chunk: the weight stages past the last tap re-load chunk 0 (never used)")
@@ -835,6 +1065,8 @@ class Gen:
                 # chunk offsets: current and next (the last chunk re-loads chunk 0: valid memory, never used)
                 e("s_add_u32 %s, %s, 128" % (R("s", self.s_cN), R("s", self.s_cC)))
                 e("s_cmp_eq_u32 %s, 1" % R("s", self.s_cnt))
+                if bn:
+                    e("s_cselect_b32 %s, 0x%x, 0" % (R("s", self.s_last), TR_SKIP), "the look-ahead tile behind the last chunk is transformed in place and stored nowhere")
                 e("s_cbranch_scc0 %s" % (lab := self.newlabel("notlast")))
                 e("s_mov_b32 %s, 0" % R("s", self.s_cN))
                 self.label(lab)
@@ -844,24 +1076,31 @@ class Gen:
                     e("s_cselect_b32 %s, 0, %s" % (R("s", self.s_cNN), R("s", self.s_cNN)))
             for t in range(T):
                 rt, ws = stages[t]
-                bp = (cp * T + t) % c.NB          # ring stage of (chunk parity, tap): 9 % 3 == 0, so NB = 3 does not depend on cp
-                bp1 = (cp * T + t + 1) % c.NB     # ... of the next stage
+                q = cp * T + t
+                bp = q % c.NB                     # ring stage of (chunk parity, tap): 9 % 3 == 0, so NB = 3 does not depend on cp
+                bp1 = (q + 1) % c.NB              # ... of the next stage
                 # ---- substep kk = 0: compute on set 0, read (t, kk 1) into set 1, one A piece of the next chunk
                 self.comment("chunk parity %d tap %d substep 0" % (cp, t))
                 e("s_waitcnt lgkmcnt(0)")
                 groups = [[r] for r in self.frag_reads(1, rt, 1, bp)]
                 mf = self.mfmas(0)
-                pieces = [self.a_piece_insts(k, cp ^ 1, self.s_cN) for k in range(t * aps, min((t + 1) * aps, self.NPA))] if (c.NA == 2 and t < ntap_a) else []
+                pieces = [self.a_piece_insts(k, cp ^ 1, self.s_cN, "A") for k in range(t * aps, min((t + 1) * aps, self.NPA))] if (c.NA == 2 and t < ntap_a) else []
+                if bn and t == 0:
+                    pieces = [self.ss_loads(self.s_cN)] + pieces   # scale / shift of the next chunk (its transform starts behind tap tc's barrier)
                 if c.probe & 1:
                     pieces = []
                 if c.probe & 2:
                     groups = []
-                self.interleave(mf, self.merge(groups, pieces))
+                groups = self.merge(groups, pieces)
+                if bn:
+                    groups = self.tr_groups(groups, read_at.get((t, 0), []), work_at.get((t, 0), []), cp ^ 1)
+                self.interleave(mf, groups)
                 # ---- the stage barrier: stage t+1's weights (and after the last tap the next A tile) have landed for every wave
                 self.comment("chunk parity %d tap %d substep 1" % (cp, t))
                 # younger than stage t+1's pieces: the weight groups of stages t+2 .. t+NB-1 and the A pieces issued since; at the last tap
-                # the A pieces must have landed too
-                e("s_waitcnt vmcnt(%d)" % self.wait_count(T, t))
+                # the A pieces must have landed too (patch_waits counts them)
+                need = ["B%d" % ((q + 1) % L)] + (["A"] if (t == T - 1 and c.NA == 2) else [])
+                e("s_waitcnt vmcnt(@need:%s@)" % ",".join(need))
                 e("s_waitcnt lgkmcnt(0)")
                 if not c.probe & 4:
                     e("s_barrier")
@@ -879,7 +1118,7 @@ class Gen:
                 s_ch = s_c[(t + c.NB) // T]
                 pieces = []
                 for i in range(c.NPB):
-                    g = self.b_piece_insts(i, bp, self.s_stg)
+                    g = self.b_piece_insts(i, bp, self.s_stg, "B%d" % ((q + c.NB) % L))
                     if i == 0:
                         g = ["s_add_u32 %s, %s, %s" % (R("s", self.s_stg), R("s", self.s_wt + stages[t3][1]), R("s", s_ch))] + g
                     pieces.append(g)
@@ -888,7 +1127,10 @@ class Gen:
                     pieces = []
                 if c.probe & 2:
                     groups = []
-                self.interleave(mf, self.merge(groups, pieces))
+                groups = self.merge(groups, pieces)
+                if bn:
+                    groups = self.tr_groups(groups, read_at.get((t, 1), []), work_at.get((t, 1), []), cp ^ 1)
+                self.interleave(mf, groups)
             if c.NA == 1:
                 break
             # next chunk
@@ -899,7 +1141,15 @@ class Gen:
                 e("s_cbranch_scc1 %s" % done)
             else:
                 e("s_cbranch_scc0 %s" % top)
+        self.patch_waits(body)
         self.label(done)
+
+    def tr_groups(self, groups, reads, works, buf):
+        """the substep's instruction groups with the transform's: the block reads first (their data is waited for at the head of the NEXT substep),
+        the work on the blocks read in the previous substep spread through the rest, one block after the other (they share scalar temporaries)"""
+        rd = [self.tr_read(k, buf, k % len(self.tr)) for k in reads]
+        wk = [g for k in works for g in self.tr_work(k, self.s_cN, k % len(self.tr))]
+        return rd + self.merge(groups, wk) if (rd or wk) else groups
 
     @staticmethod
     def merge(a, b):
@@ -1221,6 +1471,7 @@ class Gen:
         lds = c.NA * c.ABUF + c.NB * c.BSTAGE  # the A buffer(s), the weight ring
         assert lds <= 160 * 1024
         total_v = self.accum_offset + self.nagpr
+        self.ka_size = self.KA["size"] + (NCLS * 4 * 256 if getattr(c, "bnin", 0) else 0)   # (bnin: + the transform tables)
         hdr = []
         hdr.append('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
         hdr.append("\t.amdhsa_code_object_version 6")
@@ -1234,7 +1485,7 @@ class Gen:
         tail.append("\t.section\t.rodata,\"a\",@progbits")
         tail.append("\t.p2align\t6, 0x0")
         tail.append("\t.amdhsa_kernel %s" % name)
-        kd = dict(group_segment_fixed_size=lds, private_segment_fixed_size=0, kernarg_size=self.KA["size"],
+        kd = dict(group_segment_fixed_size=lds, private_segment_fixed_size=0, kernarg_size=self.ka_size,
                   user_sgpr_count=2, user_sgpr_dispatch_ptr=0, user_sgpr_queue_ptr=0, user_sgpr_kernarg_segment_ptr=1,
                   user_sgpr_dispatch_id=0, user_sgpr_kernarg_preload_length=0, user_sgpr_kernarg_preload_offset=0,
                   user_sgpr_private_segment_size=0, uses_dynamic_stack=0, enable_private_segment=0,
@@ -1259,12 +1510,12 @@ class Gen:
         for i in range(10):
             tail.append("      - .offset:         %d\n        .size:           4\n        .value_kind:     by_value" % off)
             off += 4
-        tail.append("      - .offset:         %d\n        .size:           %d\n        .value_kind:     by_value" % (off, self.KA["size"] - off))
-        off = self.KA["size"]
-        assert off == self.KA["size"]
+        tail.append("      - .offset:         %d\n        .size:           %d\n        .value_kind:     by_value" % (off, self.ka_size - off))
+        off = self.ka_size
+        assert off == self.ka_size
         tail.append("    .group_segment_fixed_size: %d" % lds)
         tail.append("    .kernarg_segment_align: 8")
-        tail.append("    .kernarg_segment_size: %d" % self.KA["size"])
+        tail.append("    .kernarg_segment_size: %d" % self.ka_size)
         tail.append("    .max_flat_workgroup_size: 256")
         tail.append("    .name:           %s" % name)
         tail.append("    .private_segment_fixed_size: 0")
@@ -1304,6 +1555,17 @@ VARIANTS = {
     "dconv_l1_s1": Cfg("dconv_l1_s1", H=56, W=56, P=64, IPT=1, Cin=64, NCOLS=64, stats=1, WM=4, WN=1, NT=4, ROWS_T=4),
     "dconv_l1_s2": Cfg("dconv_l1_s2", H=56, W=56, P=64, IPT=1, Cin=64, NCOLS=64, stats=2, WM=4, WN=1, NT=4, ROWS_T=4),
 }
+
+
+def _bn_in():
+    """conv2 of the stride-1 bottlenecks at 224 px with bn1 + ReLU in its operand path (Cfg.bnin): the training forward (BN statistics of its own output)"""
+    for tag in ("l1", "l2", "l3", "l4"):
+        base = VARIANTS["dconv_%s_s1" % tag]
+        name = "dconv_%s_s1_bn" % tag
+        VARIANTS[name] = Cfg(**{**base.__dict__, "name": name, "bnin": 1})
+
+
+_bn_in()
 
 
 def _stride2_dgrad():

@@ -105,6 +105,7 @@ static void load_knobs() {
   sw("MI355_PO", &k.po, 2);
   sw("MI355_PO64", &k.po64, 2);
   sw("MI355_DCONV_S2", &k.dconv_s2, 1);
+  sw("MI355_DCONV_BN", &k.dconv_bn, 1);
   if (k.has_igemm_big && k.igemm_big != 0 && k.igemm_big != 1 && k.igemm_big != 3 && !k.error[0])
     snprintf(k.error, sizeof(k.error), "MI355_IGEMM_BIG=%d: not one of 0, 1, 3", k.igemm_big);
   g_knobs = k;
@@ -316,6 +317,21 @@ int mi355_conv2d_fwd_stats(int dtype, const void* x, const void* w, void* y, flo
   a.in = x; a.wt = w; a.out = y;
   a.stat_partial = partial;
   a.stat_rows_cap = (int)std::min<size_t>(partial_bytes / ((size_t)2 * Cout * sizeof(float)), 1u << 20);  // (the generated kernels write one row per pixel tile)
+  return launch_igemm(dtype, a, 1, (hipStream_t)stream, nblk);
+}
+
+int mi355_conv2d_fwd_bn_in(int dtype, const void* y_in, const float* scale_shift, const void* w, void* y, void* a_out, uint8_t* a_bits, float* partial,
+                           size_t partial_bytes, int* nblk, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+  MI355_TRY(check_conv(dtype, Cin, Cout, KH, KW, stride));
+  MI355_ARG(y_in && scale_shift && a_out && a_bits, "conv2d_fwd_bn_in: null pointer");
+  MI355_ARG(partial && nblk && partial_bytes >= (size_t)768 * 2 * Cout * sizeof(float), "conv2d_fwd_bn_in: partial buffer needs 768 * 2 * Cout floats");
+  IgemmArgs a;
+  build_fwd_args(a, N, H, W, Cin, Cout, KH, KW, stride, pad);
+  a.in = y_in; a.wt = w; a.out = y;
+  a.bn_in = scale_shift; a.bn_in_a = a_out; a.bn_in_bits = a_bits;
+  a.stat_partial = partial;
+  a.stat_rows_cap = (int)std::min<size_t>(partial_bytes / ((size_t)2 * Cout * sizeof(float)), 1u << 20);
+  MI355_ARG(dconv_bn_in_legal(dtype, a, 1), "conv2d_fwd_bn_in: no kernel applies the input's BatchNorm for this launch (bf16, 3x3 / stride 1 at a generated shape)");
   return launch_igemm(dtype, a, 1, (hipStream_t)stream, nblk);
 }
 

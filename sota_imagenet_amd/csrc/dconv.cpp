@@ -13,8 +13,9 @@ namespace {
 
 struct DconvVariant {
   const char* name;
-  int H, W, IPT, TPI, BN, Cin, NCOLS, stats, s2d, lds, kernarg;  // IPT images per tile, or TPI tiles per image; BN columns per workgroup;
-                                                                 // s2d: the data gradient of a stride-2 3x3 (H x W = the dy image, four classes)
+  int H, W, IPT, TPI, BN, Cin, NCOLS, stats, s2d, bnin, lds, kernarg;  // IPT images per tile, or TPI tiles per image; BN columns per workgroup;
+                                                                 // s2d: the data gradient of a stride-2 3x3 (H x W = the dy image, four classes);
+                                                                 // bnin: BatchNorm + ReLU of the input in the operand path (IgemmArgs::bn_in)
   unsigned table[3 * 4 * 64];  // [tile class][wave] LDS-DMA piece tables (asm/dconv_gen.py tables())
 };
 
@@ -22,6 +23,16 @@ const DconvVariant g_variants[] = {
 #include "build/asm/dconv_meta.inc"
 };
 constexpr int NVAR = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
+
+// transform tables of the bnin kernels (asm/dconv_gen.py ttables()): [tile class][wave][64]
+struct DconvTT {
+  const char* name;
+  unsigned table[3 * 4 * 64];
+};
+const DconvTT g_tt[] = {
+#include "build/asm/dconv_tt.inc"
+};
+constexpr int NTT = (int)(sizeof(g_tt) / sizeof(g_tt[0]));
 
 // persistent pointwise kernels (asm/pw_gen.py)
 struct PwVariant {
@@ -207,8 +218,11 @@ int find_variant(const IgemmArgs& a, int nclass, int stats) {
   if (a.q_scale_in != nullptr || a.q_scale_wt != nullptr) return -1;
   int wtap[9];
   if (!tap_table(a.cls[0], wtap)) return -1;
+  const int bnin = a.bn_in != nullptr ? 1 : 0;
+  if (bnin && (a.bn_in_a == nullptr || a.bn_in_bits == nullptr)) return -1;
   for (int i = 0; i < NVAR; ++i) {
     const DconvVariant& v = g_variants[i];
+    if (v.bnin != bnin) continue;
     if (!v.s2d && v.H == a.Hin && v.W == a.Win && v.Cin == a.Ck && v.NCOLS == a.Ncols && v.stats == stats && a.N % v.IPT == 0) return i;
   }
   return -1;
@@ -469,6 +483,7 @@ bool dconv_legal(const IgemmArgs& a, int nclass) {
   const int v = find_variant(a, nclass, wanted_stats(a));
   if (v < 0) return false;
   if (g_variants[v].s2d && !knobs().dconv_s2) return false;
+  if (g_variants[v].bnin && !knobs().dconv_bn) return false;
   // one partial statistics row per tile (and class): the caller's buffer must hold them (bn_finalize adds any number of rows, 512 per pass)
   if (a.stat_partial != nullptr && a.N * g_variants[v].TPI / g_variants[v].IPT * (g_variants[v].s2d ? 4 : 1) > (a.stat_rows_cap > 0 ? a.stat_rows_cap : 768)) return false;
   return module_ok();
@@ -496,10 +511,12 @@ int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_r
     unsigned wtap_off[9];
     unsigned nchunks;
     unsigned pad[4];
-    unsigned table[768];  // [tile class][wave][64] LDS-DMA piece tables
+    unsigned table[768];   // [tile class][wave][64] LDS-DMA piece tables
+    unsigned ttable[768];  // bnin kernels only: the transform tables
   } k;
-  static_assert(sizeof(KArgs) == 128 + 3072, "kernarg layout of asm/dconv_gen.py (Gen.KA)");
-  MI355_ARG((int)sizeof(KArgs) == v.kernarg, "dconv: kernarg size mismatch");
+  static_assert(sizeof(KArgs) == 128 + 3072 + 3072, "kernarg layout of asm/dconv_gen.py (Gen.KA; + ttables for Cfg.bnin)");
+  size_t ksize = v.bnin ? sizeof(KArgs) : sizeof(KArgs) - sizeof(k.ttable);
+  MI355_ARG((int)ksize == v.kernarg, "dconv: kernarg size mismatch");
   k.in = a.in;
   k.wt = a.wt;
   k.out = a.out;
@@ -511,9 +528,19 @@ int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_r
   k.rsvd = nullptr;
   memset(k.pad, 0, sizeof(k.pad));
   memcpy(k.table, v.table, sizeof(k.table));
+  if (v.bnin) {  // the pointer slots of the BN-backward sums carry the input's BatchNorm: a out, its bits out, [2][Ck] scale / shift
+    k.bn_y = a.bn_in_a;
+    k.bn_bits = a.bn_in_bits;
+    k.bn_mean = a.bn_in;
+    k.bn_invstd = nullptr;
+    int ti = -1;
+    for (int i = 0; i < NTT; ++i)
+      if (strcmp(g_tt[i].name, v.name) == 0) ti = i;
+    MI355_ARG(ti >= 0, "dconv: no transform table for %s", v.name);
+    memcpy(k.ttable, g_tt[ti].table, sizeof(k.ttable));
+  }
   for (int t = 0; t < 9; ++t) k.wtap_off[t] = (unsigned)(wtap[t] * a.Ck * 2);
   k.nchunks = (unsigned)(a.Ck / 64);
-  size_t ksize = sizeof(k);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
   const int tiles = a.N * v.TPI / v.IPT;
   const int ncls = v.s2d ? 4 : 1;   // workgroup id y = class * column tiles + column tile: the long classes (4 taps) are dispatched first
@@ -595,6 +622,8 @@ bool po_legal(const IgemmArgs& a, int nclass) {
   }
   return module_ok();
 }
+
+bool dconv_bn_in_legal(int dtype, const IgemmArgs& a, int nclass) { return dtype == MI355_BF16 && a.bn_in != nullptr && dconv_legal(a, nclass); }
 
 bool igemm_sub2_legal(int dtype, const IgemmArgs& a, int nclass) { return dtype == MI355_BF16 && a.addend_sub2 && po_legal(a, nclass); }
 

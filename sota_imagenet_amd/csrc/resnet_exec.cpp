@@ -156,6 +156,7 @@ struct mi355_ctx {
   // weight-gradient side stream (wgrad + split-K reduce run beside the BN-backward / dgrad chain of the main stream)
   bool overlap = false;
   bool fuse_bn_bwd = false;  // BN-backward sums in the dgrad epilogues (MI355_FUSE_BN_BWD=0/1 overrides the default)
+  bool fuse_bn_in = true;    // bn1 + ReLU in conv2's operand path where a generated kernel has that form (library switch MI355_DCONV_BN)
   bool stem_fused_bwd = true;  // stem BN backward gathers the pool gradient on the fly (MI355_STEM_FUSED=0: pool-backward kernel + plain BN backward)
   hipStream_t wstream = nullptr;
   std::vector<hipEvent_t> fork_ev;
@@ -254,10 +255,18 @@ double conv_flops(const mi355_ctx* c, const ConvBN& l) {
 
 // conv forward; in training the epilogue also leaves the BN statistics partials of its output in c->bn_partial
 // (l.stat_rows > 0), unless the shape does not allow it (then bn_prepare runs the standalone statistics kernel)
-int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, float momentum, hipStream_t s) {
+// bn_in (optional): the conv+BN layer whose RAW output `in` is — its BatchNorm + ReLU is applied in this conv's operand path and the
+// activation + its ReLU bits land in a_out / a_bits as a by-product (the caller has checked conv_bn_in_legal)
+int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, float momentum, hipStream_t s, const ConvBN* bn_in = nullptr,
+                 void* a_out = nullptr, uint8_t* a_bits = nullptr) {
   IgemmArgs a;
   build_fwd_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
   a.in = in;
+  if (bn_in) {
+    a.bn_in = bn_in->stat + 2 * bn_in->Cout;  // scale[C], shift[C]: contiguous in the layer's statistics block
+    a.bn_in_a = a_out;
+    a.bn_in_bits = a_bits;
+  }
   a.stat_partial = training ? bn_partial_of(c, s) : nullptr;
   a.stat_rows_cap = (int)((size_t)bn_max_blocks() * c->max_c / l.Cout);  // the scratch holds bn_max_blocks() rows of the widest layer
   a.sk_ws = sk_ws_of(c, s);
@@ -265,7 +274,7 @@ int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, float mo
   a.out = l.y;
   const double fl = conv_flops(c, l);
   const bool q = training && c->fp8_fwd_on && l.fp8_fwd;
-  const double by = (double)c->N * l.Hin * l.Win * l.Cin * (q ? 1 : c->es) + (double)c->N * l.Hout * l.Wout * l.Cout * c->es;
+  const double by = (double)c->N * l.Hin * l.Win * l.Cin * (q ? 1 : c->es) * (bn_in ? 2.0 + 1.0 / 16 : 1.0) + (double)c->N * l.Hout * l.Wout * l.Cout * c->es;
   Prof p(c, igemm_class(l.Cout), fl, by, s, (l.K == 3 ? 1 : 0) | (q ? 2 : 0));
   if (q) {
     a.in = l.in_q; a.wt = l.w_q;
@@ -276,6 +285,18 @@ int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, float mo
   }
   snprintf(l.k_fwd, sizeof(l.k_fwd), "%s", mi355_last_conv_kernel());
   return 0;
+}
+
+// conv2 of block b can take bn1 + ReLU in its operand path (training forward, bf16 operands, a generated stride-1 3x3 kernel with that form)
+bool conv_bn_in_legal(mi355_ctx* c, const ConvBN& prev, const ConvBN& l, int training) {
+  if (!training || c->dtype != MI355_BF16 || c->fp8 || !c->fuse_bn_in) return false;
+  IgemmArgs a;
+  build_fwd_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
+  a.in = prev.y; a.wt = l.w_cast; a.out = l.y;
+  a.stat_partial = c->bn_partial;
+  a.stat_rows_cap = (int)((size_t)bn_max_blocks() * c->max_c / l.Cout);
+  a.bn_in = prev.stat; a.bn_in_a = prev.y; a.bn_in_bits = (uint8_t*)prev.y;  // (placeholders: only their presence matters for the check)
+  return dconv_bn_in_legal(c->dtype, a, 1);
 }
 
 // BN statistics + finalize for one layer (training) or eval coefficients
@@ -1150,9 +1171,14 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
     MI355_TRY(conv_forward(c, b.c1, b.in, training, bn_momentum, s));
     MI355_TRY(bn_prepare(c, b.c1, training, bn_momentum, s));
     // (fp8 step, lean: a1 / a2 are read by conv2 / conv3 forward and their weight gradients only — all through the twin)
-    MI355_TRY(bn_apply(c, b.c1, nullptr, nullptr, b.a1, 1, s, training ? b.a1_bits : nullptr, b.a1_q, b.qid_a1,
-                       training && c->fp8_lean && b.c2.fp8_fwd && b.c2.fp8_wgrad));
-    MI355_TRY(conv_forward(c, b.c2, b.a1, training, bn_momentum, s));
+    if (conv_bn_in_legal(c, b.c1, b.c2, training)) {
+      // bn1 + ReLU in conv2's operand path: a1 and its bits are by-products of that launch (no bn_apply pass over y1)
+      MI355_TRY(conv_forward(c, b.c2, b.c1.y, training, bn_momentum, s, &b.c1, b.a1, b.a1_bits));
+    } else {
+      MI355_TRY(bn_apply(c, b.c1, nullptr, nullptr, b.a1, 1, s, training ? b.a1_bits : nullptr, b.a1_q, b.qid_a1,
+                         training && c->fp8_lean && b.c2.fp8_fwd && b.c2.fp8_wgrad));
+      MI355_TRY(conv_forward(c, b.c2, b.a1, training, bn_momentum, s));
+    }
     MI355_TRY(bn_prepare(c, b.c2, training, bn_momentum, s));
     MI355_TRY(bn_apply(c, b.c2, nullptr, nullptr, b.a2, 1, s, training ? b.a2_bits : nullptr, b.a2_q, b.qid_a2,
                        training && c->fp8_lean && b.c3.fp8_fwd && b.c3.fp8_wgrad));

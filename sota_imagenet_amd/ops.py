@@ -48,6 +48,25 @@ def conv2d_fwd(x, w, stride=1, pad=0, stats=False):
     return y, (partial[: nblk.value * 2 * Cout].view(nblk.value, 2, Cout) if nblk.value > 0 else None)
 
 
+def conv2d_fwd_bn_in(y_in, scale, shift, w, pad=1):
+    """the forward conv with the previous layer's BatchNorm + ReLU in its operand path (mi355_conv2d_fwd_bn_in): returns
+    (y, partial, a, a_bits) — y = conv(a, w) with a = relu(y_in * scale + shift) rounded to y_in's dtype, the BN statistics rows of y, and
+    the by-products a and its ReLU bits (1 byte per 8 channels) the same launch leaves for the backward pass"""
+    _need_cuda(y_in, scale, shift, w)
+    N, H, W, Cin = y_in.shape
+    Cout, KH, KW, _ = w.shape
+    y = torch.empty((N, H, W, Cout), dtype=y_in.dtype, device=y_in.device)
+    a = torch.empty_like(y_in)
+    bits = torch.empty((N, H, W, Cin // 8), dtype=torch.uint8, device=y_in.device)
+    ss = torch.cat([scale.float().reshape(-1), shift.float().reshape(-1)]).contiguous()
+    rows = 8192 if Cout <= 256 else 768
+    partial = torch.empty(rows * 2 * Cout, dtype=torch.float32, device=y_in.device)
+    nblk = ctypes.c_int(0)
+    check(_L().mi355_conv2d_fwd_bn_in(dtype_code(y_in.dtype), ptr(y_in), ptr(ss), ptr(w), ptr(y), ptr(a), ptr(bits), ptr(partial), partial.numel() * 4,
+                                      ctypes.byref(nblk), N, H, W, Cin, Cout, KH, KW, 1, pad, cur_stream()))
+    return y, (partial[: nblk.value * 2 * Cout].view(nblk.value, 2, Cout) if nblk.value > 0 else None), a, bits
+
+
 def quantize_fp8(x, scale=1.0):
     """q = saturate_e4m3fn(x * scale) as a torch.float8_e4m3fn tensor of x's shape (x fp32 or bf16, numel % 8 == 0)."""
     _need_cuda(x)

@@ -62,6 +62,20 @@ def test_stride2_data_gradient_kernels_are_exact_in_the_emulator(name, kw):
 
 
 @pytest.mark.parametrize("name,kw", [
+    ("dconv_l3_s1_bn", dict(Cin=192)),                          # 3 chunks: the prologue's transform, two in-loop ones, the skipped look-ahead tile
+    ("dconv_l3_s1_bn", dict(Cin=64, NCOLS=512, ntile=1)),       # one chunk, second column tile
+    ("dconv_l2_s1_bn", dict(Cin=128, tiles=(0, 1, 3))),         # two blocks per substep; first / last half-image tiles (halo rows skipped)
+    ("dconv_l1_s1_bn", dict(tiles=(0, 1, 13, 14))),             # one chunk (transform in the prologue only), three tile classes, slots without a block
+    ("dconv_l4_s1_bn", dict(Cin=128, tiles=(1,), ntile=1)),     # two images per tile, 3-stage weight ring
+])
+def test_forward_kernels_with_the_inputs_batchnorm_in_the_operand_path_are_exact_in_the_emulator(name, kw):
+    """Cfg.bnin: out = conv(relu(y * scale + shift)) with the activation and its ReLU bits left in memory, on dyadic data (every step exact)"""
+    r = D.run_bn(name, **kw)
+    assert r["max_err"] == 0.0 and r["a_ok"] and r["bits_ok"], r
+    assert r["stat_err"] < 1e-6, r
+
+
+@pytest.mark.parametrize("name,kw", [
     ("pw_k256_n1024_s1", dict(mtiles=2, grid=2, N=512)),   # pixel-tile change inside a workgroup's range, statistics rows
     ("pw_k256_n1024_s1", dict(mtiles=3, grid=2)),          # 6 units per workgroup: both accumulator sets, refill path and not
     ("pw_k256_n1024_s0", dict(mtiles=2, grid=3, N=256)),   # one column tile: every unit refills

@@ -253,6 +253,64 @@ def test_stride2_data_gradient_switch_keeps_the_implicit_gemm_kernel(dev, monkey
     assert torch.equal(a, b)
 
 
+# (N, H, C, family): conv2 of the stride-1 bottlenecks of layers 1 .. 4 (C -> C), + ragged batches
+BN_IN = [(256, 56, 64, "dconv_l1"), (256, 28, 128, "dconv_l2"), (256, 14, 256, "dconv_l3"), (256, 7, 512, "dconv_l4"), (3, 28, 128, "dconv_l2"), (6, 7, 512, "dconv_l4")]
+
+
+@pytest.mark.parametrize("N,H,C,fam", BN_IN)
+def test_conv2_forward_with_bn1_in_its_operand_path_is_exact(dev, N, H, C, fam):
+    """dconv_*_s1_bn (asm/dconv_gen.py Cfg.bnin) through mi355_conv2d_fwd_bn_in on dyadic data, where every step is exact: the activation
+    a = relu(y * scale + shift) and its ReLU bits the launch leaves behind, y2 = conv(a, w) bit for bit against torch's fp32 convolution, and
+    the BatchNorm statistics rows of y2"""
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(23)
+    y1 = torch.randint(-3, 4, (N, H, H, C), device=dev).to(torch.bfloat16)
+    scale = (torch.randint(1, 9, (C,), device=dev) * 0.25).float()
+    shift = (torch.randint(-8, 9, (C,), device=dev) * 0.25).float()
+    w = torch.randint(-2, 3, (C, 3, 3, C), device=dev).to(torch.bfloat16)
+    y2, part, a, bits = ops.conv2d_fwd_bn_in(y1, scale, shift, w)
+    assert ops.last_conv_kernel() == fam + "_s1_bn", ops.last_conv_kernel()
+    v = y1.float() * scale + shift
+    a_ref = v.clamp_min(0).to(torch.bfloat16)
+    assert torch.equal(a, a_ref)
+    bits_ref = ((v > 0).reshape(N, H, H, C // 8, 8).to(torch.int32) << torch.arange(8, device=dev, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    assert torch.equal(bits, bits_ref)
+    ref = _ref(a_ref, w, 3).to(torch.bfloat16)
+    assert torch.equal(y2, ref)
+    s1, s2 = ref.double().sum(dim=(0, 1, 2)), (ref.double() ** 2).sum(dim=(0, 1, 2))
+    assert part is not None and part.shape[1:] == (2, C)
+    assert (part[:, 0].double().sum(0) - s1).abs().max() <= 1e-6 * max(1.0, s1.abs().max().item())
+    assert (part[:, 1].double().sum(0) - s2).abs().max() <= 1e-6 * s2.abs().max().item()
+
+
+def test_conv2_forward_with_bn1_in_its_operand_path_against_the_oracle_and_the_unfused_launches(dev):
+    """random data: (i) against oracle/ops_ref: BatchNorm (batch statistics) -> ReLU -> conv, with the coefficients mi355_bn_fwd_train leaves;
+    (ii) bit for bit against the library's own two launches (bn_apply, then the plain forward kernel)"""
+    from oracle import ops_ref
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(24)
+    N, H, C = 8, 14, 256
+    y1 = (torch.randn(N, H, H, C) * 2).to(torch.bfloat16)
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.3
+    w = (torch.randn(C, 3, 3, C) * 0.05).to(torch.bfloat16)
+    a_o, _, _, mean, invstd = ops_ref.bn_train(y1, gamma, beta, torch.zeros(C), torch.ones(C), relu=True)
+    out_o = ops_ref.conv2d_fwd(a_o.to(torch.bfloat16), w, 1, 1)
+    scale = (gamma * invstd).float()
+    shift = (beta - mean * scale).float()
+    y2, part, a, bits = ops.conv2d_fwd_bn_in(y1.to(dev), scale.to(dev), shift.to(dev), w.to(dev))
+    assert ops.last_conv_kernel() == "dconv_l3_s1_bn"
+    assert (a.float().cpu() - a_o.float()).abs().max() <= 2.0 ** -7 * a_o.abs().max()        # one bf16 rounding of the larger values
+    err = (y2.float().cpu() - out_o.float()).abs().max() / out_o.float().abs().max()
+    assert err < 2e-2, err
+    a_n = torch.relu(torch.addcmul(shift.to(dev), y1.to(dev).float(), scale.to(dev))).to(torch.bfloat16)   # fma, one rounding: bn_apply's arithmetic
+    y_plain, _ = ops.conv2d_fwd(a, w.to(dev), 1, 1, stats=True)
+    assert ops.last_conv_kernel() == "dconv_l3_s1"
+    assert torch.equal(y2, y_plain)
+    assert (a.float() - a_n.float()).abs().max() <= 2.0 ** -7 * a_n.float().abs().max()
+
+
 def test_bn_backward_sums_of_the_data_gradient_against_the_oracle(dev):
     """the same launch against oracle/ops_ref at a batch the CPU oracle handles: y -> BatchNorm (batch statistics) -> ReLU, the data
     gradient of the next conv as the gradient of that activation; the partial rows must add up to the oracle's dbeta / dgamma / (gamma = 1)"""

@@ -186,6 +186,68 @@ def run_s2d(name, tiles=(0,), ntile=0, classes=(0, 1, 2, 3), seed=0, check=True,
     return res
 
 
+def run_bn(name, tiles=(0,), ntile=0, seed=0, check=True, **over):
+    """a forward kernel with the previous layer's BatchNorm + ReLU in its operand path (Cfg.bnin): out = conv(a), a = bf16(relu(y * scale + shift)) — what
+    bn_apply_kernel computes —, with a and its ReLU bits (1 byte per 8 channels) left in memory by the kernel; dyadic data makes every step exact"""
+    c, g, text = dconv_gen.generate(name, **over)
+    assert c.bnin
+    rng = np.random.default_rng(seed)
+    ntiles = max(tiles) + 1
+    N = -(-ntiles // c.TPI) if c.ROWS_T else ntiles * c.IPT
+    y = rng.integers(-3, 4, size=(N, c.H, c.W, c.Cin)).astype(np.float32)
+    scale = (rng.integers(1, 9, size=c.Cin) * 0.25).astype(np.float32)
+    shift = (rng.integers(-8, 9, size=c.Cin) * 0.25).astype(np.float32)
+    w = rng.integers(-2, 3, size=(c.NCOLS, 9, c.Cin)).astype(np.float32)
+    v = y * scale + shift                       # exact: multiples of 1/16 below 16
+    a = np.maximum(v, 0).astype(np.float32)
+    assert (bf16_round(a) == a).all()
+    abits = np.packbits((v > 0).reshape(N, c.H, c.W, c.Cin // 8, 8), axis=-1, bitorder="little")[..., 0]
+    taps = [(kh - 1, kw - 1, kh * 3 + kw) for kh in range(3) for kw in range(3)]
+    mem = gcn_emu.Memory()
+    a_in, a_wt = mem.alloc(to_bf16_bits(y)), mem.alloc(to_bf16_bits(w))
+    out0 = np.full((N, c.H, c.W, c.NCOLS), 0x7FC0, dtype=np.uint16)
+    a_out = mem.alloc(out0)
+    ntiles_all = N * c.TPI if c.ROWS_T else ntiles
+    a_stat = mem.alloc(np.full((ntiles_all, 2, c.NCOLS), np.nan, dtype=np.float32))
+    a_a = mem.alloc(np.full((N, c.H, c.W, c.Cin), 0x7FC0, dtype=np.uint16))
+    a_bits = mem.alloc(np.full((N, c.H, c.W, c.Cin // 8), 0x55, dtype=np.uint8))
+    a_ss = mem.alloc(np.concatenate([scale, shift]))
+    fields = [("q", a_in), ("q", a_wt), ("q", a_out), ("q", a_stat), ("q", a_a), ("q", a_bits), ("q", a_ss), ("q", 0),
+              ("q", 0)] + [("I", t * c.Cin * 2) for t in range(9)] + [("I", c.Cin // 64)] + [("I", 0)] * 4
+    fields += [("I", x) for par in dconv_gen.tables(c) for row in par for x in row]
+    fields += [("I", x) for par in dconv_gen.ttables(c) for row in par for x in row]
+    ka = gcn_emu.pack_kernarg(fields)
+    assert len(ka) == g.ka_size, (len(ka), g.ka_size)
+    a_ka = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
+    total = 0
+    for t in tiles:
+        emu = gcn_emu.Emulator(text, mem, lds_bytes=g.lds_bytes, check=check, dontcare=[(c.ABASE + (b + 1) * c.ABUF, c.ABASE + (b + 1) * c.ABUF + 256) for b in range(2)])
+        total += emu.run_workgroup(4, a_ka, wg_id=(t, ntile, 0))
+    got = from_bf16_bits(mem.array(a_out, np.uint16, out0.shape)).astype(np.float64).reshape(N * c.H, c.W, c.NCOLS)
+    refr = bf16_round(conv_ref(a.astype(np.float64), w.astype(np.float64), taps).astype(np.float32)).astype(np.float64).reshape(N * c.H, c.W, c.NCOLS)
+    cols = slice(ntile * c.BN, ntile * c.BN + c.BN)
+    rows_of = lambda t: slice(t * c.tile_rows, (t + 1) * c.tile_rows)
+    res = {"insts": total, "cfg": c}
+    res["max_err"] = float(max(np.abs(got[rows_of(t)][..., cols] - refr[rows_of(t)][..., cols]).max() for t in tiles))
+    if c.stats == 1:
+        st = mem.array(a_stat, np.float32, (ntiles_all, 2, c.NCOLS))
+        tl = list(tiles)
+        s1 = np.stack([refr[rows_of(t)].sum(axis=(0, 1)) for t in tl])
+        s2 = np.stack([(refr[rows_of(t)] ** 2).sum(axis=(0, 1)) for t in tl])
+        # (relative: the outputs are multiples of 1/16 here, their squares do not add exactly in fp32)
+        res["stat_err"] = float(max(np.abs(st[tl, 0][:, cols] - s1[:, cols]).max() / max(1.0, np.abs(s1).max()), np.abs(st[tl, 1][:, cols] - s2[:, cols]).max() / max(1.0, np.abs(s2).max())))
+    # the by-products: every pixel of the tiles' own rows written and right; whatever else was written (halo rows of neighbouring tiles) right too
+    ga = from_bf16_bits(mem.array(a_a, np.uint16, (N, c.H, c.W, c.Cin))).reshape(N * c.H, c.W, c.Cin)
+    gb = mem.array(a_bits, np.uint8, (N, c.H, c.W, c.Cin // 8)).reshape(N * c.H, c.W, c.Cin // 8)
+    ra, rb = a.reshape(N * c.H, c.W, c.Cin), abits.reshape(N * c.H, c.W, c.Cin // 8)
+    own = np.zeros(N * c.H, dtype=bool)
+    for t in tiles:
+        own[rows_of(t)] = True
+    res["a_ok"] = bool((ga[own] == ra[own]).all() and (np.isnan(ga[~own]) | (ga[~own] == ra[~own])).all())
+    res["bits_ok"] = bool((gb[own] == rb[own]).all() and ((gb[~own] == 0x55) | (gb[~own] == rb[~own])).all())
+    return res
+
+
 if __name__ == "__main__":
     import time
     t0 = time.time()

@@ -536,6 +536,11 @@ class Emulator:
         wv.scc = 1 if r else 0
         self.swrite64(wv, ins.ops[0], r, ins)
 
+    def i_s_andn2_b64(self, wv, ins):
+        r = self.sval64(wv, ins.ops[1], ins) & ~self.sval64(wv, ins.ops[2], ins) & ((1 << 64) - 1)
+        wv.scc = 1 if r else 0
+        self.swrite64(wv, ins.ops[0], r, ins)
+
     def i_s_min_u32(self, wv, ins):
         a, b = self._s2(wv, ins)
         wv.scc = 1 if a <= b else 0
@@ -761,6 +766,36 @@ class Emulator:
         for l in np.nonzero(res)[0]:
             val |= 1 << int(l)
         self.swrite64(wv, ins.ops[0], val, ins)
+
+    def _vcmpf(self, wv, ins, f):
+        # v_cmp_xx_f32 vcc|s[..], a, b
+        a = _f32(self.vval(wv, ins.ops[1], ins))
+        b = _f32(self.vval(wv, ins.ops[2], ins))
+        with np.errstate(all="ignore"):
+            res = f(a, b) & self.lanes(wv)
+        val = 0
+        for l in np.nonzero(res)[0]:
+            val |= 1 << int(l)
+        self.swrite64(wv, ins.ops[0], val, ins)
+
+    def i_v_cmp_lt_f32(self, wv, ins):
+        self._vcmpf(wv, ins, lambda a, b: a < b)
+
+    def i_v_cmp_gt_f32(self, wv, ins):
+        self._vcmpf(wv, ins, lambda a, b: a > b)
+
+    def i_v_addc_co_u32(self, wv, ins):
+        # v_addc_co_u32 dst, carry_out (vcc | s[..]), a, b, carry_in (vcc | s[..])
+        a = self.vval(wv, ins.ops[2], ins).astype(np.int64)
+        b = self.vval(wv, ins.ops[3], ins).astype(np.int64)
+        cin = self.bits64(self.sval64(wv, ins.ops[4], ins)).astype(np.int64)
+        r = a + b + cin
+        act = self.lanes(wv)
+        val = 0
+        for l in np.nonzero((r > MASK32) & act)[0]:
+            val |= 1 << int(l)
+        self.vwrite(wv, ins.ops[0], (r & MASK32).astype(np.uint32), ins)
+        self.swrite64(wv, ins.ops[1], val, ins)
 
     def i_v_cmp_lt_u32(self, wv, ins):
         self._vcmp(wv, ins, lambda a, b: a < b)
@@ -1124,6 +1159,17 @@ class Emulator:
 
     def i_buffer_store_dword(self, wv, ins):
         self._buf_store(wv, ins, 4)
+
+    def i_buffer_store_byte(self, wv, ins):
+        data, vaddr_o, srd_o, soff_o = ins.ops
+        base, off, soff, nrec = self._buf_addr(wv, ins, vaddr_o, srd_o, soff_o)
+        vals = self.vval(wv, data, ins)
+        for l in np.nonzero(self.lanes(wv))[0]:
+            o = int(off[l])
+            if o + 1 > nrec - soff or o < 0:
+                continue
+            self.mem.write(base + o + soff, np.array([int(vals[l]) & 0xFF], dtype=np.uint8))
+        wv.vm_ops.append({"kind": "store"})
 
 
 def pack_kernarg(fields):

@@ -21,43 +21,394 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-// 8 x 16x16x32 per trip = 4 x 32x32x16 per trip = 131072 FLOP per wave and trip; 8 (4) operand pairs per lane, loaded once
+// 8 x 16x16x32 per trip = 4 x 32x32x16 per trip = 131072 FLOP per wave and trip.  The timed loop is ONE asm block with explicit registers (a first
+// version left the loop to hipcc, which parked operands in AGPRs and copied them back every trip: 22 cycles per 16x16x32): operands v[64:127] loaded
+// once, accumulators a[0:31] / a[0:63]; `_b1`: one weight-side operand for all MFMAs of a trip (the dconv loop reuses it MFR times), else one per MFMA.
 __global__ void k16(int iters, const i32x4* __restrict__ src, float* out, unsigned long long* st) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  i32x4 a[8], b[8];
-  for (int i = 0; i < 8; ++i) { a[i] = src[(size_t)t * 16 + i]; b[i] = src[(size_t)t * 16 + 8 + i]; }
-  f32x4 c[8];
-  for (int i = 0; i < 8; ++i) c[i] = f32x4{0, 0, 0, 0};
-  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c[i]) : "v"(a[i]), "v"(b[i]));
-  }
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-  float s = 0;
-  for (int i = 0; i < 8; ++i) s += c[i][0] + c[i][3];
-  out[t] = s;
+  const i32x4* p = src + (size_t)t * 16;
+  unsigned long long t0, t1, r0, r1; float res; int n = iters;
+  asm volatile(
+    "global_load_dwordx4 v[64:67], %[p], off offset:0\n"
+    "global_load_dwordx4 v[68:71], %[p], off offset:16\n"
+    "global_load_dwordx4 v[72:75], %[p], off offset:32\n"
+    "global_load_dwordx4 v[76:79], %[p], off offset:48\n"
+    "global_load_dwordx4 v[80:83], %[p], off offset:64\n"
+    "global_load_dwordx4 v[84:87], %[p], off offset:80\n"
+    "global_load_dwordx4 v[88:91], %[p], off offset:96\n"
+    "global_load_dwordx4 v[92:95], %[p], off offset:112\n"
+    "global_load_dwordx4 v[96:99], %[p], off offset:128\n"
+    "global_load_dwordx4 v[100:103], %[p], off offset:144\n"
+    "global_load_dwordx4 v[104:107], %[p], off offset:160\n"
+    "global_load_dwordx4 v[108:111], %[p], off offset:176\n"
+    "global_load_dwordx4 v[112:115], %[p], off offset:192\n"
+    "global_load_dwordx4 v[116:119], %[p], off offset:208\n"
+    "global_load_dwordx4 v[120:123], %[p], off offset:224\n"
+    "global_load_dwordx4 v[124:127], %[p], off offset:240\n"
+    "s_waitcnt vmcnt(0)\n"
+    "v_accvgpr_write_b32 a0, 0\n"
+    "v_accvgpr_write_b32 a1, 0\n"
+    "v_accvgpr_write_b32 a2, 0\n"
+    "v_accvgpr_write_b32 a3, 0\n"
+    "v_accvgpr_write_b32 a4, 0\n"
+    "v_accvgpr_write_b32 a5, 0\n"
+    "v_accvgpr_write_b32 a6, 0\n"
+    "v_accvgpr_write_b32 a7, 0\n"
+    "v_accvgpr_write_b32 a8, 0\n"
+    "v_accvgpr_write_b32 a9, 0\n"
+    "v_accvgpr_write_b32 a10, 0\n"
+    "v_accvgpr_write_b32 a11, 0\n"
+    "v_accvgpr_write_b32 a12, 0\n"
+    "v_accvgpr_write_b32 a13, 0\n"
+    "v_accvgpr_write_b32 a14, 0\n"
+    "v_accvgpr_write_b32 a15, 0\n"
+    "v_accvgpr_write_b32 a16, 0\n"
+    "v_accvgpr_write_b32 a17, 0\n"
+    "v_accvgpr_write_b32 a18, 0\n"
+    "v_accvgpr_write_b32 a19, 0\n"
+    "v_accvgpr_write_b32 a20, 0\n"
+    "v_accvgpr_write_b32 a21, 0\n"
+    "v_accvgpr_write_b32 a22, 0\n"
+    "v_accvgpr_write_b32 a23, 0\n"
+    "v_accvgpr_write_b32 a24, 0\n"
+    "v_accvgpr_write_b32 a25, 0\n"
+    "v_accvgpr_write_b32 a26, 0\n"
+    "v_accvgpr_write_b32 a27, 0\n"
+    "v_accvgpr_write_b32 a28, 0\n"
+    "v_accvgpr_write_b32 a29, 0\n"
+    "v_accvgpr_write_b32 a30, 0\n"
+    "v_accvgpr_write_b32 a31, 0\n"
+    "s_nop 7\n"
+    "s_memtime %[t0]\n"
+    "s_memrealtime %[r0]\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "1:\n"
+    "v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[64:67], a[0:3]\n"
+    "v_mfma_f32_16x16x32_bf16 a[4:7], v[100:103], v[68:71], a[4:7]\n"
+    "v_mfma_f32_16x16x32_bf16 a[8:11], v[104:107], v[72:75], a[8:11]\n"
+    "v_mfma_f32_16x16x32_bf16 a[12:15], v[108:111], v[76:79], a[12:15]\n"
+    "v_mfma_f32_16x16x32_bf16 a[16:19], v[112:115], v[80:83], a[16:19]\n"
+    "v_mfma_f32_16x16x32_bf16 a[20:23], v[116:119], v[84:87], a[20:23]\n"
+    "v_mfma_f32_16x16x32_bf16 a[24:27], v[120:123], v[88:91], a[24:27]\n"
+    "v_mfma_f32_16x16x32_bf16 a[28:31], v[124:127], v[92:95], a[28:31]\n"
+    "s_sub_u32 %[n], %[n], 1\n"
+    "s_cmp_lg_u32 %[n], 0\n"
+    "s_cbranch_scc1 1b\n"
+    "s_nop 15\n"
+    "s_nop 15\n"
+    "s_memtime %[t1]\n"
+    "s_memrealtime %[r1]\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "v_accvgpr_read_b32 %[res], a0\n"
+    : [t0] "=s"(t0), [t1] "=s"(t1), [r0] "=s"(r0), [r1] "=s"(r1), [res] "=v"(res), [n] "+s"(n)
+    : [p] "v"(p)
+    : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "scc", "memory");
+  out[t] = res;
+  if ((threadIdx.x & 63) == 0) { st[(size_t)(t >> 6) * 2] = t1 - t0; st[(size_t)(t >> 6) * 2 + 1] = r1 - r0; }
+}
+
+__global__ void k16_b1(int iters, const i32x4* __restrict__ src, float* out, unsigned long long* st) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const i32x4* p = src + (size_t)t * 16;
+  unsigned long long t0, t1, r0, r1; float res; int n = iters;
+  asm volatile(
+    "global_load_dwordx4 v[64:67], %[p], off offset:0\n"
+    "global_load_dwordx4 v[68:71], %[p], off offset:16\n"
+    "global_load_dwordx4 v[72:75], %[p], off offset:32\n"
+    "global_load_dwordx4 v[76:79], %[p], off offset:48\n"
+    "global_load_dwordx4 v[80:83], %[p], off offset:64\n"
+    "global_load_dwordx4 v[84:87], %[p], off offset:80\n"
+    "global_load_dwordx4 v[88:91], %[p], off offset:96\n"
+    "global_load_dwordx4 v[92:95], %[p], off offset:112\n"
+    "global_load_dwordx4 v[96:99], %[p], off offset:128\n"
+    "global_load_dwordx4 v[100:103], %[p], off offset:144\n"
+    "global_load_dwordx4 v[104:107], %[p], off offset:160\n"
+    "global_load_dwordx4 v[108:111], %[p], off offset:176\n"
+    "global_load_dwordx4 v[112:115], %[p], off offset:192\n"
+    "global_load_dwordx4 v[116:119], %[p], off offset:208\n"
+    "global_load_dwordx4 v[120:123], %[p], off offset:224\n"
+    "global_load_dwordx4 v[124:127], %[p], off offset:240\n"
+    "s_waitcnt vmcnt(0)\n"
+    "v_accvgpr_write_b32 a0, 0\n"
+    "v_accvgpr_write_b32 a1, 0\n"
+    "v_accvgpr_write_b32 a2, 0\n"
+    "v_accvgpr_write_b32 a3, 0\n"
+    "v_accvgpr_write_b32 a4, 0\n"
+    "v_accvgpr_write_b32 a5, 0\n"
+    "v_accvgpr_write_b32 a6, 0\n"
+    "v_accvgpr_write_b32 a7, 0\n"
+    "v_accvgpr_write_b32 a8, 0\n"
+    "v_accvgpr_write_b32 a9, 0\n"
+    "v_accvgpr_write_b32 a10, 0\n"
+    "v_accvgpr_write_b32 a11, 0\n"
+    "v_accvgpr_write_b32 a12, 0\n"
+    "v_accvgpr_write_b32 a13, 0\n"
+    "v_accvgpr_write_b32 a14, 0\n"
+    "v_accvgpr_write_b32 a15, 0\n"
+    "v_accvgpr_write_b32 a16, 0\n"
+    "v_accvgpr_write_b32 a17, 0\n"
+    "v_accvgpr_write_b32 a18, 0\n"
+    "v_accvgpr_write_b32 a19, 0\n"
+    "v_accvgpr_write_b32 a20, 0\n"
+    "v_accvgpr_write_b32 a21, 0\n"
+    "v_accvgpr_write_b32 a22, 0\n"
+    "v_accvgpr_write_b32 a23, 0\n"
+    "v_accvgpr_write_b32 a24, 0\n"
+    "v_accvgpr_write_b32 a25, 0\n"
+    "v_accvgpr_write_b32 a26, 0\n"
+    "v_accvgpr_write_b32 a27, 0\n"
+    "v_accvgpr_write_b32 a28, 0\n"
+    "v_accvgpr_write_b32 a29, 0\n"
+    "v_accvgpr_write_b32 a30, 0\n"
+    "v_accvgpr_write_b32 a31, 0\n"
+    "s_nop 7\n"
+    "s_memtime %[t0]\n"
+    "s_memrealtime %[r0]\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "1:\n"
+    "v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[64:67], a[0:3]\n"
+    "v_mfma_f32_16x16x32_bf16 a[4:7], v[96:99], v[68:71], a[4:7]\n"
+    "v_mfma_f32_16x16x32_bf16 a[8:11], v[96:99], v[72:75], a[8:11]\n"
+    "v_mfma_f32_16x16x32_bf16 a[12:15], v[96:99], v[76:79], a[12:15]\n"
+    "v_mfma_f32_16x16x32_bf16 a[16:19], v[96:99], v[80:83], a[16:19]\n"
+    "v_mfma_f32_16x16x32_bf16 a[20:23], v[96:99], v[84:87], a[20:23]\n"
+    "v_mfma_f32_16x16x32_bf16 a[24:27], v[96:99], v[88:91], a[24:27]\n"
+    "v_mfma_f32_16x16x32_bf16 a[28:31], v[96:99], v[92:95], a[28:31]\n"
+    "s_sub_u32 %[n], %[n], 1\n"
+    "s_cmp_lg_u32 %[n], 0\n"
+    "s_cbranch_scc1 1b\n"
+    "s_nop 15\n"
+    "s_nop 15\n"
+    "s_memtime %[t1]\n"
+    "s_memrealtime %[r1]\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "v_accvgpr_read_b32 %[res], a0\n"
+    : [t0] "=s"(t0), [t1] "=s"(t1), [r0] "=s"(r0), [r1] "=s"(r1), [res] "=v"(res), [n] "+s"(n)
+    : [p] "v"(p)
+    : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "scc", "memory");
+  out[t] = res;
   if ((threadIdx.x & 63) == 0) { st[(size_t)(t >> 6) * 2] = t1 - t0; st[(size_t)(t >> 6) * 2 + 1] = r1 - r0; }
 }
 
 __global__ void k32(int iters, const i32x4* __restrict__ src, float* out, unsigned long long* st) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  i32x4 a[4], b[4];
-  for (int i = 0; i < 4; ++i) { a[i] = src[(size_t)t * 16 + i]; b[i] = src[(size_t)t * 16 + 8 + i]; }
-  f32x16 c[4];
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 16; ++j) c[i][j] = 0;
-  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c[i]) : "v"(a[i]), "v"(b[i]));
-  }
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-  float s = 0;
-  for (int i = 0; i < 4; ++i) s += c[i][0] + c[i][15];
-  out[t] = s;
+  const i32x4* p = src + (size_t)t * 16;
+  unsigned long long t0, t1, r0, r1; float res; int n = iters;
+  asm volatile(
+    "global_load_dwordx4 v[64:67], %[p], off offset:0\n"
+    "global_load_dwordx4 v[68:71], %[p], off offset:16\n"
+    "global_load_dwordx4 v[72:75], %[p], off offset:32\n"
+    "global_load_dwordx4 v[76:79], %[p], off offset:48\n"
+    "global_load_dwordx4 v[80:83], %[p], off offset:64\n"
+    "global_load_dwordx4 v[84:87], %[p], off offset:80\n"
+    "global_load_dwordx4 v[88:91], %[p], off offset:96\n"
+    "global_load_dwordx4 v[92:95], %[p], off offset:112\n"
+    "global_load_dwordx4 v[96:99], %[p], off offset:128\n"
+    "global_load_dwordx4 v[100:103], %[p], off offset:144\n"
+    "global_load_dwordx4 v[104:107], %[p], off offset:160\n"
+    "global_load_dwordx4 v[108:111], %[p], off offset:176\n"
+    "global_load_dwordx4 v[112:115], %[p], off offset:192\n"
+    "global_load_dwordx4 v[116:119], %[p], off offset:208\n"
+    "global_load_dwordx4 v[120:123], %[p], off offset:224\n"
+    "global_load_dwordx4 v[124:127], %[p], off offset:240\n"
+    "s_waitcnt vmcnt(0)\n"
+    "v_accvgpr_write_b32 a0, 0\n"
+    "v_accvgpr_write_b32 a1, 0\n"
+    "v_accvgpr_write_b32 a2, 0\n"
+    "v_accvgpr_write_b32 a3, 0\n"
+    "v_accvgpr_write_b32 a4, 0\n"
+    "v_accvgpr_write_b32 a5, 0\n"
+    "v_accvgpr_write_b32 a6, 0\n"
+    "v_accvgpr_write_b32 a7, 0\n"
+    "v_accvgpr_write_b32 a8, 0\n"
+    "v_accvgpr_write_b32 a9, 0\n"
+    "v_accvgpr_write_b32 a10, 0\n"
+    "v_accvgpr_write_b32 a11, 0\n"
+    "v_accvgpr_write_b32 a12, 0\n"
+    "v_accvgpr_write_b32 a13, 0\n"
+    "v_accvgpr_write_b32 a14, 0\n"
+    "v_accvgpr_write_b32 a15, 0\n"
+    "v_accvgpr_write_b32 a16, 0\n"
+    "v_accvgpr_write_b32 a17, 0\n"
+    "v_accvgpr_write_b32 a18, 0\n"
+    "v_accvgpr_write_b32 a19, 0\n"
+    "v_accvgpr_write_b32 a20, 0\n"
+    "v_accvgpr_write_b32 a21, 0\n"
+    "v_accvgpr_write_b32 a22, 0\n"
+    "v_accvgpr_write_b32 a23, 0\n"
+    "v_accvgpr_write_b32 a24, 0\n"
+    "v_accvgpr_write_b32 a25, 0\n"
+    "v_accvgpr_write_b32 a26, 0\n"
+    "v_accvgpr_write_b32 a27, 0\n"
+    "v_accvgpr_write_b32 a28, 0\n"
+    "v_accvgpr_write_b32 a29, 0\n"
+    "v_accvgpr_write_b32 a30, 0\n"
+    "v_accvgpr_write_b32 a31, 0\n"
+    "v_accvgpr_write_b32 a32, 0\n"
+    "v_accvgpr_write_b32 a33, 0\n"
+    "v_accvgpr_write_b32 a34, 0\n"
+    "v_accvgpr_write_b32 a35, 0\n"
+    "v_accvgpr_write_b32 a36, 0\n"
+    "v_accvgpr_write_b32 a37, 0\n"
+    "v_accvgpr_write_b32 a38, 0\n"
+    "v_accvgpr_write_b32 a39, 0\n"
+    "v_accvgpr_write_b32 a40, 0\n"
+    "v_accvgpr_write_b32 a41, 0\n"
+    "v_accvgpr_write_b32 a42, 0\n"
+    "v_accvgpr_write_b32 a43, 0\n"
+    "v_accvgpr_write_b32 a44, 0\n"
+    "v_accvgpr_write_b32 a45, 0\n"
+    "v_accvgpr_write_b32 a46, 0\n"
+    "v_accvgpr_write_b32 a47, 0\n"
+    "v_accvgpr_write_b32 a48, 0\n"
+    "v_accvgpr_write_b32 a49, 0\n"
+    "v_accvgpr_write_b32 a50, 0\n"
+    "v_accvgpr_write_b32 a51, 0\n"
+    "v_accvgpr_write_b32 a52, 0\n"
+    "v_accvgpr_write_b32 a53, 0\n"
+    "v_accvgpr_write_b32 a54, 0\n"
+    "v_accvgpr_write_b32 a55, 0\n"
+    "v_accvgpr_write_b32 a56, 0\n"
+    "v_accvgpr_write_b32 a57, 0\n"
+    "v_accvgpr_write_b32 a58, 0\n"
+    "v_accvgpr_write_b32 a59, 0\n"
+    "v_accvgpr_write_b32 a60, 0\n"
+    "v_accvgpr_write_b32 a61, 0\n"
+    "v_accvgpr_write_b32 a62, 0\n"
+    "v_accvgpr_write_b32 a63, 0\n"
+    "s_nop 7\n"
+    "s_memtime %[t0]\n"
+    "s_memrealtime %[r0]\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "1:\n"
+    "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
+    "v_mfma_f32_32x32x16_bf16 a[16:31], v[100:103], v[68:71], a[16:31]\n"
+    "v_mfma_f32_32x32x16_bf16 a[32:47], v[104:107], v[72:75], a[32:47]\n"
+    "v_mfma_f32_32x32x16_bf16 a[48:63], v[108:111], v[76:79], a[48:63]\n"
+    "s_sub_u32 %[n], %[n], 1\n"
+    "s_cmp_lg_u32 %[n], 0\n"
+    "s_cbranch_scc1 1b\n"
+    "s_nop 15\n"
+    "s_nop 15\n"
+    "s_memtime %[t1]\n"
+    "s_memrealtime %[r1]\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "v_accvgpr_read_b32 %[res], a0\n"
+    : [t0] "=s"(t0), [t1] "=s"(t1), [r0] "=s"(r0), [r1] "=s"(r1), [res] "=v"(res), [n] "+s"(n)
+    : [p] "v"(p)
+    : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "scc", "memory");
+  out[t] = res;
+  if ((threadIdx.x & 63) == 0) { st[(size_t)(t >> 6) * 2] = t1 - t0; st[(size_t)(t >> 6) * 2 + 1] = r1 - r0; }
+}
+
+__global__ void k32_b1(int iters, const i32x4* __restrict__ src, float* out, unsigned long long* st) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const i32x4* p = src + (size_t)t * 16;
+  unsigned long long t0, t1, r0, r1; float res; int n = iters;
+  asm volatile(
+    "global_load_dwordx4 v[64:67], %[p], off offset:0\n"
+    "global_load_dwordx4 v[68:71], %[p], off offset:16\n"
+    "global_load_dwordx4 v[72:75], %[p], off offset:32\n"
+    "global_load_dwordx4 v[76:79], %[p], off offset:48\n"
+    "global_load_dwordx4 v[80:83], %[p], off offset:64\n"
+    "global_load_dwordx4 v[84:87], %[p], off offset:80\n"
+    "global_load_dwordx4 v[88:91], %[p], off offset:96\n"
+    "global_load_dwordx4 v[92:95], %[p], off offset:112\n"
+    "global_load_dwordx4 v[96:99], %[p], off offset:128\n"
+    "global_load_dwordx4 v[100:103], %[p], off offset:144\n"
+    "global_load_dwordx4 v[104:107], %[p], off offset:160\n"
+    "global_load_dwordx4 v[108:111], %[p], off offset:176\n"
+    "global_load_dwordx4 v[112:115], %[p], off offset:192\n"
+    "global_load_dwordx4 v[116:119], %[p], off offset:208\n"
+    "global_load_dwordx4 v[120:123], %[p], off offset:224\n"
+    "global_load_dwordx4 v[124:127], %[p], off offset:240\n"
+    "s_waitcnt vmcnt(0)\n"
+    "v_accvgpr_write_b32 a0, 0\n"
+    "v_accvgpr_write_b32 a1, 0\n"
+    "v_accvgpr_write_b32 a2, 0\n"
+    "v_accvgpr_write_b32 a3, 0\n"
+    "v_accvgpr_write_b32 a4, 0\n"
+    "v_accvgpr_write_b32 a5, 0\n"
+    "v_accvgpr_write_b32 a6, 0\n"
+    "v_accvgpr_write_b32 a7, 0\n"
+    "v_accvgpr_write_b32 a8, 0\n"
+    "v_accvgpr_write_b32 a9, 0\n"
+    "v_accvgpr_write_b32 a10, 0\n"
+    "v_accvgpr_write_b32 a11, 0\n"
+    "v_accvgpr_write_b32 a12, 0\n"
+    "v_accvgpr_write_b32 a13, 0\n"
+    "v_accvgpr_write_b32 a14, 0\n"
+    "v_accvgpr_write_b32 a15, 0\n"
+    "v_accvgpr_write_b32 a16, 0\n"
+    "v_accvgpr_write_b32 a17, 0\n"
+    "v_accvgpr_write_b32 a18, 0\n"
+    "v_accvgpr_write_b32 a19, 0\n"
+    "v_accvgpr_write_b32 a20, 0\n"
+    "v_accvgpr_write_b32 a21, 0\n"
+    "v_accvgpr_write_b32 a22, 0\n"
+    "v_accvgpr_write_b32 a23, 0\n"
+    "v_accvgpr_write_b32 a24, 0\n"
+    "v_accvgpr_write_b32 a25, 0\n"
+    "v_accvgpr_write_b32 a26, 0\n"
+    "v_accvgpr_write_b32 a27, 0\n"
+    "v_accvgpr_write_b32 a28, 0\n"
+    "v_accvgpr_write_b32 a29, 0\n"
+    "v_accvgpr_write_b32 a30, 0\n"
+    "v_accvgpr_write_b32 a31, 0\n"
+    "v_accvgpr_write_b32 a32, 0\n"
+    "v_accvgpr_write_b32 a33, 0\n"
+    "v_accvgpr_write_b32 a34, 0\n"
+    "v_accvgpr_write_b32 a35, 0\n"
+    "v_accvgpr_write_b32 a36, 0\n"
+    "v_accvgpr_write_b32 a37, 0\n"
+    "v_accvgpr_write_b32 a38, 0\n"
+    "v_accvgpr_write_b32 a39, 0\n"
+    "v_accvgpr_write_b32 a40, 0\n"
+    "v_accvgpr_write_b32 a41, 0\n"
+    "v_accvgpr_write_b32 a42, 0\n"
+    "v_accvgpr_write_b32 a43, 0\n"
+    "v_accvgpr_write_b32 a44, 0\n"
+    "v_accvgpr_write_b32 a45, 0\n"
+    "v_accvgpr_write_b32 a46, 0\n"
+    "v_accvgpr_write_b32 a47, 0\n"
+    "v_accvgpr_write_b32 a48, 0\n"
+    "v_accvgpr_write_b32 a49, 0\n"
+    "v_accvgpr_write_b32 a50, 0\n"
+    "v_accvgpr_write_b32 a51, 0\n"
+    "v_accvgpr_write_b32 a52, 0\n"
+    "v_accvgpr_write_b32 a53, 0\n"
+    "v_accvgpr_write_b32 a54, 0\n"
+    "v_accvgpr_write_b32 a55, 0\n"
+    "v_accvgpr_write_b32 a56, 0\n"
+    "v_accvgpr_write_b32 a57, 0\n"
+    "v_accvgpr_write_b32 a58, 0\n"
+    "v_accvgpr_write_b32 a59, 0\n"
+    "v_accvgpr_write_b32 a60, 0\n"
+    "v_accvgpr_write_b32 a61, 0\n"
+    "v_accvgpr_write_b32 a62, 0\n"
+    "v_accvgpr_write_b32 a63, 0\n"
+    "s_nop 7\n"
+    "s_memtime %[t0]\n"
+    "s_memrealtime %[r0]\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "1:\n"
+    "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
+    "v_mfma_f32_32x32x16_bf16 a[16:31], v[96:99], v[68:71], a[16:31]\n"
+    "v_mfma_f32_32x32x16_bf16 a[32:47], v[96:99], v[72:75], a[32:47]\n"
+    "v_mfma_f32_32x32x16_bf16 a[48:63], v[96:99], v[76:79], a[48:63]\n"
+    "s_sub_u32 %[n], %[n], 1\n"
+    "s_cmp_lg_u32 %[n], 0\n"
+    "s_cbranch_scc1 1b\n"
+    "s_nop 15\n"
+    "s_nop 15\n"
+    "s_memtime %[t1]\n"
+    "s_memrealtime %[r1]\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "v_accvgpr_read_b32 %[res], a0\n"
+    : [t0] "=s"(t0), [t1] "=s"(t1), [r0] "=s"(r0), [r1] "=s"(r1), [res] "=v"(res), [n] "+s"(n)
+    : [p] "v"(p)
+    : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "scc", "memory");
+  out[t] = res;
   if ((threadIdx.x & 63) == 0) { st[(size_t)(t >> 6) * 2] = t1 - t0; st[(size_t)(t >> 6) * 2 + 1] = r1 - r0; }
 }
 
@@ -93,7 +444,7 @@ static void run(const char* name, const char* data, K kern, int per_trip, const 
   std::sort(cyc.begin(), cyc.end());
   std::sort(clk.begin(), clk.end());
   const double flop = 131072.0 * iters * cus * wpc;
-  printf("%-26s %-7s %8.1f TFLOP/s   %6.2f cycles per instruction and wave (median)   in-kernel clock %.3f GHz (median; min %.3f max %.3f)   %.1f ms\n", name, data,
+  printf("%-30s %-7s %8.1f TFLOP/s   %6.2f cycles per instruction and wave (median)   in-kernel clock %.3f GHz (median; min %.3f max %.3f)   %.1f ms\n", name, data,
          flop / (best * 1e-3) * 1e-12, cyc[cyc.size() / 2], clk[clk.size() / 2], clk.front(), clk.back(), best);
 }
 
@@ -119,7 +470,9 @@ int main() {
   printf("one wave per SIMD (4 per CU, 256 workgroups), operands in VGPRs, accumulators in AGPRs, 131072 FLOP per wave and trip, 4000000 trips\n");
   for (int rep = 0; rep < 2; ++rep) {
     run("v_mfma_f32_16x16x32_bf16", "random", k16, 8, dr, out, st, nwaves);
+    run("v_mfma_f32_16x16x32_bf16 b1", "random", k16_b1, 8, dr, out, st, nwaves);
     run("v_mfma_f32_32x32x16_bf16", "random", k32, 4, dr, out, st, nwaves);
+    run("v_mfma_f32_32x32x16_bf16 b1", "random", k32_b1, 4, dr, out, st, nwaves);
     run("v_mfma_f32_16x16x32_bf16", "zeros", k16, 8, dz, out, st, nwaves);
     run("v_mfma_f32_32x32x16_bf16", "zeros", k32, 4, dz, out, st, nwaves);
   }
