@@ -21,13 +21,14 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-// 8 x 16x16x32 per trip = 4 x 32x32x16 per trip = 131072 FLOP per wave and trip.  The timed loop is ONE asm block with explicit registers (a first
-// version left the loop to hipcc, which parked operands in AGPRs and copied them back every trip: 22 cycles per 16x16x32): operands v[64:127] loaded
-// once, accumulators a[0:31] / a[0:63]; `_b1`: one weight-side operand for all MFMAs of a trip (the dconv loop reuses it MFR times), else one per MFMA.
+// 8 x 16x16x32 = 4 x 32x32x16 = 131072 FLOP per wave and body; a trip of the timed loop is EIGHT bodies (64 / 32 MFMAs: with one body per trip the
+// loop branch costs 36 / 20 cycles per trip, 20.5 / 37 cycles per instruction).  The timed loop is ONE asm block with explicit registers (a first
+// version left the loop to hipcc, which parked operands in AGPRs and copied them back every trip): operands v[64:127] loaded once, accumulators
+// a[0:31] / a[0:63]; `b1`: one weight-side operand for all MFMAs (the dconv loop reuses it MFR times), else one per MFMA.
 __global__ void k16(int iters, const i32x4* __restrict__ src, float* out, unsigned long long* st) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const i32x4* p = src + (size_t)t * 16;
-  unsigned long long t0, t1, r0, r1; float res; int n = iters;
+  unsigned long long t0, t1, r0, r1; float res; int n = iters / 8;
   asm volatile(
     "global_load_dwordx4 v[64:67], %[p], off offset:0\n"
     "global_load_dwordx4 v[68:71], %[p], off offset:16\n"
@@ -91,6 +92,62 @@ __global__ void k16(int iters, const i32x4* __restrict__ src, float* out, unsign
     "v_mfma_f32_16x16x32_bf16 a[20:23], v[116:119], v[84:87], a[20:23]\n"
     "v_mfma_f32_16x16x32_bf16 a[24:27], v[120:123], v[88:91], a[24:27]\n"
     "v_mfma_f32_16x16x32_bf16 a[28:31], v[124:127], v[92:95], a[28:31]\n"
+    "v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[64:67], a[0:3]\n"
+    "v_mfma_f32_16x16x32_bf16 a[4:7], v[100:103], v[68:71], a[4:7]\n"
+    "v_mfma_f32_16x16x32_bf16 a[8:11], v[104:107], v[72:75], a[8:11]\n"
+    "v_mfma_f32_16x16x32_bf16 a[12:15], v[108:111], v[76:79], a[12:15]\n"
+    "v_mfma_f32_16x16x32_bf16 a[16:19], v[112:115], v[80:83], a[16:19]\n"
+    "v_mfma_f32_16x16x32_bf16 a[20:23], v[116:119], v[84:87], a[20:23]\n"
+    "v_mfma_f32_16x16x32_bf16 a[24:27], v[120:123], v[88:91], a[24:27]\n"
+    "v_mfma_f32_16x16x32_bf16 a[28:31], v[124:127], v[92:95], a[28:31]\n"
+    "v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[64:67], a[0:3]\n"
+    "v_mfma_f32_16x16x32_bf16 a[4:7], v[100:103], v[68:71], a[4:7]\n"
+    "v_mfma_f32_16x16x32_bf16 a[8:11], v[104:107], v[72:75], a[8:11]\n"
+    "v_mfma_f32_16x16x32_bf16 a[12:15], v[108:111], v[76:79], a[12:15]\n"
+    "v_mfma_f32_16x16x32_bf16 a[16:19], v[112:115], v[80:83], a[16:19]\n"
+    "v_mfma_f32_16x16x32_bf16 a[20:23], v[116:119], v[84:87], a[20:23]\n"
+    "v_mfma_f32_16x16x32_bf16 a[24:27], v[120:123], v[88:91], a[24:27]\n"
+    "v_mfma_f32_16x16x32_bf16 a[28:31], v[124:127], v[92:95], a[28:31]\n"
+    "v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[64:67], a[0:3]\n"
+    "v_mfma_f32_16x16x32_bf16 a[4:7], v[100:103], v[68:71], a[4:7]\n"
+    "v_mfma_f32_16x16x32_bf16 a[8:11], v[104:107], v[72:75], a[8:11]\n"
+    "v_mfma_f32_16x16x32_bf16 a[12:15], v[108:111], v[76:79], a[12:15]\n"
+    "v_mfma_f32_16x16x32_bf16 a[16:19], v[112:115], v[80:83], a[16:19]\n"
+    "v_mfma_f32_16x16x32_bf16 a[20:23], v[116:119], v[84:87], a[20:23]\n"
+    "v_mfma_f32_16x16x32_bf16 a[24:27], v[120:123], v[88:91], a[24:27]\n"
+    "v_mfma_f32_16x16x32_bf16 a[28:31], v[124:127], v[92:95], a[28:31]\n"
+    "v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[64:67], a[0:3]\n"
+    "v_mfma_f32_16x16x32_bf16 a[4:7], v[100:103], v[68:71], a[4:7]\n"
+    "v_mfma_f32_16x16x32_bf16 a[8:11], v[104:107], v[72:75], a[8:11]\n"
+    "v_mfma_f32_16x16x32_bf16 a[12:15], v[108:111], v[76:79], a[12:15]\n"
+    "v_mfma_f32_16x16x32_bf16 a[16:19], v[112:115], v[80:83], a[16:19]\n"
+    "v_mfma_f32_16x16x32_bf16 a[20:23], v[116:119], v[84:87], a[20:23]\n"
+    "v_mfma_f32_16x16x32_bf16 a[24:27], v[120:123], v[88:91], a[24:27]\n"
+    "v_mfma_f32_16x16x32_bf16 a[28:31], v[124:127], v[92:95], a[28:31]\n"
+    "v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[64:67], a[0:3]\n"
+    "v_mfma_f32_16x16x32_bf16 a[4:7], v[100:103], v[68:71], a[4:7]\n"
+    "v_mfma_f32_16x16x32_bf16 a[8:11], v[104:107], v[72:75], a[8:11]\n"
+    "v_mfma_f32_16x16x32_bf16 a[12:15], v[108:111], v[76:79], a[12:15]\n"
+    "v_mfma_f32_16x16x32_bf16 a[16:19], v[112:115], v[80:83], a[16:19]\n"
+    "v_mfma_f32_16x16x32_bf16 a[20:23], v[116:119], v[84:87], a[20:23]\n"
+    "v_mfma_f32_16x16x32_bf16 a[24:27], v[120:123], v[88:91], a[24:27]\n"
+    "v_mfma_f32_16x16x32_bf16 a[28:31], v[124:127], v[92:95], a[28:31]\n"
+    "v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[64:67], a[0:3]\n"
+    "v_mfma_f32_16x16x32_bf16 a[4:7], v[100:103], v[68:71], a[4:7]\n"
+    "v_mfma_f32_16x16x32_bf16 a[8:11], v[104:107], v[72:75], a[8:11]\n"
+    "v_mfma_f32_16x16x32_bf16 a[12:15], v[108:111], v[76:79], a[12:15]\n"
+    "v_mfma_f32_16x16x32_bf16 a[16:19], v[112:115], v[80:83], a[16:19]\n"
+    "v_mfma_f32_16x16x32_bf16 a[20:23], v[116:119], v[84:87], a[20:23]\n"
+    "v_mfma_f32_16x16x32_bf16 a[24:27], v[120:123], v[88:91], a[24:27]\n"
+    "v_mfma_f32_16x16x32_bf16 a[28:31], v[124:127], v[92:95], a[28:31]\n"
+    "v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[64:67], a[0:3]\n"
+    "v_mfma_f32_16x16x32_bf16 a[4:7], v[100:103], v[68:71], a[4:7]\n"
+    "v_mfma_f32_16x16x32_bf16 a[8:11], v[104:107], v[72:75], a[8:11]\n"
+    "v_mfma_f32_16x16x32_bf16 a[12:15], v[108:111], v[76:79], a[12:15]\n"
+    "v_mfma_f32_16x16x32_bf16 a[16:19], v[112:115], v[80:83], a[16:19]\n"
+    "v_mfma_f32_16x16x32_bf16 a[20:23], v[116:119], v[84:87], a[20:23]\n"
+    "v_mfma_f32_16x16x32_bf16 a[24:27], v[120:123], v[88:91], a[24:27]\n"
+    "v_mfma_f32_16x16x32_bf16 a[28:31], v[124:127], v[92:95], a[28:31]\n"
     "s_sub_u32 %[n], %[n], 1\n"
     "s_cmp_lg_u32 %[n], 0\n"
     "s_cbranch_scc1 1b\n"
@@ -110,7 +167,7 @@ __global__ void k16(int iters, const i32x4* __restrict__ src, float* out, unsign
 __global__ void k16_b1(int iters, const i32x4* __restrict__ src, float* out, unsigned long long* st) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const i32x4* p = src + (size_t)t * 16;
-  unsigned long long t0, t1, r0, r1; float res; int n = iters;
+  unsigned long long t0, t1, r0, r1; float res; int n = iters / 8;
   asm volatile(
     "global_load_dwordx4 v[64:67], %[p], off offset:0\n"
     "global_load_dwordx4 v[68:71], %[p], off offset:16\n"
@@ -174,6 +231,62 @@ __global__ void k16_b1(int iters, const i32x4* __restrict__ src, float* out, uns
     "v_mfma_f32_16x16x32_bf16 a[20:23], v[96:99], v[84:87], a[20:23]\n"
     "v_mfma_f32_16x16x32_bf16 a[24:27], v[96:99], v[88:91], a[24:27]\n"
     "v_mfma_f32_16x16x32_bf16 a[28:31], v[96:99], v[92:95], a[28:31]\n"
+    "v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[64:67], a[0:3]\n"
+    "v_mfma_f32_16x16x32_bf16 a[4:7], v[96:99], v[68:71], a[4:7]\n"
+    "v_mfma_f32_16x16x32_bf16 a[8:11], v[96:99], v[72:75], a[8:11]\n"
+    "v_mfma_f32_16x16x32_bf16 a[12:15], v[96:99], v[76:79], a[12:15]\n"
+    "v_mfma_f32_16x16x32_bf16 a[16:19], v[96:99], v[80:83], a[16:19]\n"
+    "v_mfma_f32_16x16x32_bf16 a[20:23], v[96:99], v[84:87], a[20:23]\n"
+    "v_mfma_f32_16x16x32_bf16 a[24:27], v[96:99], v[88:91], a[24:27]\n"
+    "v_mfma_f32_16x16x32_bf16 a[28:31], v[96:99], v[92:95], a[28:31]\n"
+    "v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[64:67], a[0:3]\n"
+    "v_mfma_f32_16x16x32_bf16 a[4:7], v[96:99], v[68:71], a[4:7]\n"
+    "v_mfma_f32_16x16x32_bf16 a[8:11], v[96:99], v[72:75], a[8:11]\n"
+    "v_mfma_f32_16x16x32_bf16 a[12:15], v[96:99], v[76:79], a[12:15]\n"
+    "v_mfma_f32_16x16x32_bf16 a[16:19], v[96:99], v[80:83], a[16:19]\n"
+    "v_mfma_f32_16x16x32_bf16 a[20:23], v[96:99], v[84:87], a[20:23]\n"
+    "v_mfma_f32_16x16x32_bf16 a[24:27], v[96:99], v[88:91], a[24:27]\n"
+    "v_mfma_f32_16x16x32_bf16 a[28:31], v[96:99], v[92:95], a[28:31]\n"
+    "v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[64:67], a[0:3]\n"
+    "v_mfma_f32_16x16x32_bf16 a[4:7], v[96:99], v[68:71], a[4:7]\n"
+    "v_mfma_f32_16x16x32_bf16 a[8:11], v[96:99], v[72:75], a[8:11]\n"
+    "v_mfma_f32_16x16x32_bf16 a[12:15], v[96:99], v[76:79], a[12:15]\n"
+    "v_mfma_f32_16x16x32_bf16 a[16:19], v[96:99], v[80:83], a[16:19]\n"
+    "v_mfma_f32_16x16x32_bf16 a[20:23], v[96:99], v[84:87], a[20:23]\n"
+    "v_mfma_f32_16x16x32_bf16 a[24:27], v[96:99], v[88:91], a[24:27]\n"
+    "v_mfma_f32_16x16x32_bf16 a[28:31], v[96:99], v[92:95], a[28:31]\n"
+    "v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[64:67], a[0:3]\n"
+    "v_mfma_f32_16x16x32_bf16 a[4:7], v[96:99], v[68:71], a[4:7]\n"
+    "v_mfma_f32_16x16x32_bf16 a[8:11], v[96:99], v[72:75], a[8:11]\n"
+    "v_mfma_f32_16x16x32_bf16 a[12:15], v[96:99], v[76:79], a[12:15]\n"
+    "v_mfma_f32_16x16x32_bf16 a[16:19], v[96:99], v[80:83], a[16:19]\n"
+    "v_mfma_f32_16x16x32_bf16 a[20:23], v[96:99], v[84:87], a[20:23]\n"
+    "v_mfma_f32_16x16x32_bf16 a[24:27], v[96:99], v[88:91], a[24:27]\n"
+    "v_mfma_f32_16x16x32_bf16 a[28:31], v[96:99], v[92:95], a[28:31]\n"
+    "v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[64:67], a[0:3]\n"
+    "v_mfma_f32_16x16x32_bf16 a[4:7], v[96:99], v[68:71], a[4:7]\n"
+    "v_mfma_f32_16x16x32_bf16 a[8:11], v[96:99], v[72:75], a[8:11]\n"
+    "v_mfma_f32_16x16x32_bf16 a[12:15], v[96:99], v[76:79], a[12:15]\n"
+    "v_mfma_f32_16x16x32_bf16 a[16:19], v[96:99], v[80:83], a[16:19]\n"
+    "v_mfma_f32_16x16x32_bf16 a[20:23], v[96:99], v[84:87], a[20:23]\n"
+    "v_mfma_f32_16x16x32_bf16 a[24:27], v[96:99], v[88:91], a[24:27]\n"
+    "v_mfma_f32_16x16x32_bf16 a[28:31], v[96:99], v[92:95], a[28:31]\n"
+    "v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[64:67], a[0:3]\n"
+    "v_mfma_f32_16x16x32_bf16 a[4:7], v[96:99], v[68:71], a[4:7]\n"
+    "v_mfma_f32_16x16x32_bf16 a[8:11], v[96:99], v[72:75], a[8:11]\n"
+    "v_mfma_f32_16x16x32_bf16 a[12:15], v[96:99], v[76:79], a[12:15]\n"
+    "v_mfma_f32_16x16x32_bf16 a[16:19], v[96:99], v[80:83], a[16:19]\n"
+    "v_mfma_f32_16x16x32_bf16 a[20:23], v[96:99], v[84:87], a[20:23]\n"
+    "v_mfma_f32_16x16x32_bf16 a[24:27], v[96:99], v[88:91], a[24:27]\n"
+    "v_mfma_f32_16x16x32_bf16 a[28:31], v[96:99], v[92:95], a[28:31]\n"
+    "v_mfma_f32_16x16x32_bf16 a[0:3], v[96:99], v[64:67], a[0:3]\n"
+    "v_mfma_f32_16x16x32_bf16 a[4:7], v[96:99], v[68:71], a[4:7]\n"
+    "v_mfma_f32_16x16x32_bf16 a[8:11], v[96:99], v[72:75], a[8:11]\n"
+    "v_mfma_f32_16x16x32_bf16 a[12:15], v[96:99], v[76:79], a[12:15]\n"
+    "v_mfma_f32_16x16x32_bf16 a[16:19], v[96:99], v[80:83], a[16:19]\n"
+    "v_mfma_f32_16x16x32_bf16 a[20:23], v[96:99], v[84:87], a[20:23]\n"
+    "v_mfma_f32_16x16x32_bf16 a[24:27], v[96:99], v[88:91], a[24:27]\n"
+    "v_mfma_f32_16x16x32_bf16 a[28:31], v[96:99], v[92:95], a[28:31]\n"
     "s_sub_u32 %[n], %[n], 1\n"
     "s_cmp_lg_u32 %[n], 0\n"
     "s_cbranch_scc1 1b\n"
@@ -193,7 +306,7 @@ __global__ void k16_b1(int iters, const i32x4* __restrict__ src, float* out, uns
 __global__ void k32(int iters, const i32x4* __restrict__ src, float* out, unsigned long long* st) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const i32x4* p = src + (size_t)t * 16;
-  unsigned long long t0, t1, r0, r1; float res; int n = iters;
+  unsigned long long t0, t1, r0, r1; float res; int n = iters / 8;
   asm volatile(
     "global_load_dwordx4 v[64:67], %[p], off offset:0\n"
     "global_load_dwordx4 v[68:71], %[p], off offset:16\n"
@@ -285,6 +398,34 @@ __global__ void k32(int iters, const i32x4* __restrict__ src, float* out, unsign
     "v_mfma_f32_32x32x16_bf16 a[16:31], v[100:103], v[68:71], a[16:31]\n"
     "v_mfma_f32_32x32x16_bf16 a[32:47], v[104:107], v[72:75], a[32:47]\n"
     "v_mfma_f32_32x32x16_bf16 a[48:63], v[108:111], v[76:79], a[48:63]\n"
+    "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
+    "v_mfma_f32_32x32x16_bf16 a[16:31], v[100:103], v[68:71], a[16:31]\n"
+    "v_mfma_f32_32x32x16_bf16 a[32:47], v[104:107], v[72:75], a[32:47]\n"
+    "v_mfma_f32_32x32x16_bf16 a[48:63], v[108:111], v[76:79], a[48:63]\n"
+    "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
+    "v_mfma_f32_32x32x16_bf16 a[16:31], v[100:103], v[68:71], a[16:31]\n"
+    "v_mfma_f32_32x32x16_bf16 a[32:47], v[104:107], v[72:75], a[32:47]\n"
+    "v_mfma_f32_32x32x16_bf16 a[48:63], v[108:111], v[76:79], a[48:63]\n"
+    "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
+    "v_mfma_f32_32x32x16_bf16 a[16:31], v[100:103], v[68:71], a[16:31]\n"
+    "v_mfma_f32_32x32x16_bf16 a[32:47], v[104:107], v[72:75], a[32:47]\n"
+    "v_mfma_f32_32x32x16_bf16 a[48:63], v[108:111], v[76:79], a[48:63]\n"
+    "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
+    "v_mfma_f32_32x32x16_bf16 a[16:31], v[100:103], v[68:71], a[16:31]\n"
+    "v_mfma_f32_32x32x16_bf16 a[32:47], v[104:107], v[72:75], a[32:47]\n"
+    "v_mfma_f32_32x32x16_bf16 a[48:63], v[108:111], v[76:79], a[48:63]\n"
+    "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
+    "v_mfma_f32_32x32x16_bf16 a[16:31], v[100:103], v[68:71], a[16:31]\n"
+    "v_mfma_f32_32x32x16_bf16 a[32:47], v[104:107], v[72:75], a[32:47]\n"
+    "v_mfma_f32_32x32x16_bf16 a[48:63], v[108:111], v[76:79], a[48:63]\n"
+    "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
+    "v_mfma_f32_32x32x16_bf16 a[16:31], v[100:103], v[68:71], a[16:31]\n"
+    "v_mfma_f32_32x32x16_bf16 a[32:47], v[104:107], v[72:75], a[32:47]\n"
+    "v_mfma_f32_32x32x16_bf16 a[48:63], v[108:111], v[76:79], a[48:63]\n"
+    "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
+    "v_mfma_f32_32x32x16_bf16 a[16:31], v[100:103], v[68:71], a[16:31]\n"
+    "v_mfma_f32_32x32x16_bf16 a[32:47], v[104:107], v[72:75], a[32:47]\n"
+    "v_mfma_f32_32x32x16_bf16 a[48:63], v[108:111], v[76:79], a[48:63]\n"
     "s_sub_u32 %[n], %[n], 1\n"
     "s_cmp_lg_u32 %[n], 0\n"
     "s_cbranch_scc1 1b\n"
@@ -304,7 +445,7 @@ __global__ void k32(int iters, const i32x4* __restrict__ src, float* out, unsign
 __global__ void k32_b1(int iters, const i32x4* __restrict__ src, float* out, unsigned long long* st) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const i32x4* p = src + (size_t)t * 16;
-  unsigned long long t0, t1, r0, r1; float res; int n = iters;
+  unsigned long long t0, t1, r0, r1; float res; int n = iters / 8;
   asm volatile(
     "global_load_dwordx4 v[64:67], %[p], off offset:0\n"
     "global_load_dwordx4 v[68:71], %[p], off offset:16\n"
@@ -392,6 +533,34 @@ __global__ void k32_b1(int iters, const i32x4* __restrict__ src, float* out, uns
     "s_memrealtime %[r0]\n"
     "s_waitcnt lgkmcnt(0)\n"
     "1:\n"
+    "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
+    "v_mfma_f32_32x32x16_bf16 a[16:31], v[96:99], v[68:71], a[16:31]\n"
+    "v_mfma_f32_32x32x16_bf16 a[32:47], v[96:99], v[72:75], a[32:47]\n"
+    "v_mfma_f32_32x32x16_bf16 a[48:63], v[96:99], v[76:79], a[48:63]\n"
+    "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
+    "v_mfma_f32_32x32x16_bf16 a[16:31], v[96:99], v[68:71], a[16:31]\n"
+    "v_mfma_f32_32x32x16_bf16 a[32:47], v[96:99], v[72:75], a[32:47]\n"
+    "v_mfma_f32_32x32x16_bf16 a[48:63], v[96:99], v[76:79], a[48:63]\n"
+    "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
+    "v_mfma_f32_32x32x16_bf16 a[16:31], v[96:99], v[68:71], a[16:31]\n"
+    "v_mfma_f32_32x32x16_bf16 a[32:47], v[96:99], v[72:75], a[32:47]\n"
+    "v_mfma_f32_32x32x16_bf16 a[48:63], v[96:99], v[76:79], a[48:63]\n"
+    "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
+    "v_mfma_f32_32x32x16_bf16 a[16:31], v[96:99], v[68:71], a[16:31]\n"
+    "v_mfma_f32_32x32x16_bf16 a[32:47], v[96:99], v[72:75], a[32:47]\n"
+    "v_mfma_f32_32x32x16_bf16 a[48:63], v[96:99], v[76:79], a[48:63]\n"
+    "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
+    "v_mfma_f32_32x32x16_bf16 a[16:31], v[96:99], v[68:71], a[16:31]\n"
+    "v_mfma_f32_32x32x16_bf16 a[32:47], v[96:99], v[72:75], a[32:47]\n"
+    "v_mfma_f32_32x32x16_bf16 a[48:63], v[96:99], v[76:79], a[48:63]\n"
+    "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
+    "v_mfma_f32_32x32x16_bf16 a[16:31], v[96:99], v[68:71], a[16:31]\n"
+    "v_mfma_f32_32x32x16_bf16 a[32:47], v[96:99], v[72:75], a[32:47]\n"
+    "v_mfma_f32_32x32x16_bf16 a[48:63], v[96:99], v[76:79], a[48:63]\n"
+    "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
+    "v_mfma_f32_32x32x16_bf16 a[16:31], v[96:99], v[68:71], a[16:31]\n"
+    "v_mfma_f32_32x32x16_bf16 a[32:47], v[96:99], v[72:75], a[32:47]\n"
+    "v_mfma_f32_32x32x16_bf16 a[48:63], v[96:99], v[76:79], a[48:63]\n"
     "v_mfma_f32_32x32x16_bf16 a[0:15], v[96:99], v[64:67], a[0:15]\n"
     "v_mfma_f32_32x32x16_bf16 a[16:31], v[96:99], v[68:71], a[16:31]\n"
     "v_mfma_f32_32x32x16_bf16 a[32:47], v[96:99], v[72:75], a[32:47]\n"
