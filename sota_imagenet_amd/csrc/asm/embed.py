@@ -52,7 +52,7 @@ def main():
     with open(os.path.join(out_dir, "po_meta.inc"), "w") as f:
         for name in po_gen.VARIANTS:
             c, g, _ = po_gen.generate(name)
-            f.write('{"%s", %d, %d, %d, %d, %d, %d, %d, %d},\n' % (name, c.K, c.BN, c.stats, c.add, c.TP, c.WM, g.lds_bytes, po_gen.Gen.KA["size"]))
+            f.write('{"%s", %d, %d, %d, %d, %d, %d, %d, %d, %d},\n' % (name, c.K, c.BN, c.stats, c.add, c.TP, c.WM, c.bnin, g.lds_bytes, po_gen.Gen.KA["size"]))
 
 
 if __name__ == "__main__":

@@ -55,6 +55,11 @@ class PoCfg:
     weave: int = 1    # 1: two accumulator sets, the MFMAs of tile t + 1 issued between the epilogue instructions of tile t
     nt: int = 0       # non-temporal cache policy: 1 epilogue operand loads, 2 output stores, 4 A pieces
     probe: int = 0    # timing probes (WRONG results): 1 no MFMAs, 2 no epilogue arithmetic, 4 no operand loads, 8 no stores
+    bnin: int = 0     # 1: the input is the RAW output y of the previous convolution: a = relu(y * scale[c] + shift[c]) rounded to bf16 (bn_apply_kernel's
+                      # value) is formed in LDS — every wave transforms the pieces its own LDS-DMA lanes wrote, between their landing and the tile's
+                      # barrier — and the workgroups of column tile 0 leave a and its ReLU bits in memory (conv3's forward: bn2 + ReLU in the operand
+                      # path; these launches are HBM-bound, the transform's ~40 VALU instructions per KiB hide under the memory time).  Pixel counts that
+                      # are a multiple of the tile only (a ragged tile's missing pixels would become relu(shift), not zero)
 
     @property
     def WN(self):     # waves along the output columns
@@ -148,6 +153,7 @@ class Gen:
         assert c.WM == 1 or (not c.FULL and (not c.NMT or c.MFRW == 4)), "2 x 2 waves: half-line stores; the tile-wide mask load is one lane per pixel of the wave's 64"
         assert (c.L + 1) * c.NI + c.NPW + c.NMT <= 63, "vmcnt range"
         assert c.LDS <= 160 * 1024
+        assert not c.bnin or (c.stats == 1 and c.add == 0 and c.WM == 1 and c.weave and c.NBUF == 2)
         self.s_wg = 2
         self.srdA, self.srdB, self.srdO, self.srdX = S.get(4, 4), S.get(4, 4), S.get(4, 4), S.get(4, 4)
         self.srdY = self.srdM = self.srdAD = self.srdAB = None
@@ -162,6 +168,9 @@ class Gen:
         (self.s_w, self.s_t0, self.s_t1, self.s_t2, self.s_t3, self.s_cnt, self.s_pf, self.s_tout, self.s_tbits, self.s_g, self.s_ct, self.s_ldsA, self.s_n4,
          self.s_ia, self.s_io, self.s_ib, self.s_8rows, self.s_pfa) = [S.get() for _ in range(18)]
         self.s_lo8 = S.get(2, 2)   # lanes 0 .. 7 of every row of 16
+        if c.bnin:
+            self.srdA2, self.srdBt, self.srdSS = S.get(4, 4), S.get(4, 4), S.get(4, 4)   # a out, its ReLU bits out (the A descriptor's offsets / 16), [2][K] scale / shift
+            self.s_trleft, self.s_trflag, self.s_k1, self.s_ta, self.s_tinc, self.s_tincb = [S.get() for _ in range(6)]
         self.s_wn, self.s_wm = (S.get(), S.get()) if c.WM > 1 else (self.s_w, None)   # this wave's column / pixel part
         self.vA_rd = [[V.get() for kk in range(2)] for b in range(c.NBUF)]
         self.vA_dma = V.get()
@@ -207,6 +216,12 @@ class Gen:
         self.xr = V.get(8, 2)
         self.yv = V.get(2, 2)
         self.v_m = V.get()
+        if c.bnin:
+            self.v_lane16 = V.get()
+            self.v_ssoff = V.get()
+            self.v_sc = [V.get(8, 4) for _ in range(c.NPL)]   # this lane's 8 channels of every 64-channel plane
+            self.v_sh = [V.get(8, 4) for _ in range(c.NPL)]
+            self.tr = [dict(ta=V.get(), d=V.get(4, 4), f=V.get(8, 4), bits=V.get(), o=V.get(), o2=V.get()) for _ in range(2)]
         self.nvgpr = V.n
         self.accum_offset = (self.nvgpr + 7) // 8 * 8
         self.aB = 0
@@ -403,6 +418,23 @@ class Gen:
         e("s_mul_hi_u32 %s, %s, %d" % (R("s", t1), R("s", S_first), tin))
         e("s_mul_i32 %s, %s, %d" % (R("s", t2), R("s", M), c.K * 2))
         self.desc_from(self.srdA, ka + 0, t0, t1, t2, "A: this run's pixels")
+        if c.bnin:
+            self.desc_from(self.srdA2, ka + 8, t0, t1, t2, "a out: the same pixels of the other tensor")
+            # its ReLU bits: 1 byte per 16 bytes
+            e("s_lshr_b32 %s, %s, 4" % (R("s", t0), R("s", t0)))
+            e("s_lshl_b32 %s, %s, 28" % (R("s", t3), R("s", t1)))
+            e("s_or_b32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", t3)))
+            e("s_lshr_b32 %s, %s, 4" % (R("s", t1), R("s", t1)))
+            e("s_lshr_b32 %s, %s, 4" % (R("s", t2), R("s", t2)))
+            self.desc_from(self.srdBt, ka + 10, t0, t1, t2, "its ReLU bits")
+            e("s_mov_b32 %s, %s" % (R("s", self.srdSS), R("s", ka + 12)))
+            e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdSS + 1), R("s", ka + 13)))
+            e("s_mov_b32 %s, %d" % (R("s", self.srdSS + 2), 2 * c.K * 4))
+            e("s_mov_b32 %s, 0x00020000" % R("s", self.srdSS + 3))
+            e("s_mov_b32 %s, 0x00010001" % R("s", self.s_k1))
+            # only the workgroups of column tile 0 store a and its bits (every column tile transforms its own LDS copy)
+            e("s_cmp_eq_u32 %s, 0" % R("s", self.s_ct))
+            e("s_cselect_b32 %s, 0, 0x80000000" % R("s", self.s_trflag))
         # ---- B: this wave's NT*16 weight rows
         e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_ct), c.BN * c.K * 2))
         e("s_mul_i32 %s, %s, %d" % (R("s", t1), R("s", self.s_wn), c.NT * 16 * c.K * 2))
@@ -439,10 +471,18 @@ class Gen:
         e("v_or_b32 %s, %s, %s" % (R("v", j), R("s", t0), R("v", j)))
         e("v_xor_b32 %s, %s, %s" % (R("v", j), R("v", l7), R("v", j)))
         e("v_lshlrev_b32 %s, 4, %s" % (R("v", j), R("v", j)))
+        if c.bnin:
+            e("v_lshlrev_b32 %s, 1, %s" % (R("v", self.v_ssoff), R("v", j)), "this lane's 16 bytes of a pixel's plane = 8 channels = 32 bytes of scale / shift")
+            e("v_lshlrev_b32 %s, 4, %s" % (R("v", self.v_lane16), R("v", lane)))
         e("v_mov_b32 %s, %d" % (R("v", v[9]), c.K * 2))
         e("v_mad_u32_u24 %s, %s, %s, %s" % (R("v", self.vA_dma), R("v", l3), R("v", v[9]), R("v", j)))
         e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_w), 8 * c.K * 2))
         e("v_add_u32 %s, %s, %s" % (R("v", self.vA_dma), R("s", t0), R("v", self.vA_dma)))
+        if c.bnin:
+            for pl in range(c.NPL):
+                for h in range(2):
+                    e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", self.v_sc[pl] + 4 * h, 4), R("v", self.v_ssoff), R("s", self.srdSS, 4), pl * 256 + 16 * h))
+                    e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (R("v", self.v_sh[pl] + 4 * h, 4), R("v", self.v_ssoff), R("s", self.srdSS, 4), c.K * 4 + pl * 256 + 16 * h))
         self.comment("A tile of the first tile")
         for jj in range(c.NPW):
             for ins in self.a_piece(jj, 0):
@@ -555,6 +595,74 @@ class Gen:
                     e("v_mov_b32 %s, 0" % R("v", self.s2[p] + i))
         e("s_waitcnt vmcnt(0)", "weights, first tile, first operands")
 
+    # ---- Cfg.bnin: BatchNorm + ReLU of a landed tile in LDS ----------------------------------------------------------------------------------------------
+    def tr_read(self, j, buf, i):
+        c, r = self.c, self.tr[i]
+        rb4 = c.TP // 8 // 4
+        blk4, plane = j % rb4, j // rb4
+        return ["s_add_u32 %s, %s, %d" % (R("s", self.s_ta), R("s", self.s_ldsA), buf * c.ABUF + plane * c.PLANE + blk4 * 4096),
+                "v_add_u32 %s, %s, %s" % (R("v", r["ta"]), R("s", self.s_ta), R("v", self.v_lane16)),
+                "ds_read_b128 %s, %s" % (R("v", r["d"], 4), R("v", r["ta"]))]
+
+    def tr_work(self, j, i):
+        """a = relu(y * scale + shift) of piece j (the 16 bytes this lane's LDS-DMA lane wrote) in register set i: back to LDS, to the `a` tensor at the
+        LDS-DMA's own offset and one byte of ReLU bits at that offset / 16 (out of range, hence dropped, unless this workgroup stores: s_trflag)"""
+        c, r = self.c, self.tr[i]
+        rb4 = c.TP // 8 // 4
+        blk4, plane = j % rb4, j // rb4
+        d, f, t = r["d"], r["f"], r["f"] + 4
+        sc, sh = self.v_sc[plane], self.v_sh[plane]
+        g = ["v_add_u32 %s, %d, %s" % (R("v", r["o"]), blk4 * 32 * c.K * 2 + plane * 128, R("v", self.vA_dma)),
+             "v_or_b32 %s, %s, %s" % (R("v", r["o"]), R("s", self.s_trflag), R("v", r["o"]))]
+        for q in range(4):
+            g += ["v_lshlrev_b32 %s, 16, %s" % (R("v", f + 2 * q), R("v", d + q)), "v_and_b32 %s, 0xffff0000, %s" % (R("v", f + 2 * q + 1), R("v", d + q))]
+        for q in range(8):
+            g.append("v_fma_f32 %s, %s, %s, %s" % (R("v", f + q), R("v", f + q), R("v", sc + q), R("v", sh + q)))
+        for q in range(4):   # round first, ReLU on the packed pairs as signed 16-bit integers: the values of ReLU in fp32 followed by the rounding
+            g.append("v_cvt_pk_bf16_f32 %s, %s, %s" % (R("v", f + q), R("v", f + 2 * q), R("v", f + 2 * q + 1)))
+        for q in range(4):
+            g.append("v_pk_max_i16 %s, %s, 0" % (R("v", f + q), R("v", f + q)))
+        for q in range(4):   # ReLU bits = (a != 0): 0 / 1 per half, gathered to bit 2q + half of one byte
+            g.append("v_pk_min_u16 %s, %s, %s" % (R("v", t + q), R("v", f + q), R("s", self.s_k1)))
+        g += ["v_lshl_or_b32 %s, %s, 2, %s" % (R("v", t), R("v", t + 1), R("v", t)), "v_lshl_or_b32 %s, %s, 2, %s" % (R("v", t + 2), R("v", t + 3), R("v", t + 2)),
+              "v_lshl_or_b32 %s, %s, 4, %s" % (R("v", t), R("v", t + 2), R("v", t)), "v_lshrrev_b32 %s, 4, %s" % (R("v", r["o2"]), R("v", r["o"])),
+              "v_lshrrev_b32 %s, 15, %s" % (R("v", t + 1), R("v", t)), "v_and_b32 %s, 0x55, %s" % (R("v", t), R("v", t)),
+              "v_and_b32 %s, 0xaa, %s" % (R("v", t + 1), R("v", t + 1)), "v_or_b32 %s, %s, %s" % (R("v", r["bits"]), R("v", t + 1), R("v", t)),
+              "ds_write_b128 %s, %s" % (R("v", r["ta"]), R("v", f, 4)),
+              "buffer_store_dwordx4 %s, %s, %s, 0 offen" % (R("v", f, 4), R("v", r["o"]), R("s", self.srdA2, 4)),
+              "buffer_store_byte %s, %s, %s, 0 offen" % (R("v", r["bits"]), R("v", r["o2"]), R("s", self.srdBt, 4))]
+        return g
+
+    def transform_tile(self, buf, first):
+        """this wave's NPW pieces of the tile in A buffer `buf` (they have landed: the caller waited for this wave's own LDS-DMA), the next piece's
+        read under the work on this one; then the a / bits descriptors move on to the next tile while one is left (else the stores are switched
+        off: the look-ahead tile behind the run's last one is a re-read that nobody uses)"""
+        c, e = self.c, self.e
+        if not first:
+            # a real tile?  (the stores of the workgroups of column tiles > 0 are off for good)
+            e("s_cmp_gt_u32 %s, 0" % R("s", self.s_trleft))
+            e("s_cselect_b32 %s, %s, 0x80000000" % (R("s", self.s_trflag), R("s", self.s_trflag)))
+        for ins in self.tr_read(0, buf, 0):
+            e(ins)
+        for j in range(c.NPW):
+            e("s_waitcnt lgkmcnt(%d)" % (1 if j else 0))
+            if j + 1 < c.NPW:
+                for ins in self.tr_read(j + 1, buf, (j + 1) & 1):
+                    e(ins)
+            for ins in self.tr_work(j, j & 1):
+                e(ins)
+        # descriptors one tile on (prologue: if the run has a second tile; loop: if another real tile follows this one)
+        e("s_cmp_gt_u32 %s, %d" % (R("s", self.s_trleft), 0 if first else 1))
+        e("s_cselect_b32 %s, %d, 0" % (R("s", self.s_tinc), c.TP * c.K * 2))
+        e("s_cselect_b32 %s, %d, 0" % (R("s", self.s_tincb), c.TP * c.K * 2 // 16))
+        for ins in self.desc_adv(self.srdA2, self.s_tinc) + self.desc_adv(self.srdBt, self.s_tincb):
+            e(ins)
+        if not first:
+            e("s_cmp_gt_u32 %s, 0" % R("s", self.s_trleft))
+            e("s_cselect_b32 %s, 1, 0" % R("s", self.s_t3))
+            e("s_sub_u32 %s, %s, %s" % (R("s", self.s_trleft), R("s", self.s_trleft), R("s", self.s_t3)))
+        e("s_waitcnt lgkmcnt(0)")
+
     def a_advance(self):
         """the A descriptor moves to the next tile while one is left, else stays (re-reads of the last tile, never used)"""
         c = self.c
@@ -663,6 +771,9 @@ class Gen:
         TOPW = c.NI * (c.L + 1) + c.NMT   # younger than a tile's A pieces at the top of the trip that needs them
         if c.weave:
             self.comment("---- first tile: its MFMAs alone (A buffer 0 -> accumulator set 0), the second tile requested")
+            if c.bnin:
+                e("s_sub_u32 %s, %s, 1" % (R("s", self.s_trleft), R("s", self.s_cnt)), "tiles behind the first")
+                self.transform_tile(0, True)
             e("s_barrier")
             for jj in range(c.NPW):
                 for ins in self.a_piece(jj, 1):
@@ -682,6 +793,8 @@ class Gen:
                 # at the top of the trip of tile t: tile t + 1 (requested a trip ago) has landed for every wave; buffer b (tile t: its MFMAs ran
                 # in the previous trip) takes tile t + 2
                 e("s_waitcnt vmcnt(%d)" % TOPW, "tile t + 1's A pieces have landed (younger: the last trip's stores and refills)")
+                if c.bnin:
+                    self.transform_tile(nb, False)
                 e("s_barrier")
                 for jj in range(c.NPW):
                     for ins in self.a_piece(jj, b):
@@ -966,6 +1079,9 @@ def _variants():
                 continue
             name = "po_k%d_b%d_s%d_a%d" % (K, BN, st, add)
             v[name] = PoCfg(name, K=K, BN=BN, stats=st, add=add, **(dict(WM=2, MFR=8) if BN == 64 else {}))
+    for K in (64, 128, 256):   # conv3's forward of layers 1 - 3 with bn2 + ReLU in its operand path
+        name = "po_k%d_b256_s1_a0_bn" % K
+        v[name] = PoCfg(name, K=K, BN=256, stats=1, add=0, bnin=1)
     return v
 
 

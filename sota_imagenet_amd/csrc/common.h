@@ -92,7 +92,7 @@ struct IgemmArgs {
   const uint8_t* bn_bits = nullptr;    // 1 byte per 16-byte vector of out
   const float* bn_mean = nullptr;      // [Ncols]
   const float* bn_invstd = nullptr;    // [Ncols]
-  // BatchNorm + ReLU of the INPUT in the operand path (generated stride-1 3x3 forward kernels only: dconv_bn_in_legal): `in` is the raw output y
+  // BatchNorm + ReLU of the INPUT in the operand path (generated stride-1 3x3 and resident-weight 1x1 forward kernels only: igemm_bn_in_legal): `in` is the raw output y
   // of the previous convolution, the kernel reads relu(y * scale[c] + shift[c]) rounded to the tensor dtype — bn_apply's value — and leaves that
   // tensor and its ReLU bits in memory as a by-product (the weight gradient and the BN backward read them as before)
   const float* bn_in = nullptr;        // [2][Ck]: scale, shift
@@ -126,7 +126,7 @@ struct WgradArgs {
 // stat_rows (optional): number of partial rows written to a.stat_partial, 0 if the statistics were not produced
 int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows = nullptr);
 bool igemm_sub2_legal(int dtype, const IgemmArgs& a, int nclass);
-bool dconv_bn_in_legal(int dtype, const IgemmArgs& a, int nclass);  // a launch with a.bn_in has a kernel (else: run bn_apply first)  // a launch with a.addend_sub2 has a kernel (else: materialise the addend)
+bool igemm_bn_in_legal(int dtype, const IgemmArgs& a, int nclass);  // a launch with a.bn_in has a kernel (else: run bn_apply first)  // a launch with a.addend_sub2 has a kernel (else: materialise the addend)
 static constexpr size_t IGEMM_SK_FLAG_BYTES = 4096;  // 512 flags + an error word, padded
 static constexpr int IGEMM_SK_ERR_WORD = 512;        // index of the error word in the flag block: nonzero = a stream-K
                                                      // hand-off timed out in some launch that used this scratch
@@ -157,7 +157,10 @@ struct Knobs {
   int po = 1;                // MI355_PO: the output-heavy pointwise kernels with resident weights (asm/po_gen.py); 1: the measured per-shape rule, 2: wherever a variant is legal
   int po64 = 1;              // MI355_PO64: the 64-column forms of po (layer 1's 1x1 launches into 64 channels): 0 leaves them on the implicit-GEMM kernel,
                              // 1: the measured per-shape rule, 2: wherever legal
-  int dconv_bn = 1;          // MI355_DCONV_BN: bn1 + ReLU in conv2's operand path (dconv_*_s1_bn: the executor's training forward skips that bn_apply launch)
+  int po_bn = 1;             // MI355_PO_BN: bn2 + ReLU in conv3's operand path (po_*_s1_a0_bn: HBM-bound launches, the transform hides under the memory time)
+  int dconv_bn = 0;          // MI355_DCONV_BN=1: bn1 + ReLU in conv2's operand path (dconv_*_s1_bn: the executor's training forward skips that bn_apply launch).
+                             // Off by default: measured break-even (profiles/r06_ab_bn_in_operand_path.txt: the transform's VALU work is not hidden in a
+                             // one-wave-per-SIMD MFMA-bound kernel: +8 .. +30 us per launch against 8 .. 37 us of bn_apply)
   int dconv_s2 = 1;          // MI355_DCONV_S2: the generated kernels of the stride-2 3x3 convolutions (dconv_*_d2: the data gradient by output-parity classes)
   char error[160] = {0};     // a switch with a value outside its domain: every conv launch fails with MI355_E_ARG and this text
 };

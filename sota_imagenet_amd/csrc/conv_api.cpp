@@ -106,6 +106,7 @@ static void load_knobs() {
   sw("MI355_PO64", &k.po64, 2);
   sw("MI355_DCONV_S2", &k.dconv_s2, 1);
   sw("MI355_DCONV_BN", &k.dconv_bn, 1);
+  sw("MI355_PO_BN", &k.po_bn, 1);
   if (k.has_igemm_big && k.igemm_big != 0 && k.igemm_big != 1 && k.igemm_big != 3 && !k.error[0])
     snprintf(k.error, sizeof(k.error), "MI355_IGEMM_BIG=%d: not one of 0, 1, 3", k.igemm_big);
   g_knobs = k;
@@ -331,7 +332,7 @@ int mi355_conv2d_fwd_bn_in(int dtype, const void* y_in, const float* scale_shift
   a.bn_in = scale_shift; a.bn_in_a = a_out; a.bn_in_bits = a_bits;
   a.stat_partial = partial;
   a.stat_rows_cap = (int)std::min<size_t>(partial_bytes / ((size_t)2 * Cout * sizeof(float)), 1u << 20);
-  MI355_ARG(dconv_bn_in_legal(dtype, a, 1), "conv2d_fwd_bn_in: no kernel applies the input's BatchNorm for this launch (bf16, 3x3 / stride 1 at a generated shape)");
+  MI355_ARG(igemm_bn_in_legal(dtype, a, 1), "conv2d_fwd_bn_in: no kernel applies the input's BatchNorm for this launch (bf16; 3x3 / stride 1 at a generated shape, or 1x1 with 64 / 128 / 256 input channels into a multiple of 256 columns over whole 64-pixel tiles)");
   return launch_igemm(dtype, a, 1, (hipStream_t)stream, nblk);
 }
 

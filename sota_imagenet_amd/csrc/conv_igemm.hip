@@ -894,7 +894,7 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
   static const int narrow_env = getenv("MI355_IGEMM_NARROW") ? atoi(getenv("MI355_IGEMM_NARROW")) : 0;  // A/B knob
   const bool wide = (a.Ncols % 128 == 0) && tiles128 * 2 >= device_cus() && !narrow_env;
   MI355_ARG(dtype == MI355_BF16 || !a.addend_sub2, "igemm: a half-resolution addend needs the generated pointwise kernel (igemm_sub2_legal)");
-  MI355_ARG(a.bn_in == nullptr || dconv_bn_in_legal(dtype, a, nclass), "igemm: the input's BatchNorm in the operand path needs a generated 3x3 kernel (dconv_bn_in_legal)");
+  MI355_ARG(a.bn_in == nullptr || igemm_bn_in_legal(dtype, a, nclass), "igemm: the input's BatchNorm in the operand path needs a generated kernel with that form (igemm_bn_in_legal)");
   if (dtype == MI355_F32)
     return wide ? launch_t<float, 128, 128>(a, nclass, stream, stat_rows) : launch_t<float, 128, 64>(a, nclass, stream, stat_rows);
   if (dtype == MI355_BF16) {

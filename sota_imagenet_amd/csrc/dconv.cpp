@@ -79,7 +79,7 @@ constexpr int NWG1 = (int)(sizeof(g_wg1) / sizeof(g_wg1[0]));
 // WM = 2 (the 64-column forms): the two waves that share columns leave a statistics row each -> 2 rows per workgroup
 struct PoVariant {
   const char* name;
-  int K, BN, stats, add, TP, WM, lds, kernarg;
+  int K, BN, stats, add, TP, WM, bnin, lds, kernarg;  // bnin: BatchNorm + ReLU of the input in the operand path (IgemmArgs::bn_in)
 };
 const PoVariant g_po[] = {
 #include "build/asm/po_meta.inc"
@@ -574,10 +574,13 @@ bool plan_po(const IgemmArgs& a, int nclass, PoPlan* pl) {
   if (a.addend_sub2 && (a.addend_bits != nullptr || a.Hout % 2 || a.Wout % 2)) return false;
   const long M = (long)a.N * a.Hin * a.Win;
   if (M * a.Ck * 2 >= (1L << 32) || M * a.Ncols * 2 >= (1L << 32)) return false;  // 32-bit num_records of the tile-by-tile descriptors
+  const int bnin = a.bn_in != nullptr ? 1 : 0;
+  if (bnin && (a.bn_in_a == nullptr || a.bn_in_bits == nullptr)) return false;
   if (a.addend_sub2 && (M + 64) * (a.Wout > a.Hout ? a.Wout : a.Hout) >= (1L << 32)) return false;  // exactness of the kernel's divisions
   for (int i = 0; i < NPO; ++i) {
     const PoVariant& v = g_po[i];
-    if (v.K != a.Ck || v.stats != stats || v.add != add || a.Ncols % v.BN != 0) continue;
+    if (v.K != a.Ck || v.stats != stats || v.add != add || a.Ncols % v.BN != 0 || v.bnin != bnin) continue;
+    if (v.bnin && M % v.TP != 0) continue;   // (a ragged tile's missing pixels would become relu(shift) instead of zero)
     const unsigned nct = (unsigned)(a.Ncols / v.BN);
     if ((nct & (nct - 1)) != 0 || nct > 32) continue;
     pl->vi = i;
@@ -603,6 +606,7 @@ bool po_legal(const IgemmArgs& a, int nclass) {
   PoPlan pl;
   if (!plan_po(a, nclass, &pl)) return false;
   if (a.stat_partial != nullptr && (int)pl.G * g_po[pl.vi].WM > (a.stat_rows_cap > 0 ? a.stat_rows_cap : 768)) return false;
+  if (g_po[pl.vi].bnin && !knobs().po_bn) return false;
   if (mode < 2) {
     // MI355_PO=1 (default): the measured rule, per launch shape of the bs-256 step in a serial trace (profiles/r05_ab_po_*.txt):
     //  - 64 -> 256 under the shortcut addend + BN-backward sums (layer 1's conv1 data gradient, 1.39 GB per launch): the implicit-GEMM
@@ -623,9 +627,13 @@ bool po_legal(const IgemmArgs& a, int nclass) {
   return module_ok();
 }
 
-bool dconv_bn_in_legal(int dtype, const IgemmArgs& a, int nclass) { return dtype == MI355_BF16 && a.bn_in != nullptr && dconv_legal(a, nclass); }
-
 bool igemm_sub2_legal(int dtype, const IgemmArgs& a, int nclass) { return dtype == MI355_BF16 && a.addend_sub2 && po_legal(a, nclass); }
+
+// a launch with the input's BatchNorm + ReLU in the operand path (IgemmArgs::bn_in) has a kernel: the direct 3x3 kernels (conv2 <- bn1) or the
+// resident-weight pointwise kernels (conv3 <- bn2)
+bool igemm_bn_in_legal(int dtype, const IgemmArgs& a, int nclass) {
+  return dtype == MI355_BF16 && a.bn_in != nullptr && (dconv_legal(a, nclass) || po_legal(a, nclass));
+}
 
 int launch_po(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
   PoPlan pl;
@@ -658,6 +666,12 @@ int launch_po(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
   k.bn_bits = a.bn_bits;
   k.bn_mean = a.bn_mean;
   k.bn_invstd = a.bn_invstd;
+  if (v.bnin) {  // the pointer slots of the BN-backward sums carry the input's BatchNorm: a out, its bits out, [2][Ck] scale / shift
+    k.bn_y = a.bn_in_a;
+    k.bn_bits = a.bn_in_bits;
+    k.bn_mean = a.bn_in;
+    k.bn_invstd = nullptr;
+  }
   k.addend = a.addend;
   k.addend_bits = a.addend_bits;
   k.npix = (unsigned)((long)a.N * a.Hin * a.Win);

@@ -287,7 +287,8 @@ int conv_forward(mi355_ctx* c, ConvBN& l, const void* in, int training, float mo
   return 0;
 }
 
-// conv2 of block b can take bn1 + ReLU in its operand path (training forward, bf16 operands, a generated stride-1 3x3 kernel with that form)
+// conv `l` can take the BatchNorm + ReLU of its producer `prev` in its operand path (training forward, bf16 operands, a generated kernel with that form:
+// conv2 <- bn1 on the direct 3x3 kernels, conv3 <- bn2 on the resident-weight pointwise kernels)
 bool conv_bn_in_legal(mi355_ctx* c, const ConvBN& prev, const ConvBN& l, int training) {
   if (!training || c->dtype != MI355_BF16 || c->fp8 || !c->fuse_bn_in) return false;
   IgemmArgs a;
@@ -296,7 +297,7 @@ bool conv_bn_in_legal(mi355_ctx* c, const ConvBN& prev, const ConvBN& l, int tra
   a.stat_partial = c->bn_partial;
   a.stat_rows_cap = (int)((size_t)bn_max_blocks() * c->max_c / l.Cout);
   a.bn_in = prev.stat; a.bn_in_a = prev.y; a.bn_in_bits = (uint8_t*)prev.y;  // (placeholders: only their presence matters for the check)
-  return dconv_bn_in_legal(c->dtype, a, 1);
+  return igemm_bn_in_legal(c->dtype, a, 1);
 }
 
 // BN statistics + finalize for one layer (training) or eval coefficients
@@ -1180,9 +1181,13 @@ int mi355_resnet50_forward(mi355_ctx* c, const float* x_nchw, float* logits, int
       MI355_TRY(conv_forward(c, b.c2, b.a1, training, bn_momentum, s));
     }
     MI355_TRY(bn_prepare(c, b.c2, training, bn_momentum, s));
-    MI355_TRY(bn_apply(c, b.c2, nullptr, nullptr, b.a2, 1, s, training ? b.a2_bits : nullptr, b.a2_q, b.qid_a2,
-                       training && c->fp8_lean && b.c3.fp8_fwd && b.c3.fp8_wgrad));
-    MI355_TRY(conv_forward(c, b.c3, b.a2, training, bn_momentum, s));
+    if (conv_bn_in_legal(c, b.c2, b.c3, training)) {
+      MI355_TRY(conv_forward(c, b.c3, b.c2.y, training, bn_momentum, s, &b.c2, b.a2, b.a2_bits));   // bn2 + ReLU in conv3's operand path
+    } else {
+      MI355_TRY(bn_apply(c, b.c2, nullptr, nullptr, b.a2, 1, s, training ? b.a2_bits : nullptr, b.a2_q, b.qid_a2,
+                         training && c->fp8_lean && b.c3.fp8_fwd && b.c3.fp8_wgrad));
+      MI355_TRY(conv_forward(c, b.c3, b.a2, training, bn_momentum, s));
+    }
     MI355_TRY(bn_prepare(c, b.c3, training, bn_momentum, s));
     if (b.has_ds) {
       if (c->overlap) MI355_HIP(hipStreamWaitEvent(s, c->ds_done, 0));

@@ -76,6 +76,21 @@ def test_forward_kernels_with_the_inputs_batchnorm_in_the_operand_path_are_exact
 
 
 @pytest.mark.parametrize("name,kw", [
+    ("po_k64_b256_s1_a0_bn", dict(M=256)),                                                         # four tiles: prologue transform, three in the loop, the skipped look-ahead
+    ("po_k64_b256_s1_a0_bn", dict(M=64)),                                                          # a single tile
+    ("po_k128_b256_s1_a0_bn", dict(M=320, N=512, tpg=3, groups=((0, 0), (1, 1), (1, 0)))),           # two runs x two column tiles: only column tile 0 stores a / bits
+    ("po_k256_b256_s1_a0_bn", dict(M=192, N=1024, groups=((0, 3), (0, 0)))),                         # four planes, eight pieces per wave and tile
+])
+def test_pointwise_kernels_with_the_inputs_batchnorm_in_the_operand_path_are_exact_in_the_emulator(name, kw):
+    """PoCfg.bnin: out = relu(y * scale + shift) @ w^T with the activation and its ReLU bits left in memory by the workgroups of column tile 0"""
+    import po_emu_check as PO
+
+    r = PO.run(name, **kw)
+    assert r["max_err"] == 0.0 and r["untouched_ok"] and r["a_ok"] and r["bits_ok"], r
+    assert r["stat_err"] < 1e-6, r
+
+
+@pytest.mark.parametrize("name,kw", [
     ("pw_k256_n1024_s1", dict(mtiles=2, grid=2, N=512)),   # pixel-tile change inside a workgroup's range, statistics rows
     ("pw_k256_n1024_s1", dict(mtiles=3, grid=2)),          # 6 units per workgroup: both accumulator sets, refill path and not
     ("pw_k256_n1024_s0", dict(mtiles=2, grid=3, N=256)),   # one column tile: every unit refills

@@ -258,12 +258,14 @@ BN_IN = [(256, 56, 64, "dconv_l1"), (256, 28, 128, "dconv_l2"), (256, 14, 256, "
 
 
 @pytest.mark.parametrize("N,H,C,fam", BN_IN)
-def test_conv2_forward_with_bn1_in_its_operand_path_is_exact(dev, N, H, C, fam):
-    """dconv_*_s1_bn (asm/dconv_gen.py Cfg.bnin) through mi355_conv2d_fwd_bn_in on dyadic data, where every step is exact: the activation
-    a = relu(y * scale + shift) and its ReLU bits the launch leaves behind, y2 = conv(a, w) bit for bit against torch's fp32 convolution, and
-    the BatchNorm statistics rows of y2"""
-    from sota_imagenet_amd import ops
+def test_conv2_forward_with_bn1_in_its_operand_path_is_exact(dev, N, H, C, fam, monkeypatch):
+    """dconv_*_s1_bn (asm/dconv_gen.py Cfg.bnin; MI355_DCONV_BN=1: off by default, measured break-even) through mi355_conv2d_fwd_bn_in on dyadic data,
+    where every step is exact: the activation a = relu(y * scale + shift) and its ReLU bits the launch leaves behind, y2 = conv(a, w) bit for bit against
+    torch's fp32 convolution, and the BatchNorm statistics rows of y2"""
+    from sota_imagenet_amd import native, ops
 
+    monkeypatch.setenv("MI355_DCONV_BN", "1")
+    native.lib().mi355_reload_knobs()
     torch.manual_seed(23)
     y1 = torch.randint(-3, 4, (N, H, H, C), device=dev).to(torch.bfloat16)
     scale = (torch.randint(1, 9, (C,), device=dev) * 0.25).float()
@@ -284,12 +286,14 @@ def test_conv2_forward_with_bn1_in_its_operand_path_is_exact(dev, N, H, C, fam):
     assert (part[:, 1].double().sum(0) - s2).abs().max() <= 1e-6 * s2.abs().max().item()
 
 
-def test_conv2_forward_with_bn1_in_its_operand_path_against_the_oracle_and_the_unfused_launches(dev):
+def test_conv2_forward_with_bn1_in_its_operand_path_against_the_oracle_and_the_unfused_launches(dev, monkeypatch):
     """random data: (i) against oracle/ops_ref: BatchNorm (batch statistics) -> ReLU -> conv, with the coefficients mi355_bn_fwd_train leaves;
     (ii) bit for bit against the library's own two launches (bn_apply, then the plain forward kernel)"""
     from oracle import ops_ref
-    from sota_imagenet_amd import ops
+    from sota_imagenet_amd import native, ops
 
+    monkeypatch.setenv("MI355_DCONV_BN", "1")
+    native.lib().mi355_reload_knobs()
     torch.manual_seed(24)
     N, H, C = 8, 14, 256
     y1 = (torch.randn(N, H, H, C) * 2).to(torch.bfloat16)
@@ -309,6 +313,58 @@ def test_conv2_forward_with_bn1_in_its_operand_path_against_the_oracle_and_the_u
     assert ops.last_conv_kernel() == "dconv_l3_s1"
     assert torch.equal(y2, y_plain)
     assert (a.float() - a_n.float()).abs().max() <= 2.0 ** -7 * a_n.float().abs().max()
+
+
+# (N, H, Cin, Cout, family): conv3 of the bottlenecks of layers 1 .. 3 (bn2 + ReLU in its operand path), + a small batch of whole 64-pixel tiles
+PO_BN = [(256, 56, 64, 256, "po_k64_b256"), (256, 28, 128, 512, "po_k128_b256"), (256, 14, 256, 1024, "po_k256_b256"), (4, 28, 128, 512, "po_k128_b256")]
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout,fam", PO_BN)
+def test_conv3_forward_with_bn2_in_its_operand_path_is_exact(dev, N, H, Cin, Cout, fam):
+    """po_*_s1_a0_bn (asm/po_gen.py PoCfg.bnin) through mi355_conv2d_fwd_bn_in on dyadic data: the activation and its ReLU bits the launch leaves behind,
+    y3 = conv1x1(a, w) bit for bit, the BatchNorm statistics rows of y3"""
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(25)
+    y2 = torch.randint(-3, 4, (N, H, H, Cin), device=dev).to(torch.bfloat16)
+    scale = (torch.randint(1, 9, (Cin,), device=dev) * 0.25).float()
+    shift = (torch.randint(-8, 9, (Cin,), device=dev) * 0.25).float()
+    w = torch.randint(-2, 3, (Cout, 1, 1, Cin), device=dev).to(torch.bfloat16)
+    y3, part, a, bits = ops.conv2d_fwd_bn_in(y2, scale, shift, w, pad=0)
+    assert ops.last_conv_kernel() == fam + "_s1_a0_bn", ops.last_conv_kernel()
+    v = y2.float() * scale + shift
+    a_ref = v.clamp_min(0).to(torch.bfloat16)
+    assert torch.equal(a, a_ref)
+    bits_ref = ((v > 0).reshape(N, H, H, Cin // 8, 8).to(torch.int32) << torch.arange(8, device=dev, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    assert torch.equal(bits, bits_ref)
+    ref = (a_ref.float().reshape(-1, Cin) @ w.float().reshape(Cout, Cin).t()).reshape(N, H, H, Cout).to(torch.bfloat16)
+    assert torch.equal(y3, ref)
+    s1, s2 = ref.double().sum(dim=(0, 1, 2)), (ref.double() ** 2).sum(dim=(0, 1, 2))
+    assert part is not None and part.shape[1:] == (2, Cout)
+    assert (part[:, 0].double().sum(0) - s1).abs().max() <= 1e-6 * max(1.0, s1.abs().max().item())
+    assert (part[:, 1].double().sum(0) - s2).abs().max() <= 1e-6 * s2.abs().max().item()
+
+
+def test_conv3_forward_with_bn2_in_its_operand_path_random_data_and_ragged_pixel_counts(dev):
+    """random data against the library's own two launches (bn_apply's arithmetic, then the plain kernel); a pixel count that is no multiple of the 64-pixel
+    tile has no kernel of this form: the entry point says so (the executor then runs bn_apply)"""
+    from sota_imagenet_amd import native, ops
+
+    torch.manual_seed(26)
+    N, H, Cin, Cout = 8, 28, 128, 512
+    y2 = (torch.randn(N, H, H, Cin, device=dev) * 2).to(torch.bfloat16)
+    scale, shift = torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev) * 0.3
+    w = (torch.randn(Cout, 1, 1, Cin, device=dev) * 0.05).to(torch.bfloat16)
+    y3, part, a, bits = ops.conv2d_fwd_bn_in(y2, scale, shift, w, pad=0)
+    assert ops.last_conv_kernel() == "po_k128_b256_s1_a0_bn"
+    a_n = torch.relu(torch.addcmul(shift, y2.float(), scale)).to(torch.bfloat16)
+    assert (a.float() - a_n.float()).abs().max() <= 2.0 ** -7 * a_n.float().abs().max()
+    y_plain, _ = ops.conv2d_fwd(a, w, 1, 0, stats=True)
+    assert ops.last_conv_kernel() == "po_k128_b256_s1_a0"
+    assert torch.equal(y3, y_plain)
+    assert torch.equal(bits, ((a.float() != 0).reshape(N, H, H, Cin // 8, 8).to(torch.int32) << torch.arange(8, device=dev, dtype=torch.int32)).sum(-1).to(torch.uint8))
+    with pytest.raises(RuntimeError, match="no kernel applies the input's BatchNorm"):
+        ops.conv2d_fwd_bn_in(y2[:3], scale, shift, w, pad=0)      # 3 * 784 pixels: not whole 64-pixel tiles
 
 
 def test_bn_backward_sums_of_the_data_gradient_against_the_oracle(dev):

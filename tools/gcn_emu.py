@@ -797,6 +797,21 @@ class Emulator:
         self.vwrite(wv, ins.ops[0], (r & MASK32).astype(np.uint32), ins)
         self.swrite64(wv, ins.ops[1], val, ins)
 
+    def i_v_pk_max_i16(self, wv, ins):
+        a = self.vval(wv, ins.ops[1], ins).astype(np.int64)
+        b = self.vval(wv, ins.ops[2], ins).astype(np.int64)
+        s16 = lambda x: np.where(x & 0x8000, x - 0x10000, x)
+        lo = np.maximum(s16(a & 0xFFFF), s16(b & 0xFFFF)) & 0xFFFF
+        hi = np.maximum(s16((a >> 16) & 0xFFFF), s16((b >> 16) & 0xFFFF)) & 0xFFFF
+        self.vwrite(wv, ins.ops[0], ((hi << 16) | lo).astype(np.uint32), ins)
+
+    def i_v_pk_min_u16(self, wv, ins):
+        a = self.vval(wv, ins.ops[1], ins).astype(np.int64)
+        b = self.vval(wv, ins.ops[2], ins).astype(np.int64)
+        lo = np.minimum(a & 0xFFFF, b & 0xFFFF)
+        hi = np.minimum((a >> 16) & 0xFFFF, (b >> 16) & 0xFFFF)
+        self.vwrite(wv, ins.ops[0], ((hi << 16) | lo).astype(np.uint32), ins)
+
     def i_v_cmp_lt_u32(self, wv, ins):
         self._vcmp(wv, ins, lambda a, b: a < b)
 

@@ -41,6 +41,16 @@ def run(name, M=200, N=None, groups=((0, 0),), tpg=None, seed=0, check=True, ext
     G = -(-T // tpg)
     x = rng.integers(-2, 3, size=(M, c.K)).astype(np.float32)
     w = rng.integers(-2, 3, size=(N, c.K)).astype(np.float32)
+    bn = getattr(c, "bnin", 0)
+    if bn:   # the input is raw: a = relu(x * scale + shift) (dyadic: exact), the kernel multiplies a and leaves a + its ReLU bits in memory
+        assert M % c.TP == 0
+        x = rng.integers(-3, 4, size=(M, c.K)).astype(np.float32)
+        scale = (rng.integers(1, 9, size=c.K) * 0.25).astype(np.float32)
+        shift = (rng.integers(-8, 9, size=c.K) * 0.25).astype(np.float32)
+        v_ = x * scale + shift
+        a_act = np.maximum(v_, 0).astype(np.float32)
+        assert (bf16_round(a_act) == a_act).all()
+        act_bits = np.packbits((v_ > 0).reshape(M, c.K // 8, 8), axis=-1, bitorder="little")[..., 0]
     ad = rng.integers(-3, 4, size=(M, N)).astype(np.float32)
     H, W = HW
     if c.add == 3:
@@ -62,6 +72,10 @@ def run(name, M=200, N=None, groups=((0, 0),), tpg=None, seed=0, check=True, ext
     a_out = mem.alloc(out0)
     a_stat = mem.alloc(np.full((G * c.WM, 2, N), np.nan, dtype=np.float32))   # (waves 2 x 2: the two waves that share columns leave a row each)
     a_y, a_bits, a_mu, a_is = mem.alloc(to_bf16_bits(yb)), mem.alloc(bits), mem.alloc(mean), mem.alloc(invstd)
+    if bn:   # the pointer slots of the BN-backward sums carry the input's BatchNorm: a out, its bits out, [2][K] scale / shift
+        a_y = mem.alloc(np.full((M, c.K), 0x7FC0, dtype=np.uint16))
+        a_bits = mem.alloc(np.full((M, c.K // 8), 0x55, dtype=np.uint8))
+        a_mu = mem.alloc(np.concatenate([scale, shift]))
     a_ad, a_ab = mem.alloc(to_bf16_bits(adc if c.add == 3 else ad)), mem.alloc(abits)
     lognct = nct.bit_length() - 1
     assert 1 << lognct == nct
@@ -79,7 +93,7 @@ def run(name, M=200, N=None, groups=((0, 0),), tpg=None, seed=0, check=True, ext
         assert gi >= G
         total += emu.run_workgroup(4, a_ka, wg_id=(wg_of(gi, 0, nct), 0, 0))
     got = from_bf16_bits(mem.array(a_out, np.uint16, out0.shape)).astype(np.float64)
-    ref = (x.astype(np.float64) @ w.astype(np.float64).T).astype(np.float32)
+    ref = ((a_act if bn else x).astype(np.float64) @ w.astype(np.float64).T).astype(np.float32)
     if c.add:
         amask = ((abits[..., None] >> np.arange(8)) & 1).reshape(M, N).astype(np.float32) if c.add == 2 else np.ones((M, N), dtype=np.float32)  # (add == 3: `ad` is the zero-filled full tensor)
         ref = ref + ad * amask
@@ -92,6 +106,15 @@ def run(name, M=200, N=None, groups=((0, 0),), tpg=None, seed=0, check=True, ext
         touched[rows_of(gi), cols_of(ct)] = True
     res["max_err"] = (float(np.abs(np.where(touched, got - refr, 0.0)).max()) if not np.isnan(got[touched]).any() else float("nan")) if touched.any() else 0.0
     res["untouched_ok"] = bool(np.isnan(got[~touched]).all())
+    if bn:
+        ga = from_bf16_bits(mem.array(a_y, np.uint16, (M, c.K)))
+        gb = mem.array(a_bits, np.uint8, (M, c.K // 8))
+        wrote = np.zeros(M, dtype=bool)
+        for (gi, ct) in groups:
+            if ct == 0:
+                wrote[rows_of(gi)] = True
+        res["a_ok"] = bool((ga[wrote] == a_act[wrote]).all() and np.isnan(ga[~wrote]).all())
+        res["bits_ok"] = bool((gb[wrote] == act_bits[wrote]).all() and (gb[~wrote] == 0x55).all())
     st = mem.array(a_stat, np.float32, (G * c.WM, 2, N))
     if c.stats:
         stsum = st.reshape(G, c.WM, 2, N).astype(np.float64).sum(axis=1)
