@@ -769,6 +769,8 @@ class Gen:
         # tile and the A pieces requested at the top of this tile's trip
         CW = ((c.L + 1) * (c.NI - 1) if not c.FULL else 2 * (c.L + 1) * (c.MFRW - 1)) + c.NPW + c.NMT
         TOPW = c.NI * (c.L + 1) + c.NMT   # younger than a tile's A pieces at the top of the trip that needs them
+        if c.bnin:
+            TOPW += 2 * c.NPW             # ... and the a / bits stores of the transform, which runs BEHIND the request of the tile after next
         if c.weave:
             self.comment("---- first tile: its MFMAs alone (A buffer 0 -> accumulator set 0), the second tile requested")
             if c.bnin:
@@ -793,14 +795,17 @@ class Gen:
                 # at the top of the trip of tile t: tile t + 1 (requested a trip ago) has landed for every wave; buffer b (tile t: its MFMAs ran
                 # in the previous trip) takes tile t + 2
                 e("s_waitcnt vmcnt(%d)" % TOPW, "tile t + 1's A pieces have landed (younger: the last trip's stores and refills)")
-                if c.bnin:
-                    self.transform_tile(nb, False)
                 e("s_barrier")
                 for jj in range(c.NPW):
                     for ins in self.a_piece(jj, b):
                         e(ins)
                 for ins in self.a_advance():
                     e(ins)
+                if c.bnin:
+                    # tile t + 2 is on its way: the transform of tile t + 1 runs under that latency (in front of the request it lengthened the
+                    # chain wait -> request by 300 cycles per piece: +15 us per launch); a second barrier publishes it
+                    self.transform_tile(nb, False)
+                    e("s_barrier")
                 self.accset = b
                 self.mbuf = b
                 epi = self.capture(self.epilogue_tile, CW)
