@@ -240,11 +240,9 @@ struct FinalizeArgs {
   float* coef;
 };
 
-// MI355_BN_FIN_WIDE=0: the four-channel form for every layer (A/B switch, read once)
-static int fin_wide_mode() {
-  static const int m = getenv("MI355_BN_FIN_WIDE") ? atoi(getenv("MI355_BN_FIN_WIDE")) : 2;
-  return m;
-}
+// rule 2 of the comment below (the A/B switch MI355_BN_FIN_WIDE is gone: its verdict is profiles/r05_bn_finalize_per_launch.txt and the two same-box
+// step measurements quoted there)
+static int fin_wide_mode() { return 2; }
 // one channel per workgroup?  0 never; 1: few channels and more than one pass of rows (round 5's first rule); 2 (default): also up to 512
 // channels from 128 rows on — four-channel workgroups leave most of the chip idle there and the kernel is a chain of load latencies
 // (same box: 18.15 -> 18.05 ms per step, 17.75 -> 17.69 on a faster box); 3 / 4: wider still (no further gain)
@@ -727,12 +725,8 @@ int reduce_grid(int dtype, int M, int C, dim3* grid) {
   const int rpp = 256 / tpr;
   const int gy = tpr_full / tpr;
   int nblk = cdiv(M, rpp * 8);
-  // MI355_BN_REDUCE_BLOCKS (A/B switch, read once): partial rows of the stand-alone reductions, 512 (two workgroups per CU) .. bn_max_blocks()
-  static const int cap = [] {
-    const char* e = getenv("MI355_BN_REDUCE_BLOCKS");
-    const int v = e ? atoi(e) : MAXBLK;
-    return v >= 64 && v <= 2 * MAXBLK ? v : MAXBLK;
-  }();
+  // partial rows of the stand-alone reductions: MAXBLK (two workgroups per CU; 1024 rows measured +0.2 ms per step in round 1)
+  const int cap = MAXBLK;
   if (nblk > cap / gy) nblk = cap / gy;
   if (nblk < 1) nblk = 1;
   *grid = dim3(nblk, gy);
@@ -742,10 +736,10 @@ int reduce_grid(int dtype, int M, int C, dim3* grid) {
 int elementwise_blocks(size_t nvec, int cvecs) {
   // 4 vectors per thread (amortises the per-channel constant loads; 2 is a tie, 8 and 1 are slower) and NO practical cap on the workgroups: the cap of
   // 4096 the kernels ran under until late round 5 cost 0.15 ms per bf16 step and 0.47 ms per fp8 step at batch 512 (17.72 -> 17.55, 33.8 -> 33.3, same box:
-  // short workgroups interleave with the weight-gradient stream's kernels and leave no tail).  MI355_EW_BLOCKS / MI355_EW_VPT: A/B, read once.
-  static const size_t vpt = getenv("MI355_EW_VPT") ? (size_t)std::max(1, atoi(getenv("MI355_EW_VPT"))) : 4;
+  // short workgroups interleave with the weight-gradient stream's kernels and leave no tail; profiles/r05b_ab_elementwise_grid_caps.txt).
+  const size_t vpt = 4;
   size_t b = (nvec + vpt * 256 - 1) / (vpt * 256);
-  static const size_t cap = getenv("MI355_EW_BLOCKS") ? (size_t)std::max(4, atoi(getenv("MI355_EW_BLOCKS"))) : 65536;
+  const size_t cap = 65536;
   if (b > cap) b = cap;
   if (b < 4) b = 4;
   // stride = b*256 must be a multiple of cvecs (a power of two <= 1024): make b a multiple of 4

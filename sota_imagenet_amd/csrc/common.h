@@ -149,6 +149,7 @@ struct Knobs {
   int stem_direct = 1;       // MI355_STEM_DIRECT=0: the row-pair implicit GEMM
   int stem_th = 0;           // MI355_STEM_TH: a smaller stem tile (0: the plan)
   bool stem_dbg = false;     // MI355_STEM_DBG: print the stem launch plan
+  bool sk_mute = false;      // MI355_SK_DEBUG=mute: stream-K contributors never publish (test hook: the owner's bounded wait must time out and report)
   // kernel-selection switches of the generated gfx950 kernels (A/B): "0" keeps the launches they serve on the implicit-GEMM kernels
   int dconv = 1;             // MI355_DCONV: every generated kernel
   int wg3 = 1;               // MI355_WG3: the generated weight-gradient kernels (asm/wg_gen.py, wg1_gen.py)
@@ -165,6 +166,15 @@ struct Knobs {
   char error[160] = {0};     // a switch with a value outside its domain: every conv launch fails with MI355_E_ARG and this text
 };
 const Knobs& knobs();
+// an executor switch, read at context creation: unset -> def; one digit "0" .. maxv -> that value; anything else -> *bad = the switch's name
+// (the creation then fails with MI355_E_ARG: a stale or mistyped switch in a job script is an error, not a silent default)
+inline int env_switch(const char* name, int def, int maxv, const char** bad) {
+  const char* e = getenv(name);
+  if (!e) return def;
+  if (e[0] >= '0' && e[0] <= '0' + maxv && e[1] == 0) return e[0] - '0';
+  if (bad && !*bad) *bad = name;
+  return def;
+}
 int plan_wgrad(int dtype, const WgradArgs& a);
 int wg3_plan(int dtype, const WgradArgs& a);  // 0: the launch is not served by a generated kernel
 // name of the kernel the last conv / weight-gradient launch of this thread went to (a generated kernel's symbol, or the implicit-GEMM

@@ -86,6 +86,10 @@ static void load_knobs() {
   }
   if (const char* e = getenv("MI355_STEM_TH")) k.stem_th = atoi(e);
   k.stem_dbg = getenv("MI355_STEM_DBG") != nullptr;
+  if (const char* e = getenv("MI355_SK_DEBUG")) {
+    if (strcmp(e, "mute") == 0) k.sk_mute = true;
+    else if (!k.error[0]) snprintf(k.error, sizeof(k.error), "MI355_SK_DEBUG=%s: not \"mute\"", e);
+  }
   // switches with a closed domain: anything else is an error, not a silent default (a stale MI355_DCONV=off in a job script would
   // otherwise cost a millisecond per step without a word)
   auto sw = [&](const char* name, int* dst, int maxv) {

@@ -723,17 +723,13 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
   k.sk_epoch = 0;
   k.sk_partial = nullptr;
   k.sk_flags = nullptr;
-  static const bool sk_mute = [] {
-    const char* e = getenv("MI355_SK_DEBUG");
-    return e && strcmp(e, "mute") == 0;
-  }();
-  k.sk_mute = sk_mute ? 1 : 0;
+  k.sk_mute = knobs().sk_mute ? 1 : 0;   // (MI355_SK_DEBUG=mute: the test hook of the stream-K failure path)
 #ifdef MI355_PROBES
   k.dbg = probe_env("MI355_IGEMM_DBG");  // read per launch: timing probes only, results are wrong with it set
 #else
   k.dbg = 0;
 #endif
-  k.sk_spin_limit = sk_mute ? (1u << 8) : (1u << 24);
+  k.sk_spin_limit = k.sk_mute ? (1u << 8) : (1u << 24);
   bool sk = false;
   // (fp32 only: a hand-off costs the owner ~10 us, nothing beside a 150-300 us fp32 tile, but most of what the cut
   // saves on a 30-60 us bf16 tile — measured)
@@ -765,10 +761,9 @@ int launch_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows)
   // remap puts all n-tiles of a row tile behind ONE L2 at the same time (and its A rows are fetched once instead of ng times):
   // conv1's dgrad of layers 2-4 612 -> 366 MB and 112 -> 99 us (layer 3), 417 -> 226 MB and 84 -> 67 us (layer 4), 156 -> 146 us
   // (layer 2); the 256-column launches of layer 1 (2 n-tiles) lose 8 us and keep the plain order.
-  static const int xcd_env = getenv("MI355_IGEMM_XCD") ? atoi(getenv("MI355_IGEMM_XCD")) : -1;  // A/B knob: 0 never, 1 wherever legal
   k.xcd = 0;
   if (sizeof(T) == 2 && !sk && BM == 128 && MAX_WG % 8 == 0 && (MAX_WG / 8) % k.ny == 0 && R * k.ny >= MAX_WG && k.ny >= 2 &&
-      (xcd_env < 0 ? (a.addend_bits != nullptr || a.bn_bits != nullptr) && a.Ncols >= 512 : xcd_env == 1)) {
+      (a.addend_bits != nullptr || a.bn_bits != nullptr) && a.Ncols >= 512) {
     ng = k.ny;
     k.xcd = 1;
   }
@@ -891,8 +886,7 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
   // BN = 128 unless that leaves most of the 256 CUs without a tile (the FC layer: 256 rows): then 64-wide tiles double
   // the workgroups
   const long tiles128 = (long)cdiv(a.N * a.Hsub * a.Wsub, 128) * nclass * (a.Ncols / 128);
-  static const int narrow_env = getenv("MI355_IGEMM_NARROW") ? atoi(getenv("MI355_IGEMM_NARROW")) : 0;  // A/B knob
-  const bool wide = (a.Ncols % 128 == 0) && tiles128 * 2 >= device_cus() && !narrow_env;
+  const bool wide = (a.Ncols % 128 == 0) && tiles128 * 2 >= device_cus();
   MI355_ARG(dtype == MI355_BF16 || !a.addend_sub2, "igemm: a half-resolution addend needs the generated pointwise kernel (igemm_sub2_legal)");
   MI355_ARG(a.bn_in == nullptr || igemm_bn_in_legal(dtype, a, nclass), "igemm: the input's BatchNorm in the operand path needs a generated kernel with that form (igemm_bn_in_legal)");
   if (dtype == MI355_F32)

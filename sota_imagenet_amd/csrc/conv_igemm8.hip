@@ -822,13 +822,12 @@ int launch8_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
       ng = d;
       break;
     }
-  // MI355_IGEMM8_XCD (A/B knob, read once): 1 = one n-tile per item + XCD-aware item order wherever there are >= 2 n-tiles
-  static const int xcd_env = getenv("MI355_IGEMM8_XCD") ? atoi(getenv("MI355_IGEMM8_XCD")) : -1;
+  // one n-tile per item + XCD-aware item order where there are >= 2 n-tiles:
   k.xcd = 0;
   // measured per layer (profiles/r03f): neutral or +2...+12 us on the forward launches although their L2-side traffic drops
   // (layer-3 conv3 270 -> 218 MB), -51 us on the stride-2 downsample dgrad of layer 4 (4 tap classes, 3 of them empty) and
   // -6 us on layer 3's: on by default for multi-class launches only.
-  if ((xcd_env < 0 ? nclass > 1 : xcd_env == 1) && ny >= 2 && R * ny >= MAX_WG) {
+  if (nclass > 1 && ny >= 2 && R * ny >= MAX_WG) {
     ng = ny;
     k.xcd = 1;
   }

@@ -485,8 +485,7 @@ int launch_t(const WgradArgs& a, int splits, hipStream_t stream) {
   // grid divides over the 8 XCDs.  Same-box whole-step A/B at batch 256 (tools/ab_step.sh MI355_WGRAD_XCD): 20.46 -> 20.36 ms
   // with it on for every layer (round 1 had it for <= 16 tiles only, from warm-cache per-op timings where the MALL hides
   // the re-fetch).
-  static const int xcd_env = getenv("MI355_WGRAD_XCD") ? atoi(getenv("MI355_WGRAD_XCD")) : -1;  // A/B knob: 0 never, 1 always
-  k.xcd = (k.tiles > 1 && grid % 8 == 0 && (xcd_env < 0 || xcd_env == 1)) ? 1 : 0;
+  k.xcd = (k.tiles > 1 && grid % 8 == 0) ? 1 : 0;
   const size_t lds = (size_t)2 * BKP * (BMC + TPI * BNC) * ES;
   static bool attr_set = false;
   if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in

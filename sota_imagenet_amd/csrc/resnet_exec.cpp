@@ -547,17 +547,15 @@ int plan_arena(mi355_ctx* c, Arena& ar) {
 
 // fp8 step: which layers run on e4m3 operands (geometry the fp8 form of the 8-wave kernel accepts: channel counts in multiples of
 // 128 on both sides — layers 2-4 of the network; stem, layer 1 and FC stay bf16), the twins they read, and their scale slots.
-// MI355_FP8_LAYERS=<substring> restricts the set to layers whose conv name contains it (A/B, tests).
-void plan_fp8(mi355_ctx* c) {
-  const char* only = getenv("MI355_FP8_LAYERS");
+void plan_fp8(mi355_ctx* c, const char** bad) {
   // MI355_FP8_PLAN=rule: the per-layer exclusions of mid round 5 below.  Default since the K = 128 / K = 64 matrix instructions (conv_igemm8.hip, conv_wgrad.hip):
   // every legal launch on e4m3 operands — 33.98 against 34.54 ms per step at batch 512 (two alternations on one box): single launches the rule excluded are
   // still a few us slower than the generated bf16 kernel (3x3 weight gradients 98-111 against 88-99 us, layer 3's conv3 forward 84-88 / 65-75), but with
   // every consumer of a tensor on its e4m3 twin the bf16 copy is not written at all, and the step follows its bytes
-  const char* pa = getenv("MI355_FP8_PLAN");
+  const char* pa = getenv("MI355_FP8_PLAN");   // "all" (default) | "rule"
+  if (pa && strcmp(pa, "all") != 0 && strcmp(pa, "rule") != 0 && bad && !*bad) *bad = "MI355_FP8_PLAN";
   const bool plan_all = !(pa && pa[0] == 'r');
-  const char* dce = getenv("MI355_DS_COMPACT");
-  const bool ds_compact_env = !(dce && dce[0] == '0');
+  const bool ds_compact_env = env_switch("MI355_DS_COMPACT", 1, 1, bad) != 0;
   int n = 0;
   // Measured per layer at batch 256 / 224 px (profiles/r03a_conv_per_layer_fp8_vs_bf16.txt): the e4m3 form wins 4-10 us per launch
   // wherever the reduction spans >= 2 of its 128-channel k-tiles, and loses 15-90 us on the output-heavy launches — the 128 -> 512
@@ -565,7 +563,6 @@ void plan_fp8(mi355_ctx* c) {
   // addend + BN-backward epilogue: the single workgroup per CU of the 8-wave kernel runs that epilogue with the matrix pipe idle,
   // the same reason the bf16 rule keeps them on the 4-wave kernel).  Those stay bf16 and get no twins.
   auto legal = [&](ConvBN& l, bool is_c1) {
-    if (only && only[0] && l.conv_name.find(only) == std::string::npos) return;
     IgemmArgs a;
     build_fwd_args(a, c->N, l.Hin, l.Win, l.Cin, l.Cout, l.K, l.K, l.stride, l.pad);
     l.fp8_fwd = igemm_fp8_legal(a, 1) && l.Cin * l.K * l.K >= 256;
@@ -586,10 +583,8 @@ void plan_fp8(mi355_ctx* c) {
     if (l.fp8_fwd || l.fp8_dgrad) l.qid_w = n++;
     if (l.fp8_dgrad) l.qid_dy = n++;
   };
-  const char* wg = getenv("MI355_FP8_WGRAD");
-  c->fp8_use_wgrad = !(wg && wg[0] == '0');
-  const char* kb = getenv("MI355_FP8_KEEP_BF16");
-  c->fp8_keep_bf16 = kb && kb[0] == '1';
+  c->fp8_use_wgrad = true;
+  c->fp8_keep_bf16 = env_switch("MI355_FP8_KEEP_BF16", 0, 1, bad) != 0;
   for (size_t i = 0; i < c->blocks.size(); ++i) {
     Block& b = c->blocks[i];
     legal(b.c1, true); legal(b.c2, false); legal(b.c3, false);
@@ -935,16 +930,23 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
   c->train_flops = tr + 3 * ffc;
 
   // ---- workspace ----
+  // executor switches: closed domains, read here once (a value outside its domain fails the creation below)
+  const char* bad = nullptr;
   if (c->fp8) {
-    plan_fp8(c);
-    const char* e = getenv("MI355_FP8_FWD");
-    c->fp8_use_fwd = !(e && e[0] == '0');
-    e = getenv("MI355_FP8_BWD");
-    c->fp8_use_bwd = !(e && e[0] == '0');
+    plan_fp8(c, &bad);
+    c->fp8_use_fwd = env_switch("MI355_FP8_FWD", 1, 1, &bad) != 0;
+    c->fp8_use_bwd = env_switch("MI355_FP8_BWD", 1, 1, &bad) != 0;
   }
-  if (const char* gs = getenv("MI355_GSETS")) {  // A/B knob, read once per ctx (before the workspace is planned)
-    const int v = atoi(gs);
-    if (v >= 2 && v <= MAX_GSETS) c->nsets = v;
+  c->stream_k = env_switch("MI355_STREAM_K", 1, 1, &bad) != 0;
+  // BN-backward sums in the dgrad epilogues: measured same-box -0.6 ms/step in bf16, +0.9 ms in fp32 (the fp32 epilogue is already register-heavy)
+  c->fuse_bn_bwd = env_switch("MI355_FUSE_BN_BWD", dtype == MI355_BF16 ? 1 : 0, 1, &bad) != 0;
+  c->stem_fused_bwd = env_switch("MI355_STEM_FUSED", 1, 1, &bad) != 0;
+  c->overlap = env_switch("MI355_WGRAD_STREAM", 1, 1, &bad) != 0;   // 0 keeps everything on the caller's stream
+  c->ds_compact = env_switch("MI355_DS_COMPACT", 1, 1, &bad) != 0;
+  if (bad) {
+    set_error("create: %s=%s is outside the switch's domain", bad, getenv(bad));
+    mi355_resnet50_destroy(c);
+    return MI355_E_ARG;
   }
   Arena ar;
   plan_arena(c, ar);
@@ -1015,8 +1017,6 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
     }
   }
   // weight-gradient side stream (MI355_WGRAD_STREAM=0 keeps everything on the caller's stream)
-  const char* skv = getenv("MI355_STREAM_K");
-  c->stream_k = !(skv && skv[0] == '0');
   if (c->stream_k && dtype == MI355_F32) {
     if (hipHostMalloc((void**)&c->sk_err_host, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
       set_error("create: hipHostMalloc -> %s", hipGetErrorString(hipGetLastError()));
@@ -1025,28 +1025,14 @@ int mi355_resnet50_create(mi355_ctx** out, int device, int dtype, int N, int H, 
     }
     c->sk_err_host[0] = c->sk_err_host[1] = 0;
   }
-  const char* fb = getenv("MI355_FUSE_BN_BWD");
-  // measured same-box: -0.6 ms/step in bf16, +0.9 ms in fp32 (the fp32 epilogue is already register-heavy)
-  c->fuse_bn_bwd = fb ? fb[0] != '0' : dtype == MI355_BF16;
-  const char* sf = getenv("MI355_STEM_FUSED");
-  c->stem_fused_bwd = !(sf && sf[0] == '0');
-  const char* ov = getenv("MI355_WGRAD_STREAM");
-  c->overlap = !(ov && ov[0] == '0');
-  {
-    const char* dc = getenv("MI355_DS_COMPACT");
-    c->ds_compact = !(dc && dc[0] == '0');
-  }
   if (c->overlap) {
     // the weight-gradient stream runs at the highest priority: it is the busier of the two during backward and the main stream ends
-    // up waiting for it (profiles/r04_ab_side_stream_priority.txt: -0.07..-0.13 ms per step on three boxes); MI355_SIDE_PRIO=0 restores
-    // the default priority, 1 selects the lowest
+    // up waiting for it (profiles/r04_ab_side_stream_priority.txt: -0.07..-0.13 ms per step on three boxes)
     bool ok;
     {
-      const char* sp = getenv("MI355_SIDE_PRIO");
-      int want = sp ? atoi(sp) : -1, lo = 0, hi = 0;
+      int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      ok = want == 0 ? hipStreamCreateWithFlags(&c->wstream, hipStreamNonBlocking) == hipSuccess
-                     : hipStreamCreateWithPriority(&c->wstream, hipStreamNonBlocking, want < 0 ? hi : lo) == hipSuccess;
+      ok = hipStreamCreateWithPriority(&c->wstream, hipStreamNonBlocking, hi) == hipSuccess;
     }
     c->fork_ev.resize(16);
     for (auto& ev : c->fork_ev) ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;

@@ -24,19 +24,13 @@ __device__ __forceinline__ float act_slope(float out, int act) { return act == 0
 
 #define GRID_STRIDE(i, total) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (size_t)gridDim.x * blockDim.x)
 
-// pixels per thread of the row-walking pools (MI355_POOL_SEG: A/B, read once)
-static int pool_seg(int W) {
-  static const int env = getenv("MI355_POOL_SEG") ? atoi(getenv("MI355_POOL_SEG")) : 0;
-  if (env == 1) return 0;  // the point-wise kernels
-  const int sgm = env >= 3 ? env : 112;
-  return sgm < W ? sgm : W;
-}
-// workgroups of the grid-stride elementwise kernels: one per 256 elements-vectors up to a cap (MI355_VAR_BLOCKS: A/B, read once).  The cap was 2048 (eight
+// pixels per thread of the row-walking pools (profiles/r05b_ab_bresnet50_steps.txt: the row-walking form against the point-wise kernels)
+static int pool_seg(int W) { return 112 < W ? 112 : W; }
+// workgroups of the grid-stride elementwise kernels: one per 256 elements-vectors up to a cap.  The cap was 2048 (eight
 // resident rounds of one workgroup per CU) until late round 5: 32768+ is 0.3-0.4 ms per BResNet-50 step faster (28.65 -> 28.35) — short workgroups interleave
 // with the other stream's kernels and leave no tail
 static int grid_for(size_t total) {
-  static const size_t cap = getenv("MI355_VAR_BLOCKS") ? (size_t)atoi(getenv("MI355_VAR_BLOCKS")) : (size_t)65536;
-  return (int)std::min<size_t>((total + 255) / 256, cap);
+  return (int)std::min<size_t>((total + 255) / 256, (size_t)65536);
 }
 
 // ---- blur pool -----------------------------------------------------------------------------------------------------

@@ -581,6 +581,20 @@ def test_backward_of_the_baseline_batch_teacher_forced_segment_by_segment(dev, m
     assert max(errs) < 2e-3, f"per-segment error under teacher forcing {['%.1e' % x for x in errs]}"
 
 
+def test_an_executor_switch_outside_its_domain_fails_the_creation(dev, monkeypatch):
+    """the executor's environment switches (MI355_WGRAD_STREAM, MI355_STREAM_K, MI355_FUSE_BN_BWD, MI355_STEM_FUSED, MI355_DS_COMPACT, the MI355_FP8_* ones) have
+    closed domains, read once at context creation: a mistyped value is an error with the switch's name, not a silent default"""
+    from sota_imagenet_amd.models import resnet50
+
+    m = resnet50(dtype="bf16").to(dev)
+    x = torch.zeros(2, 3, 64, 64, device=dev)
+    monkeypatch.setenv("MI355_WGRAD_STREAM", "off")
+    with pytest.raises(RuntimeError, match="MI355_WGRAD_STREAM=off"):
+        m.eval()(x)
+    monkeypatch.setenv("MI355_WGRAD_STREAM", "0")
+    assert m.eval()(x).shape == (2, 1000)
+
+
 @pytest.mark.parametrize("S", [160, 224, 320])
 def test_config5_batch_512_progressive_sizes(dev, S):
     """BASELINE.json configs[4]'s per-GPU shapes: batch 512 at the progressive-resize sizes 160 / 224 / 320 px, bf16, default
