@@ -158,6 +158,7 @@ struct Knobs {
   int po = 1;                // MI355_PO: the output-heavy pointwise kernels with resident weights (asm/po_gen.py); 1: the measured per-shape rule, 2: wherever a variant is legal
   int po64 = 1;              // MI355_PO64: the 64-column forms of po (layer 1's 1x1 launches into 64 channels): 0 leaves them on the implicit-GEMM kernel,
                              // 1: the measured per-shape rule, 2: wherever legal
+  int pool_keys = 1;         // MI355_POOL_KEYS: the stem's BN + ReLU + max pool on packed (value, tap) keys (misc.hip bn_relu_maxpool3_kernel; 0: the compare / select form)
   int po_bn = 1;             // MI355_PO_BN: bn2 + ReLU in conv3's operand path (po_*_s1_a0_bn: HBM-bound launches, the transform hides under the memory time)
   int dconv_bn = 0;          // MI355_DCONV_BN=1: bn1 + ReLU in conv2's operand path (dconv_*_s1_bn: the executor's training forward skips that bn_apply launch).
                              // Off by default: measured break-even (profiles/r06_ab_bn_in_operand_path.txt: the transform's VALU work is not hidden in a

@@ -250,6 +250,118 @@ __global__ void bn_relu_maxpool2_kernel(const T* __restrict__ y, const float* __
   }
 }
 
+// The same operator for bf16 on PACKED KEYS (round 6).  The kernel above is bound by its compare / select arithmetic (~19 VALU operations per input
+// element: 210 us for 565 MB = 2.7 TB/s).  After ReLU every value is a non-negative bf16, whose bit pattern orders like an unsigned integer, so
+// (value << 16) | (15 - tap code) is a key whose integer maximum is the window's maximum WITH the first-maximum tie rule of the scan above (equal values:
+// the smaller tap code wins): one v_lshl_or / v_and_or + one v_max_u32 per (element, window) instead of a compare and two selects, BatchNorm + ReLU on
+// packed pairs (round to bf16, then v_pk_max_i16 with 0), the ReLU bits from the packed values.  Identical pooled values and argmax codes; the ReLU bit is
+// (stored value != 0), which differs from (fp32 value > 0) only where a positive fp32 value rounds to a bf16 zero (below 2^-134).
+static __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {   // (hipcc turns min(x, 1) into a compare + select per half)
+  uint32_t r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+__global__ __launch_bounds__(256) void bn_relu_maxpool3_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                        bf16_t* __restrict__ p, uint8_t* __restrict__ idx, uint8_t* __restrict__ bits, int N, int H, int W, int C,
+                                        int Ho, int Wo) {
+  constexpr int V = 8;
+  const int cv = C / V;
+  const int Hb = Ho / 2, Wb = Wo / 2;
+  const size_t total = (size_t)N * Hb * Wb * cv;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cvi = (int)(i % cv);
+    const int c0 = cvi * V;
+    size_t t = i / cv;
+    const int bw = (int)(t % Wb);
+    t /= Wb;
+    const int bh = (int)(t % Hb);
+    const int n = (int)(t / Hb);
+    float sc[V], sh[V];
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(scale + c0 + 4 * q);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(shift + c0 + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[4 * q + e] = a[e];
+        sh[4 * q + e] = b[e];
+      }
+    }
+    uint32_t best[4][V];   // (value << 16) | (15 - code); every window has at least four taps, each key is >= 7: 0 is "none yet"
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int e = 0; e < V; ++e) best[w][e] = 0u;
+    const int ih0 = 4 * bh - 1, iw0 = 4 * bw - 1;  // top-left corner of the 5 x 5 patch
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int ih = ih0 + r;
+      if (r == 0 && bh == 0) continue;   // (H = 4 Hb, W = 4 Wb: only the patch's first row / column can lie outside the image)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const int iw = iw0 + c;
+        if (c == 0 && bw == 0) continue;
+        const size_t pix = ((size_t)n * H + ih) * W + iw;
+        const uint4 raw = *reinterpret_cast<const uint4*>(y + pix * C + c0);
+        const uint32_t d[4] = {raw.x, raw.y, raw.z, raw.w};
+        uint32_t pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = fmaf(__uint_as_float(d[j] << 16), sc[2 * j], sh[2 * j]);
+          const float hi = fmaf(__uint_as_float(d[j] & 0xffff0000u), sc[2 * j + 1], sh[2 * j + 1]);
+          typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+          typedef short s16x2 __attribute__((ext_vector_type(2)));
+          bf16x2 t2 = {(bf16_t)lo, (bf16_t)hi};                       // v_cvt_pk_bf16_f32 (RNE)
+          s16x2 s2 = __builtin_bit_cast(s16x2, t2);
+          s2 = __builtin_elementwise_max(s2, (s16x2){0, 0});          // ReLU on the packed pair: a negative bf16 (-0 included) is a negative int16
+          pk[j] = __builtin_bit_cast(uint32_t, s2);
+        }
+        if (r >= 1 && c >= 1) {  // rows / columns 1..4 of the patch are owned by this block: bit e = (stored value e != 0)
+          uint32_t t4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t4[j] = pk_min_u16(pk[j], 0x00010001u);   // 0 / 1 per half
+          const uint32_t g = (t4[0] | (t4[1] << 2)) | ((t4[2] | (t4[3] << 2)) << 4);   // even elements at bits 0, 2, 4, 6; odd ones at 16, 18, 20, 22
+          bits[pix * cv + cvi] = (uint8_t)((g & 0x55u) | ((g >> 15) & 0xaau));
+        }
+        // windows (dr, dc) of the block that contain patch element (r, c): kh = r - 2 dr, kw = c - 2 dc in 0..2
+#pragma unroll
+        for (int dr = 0; dr < 2; ++dr) {
+          const int kh = r - 2 * dr;
+          if (kh < 0 || kh > 2) continue;
+#pragma unroll
+          for (int dc = 0; dc < 2; ++dc) {
+            const int kw = c - 2 * dc;
+            if (kw < 0 || kw > 2) continue;
+            const int w = 2 * dr + dc;
+            const uint32_t code = 15u - (uint32_t)(kh * 3 + kw);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t klo = (pk[j] << 16) | code, khi = (pk[j] & 0xffff0000u) | code;
+              best[w][2 * j] = __builtin_elementwise_max(best[w][2 * j], klo);
+              best[w][2 * j + 1] = __builtin_elementwise_max(best[w][2 * j + 1], khi);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const size_t o = (((size_t)n * Ho + 2 * bh + (w >> 1)) * Wo + 2 * bw + (w & 1)) * C + c0;
+      uint4 v;
+      v.x = (best[w][0] >> 16) | (best[w][1] & 0xffff0000u);
+      v.y = (best[w][2] >> 16) | (best[w][3] & 0xffff0000u);
+      v.z = (best[w][4] >> 16) | (best[w][5] & 0xffff0000u);
+      v.w = (best[w][6] >> 16) | (best[w][7] & 0xffff0000u);
+      *reinterpret_cast<uint4*>(p + o) = v;
+      uint2 x;
+      x.x = (15u - (best[w][0] & 15u)) | ((15u - (best[w][1] & 15u)) << 8) | ((15u - (best[w][2] & 15u)) << 16) | ((15u - (best[w][3] & 15u)) << 24);
+      x.y = (15u - (best[w][4] & 15u)) | ((15u - (best[w][5] & 15u)) << 8) | ((15u - (best[w][6] & 15u)) << 16) | ((15u - (best[w][7] & 15u)) << 24);
+      *reinterpret_cast<uint2*>(idx + o) = x;
+    }
+  }
+}
+
 // Gather form (no atomics): one thread per 2 x 2 block of INPUT pixels and channel vector.  The four windows (a,b), (a,b+1), (a+1,b),
 // (a+1,b+1) are the only ones that touch the block (an even row / column lies in one window, an odd one in two), so 4 loads of
 // dy + argmax serve the 9 (pixel, window) pairs a thread per pixel fetched with 9 loads.  A pixel adds its windows in (oh, ow)
@@ -556,6 +668,8 @@ int launch_bn_relu_maxpool(int dtype, const void* y, const float* scale, const f
     if (dtype == MI355_F32)
       hipLaunchKernelGGL(bn_relu_maxpool2_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)y, scale, shift, (float*)p, idx, bits, N, H, W,
                          C, Ho, Wo);
+    else if (knobs().pool_keys)
+      hipLaunchKernelGGL(bn_relu_maxpool3_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, scale, shift, (bf16_t*)p, idx, bits, N, H, W, C, Ho, Wo);
     else
       hipLaunchKernelGGL(bn_relu_maxpool2_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, scale, shift, (bf16_t*)p, idx, bits, N,
                          H, W, C, Ho, Wo);

@@ -289,9 +289,12 @@ def _train_steps(dtype, env, steps=3, N=8, S=64):
     from sota_imagenet_amd.losses import CrossEntropyLoss
     from sota_imagenet_amd.optim import SGD
 
+    from sota_imagenet_amd import native
+
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
+        native.lib().mi355_reload_knobs()   # (library switches are cached: MI355_POOL_KEYS, ...; executor switches are read at context creation)
         m, _ = build(dtype)
         crit = CrossEntropyLoss(smoothing=0.1).cuda()
         opt = SGD([{"params": list(m.parameters())}], lr=0.05, momentum=0.9, weight_decay=3e-5)
@@ -314,6 +317,7 @@ def _train_steps(dtype, env, steps=3, N=8, S=64):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        native.lib().mi355_reload_knobs()
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -330,6 +334,19 @@ def test_side_stream_is_bitwise_neutral_and_runs_are_reproducible(dev, dtype):
         assert torch.equal(x, y), f"gradients of step {i}: side stream on vs off"
         assert torch.equal(x, z), f"gradients of step {i}: run to run"
     assert torch.equal(a[2], b[2]) and torch.equal(a[2], c[2])
+
+
+def test_stem_pool_on_packed_keys_is_bitwise_the_compare_select_kernel(dev):
+    """the stem's BN + ReLU + 3x3/2 max pool on packed (value << 16 | 15 - tap) keys (misc.hip bn_relu_maxpool3_kernel: integer maxima instead of a compare
+    and two selects per window element) against the compare / select form (MI355_POOL_KEYS=0): the pooled values, the argmax codes and the ReLU bits
+    feed everything downstream and the stem's backward, so three SGD steps must agree bit for bit in logits, every gradient and the parameters"""
+    a = _train_steps("bf16", {"MI355_POOL_KEYS": "1"})
+    b = _train_steps("bf16", {"MI355_POOL_KEYS": "0"})
+    for i, (x, y) in enumerate(zip(a[0], b[0])):
+        assert torch.equal(x, y), f"logits of step {i}"
+    for i, (x, y) in enumerate(zip(a[1], b[1])):
+        assert torch.equal(x, y), f"gradients of step {i}"
+    assert torch.equal(a[2], b[2])
 
 
 def test_fused_bn_backward_sums_match_standalone_reduce(dev):
