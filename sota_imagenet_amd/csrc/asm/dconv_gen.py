@@ -328,7 +328,7 @@ class Gen:
         self.s_ka = S.get(16, 4)         # the 8 pointers
         self.s_kb = S.get(4, 4)
         if c.s2d:
-            self.s_cls, self.s_clsoff, self.s_cNN, self.s_ntl = S.get(), S.get(), S.get(), S.get()
+            self.s_cls, self.s_clsoff, self.s_cNN = S.get(), S.get(), S.get()
         if c.bnin:
             assert c.stats in (0, 1) and not c.s2d
             self.srdA1 = S.get(4, 4)     # a (the normalised input) out: the window of srdA on the other tensor
@@ -418,18 +418,9 @@ class Gen:
         e("v_bfe_u32 %s, v0, 4, 2" % R("v", kg))
         e("s_nop 3")
         if c.s2d:
-            # ONE grid dimension: workgroup id = (tile / 8 * 4 nct + class * nct + column tile) * 8 + tile % 8 — the four classes (and the column tiles)
-            # of a tile are 8 ids apart: dispatched together and on ONE XCD (id % 8), so the dy tile they all stage is fetched from HBM once
-            # (class-major dispatch re-fetched it per class: 1.65 x the algorithmic bytes at layer 2, profiles/r06_pmc_per_conv_launch_bf16_serial.txt)
+            # workgroup id y = class * column tiles + column tile; the class's first output pixel (ph, pw) as a byte offset into the tile's window
             nct = c.NCOLS // c.BN
             assert nct & (nct - 1) == 0
-            e("s_load_dword %s, s[0:1], 0x70" % R("s", self.s_ntl), "tiles (the grid is padded to a multiple of 8 tiles)")
-            e("s_and_b32 %s, %s, 7" % (R("s", t0), R("s", self.s_tile)))
-            e("s_lshr_b32 %s, %s, 3" % (R("s", t1), R("s", self.s_tile)))
-            e("s_and_b32 %s, %s, %d" % (R("s", self.s_nt), R("s", t1), 4 * nct - 1))
-            e("s_lshr_b32 %s, %s, %d" % (R("s", t1), R("s", t1), (4 * nct).bit_length() - 1))
-            e("s_lshl_b32 %s, %s, 3" % (R("s", t1), R("s", t1)))
-            e("s_add_u32 %s, %s, %s" % (R("s", self.s_tile), R("s", t1), R("s", t0)))
             e("s_lshr_b32 %s, %s, %d" % (R("s", self.s_cls), R("s", self.s_nt), nct.bit_length() - 1))
             e("s_and_b32 %s, %s, %d" % (R("s", self.s_nt), R("s", self.s_nt), nct - 1))
             offs = [(ph * 2 * c.W + pw) * c.NCOLS * 2 for (ph, pw), _ in self.S2D_CLASSES]
@@ -514,11 +505,6 @@ class Gen:
 
         # ---- descriptors ------------------------------------------------------------------------------------------
         e("s_waitcnt lgkmcnt(0)")
-        if c.s2d:
-            e("s_cmp_lt_u32 %s, %s" % (R("s", self.s_tile), R("s", self.s_ntl)))
-            e("s_cbranch_scc1 %s" % (lab_run := self.newlabel("run")))
-            e("s_endpgm", "a padding workgroup of the grid")
-            self.label(lab_run)
         self.comment("descriptors: A = this tile's images, B = this column tile's weight rows, O = this tile's output pixels")
         tile_out = c.tile_rows * c.W * c.NCOLS * 2 * (4 if c.s2d else 1)
         rowb = c.W * c.Cin * 2

@@ -527,7 +527,6 @@ int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_r
   k.bn_invstd = a.bn_invstd;
   k.rsvd = nullptr;
   memset(k.pad, 0, sizeof(k.pad));
-  k.pad[0] = (unsigned)(a.N * v.TPI / v.IPT);   // tiles (the stride-2 data-gradient kernels run on a padded one-dimensional grid)
   memcpy(k.table, v.table, sizeof(k.table));
   if (v.bnin) {  // the pointer slots of the BN-backward sums carry the input's BatchNorm: a out, its bits out, [2][Ck] scale / shift
     k.bn_y = a.bn_in_a;
@@ -544,11 +543,8 @@ int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_r
   k.nchunks = (unsigned)(a.Ck / 64);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
   const int tiles = a.N * v.TPI / v.IPT;
-  const int ncls = v.s2d ? 4 : 1;
-  // stride-2 data gradient: ONE grid dimension, id = (tile / 8 * 4 nct + class * nct + column tile) * 8 + tile % 8 (the classes of a tile side by side on one XCD)
-  const unsigned gx = v.s2d ? (unsigned)((tiles + 7) / 8 * 8 * (a.Ncols / v.BN) * 4) : (unsigned)tiles;
-  const unsigned gy = v.s2d ? 1u : (unsigned)(a.Ncols / v.BN);
-  const hipError_t e = hipModuleLaunchKernel(d->fn[vi], gx, gy, 1, 256, 1, 1, 0, stream, nullptr, extra);
+  const int ncls = v.s2d ? 4 : 1;   // workgroup id y = class * column tiles + column tile: the long classes (4 taps) are dispatched first
+  const hipError_t e = hipModuleLaunchKernel(d->fn[vi], (unsigned)tiles, (unsigned)(a.Ncols / v.BN * ncls), 1, 256, 1, 1, 0, stream, nullptr, extra);
   if (e != hipSuccess) {
     set_error("dconv: hipModuleLaunchKernel(%s) -> %s", v.name, hipGetErrorString(e));
     return MI355_E_HIP;

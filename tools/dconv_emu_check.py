@@ -145,21 +145,17 @@ def run_s2d(name, tiles=(0,), ntile=0, classes=(0, 1, 2, 3), seed=0, check=True,
     invstd = (rng.integers(1, 5, size=c.NCOLS) * 0.5).astype(np.float32)
     a_y, a_bits, a_mu, a_is = mem.alloc(to_bf16_bits(yb)), mem.alloc(bits), mem.alloc(mean), mem.alloc(invstd)
     fields = [("q", a_in), ("q", a_wt), ("q", a_out), ("q", a_stat), ("q", a_y), ("q", a_bits), ("q", a_mu), ("q", a_is),
-              ("q", 0)] + [("I", wtap_of[t] * c.Cin * 2) for t in range(9)] + [("I", c.Cin // 64)] + [("I", ntiles_all)] + [("I", 0)] * 3
+              ("q", 0)] + [("I", wtap_of[t] * c.Cin * 2) for t in range(9)] + [("I", c.Cin // 64)] + [("I", 0)] * 4
     fields += [("I", x) for par in dconv_gen.tables(c) for row in par for x in row]
     ka = gcn_emu.pack_kernarg(fields)
     assert len(ka) == dconv_gen.Gen.KA["size"], len(ka)
     a_ka = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     nct = c.NCOLS // c.BN
-    wg = lambda t, k, ct: ((t // 8) * 4 * nct + k * nct + ct) * 8 + t % 8    # one grid dimension: the classes of a tile 8 ids apart (one XCD)
     total = 0
     for t in tiles:
         for k in classes:
             emu = gcn_emu.Emulator(text, mem, lds_bytes=g.lds_bytes, check=check, dontcare=[(c.ABASE + (b + 1) * c.ABUF, c.ABASE + (b + 1) * c.ABUF + 256) for b in range(2)])
-            total += emu.run_workgroup(4, a_ka, wg_id=(wg(t, k, ntile), 0, 0))
-    # a padding workgroup of the grid (tile index >= tiles) ends without touching memory (checked by the untouched outputs below)
-    emu = gcn_emu.Emulator(text, mem, lds_bytes=g.lds_bytes, check=check)
-    emu.run_workgroup(4, a_ka, wg_id=(wg(ntiles_all, 0, 0), 0, 0))
+            total += emu.run_workgroup(4, a_ka, wg_id=(t, k * nct + ntile, 0))
     got = from_bf16_bits(mem.array(a_out, np.uint16, out0.shape)).astype(np.float64).reshape(N * H2, W2, c.NCOLS)
     refr = bf16_round(ref.astype(np.float32)).astype(np.float64).reshape(N * H2, W2, c.NCOLS)
     cols = slice(ntile * c.BN, ntile * c.BN + c.BN)
