@@ -581,6 +581,146 @@ __global__ void k32_b1(int iters, const i32x4* __restrict__ src, float* out, uns
   if ((threadIdx.x & 63) == 0) { st[(size_t)(t >> 6) * 2] = t1 - t0; st[(size_t)(t >> 6) * 2 + 1] = r1 - r0; }
 }
 
+// e4m3 x e4m3 at K = 128 (the non-scaled f8f6f4 form, cbsz = blgp = 0): 8 x 16x16x128 per body = 4 x the FLOP of a bf16 body
+__global__ void k8(int iters, const i32x4* __restrict__ src, float* out, unsigned long long* st) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const i32x4* p = src + (size_t)t * 16;
+  unsigned long long t0, t1, r0, r1; float res; int n = iters / 8;
+  asm volatile(
+    "global_load_dwordx4 v[64:67], %[p], off offset:0\n"
+    "global_load_dwordx4 v[68:71], %[p], off offset:16\n"
+    "global_load_dwordx4 v[72:75], %[p], off offset:32\n"
+    "global_load_dwordx4 v[76:79], %[p], off offset:48\n"
+    "global_load_dwordx4 v[80:83], %[p], off offset:64\n"
+    "global_load_dwordx4 v[84:87], %[p], off offset:80\n"
+    "global_load_dwordx4 v[88:91], %[p], off offset:96\n"
+    "global_load_dwordx4 v[92:95], %[p], off offset:112\n"
+    "global_load_dwordx4 v[96:99], %[p], off offset:128\n"
+    "global_load_dwordx4 v[100:103], %[p], off offset:144\n"
+    "global_load_dwordx4 v[104:107], %[p], off offset:160\n"
+    "global_load_dwordx4 v[108:111], %[p], off offset:176\n"
+    "global_load_dwordx4 v[112:115], %[p], off offset:192\n"
+    "global_load_dwordx4 v[116:119], %[p], off offset:208\n"
+    "global_load_dwordx4 v[120:123], %[p], off offset:224\n"
+    "global_load_dwordx4 v[124:127], %[p], off offset:240\n"
+    "s_waitcnt vmcnt(0)\n"
+    "v_accvgpr_write_b32 a0, 0\n"
+    "v_accvgpr_write_b32 a1, 0\n"
+    "v_accvgpr_write_b32 a2, 0\n"
+    "v_accvgpr_write_b32 a3, 0\n"
+    "v_accvgpr_write_b32 a4, 0\n"
+    "v_accvgpr_write_b32 a5, 0\n"
+    "v_accvgpr_write_b32 a6, 0\n"
+    "v_accvgpr_write_b32 a7, 0\n"
+    "v_accvgpr_write_b32 a8, 0\n"
+    "v_accvgpr_write_b32 a9, 0\n"
+    "v_accvgpr_write_b32 a10, 0\n"
+    "v_accvgpr_write_b32 a11, 0\n"
+    "v_accvgpr_write_b32 a12, 0\n"
+    "v_accvgpr_write_b32 a13, 0\n"
+    "v_accvgpr_write_b32 a14, 0\n"
+    "v_accvgpr_write_b32 a15, 0\n"
+    "v_accvgpr_write_b32 a16, 0\n"
+    "v_accvgpr_write_b32 a17, 0\n"
+    "v_accvgpr_write_b32 a18, 0\n"
+    "v_accvgpr_write_b32 a19, 0\n"
+    "v_accvgpr_write_b32 a20, 0\n"
+    "v_accvgpr_write_b32 a21, 0\n"
+    "v_accvgpr_write_b32 a22, 0\n"
+    "v_accvgpr_write_b32 a23, 0\n"
+    "v_accvgpr_write_b32 a24, 0\n"
+    "v_accvgpr_write_b32 a25, 0\n"
+    "v_accvgpr_write_b32 a26, 0\n"
+    "v_accvgpr_write_b32 a27, 0\n"
+    "v_accvgpr_write_b32 a28, 0\n"
+    "v_accvgpr_write_b32 a29, 0\n"
+    "v_accvgpr_write_b32 a30, 0\n"
+    "v_accvgpr_write_b32 a31, 0\n"
+    "s_nop 7\n"
+    "s_memtime %[t0]\n"
+    "s_memrealtime %[r0]\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "1:\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[0:3], v[96:103], v[64:71], a[0:3]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[4:7], v[104:111], v[72:79], a[4:7]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[8:11], v[112:119], v[80:87], a[8:11]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[12:15], v[120:127], v[88:95], a[12:15]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[16:19], v[96:103], v[64:71], a[16:19]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[20:23], v[104:111], v[72:79], a[20:23]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[24:27], v[112:119], v[80:87], a[24:27]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[28:31], v[120:127], v[88:95], a[28:31]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[0:3], v[104:111], v[64:71], a[0:3]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[4:7], v[112:119], v[72:79], a[4:7]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[8:11], v[120:127], v[80:87], a[8:11]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[12:15], v[96:103], v[88:95], a[12:15]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[16:19], v[104:111], v[64:71], a[16:19]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[20:23], v[112:119], v[72:79], a[20:23]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[24:27], v[120:127], v[80:87], a[24:27]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[28:31], v[96:103], v[88:95], a[28:31]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[0:3], v[112:119], v[64:71], a[0:3]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[4:7], v[120:127], v[72:79], a[4:7]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[8:11], v[96:103], v[80:87], a[8:11]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[12:15], v[104:111], v[88:95], a[12:15]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[16:19], v[112:119], v[64:71], a[16:19]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[20:23], v[120:127], v[72:79], a[20:23]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[24:27], v[96:103], v[80:87], a[24:27]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[28:31], v[104:111], v[88:95], a[28:31]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[0:3], v[120:127], v[64:71], a[0:3]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[4:7], v[96:103], v[72:79], a[4:7]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[8:11], v[104:111], v[80:87], a[8:11]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[12:15], v[112:119], v[88:95], a[12:15]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[16:19], v[120:127], v[64:71], a[16:19]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[20:23], v[96:103], v[72:79], a[20:23]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[24:27], v[104:111], v[80:87], a[24:27]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[28:31], v[112:119], v[88:95], a[28:31]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[0:3], v[96:103], v[64:71], a[0:3]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[4:7], v[104:111], v[72:79], a[4:7]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[8:11], v[112:119], v[80:87], a[8:11]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[12:15], v[120:127], v[88:95], a[12:15]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[16:19], v[96:103], v[64:71], a[16:19]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[20:23], v[104:111], v[72:79], a[20:23]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[24:27], v[112:119], v[80:87], a[24:27]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[28:31], v[120:127], v[88:95], a[28:31]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[0:3], v[104:111], v[64:71], a[0:3]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[4:7], v[112:119], v[72:79], a[4:7]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[8:11], v[120:127], v[80:87], a[8:11]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[12:15], v[96:103], v[88:95], a[12:15]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[16:19], v[104:111], v[64:71], a[16:19]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[20:23], v[112:119], v[72:79], a[20:23]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[24:27], v[120:127], v[80:87], a[24:27]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[28:31], v[96:103], v[88:95], a[28:31]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[0:3], v[112:119], v[64:71], a[0:3]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[4:7], v[120:127], v[72:79], a[4:7]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[8:11], v[96:103], v[80:87], a[8:11]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[12:15], v[104:111], v[88:95], a[12:15]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[16:19], v[112:119], v[64:71], a[16:19]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[20:23], v[120:127], v[72:79], a[20:23]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[24:27], v[96:103], v[80:87], a[24:27]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[28:31], v[104:111], v[88:95], a[28:31]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[0:3], v[120:127], v[64:71], a[0:3]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[4:7], v[96:103], v[72:79], a[4:7]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[8:11], v[104:111], v[80:87], a[8:11]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[12:15], v[112:119], v[88:95], a[12:15]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[16:19], v[120:127], v[64:71], a[16:19]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[20:23], v[96:103], v[72:79], a[20:23]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[24:27], v[104:111], v[80:87], a[24:27]\n"
+    "v_mfma_f32_16x16x128_f8f6f4 a[28:31], v[112:119], v[88:95], a[28:31]\n"
+    "s_sub_u32 %[n], %[n], 1\n"
+    "s_cmp_lg_u32 %[n], 0\n"
+    "s_cbranch_scc1 1b\n"
+    "s_nop 15\n"
+    "s_nop 15\n"
+    "s_memtime %[t1]\n"
+    "s_memrealtime %[r1]\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "v_accvgpr_read_b32 %[res], a0\n"
+    : [t0] "=s"(t0), [t1] "=s"(t1), [r0] "=s"(r0), [r1] "=s"(r1), [res] "=v"(res), [n] "+s"(n)
+    : [p] "v"(p)
+    : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "scc", "memory");
+  out[t] = res;
+  if ((threadIdx.x & 63) == 0) { st[(size_t)(t >> 6) * 2] = t1 - t0; st[(size_t)(t >> 6) * 2 + 1] = r1 - r0; }
+}
+
 static uint16_t bf16_of(float f) {
   uint32_t u;
   memcpy(&u, &f, 4);
@@ -588,7 +728,7 @@ static uint16_t bf16_of(float f) {
 }
 
 template <typename K>
-static void run(const char* name, const char* data, K kern, int per_trip, const i32x4* src, float* out, unsigned long long* st, int nwaves) {
+static void run(const char* name, const char* data, K kern, int per_trip, const i32x4* src, float* out, unsigned long long* st, int nwaves, double flop_per_body = 131072.0) {
   const int cus = 256, wpc = 4, iters = 4000000;   // ~0.3-0.5 s per launch: long enough for the clock to settle
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
@@ -612,7 +752,7 @@ static void run(const char* name, const char* data, K kern, int per_trip, const 
   }
   std::sort(cyc.begin(), cyc.end());
   std::sort(clk.begin(), clk.end());
-  const double flop = 131072.0 * iters * cus * wpc;
+  const double flop = flop_per_body * iters * cus * wpc;
   printf("%-30s %-7s %8.1f TFLOP/s   %6.2f cycles per instruction and wave (median)   in-kernel clock %.3f GHz (median; min %.3f max %.3f)   %.1f ms\n", name, data,
          flop / (best * 1e-3) * 1e-12, cyc[cyc.size() / 2], clk[clk.size() / 2], clk.front(), clk.back(), best);
 }
@@ -636,12 +776,25 @@ int main() {
   CK(hipMalloc(&st, (size_t)nwaves * 16));
   CK(hipMemcpy(dr, hr.data(), hr.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(dz, hz.data(), hz.size() * 2, hipMemcpyHostToDevice));
+  // random e4m3 bytes without the NaN codes (0x7f / 0xff): magnitudes spread over the whole format
+  std::vector<uint8_t> h8(hr.size() * 2);
+  for (auto& x : h8) {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    uint8_t v = (uint8_t)(s >> 33);
+    if ((v & 0x7f) == 0x7f) v ^= 1;
+    x = v;
+  }
+  i32x4* d8;
+  CK(hipMalloc(&d8, h8.size()));
+  CK(hipMemcpy(d8, h8.data(), h8.size(), hipMemcpyHostToDevice));
   printf("one wave per SIMD (4 per CU, 256 workgroups), operands in VGPRs, accumulators in AGPRs, 131072 FLOP per wave and trip, 4000000 trips\n");
   for (int rep = 0; rep < 2; ++rep) {
     run("v_mfma_f32_16x16x32_bf16", "random", k16, 8, dr, out, st, nwaves);
     run("v_mfma_f32_16x16x32_bf16 b1", "random", k16_b1, 8, dr, out, st, nwaves);
     run("v_mfma_f32_32x32x16_bf16", "random", k32, 4, dr, out, st, nwaves);
     run("v_mfma_f32_32x32x16_bf16 b1", "random", k32_b1, 4, dr, out, st, nwaves);
+    run("v_mfma_f32_16x16x128_f8f6f4", "random", k8, 8, d8, out, st, nwaves, 4 * 131072.0);
+    run("v_mfma_f32_16x16x128_f8f6f4", "zeros", k8, 8, dz, out, st, nwaves, 4 * 131072.0);
     run("v_mfma_f32_16x16x32_bf16", "zeros", k16, 8, dz, out, st, nwaves);
     run("v_mfma_f32_32x32x16_bf16", "zeros", k32, 4, dz, out, st, nwaves);
   }
