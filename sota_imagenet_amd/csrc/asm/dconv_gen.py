@@ -57,8 +57,20 @@ class Cfg:
     bnin: int = 0     # 1: the input is the RAW output y of the previous convolution: its BatchNorm + ReLU (a = relu(y * scale[c] + shift[c]), what
                       # bn_apply_kernel computes) is applied to the staged tile in LDS before the taps read it, and the kernel leaves a and its ReLU
                       # bit mask in memory as a by-product (every later reader of a — the weight gradient, the BN backward — is unchanged); forward only
+    fp8: int = 0      # 1: e4m3 operands (input tensor and weights: one byte per element), bf16 output = accumulator * oscale / (scale_in * scale_wt): a chunk
+                      # is 128 channels in the SAME 128-byte LDS rows, the two 16-byte reads per lane that feed two 16x16x32 bf16 MFMAs are the 32-byte
+                      # operand of ONE v_mfma_f32_16x16x128_f8f6f4 (k is a summation index: the same bytes on both sides) — the stage of a tap does twice
+                      # the channels in the same MFMA time (tools/micro/mfma_shape_random.hip: 4.06 against 2.02 PFLOP/s on random data)
     s2d: int = 0      # 1: the data gradient of a 3x3 / stride-2 convolution: H x W is the dy image the tile stages, the output is 2H x 2W; four
                       # kernel classes (output parities, Gen.class_stages), workgroup id y = class * column tiles + column tile
+
+    @property
+    def ES(self):     # bytes per input / weight element
+        return 1 if self.fp8 else 2
+
+    @property
+    def CH(self):     # channels per chunk (= one 128-byte LDS row)
+        return 128 // self.ES
 
     @property
     def BN(self):     # output columns per workgroup
@@ -74,7 +86,7 @@ class Cfg:
 
     @property
     def NA(self):     # A buffers: the tile of chunk c + 1 lands while chunk c is computed; one chunk (Cin = 64) needs one buffer
-        return 1 if self.Cin == 64 else 2
+        return 1 if self.Cin == self.CH else 2
 
     @property
     def BBASE(self):
@@ -122,7 +134,7 @@ class Cfg:
 
     @property
     def w_row(self):  # bytes of one weight row [taps][Cin]
-        return 9 * self.Cin * 2
+        return 9 * self.Cin * self.ES
 
     @property
     def tile_rows(self):
@@ -142,13 +154,13 @@ def a_rows(c, cls):
     for g in range(c.LROWS):
         if c.ROWS_T:
             dead = (cls == 0 and g == 0) or (cls == 2 and g == c.LROWS - 1) or (c.TPI == 1 and g in (0, c.LROWS - 1))
-            rows.append((g, None if dead else g * c.W * c.Cin * 2))
+            rows.append((g, None if dead else g * c.W * c.Cin * c.ES))
         elif c.IPT == 1:
-            rows.append((g, (g - 1) * c.W * c.Cin * 2 if 1 <= g <= c.H else None))
+            rows.append((g, (g - 1) * c.W * c.Cin * c.ES if 1 <= g <= c.H else None))
         else:
             i, y = divmod(g - 1, c.SR) if g >= 1 else (0, -1)
             ok = g >= 1 and y < c.H and i < c.IPT
-            rows.append((g, ((i * c.H + y) * c.W) * c.Cin * 2 if ok else None))
+            rows.append((g, ((i * c.H + y) * c.W) * c.Cin * c.ES if ok else None))
     return rows
 
 
@@ -310,7 +322,7 @@ class Gen:
         self.srdO = S.get(4, 4)
         self.srdX = S.get(4, 4)   # statistics rows
         # the piece table of this wave: in SGPRs (scalar loads, as many as 24 words) or, when larger, in a VGPR read with v_readlane
-        self.tab_sgpr = (2 * NPA + c.NPB <= 24) and c.TPI == 1 and not (c.s2d and c.stats == 2) and not c.bnin   # (s2d + BN-backward sums, bnin: out of SGPRs)
+        self.tab_sgpr = (2 * NPA + c.NPB <= 24) and c.TPI == 1 and not (c.s2d and c.stats == 2) and not c.bnin and not c.fp8   # (s2d + BN-backward sums, bnin, fp8: out of SGPRs)
         if not self.tab_sgpr:
             self.srdK = S.get(4, 4)   # the piece tables in the kernarg segment
         if c.stats == 2:
@@ -329,6 +341,9 @@ class Gen:
         self.s_kb = S.get(4, 4)
         if c.s2d:
             self.s_cls, self.s_clsoff, self.s_cNN = S.get(), S.get(), S.get()
+        if c.fp8:
+            self.s_sci = S.get(2, 2)      # scale_in pointer (kernarg slot `rsvd`)
+            self.s_x4 = S.get(4, 4)       # kernarg 0x70: -, oscale, scale_wt pointer
         if c.bnin:
             assert c.stats in (0, 1) and not c.s2d
             self.srdA1 = S.get(4, 4)     # a (the normalised input) out: the window of srdA on the other tensor
@@ -347,7 +362,15 @@ class Gen:
         self.v_tab = V.get()             # this wave's piece table: word i in lane i (read with v_readlane)
         self.v_kg = V.get()              # lane >> 4 (kept for the epilogue)
         self.F = []
-        for s in range(2):
+        if c.fp8:
+            # 8-register operands (both 16-byte halves of a lane's 32 bytes): two whole sets of pixel fragments (the next stage's are read under this
+            # stage's MFMAs) and four rolling slots for the weight fragments (column n + 2's slot is read while column n computes)
+            assert c.NB == 3 and not c.bnin
+            self.A8 = [V.get(8 * c.MFR, 4), V.get(8 * c.MFR, 4)]
+            self.B8 = [V.get(8, 4) for _ in range(4)]
+            # (the epilogue and the prologue use the fragment registers as temporaries)
+            self.F = [(self.A8[0], self.A8[0] + 4 * c.MFR), (self.A8[1], self.B8[3] + 8 - 4 * c.NT)]
+        for s in range(0 if c.fp8 else 2):
             fa = V.get(4 * c.MFR, 4)
             fb = V.get(4 * c.NT, 4)
             self.F.append((fa, fb))
@@ -358,10 +381,25 @@ class Gen:
             # BN-backward sums: y / mask of the same (pixel, 8 channels) vectors as the output in two register sets, mean / invstd of
             # this lane's 8 channels per tile pair.  The sets of pairs 0 and 1 are loaded in the PROLOGUE (the main loop does not
             # touch these registers), pairs 2 and 3 under the arithmetic of pairs 0 and 1.
-            self.ysets = [[V.get(4, 4) for m in range(c.MFR)] for _ in range(2)]
-            self.msets = [V.get(16, 4) for _ in range(2)]   # mean[8], invstd[8]
+            if c.fp8:
+                # (e4m3: the 8-register operands leave no room for two sets: the second one is loaded at the start of the epilogue INTO the fragment
+                # registers, free by then; the epilogue's temporaries use the first 51 of them)
+                self.late_pair1 = True
+                f0 = self.A8[0]
+                free = list(range(f0 + 52, f0 + 16 * c.MFR)) + [r + i for r in self.B8 for i in range(8)]
+                free4 = [r for r in free if r % 4 == 0 and all(r + i in free for i in range(4))]
+                m1 = next(r for r in free4 if all(r + i in free for i in range(16)))
+                y1 = [r for r in free4 if not (m1 <= r < m1 + 16)][:c.MFR]
+                assert len(y1) == c.MFR, "no room for the late register set"
+                self.ysets = [[V.get(4, 4) for m in range(c.MFR)], y1]
+                self.msets = [V.get(16, 4), m1]
+            else:
+                self.ysets = [[V.get(4, 4) for m in range(c.MFR)] for _ in range(2)]
+                self.msets = [V.get(16, 4) for _ in range(2)]   # mean[8], invstd[8]
             self.v_chan = V.get()
             self.alloc_tile_masks()
+        if c.fp8:
+            self.v_osc = V.get()             # oscale / (scale_in * scale_wt): applied to the accumulators before the one bf16 rounding
         if c.bnin:
             self.v_tab2 = V.get()            # this wave's transform table (ttables): word i in lane i
             self.v_lane16 = V.get()          # lane * 16: a lane transforms the 16 bytes its LDS-DMA lane wrote
@@ -410,6 +448,9 @@ class Gen:
         e("s_load_dwordx16 %s, s[0:1], 0x0" % R("s", ka, 16))       # in, wt, out, stat, bn_y, bn_bits, bn_mean, bn_invstd
         e("s_load_dwordx8 %s, s[0:1], 0x48" % R("s", self.s_wt, 8))  # wtap[0..7]
         e("s_load_dwordx2 %s, s[0:1], 0x68" % R("s", kb + 2, 2))    # wtap[8], nchunks
+        if c.fp8:
+            e("s_load_dwordx2 %s, s[0:1], 0x40" % R("s", self.s_sci, 2), "scale_in (device scalar) or null")
+            e("s_load_dwordx4 %s, s[0:1], 0x70" % R("s", self.s_x4, 4), "-, oscale, scale_wt")
         lane, r, kg = v[0], v[1], v[2]
         e("v_lshrrev_b32 %s, 6, v0" % R("v", v[3]))
         e("v_and_b32 %s, 63, v0" % R("v", lane))
@@ -483,7 +524,7 @@ class Gen:
             if xb * 8 > c.W:
                 continue
             e("v_add_u32 %s, %d, %s" % (R("v", x), xb * 8 - 1, R("v", l3)), "input x of this lane's position")
-            e("v_mov_b32 %s, %d" % (R("v", off), c.Cin * 2))
+            e("v_mov_b32 %s, %d" % (R("v", off), c.Cin * c.ES))
             e("v_mad_u32_u24 %s, %s, %s, %s" % (R("v", off), R("v", x), R("v", off), R("v", j)))
             e("v_cmp_gt_u32 vcc, %d, %s" % (c.W, R("v", x)), "0 <= x < W (x = -1 wraps to 2^32 - 1)")
             e("v_mov_b32 %s, 0x80000000" % R("v", x))
@@ -505,9 +546,24 @@ class Gen:
 
         # ---- descriptors ------------------------------------------------------------------------------------------
         e("s_waitcnt lgkmcnt(0)")
+        if c.fp8:
+            # output scale: oscale alone, or oscale / (*scale_in * *scale_wt) with the two per-tensor scales read from device memory (delayed scaling)
+            lab = self.newlabel("noscale")
+            e("v_mov_b32 %s, %s" % (R("v", self.v_osc), R("s", self.s_x4 + 1)))
+            e("s_cmp_eq_u64 %s, 0" % R("s", self.s_sci, 2))
+            e("s_cbranch_scc1 %s" % lab)
+            e("s_load_dword %s, %s, 0x0" % (R("s", t0), R("s", self.s_sci, 2)))
+            e("s_load_dword %s, %s, 0x0" % (R("s", t1), R("s", self.s_x4 + 2, 2)))
+            e("s_waitcnt lgkmcnt(0)")
+            e("v_mov_b32 %s, %s" % (R("v", self.v_osc), R("s", t0)))
+            e("v_mul_f32 %s, %s, %s" % (R("v", self.v_osc), R("s", t1), R("v", self.v_osc)))
+            e("v_rcp_f32 %s, %s" % (R("v", self.v_osc), R("v", self.v_osc)))
+            e("s_nop 1")
+            e("v_mul_f32 %s, %s, %s" % (R("v", self.v_osc), R("s", self.s_x4 + 1), R("v", self.v_osc)))
+            self.label(lab)
         self.comment("descriptors: A = this tile's images, B = this column tile's weight rows, O = this tile's output pixels")
         tile_out = c.tile_rows * c.W * c.NCOLS * 2 * (4 if c.s2d else 1)
-        rowb = c.W * c.Cin * 2
+        rowb = c.W * c.Cin * c.ES
         if c.ROWS_T:
             # A window of a row tile: LROWS image rows starting ONE ROW ABOVE the tile (the first tile of an image never touches
             # that row, the last never the row below: those table slots repeat another piece).  tile*ROWS_T rows - 1 row, 64-bit
@@ -581,7 +637,7 @@ class Gen:
             for i in range(self.NPA):
                 for ins in self.a_piece_insts(i, 0, self.s_cC):
                     e(ins)
-            for st in range(1, c.NB):
+            for st in range(1, c.NB - (1 if c.fp8 else 0)):   # (fp8: stage t requests stage t + 2 itself)
                 self.first_stage_issue(st)
 
 
@@ -656,7 +712,8 @@ class Gen:
             e("s_mul_i32 %s, %s, %d" % (R("s", t0), R("s", self.s_wn), c.NT * 16 * 4))
             e("v_lshl_add_u32 %s, %s, 5, %s" % (R("v", self.v_chan), R("v", self.v_kg), R("s", t0)), "this lane's 8 floats of mean / invstd")
             self.epi_issue_loads(0)
-            self.epi_issue_loads(1)
+            if not getattr(self, "late_pair1", False):
+                self.epi_issue_loads(1)
             first_loads()
         else:
             first_loads()
@@ -694,7 +751,7 @@ class Gen:
         # accumulators = 0
         for i in range(self.nagpr):
             e("v_accvgpr_write_b32 a%d, 0" % i)
-        e("s_waitcnt vmcnt(%d)" % (c.NPB * (c.NB - 1)))
+        e("s_waitcnt vmcnt(%d)" % (c.NPB * (c.NB - 1 - (1 if c.fp8 else 0))))
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier")
         if c.bnin:
@@ -717,8 +774,12 @@ class Gen:
         # fragments of (stage 0, kk 0)
         rt0 = {stg[0][0] for stg in self.class_stages()}
         assert len(rt0) == 1, "every class starts with the same read tap (the first fragment reads are common)"
-        for ins in self.frag_reads(0, rt0.pop(), 0, 0):
-            e(ins)
+        if c.fp8:
+            for ins in self.a8_reads(0, rt0.pop()) + self.b8_reads(0, 0) + self.b8_reads(1, 0):
+                e(ins)
+        else:
+            for ins in self.frag_reads(0, rt0.pop(), 0, 0):
+                e(ins)
         e("s_mov_b32 %s, %s" % (R("s", self.s_cnt), R("s", self.s_nch)))
 
     def zero_blocks(self, blocks):
@@ -1046,7 +1107,116 @@ class Gen:
                 e("s_branch %s" % l_epi)
         self.label(l_epi)
 
+    # ---- Cfg.fp8 ---------------------------------------------------------------------------------------------------------------------------------------
+    def a8_reads(self, aset, rt):
+        """the pixel fragments of read tap rt into A set `aset`: two ds_read_b128 per fragment (chunks kg and kg + 4 of the row: this lane's 32 bytes)"""
+        c = self.c
+        ky, kx = divmod(rt, 3)
+        return ["ds_read_b128 %s, %s offset:%d" % (R("v", self.A8[aset] + 8 * m + 4 * kk, 4), R("v", self.vA_rd[kx][kk]), m * 2048 + ky * c.P * 128)
+                for m in range(c.MFR) for kk in range(2)]
+
+    def b8_reads(self, n, bp):
+        """the weight fragment of column n from ring stage bp into slot n % 4"""
+        return ["ds_read_b128 %s, %s offset:%d" % (R("v", self.B8[n % 4] + 4 * kk, 4), R("v", self.vB_rd[bp][kk]), n * 2048) for kk in range(2)]
+
+    def mfma8_col(self, n, aset):
+        c = self.c
+        return ["v_mfma_f32_16x16x128_f8f6f4 %s, %s, %s, %s" % (R("a", (m * c.NT + n) * 4, 4), R("v", self.B8[n % 4], 8), R("v", self.A8[aset] + 8 * m, 8), R("a", (m * c.NT + n) * 4, 4))
+                for m in range(c.MFR)]
+
+    def mainloop_fp8(self, stages):
+        """e4m3 operands: a stage = one tap of a 128-channel chunk = NT columns of MFR v_mfma_f32_16x16x128_f8f6f4.  Weight ring of THREE stages: stage t
+        requests stage t + 2 (into the slot stage t - 1 released at its barrier) in its first columns; the stage barrier stands in front of column NT - 2,
+        behind the last weight-fragment read of the stage, and the next stage's first two weight fragments (and, at a chunk switch, its pixel fragments)
+        are read behind it; within a chunk the next tap's pixel fragments are read in the columns before the barrier."""
+        c, e = self.c, self.e
+        T, NT = len(stages), c.NT
+        L = c.NA * T
+        assert (L % c.NB == 0 or c.NA == 1) and T % c.NB == 0 and NT >= 4 and (T - 1 + c.NB - 1) // T <= 1
+        ntap_a, aps = self.a_carriers(T)
+        self.comment("---- main loop (e4m3): chunks (2 per trip) x %d taps x %d columns of %d MFMAs" % (T, NT, c.MFR))
+        top, done = self.newlabel("loop"), self.newlabel("done")
+        self.label(top)
+        body = len(self.out)
+        aset = 0
+        for cp in range(c.NA):
+            if c.NA == 1:
+                e("s_mov_b32 %s, 0" % R("s", self.s_cN), "one chunk: the weight stages past the last tap re-load chunk 0 (never used)")
+            else:
+                e("s_add_u32 %s, %s, 128" % (R("s", self.s_cN), R("s", self.s_cC)))
+                e("s_cmp_eq_u32 %s, 1" % R("s", self.s_cnt))
+                e("s_cbranch_scc0 %s" % (lab := self.newlabel("notlast")))
+                e("s_mov_b32 %s, 0" % R("s", self.s_cN))
+                self.label(lab)
+            for t in range(T):
+                rt, ws = stages[t]
+                q = cp * T + t
+                bp, bp1, bp2 = q % c.NB, (q + 1) % c.NB, (q + 2) % c.NB
+                t1 = (t + 1) % T
+                switch = (t == T - 1 and c.NA == 2)           # the next stage reads the other A buffer
+                # vector-memory requests of the stage, in its first columns: next chunk's A pieces, then the weight pieces of stage t + 2
+                t3 = (t + 2) % T
+                s_ch = self.s_cC if t + 2 < T else self.s_cN
+                vm = [self.a_piece_insts(k, cp ^ 1, self.s_cN, "A") for k in range(t * aps, min((t + 1) * aps, self.NPA))] if (c.NA == 2 and t < ntap_a) else []
+                for i in range(c.NPB):
+                    g = self.b_piece_insts(i, bp2, self.s_stg, "B%d" % ((q + 2) % L))
+                    if i == 0:
+                        g = ["s_add_u32 %s, %s, %s" % (R("s", self.s_stg), R("s", self.s_wt + stages[t3][1]), R("s", s_ch))] + g
+                    vm.append(g)
+                if c.probe & 1:
+                    vm = []
+                # the next tap's pixel fragments: before the barrier within a chunk, behind it at a chunk switch
+                a_next = [[r] for r in self.a8_reads(aset ^ 1, stages[t1][0])]
+                pre = NT - 2
+                for n in range(NT):
+                    self.comment("chunk parity %d tap %d column %d" % (cp, t, n))
+                    e("s_waitcnt lgkmcnt(0)")
+                    if n == pre:
+                        need = ["B%d" % ((q + 1) % L)] + (["A"] if switch else [])
+                        e("s_waitcnt vmcnt(@need:%s@)" % ",".join(need))
+                        if not c.probe & 4:
+                            e("s_barrier")
+                        if switch:
+                            d = c.ASTRIDE if cp == 0 else -c.ASTRIDE
+                            for kx in range(3):
+                                for kk in range(2):
+                                    rr = R("v", self.vA_rd[kx][kk])
+                                    e("v_add_u32 %s, %d, %s" % (rr, d, rr) if d > 0 else "v_subrev_u32 %s, %d, %s" % (rr, -d, rr))
+                    groups = []
+                    if n + 2 < NT:
+                        groups.append(self.b8_reads(n + 2, bp))
+                    else:
+                        groups.append(self.b8_reads(n + 2 - NT, bp1))
+                    if switch:
+                        if n >= pre:
+                            k0 = (n - pre) * len(a_next) // 2
+                            groups += a_next[k0:k0 + (len(a_next) + 1) // 2] if n == pre else a_next[k0:]
+                    elif n < pre:
+                        per = -(-len(a_next) // pre)
+                        groups += a_next[n * per:(n + 1) * per]
+                    if n < pre:
+                        per = -(-len(vm) // pre)
+                        groups = self.merge(groups, vm[n * per:(n + 1) * per])
+                    if c.probe & 2:
+                        groups = [g for g in groups if not g[0].startswith("ds_read")]
+                    self.interleave(self.mfma8_col(n, aset), groups, first=0)
+                aset ^= 1
+            if c.NA == 1:
+                break
+            e("s_mov_b32 %s, %s" % (R("s", self.s_cC), R("s", self.s_cN)))
+            e("s_sub_u32 %s, %s, 1" % (R("s", self.s_cnt), R("s", self.s_cnt)))
+            e("s_cmp_eq_u32 %s, 0" % R("s", self.s_cnt))
+            if cp == 0:
+                e("s_cbranch_scc1 %s" % done)
+            else:
+                e("s_cbranch_scc0 %s" % top)
+        assert c.NA == 1 or aset == 0 or (c.NA * T) % 2 == 0
+        self.patch_waits(body)
+        self.label(done)
+
     def mainloop_of(self, stages):
+        if self.c.fp8:
+            return self.mainloop_fp8(stages)
         c, e = self.c, self.e
         T = len(stages)
         L = c.NA * T                       # stages per trip
@@ -1381,6 +1551,9 @@ class Gen:
                 for i in range(4):
                     e("v_accvgpr_read_b32 %s, a%d" % (R("v", tv[i]), (m * c.NT + 2 * p) * 4 + i))
                     e("v_accvgpr_read_b32 %s, a%d" % (R("v", tv[4 + i]), (m * c.NT + 2 * p + 1) * 4 + i))
+                if c.fp8:
+                    for i in range(8):
+                        e("v_mul_f32 %s, %s, %s" % (R("v", tv[i]), R("v", self.v_osc), R("v", tv[i])))
                 for i in range(4):
                     e("v_cvt_pk_bf16_f32 %s, %s, %s" % (R("v", d + i), R("v", tv[2 * i]), R("v", tv[2 * i + 1])))
                 if not (c.probe & 32):
@@ -1574,6 +1747,19 @@ def _bn_in():
 
 
 _bn_in()
+
+
+def _fp8():
+    """the stride-1 3x3 convolutions of layers 2 - 4 on e4m3 operands (BASELINE configs[4]: "fp8 MFMA convs"; the e4m3 training step of resnet_exec.cpp): forward
+    with / without the BN statistics, data gradient with the BN-backward sums.  Layer 2: ONE 128-channel chunk (the tile stays staged for the nine taps)."""
+    for tag in ("l2", "l3", "l4"):
+        for st in (0, 1, 2):
+            base = VARIANTS["dconv_%s_s%d" % (tag, st)]
+            name = "dconv_%s_s%d_q" % (tag, st)
+            VARIANTS[name] = Cfg(**{**base.__dict__, "name": name, "fp8": 1, "NB": 3})
+
+
+_fp8()
 
 
 def _stride2_dgrad():

@@ -24,7 +24,7 @@ def main():
         for name in dconv_gen.VARIANTS:
             c, g, _ = dconv_gen.generate(name)
             words = ",".join("%du" % w for par in dconv_gen.tables(c) for row in par for w in row)
-            f.write('{"%s", %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, {%s}},\n' % (name, c.H, c.W, c.IPT, c.TPI, c.BN, c.Cin, c.NCOLS, c.stats, c.s2d, c.bnin, g.lds_bytes, g.ka_size, words))
+            f.write('{"%s", %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, {%s}},\n' % (name, c.H, c.W, c.IPT, c.TPI, c.BN, c.Cin, c.NCOLS, c.stats, c.s2d, c.bnin, c.fp8, g.lds_bytes, g.ka_size, words))
     with open(os.path.join(out_dir, "dconv_tt.inc"), "w") as f:   # the transform tables of the kernels with the input's BatchNorm in their operand path
         for name in dconv_gen.VARIANTS:
             c, g, _ = dconv_gen.generate(name)

@@ -126,6 +126,8 @@ struct WgradArgs {
 // stat_rows (optional): number of partial rows written to a.stat_partial, 0 if the statistics were not produced
 int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows = nullptr);
 bool igemm_sub2_legal(int dtype, const IgemmArgs& a, int nclass);
+bool dconv_fp8_legal(const IgemmArgs& a, int nclass);   // launch_igemm_fp8: the generated e4m3 3x3 kernel serves this launch
+int launch_dconv_fp8(const IgemmArgs& a, int nclass, float oscale, hipStream_t stream, int* stat_rows);
 bool igemm_bn_in_legal(int dtype, const IgemmArgs& a, int nclass);  // a launch with a.bn_in has a kernel (else: run bn_apply first)  // a launch with a.addend_sub2 has a kernel (else: materialise the addend)
 static constexpr size_t IGEMM_SK_FLAG_BYTES = 4096;  // 512 flags + an error word, padded
 static constexpr int IGEMM_SK_ERR_WORD = 512;        // index of the error word in the flag block: nonzero = a stream-K
@@ -158,6 +160,7 @@ struct Knobs {
   int po = 1;                // MI355_PO: the output-heavy pointwise kernels with resident weights (asm/po_gen.py); 1: the measured per-shape rule, 2: wherever a variant is legal
   int po64 = 1;              // MI355_PO64: the 64-column forms of po (layer 1's 1x1 launches into 64 channels): 0 leaves them on the implicit-GEMM kernel,
                              // 1: the measured per-shape rule, 2: wherever legal
+  int dconv_fp8 = 1;         // MI355_DCONV_FP8: the e4m3 step's stride-1 3x3 launches on the generated kernels (dconv_*_q: K = 128 MFMA); 0: the 8-wave HIP kernel
   int pool_keys = 1;         // MI355_POOL_KEYS: the stem's BN + ReLU + max pool on packed (value, tap) keys (misc.hip bn_relu_maxpool3_kernel; 0: the compare / select form)
   int po_bn = 1;             // MI355_PO_BN: bn2 + ReLU in conv3's operand path (po_*_s1_a0_bn: HBM-bound launches, the transform hides under the memory time)
   int dconv_bn = 0;          // MI355_DCONV_BN=1: bn1 + ReLU in conv2's operand path (dconv_*_s1_bn: the executor's training forward skips that bn_apply launch).

@@ -112,6 +112,7 @@ static void load_knobs() {
   sw("MI355_DCONV_BN", &k.dconv_bn, 1);
   sw("MI355_PO_BN", &k.po_bn, 1);
   sw("MI355_POOL_KEYS", &k.pool_keys, 1);
+  sw("MI355_DCONV_FP8", &k.dconv_fp8, 1);
   if (k.has_igemm_big && k.igemm_big != 0 && k.igemm_big != 1 && k.igemm_big != 3 && !k.error[0])
     snprintf(k.error, sizeof(k.error), "MI355_IGEMM_BIG=%d: not one of 0, 1, 3", k.igemm_big);
   g_knobs = k;

@@ -13,9 +13,10 @@ namespace {
 
 struct DconvVariant {
   const char* name;
-  int H, W, IPT, TPI, BN, Cin, NCOLS, stats, s2d, bnin, lds, kernarg;  // IPT images per tile, or TPI tiles per image; BN columns per workgroup;
+  int H, W, IPT, TPI, BN, Cin, NCOLS, stats, s2d, bnin, fp8, lds, kernarg;  // IPT images per tile, or TPI tiles per image; BN columns per workgroup;
                                                                  // s2d: the data gradient of a stride-2 3x3 (H x W = the dy image, four classes);
-                                                                 // bnin: BatchNorm + ReLU of the input in the operand path (IgemmArgs::bn_in)
+                                                                 // bnin: BatchNorm + ReLU of the input in the operand path (IgemmArgs::bn_in);
+                                                                 // fp8: e4m3 operands (one byte per element), 128-channel chunks, K = 128 MFMA
   unsigned table[3 * 4 * 64];  // [tile class][wave] LDS-DMA piece tables (asm/dconv_gen.py tables())
 };
 
@@ -210,19 +211,20 @@ int find_variant_s2d(const IgemmArgs& a, int nclass, int stats) {
   return -1;
 }
 
-int find_variant(const IgemmArgs& a, int nclass, int stats) {
-  if (nclass == 4) return find_variant_s2d(a, nclass, stats);
+int find_variant(const IgemmArgs& a, int nclass, int stats, int fp8 = 0) {
+  if (nclass == 4) return fp8 ? -1 : find_variant_s2d(a, nclass, stats);
   if (nclass != 1 || a.IS != 1 || a.OS != 1 || a.pair_delta != 0 || a.wtaps != 9) return -1;
   if (a.Hsub != a.Hin || a.Wsub != a.Win || a.Hout != a.Hin || a.Wout != a.Win) return -1;
   if (a.pix_stride != a.Ck || a.addend != nullptr) return -1;  // (sk_ws is optional scratch: not needed here)
-  if (a.q_scale_in != nullptr || a.q_scale_wt != nullptr) return -1;
+  if (!fp8 && (a.q_scale_in != nullptr || a.q_scale_wt != nullptr)) return -1;
+  if (fp8 && ((a.q_scale_in == nullptr) != (a.q_scale_wt == nullptr) || a.bn_in != nullptr)) return -1;
   int wtap[9];
   if (!tap_table(a.cls[0], wtap)) return -1;
   const int bnin = a.bn_in != nullptr ? 1 : 0;
   if (bnin && (a.bn_in_a == nullptr || a.bn_in_bits == nullptr)) return -1;
   for (int i = 0; i < NVAR; ++i) {
     const DconvVariant& v = g_variants[i];
-    if (v.bnin != bnin) continue;
+    if (v.bnin != bnin || v.fp8 != fp8) continue;
     if (!v.s2d && v.H == a.Hin && v.W == a.Win && v.Cin == a.Ck && v.NCOLS == a.Ncols && v.stats == stats && a.N % v.IPT == 0) return i;
   }
   return -1;
@@ -478,10 +480,11 @@ int launch_pk(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
   return 0;
 }
 
-bool dconv_legal(const IgemmArgs& a, int nclass) {
+static bool dconv_legal_of(const IgemmArgs& a, int nclass, int fp8) {
   if (!dconv_enabled()) return false;
-  const int v = find_variant(a, nclass, wanted_stats(a));
+  const int v = find_variant(a, nclass, wanted_stats(a), fp8);
   if (v < 0) return false;
+  if (fp8 && !knobs().dconv_fp8) return false;
   if (g_variants[v].s2d && !knobs().dconv_s2) return false;
   if (g_variants[v].bnin && !knobs().dconv_bn) return false;
   // one partial statistics row per tile (and class): the caller's buffer must hold them (bn_finalize adds any number of rows, 512 per pass)
@@ -489,8 +492,16 @@ bool dconv_legal(const IgemmArgs& a, int nclass) {
   return module_ok();
 }
 
-int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
-  const int vi = find_variant(a, nclass, wanted_stats(a));
+bool dconv_legal(const IgemmArgs& a, int nclass) { return dconv_legal_of(a, nclass, 0); }
+// the same launch on e4m3 operands (a.in / a.wt one byte per element; launch_igemm_fp8)
+bool dconv_fp8_legal(const IgemmArgs& a, int nclass) { return dconv_legal_of(a, nclass, 1); }
+
+static int launch_dconv_of(const IgemmArgs& a, int nclass, int fp8, float oscale, hipStream_t stream, int* stat_rows);
+int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) { return launch_dconv_of(a, nclass, 0, 1.f, stream, stat_rows); }
+int launch_dconv_fp8(const IgemmArgs& a, int nclass, float oscale, hipStream_t stream, int* stat_rows) { return launch_dconv_of(a, nclass, 1, oscale, stream, stat_rows); }
+
+static int launch_dconv_of(const IgemmArgs& a, int nclass, int fp8, float oscale, hipStream_t stream, int* stat_rows) {
+  const int vi = find_variant(a, nclass, wanted_stats(a), fp8);
   MI355_ARG(vi >= 0, "dconv: no kernel variant for this launch");
   const DconvVariant& v = g_variants[vi];
   DevState* d = nullptr;
@@ -539,8 +550,14 @@ int launch_dconv(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_r
     MI355_ARG(ti >= 0, "dconv: no transform table for %s", v.name);
     memcpy(k.ttable, g_tt[ti].table, sizeof(k.ttable));
   }
-  for (int t = 0; t < 9; ++t) k.wtap_off[t] = (unsigned)(wtap[t] * a.Ck * 2);
-  k.nchunks = (unsigned)(a.Ck / 64);
+  const int es = v.fp8 ? 1 : 2;
+  for (int t = 0; t < 9; ++t) k.wtap_off[t] = (unsigned)(wtap[t] * a.Ck * es);
+  k.nchunks = (unsigned)(a.Ck * es / 128);   // chunks of one 128-byte LDS row: 64 bf16 / 128 e4m3 channels
+  if (v.fp8) {  // out = accumulator * oscale / (*q_scale_in * *q_scale_wt) (both null: oscale alone); kernarg slots rsvd, pad[1], pad[2:3]
+    k.rsvd = a.q_scale_in;
+    memcpy(&k.pad[1], &oscale, sizeof(float));
+    memcpy(&k.pad[2], &a.q_scale_wt, sizeof(void*));
+  }
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksize, HIP_LAUNCH_PARAM_END};
   const int tiles = a.N * v.TPI / v.IPT;
   const int ncls = v.s2d ? 4 : 1;   // workgroup id y = class * column tiles + column tile: the long classes (4 taps) are dispatched first

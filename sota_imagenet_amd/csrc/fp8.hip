@@ -57,6 +57,8 @@ __global__ void fp8_scale_update_kernel(float* scale, unsigned* amax, int n, flo
 bool igemm_fp8_legal(const IgemmArgs& a, int nclass) { return igemm8_fp8_legal(a, nclass, 128); }
 
 int launch_igemm_fp8(const IgemmArgs& a, int nclass, float oscale, hipStream_t stream, int* stat_rows) {
+  // the stride-1 3x3 launches of layers 2 - 4: the generated direct kernel on the K = 128 MFMA (asm/dconv_gen.py Cfg.fp8)
+  if (dconv_fp8_legal(a, nclass)) return launch_dconv_fp8(a, nclass, oscale, stream, stat_rows);
   int bm, bn;
   MI355_TRY(pick_tile(a, nclass, &bm, &bn));
   int max_taps = 0;

@@ -117,3 +117,53 @@ def test_conv_fp8_rejects_unsupported_shapes(dev):
     wq = torch.zeros((128, 1, 1, 128), dtype=torch.uint8, device=dev).view(F8)
     with pytest.raises(Exception, match="at least 2"):
         ops.conv2d_fwd_fp8(xq, wq, 1, 0)
+
+
+# (N, H, C, family): conv2 of the stride-1 bottlenecks of layers 2 - 4 at 224 px — the e4m3 step's 3x3 launches on the generated kernels (asm/dconv_gen.py
+# Cfg.fp8: 128-channel chunks, v_mfma_f32_16x16x128_f8f6f4), + ragged batches
+Q3X3 = [(256, 28, 128, "dconv_l2"), (256, 14, 256, "dconv_l3"), (256, 7, 512, "dconv_l4"), (5, 14, 256, "dconv_l3"), (6, 7, 512, "dconv_l4")]
+
+
+@pytest.mark.parametrize("N,H,C,fam", Q3X3)
+def test_generated_e4m3_3x3_kernels_equal_the_bf16_kernels_on_integers(dev, N, H, C, fam, monkeypatch):
+    """forward and data gradient on e4m3 operands through mi355_conv2d_fwd_fp8 / _dgrad_fp8: small integers are exact in e4m3, bf16 and every partial sum,
+    so the generated e4m3 kernel, the generated bf16 kernel and (MI355_DCONV_FP8=0) the 8-wave e4m3 kernel must agree bit for bit; the launch is
+    asserted by name"""
+    from sota_imagenet_amd import native, ops
+
+    g = torch.Generator().manual_seed(31)
+    x = torch.randint(-2, 3, (N, H, H, C), generator=g).float().to(dev)
+    w = torch.randint(-2, 3, (C, 3, 3, C), generator=g).float().to(dev)
+    dy = torch.randint(-2, 3, (N, H, H, C), generator=g).float().to(dev)
+    xq, wq, dyq = ops.quantize_fp8(x), ops.quantize_fp8(w), ops.quantize_fp8(dy)
+    y8 = ops.conv2d_fwd_fp8(xq, wq, 1, 1)
+    assert ops.last_conv_kernel() == fam + "_s0_q", ops.last_conv_kernel()
+    y16 = ops.conv2d_fwd(x.bfloat16(), w.bfloat16(), 1, 1)
+    assert ops.last_conv_kernel() == fam + "_s0"
+    assert torch.equal(y8, y16)
+    dx8 = ops.conv2d_dgrad_fp8(dyq, wq, (N, H, H, C), 1, 1)
+    assert ops.last_conv_kernel() == fam + "_s0_q", ops.last_conv_kernel()
+    assert torch.equal(dx8, ops.conv2d_dgrad(dy.bfloat16(), w.bfloat16(), (N, H, H, C), 1, 1))
+    y8h = ops.conv2d_fwd_fp8(xq, wq, 1, 1, oscale=0.25)
+    assert torch.equal(y8h.float(), y16.float() * 0.25)
+    monkeypatch.setenv("MI355_DCONV_FP8", "0")
+    native.lib().mi355_reload_knobs()
+    y8o = ops.conv2d_fwd_fp8(xq, wq, 1, 1)
+    assert not ops.last_conv_kernel().startswith("dconv"), ops.last_conv_kernel()
+    assert torch.equal(y8o, y8)
+
+
+def test_generated_e4m3_3x3_kernel_on_scaled_random_data(dev):
+    """random operands quantised with per-tensor scales: within one bf16 rounding of the fp32 convolution of the dequantised operands (the bar of
+    test_conv_fp8_scaled_random), and within summation-order noise of the 8-wave e4m3 kernel"""
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(32)
+    N, H, C = 32, 14, 256
+    x, w = torch.randn(N, H, H, C, device=dev), torch.randn(C, 3, 3, C, device=dev) * 0.05
+    sx, sw = 448.0 / (2 * x.abs().max().item()), 448.0 / (2 * w.abs().max().item())
+    xq, wq = ops.quantize_fp8(x, sx), ops.quantize_fp8(w, sw)
+    y8 = ops.conv2d_fwd_fp8(xq, wq, 1, 1, oscale=1.0 / (sx * sw))
+    assert ops.last_conv_kernel() == "dconv_l3_s0_q"
+    ref = torch.nn.functional.conv2d((xq.float() / sx).permute(0, 3, 1, 2), (wq.float() / sw).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    assert (y8.float() - ref).abs().max() <= 2.0 ** -8 * ref.abs().max()

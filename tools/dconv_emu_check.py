@@ -27,6 +27,15 @@ def bf16_round(x):
     return from_bf16_bits(gcn_emu.bf16_round_rne(np.asarray(x, dtype=np.float32)).astype(np.uint16))
 
 
+def to_e4m3_bytes(x):
+    """exactly representable values -> OCP e4m3fn bytes (the decode table of the emulator, inverted)"""
+    table = gcn_emu.Emulator._e4m3(np.arange(256))
+    lut = {float(v): i for i, v in enumerate(table) if not np.isnan(v) and not (i == 0x80)}
+    flat = np.asarray(x, dtype=np.float64).ravel()
+    out = np.array([lut[float(v)] for v in flat], dtype=np.uint8)
+    return out.reshape(np.shape(x))
+
+
 def conv_ref(x, w, taps):
     """x [N][H][W][C], w [Co][9][C] (float64); taps: list of 9 (dh, dw, wtap) -> out [N][H][W][Co]"""
     N, H, W, C = x.shape
@@ -39,7 +48,7 @@ def conv_ref(x, w, taps):
     return out
 
 
-def run(name, tiles=(0,), ntile=0, seed=0, dgrad_taps=False, check=True, **over):
+def run(name, tiles=(0,), ntile=0, seed=0, dgrad_taps=False, check=True, over_scales=True, **over):
     c, g, text = dconv_gen.generate(name, **over)
     rng = np.random.default_rng(seed)
     ntiles = max(tiles) + 1
@@ -55,8 +64,9 @@ def run(name, tiles=(0,), ntile=0, seed=0, dgrad_taps=False, check=True, **over)
     for dh, dw, wt in taps:
         wtap_of[(dh + 1) * 3 + (dw + 1)] = wt
     mem = gcn_emu.Memory()
-    a_in = mem.alloc(to_bf16_bits(x))
-    a_wt = mem.alloc(to_bf16_bits(w))
+    fp8 = getattr(c, "fp8", 0)
+    a_in = mem.alloc(to_e4m3_bytes(x) if fp8 else to_bf16_bits(x))
+    a_wt = mem.alloc(to_e4m3_bytes(w) if fp8 else to_bf16_bits(w))
     out0 = np.full((N, c.H, c.W, c.NCOLS), 0x7FC0, dtype=np.uint16)  # NaN: unwritten outputs show
     a_out = mem.alloc(out0)
     ntiles_all = N * c.TPI if c.ROWS_T else ntiles
@@ -67,8 +77,18 @@ def run(name, tiles=(0,), ntile=0, seed=0, dgrad_taps=False, check=True, **over)
     mean = (rng.integers(-4, 5, size=c.NCOLS) * 0.25).astype(np.float32)
     invstd = (rng.integers(1, 5, size=c.NCOLS) * 0.5).astype(np.float32)
     a_y, a_bits, a_mu, a_is = mem.alloc(to_bf16_bits(yb)), mem.alloc(bits), mem.alloc(mean), mem.alloc(invstd)
-    fields = [("q", a_in), ("q", a_wt), ("q", a_out), ("q", a_stat), ("q", a_y), ("q", a_bits), ("q", a_mu), ("q", a_is),
-              ("q", 0)] + [("I", wtap_of[t] * c.Cin * 2) for t in range(9)] + [("I", c.Cin // 64)] + [("I", 0)] * 4
+    if fp8:
+        # e4m3 operands: out = acc * oscale / (scale_in * scale_wt); powers of two keep the integer test exact.  scales=False: oscale alone (null pointers)
+        oscale, sc_in, sc_wt = (0.5, 2.0, 0.25) if over_scales else (0.5, None, None)
+        a_si = mem.alloc(np.array([sc_in or 1.0], dtype=np.float32))
+        a_sw = mem.alloc(np.array([sc_wt or 1.0], dtype=np.float32))
+        osc_eff = oscale / ((sc_in or 1.0) * (sc_wt or 1.0))
+        fields = [("q", a_in), ("q", a_wt), ("q", a_out), ("q", a_stat), ("q", a_y), ("q", a_bits), ("q", a_mu), ("q", a_is),
+                  ("q", a_si if sc_in else 0)] + [("I", wtap_of[t] * c.Cin) for t in range(9)] + [("I", c.Cin // 128)] + [("I", 0), ("f", oscale), ("q", a_sw if sc_in else 0)]
+    else:
+        osc_eff = 1.0
+        fields = [("q", a_in), ("q", a_wt), ("q", a_out), ("q", a_stat), ("q", a_y), ("q", a_bits), ("q", a_mu), ("q", a_is),
+                  ("q", 0)] + [("I", wtap_of[t] * c.Cin * 2) for t in range(9)] + [("I", c.Cin // 64)] + [("I", 0)] * 4
     fields += [("I", w) for par in dconv_gen.tables(c) for row in par for w in row]
     ka = gcn_emu.pack_kernarg(fields)
     assert len(ka) == dconv_gen.Gen.KA["size"], len(ka)
@@ -78,7 +98,7 @@ def run(name, tiles=(0,), ntile=0, seed=0, dgrad_taps=False, check=True, **over)
         emu = gcn_emu.Emulator(text, mem, lds_bytes=g.lds_bytes, check=check, dontcare=[(c.ABASE + (b + 1) * c.ABUF, c.ABASE + (b + 1) * c.ABUF + 256) for b in range(2)])
         total += emu.run_workgroup(4, a_ka, wg_id=(t, ntile, 0))
     got = from_bf16_bits(mem.array(a_out, np.uint16, out0.shape)).astype(np.float64)
-    ref = conv_ref(x.astype(np.float64), w.astype(np.float64), taps)
+    ref = conv_ref(x.astype(np.float64), w.astype(np.float64), taps) * osc_eff
     cols = slice(ntile * c.BN, ntile * c.BN + c.BN)
     res = {"insts": total, "cfg": c}
     refr = bf16_round(ref.astype(np.float32)).astype(np.float64)

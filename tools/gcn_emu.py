@@ -536,6 +536,9 @@ class Emulator:
         wv.scc = 1 if r else 0
         self.swrite64(wv, ins.ops[0], r, ins)
 
+    def i_s_cmp_eq_u64(self, wv, ins):
+        wv.scc = 1 if self.sval64(wv, ins.ops[0], ins) == self.sval64(wv, ins.ops[1], ins) else 0
+
     def i_s_andn2_b64(self, wv, ins):
         r = self.sval64(wv, ins.ops[1], ins) & ~self.sval64(wv, ins.ops[2], ins) & ((1 << 64) - 1)
         wv.scc = 1 if r else 0
@@ -933,6 +936,45 @@ class Emulator:
                 k = 8 * (lane >> 4) + 2 * r + h
                 A[lane & 15, k] = _f32(((av >> (16 * h)) & 0xFFFF) << 16)
                 B[k, lane & 15] = _f32(((bv >> (16 * h)) & 0xFFFF) << 16)
+        C = np.zeros((16, 16), dtype=np.float64)
+        for r in range(4):
+            cv = self.vval(wv, c, ins, r) if c.kind != "imm" else np.full(64, c.val, dtype=np.uint32)
+            C[4 * (lane >> 4) + r, lane & 15] = _f32(cv)
+        D = (A @ B + C).astype(np.float32)
+        full = np.ones(64, dtype=bool)
+        for r in range(4):
+            self.vwrite(wv, d, _u32(D[4 * (lane >> 4) + r, lane & 15]), ins, r, mask=full)
+
+    def i_v_rcp_f32(self, wv, ins):
+        a = _f32(self.vval(wv, ins.ops[1], ins)).astype(np.float64)
+        with np.errstate(all="ignore"):
+            self.vwrite(wv, ins.ops[0], _u32((1.0 / a).astype(np.float32)), ins)
+
+    @staticmethod
+    def _e4m3(b):
+        """OCP e4m3fn bytes -> float64 (no infinities; 0x7f / 0xff are NaN)"""
+        b = b.astype(np.int64)
+        sgn = np.where(b & 0x80, -1.0, 1.0)
+        ex, man = (b >> 3) & 0xF, b & 7
+        val = np.where(ex == 0, man / 8.0 * 2.0 ** -6, (1 + man / 8.0) * 2.0 ** (ex - 7.0))
+        val = np.where((ex == 15) & (man == 7), np.nan, val)
+        return sgn * val
+
+    def i_v_mfma_f32_16x16x128_f8f6f4(self, wv, ins):
+        """D = A (16 x 128) * B (128 x 16) + C on e4m3 bytes (cbsz = blgp = 0); lane l supplies row / column l & 15, k = 32 (l >> 4) + 4 r + byte of register r"""
+        d, a, b, c = ins.ops
+        if any(k in ins.mods for k in ("cbsz", "blgp")):
+            self.err(ins, "only the e4m3 x e4m3 form (cbsz = blgp = 0) is modelled")
+        A = np.zeros((16, 128), dtype=np.float64)
+        B = np.zeros((128, 16), dtype=np.float64)
+        lane = np.arange(64)
+        for r in range(8):
+            av = self.vval(wv, a, ins, r)
+            bv = self.vval(wv, b, ins, r)
+            for h in range(4):
+                k = 32 * (lane >> 4) + 4 * r + h
+                A[lane & 15, k] = self._e4m3((av >> (8 * h)) & 0xFF)
+                B[k, lane & 15] = self._e4m3((bv >> (8 * h)) & 0xFF)
         C = np.zeros((16, 16), dtype=np.float64)
         for r in range(4):
             cv = self.vval(wv, c, ins, r) if c.kind != "imm" else np.full(64, c.val, dtype=np.uint32)
