@@ -121,9 +121,14 @@ def bresnet_step_hbm(batch, size, ms):
     if not files:
         return None
     with open(files[-1]) as f:
-        tb = json.load(f)["hbm_bytes_per_step"]
+        prof = json.load(f)
+    tb = prof["hbm_bytes_per_step"]
     gbs = tb / (ms * 1e-3) / 1e9
+    # the bytes are a STORED profile's (a serial trace of the build named in the file name), only the step time is this run's: `derived` says so, and
+    # the profile's kernel count travels with the number so that a reader can compare it with a fresh trace of the current build
     return {"bound": "hbm", "traffic": tb, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "derived": "traffic of a stored profile / step time of this run",
+            "profile_kernels_in_step": prof.get("kernels_in_step"), "profile_commit": prof.get("commit"),
             "source": f"profiles/{os.path.basename(files[-1])}: every kernel of a serial step, separate --pmc passes"}
 
 
@@ -319,13 +324,13 @@ def main():
         """(roofline, roofline_hbm) dicts from the HIP events recorded in the last timed steps of `model`"""
         roof = roof_hbm = None
         N = shape[0]
-        # fp8: the launches that ran on e4m3 operands (igemm8_kernel<..., EB = 1>), against the fp8 peak
+        # fp8: the launches that ran on e4m3 operands (igemm8_kernel<..., EB = 1> and the generated dconv_*_q 3x3 kernels), against the fp8 peak
         tot_ms, launches, flops, nbytes = model.profile_read(shape, FP8_KIND if dtype == "fp8" else dom)
         tdt = "float" if dtype == "fp32" else "__bf16"
         if launches:
             ach = flops / (tot_ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[dtype]
-            knames = ["igemm8_kernel<224,256,EB=1>", "igemm8_kernel<256,128,EB=1>"] if dtype == "fp8" else \
+            knames = ["igemm8_kernel<224,256,EB=1>", "igemm8_kernel<256,128,EB=1>", "dconv_l{2,3,4}_s{0,1,2}_q"] if dtype == "fp8" else \
                 [n.format(T=tdt) for n in KERNEL_NAMES[dom] if not (dtype == "fp32" and n.startswith(("igemm8", "dconv_", "pw_", "pk_", "po_", "wg3_", "wg1_")))]
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": pmc_traffic(knames, dtype, N, S), "traffic_source": getattr(pmc_traffic, "source", None), "kernel": " + ".join(knames),

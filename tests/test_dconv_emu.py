@@ -48,6 +48,22 @@ def test_direct_conv_kernels_are_exact_in_the_emulator(name, kw):
 
 
 @pytest.mark.parametrize("name,kw", [
+    ("dconv_l3_s1_q", dict(Cin=384, tiles=(1,))),                                      # three 128-channel chunks, BN statistics
+    ("dconv_l3_s0_q", dict(Cin=256, over_scales=False)),                               # the output scale alone (no input / weight scale pointers)
+    ("dconv_l3_s2_q", dict(Cin=128, NCOLS=512, ntile=1, dgrad_taps=True)),             # one chunk, dgrad taps, BN-backward sums from the late register pair
+    ("dconv_l2_s2_q", dict(tiles=(3,), dgrad_taps=True)),                              # half-image tiles
+    ("dconv_l4_s1_q", dict(Cin=256, ntile=1)),                                         # two images per tile, 2nd column tile
+])
+def test_e4m3_direct_conv_kernels_are_exact_in_the_emulator(name, kw):
+    """the dconv_*_q variants (Cfg.fp8: e4m3 operands, 128-channel chunks, v_mfma_f32_16x16x128_f8f6f4, output x oscale / (sc_in * sc_wt))
+    against the fp32 convolution of the decoded bytes"""
+    r = D.run(name, **kw)
+    assert r["max_err"] == 0.0 and r["untouched_ok"], r
+    if "stat_err" in r:
+        assert r["stat_err"] < 1e-6, r
+
+
+@pytest.mark.parametrize("name,kw", [
     ("dconv_l3_d2_s2", dict(Cin=128, tiles=(1,))),                                 # whole-image tiles, 2 chunks, BN-backward sums, all four classes
     ("dconv_l3_d2_s0", dict(Cin=192, classes=(0, 3))),                             # odd chunk count: the 1-tap class requests weights two chunks ahead
     ("dconv_l3_d2_s0", dict(Cin=64, NCOLS=512, ntile=1, classes=(1, 2))),          # one chunk; class and column tile from workgroup id y

@@ -8,6 +8,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
 
@@ -38,7 +39,7 @@ def main():
     total = int(sum(v[1] for v in ker.values()))
     top = {k: {"launches": v[0], "hbm_bytes": int(v[1])} for k, v in sorted(ker.items(), key=lambda kv: -kv[1][1])[:40]}
     print(json.dumps({"formula": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch (gfx950 half-count correction), every kernel of the last whole step of the passes",
-                      "kernels_in_step": len(fe), "hbm_bytes_per_step": total, "kernels_top40": top}, indent=1))
+                      "commit": os.environ.get("MI355_PROFILE_COMMIT"), "kernels_in_step": len(fe), "hbm_bytes_per_step": total, "kernels_top40": top}, indent=1))
 
 
 if __name__ == "__main__":
