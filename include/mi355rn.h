@@ -102,6 +102,15 @@ int mi355_conv2d_dgrad_bn(int dtype, const void* dy, const void* w, void* dx, co
                           const void* bn_y, const uint8_t* bn_bits, const float* bn_mean, const float* bn_invstd, float* partial,
                           size_t partial_bytes, int* nblk, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                           void* ws, size_t ws_bytes, void* stream);
+/* the same with the sums under a LEAKY ReLU mask: dz = dx where the bit is set, dx * slope elsewhere — the activation of BASELINE configs[3]'s model
+ * (`norm_act: leaky_relu`, /root/reference/configs/_old_configs/_first_attempts/BResNet50_encoder.yaml:41-51; autograd's LeakyReLU + BatchNorm backward
+ * around cuDNN's dgrad under loss.backward(), /root/reference/sota_imagenet/callbacks.py:317).  slope = 0: mi355_conv2d_dgrad_bn.  slope = 0.01 at the
+ * shapes of that model's bottlenecks (bf16, generated kernels with that epilogue); any other slope or shape: MI355_E_ARG (run the BatchNorm backward's
+ * own reduction, mi355_bn_bwd).                                                                                                                    */
+int mi355_conv2d_dgrad_bn_leaky(int dtype, const void* dy, const void* w, void* dx, const void* addend, const uint8_t* addend_bits, int addend_sub2,
+                                const void* bn_y, const uint8_t* bn_bits, const float* bn_mean, const float* bn_invstd, float slope, float* partial,
+                                size_t partial_bytes, int* nblk, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                void* ws, size_t ws_bytes, void* stream);
 
 /* dw[Cout,KH,KW,Cin] (fp32) = sum_{n,oh,ow} dy (x) x.  beta=0 overwrites, beta=1 accumulates.
  * replaces cuDNN wgrad under loss.backward() — callbacks.py:317 (K8)                                */

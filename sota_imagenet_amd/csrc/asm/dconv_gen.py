@@ -45,7 +45,8 @@ class Cfg:
     IPT: int          # images per tile
     Cin: int          # channels of the input tensor (= pixel stride = reduction per tap)
     NCOLS: int        # columns of the output tensor (multiple of 256; blockIdx.y picks the 256-column tile)
-    stats: int        # 0 none, 1 BN statistics of the output, 2 BN-backward sums
+    stats: int        # 0 none, 1 BN statistics of the output, 2 BN-backward sums (ReLU mask), 3 BN-backward sums under a LEAKY ReLU mask: dz = dx where the bit is set,
+                      # dx * 0.01 elsewhere (the slope of BASELINE configs[3]'s activation, /root/reference/configs/_old_configs/_first_attempts/BResNet50_encoder.yaml:41-51)
     skew: int = 0     # s_nop-based wave stagger after each barrier (experiment knob)
     probe: int = 0    # timing probes (WRONG results): 1 no LDS-DMA in the main loop, 2 no fragment reads, 4 no barriers,
                       # 8 no BN-backward input loads, 16 no statistics arithmetic, 32 no output stores
@@ -144,6 +145,7 @@ class Cfg:
 # LDS: [A buffer 0][A buffer 1][weight ring NB stages]; the statistics scratch reuses the ring
 
 
+LEAKY_BITS = 0x3c23d70a   # 0.01f: the slope of the stats == 3 epilogues
 NCLS = 3  # tile classes of a row tile: 0 first of its image (the row above is zero halo), 1 middle, 2 last (the row below is)
 
 
@@ -322,10 +324,10 @@ class Gen:
         self.srdO = S.get(4, 4)
         self.srdX = S.get(4, 4)   # statistics rows
         # the piece table of this wave: in SGPRs (scalar loads, as many as 24 words) or, when larger, in a VGPR read with v_readlane
-        self.tab_sgpr = (2 * NPA + c.NPB <= 24) and c.TPI == 1 and not (c.s2d and c.stats == 2) and not c.bnin and not c.fp8   # (s2d + BN-backward sums, bnin, fp8: out of SGPRs)
+        self.tab_sgpr = (2 * NPA + c.NPB <= 24) and c.TPI == 1 and not (c.s2d and c.stats >= 2) and not c.bnin and not c.fp8   # (s2d + BN-backward sums, bnin, fp8: out of SGPRs)
         if not self.tab_sgpr:
             self.srdK = S.get(4, 4)   # the piece tables in the kernarg segment
-        if c.stats == 2:
+        if c.stats >= 2:
             self.srdM = S.get(4, 4)   # bn_bits
             self.srdY = S.get(4, 4)   # bn_y
             self.srdMu = S.get(4, 4)  # bn_mean
@@ -377,7 +379,7 @@ class Gen:
         # prologue temporaries live in fragment set 1, which is first written by the main loop (v_t[2] = the kept lane >> 4)
         self.v_t = [self.F[1][0] + i for i in range(10)]
         self.v_t[2] = self.v_kg
-        if c.stats == 2:
+        if c.stats >= 2:
             # BN-backward sums: y / mask of the same (pixel, 8 channels) vectors as the output in two register sets, mean / invstd of
             # this lane's 8 channels per tile pair.  The sets of pairs 0 and 1 are loaded in the PROLOGUE (the main loop does not
             # touch these registers), pairs 2 and 3 under the arithmetic of pairs 0 and 1.
@@ -660,7 +662,7 @@ class Gen:
             e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdX + 1), R("s", ka + 7)))
             e("s_mov_b32 %s, 0x7fffffff" % R("s", self.srdX + 2))
             e("s_mov_b32 %s, 0x00020000" % R("s", self.srdX + 3))
-            if c.stats == 2:
+            if c.stats >= 2:
                 # y: laid out like the output (same window); mask bytes: 1/16 of it; mean / invstd: this column tile's 256 floats
                 e("s_add_u32 %s, %s, %s" % (R("s", self.srdY), R("s", ka + 8), R("s", t0)))
                 e("s_addc_u32 %s, %s, %s" % (R("s", self.srdY + 1), R("s", ka + 9), R("s", t1)))
@@ -703,7 +705,7 @@ class Gen:
             e("v_add_u32 %s, %s, %s" % (R("v", self.v_out), R("s", t0), R("v", x)))
 
 
-        if c.stats == 2:
+        if c.stats >= 2:
             # the BN-backward inputs of tile pairs 0 and 1 are requested FIRST (oldest vector-memory operations: every counted wait
             # of the main loop is unaffected), so the epilogue finds them in registers
             descriptors_out()
@@ -1515,7 +1517,7 @@ class Gen:
         yv = [base + 49 + i for i in range(2)]
         assert base + 51 <= self.F[1][1] + 4 * c.NT
         npair = c.NT // 2
-        if c.stats == 2:
+        if c.stats >= 2:
             ysets, msets = self.ysets, self.msets
             issue_loads = self.epi_issue_loads
             GL = c.MFR + 4
@@ -1524,7 +1526,7 @@ class Gen:
         e("s_barrier", "every LDS-DMA of the (unused) lookahead has landed: the ring is free for the statistics scratch")
         e("s_nop 15")
         e("s_nop 15")
-        late1 = c.stats == 2 and getattr(self, "late_pair1", False)  # (pk_gen.py: the second register set lives in the fragment registers)
+        late1 = c.stats >= 2 and getattr(self, "late_pair1", False)  # (pk_gen.py: the second register set lives in the fragment registers)
         if late1:
             issue_loads(1)
         if c.stats:
@@ -1539,11 +1541,11 @@ class Gen:
                 for i in range(8):
                     e("v_mov_b32 %s, 0" % R("v", s1[i]))
                     e("v_mov_b32 %s, 0" % R("v", s2[i]))
-            if c.stats == 2 and (p >= 2 or (late1 and p == 1)):
+            if c.stats >= 2 and (p >= 2 or (late1 and p == 1)):
                 # pair p's loads were issued behind pair p - 2; younger: pair p - 1's stores (+ pair p + 1's loads)
                 e("s_waitcnt vmcnt(%d)" % (0 if c.probe & 40 else c.MFR + (GL if p + 1 < npair else 0)))
             for m in range(c.MFR):
-                if c.stats == 2 and not (c.probe & 24):
+                if c.stats >= 2 and not (c.probe & 24):
                     for ins in self.tile_mask_fetch(m, p):
                         e(ins)
                 self.emit_frag(m)
@@ -1568,12 +1570,17 @@ class Gen:
                     for i in range(8):
                         e("v_add_f32 %s, %s, %s" % (R("v", s1[i]), R("v", s1[i]), R("v", xr[i])))
                         e("v_fma_f32 %s, %s, %s, %s" % (R("v", s2[i]), R("v", xr[i]), R("v", xr[i]), R("v", s2[i])))
-                if c.stats == 2 and not (c.probe & 16):
+                if c.stats >= 2 and not (c.probe & 16):
                     yr, br = ysets[p & 1][m], self.v_mb
                     for i in range(8):
                         t = tv[i]  # (the accumulator copies are dead after the conversion)
                         e("v_bfe_i32 %s, %s, %d, 1" % (R("v", t), R("v", br), i), "0 / -1: ReLU mask bit of element %d" % i)
-                        e("v_and_b32 %s, %s, %s" % (R("v", xr[i]), R("v", xr[i]), R("v", t)), "dz")
+                        if c.stats == 3:   # leaky: dz = bit ? dx : dx * 0.01 (the fp32 product of the rounded value, as bn_reduce_kernel<MASK = 3>)
+                            t2 = tv[(i + 1) % 8]
+                            e("v_mul_f32 %s, 0x%08x, %s" % (R("v", t2), LEAKY_BITS, R("v", xr[i])))
+                            e("v_bfi_b32 %s, %s, %s, %s" % (R("v", xr[i]), R("v", t), R("v", xr[i]), R("v", t2)), "dz")
+                        else:
+                            e("v_and_b32 %s, %s, %s" % (R("v", xr[i]), R("v", xr[i]), R("v", t)), "dz")
                         if i & 1:
                             e("v_and_b32 %s, 0xffff0000, %s" % (R("v", yv[1]), R("v", yr + i // 2)))
                         else:
@@ -1588,7 +1595,7 @@ class Gen:
                         for i in range(8):
                             rr = R("v", arr[i])
                             e("v_add_f32_dpp %s, %s, %s row_shr:%d row_mask:0xf bank_mask:0xf bound_ctrl:1" % (rr, rr, rr, sh))
-                if c.stats == 2:
+                if c.stats >= 2:
                     # sum dz*xhat = invstd * (sum dz*y - mean * sum dz)
                     mu, isd = msets[p & 1], msets[p & 1] + 8
                     for i in range(8):
@@ -1603,7 +1610,7 @@ class Gen:
                     e("ds_write_b32 %s, %s offset:%d" % (R("v", vst), R("v", s1[i]), p * 32 * 8 + i * 8))
                     e("ds_write_b32 %s, %s offset:%d" % (R("v", vst), R("v", s2[i]), p * 32 * 8 + i * 8 + 4))
                 e("s_mov_b64 exec, -1")
-                if c.stats == 2 and p + 2 < npair:
+                if c.stats >= 2 and p + 2 < npair:
                     issue_loads(p + 2)
         if c.stats:
             # partial row of this workgroup: row[c] = sum, row[NCOLS + c] = sum of squares, c = nt*256 + tid
@@ -1780,6 +1787,18 @@ def _stride2_dgrad():
 _stride2_dgrad()
 
 
+def _leaky_sums():
+    """BASELINE configs[3] (BResNet-50): conv2's data gradient with bn1's backward sums under the leaky-ReLU mask (stats 3) — the stride-1 blocks at ResNet-50's
+    own shapes, the striding blocks at their input resolution (v2 .. v4, defined below)"""
+    for tag in ("l1", "l2", "l3", "l4"):
+        base = VARIANTS["dconv_%s_s2" % tag]
+        name = "dconv_%s_s3" % tag
+        VARIANTS[name] = Cfg(**{**base.__dict__, "name": name, "stats": 3})
+
+
+_leaky_sums()
+
+
 def _other_sizes():
     """the same four layers at the other two sizes of the progressive-resize recipe (BASELINE configs[4]: 160 -> 224 -> 320 px, stage schema
     /root/reference/sota_imagenet/arg_parser.py:63-72): a = 160 px (40 / 20 / 10 / 5), b = 320 px (80 / 40 / 20 / 10).  The row pitch is 8 or a
@@ -1807,7 +1826,7 @@ def _variant_model_sizes():
     """BASELINE configs[3]'s 3x3 launches that ResNet-50 does not have (anti-aliased BResNet-50: the stride of a striding block moves behind
     conv2 into the blur pool, so its conv2 runs at the INPUT resolution — 56 x 56 x 128, 28 x 28 x 256, 14 x 14 x 512 — and the deep stem has two
     3x3 convolutions at 112 x 112 on 32 channels zero-padded to 64; /root/reference/configs/_old_configs/_first_attempts/BResNet50_encoder.yaml:41-51).
-    The backward of that model has no fused BN-backward sums (leaky ReLU): forward (s1) and plain data gradient (s0) only."""
+    Forward (s1), plain data gradient (s0) and the data gradient with the BN-backward sums under the leaky mask (s3)."""
     geo = {
         "v0": dict(H=112, W=112, P=128, IPT=1, Cin=64, NCOLS=64, WM=4, WN=1, NT=4, ROWS_T=4),
         "v2": dict(H=56, W=56, P=64, IPT=1, Cin=128, NCOLS=128, WM=4, WN=1, ROWS_T=4),
@@ -1815,7 +1834,7 @@ def _variant_model_sizes():
         "v4": dict(H=14, W=14, P=16, IPT=1, Cin=512, NCOLS=512),
     }
     for tag, kw in geo.items():
-        for st in (0, 1):
+        for st in (0, 1, 3):
             name = "dconv_%s_s%d" % (tag, st)
             VARIANTS[name] = Cfg(name, stats=st, **kw)
 

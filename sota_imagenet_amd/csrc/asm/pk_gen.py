@@ -72,7 +72,7 @@ class Gen(dconv_gen.Gen):
         self.srdB = S.get(4, 4)
         self.srdO = S.get(4, 4)
         self.srdX = S.get(4, 4)
-        if c.stats == 2:
+        if c.stats >= 2:
             self.srdM = S.get(4, 4)
             self.srdY = S.get(4, 4)
             self.srdMu = S.get(4, 4)
@@ -97,7 +97,7 @@ class Gen(dconv_gen.Gen):
         self.v_t = [self.F[1][0] + i for i in range(10)]
         self.v_t[2] = self.v_kg
         self.late_pair1 = False
-        if c.stats == 2:
+        if c.stats >= 2:
             # BN-backward inputs of the two tile pairs.  Where two full sets do not fit (13 fragments), the second set is loaded at the
             # start of the epilogue INTO the fragment registers (free by then; the epilogue's temporaries use the first 51 of them)
             self.late_pair1 = c.MFR > 8 and c.NT >= 4
@@ -279,7 +279,7 @@ class Gen(dconv_gen.Gen):
             e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdX + 1), R("s", ka + 7)))
             e("s_mov_b32 %s, 0x7fffffff" % R("s", self.srdX + 2))
             e("s_mov_b32 %s, 0x00020000" % R("s", self.srdX + 3))
-            if c.stats == 2:
+            if c.stats >= 2:
                 e("s_add_u32 %s, %s, %s" % (R("s", self.srdY), R("s", ka + 8), R("s", t0)))
                 e("s_addc_u32 %s, %s, %s" % (R("s", self.srdY + 1), R("s", ka + 9), R("s", t1)))
                 e("s_and_b32 %s, %s, 0xffff" % (R("s", self.srdY + 1), R("s", self.srdY + 1)))
@@ -310,7 +310,7 @@ class Gen(dconv_gen.Gen):
             e("v_lshl_add_u32 %s, %s, 4, %s" % (R("v", x), R("v", kg), R("v", x)))
             e("v_add_u32 %s, %s, %s" % (R("v", self.v_out), R("s", t0), R("v", x)))
 
-        if c.stats == 2:
+        if c.stats >= 2:
             descriptors_out()
             lane_out()
             self.tile_mask_loads()
@@ -430,6 +430,8 @@ def _variants():
     # (not shipped: 256 -> 128 at 56 x 56, layer 2's first conv1 — 173 us against 156 us of the implicit-GEMM kernel, profiles/r05_*)
     # the same families with tiles of 200 / 100 pixels: the pixel counts of the 160 px and 320 px stages of the progressive-resize recipe
     # (BASELINE configs[4]: 10 x 10 and 20 x 20 at layer 3, 5 x 5 and 10 x 10 at layer 4) are multiples of 100, not of 49
+    # BASELINE configs[3] (BResNet-50): conv3's data gradient of layers 3 / 4 with bn2's backward sums under the leaky mask (stats 3, dconv_gen.py)
+    fam = fam + ((1024, 256, 196, 2, (3,)), (2048, 512, 98, 3, (3,)))
     for (K, N, W, NB, stats, *rest) in fam + tuple((K, N, {196: 200, 98: 100}[W], NB, st, *rest) for (K, N, W, NB, st, *rest) in fam):
         for st in stats:
             name = "pk_k%d_n%d_w%d_s%d" % (K, N, W, st)

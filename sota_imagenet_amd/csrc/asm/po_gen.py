@@ -33,7 +33,7 @@ import sys
 from dataclasses import dataclass
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from dconv_gen import Alloc, R  # noqa: E402
+from dconv_gen import Alloc, R, LEAKY_BITS  # noqa: E402
 
 
 @dataclass
@@ -41,7 +41,7 @@ class PoCfg:
     name: str
     K: int            # input channels (reduction), multiple of 64
     BN: int           # output columns per workgroup (256 | 128)
-    stats: int        # 0 none, 1 BN statistics of the output, 2 BN-backward sums
+    stats: int        # 0 none, 1 BN statistics of the output, 2 BN-backward sums, 3 BN-backward sums under a leaky-ReLU mask (slope 0.01: dconv_gen.py Cfg.stats)
     add: int = 0      # 0 no addend, 1 addend, 2 addend under its ReLU bit mask, 3 addend given at HALF resolution: a compact [N][H/2][W/2][cols]
                       # tensor that stands for a full-resolution one whose odd rows / columns are zero (the data gradient of a stride-2 1x1
                       # convolution — the downsample branch of a stage's first block — which is then never written at full size)
@@ -107,11 +107,11 @@ class PoCfg:
 
     @property
     def NM(self):     # mask tensors (BN layer's ReLU bits, addend's ReLU bits)
-        return (1 if self.stats == 2 else 0) + (1 if self.add == 2 else 0)
+        return (1 if self.stats >= 2 else 0) + (1 if self.add == 2 else 0)
 
     @property
     def L(self):      # vector-memory loads per item
-        return (1 if self.stats == 2 else 0) + (1 if self.add else 0) + (0 if self.tmask else self.NM)
+        return (1 if self.stats >= 2 else 0) + (1 if self.add else 0) + (0 if self.tmask else self.NM)
 
     @property
     def NMT(self):    # mask loads per tile (tmask)
@@ -157,7 +157,7 @@ class Gen:
         self.s_wg = 2
         self.srdA, self.srdB, self.srdO, self.srdX = S.get(4, 4), S.get(4, 4), S.get(4, 4), S.get(4, 4)
         self.srdY = self.srdM = self.srdAD = self.srdAB = None
-        if c.stats == 2:
+        if c.stats >= 2:
             self.srdY, self.srdM = S.get(4, 4), S.get(4, 4)
         if c.add:
             self.srdAD = S.get(4, 4)
@@ -182,7 +182,7 @@ class Gen:
             self.v_mk = V.get()                  # lane = pixel: byte offset of its mask bytes
             self.v_bp = V.get()                  # (lane & 15) * 4: ds_bpermute address of fragment 0's pixel (+ 64 m by the offset field)
             self.v_kg8 = V.get()                 # (lane >> 4) * 8: this lane's byte of a tile pair's dword
-            self.mk = {T: [V.get(nd, 2) for b in range(2)] for T in (["y"] if c.stats == 2 else []) + (["a"] if c.add == 2 else [])}
+            self.mk = {T: [V.get(nd, 2) for b in range(2)] for T in (["y"] if c.stats >= 2 else []) + (["a"] if c.add == 2 else [])}
             self.mkt = {T: [V.get() for p in range(nd)] for T in self.mk}   # the unit's mask dwords after the permute / shift
         self.v_chan = V.get()
         self.v_st_m = [V.get() for m in range(c.MFRW)] if c.FULL else None
@@ -197,11 +197,11 @@ class Gen:
         self.it = []
         for i in range(c.NI):
             d = {}
-            if c.stats == 2:
+            if c.stats >= 2:
                 d["y"] = V.get(4, 4)
             if c.add:
                 d["ad"] = V.get(4, 4)
-            if c.stats == 2:
+            if c.stats >= 2:
                 d["yb"] = self.mkt["y"][i % (c.NT // 2)] if c.tmask else V.get()
             if c.add == 2:
                 d["ab"] = self.mkt["a"][i % (c.NT // 2)] if c.tmask else V.get()
@@ -345,7 +345,7 @@ class Gen:
         out = []
         nt = " nt" if c.nt & 1 else ""
         nomask, nobig = c.probe & 16, c.probe & 32   # (probes: the mask-byte loads / the 16-byte loads replaced by a scalar no-op each: same counts)
-        if c.stats == 2:
+        if c.stats >= 2:
             out.append("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["y"], 4), R("v", self.v_out_m[m]), R("s", self.srdY, 4), p * 64, nt) if not nobig else "s_nop 0")
             if not c.tmask:
                 out.append("buffer_load_ubyte %s, %s, %s, 0 offen offset:%d%s" % (R("v", d["yb"]), R("v", self.v_bits_m[m]), R("s", self.srdM, 4), p * 4, nt) if not nomask else "s_nop 0")
@@ -498,7 +498,7 @@ class Gen:
         e("s_mul_i32 %s, %s, %s" % (R("s", t2), R("s", M), R("s", N)))
         e("s_lshl_b32 %s, %s, 1" % (R("s", t2), R("s", t2)), "bytes of an output-shaped tensor")
         self.desc_from(self.srdO, ka + 4, t0, t1, t2, "O")
-        if c.stats == 2:
+        if c.stats >= 2:
             self.desc_from(self.srdY, ka + 8, t0, t1, t2, "y of the BN layer")
         if c.add == 3:
             # the whole half-resolution tensor from this column tile's first column on: npix / 4 pixels
@@ -512,14 +512,14 @@ class Gen:
             e("s_mul_i32 %s, %s, %d" % (R("s", self.s_qpf), R("s", S_first), c.TP))
         elif c.add:
             self.desc_from(self.srdAD, ka + 16, t0, t1, t2, "addend")
-        if c.stats == 2 or c.add == 2:
+        if c.stats >= 2 or c.add == 2:
             # mask bytes: 1/16 of the byte offsets
             e("s_lshr_b32 %s, %s, 4" % (R("s", t0), R("s", t0)))
             e("s_lshl_b32 %s, %s, 28" % (R("s", t3), R("s", t1)))
             e("s_or_b32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", t3)))
             e("s_lshr_b32 %s, %s, 4" % (R("s", t1), R("s", t1)))
             e("s_lshr_b32 %s, %s, 4" % (R("s", t2), R("s", t2)))
-            if c.stats == 2:
+            if c.stats >= 2:
                 self.desc_from(self.srdM, ka + 10, t0, t1, t2, "ReLU bits of the BN layer")
             if c.add == 2:
                 self.desc_from(self.srdAB, ka + 18, t0, t1, t2, "ReLU bits of the addend")
@@ -684,7 +684,7 @@ class Gen:
         if c.add == 3:
             out += ["s_mul_i32 %s, %s, %d" % (R("s", self.s_t3), R("s", self.s_t3), c.TP),
                     "s_add_u32 %s, %s, %s" % (R("s", self.s_qpf), R("s", self.s_qpf), R("s", self.s_t3))]
-        if c.stats == 2:
+        if c.stats >= 2:
             out += self.desc_adv(self.srdY, self.s_io) + self.desc_adv(self.srdM, self.s_ib)
         if c.add in (1, 2):
             out += self.desc_adv(self.srdAD, self.s_io)
@@ -873,7 +873,11 @@ class Gen:
             else:
                 for k in range(8):
                     e("v_bfe_i32 %s, %s, %d, 1" % (R("v", vm), R("v", d["yb"]), k), "0 / -1: ReLU bit of element %d" % k)
-                    e("v_and_b32 %s, %s, %s" % (R("v", xr + k), R("v", xr + k), R("v", vm)), "dz")
+                    if c.stats == 3:   # leaky mask: dz = bit ? dx : dx * 0.01 (dconv_gen.py LEAKY_BITS; tv + k is dead after the conversion)
+                        e("v_mul_f32 %s, 0x%08x, %s" % (R("v", tv + k), LEAKY_BITS, R("v", xr + k)))
+                        e("v_bfi_b32 %s, %s, %s, %s" % (R("v", xr + k), R("v", vm), R("v", xr + k), R("v", tv + k)), "dz")
+                    else:
+                        e("v_and_b32 %s, %s, %s" % (R("v", xr + k), R("v", xr + k), R("v", vm)), "dz")
                     if k & 1:
                         e("v_and_b32 %s, 0xffff0000, %s" % (R("v", yv + 1), R("v", d["y"] + k // 2)))
                     else:
@@ -952,7 +956,11 @@ class Gen:
             else:
                 for k in range(8):
                     e("v_bfe_i32 %s, %s, %d, 1" % (R("v", vm), R("v", d["yb"]), k), "0 / -1: ReLU bit of element %d" % k)
-                    e("v_and_b32 %s, %s, %s" % (R("v", xr + k), R("v", xr + k), R("v", vm)), "dz")
+                    if c.stats == 3:   # leaky mask: dz = bit ? dx : dx * 0.01 (dconv_gen.py LEAKY_BITS; tv + k is dead after the conversion)
+                        e("v_mul_f32 %s, 0x%08x, %s" % (R("v", tv + k), LEAKY_BITS, R("v", xr + k)))
+                        e("v_bfi_b32 %s, %s, %s, %s" % (R("v", xr + k), R("v", vm), R("v", xr + k), R("v", tv + k)), "dz")
+                    else:
+                        e("v_and_b32 %s, %s, %s" % (R("v", xr + k), R("v", xr + k), R("v", vm)), "dz")
                     if k & 1:
                         e("v_and_b32 %s, 0xffff0000, %s" % (R("v", yv + 1), R("v", d["y"] + k // 2)))
                     else:
@@ -978,7 +986,7 @@ class Gen:
         e("s_mul_i32 %s, %s, %d" % (R("s", t1), R("s", self.s_wn), c.NT * 16 * 4))
         e("s_add_u32 %s, %s, %s" % (R("s", t0), R("s", t0), R("s", t1)), "byte offset of this wave's channels in a per-channel float row")
         mu = isd = None
-        if c.stats == 2:
+        if c.stats >= 2:
             # mean / invstd of this lane's 8 channels per pair (the fragment registers are free)
             for name, k0 in (("mu", 12), ("is", 14)):
                 srd = self.srdY if name == "mu" else self.srdM
@@ -1015,7 +1023,7 @@ class Gen:
                     for k in range(8):
                         rr = R("v", arr + k)
                         e("v_add_f32_dpp %s, %s, %s row_shr:%d row_mask:0xf bank_mask:0xf bound_ctrl:1" % (rr, rr, rr, sh))
-        if c.stats == 2:
+        if c.stats >= 2:
             e("s_waitcnt vmcnt(0)")
             tv = self.tv
             for p in range(npair):
@@ -1084,6 +1092,9 @@ def _variants():
                 continue
             name = "po_k%d_b%d_s%d_a%d" % (K, BN, st, add)
             v[name] = PoCfg(name, K=K, BN=BN, stats=st, add=add, **(dict(WM=2, MFR=8) if BN == 64 else {}))
+    for (K, BN) in ((256, 64), (512, 128)):   # BASELINE configs[3] (BResNet-50): conv3's data gradient of layers 1 / 2 with bn2's backward sums under the leaky mask
+        name = "po_k%d_b%d_s3_a0" % (K, BN)
+        v[name] = PoCfg(name, K=K, BN=BN, stats=3, add=0, **(dict(WM=2, MFR=8) if BN == 64 else {}))
     for K in (64, 128, 256):   # conv3's forward of layers 1 - 3 with bn2 + ReLU in its operand path
         name = "po_k%d_b256_s1_a0_bn" % K
         v[name] = PoCfg(name, K=K, BN=256, stats=1, add=0, bnin=1)

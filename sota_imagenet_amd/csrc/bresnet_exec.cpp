@@ -151,6 +151,7 @@ struct mi355_bctx {
   std::vector<Bucket> buckets;
   mi355_comm* comm = nullptr;
   bool grad_sync = true, comm_dirty = false;
+  bool fuse_bn_bwd = true; // bn1's / bn2's (and the deep stem's) backward sums in the epilogue of the data gradient in front of them (MI355_BRESNET_FUSE_BN_BWD=0: reduction passes)
   bool fused_add = true;   // shortcut gradient added in conv1's dgrad epilogue (MI355_BRESNET_FUSED_ADD=0: its own launch, as the per-op graph)
   const char* bad_switch = nullptr;   // an environment switch with a value outside its domain (the creation fails)
   bool use_bits = true;    // leaky-ReLU masks travel as one bit per element (round 3: 36.5 -> 35.5 ms; the A/B switch is gone)
@@ -324,7 +325,7 @@ int conv_bn(mi355_bctx* c, VConv& v, VBN& b, const void* in, bool training, floa
 
 // v.dy = gradient wrt the conv output, from the gradient wrt the activation b.dout (dout may be another buffer)
 // eg (optional): `dout` is the gradient wrt an ECA module's OUTPUT side (see EcaGrad): both passes form the module's input gradient on the fly
-// have_rows > 0: the partial rows of the sums are already in c->bn_ws (left by the fused ECA backward): no reduction pass
+// have_rows > 0: the partial rows of the sums are already in c->bn_ws (left by the fused ECA backward or by the data gradient that produced dout): no reduction pass
 // rows_at: ... kept elsewhere (the downsample BatchNorm's row waits there while other layers use c->bn_ws)
 int bn_back(mi355_bctx* c, VConv& v, VBN& b, const void* dout, float beta, hipStream_t s, const EcaGrad* eg = nullptr, int have_rows = 0,
             const float* rows_at = nullptr) {
@@ -334,7 +335,7 @@ int bn_back(mi355_bctx* c, VConv& v, VBN& b, const void* dout, float beta, hipSt
   const bool staged = b.Cp != b.C;
   {
     float* partial = (float*)c->bn_ws;
-    float* coef = partial + (size_t)bn_max_blocks() * 2 * b.Cp;
+    float* coef = partial + (size_t)std::max(bn_max_blocks(), have_rows) * 2 * b.Cp;   // (a data gradient's epilogue may leave more rows than a reduction pass)
     const uint8_t* bits = b.has_bits ? b.bits : nullptr;
     const void* mask = (b.act != ACT_NONE && !bits) ? b.out : nullptr;
     const float slope = b.act == ACT_LEAKY ? 0.01f : 0.f;
@@ -372,11 +373,22 @@ int conv_wgrad(mi355_bctx* c, VConv& v, const void* in, float beta, hipStream_t 
 
 // dx = conv_transpose(v.dy) (+ addend), from the transposed weights the forward's weight preparation left in v.wtr (mi355_conv2d_dgrad
 // would transpose them again in front of every launch: 54 small kernels on backward's critical path)
-int conv_dgrad(mi355_bctx* c, VConv& v, void* dx, const void* addend, hipStream_t s) {
+// pv / pb / rows: dx is the activation gradient of the BatchNorm pb behind the convolution pv — where a generated kernel has the epilogue
+// (asm/dconv_gen.py Cfg.stats == 3: the sums under the leaky-ReLU bit mask), the BN-backward sums of pb ride in this launch: *rows partial rows in
+// c->bn_ws, and bn_back() runs without its reduction pass (2 x the tensor + its mask not read again); *rows == 0: not fused
+int conv_dgrad(mi355_bctx* c, VConv& v, void* dx, const void* addend, hipStream_t s, VConv* pv = nullptr, VBN* pb = nullptr, int* rows = nullptr) {
   IgemmArgs a;
   const int nclass = build_dgrad_args(a, c->N, v.Hin, v.Win, v.Cinp, v.Coutp, v.K, v.K, v.stride, v.pad);
   if (nclass < 0) return nclass;
   a.in = v.dy; a.wt = v.wtr; a.out = dx; a.addend = addend;
+  if (rows) *rows = 0;
+  if (pv && pb && rows && c->fuse_bn_bwd && pb->has_bits && pb->act == ACT_LEAKY && pb->Cp == v.Cinp) {
+    IgemmArgs t = a;
+    t.bn_y = pv->y; t.bn_bits = pb->bits; t.bn_mean = pb->mean; t.bn_invstd = pb->invstd; t.bn_slope = 0.01f;
+    t.stat_partial = (float*)c->bn_ws;
+    t.stat_rows_cap = (int)std::min<size_t>((c->bn_ws_bytes / 4 - (size_t)3 * pb->Cp) / ((size_t)2 * pb->Cp), 1u << 20);
+    if (igemm_leaky_sums_legal(c->dtype, t, nclass)) return launch_igemm(c->dtype, t, nclass, s, rows);
+  }
   return launch_igemm(c->dtype, a, nclass, s);
 }
 
@@ -602,6 +614,7 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
   // executor switches: closed domains, read here once (the bit-identity tests against the per-op graph switch the fused forms off)
   c->overlap = env_switch("MI355_WGRAD_STREAM", 1, 1, &c->bad_switch) != 0;
   c->fused_add = env_switch("MI355_BRESNET_FUSED_ADD", 1, 1, &c->bad_switch) != 0;
+  c->fuse_bn_bwd = env_switch("MI355_BRESNET_FUSE_BN_BWD", 1, 1, &c->bad_switch) != 0;
   c->lazy_bn = env_switch("MI355_BRESNET_LAZY_BN", 1, 1, &c->bad_switch) != 0;
   c->fused_eca = env_switch("MI355_BRESNET_FUSED_ECA", 1, 1, &c->bad_switch) != 0;
   c->eca_sums = env_switch("MI355_BRESNET_ECA_SUMS", 1, 1, &c->bad_switch) != 0;
@@ -834,17 +847,18 @@ int mi355_bresnet50_backward(mi355_bctx* c, const float* dlogits, int accumulate
       MI355_TRY(bn_back(c, b.c3, b.b3, b.b3.dout, beta, s));
     }
     const void* a2 = b.stride == 2 ? b.a2b : b.b2.out;
+    int rows1 = 0, rows2 = 0;   // partial rows of bn1's / bn2's backward sums left by the data gradient in front of them (0: their own reduction pass)
     MI355_TRY(conv_wgrad(c, b.c3, a2, beta, s));
     if (b.stride == 2) {
       MI355_TRY(conv_dgrad(c, b.c3, b.da2b, nullptr, s));
       MI355_TRY(mi355_blurpool_bwd(dt, b.da2b, b.b2.dout, N, b.H, b.W, b.planes, s));
     } else {
-      MI355_TRY(conv_dgrad(c, b.c3, b.b2.dout, nullptr, s));
+      MI355_TRY(conv_dgrad(c, b.c3, b.b2.dout, nullptr, s, &b.c2, &b.b2, &rows2));   // + bn2's backward sums
     }
-    MI355_TRY(bn_back(c, b.c2, b.b2, b.b2.dout, beta, s));
+    MI355_TRY(bn_back(c, b.c2, b.b2, b.b2.dout, beta, s, nullptr, rows2));
     MI355_TRY(conv_wgrad(c, b.c2, b.b1.out, beta, s));
-    MI355_TRY(conv_dgrad(c, b.c2, b.b1.dout, nullptr, s));
-    MI355_TRY(bn_back(c, b.c1, b.b1, b.b1.dout, beta, s));
+    MI355_TRY(conv_dgrad(c, b.c2, b.b1.dout, nullptr, s, &b.c1, &b.b1, &rows1));     // + bn1's backward sums
+    MI355_TRY(bn_back(c, b.c1, b.b1, b.b1.dout, beta, s, nullptr, rows1));
     MI355_TRY(conv_wgrad(c, b.c1, xin, beta, s));
     // shortcut gradient first: it is the addend of conv1's input gradient
     const void* gs = b.dsc;
@@ -873,11 +887,12 @@ int mi355_bresnet50_backward(mi355_bctx* c, const float* dlogits, int accumulate
   MI355_TRY(mi355_maxpool3s1_bwd(dt, c->dm, c->pool_idx, c->sb2.dout, N, c->H / 2, c->W / 2, 64, s));
   MI355_TRY(bn_back(c, c->s2, c->sb2, c->sb2.dout, beta, s));
   MI355_TRY(conv_wgrad(c, c->s2, c->sb1.out, beta, s));
-  MI355_TRY(conv_dgrad(c, c->s2, c->sb1.dout, nullptr, s));
-  MI355_TRY(bn_back(c, c->s1, c->sb1, c->sb1.dout, beta, s));
+  int srows = 0;
+  MI355_TRY(conv_dgrad(c, c->s2, c->sb1.dout, nullptr, s, &c->s1, &c->sb1, &srows));
+  MI355_TRY(bn_back(c, c->s1, c->sb1, c->sb1.dout, beta, s, nullptr, srows));
   MI355_TRY(conv_wgrad(c, c->s1, c->sb0.out, beta, s));
-  MI355_TRY(conv_dgrad(c, c->s1, c->sb0.dout, nullptr, s));
-  MI355_TRY(bn_back(c, c->s0, c->sb0, c->sb0.dout, beta, s));
+  MI355_TRY(conv_dgrad(c, c->s1, c->sb0.dout, nullptr, s, &c->s0, &c->sb0, &srows));
+  MI355_TRY(bn_back(c, c->s0, c->sb0, c->sb0.dout, beta, s, nullptr, srows));
   MI355_TRY(conv_wgrad(c, c->s0, c->h0, beta, s));
   MI355_TRY(after_segment(c, (int)c->blocks.size() + 1, s));
   MI355_TRY(join(c, s));

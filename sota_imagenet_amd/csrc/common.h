@@ -92,6 +92,7 @@ struct IgemmArgs {
   const uint8_t* bn_bits = nullptr;    // 1 byte per 16-byte vector of out
   const float* bn_mean = nullptr;      // [Ncols]
   const float* bn_invstd = nullptr;    // [Ncols]
+  float bn_slope = 0.f;                // 0: ReLU mask (dz = 0 where the bit is clear); 0.01: leaky ReLU (dz = out * 0.01 there) — generated bf16 kernels only (igemm_leaky_sums_legal)
   // BatchNorm + ReLU of the INPUT in the operand path (generated stride-1 3x3 and resident-weight 1x1 forward kernels only: igemm_bn_in_legal): `in` is the raw output y
   // of the previous convolution, the kernel reads relu(y * scale[c] + shift[c]) rounded to the tensor dtype — bn_apply's value — and leaves that
   // tensor and its ReLU bits in memory as a by-product (the weight gradient and the BN backward read them as before)
@@ -124,6 +125,8 @@ struct WgradArgs {
 
 // ---- kernel launchers (all enqueue on `stream`, return mi355_status) -------------------------------
 // stat_rows (optional): number of partial rows written to a.stat_partial, 0 if the statistics were not produced
+// does a generated kernel with the leaky form of the BN-backward sums (IgemmArgs::bn_slope == 0.01) take this launch?  (no other kernel has that epilogue)
+bool igemm_leaky_sums_legal(int dtype, const IgemmArgs& a, int nclass);
 int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows = nullptr);
 bool igemm_sub2_legal(int dtype, const IgemmArgs& a, int nclass);
 bool dconv_fp8_legal(const IgemmArgs& a, int nclass);   // launch_igemm_fp8: the generated e4m3 3x3 kernel serves this launch

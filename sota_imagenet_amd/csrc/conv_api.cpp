@@ -362,7 +362,16 @@ int mi355_conv2d_dgrad(int dtype, const void* dy, const void* w, void* dx, const
 int mi355_conv2d_dgrad_bn(int dtype, const void* dy, const void* w, void* dx, const void* addend, const uint8_t* addend_bits, int addend_sub2, const void* bn_y,
                           const uint8_t* bn_bits, const float* bn_mean, const float* bn_invstd, float* partial, size_t partial_bytes, int* nblk, int N,
                           int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+  return mi355_conv2d_dgrad_bn_leaky(dtype, dy, w, dx, addend, addend_bits, addend_sub2, bn_y, bn_bits, bn_mean, bn_invstd, 0.f, partial, partial_bytes, nblk, N, H, W,
+                                     Cin, Cout, KH, KW, stride, pad, ws, ws_bytes, stream);
+}
+
+int mi355_conv2d_dgrad_bn_leaky(int dtype, const void* dy, const void* w, void* dx, const void* addend, const uint8_t* addend_bits, int addend_sub2,
+                                const void* bn_y, const uint8_t* bn_bits, const float* bn_mean, const float* bn_invstd, float slope, float* partial,
+                                size_t partial_bytes, int* nblk, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* ws,
+                                size_t ws_bytes, void* stream) {
   MI355_TRY(check_conv(dtype, Cin, Cout, KH, KW, stride));
+  MI355_ARG(slope == 0.f || partial, "dgrad_bn_leaky: a slope without the BN-backward sums");
   const size_t es = dtype_size(dtype);
   const size_t wbytes = (size_t)Cin * KH * KW * Cout * es;
   MI355_ARG(ws && ws_bytes >= wbytes, "dgrad_bn: workspace too small (%zu < %zu)", ws_bytes, wbytes);
@@ -379,7 +388,7 @@ int mi355_conv2d_dgrad_bn(int dtype, const void* dy, const void* w, void* dx, co
   if (partial) {
     a.stat_partial = partial;
     a.stat_rows_cap = (int)std::min<size_t>(partial_bytes / ((size_t)2 * Cin * sizeof(float)), 1u << 20);
-    a.bn_y = bn_y; a.bn_bits = bn_bits; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd;
+    a.bn_y = bn_y; a.bn_bits = bn_bits; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd; a.bn_slope = slope;
   }
   if (nblk) *nblk = 0;
   return launch_igemm(dtype, a, nclass, s, partial ? nblk : nullptr);

@@ -874,6 +874,11 @@ static bool choose_igemm8(const IgemmArgs& a, int nclass, int* bm, int* bn, int*
   return false;
 }
 
+bool igemm_leaky_sums_legal(int dtype, const IgemmArgs& a, int nclass) {
+  if (dtype != MI355_BF16 || !a.bn_y || !a.stat_partial || a.bn_slope != 0.01f || knobs().error[0]) return false;
+  return dconv_legal(a, nclass) || po_legal(a, nclass) || pk_legal(a, nclass);
+}
+
 int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows) {
   const int bk = BKB / (int)dtype_size(dtype);
   MI355_ARG(a.in && a.wt && a.out, "igemm: null pointer");
@@ -888,6 +893,7 @@ int launch_igemm(int dtype, const IgemmArgs& a, int nclass, hipStream_t stream, 
   const long tiles128 = (long)cdiv(a.N * a.Hsub * a.Wsub, 128) * nclass * (a.Ncols / 128);
   const bool wide = (a.Ncols % 128 == 0) && tiles128 * 2 >= device_cus();
   MI355_ARG(dtype == MI355_BF16 || !a.addend_sub2, "igemm: a half-resolution addend needs the generated pointwise kernel (igemm_sub2_legal)");
+  MI355_ARG(a.bn_slope == 0.f || igemm_leaky_sums_legal(dtype, a, nclass), "igemm: BN-backward sums under a leaky mask need a generated kernel with that epilogue and slope 0.01 (igemm_leaky_sums_legal)");
   MI355_ARG(a.bn_in == nullptr || igemm_bn_in_legal(dtype, a, nclass), "igemm: the input's BatchNorm in the operand path needs a generated kernel with that form (igemm_bn_in_legal)");
   if (dtype == MI355_F32)
     return wide ? launch_t<float, 128, 128>(a, nclass, stream, stat_rows) : launch_t<float, 128, 64>(a, nclass, stream, stat_rows);

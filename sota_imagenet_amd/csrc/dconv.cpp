@@ -236,7 +236,7 @@ int find_pw(const IgemmArgs& a, int nclass, int stats) {
   if (a.cls[0].taps[0].dh != 0 || a.cls[0].taps[0].dw != 0 || a.cls[0].taps[0].wtap != 0 || a.cls[0].ph != 0 || a.cls[0].pw != 0) return -1;
   if (a.Hsub != a.Hin || a.Wsub != a.Win || a.Hout != a.Hin || a.Wout != a.Win) return -1;
   if (a.pix_stride != a.Ck || a.addend != nullptr || a.q_scale_in != nullptr || a.q_scale_wt != nullptr) return -1;
-  if (stats == 2) return -1;
+  if (stats >= 2) return -1;
   const long M = (long)a.N * a.Hin * a.Win;
   for (int i = 0; i < NPW; ++i) {
     const PwVariant& v = g_pw[i];
@@ -268,7 +268,8 @@ int find_wg1(int dtype, const WgradArgs& a) {
   return -1;
 }
 
-int wanted_stats(const IgemmArgs& a) { return a.stat_partial == nullptr ? 0 : (a.bn_y != nullptr ? 2 : 1); }
+// 3: the BN-backward sums under a leaky-ReLU mask of slope 0.01 (asm/dconv_gen.py Cfg.stats, LEAKY_BITS)
+int wanted_stats(const IgemmArgs& a) { return a.stat_partial == nullptr ? 0 : (a.bn_y != nullptr ? (a.bn_slope != 0.f ? 3 : 2) : 1); }
 
 // the long-reduction pointwise kernel that can run this launch (1x1, stride 1, no addend), or -1
 int find_pk(const IgemmArgs& a, int nclass, int stats) {

@@ -154,11 +154,12 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, addend=None):
     return dx
 
 
-def conv2d_dgrad_bn(dy, w, x_shape, stride=1, pad=0, addend=None, addend_bits=None, bn_y=None, bn_bits=None, bn_mean=None, bn_invstd=None, addend_sub2=False):
+def conv2d_dgrad_bn(dy, w, x_shape, stride=1, pad=0, addend=None, addend_bits=None, bn_y=None, bn_bits=None, bn_mean=None, bn_invstd=None, addend_sub2=False, slope=0.0):
     """the data gradient as the executor's backward launches it: dx = dgrad(dy) + addend (under the ReLU bits addend_bits), and — with
     bn_y / bn_bits / bn_mean / bn_invstd — the BN-backward partial rows [nblk][2][Cin] (sum dz, sum dz * xhat) of the layer dx is the
     activation gradient of.  addend_sub2: the addend is [N, H/2, W/2, Cin], standing for a full-resolution tensor that is zero at odd rows /
-    columns.  Returns (dx, partial or None)."""
+    columns.  slope: the sums under a leaky-ReLU mask (dz = dx * slope where the bit is clear; 0.01 at BResNet-50's shapes, mi355_conv2d_dgrad_bn_leaky).
+    Returns (dx, partial or None)."""
     _need_cuda(dy, w, addend, addend_bits, bn_y, bn_bits, bn_mean, bn_invstd)
     N, H, W, Cin = x_shape
     Cout, KH, KW, _ = w.shape
@@ -169,9 +170,9 @@ def conv2d_dgrad_bn(dy, w, x_shape, stride=1, pad=0, addend=None, addend_bits=No
     nblk = ctypes.c_int(0)
     if bn_y is not None:
         part = torch.empty((4096, 2, Cin), dtype=torch.float32, device=dy.device)
-    check(_L().mi355_conv2d_dgrad_bn(dt, ptr(dy), ptr(w), ptr(dx), ptr(addend), ptr(addend_bits), int(addend_sub2), ptr(bn_y), ptr(bn_bits), ptr(bn_mean), ptr(bn_invstd),
-                                     ptr(part), 0 if part is None else part.numel() * 4, ctypes.byref(nblk), N, H, W, Cin, Cout, KH, KW, stride, pad,
-                                     ptr(ws), n, cur_stream()))
+    check(_L().mi355_conv2d_dgrad_bn_leaky(dt, ptr(dy), ptr(w), ptr(dx), ptr(addend), ptr(addend_bits), int(addend_sub2), ptr(bn_y), ptr(bn_bits), ptr(bn_mean),
+                                           ptr(bn_invstd), float(slope), ptr(part), 0 if part is None else part.numel() * 4, ctypes.byref(nblk), N, H, W, Cin, Cout,
+                                           KH, KW, stride, pad, ptr(ws), n, cur_stream()))
     if part is not None:
         part = part[:nblk.value] if nblk.value > 0 else None
     return dx, part

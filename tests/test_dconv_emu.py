@@ -63,6 +63,25 @@ def test_e4m3_direct_conv_kernels_are_exact_in_the_emulator(name, kw):
         assert r["stat_err"] < 1e-6, r
 
 
+@pytest.mark.parametrize("mod,name,kw", [
+    ("dconv", "dconv_l3_s3", dict(Cin=64, NCOLS=512, ntile=1, tiles=(1,), dgrad_taps=True)),
+    ("dconv", "dconv_l1_s3", dict(tiles=(14, 27), dgrad_taps=True)),
+    ("dconv", "dconv_v3_s3", dict(Cin=64, tiles=(0, 3), dgrad_taps=True)),
+    ("po", "po_k256_b64_s3_a0", dict(M=300, N=64, tpg=2, groups=((1, 0), (0, 0)))),
+    ("po", "po_k512_b128_s3_a0", dict(M=150, N=256, tpg=2, groups=((1, 1), (0, 0)))),
+    ("pk", "pk_k1024_n256_w196_s3", dict(tiles=(0, 2), Cin=192)),
+    ("pk", "pk_k2048_n512_w98_s3", dict(tiles=(0,), ntile=1, Cin=192)),
+])
+def test_bn_backward_sums_under_a_leaky_mask_are_exact_in_the_emulator(mod, name, kw):
+    """the stats == 3 epilogues (BASELINE configs[3]'s leaky ReLU, slope 0.01: dz = dx where the mask bit is set, fp32(dx) * fp32(0.01) elsewhere) of
+    the three generator families: outputs exact, sums against fp64"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import importlib
+
+    r = importlib.import_module(mod + "_emu_check").run(name, **kw)
+    assert r["max_err"] == 0.0 and r["untouched_ok"] and r["stat_err"] < 1e-6, r
+
+
 @pytest.mark.parametrize("name,kw", [
     ("dconv_l3_d2_s2", dict(Cin=128, tiles=(1,))),                                 # whole-image tiles, 2 chunks, BN-backward sums, all four classes
     ("dconv_l3_d2_s0", dict(Cin=192, classes=(0, 3))),                             # odd chunk count: the 1-tap class requests weights two chunks ahead

@@ -391,6 +391,62 @@ def test_bn_backward_sums_of_the_data_gradient_against_the_oracle(dev):
     assert (s[1] - dgamma.double()).abs().max() <= 1e-4 * dgamma.abs().max()
 
 
+# BASELINE configs[3] (BResNet-50): every data gradient whose output is the gradient of a leaky-ReLU activation behind a BatchNorm —
+# (N, H, Cx = channels of dx, Cy = channels of dy, K, kernel): conv2's 3x3 (stride-1 blocks, striding blocks at their input resolution, the deep stem),
+# conv3's 1x1 (4 C -> C)
+LEAKY = [(256, 56, 64, 64, 3, "dconv_l1_s3"), (256, 28, 128, 128, 3, "dconv_l2_s3"), (256, 14, 256, 256, 3, "dconv_l3_s3"), (256, 7, 512, 512, 3, "dconv_l4_s3"),
+         (32, 56, 128, 128, 3, "dconv_v2_s3"), (64, 28, 256, 256, 3, "dconv_v3_s3"), (256, 14, 512, 512, 3, "dconv_v4_s3"), (16, 112, 64, 64, 3, "dconv_v0_s3"),
+         (256, 56, 64, 256, 1, "po_k256_b64_s3_a0"), (256, 28, 128, 512, 1, "po_k512_b128_s3_a0"), (256, 14, 256, 1024, 1, "pk_k1024_n256_w196_s3"),
+         (256, 7, 512, 2048, 1, "pk_k2048_n512_w98_s3"), (6, 14, 256, 1024, 1, "pk_k1024_n256_w196_s3")]
+
+
+@pytest.mark.parametrize("N,H,Cx,Cy,K,kernel", LEAKY)
+def test_data_gradient_with_bn_backward_sums_under_a_leaky_mask_is_exact(dev, N, H, Cx, Cy, K, kernel):
+    """mi355_conv2d_dgrad_bn_leaky (slope 0.01): dx bit for bit the fp32 transposed convolution of integer data, the partial rows against fp64 sums of
+    dz = dx where the bit is set, fp32(dx) * fp32(0.01) elsewhere (what bn_reduce_kernel<MASK = 3> forms), and dz * xhat; the kernel asserted by name"""
+    from sota_imagenet_amd import ops
+
+    torch.manual_seed(21)
+    dy = torch.randint(-2, 3, (N, H, H, Cy), device=dev).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (Cy, K, K, Cx), device=dev).to(torch.bfloat16)
+    y = torch.randint(-3, 4, (N, H, H, Cx), device=dev).to(torch.bfloat16)
+    ybits = torch.randint(0, 256, (N, H, H, Cx // 8), device=dev, dtype=torch.uint8)
+    mean = (torch.randint(-4, 5, (Cx,), device=dev) * 0.25).float()
+    invstd = (torch.randint(1, 5, (Cx,), device=dev) * 0.5).float()
+    dx, part = ops.conv2d_dgrad_bn(dy, w, (N, H, H, Cx), 1, K // 2, bn_y=y, bn_bits=ybits, bn_mean=mean, bn_invstd=invstd, slope=0.01)
+    assert ops.last_conv_kernel() == kernel
+    ref = torch.nn.functional.conv_transpose2d(dy.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=K // 2).permute(0, 2, 3, 1).to(torch.bfloat16)
+    assert torch.equal(dx, ref)
+    bit = ((ybits.reshape(-1, Cx // 8, 1).to(torch.int32) >> torch.arange(8, device=dev, dtype=torch.int32)) & 1).reshape(-1, Cx)
+    r32 = ref.float().reshape(-1, Cx)
+    dz = torch.where(bit > 0, r32, r32 * 0.01).double()
+    xhat = (y.double().reshape(-1, Cx) - mean.double()) * invstd.double()
+    s1, s2 = dz.sum(0), (dz * xhat).sum(0)
+    assert part is not None and part.shape[1:] == (2, Cx)
+    assert (part[:, 0].double().sum(0) - s1).abs().max() <= 2e-6 * max(1.0, s1.abs().max().item())
+    assert (part[:, 1].double().sum(0) - s2).abs().max() <= 2e-6 * max(1.0, s2.abs().max().item())
+
+
+def test_a_leaky_slope_without_a_generated_kernel_is_an_error(dev):
+    """no other kernel has the leaky epilogue: a slope other than 0.01, fp32, or a shape without a generated kernel fail the call (the caller runs
+    the BatchNorm backward's own reduction pass) instead of silently returning ReLU sums"""
+    from sota_imagenet_amd import ops
+
+    N, H, Cx, Cy = 8, 14, 256, 1024
+    dy = torch.zeros((N, H, H, Cy), device=dev, dtype=torch.bfloat16)
+    w = torch.zeros((Cy, 1, 1, Cx), device=dev, dtype=torch.bfloat16)
+    y = torch.zeros((N, H, H, Cx), device=dev, dtype=torch.bfloat16)
+    ybits = torch.zeros((N, H, H, Cx // 8), device=dev, dtype=torch.uint8)
+    mean, invstd = torch.zeros(Cx, device=dev), torch.ones(Cx, device=dev)
+    with pytest.raises(RuntimeError, match="leaky"):
+        ops.conv2d_dgrad_bn(dy, w, (N, H, H, Cx), 1, 0, bn_y=y, bn_bits=ybits, bn_mean=mean, bn_invstd=invstd, slope=0.2)
+    with pytest.raises(RuntimeError, match="leaky"):
+        ops.conv2d_dgrad_bn(dy.float(), w.float(), (N, H, H, Cx), 1, 0, bn_y=y.float(), bn_bits=ybits, bn_mean=mean, bn_invstd=invstd, slope=0.01)
+    with pytest.raises(RuntimeError, match="leaky"):   # 18 x 18 pixels: no generated kernel
+        ops.conv2d_dgrad_bn(dy[:, :9, :9].repeat(1, 2, 2, 1).contiguous(), w, (N, 18, 18, Cx), 1, 0, bn_y=y[:, :9, :9].repeat(1, 2, 2, 1).contiguous(),
+                            bn_bits=ybits[:, :9, :9].repeat(1, 2, 2, 1).contiguous(), bn_mean=mean, bn_invstd=invstd, slope=0.01)
+
+
 @pytest.mark.parametrize("N,H,Cin,Cout,fam", [(256, 56, 64, 256, "po_k64_b256"), (256, 28, 128, 512, "po_k128_b256"), (7, 28, 128, 512, "po_k128_b256"),
                                                 (256, 56, 256, 128, "po_k256_b128"), (5, 20, 256, 128, "po_k256_b128"),
                                                 (256, 56, 256, 64, "po_k256_b64"), (256, 56, 64, 64, "po_k64_b64"), (3, 10, 256, 64, "po_k256_b64")])

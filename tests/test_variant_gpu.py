@@ -387,6 +387,31 @@ def test_bn3_backward_sums_from_the_eca_pass_match_the_reduction_pass(dev, dtype
     assert not torch.equal(grads[0], grads[1]) or dtype == "fp32"
 
 
+def test_bn1_bn2_backward_sums_from_the_data_gradient_epilogues_match_the_reduction_passes(dev, monkeypatch):
+    """default: the backward sums of bn1 / bn2 (and of the deep stem's BatchNorms) ride in the epilogue of the data gradient that produces their
+    activation gradient (`*_s3` kernels: the leaky-ReLU mask, tests/test_dconv_gpu.py pins each per op); MI355_BRESNET_FUSE_BN_BWD=0: the reduction
+    passes.  Same quantities in another summation order: the first backward segments agree to fp32 rounding, later ones within the amplification
+    a re-ordered sum meets in a randomly initialised network (the ResNet-50 counterpart: test_fused_bn_backward_sums_match_standalone_reduce)."""
+    from sota_imagenet_amd.bresnet import BResNet50
+    from sota_imagenet_amd.synth import synthetic_batch
+
+    N, S = 8, 224   # (the generated kernels serve the 224 px shapes)
+    data, target = synthetic_batch(N, S, seed=0, index=3, device="cuda")
+    grads = []
+    for sw in ("1", "0"):
+        monkeypatch.setenv("MI355_BRESNET_FUSE_BN_BWD", sw)
+        m = BResNet50(dtype="bf16", drop_rate=0.0, drop_connect_rate=0.2, weight_standardization=True, seed=4).cuda()
+        m.train()
+        R.smooth_ce(m(data), target, 0.1).backward()
+        torch.cuda.synchronize()
+        grads.append(m.flat_grads.detach().clone())
+        segs = m._segments
+    errs = [((grads[0][b:e] - grads[1][b:e]).norm() / grads[1][b:e].norm().clamp_min(1e-30)).item() for b, e in segs]
+    assert errs[0] == 0.0, "the head's gradients depend on no BatchNorm backward"
+    assert errs[1] < 1e-3 and max(errs) < 5e-2, ["%.1e" % x for x in errs]   # measured at N = 16: 1.5e-5, 1e-3 ... 1.6e-2 at the stem
+    assert not torch.equal(grads[0], grads[1]), "the fused epilogues did not run"
+
+
 def test_static_executor_at_the_baseline_batch_default_fused_tail_against_the_oracle(dev):
     """BASELINE configs[3] at its own size (bs 256, 224 px, bf16) in the DEFAULT environment — the fused ECA x drop-connect x shortcut x
     leaky-ReLU pass with bn3 / the downsample BN applied inside it (MI355_BRESNET_FUSED_ECA, MI355_BRESNET_LAZY_BN at their defaults),

@@ -118,10 +118,11 @@ def run(name, tiles=(0,), ntile=0, seed=0, dgrad_taps=False, check=True, over_sc
         s2 = np.stack([(refr[rows_of(t)] ** 2).sum(axis=(0, 1)) for t in range(ntiles_all)])
         tl = list(tiles)
         res["stat_err"] = float(max(np.abs(st[tl, 0][:, cols] - s1[tl][:, cols]).max(), np.abs(st[tl, 1][:, cols] - s2[tl][:, cols]).max()))
-    if c.stats == 2:
+    if c.stats >= 2:
         st = mem.array(a_stat, np.float32, (ntiles_all, 2, c.NCOLS))
         mask = ((bits[..., None] >> np.arange(8)) & 1).reshape(N * c.H, c.W, c.NCOLS).astype(np.float64)
-        dz = refr * mask
+        # stats 3: the leaky-ReLU mask — the fp32 product of the stored (bf16) value and 0.01f where the bit is clear
+        dz = refr * mask if c.stats == 2 else np.where(mask > 0, refr, (refr.astype(np.float32) * np.float32(0.01)).astype(np.float64))
         xhat = (yb.astype(np.float64).reshape(N * c.H, c.W, c.NCOLS) - mean) * invstd
         tl = list(tiles)
         s1 = np.stack([dz[rows_of(t)].sum(axis=(0, 1)) for t in range(ntiles_all)])

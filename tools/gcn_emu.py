@@ -731,6 +731,10 @@ class Emulator:
         a, b, c = self._v3(wv, ins)
         self._vw(wv, ins, (a << (b & 31)) | c)
 
+    def i_v_bfi_b32(self, wv, ins):
+        a, b, c = self._v3(wv, ins)
+        self._vw(wv, ins, (a & b) | ((a ^ 0xFFFFFFFF) & c))
+
     def i_v_and_or_b32(self, wv, ins):
         a, b, c = self._v3(wv, ins)
         self._vw(wv, ins, (a & b) | c)

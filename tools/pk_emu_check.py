@@ -56,9 +56,9 @@ def run(name, tiles=(0,), ntile=0, ntiles=None, seed=0, check=True, **over):
         s1 = np.stack([refr[rows(t)].sum(axis=0) for t in range(ntiles)])
         s2 = np.stack([(refr[rows(t)] ** 2).sum(axis=0) for t in range(ntiles)])
         res["stat_err"] = float(max(np.abs(st[tl, 0][:, cols] - s1[tl][:, cols]).max(), np.abs(st[tl, 1][:, cols] - s2[tl][:, cols]).max()))
-    if c.stats == 2:
+    if c.stats >= 2:
         mask = ((bits[..., None] >> np.arange(8)) & 1).reshape(M, c.NCOLS).astype(np.float64)
-        dz = refr * mask
+        dz = refr * mask if c.stats == 2 else np.where(mask > 0, refr, (refr.astype(np.float32) * np.float32(0.01)).astype(np.float64))   # stats 3: leaky mask
         xhat = (yb.astype(np.float64) - mean) * invstd
         s1 = np.stack([dz[rows(t)].sum(axis=0) for t in range(ntiles)])
         s2 = np.stack([(dz * xhat)[rows(t)].sum(axis=0) for t in range(ntiles)])

@@ -126,7 +126,7 @@ def run(name, M=200, N=None, groups=((0, 0),), tpg=None, seed=0, check=True, ext
                 s1, s2 = blk.sum(axis=0), (blk ** 2).sum(axis=0)
             else:
                 mask = ((bits[..., None] >> np.arange(8)) & 1).reshape(M, N).astype(np.float64)[rows_of(gi), cols_of(ct)]
-                dz = blk * mask
+                dz = blk * mask if c.stats == 2 else np.where(mask > 0, blk, (blk.astype(np.float32) * np.float32(0.01)).astype(np.float64))   # stats 3: leaky mask
                 xhat = (yb.astype(np.float64)[rows_of(gi), cols_of(ct)] - mean[cols_of(ct)]) * invstd[cols_of(ct)]
                 s1, s2 = dz.sum(axis=0), (dz * xhat).sum(axis=0)
             scale = max(scale, np.abs(s1).max(), np.abs(s2).max())
