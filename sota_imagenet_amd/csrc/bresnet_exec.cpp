@@ -151,6 +151,10 @@ struct mi355_bctx {
   std::vector<Bucket> buckets;
   mi355_comm* comm = nullptr;
   bool grad_sync = true, comm_dirty = false;
+  bool batch_prep = true;  // every convolution's weight preparation in two launches (MI355_BRESNET_BATCH_PREP=0: three small launches per layer)
+  BPrepDesc* prep_table = nullptr;       // device copy of the table (built for the bound parameter array)
+  const float* prep_params = nullptr;    // ... the array it was built for
+  int prep_n = 0, prep_rows = 0, prep_tiles = 0;
   bool fuse_bn_bwd = true; // bn1's / bn2's (and the deep stem's) backward sums in the epilogue of the data gradient in front of them (MI355_BRESNET_FUSE_BN_BWD=0: reduction passes)
   bool fused_add = true;   // shortcut gradient added in conv1's dgrad epilogue (MI355_BRESNET_FUSED_ADD=0: its own launch, as the per-op graph)
   const char* bad_switch = nullptr;   // an environment switch with a value outside its domain (the creation fails)
@@ -591,6 +595,7 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
   ar.add(&c->wg_ws, c->wg_ws_bytes);
   ar.add(&c->dw_tmp, dw_max * 4);
   ar.add(&c->eca_ws, ((size_t)6 * N * 2048 + 1152 + 2 * 2048) * 4);  // [s][dpool][dw parts][4 per-image sums for bn3's / the downsample BN's backward][the latter's row]
+  ar.add((void**)&c->prep_table, (size_t)64 * sizeof(BPrepDesc));
   c->arena_bytes = ar.size;
   if (hipMalloc((void**)&c->arena, c->arena_bytes) != hipSuccess) {
     set_error("bresnet50_create: hipMalloc(%zu bytes) failed: %s", c->arena_bytes, hipGetErrorString(hipGetLastError()));
@@ -615,6 +620,7 @@ int mi355_bresnet50_create(mi355_bctx** out, int device, int dtype, int N, int H
   c->overlap = env_switch("MI355_WGRAD_STREAM", 1, 1, &c->bad_switch) != 0;
   c->fused_add = env_switch("MI355_BRESNET_FUSED_ADD", 1, 1, &c->bad_switch) != 0;
   c->fuse_bn_bwd = env_switch("MI355_BRESNET_FUSE_BN_BWD", 1, 1, &c->bad_switch) != 0;
+  c->batch_prep = env_switch("MI355_BRESNET_BATCH_PREP", 1, 1, &c->bad_switch) != 0;
   c->lazy_bn = env_switch("MI355_BRESNET_LAZY_BN", 1, 1, &c->bad_switch) != 0;
   c->fused_eca = env_switch("MI355_BRESNET_FUSED_ECA", 1, 1, &c->bad_switch) != 0;
   c->eca_sums = env_switch("MI355_BRESNET_ECA_SUMS", 1, 1, &c->bad_switch) != 0;
@@ -701,16 +707,38 @@ int mi355_bresnet50_forward(mi355_bctx* c, const float* x_nchw, float* logits, i
   c->have_fwd = false;  // (until this pass has completed: a failed forward must not be differentiated)
   MI355_TRY(join(c, s));  // (a previous backward's side-stream work reads the tensors this pass overwrites)
   // ---- weight preparation: [standardise] -> pad -> cast; FC weights transposed for the input gradient ------------------------------
-  // The first conv's weights on the caller's stream; everything else (106 + 54 small launches) on the side stream, beside the input
-  // conversion and the first conv, which only have to wait for their own.
+  // The first conv's weights on the caller's stream; everything else on the side stream, beside the input conversion and the first conv, which only
+  // have to wait for their own: two launches over a table of every layer (variant.hip launch_bres_weight_prep) — as 106 + 54 small launches their
+  // dispatch chain outlasted the first conv and held the second one up.
   MI355_TRY(prep_weight(c, c->s0, s));
   hipStream_t ps;
   MI355_TRY(fork(c, s, &ps));
   int rc = 0;
-  for_each_conv(c, [&](VConv& v) {
-    if (rc == 0 && &v != &c->s0) rc = prep_weight(c, v, ps);
-    if (rc == 0 && tr && &v != &c->s0) rc = launch_transpose_any(dt, v.wp, v.wtr, v.Coutp, v.K * v.K, v.Cinp, ps);
-  });
+  if (c->batch_prep) {
+    if (c->prep_params != c->params) {   // (once per bound parameter array: the table holds pointers into it)
+      std::vector<BPrepDesc> tab;
+      int rows = 0, tiles = 0;
+      for_each_conv(c, [&](VConv& v) {
+        if (&v == &c->s0) return;
+        BPrepDesc d{};
+        d.w = c->params + v.w_off; d.w_hat = c->wstd ? v.w_hat : nullptr; d.mean = v.ws_mean; d.invstd = v.ws_invstd; d.wp = v.wp; d.wtr = v.wtr;
+        d.Cout = v.Cout; d.taps = v.K * v.K; d.Cin = v.Cin; d.Coutp = v.Coutp; d.Cinp = v.Cinp; d.row_begin = rows; d.tile_begin = tiles;
+        rows += v.Coutp;
+        tiles += (v.Cinp / 32) * (v.Coutp / 32) * v.K * v.K;
+        if (v.Cinp % 32 || v.Coutp % 32) rc = MI355_E_ARG;
+        tab.push_back(d);
+      });
+      MI355_ARG(rc == 0 && tab.size() <= 64, "bresnet50_forward: weight table (%zu layers)", tab.size());
+      MI355_HIP(hipMemcpy(c->prep_table, tab.data(), tab.size() * sizeof(BPrepDesc), hipMemcpyHostToDevice));
+      c->prep_params = c->params; c->prep_n = (int)tab.size(); c->prep_rows = rows; c->prep_tiles = tiles;
+    }
+    MI355_TRY(launch_bres_weight_prep(dt, c->prep_table, c->prep_n, c->prep_rows, c->prep_tiles, WS_EPS, tr, ps));
+  } else {
+    for_each_conv(c, [&](VConv& v) {
+      if (rc == 0 && &v != &c->s0) rc = prep_weight(c, v, ps);
+      if (rc == 0 && tr && &v != &c->s0) rc = launch_transpose_any(dt, v.wp, v.wtr, v.Coutp, v.K * v.K, v.Cinp, ps);
+    });
+  }
   if (rc) return rc;
   if (tr) MI355_TRY(launch_weight_prep(MI355_F32, c->params + c->fc_w_off, nullptr, c->fc_wtr, c->fc_pad, 1, 2048, ps));
   // ---- stem --------------------------------------------------------------------------------------------------------------------

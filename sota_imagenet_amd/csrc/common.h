@@ -214,6 +214,22 @@ struct PrepDesc {
   int Cout, taps, Cin;
   int tile_begin;  // first block of this layer; a layer has (Cout/PREP_TILE)*(Cin/PREP_TILE)*taps blocks
 };
+// BResNet-50 executor (variant.hip): [weight standardisation] -> zero pad -> cast, and the transposed copy, of EVERY convolution in two launches
+// (one workgroup per padded output row, then 32 x 32 transpose tiles) instead of three small launches per layer — 164 launches whose dispatch
+// latency, not their bytes, delayed the forward's second convolution.  Same arithmetic and summation order as mi355_weight_std_fwd /
+// launch_weight_pad_cast / launch_transpose_any (the per-op graph's path): bit-identical weights.
+struct BPrepDesc {
+  const float* w;    // fp32 master [Cout][taps][Cin]
+  float* w_hat;      // standardised fp32 copy (read by the weight gradient's backward), or null: standardisation off
+  float* mean;       // [Cout]
+  float* invstd;
+  void* wp;          // [Coutp][taps][Cinp] in the compute dtype
+  void* wtr;         // [Cinp][taps][Coutp], or null (inference forward)
+  int Cout, taps, Cin, Coutp, Cinp;
+  int row_begin;     // first workgroup of this layer in the row launch (Coutp workgroups)
+  int tile_begin;    // ... in the transpose launch ((Cinp / 32) * (Coutp / 32) * taps workgroups)
+};
+int launch_bres_weight_prep(int dtype, const BPrepDesc* table, int nconv, int total_rows, int total_tiles, float eps, bool transposed, hipStream_t stream);
 int launch_weight_prep_batch(int dtype, const PrepDesc* table, int nlayers, int total_tiles, const float* params,
                              hipStream_t stream);
 // same-dtype transpose [Cout][taps][Cin] -> [Cin][taps][Cout] (per-op API, weights already in `dtype`)

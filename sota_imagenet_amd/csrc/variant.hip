@@ -868,6 +868,71 @@ __global__ __launch_bounds__(256) void weight_pad_cast_kernel(const float* __res
   }
 }
 
+// every convolution's [standardise ->] pad -> cast in ONE launch: workgroup b = padded output row (layer l, channel co) of the table; the reduction is
+// weight_std_fwd_kernel's (same strided partial sums, same tree), the values written are pad_cast's of the standardised row
+template <typename T>
+__global__ __launch_bounds__(256) void bres_weight_rows_kernel(const BPrepDesc* __restrict__ table, int nconv, float eps) {
+  __shared__ double r1[256], r2[256];
+  const int b = blockIdx.x;
+  int l = 0;
+  while (l + 1 < nconv && table[l + 1].row_begin <= b) ++l;   // uniform
+  const BPrepDesc d = table[l];
+  const int co = b - d.row_begin;
+  const int K = d.taps * d.Cin;
+  T* wp = reinterpret_cast<T*>(d.wp) + (size_t)co * d.taps * d.Cinp;
+  if (co >= d.Cout) {   // a padding row
+    for (int i = threadIdx.x; i < d.taps * d.Cinp; i += 256) wp[i] = (T)0.f;
+    return;
+  }
+  const float* row = d.w + (size_t)co * K;
+  float mu = 0.f, is = 1.f;
+  if (d.w_hat) {
+    double a = 0, q = 0;
+    for (int i = threadIdx.x; i < K; i += 256) { a += row[i]; q += (double)row[i] * row[i]; }
+    r1[threadIdx.x] = a; r2[threadIdx.x] = q;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) { r1[threadIdx.x] += r1[threadIdx.x + st]; r2[threadIdx.x] += r2[threadIdx.x + st]; }
+      __syncthreads();
+    }
+    const double m = r1[0] / K, var = fmax(r2[0] / K - m * m, 0.0);
+    mu = (float)m;
+    is = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) { d.mean[co] = mu; d.invstd[co] = is; }
+    for (int i = threadIdx.x; i < K; i += 256) d.w_hat[(size_t)co * K + i] = (row[i] - mu) * is;
+  }
+  for (int i = threadIdx.x; i < d.taps * d.Cinp; i += 256) {
+    const int t = i / d.Cinp, ci = i - t * d.Cinp;
+    float v = 0.f;
+    if (ci < d.Cin) {
+      v = row[t * d.Cin + ci];
+      if (d.w_hat) v = (v - mu) * is;
+    }
+    wp[i] = (T)v;
+  }
+}
+
+// ... and every transposed copy wtr[ci][t][co] = wp[co][t][ci] in one launch of 32 x 32 tiles (weights.hip weight_prep_kernel's tile)
+template <typename T>
+__global__ __launch_bounds__(256) void bres_weight_transpose_kernel(const BPrepDesc* __restrict__ table, int nconv) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.x;
+  int l = 0;
+  while (l + 1 < nconv && table[l + 1].tile_begin <= b) ++l;
+  const BPrepDesc d = table[l];
+  const int local = b - d.tile_begin;
+  const int nci = d.Cinp / 32, nco = d.Coutp / 32;
+  const int ci0 = (local % nci) * 32, co0 = ((local / nci) % nco) * 32, t = local / (nci * nco);
+  const T* w = reinterpret_cast<const T*>(d.wp);
+  T* wt = reinterpret_cast<T*>(d.wtr);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = (float)w[((size_t)(co0 + r) * d.taps + t) * d.Cinp + ci0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) wt[((size_t)(ci0 + r) * d.taps + t) * d.Coutp + co0 + tx] = (T)tile[tx][r];
+}
+
 // ... and the way back for the gradient: dw[Cout][taps][Cin] = beta * dw + dwp[Coutp][taps][Cinp] restricted
 __global__ __launch_bounds__(256) void weight_unpad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, float beta, int Cout, int taps, int Cin, int Cinp) {
   const size_t total = (size_t)Cout * taps * Cin;
@@ -907,6 +972,18 @@ int launch_weight_pad_cast(int dtype, const float* w, void* wp, int Cout, int ta
   if (dtype == MI355_F32) hipLaunchKernelGGL(weight_pad_cast_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w, (float*)wp, Cout, taps, Cin, Coutp, Cinp);
   else hipLaunchKernelGGL(weight_pad_cast_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, w, (bf16_t*)wp, Cout, taps, Cin, Coutp, Cinp);
   MI355_LAUNCH_CHECK();
+  return 0;
+}
+int launch_bres_weight_prep(int dtype, const BPrepDesc* table, int nconv, int total_rows, int total_tiles, float eps, bool transposed, hipStream_t s) {
+  MI355_ARG(table && nconv > 0 && total_rows > 0, "bres_weight_prep: empty table");
+  if (dtype == MI355_F32) hipLaunchKernelGGL(bres_weight_rows_kernel<float>, dim3(total_rows), dim3(256), 0, s, table, nconv, eps);
+  else hipLaunchKernelGGL(bres_weight_rows_kernel<bf16_t>, dim3(total_rows), dim3(256), 0, s, table, nconv, eps);
+  MI355_LAUNCH_CHECK();
+  if (transposed) {
+    if (dtype == MI355_F32) hipLaunchKernelGGL(bres_weight_transpose_kernel<float>, dim3(total_tiles), dim3(256), 0, s, table, nconv);
+    else hipLaunchKernelGGL(bres_weight_transpose_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, s, table, nconv);
+    MI355_LAUNCH_CHECK();
+  }
   return 0;
 }
 int launch_weight_unpad(const float* dwp, float* dw, float beta, int Cout, int taps, int Cin, int Cinp, hipStream_t s) {
