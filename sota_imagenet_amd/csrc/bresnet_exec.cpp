@@ -741,6 +741,21 @@ int mi355_bresnet50_forward(mi355_bctx* c, const float* x_nchw, float* logits, i
   }
   if (rc) return rc;
   if (tr) MI355_TRY(launch_weight_prep(MI355_F32, c->params + c->fc_w_off, nullptr, c->fc_wtr, c->fc_pad, 1, 2048, ps));
+  // the drop-connect scales of every block and the dropout mask: one launch here instead of one per block on the caller's stream (counter-based: the same values)
+  const bool batch_keep = c->batch_prep && !keep_override && tr;
+  if (batch_keep) {
+    KeepBatch kb;
+    const int nb = (int)c->blocks.size();
+    for (int i = 1; i < nb && c->drop_connect > 0.f; ++i) {
+      const int e = kb.count++;
+      kb.keep[e] = c->blocks[i].keep; kb.n[e] = (size_t)N; kb.p[e] = c->drop_connect * (float)i / (float)nb; kb.counter[e] = step * 64 + (unsigned long long)i;
+    }
+    if (!dropout_override && c->drop_rate > 0.f) {
+      const int e = kb.count++;
+      kb.keep[e] = c->do_mask; kb.n[e] = (size_t)N * 2048; kb.p[e] = c->drop_rate; kb.counter[e] = step * 64 + 63;
+    }
+    MI355_TRY(launch_keep_scale_batch(kb, c->seed, ps));
+  }
   // ---- stem --------------------------------------------------------------------------------------------------------------------
   if (c->stem_im2col) MI355_TRY(launch_nchw_im2col3s2(dt, x_nchw, c->h0, N, c->H, c->W, s));
   else MI355_TRY(launch_nchw_pad64(dt, x_nchw, c->h0, N, c->H * c->W, s));
@@ -784,14 +799,15 @@ int mi355_bresnet50_forward(mi355_bctx* c, const float* x_nchw, float* logits, i
         b.scaled = true;
       }
     } else if (tr && c->drop_connect > 0.f && i > 0) {
-      MI355_TRY(mi355_keep_scale(b.keep, (size_t)N, c->drop_connect * (float)i / (float)nblocks, c->seed, step * 64 + (unsigned long long)i, s));
+      if (!batch_keep) MI355_TRY(mi355_keep_scale(b.keep, (size_t)N, c->drop_connect * (float)i / (float)nblocks, c->seed, step * 64 + (unsigned long long)i, s));
       b.scaled = true;
     }
     b.has_out_bits = c->fused_eca && c->use_bits && tr;
     if (c->fused_eca)  // gate, drop-connect scale, shortcut add and activation in one pass: the gated tensor is never stored
       MI355_TRY(launch_eca_residual_fwd(dt, b.b3.lazy ? b.c3.y : b.b3.out, c->params + b.eca_off, 3, b.scaled ? b.keep : nullptr, sc, b.out, b.pooled, b.gate, N,
                                         b.Ho * b.Wo, C4, ACT_LEAKY, s, b.b3.lazy ? b.b3.scale : nullptr, b.b3.shift,
-                                        (b.has_ds && b.bd.lazy) ? b.bd.scale : nullptr, b.bd.shift, b.has_out_bits ? b.out_bits : nullptr));
+                                        (b.has_ds && b.bd.lazy) ? b.bd.scale : nullptr, b.bd.shift, b.has_out_bits ? b.out_bits : nullptr,
+                                        c->batch_prep ? c->eca_ws : nullptr));
     else
       MI355_TRY(mi355_residual_act_fwd(dt, b.e, b.scaled ? b.keep : nullptr, sc, b.out, N, (size_t)b.Ho * b.Wo * C4, ACT_LEAKY, s));
     x = b.out;
@@ -804,7 +820,7 @@ int mi355_bresnet50_forward(mi355_bctx* c, const float* x_nchw, float* logits, i
     MI355_HIP(hipMemcpyAsync(c->do_mask, dropout_override, (size_t)N * 2048 * 4, hipMemcpyDeviceToDevice, s));
     c->dropped = true;
   } else if (!keep_override && tr && c->drop_rate > 0.f) {
-    MI355_TRY(mi355_keep_scale(c->do_mask, (size_t)N * 2048, c->drop_rate, c->seed, step * 64 + 63, s));
+    if (!batch_keep) MI355_TRY(mi355_keep_scale(c->do_mask, (size_t)N * 2048, c->drop_rate, c->seed, step * 64 + 63, s));
     c->dropped = true;
   }
   const float* feat = c->pooled;

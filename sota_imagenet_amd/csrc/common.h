@@ -229,6 +229,15 @@ struct BPrepDesc {
   int row_begin;     // first workgroup of this layer in the row launch (Coutp workgroups)
   int tile_begin;    // ... in the transpose launch ((Cinp / 32) * (Coutp / 32) * taps workgroups)
 };
+// drop-connect / dropout scale arrays of one forward pass sampled by ONE launch (the values of mi355_keep_scale for the same seed and counter)
+struct KeepBatch {
+  float* keep[20];
+  unsigned long long n[20];
+  unsigned long long counter[20];
+  float p[20];
+  int count = 0;
+};
+int launch_keep_scale_batch(const KeepBatch& kb, unsigned long long seed, hipStream_t s);
 int launch_bres_weight_prep(int dtype, const BPrepDesc* table, int nconv, int total_rows, int total_tiles, float eps, bool transposed, hipStream_t stream);
 int launch_weight_prep_batch(int dtype, const PrepDesc* table, int nlayers, int total_tiles, const float* params,
                              hipStream_t stream);
@@ -302,7 +311,7 @@ int launch_axpby(const float* src, float* dst, float beta, size_t n, hipStream_t
 // xs / xh (optional): x stands for x * xs[c] + xh[c] (a BatchNorm with identity activation applied on the fly); ss / sh2: the same for the shortcut
 int launch_eca_residual_fwd(int dtype, const void* x, const float* w, int k, const float* keep, const void* shortcut, void* out, float* pooled, float* gate,
                             int N, int HW, int C, int act, hipStream_t s, const float* xs = nullptr, const float* xh = nullptr, const float* ss = nullptr,
-                            const float* sh2 = nullptr, uint8_t* out_bits = nullptr);
+                            const float* sh2 = nullptr, uint8_t* out_bits = nullptr, float* raw_ws = nullptr /* [N][C] scratch: xs != null -> the pooled means' affine + the gate in one launch */);
 int launch_eca_residual_bwd(int dtype, const void* dout, const void* out, const void* x, const float* keep, const float* w, int k, const float* pooled,
                             const float* gate, void* dshortcut, void* dx, float* dw, float beta, float* ws, int N, int HW, int C, int act, hipStream_t s,
                             const float* xs = nullptr, const float* xh = nullptr, float* bn_row = nullptr, const float* bn_mean = nullptr,

@@ -390,6 +390,20 @@ __global__ void eca_gate_kernel(const float* pooled, const float* w, int k, floa
     gate[i] = 1.f / (1.f + __expf(-z));
   }
 }
+// the same with the BatchNorm the pooled means still have to go through (pooled = raw * xs[c] + xh[c]: pooled_affine_kernel) applied on the way: one
+// launch instead of two, raw and pooled are different arrays (a neighbour's raw value is read after its owner has written the affine one otherwise)
+__global__ void eca_gate_affine_kernel(const float* raw, const float* xs, const float* xh, const float* w, int k, float* pooled, float* gate, int N, int C) {
+  GRID_STRIDE(i, (size_t)N * C) {
+    const int c = (int)(i % C), n = (int)(i / C);
+    float z = 0.f;
+    for (int j = 0; j < k; ++j) {
+      const int cc = c + j - k / 2;
+      if (cc >= 0 && cc < C) z += w[j] * fmaf(raw[(size_t)n * C + cc], xs[cc], xh[cc]);
+    }
+    pooled[i] = fmaf(raw[i], xs[c], xh[c]);
+    gate[i] = 1.f / (1.f + __expf(-z));
+  }
+}
 // y = x * gate[n][c]   (BWD: dx = dy * gate[n][c] + dpool[n][c])
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void eca_scale_kernel(const T* x, const float* gate, const float* dpool, T* y, int N, int HW, int C) {
@@ -799,6 +813,17 @@ __global__ void keep_scale_kernel(float* keep, size_t n, float p, unsigned long 
     keep[i] = u >= p ? 1.f / (1.f - p) : 0.f;
   }
 }
+// every drop-connect / dropout scale array of a forward pass in one launch (blockIdx.y = array): the same counter-based values as keep_scale_kernel
+__global__ void keep_scale_batch_kernel(const KeepBatch kb, unsigned long long seed) {
+  const int e = blockIdx.y;
+  const unsigned long long base = splitmix64(seed ^ splitmix64(kb.counter[e]));
+  const float p = kb.p[e];
+  float* keep = kb.keep[e];
+  GRID_STRIDE(i, kb.n[e]) {
+    const float u = ((float)(splitmix64(base + 0x632BE59BD9B4E019ull * (i + 1)) >> 40) + 0.5f) * (1.0f / 16777216.0f);
+    keep[i] = u >= p ? 1.f / (1.f - p) : 0.f;
+  }
+}
 __global__ void mul_kernel(const float* a, const float* b, float* out, size_t n) {
   GRID_STRIDE(i, n) out[i] = a[i] * b[i];
 }
@@ -974,6 +999,14 @@ int launch_weight_pad_cast(int dtype, const float* w, void* wp, int Cout, int ta
   MI355_LAUNCH_CHECK();
   return 0;
 }
+int launch_keep_scale_batch(const KeepBatch& kb, unsigned long long seed, hipStream_t s) {
+  if (kb.count <= 0) return 0;
+  size_t nmax = 0;
+  for (int e = 0; e < kb.count; ++e) nmax = kb.n[e] > nmax ? kb.n[e] : nmax;
+  hipLaunchKernelGGL(keep_scale_batch_kernel, dim3(grid_for(nmax), kb.count), dim3(256), 0, s, kb, seed);
+  MI355_LAUNCH_CHECK();
+  return 0;
+}
 int launch_bres_weight_prep(int dtype, const BPrepDesc* table, int nconv, int total_rows, int total_tiles, float eps, bool transposed, hipStream_t s) {
   MI355_ARG(table && nconv > 0 && total_rows > 0, "bres_weight_prep: empty table");
   if (dtype == MI355_F32) hipLaunchKernelGGL(bres_weight_rows_kernel<float>, dim3(total_rows), dim3(256), 0, s, table, nconv, eps);
@@ -993,10 +1026,16 @@ int launch_weight_unpad(const float* dwp, float* dw, float beta, int Cout, int t
 }
 // out = act(eca(x) * keep[n] + shortcut); pooled / gate [N][C] are kept for backward (k = 3 ... 9 odd)
 int launch_eca_residual_fwd(int dtype, const void* x, const float* w, int k, const float* keep, const void* shortcut, void* out, float* pooled, float* gate,
-                            int N, int HW, int C, int act, hipStream_t s, const float* xs, const float* xh, const float* ss, const float* sh2, uint8_t* out_bits) {
-  MI355_TRY(mi355_gap_fwd(dtype, x, pooled, N, HW, C, s));
-  if (xs) hipLaunchKernelGGL(pooled_affine_kernel, dim3(grid_for((size_t)N * C)), dim3(256), 0, s, pooled, xs, xh, N, C);
-  hipLaunchKernelGGL(eca_gate_kernel, dim3(grid_for((size_t)N * C)), dim3(256), 0, s, pooled, w, k, gate, N, C);
+                            int N, int HW, int C, int act, hipStream_t s, const float* xs, const float* xh, const float* ss, const float* sh2, uint8_t* out_bits,
+                            float* raw_ws) {
+  if (xs && raw_ws) {   // raw means into the scratch, affine + gate in one launch
+    MI355_TRY(mi355_gap_fwd(dtype, x, raw_ws, N, HW, C, s));
+    hipLaunchKernelGGL(eca_gate_affine_kernel, dim3(grid_for((size_t)N * C)), dim3(256), 0, s, raw_ws, xs, xh, w, k, pooled, gate, N, C);
+  } else {
+    MI355_TRY(mi355_gap_fwd(dtype, x, pooled, N, HW, C, s));
+    if (xs) hipLaunchKernelGGL(pooled_affine_kernel, dim3(grid_for((size_t)N * C)), dim3(256), 0, s, pooled, xs, xh, N, C);
+    hipLaunchKernelGGL(eca_gate_kernel, dim3(grid_for((size_t)N * C)), dim3(256), 0, s, pooled, w, k, gate, N, C);
+  }
   const Affine af{xs, xh, ss, sh2};
   const size_t total = (size_t)N * HW * C;
   if (dtype == MI355_F32)
