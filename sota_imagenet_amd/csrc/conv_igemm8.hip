@@ -831,6 +831,15 @@ int launch8_t(const IgemmArgs& a, int nclass, hipStream_t stream, int* stat_rows
     ng = ny;
     k.xcd = 1;
   }
+  // a workgroup keeps the statistics of its n-tile group in LDS (<= 512 channels): where the rows alone fill the chip (ng = 1) and the launch has more
+  // columns than that (conv3 of layers 3 / 4 in the e4m3 step: 1024 / 2048), split the columns into groups rather than dropping the epilogue statistics —
+  // the pixel tile is read once per group (25 MB more at layer 3, batch 512) instead of a stand-alone pass over the output (205 MB + a launch)
+  if (a.stat_partial != nullptr && (ny / ng) * BN > 512)
+    for (int d = ng; d <= ny; ++d)
+      if (ny % d == 0 && (ny / d) * BN <= 512) {
+        ng = d;
+        break;
+      }
   k.ngroups = ng;
   k.ntpg = ny / ng;
   k.items = R * ng;
