@@ -399,6 +399,12 @@ int mi355_bresnet50_set_grad_sync(mi355_bctx* ctx, int on);
  * anti-aliased pool's output = layer1.0's input), "<block>.out|gate|keep|a2b|scin" (block output, ECA gate [N][C], drop-connect
  * scales [N] when sampled, blur-pooled a2 / average-pooled input of a striding block).  Read-only use.                             */
 int mi355_bresnet50_debug_tensor(const mi355_bctx* ctx, const char* name, void** ptr, int* dtype, int* ndim, int shape[4]);
+/* test hook of the NEXT mi355_bresnet50_backward call (cleared by it): for block i (0 = layer1.0 ... 15 = layer4.2), record[i] (device memory, the
+ * size of that block's output in the compute dtype, or null) receives the gradient wrt the block's output the moment the block's backward starts,
+ * and replay[i] (or null) overwrites that gradient first — teacher forcing between backward segments: two builds / switch settings fed the SAME
+ * incoming gradient per block must agree per segment to rounding, where free-running backward passes amplify a last-bit difference (the
+ * counterpart of mi355_resnet50_force_grad; the reference has no such hook: autograd under loss.backward(), /root/reference/sota_imagenet/callbacks.py:317). */
+int mi355_bresnet50_grad_hooks(mi355_bctx* ctx, void* const* record, const void* const* replay, int nblocks);
 
 /* ---- gradient collective inside the boundary: RCCL over xGMI, one process per GPU ---------------------------------
  * replaces torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) — train.py:113-114, process group

@@ -539,6 +539,23 @@ class BResNet50(_DropStream, _FlatModel):
                     self._grad_sync(k, b, e)
         self._grads_dirty = True
 
+    def grad_hooks(self, record=None, replay=None):
+        """test hook (mi355_bresnet50_grad_hooks) of the next backward of the pending training forward: record / replay are lists of 16 tensors (or None
+        entries) shaped like the blocks' outputs in the compute dtype — the gradient each block's backward starts from is copied out / replaced"""
+        from . import native
+
+        if getattr(self, "_last", None) is None:
+            raise RuntimeError("bresnet50: grad_hooks without a pending training forward")
+        arrs = []
+        for lst in (record, replay):
+            a = (ctypes.c_void_p * 16)()
+            for i, t in enumerate(lst or []):
+                if t is not None:
+                    a[i] = t.data_ptr()
+            arrs.append(a)
+        self._hook_alive = (record, replay)
+        native.check(native.lib().mi355_bresnet50_grad_hooks(self._last[0], arrs[0], arrs[1], 16))
+
     def debug_tensor(self, shape, name):
         """copy of an internal tensor of the last forward at batch shape (N,H,W) — test hook (mi355_bresnet50_debug_tensor)."""
         from . import native

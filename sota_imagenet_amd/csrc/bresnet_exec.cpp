@@ -151,6 +151,10 @@ struct mi355_bctx {
   std::vector<Bucket> buckets;
   mi355_comm* comm = nullptr;
   bool grad_sync = true, comm_dirty = false;
+  // test hooks of the NEXT backward call (mi355_bresnet50_grad_hooks): per block, where to copy the gradient wrt its output before its backward runs,
+  // and what to overwrite it with (teacher forcing between backward segments)
+  std::vector<void*> hook_record;
+  std::vector<const void*> hook_replay;
   bool batch_prep = true;  // every convolution's weight preparation in two launches (MI355_BRESNET_BATCH_PREP=0: three small launches per layer)
   BPrepDesc* prep_table = nullptr;       // device copy of the table (built for the bound parameter array)
   const float* prep_params = nullptr;    // ... the array it was built for
@@ -866,6 +870,11 @@ int mi355_bresnet50_backward(mi355_bctx* c, const float* dlogits, int accumulate
     VBlock& b = c->blocks[i];
     const void* xin = i > 0 ? c->blocks[i - 1].out : c->p;
     const int C4 = 4 * b.planes;
+    {  // test hooks: record / replace the gradient this segment starts from
+      const size_t gbytes = (size_t)N * b.Ho * b.Wo * C4 * c->es;
+      if (i < (int)c->hook_record.size() && c->hook_record[i]) MI355_HIP(hipMemcpyAsync(c->hook_record[i], g, gbytes, hipMemcpyDeviceToDevice, s));
+      if (i < (int)c->hook_replay.size() && c->hook_replay[i]) MI355_HIP(hipMemcpyAsync(const_cast<void*>(g), c->hook_replay[i], gbytes, hipMemcpyDeviceToDevice, s));
+    }
     bool lazy_dz = false, sums_row = false, ds_row = false;
     float* ds_row_at = c->eca_ws + (size_t)6 * N * 2048 + 1152;
     if (c->fused_eca) {
@@ -943,6 +952,19 @@ int mi355_bresnet50_backward(mi355_bctx* c, const float* dlogits, int accumulate
   if (c->comm && c->comm_dirty) {
     MI355_TRY(comm_join(c->comm, s));
     c->comm_dirty = false;
+  }
+  c->hook_record.clear();
+  c->hook_replay.clear();
+  return 0;
+}
+
+int mi355_bresnet50_grad_hooks(mi355_bctx* c, void* const* record, const void* const* replay, int nblocks) {
+  MI355_ARG(c && c->arena && nblocks == (int)c->blocks.size(), "bresnet50_grad_hooks: %d entries for %zu blocks", nblocks, c ? c->blocks.size() : (size_t)0);
+  c->hook_record.assign(nblocks, nullptr);
+  c->hook_replay.assign(nblocks, nullptr);
+  for (int i = 0; i < nblocks; ++i) {
+    if (record) c->hook_record[i] = record[i];
+    if (replay) c->hook_replay[i] = replay[i];
   }
   return 0;
 }

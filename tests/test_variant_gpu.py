@@ -412,6 +412,52 @@ def test_bn1_bn2_backward_sums_from_the_data_gradient_epilogues_match_the_reduct
     assert not torch.equal(grads[0], grads[1]), "the fused epilogues did not run"
 
 
+def _bres_backward(env, monkeypatch, data, target, record=False, replay=None, dtype="bf16"):
+    """one training forward + backward of a freshly built BResNet-50 executor under the environment `env`; with record: the gradients every block's
+    backward started from; with replay: those gradients forced (mi355_bresnet50_grad_hooks).  Returns (flat gradients, segments, recorded)."""
+    from sota_imagenet_amd.bresnet import BResNet50
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    m = BResNet50(dtype=dtype, drop_rate=0.0, drop_connect_rate=0.2, weight_standardization=True, seed=4).cuda()
+    m.train()
+    loss = R.smooth_ce(m(data), target, 0.1)
+    key = (data.shape[0], data.shape[2], data.shape[3])
+    rec = None
+    if record or replay is not None:
+        names = ["layer%d.%d.out" % (li + 1, bi) for li, nb in enumerate((3, 4, 6, 3)) for bi in range(nb)]
+        rec = [torch.empty_like(m.debug_tensor(key, n)) for n in names] if record else None
+        m.grad_hooks(record=rec, replay=replay)
+    loss.backward()
+    torch.cuda.synchronize()
+    return m.flat_grads.detach().clone(), m._segments, rec
+
+
+def test_default_backward_teacher_forced_per_segment_against_the_unfused_forms(dev, monkeypatch):
+    """the DEFAULT BResNet-50 backward (im2col stem, fused ECA tail with its sums, bn1 / bn2 sums in the data gradients' epilogues, batched
+    weight preparation) against the executor with those forms switched off, segment by segment under teacher forcing: run A records the gradient
+    every block's backward starts from, run B is fed exactly those (mi355_bresnet50_grad_hooks), so a segment's parameter gradients differ only by that
+    segment's own arithmetic — a TIGHT bound per segment instead of the 5e-2 a free-running comparison needs."""
+    from sota_imagenet_amd.synth import synthetic_batch
+
+    N, S = 8, 224
+    data, target = synthetic_batch(N, S, seed=0, index=5, device="cuda")
+    ga, segs, rec = _bres_backward({}, monkeypatch, data, target, record=True)
+    off = {"MI355_BRESNET_FUSE_BN_BWD": "0", "MI355_BRESNET_ECA_SUMS": "0", "MI355_BRESNET_BATCH_PREP": "0", "MI355_BRESNET_FUSED_ADD": "0"}
+    gb, _, _ = _bres_backward(off, monkeypatch, data, target, replay=rec)
+    errs = [((ga[b:e] - gb[b:e]).norm() / gb[b:e].norm().clamp_min(1e-30)).item() for b, e in segs]
+    # segment 0 = the head, 1 .. 16 = the blocks (last first), 17 = the stem (fed by block 0's own input gradient: not forced, so it carries one block's difference)
+    print("teacher-forced per-segment differences:", ["%.1e" % x for x in errs])
+    assert errs[0] == 0.0
+    assert max(errs[1:17]) < 4e-3, ["%.1e" % x for x in errs]   # measured 0.8e-3 .. 2.5e-3 (bf16 roundings inside one block); free-running: up to 1.8e-2
+    assert errs[17] < 1e-2, errs[17]                             # measured 4.5e-3
+    # and forcing is not vacuous: free-running, the same two settings drift apart towards the stem
+    gc, _, _ = _bres_backward(off, monkeypatch, data, target)
+    free = [((ga[b:e] - gc[b:e]).norm() / gc[b:e].norm().clamp_min(1e-30)).item() for b, e in segs]
+    print("free-running:", ["%.1e" % x for x in free])
+    assert max(free[8:17]) > 2 * max(errs[8:17]), (free, errs)
+
+
 def test_static_executor_at_the_baseline_batch_default_fused_tail_against_the_oracle(dev):
     """BASELINE configs[3] at its own size (bs 256, 224 px, bf16) in the DEFAULT environment — the fused ECA x drop-connect x shortcut x
     leaky-ReLU pass with bn3 / the downsample BN applied inside it (MI355_BRESNET_FUSED_ECA, MI355_BRESNET_LAZY_BN at their defaults),
