@@ -220,7 +220,9 @@ def tables(c):
                 g = grp[w]
                 if g is None or src[g] is None:
                     cands = [gg[w] for x2, gg in sl if x2 == xb and gg[w] is not None and src[gg[w]] is not None]
-                    assert cands, "a wave without any piece of variant %d" % xb
+                    if not cands:   # (two-row tiles: one row per wave, and this wave's row is halo in this tile class) another wave's piece: the same bytes to the same place
+                        cands = [g2 for x2, gg in sl if x2 == xb for g2 in gg if g2 is not None and src[g2] is not None]
+                    assert cands, "no piece of variant %d in this tile class" % xb
                     g = cands[0]
                 lds.append((g * bpr + xb) * 1024)
                 srcs.append(src[g])
@@ -1828,7 +1830,7 @@ def _variant_model_sizes():
     3x3 convolutions at 112 x 112 on 32 channels zero-padded to 64; /root/reference/configs/_old_configs/_first_attempts/BResNet50_encoder.yaml:41-51).
     Forward (s1), plain data gradient (s0) and the data gradient with the BN-backward sums under the leaky mask (s3)."""
     geo = {
-        "v0": dict(H=112, W=112, P=128, IPT=1, Cin=64, NCOLS=64, WM=4, WN=1, NT=4, ROWS_T=4),
+        "v0": dict(H=112, W=112, P=128, IPT=1, Cin=64, NCOLS=64, WM=4, WN=1, NT=4, ROWS_T=2),   # 2-row tiles: 80 KiB of LDS, TWO workgroups per CU (4-row tiles: one)
         "v2": dict(H=56, W=56, P=64, IPT=1, Cin=128, NCOLS=128, WM=4, WN=1, ROWS_T=4),
         "v3": dict(H=28, W=28, P=32, IPT=1, Cin=256, NCOLS=256, ROWS_T=7),
         "v4": dict(H=14, W=14, P=16, IPT=1, Cin=512, NCOLS=512),

@@ -38,9 +38,9 @@ def conv2d_fwd(x, w, stride=1, pad=0, stats=False):
         check(_L().mi355_conv2d_fwd(dtype_code(x.dtype), ptr(x), ptr(w), ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, cur_stream()))
         return y
     # rows of the statistics scratch: the implicit-GEMM kernels write <= 768, the generated kernels one per pixel tile (3584 for a
-    # 56 x 56 x 64 conv at batch 256, 7168 for a 112 x 112 x 64 one); the library takes the kernel the buffer allows (the static executors give
-    # it their widest layer's)
-    rows = 8192 if Cout <= 256 else 768
+    # 56 x 56 x 64 conv at batch 256, 14336 for a 112 x 112 x 64 one: two-row tiles); the library takes the kernel the buffer allows (the static
+    # executors give it their widest layer's)
+    rows = 16384 if Cout <= 128 else (8192 if Cout <= 256 else 768)
     partial = torch.empty(rows * 2 * Cout, dtype=torch.float32, device=x.device)
     nblk = ctypes.c_int(0)
     check(_L().mi355_conv2d_fwd_stats(dtype_code(x.dtype), ptr(x), ptr(w), ptr(y), ptr(partial), partial.numel() * 4, ctypes.byref(nblk), N, H, W, Cin,
