@@ -1736,6 +1736,8 @@ VARIANTS = {
     "dconv_l4_s1": Cfg("dconv_l4_s1", H=7, W=7, P=8, IPT=2, Cin=512, NCOLS=512, stats=1, NB=3),
     "dconv_l4_s2": Cfg("dconv_l4_s2", H=7, W=7, P=8, IPT=2, Cin=512, NCOLS=512, stats=2, NB=3),
     # layer 2 (28 x 28 x 128 -> 128): a tile = 14 output rows of one image (2 tiles per image), waves 4 (pixels) x 1, 128 columns
+    # (4-row tiles — 80 KiB of LDS, two workgroups per CU, what helps the single-chunk 112 x 112 kernels — measured here: forward 60.4 -> 67.2 us, data gradient
+    # 77.8 -> 75.1, step 17.76 -> 17.79: seven times the tiles re-stream the 295 KiB of weights of two chunks; not kept)
     "dconv_l2_s0": Cfg("dconv_l2_s0", H=28, W=28, P=32, IPT=1, Cin=128, NCOLS=128, stats=0, WM=4, WN=1, ROWS_T=14),
     "dconv_l2_s1": Cfg("dconv_l2_s1", H=28, W=28, P=32, IPT=1, Cin=128, NCOLS=128, stats=1, WM=4, WN=1, ROWS_T=14),
     "dconv_l2_s2": Cfg("dconv_l2_s2", H=28, W=28, P=32, IPT=1, Cin=128, NCOLS=128, stats=2, WM=4, WN=1, ROWS_T=14),
