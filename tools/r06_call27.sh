@@ -12,6 +12,6 @@ for v in old new; do
   rm -rf $O/r06y_$v
   if [ $v = old ]; then export MI355RN_LIB=$PWD/sota_imagenet_amd/lib/libmi355rn_old.so; else unset MI355RN_LIB; fi
   MI355_WGRAD_STREAM=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r06y_$v -- $S > /dev/null 2> $O/r06y_$v.err
-  f=$(ls $O/r06y_$v/*/*_kernel_stats.csv | head -1); echo "== $v"; grep "dconv_l2" $f | awk -F, '{printf "%s calls %s avg %.1f us\n", $1, $2, $4/1000}'
+  f=$(ls $O/r06y_$v/*/*_kernel_stats.csv | head -1); echo "== $v"; grep "dconv_l1" $f | awk -F, '{printf "%s calls %s avg %.1f us\n", $1, $2, $4/1000}'
   rm -rf $O/r06y_$v
 done
