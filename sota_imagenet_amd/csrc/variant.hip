@@ -462,13 +462,16 @@ __global__ __launch_bounds__(256) void eca_prod_reduce_kernel(const T* dy, const
 // The tensors are [N][C] (up to 256 x 2048): ECA_GB workgroups walk them grid-stride, each leaves its k partial weight
 // gradients in dwpart[block][9]; eca_dw_finish adds the ECA_GB rows in block order (fixed grid => bitwise reproducible).
 constexpr int ECA_GB = 128;
-__global__ __launch_bounds__(256) void eca_gate_bwd_kernel(const float* s, const float* gate, const float* pooled, const float* w, int k,
-                                                          float* dpool, float* dwpart, int N, int C, float inv_hw) {
-  __shared__ float red[256];
+// ECA_BT threads per workgroup: the kernel is a chain of dependent loads per element (29 us per launch with 256 threads = 16 elements per thread at
+// 256 x 2048; 16 launches per BResNet-50 step on the caller's stream) — 1024 threads walk 4 elements each; still ECA_GB partial rows (the scratch contract).
+constexpr int ECA_BT = 1024;
+__global__ __launch_bounds__(ECA_BT) void eca_gate_bwd_kernel(const float* s, const float* gate, const float* pooled, const float* w, int k,
+                                                             float* dpool, float* dwpart, int N, int C, float inv_hw) {
+  __shared__ float red[ECA_BT];
   float part[9];
   for (int j = 0; j < 9; ++j) part[j] = 0.f;
   const size_t total = (size_t)N * C;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)ECA_GB * 256) {
+  for (size_t i = (size_t)blockIdx.x * ECA_BT + threadIdx.x; i < total; i += (size_t)ECA_GB * ECA_BT) {
     const int c = (int)(i % C), n = (int)(i / C);
     const float dpre_i = s[i] * gate[i] * (1.f - gate[i]);
     float dp = 0.f;
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(256) void eca_gate_bwd_kernel(const float* s, const
   for (int j = 0; j < k; ++j) {
     red[threadIdx.x] = part[j];
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
+    for (int st = ECA_BT / 2; st > 0; st >>= 1) {
       if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
       __syncthreads();
     }
@@ -1073,7 +1076,7 @@ int launch_eca_residual_bwd(int dtype, const void* dout, const void* out, const 
       hipLaunchKernelGGL((eca_residual_bwd_reduce_kernel<bf16_t, false>), dim3(N * (C / 64)), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x,
                          keep, (bf16_t*)dshortcut, sprod, N, HW, C, act, xs, xh, nullptr, out_bits, nullptr);
   }
-  hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3(ECA_GB), dim3(256), 0, s, sprod, gate, pooled, w, k, dpool, dwpart, N, C, 1.f / (float)HW);
+  hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3(ECA_GB), dim3(ECA_BT), 0, s, sprod, gate, pooled, w, k, dpool, dwpart, N, C, 1.f / (float)HW);
   hipLaunchKernelGGL(eca_dw_finish_kernel, dim3(1), dim3(64), 0, s, dwpart, dw, k, beta);
   if (bn_row) hipLaunchKernelGGL(eca_bn_sums_kernel, dim3(C / 16), dim3(256), 0, s, sums, gate, dpool, keep, bn_mean, bn_invstd, bn_row, N, C, HW);
   if (ds_row) hipLaunchKernelGGL(eca_ds_sums_kernel, dim3(C / 16), dim3(256), 0, s, sums, ds_mean, ds_invstd, ds_row, N, C);
@@ -1198,7 +1201,7 @@ int mi355_eca_bwd(int dtype, const void* dy, const void* x, const float* w, int 
   float* dwpart = ws + (size_t)2 * N * C;  // [ECA_GB][9]
   DISPATCH_T(dtype, hipLaunchKernelGGL(eca_prod_reduce_kernel<float>, dim3(N * (C / 32)), dim3(256), 0, s, (const float*)dy, (const float*)x, sprod, N, HW, C),
              hipLaunchKernelGGL(eca_prod_reduce_kernel<bf16_t>, dim3(N * (C / 64)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, sprod, N, HW, C));
-  hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3(ECA_GB), dim3(256), 0, s, sprod, gate, pooled, w, k, dpool, dwpart, N, C, 1.f / (float)HW);
+  hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3(ECA_GB), dim3(ECA_BT), 0, s, sprod, gate, pooled, w, k, dpool, dwpart, N, C, 1.f / (float)HW);
   hipLaunchKernelGGL(eca_dw_finish_kernel, dim3(1), dim3(64), 0, s, dwpart, dw, k, beta);
   const size_t total = (size_t)N * HW * C;
   DISPATCH_T(dtype, hipLaunchKernelGGL((eca_scale_kernel<float, true>), dim3(grid_for(total / 4)), dim3(256), 0, s, (const float*)dy, gate, dpool, (float*)dx, N, HW, C),
