@@ -246,6 +246,7 @@ static int fin_wide_mode() { return 2; }
 // one channel per workgroup?  0 never; 1: few channels and more than one pass of rows (round 5's first rule); 2 (default): also up to 512
 // channels from 128 rows on — four-channel workgroups leave most of the chip idle there and the kernel is a chain of load latencies
 // (same box: 18.15 -> 18.05 ms per step, 17.75 -> 17.69 on a faster box); 3 / 4: wider still (no further gain)
+constexpr int FIN_WIDE_ROWS = 4096;
 static bool fin_one_channel(int C, int nblk) {
   const int m = fin_wide_mode();
   if (m <= 0) return false;
@@ -255,15 +256,17 @@ static bool fin_one_channel(int C, int nblk) {
   return (C <= 128 && nblk > 512) || (C <= 512 && nblk >= 128);
 }
 
-template <int MODE, int CPW = 4>
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const FinalizeArgs p) {
+template <int MODE, int CPW = 4, int BT = 256>
+__global__ __launch_bounds__(BT) void bn_finalize_kernel(const FinalizeArgs p) {
   // CPW channels x 256 / CPW slices per workgroup: every thread has <= 8 independent partial rows to add per pass, then a fixed-shape
   // LDS tree — the summation order depends only on nblk (and CPW, itself a function of C and nblk), so results are bitwise reproducible.
   // CPW = 4: 64 slices, one pass up to 512 rows.  CPW = 1 (few channels, many rows: the 64-channel layers whose direct-conv kernels
   // leave one row per 4-row tile, 3584 at batch 256): 256 slices, so 3584 rows are two passes instead of seven dependent ones — the
   // kernel is a chain of load latencies, and beside an HBM-bound weight-gradient kernel each pass takes 10 us
   // (profiles/r05_bn_finalize_per_launch.txt: 35 us serial / 70-150 us in the step -> 8 / 15).
-  constexpr int SL = 256 / CPW;
+  // BT = 1024 (CPW = 1, more than FIN_WIDE_ROWS rows: the 112 x 112 x 64 layers of BASELINE configs[3] on two-row tiles leave 14 336): 1024 slices, two
+  // passes instead of seven (59 -> ~20 us per launch).  The shape is a function of (C, nblk) like CPW: every path that finalizes a layer takes the same one.
+  constexpr int SL = BT / CPW;
   __shared__ double red[2][SL][CPW];
   const int cl = threadIdx.x % CPW, sl = threadIdx.x / CPW;
   const int c = blockIdx.x * CPW + cl;
@@ -797,7 +800,8 @@ int launch_bn_finalize(const float* partial, const float* pivot, int nblk, int M
   a.shift = shift;
   a.eps = eps;
   a.momentum = momentum;
-  if (fin_one_channel(C, nblk)) hipLaunchKernelGGL((bn_finalize_kernel<0, 1>), dim3(C), dim3(256), 0, s, a);
+  if (fin_one_channel(C, nblk) && nblk > FIN_WIDE_ROWS) hipLaunchKernelGGL((bn_finalize_kernel<0, 1, 1024>), dim3(C), dim3(1024), 0, s, a);
+  else if (fin_one_channel(C, nblk)) hipLaunchKernelGGL((bn_finalize_kernel<0, 1>), dim3(C), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((bn_finalize_kernel<0, 4>), dim3(C / 4), dim3(256), 0, s, a);
   MI355_LAUNCH_CHECK();
   return 0;
@@ -935,7 +939,8 @@ int launch_bn_bwd_finalize(const float* partial, int nblk, int M, int C, const f
   a.dbeta = dbeta;
   a.beta_acc = beta_acc;
   a.coef = coef;
-  if (fin_one_channel(C, nblk)) hipLaunchKernelGGL((bn_finalize_kernel<1, 1>), dim3(C), dim3(256), 0, s, a);
+  if (fin_one_channel(C, nblk) && nblk > FIN_WIDE_ROWS) hipLaunchKernelGGL((bn_finalize_kernel<1, 1, 1024>), dim3(C), dim3(1024), 0, s, a);
+  else if (fin_one_channel(C, nblk)) hipLaunchKernelGGL((bn_finalize_kernel<1, 1>), dim3(C), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((bn_finalize_kernel<1, 4>), dim3(C / 4), dim3(256), 0, s, a);
   MI355_LAUNCH_CHECK();
   return 0;

@@ -645,16 +645,17 @@ __global__ __launch_bounds__(256) void eca_residual_bwd_reduce_kernel(const T* d
 //   sum dz3        = sum_n keep gate a + HW dpool
 //   sum dz3 * xhat = invstd * sum_n [ keep gate (b - mean a) + dpool (y - HW mean) ]          (xhat = (x - mean) * invstd)
 // from the per-image sums of pass 1 — one partial row [2][C] for bn_finalize (fp64 over the images, in image order)
-__global__ __launch_bounds__(256) void eca_bn_sums_kernel(const float* sums, const float* gate, const float* dpool, const float* keep, const float* mean,
-                                                          const float* invstd, float* row, int N, int C, int HW) {
-  // 16 channels x 16 image slices per workgroup (a serial walk over the images is a chain of 256 load latencies); slices added in slice order
-  __shared__ double red[2][16][16];
+constexpr int ECA_SL = 64;   // image slices per channel (1024 threads per workgroup: 4 images per thread at batch 256 — one round of loads instead of four dependent ones)
+__global__ __launch_bounds__(16 * ECA_SL) void eca_bn_sums_kernel(const float* sums, const float* gate, const float* dpool, const float* keep, const float* mean,
+                                                                 const float* invstd, float* row, int N, int C, int HW) {
+  // 16 channels x ECA_SL image slices per workgroup (a serial walk over the images is a chain of 256 load latencies); slices added in slice order
+  __shared__ double red[2][ECA_SL][16];
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   const double mu = (double)mean[c], hw = (double)HW;
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll 4
-  for (int n = sl; n < N; n += 16) {
+  for (int n = sl; n < N; n += ECA_SL) {
     const size_t o = (size_t)n * C + c;
     const double kg = (double)(keep ? keep[n] : 1.f) * (double)gate[o], dp = (double)dpool[o];
     const double a = (double)sums[o], b = (double)sums[(size_t)N * C + o], y = (double)sums[(size_t)2 * N * C + o];
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(256) void eca_bn_sums_kernel(const float* sums, con
   __syncthreads();
   if (sl == 0) {
     double t1 = 0.0, t2 = 0.0;
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < ECA_SL; ++k) {
       t1 += red[0][k][cl];
       t2 += red[1][k][cl];
     }
@@ -675,13 +676,13 @@ __global__ __launch_bounds__(256) void eca_bn_sums_kernel(const float* sums, con
   }
 }
 // the downsample BatchNorm's backward sums (identity activation: its output gradient is dz): sum dz = sum_n a, sum dz * xhat = invstd (sum_n d - mean sum_n a)
-__global__ __launch_bounds__(256) void eca_ds_sums_kernel(const float* sums, const float* mean, const float* invstd, float* row, int N, int C) {
-  __shared__ double red[2][16][16];
+__global__ __launch_bounds__(16 * ECA_SL) void eca_ds_sums_kernel(const float* sums, const float* mean, const float* invstd, float* row, int N, int C) {
+  __shared__ double red[2][ECA_SL][16];
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll 4
-  for (int n = sl; n < N; n += 16) {
+  for (int n = sl; n < N; n += ECA_SL) {
     const size_t o = (size_t)n * C + c;
     s1 += (double)sums[o];
     s2 += (double)sums[(size_t)3 * N * C + o];
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(256) void eca_ds_sums_kernel(const float* sums, con
   __syncthreads();
   if (sl == 0) {
     double t1 = 0.0, t2 = 0.0;
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < ECA_SL; ++k) {
       t1 += red[0][k][cl];
       t2 += red[1][k][cl];
     }
@@ -1078,8 +1079,8 @@ int launch_eca_residual_bwd(int dtype, const void* dout, const void* out, const 
   }
   hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3(ECA_GB), dim3(ECA_BT), 0, s, sprod, gate, pooled, w, k, dpool, dwpart, N, C, 1.f / (float)HW);
   hipLaunchKernelGGL(eca_dw_finish_kernel, dim3(1), dim3(64), 0, s, dwpart, dw, k, beta);
-  if (bn_row) hipLaunchKernelGGL(eca_bn_sums_kernel, dim3(C / 16), dim3(256), 0, s, sums, gate, dpool, keep, bn_mean, bn_invstd, bn_row, N, C, HW);
-  if (ds_row) hipLaunchKernelGGL(eca_ds_sums_kernel, dim3(C / 16), dim3(256), 0, s, sums, ds_mean, ds_invstd, ds_row, N, C);
+  if (bn_row) hipLaunchKernelGGL(eca_bn_sums_kernel, dim3(C / 16), dim3(16 * ECA_SL), 0, s, sums, gate, dpool, keep, bn_mean, bn_invstd, bn_row, N, C, HW);
+  if (ds_row) hipLaunchKernelGGL(eca_ds_sums_kernel, dim3(C / 16), dim3(16 * ECA_SL), 0, s, sums, ds_mean, ds_invstd, ds_row, N, C);
   if (!dx) {
     MI355_LAUNCH_CHECK();
     return 0;
