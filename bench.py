@@ -26,6 +26,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2516.6, "fp8": 5033.2}  # MI355X_MICROARCH.md: dense MFMA peaks (no sparsity)
+# what the matrix pipe SUSTAINS on random operands (the clock drops from 2.4 to ~2.0 GHz under a dense MFMA stream on real data): measured on this part with
+# tools/micro/mfma_shape_random.hip, profiles/r06_mfma_shape_random_data.txt — reported beside `frac` (which stays against the datasheet peak), never instead of it
+SUSTAINED_TFLOPS = {"bf16": 2016.0, "fp8": 4061.0}
 FP8_KIND = 9  # profile_read kind: the conv launches that ran on e4m3 operands
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 EVENT_STEPS = 1  # timed steps whose conv / BN launches carry HIP-event pairs for `roofline` (each pair is a barrier on its stream: such a
@@ -384,6 +387,9 @@ def main():
                 roof["serial_avg_launch_ms"] = round(t_ms / n_l, 4)
             if n3 and "conv3x3" in roof:
                 roof["conv3x3"]["serial_frac"] = round(fl3 / (t3 * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 4)
+                if dtype in SUSTAINED_TFLOPS:
+                    roof["conv3x3"]["sustained_peak_random_data"] = SUSTAINED_TFLOPS[dtype]
+                    roof["conv3x3"]["serial_frac_of_sustained"] = round(fl3 / (t3 * 1e-3) / 1e12 / SUSTAINED_TFLOPS[dtype], 4)
             del ms_
         finally:
             del os.environ["MI355_WGRAD_STREAM"]
